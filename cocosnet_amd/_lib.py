@@ -1,0 +1,96 @@
+"""ctypes binding of libcocos_hip.so (the C ABI declared in include/cocos_hip.h).
+
+No fallback: if the library is missing or a call fails, this raises — the product path never
+silently degrades to PyTorch or CPU code (the oracle lives under oracle/ and is test-only).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libcocos_hip.so")
+
+_c_float_p = ctypes.c_void_p      # device pointers travel as integers
+_stream_t = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/cocos_hip.h one to one
+_SIGNATURES = {
+    "cocos_version": (ctypes.c_int, []),
+    "cocos_last_error_string": (ctypes.c_char_p, []),
+    "cocos_center_l2norm_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_float, _stream_t]),
+    "cocos_center_l2norm_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                                _c_float_p, _c_float_p,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_float, _stream_t]),
+    "cocos_corr_softmax_warp_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p,
+                                                    _c_float_p, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_float, _stream_t]),
+    "cocos_corr_softmax_warp_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
+    "cocos_corr_softmax_warp_bwd": (ctypes.c_int, [_c_float_p] * 9 + [ctypes.c_void_p,
+                                                                      ctypes.c_size_t,
+                                                                      ctypes.c_int, ctypes.c_int,
+                                                                      ctypes.c_int, ctypes.c_int,
+                                                                      ctypes.c_int, ctypes.c_float,
+                                                                      _stream_t]),
+    "cocos_corr_materialize": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_float, _stream_t]),
+    "cocos_corr_materialize_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int, ctypes.c_int,
+                                                                     ctypes.c_int, ctypes.c_int,
+                                                                     ctypes.c_float, _stream_t]),
+    "cocos_row_softmax_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int64, ctypes.c_int,
+                                              _stream_t]),
+    "cocos_row_softmax_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int64,
+                                              ctypes.c_int, _stream_t]),
+    "cocos_warp_materialized_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p,
+                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                    ctypes.c_int, _stream_t]),
+    "cocos_warp_materialized_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int, ctypes.c_int,
+                                                                      ctypes.c_int, ctypes.c_int,
+                                                                      _stream_t]),
+    "cocos_debug_mfma_probe": (ctypes.c_int, [_c_float_p, _stream_t]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lock = threading.Lock()
+_lib = None
+
+
+class CocosHipError(RuntimeError):
+    """A libcocos_hip.so entry point returned a negative status."""
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the shared library. Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise CocosHipError(
+                    f"{LIB_PATH} not found: build it with `python -m cocosnet_amd.build` "
+                    "(there is no PyTorch/CPU fallback for the correspondence hot path)")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGNATURES.items():
+                fn = getattr(lib, name)   # AttributeError -> header and library disagree
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point; raise CocosHipError with the library's message."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.cocos_last_error_string()
+        raise CocosHipError(f"{name} failed with code {rc}: {msg.decode() if msg else ''}")
+    return rc

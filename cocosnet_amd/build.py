@@ -1,0 +1,95 @@
+"""In-tree build of the gfx950 kernel library (libcocos_hip.so) and of the C oracle.
+
+`hipcc --offload-arch=gfx950` cross-compiles without a GPU, so this runs in the CPU-only build
+container; the resulting .so files are git-ignored but travel to the GPU box with the snapshot.
+No cmake/ninja: a handful of translation units, compiled in parallel, linked once.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libcocos_hip.so")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+
+HIP_SOURCES = [
+    "api_common.hip",
+    "center_l2norm.hip",
+    "corr_fused_fwd.hip",
+    "corr_fused_bwd.hip",
+    "sgemm_mfma.hip",
+    "row_softmax.hip",
+]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+             "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin)")
+
+
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(p.encode())
+            h.update(f.read())
+    h.update(" ".join(HIP_FLAGS).encode())
+    return h.hexdigest()
+
+
+def build_hip(force: bool = False, verbose: bool = True) -> str:
+    """Compile every HIP translation unit for gfx950 and link libcocos_hip.so. Returns its path."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = [os.path.join(CSRC_DIR, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC_DIR, "common.h"),
+                   os.path.join(REPO_DIR, "include", "cocos_hip.h")]
+    stamp = os.path.join(OBJ_DIR, "build.sha256")
+    want = _digest(deps)
+    if (not force and os.path.exists(LIB_PATH) and os.path.exists(stamp)
+            and open(stamp).read().strip() == want):
+        return LIB_PATH
+    hipcc = _hipcc()
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        cmd = [hipcc, *HIP_FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return LIB_PATH
+
+
+def build_oracle(verbose: bool = True) -> str | None:
+    """Compile oracle/'s C restatement (test infrastructure, never loaded by the product)."""
+    mk = os.path.join(REPO_DIR, "oracle", "Makefile")
+    if not os.path.exists(mk):
+        return None
+    subprocess.run(["make", "-s", "-C", os.path.dirname(mk)], check=True)
+    return os.path.join(REPO_DIR, "oracle", "libcocos_oracle.so")
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv))
+    build_oracle()

@@ -1,0 +1,49 @@
+// Version / error reporting of the C ABI plus a one-instruction MFMA layout probe.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace cocos {
+
+std::string& last_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+// One v_mfma_f32_32x32x2_f32 with A[i][k] = 1 + i + 100k and B[k][j] = (k == 0 ? 1 : 0) * ... chosen
+// asymmetric so that a row/col swap or a wrong k-pairing is visible:
+//   D[i][j] = A[i][0]*B[0][j] + A[i][1]*B[1][j],  B[0][j] = 1 + j,  B[1][j] = 1000 * (1 + j).
+__global__ void mfma_probe_kernel(float* out) {
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5, c = lane & 31;
+    const float a = 1.0f + c + 100.0f * h;               // A[i = c][k = h]
+    const float b = (h == 0 ? 1.0f : 1000.0f) * (1 + c); // B[k = h][j = c]
+    f32x16 d;
+    for (int r = 0; r < 16; ++r) d[r] = 0.f;
+    d = mfma32(a, b, d);
+    for (int r = 0; r < 16; ++r) out[lane * 16 + r] = d[r];
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_version(void) { return 100; /* 0.1.0 */ }
+
+extern "C" const char* cocos_last_error_string(void) { return cocos::last_error().c_str(); }
+
+extern "C" int cocos_debug_mfma_probe(float* out, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(out, COCOS_ERR_INVALID, "mfma_probe: null pointer");
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, as_stream(stream), out);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}

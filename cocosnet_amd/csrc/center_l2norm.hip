@@ -1,0 +1,211 @@
+// K1: centre + L2-normalise the correlation operands, and its backward (gfx950).
+//
+// Replaces correspondence.py:277-280 (theta) and :287-289 (phi):
+//     x = x - x.mean(dim=dim_mean, keepdim=True)          dim_mean = 1 if PONO_C else -1
+//     x = x / (torch.norm(x, 2, 1, keepdim=True) + sys.float_info.epsilon)
+// The reference does this in 4-5 elementwise/reduction launches per tensor, each a full HBM
+// pass (plus autograd copies); here it is one pass-structured kernel per tensor: HBM-bound,
+// x is read once from HBM (re-reads of the 64-position column block hit L1/L2).
+//
+// Layout: x, y are channel-major [B, K, N]; a workgroup owns 64 consecutive positions, its 4
+// waves split the K channels (wave w takes k = w, w+4, ...), lanes run along positions so every
+// global access is a coalesced 256-byte row segment.
+#include "common.h"
+
+namespace cocos {
+
+constexpr int CN_POS = 64;   // positions per workgroup (one per lane)
+
+// Sum the 4 per-wave partials of up to 3 quantities; every thread gets the totals.
+template <int NQ>
+__device__ __forceinline__ void reduce_waves(float (&v)[NQ], float* red /*[NQ][4][64]*/, int wave,
+                                             int lane) {
+    __syncthreads();   // protect `red` from the previous use
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) red[(q * 4 + wave) * CN_POS + lane] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        v[q] = red[(q * 4 + 0) * CN_POS + lane] + red[(q * 4 + 1) * CN_POS + lane] +
+               red[(q * 4 + 2) * CN_POS + lane] + red[(q * 4 + 3) * CN_POS + lane];
+}
+
+// mean over N for each (b, k) row:  out[b*K + k] = mean_n f(b,k,n)
+// MODE 0: f = x.   MODE 1 (backward): f = u_n * dy - (a_n / nrm_n) * y  with u = 1/(nrm+eps).
+template <int MODE>
+__global__ __launch_bounds__(256) void row_mean_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ y,
+                                                       const float* __restrict__ nrm,
+                                                       const float* __restrict__ acol,
+                                                       float* __restrict__ out, int K, int N,
+                                                       float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;            // b*K + k
+    const int b = row / K;
+    const float* xr = x + (size_t)row * N;
+    const float* yr = (MODE == 1) ? y + (size_t)row * N : nullptr;
+    float acc = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        if (MODE == 0) {
+            acc += xr[n];
+        } else {
+            const float nn = nrm[(size_t)b * N + n];
+            const float u = 1.0f / (nn + eps);
+            const float g = (nn > 0.f) ? acol[(size_t)b * N + n] / nn : 0.f;
+            acc += u * xr[n] - g * yr[n];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[row] = (red[0] + red[1] + red[2] + red[3]) / (float)N;
+}
+
+// Forward.  PONO_C: mean over K per position (computed here); else mean over N per channel
+// (precomputed in row_mean[b*K + k]).
+template <bool PONO_C>
+__global__ __launch_bounds__(256) void center_l2norm_fwd_kernel(const float* __restrict__ x,
+                                                                float* __restrict__ y,
+                                                                float* __restrict__ norm_out,
+                                                                const float* __restrict__ row_mean,
+                                                                int K, int N, float eps) {
+    __shared__ float red[3 * 4 * CN_POS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * CN_POS + lane;
+    const bool ok = n < N;
+    const float* xb = x + (size_t)b * K * N;
+    float* yb = y + (size_t)b * K * N;
+
+    float mean = 0.f;
+    if (PONO_C) {
+        float part[1] = {0.f};
+        if (ok)
+            for (int k = wave; k < K; k += 4) part[0] += xb[(size_t)k * N + n];
+        reduce_waves<1>(part, red, wave, lane);
+        mean = part[0] / (float)K;
+    }
+    float ss[1] = {0.f};
+    if (ok)
+        for (int k = wave; k < K; k += 4) {
+            const float m = PONO_C ? mean : row_mean[(size_t)b * K + k];
+            const float d = xb[(size_t)k * N + n] - m;
+            ss[0] += d * d;
+        }
+    reduce_waves<1>(ss, red, wave, lane);
+    const float nrm = sqrtf(ss[0]);
+    const float u = 1.0f / (nrm + eps);
+    if (ok) {
+        for (int k = wave; k < K; k += 4) {
+            const float m = PONO_C ? mean : row_mean[(size_t)b * K + k];
+            yb[(size_t)k * N + n] = (xb[(size_t)k * N + n] - m) * u;
+        }
+        if (wave == 0) norm_out[(size_t)b * N + n] = nrm;
+    }
+}
+
+// Backward.  With u = 1/(nrm+eps), a = sum_k dy*y:   dxc = u*dy - (a/nrm)*y   (second term 0
+// when nrm == 0, matching the zero sub-gradient torch.norm uses there), then the centring
+// backward  dx = dxc - mean(dxc)  over the same axis as the forward mean.
+//   PONO_C: everything in this kernel.   else: this kernel only writes a[b,n] to `acol`
+//   (pass 1); row_mean_kernel<1> then gives mean_n(dxc) per channel and pass 2 finishes.
+template <bool PONO_C, int PASS>
+__global__ __launch_bounds__(256) void center_l2norm_bwd_kernel(
+    const float* __restrict__ y, const float* __restrict__ nrm_in, const float* __restrict__ dy,
+    float* __restrict__ dx, float* __restrict__ acol, const float* __restrict__ row_mean, int K,
+    int N, float eps) {
+    __shared__ float red[3 * 4 * CN_POS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * CN_POS + lane;
+    const bool ok = n < N;
+    const float* yb = y + (size_t)b * K * N;
+    const float* dyb = dy + (size_t)b * K * N;
+    float* dxb = dx + (size_t)b * K * N;
+
+    const float nrm = ok ? nrm_in[(size_t)b * N + n] : 1.f;
+    const float u = 1.0f / (nrm + eps);
+
+    if (PONO_C || PASS == 1) {
+        float s[3] = {0.f, 0.f, 0.f};   // sum dy*y, sum dy, sum y
+        if (ok)
+            for (int k = wave; k < K; k += 4) {
+                const float yy = yb[(size_t)k * N + n], dd = dyb[(size_t)k * N + n];
+                s[0] += dd * yy;
+                s[1] += dd;
+                s[2] += yy;
+            }
+        reduce_waves<3>(s, red, wave, lane);
+        if (!PONO_C) {
+            if (ok && wave == 0) acol[(size_t)b * N + n] = s[0];
+            return;
+        }
+        const float g = (nrm > 0.f) ? s[0] / nrm : 0.f;
+        const float mean_dxc = (u * s[1] - g * s[2]) / (float)K;
+        if (ok)
+            for (int k = wave; k < K; k += 4)
+                dxb[(size_t)k * N + n] =
+                    u * dyb[(size_t)k * N + n] - g * yb[(size_t)k * N + n] - mean_dxc;
+    } else {   // !PONO_C, pass 2
+        const float g = (ok && nrm > 0.f) ? acol[(size_t)b * N + n] / nrm : 0.f;
+        if (ok)
+            for (int k = wave; k < K; k += 4)
+                dxb[(size_t)k * N + n] = u * dyb[(size_t)k * N + n] - g * yb[(size_t)k * N + n] -
+                                         row_mean[(size_t)b * K + k];
+    }
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_center_l2norm_fwd(const float* x, float* y, float* norm, float* row_ws, int B,
+                                       int K, int N, int center_over_channels, float eps,
+                                       cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && y && norm, COCOS_ERR_INVALID, "center_l2norm_fwd: null pointer");
+    COCOS_REQUIRE(B >= 1 && K >= 1 && N >= 1 && B <= 65535, COCOS_ERR_INVALID,
+                  "center_l2norm_fwd: bad dims B=%d K=%d N=%d", B, K, N);
+    hipStream_t s = as_stream(stream);
+    const dim3 grid((N + CN_POS - 1) / CN_POS, B);
+    if (center_over_channels) {
+        hipLaunchKernelGGL(center_l2norm_fwd_kernel<true>, grid, dim3(256), 0, s, x, y, norm,
+                           (const float*)nullptr, K, N, eps);
+    } else {
+        COCOS_REQUIRE(row_ws, COCOS_ERR_INVALID,
+                      "center_l2norm_fwd: row_ws [B*K] required when centring over positions");
+        hipLaunchKernelGGL(row_mean_kernel<0>, dim3(B * K), dim3(256), 0, s, x,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           row_ws, K, N, eps);
+        hipLaunchKernelGGL(center_l2norm_fwd_kernel<false>, grid, dim3(256), 0, s, x, y, norm,
+                           (const float*)row_ws, K, N, eps);
+    }
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_center_l2norm_bwd(const float* y, const float* norm, const float* dy,
+                                       float* dx, float* col_ws, float* row_ws, int B, int K,
+                                       int N, int center_over_channels, float eps,
+                                       cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(y && norm && dy && dx, COCOS_ERR_INVALID, "center_l2norm_bwd: null pointer");
+    COCOS_REQUIRE(B >= 1 && K >= 1 && N >= 1 && B <= 65535, COCOS_ERR_INVALID,
+                  "center_l2norm_bwd: bad dims B=%d K=%d N=%d", B, K, N);
+    hipStream_t s = as_stream(stream);
+    const dim3 grid((N + CN_POS - 1) / CN_POS, B);
+    if (center_over_channels) {
+        hipLaunchKernelGGL((center_l2norm_bwd_kernel<true, 1>), grid, dim3(256), 0, s, y, norm, dy,
+                           dx, (float*)nullptr, (const float*)nullptr, K, N, eps);
+    } else {
+        COCOS_REQUIRE(col_ws && row_ws, COCOS_ERR_INVALID,
+                      "center_l2norm_bwd: col_ws [B*N] and row_ws [B*K] required");
+        hipLaunchKernelGGL((center_l2norm_bwd_kernel<false, 1>), grid, dim3(256), 0, s, y, norm,
+                           dy, dx, col_ws, (const float*)nullptr, K, N, eps);
+        hipLaunchKernelGGL(row_mean_kernel<1>, dim3(B * K), dim3(256), 0, s, dy, y, norm,
+                           (const float*)col_ws, row_ws, K, N, eps);
+        hipLaunchKernelGGL((center_l2norm_bwd_kernel<false, 2>), grid, dim3(256), 0, s, y, norm,
+                           dy, dx, col_ws, (const float*)row_ws, K, N, eps);
+    }
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}

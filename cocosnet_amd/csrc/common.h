@@ -1,0 +1,132 @@
+// Shared helpers for the gfx950 kernels behind include/cocos_hip.h.
+// Written for CDNA4 only: wave64, v_mfma_f32_32x32x2_f32, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/cocos_hip.h"
+
+namespace cocos {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kNumXcd = 8;         // MI355X: 8 XCDs, block b lands on XCD b % 8 (speed only)
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+std::string& last_error();
+int fail(int code, const char* fmt, ...);
+
+#define COCOS_HIP_CHECK(expr)                                                          \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return ::cocos::fail(COCOS_ERR_HIP, "%s failed: %s (%s:%d)", #expr,        \
+                                 hipGetErrorString(_e), __FILE__, __LINE__);           \
+    } while (0)
+
+#define COCOS_REQUIRE(cond, code, ...)                                                 \
+    do {                                                                               \
+        if (!(cond)) return ::cocos::fail((code), __VA_ARGS__);                        \
+    } while (0)
+
+// Row index inside a 32x32 MFMA accumulator tile for accumulator register r (0..15) of a lane
+// in half h = lane >> 5:  row = (r & 3) + 8 * (r >> 2) + 4 * h ; col = lane & 31.
+// Consequence used everywhere below: register r of an accumulator holds rows {rb, rb + 4}
+// (one per half-wave), which is exactly the k-pair layout of the A/B operands of the next
+// v_mfma_f32_32x32x2_f32 — so softmax probabilities feed the following MFMA straight from
+// the accumulator registers with no cross-lane movement.
+__device__ __forceinline__ constexpr int acc_row_base(int r) { return (r & 3) + 8 * (r >> 2); }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Exchange with the other half-wave (lane ^ 32).
+__device__ __forceinline__ float swap_half(float x) { return __shfl_xor(x, 32, 64); }
+
+// XCD-aware block remap (guide T1, bijective form).  Consecutive *virtual* ids end up on the
+// same XCD, so blocks that stream the same batch item's key/value tiles share one 4 MiB L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk / kNumXcd, r = nblk % kNumXcd;
+    const int xcd = bid % kNumXcd, slot = bid / kNumXcd;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+// ---- buffer (SRD) addressing -------------------------------------------------------------
+// All streaming reads go through raw buffer loads: a wave-uniform 128-bit descriptor plus a
+// 32-bit per-lane byte offset.  Offsets at or beyond `bytes` return 0 with no branch, which is
+// how ragged tiles are zero-filled (kBufOob forces that for masked elements).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kBufOob = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes) {
+    const unsigned n = bytes > 0x7fffffffull ? 0x7fffffffu : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)n, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
+// ---- LDS tile staging -------------------------------------------------------------------
+// A "tile" is ROWS channels x 32 positions of a channel-major tensor [rows][ncols], cut at
+// position j0.  256 threads fetch it into registers (one float4 per 32 rows per thread; the
+// loads stay in flight under the MFMAs of the previous tile) and later commit it to LDS with a
+// row stride of kTileLd = 33 floats, which makes both access patterns of the MFMA operand
+// reads conflict-free:  [row fixed][32 consecutive positions]  and  [32 consecutive rows][pos fixed].
+constexpr int kTileCols = 32;
+constexpr int kTileLd = 33;
+
+template <int ROWS>
+struct TileRegs {
+    f32x4 r[ROWS / 32];
+};
+
+template <int ROWS, bool RAGGED>
+__device__ __forceinline__ void tile_fetch(TileRegs<ROWS>& t, __amdgpu_buffer_rsrc_t rs,
+                                           int rows_valid, int ncols, int j0, int tid) {
+    const int c4 = (tid & 7) * 4;
+#pragma unroll
+    for (int u = 0; u < ROWS / 32; ++u) {
+        const int row = u * 32 + (tid >> 3);
+        if (!RAGGED) {
+            unsigned off = (unsigned)(row * ncols + j0 + c4) * 4u;
+            if (row >= rows_valid) off = kBufOob;
+            t.r[u] = buf_load4(rs, off);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = j0 + c4 + e;
+                unsigned off = (unsigned)(row * ncols + col) * 4u;
+                if (row >= rows_valid || col >= ncols) off = kBufOob;
+                t.r[u][e] = buf_load1(rs, off);
+            }
+        }
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void tile_commit(const TileRegs<ROWS>& t, float* lds, int tid) {
+    float* d0 = lds + (tid >> 3) * kTileLd + (tid & 7) * 4;
+#pragma unroll
+    for (int u = 0; u < ROWS / 32; ++u) {
+        float* d = d0 + u * 32 * kTileLd;
+        d[0] = t.r[u].x; d[1] = t.r[u].y; d[2] = t.r[u].z; d[3] = t.r[u].w;
+    }
+}
+
+inline hipStream_t as_stream(cocos_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace cocos

@@ -1,0 +1,195 @@
+// K2 forward: fused correlation -> softmax over key positions -> warp, for gfx950 (MI355X).
+//
+// Replaces correspondence.py:281 (permute), :291 (matmul), :304 (/temperature), :307 (softmax),
+// :318 (matmul with the exemplar) and the further P@V products at :334 — the [B,HW,HW] matrix
+// is never written to HBM.
+//
+// Arithmetic: exact fp32.  The logits are cos/0.01, so a cosine error d becomes a 100*d relative
+// error in every softmax weight; bf16/fp16 operands fail the 1e-3 parity bar (SURVEY.md §7 hard
+// part 1), therefore the correlation runs on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate).
+//
+// Decomposition (one workgroup = 4 waves = 128 query positions, 1 wave per SIMD):
+//   * each wave owns 32 query positions; its 32 x K query slice lives in registers as the MFMA
+//     B operand for the whole kernel (K/2 = 128 registers);
+//   * key tiles of 32 positions ([K][32] + the V tile [Cv][32]) stream through LDS, shared by
+//     the 4 waves; they are fetched into registers one tile ahead (loads in flight under the
+//     MFMAs) and written to a single LDS buffer between two barriers;
+//   * the wave computes S^T (32 keys x 32 queries) = K_tile^T . Q  — swapped operands, so that
+//     lane&31 indexes the QUERY: the softmax statistics (running max / sum) are one scalar per
+//     lane and the key axis runs over the 16 accumulator registers (+ the other half-wave);
+//   * the exponentiated accumulator registers are directly the B operand of the P.V MFMAs
+//     (see acc_row_base in common.h), A = V^T read from LDS; O^T accumulates in registers with
+//     lane&31 = query again, so the online-softmax rescale is a per-lane multiply.
+#include "common.h"
+
+namespace cocos {
+
+constexpr int FWD_BQ = 128;          // query positions per workgroup
+constexpr int FWD_BK = kTileCols;    // key positions per tile
+constexpr int FWD_LD = kTileLd;      // LDS row stride (floats)
+
+template <int KD, int CVB>
+__global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
+    const float* __restrict__ qn, const float* __restrict__ kn, const float* __restrict__ v,
+    float* __restrict__ out, float* __restrict__ lse, int B, int Nq, int Nk, int Cv,
+    float scale_log2 /* inv_temperature * log2(e) */) {
+    constexpr int CVP = CVB * 32;
+    static_assert(KD % 32 == 0, "K must be a multiple of 32");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* kt = smem;                    // [KD][FWD_LD]
+    float* vt = smem + KD * FWD_LD;      // [CVP][FWD_LD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+
+    const int nqb = (Nq + FWD_BQ - 1) / FWD_BQ;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vb / nqb, qb = vb % nqb;
+    const int i_lane = qb * FWD_BQ + wave * 32 + c;   // this lane's query position
+
+    const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qn + (size_t)b * KD * Nq, (size_t)KD * Nq * 4);
+    const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kn + (size_t)b * KD * Nk, (size_t)KD * Nk * 4);
+    const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(v + (size_t)b * Cv * Nk, (size_t)Cv * Nk * 4);
+
+    // ---- resident query slice: B operand  B[k = 2kk + h][col = query c] -------------------
+    // (positions past Nq read 0 through the descriptor; their results are never stored)
+    float qreg[KD / 2];
+    {
+        const unsigned q_off = i_lane < Nq ? (unsigned)(h * Nq + i_lane) * 4u : kBufOob;
+#pragma unroll
+        for (int kk = 0; kk < KD / 2; ++kk)
+            qreg[kk] = buf_load1(q_rs, q_off + (unsigned)(2 * kk * Nq) * 4u);
+    }
+
+    f32x16 o[CVB];
+#pragma unroll
+    for (int cb = 0; cb < CVB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+    float m_run = -INFINITY;   // running max (log2 domain), per query lane
+    float l_run = 0.f;         // running sum, partial over this half-wave's keys
+
+    // ---- register staging of the next key / V tile ----------------------------------------
+    TileRegs<KD> ks;
+    TileRegs<CVP> vs;
+    auto fetch = [&](int j0) {
+        if (j0 + FWD_BK <= Nk) {   // wave-uniform: full tile -> 16-byte loads
+            tile_fetch<KD, false>(ks, k_rs, KD, Nk, j0, tid);
+            tile_fetch<CVP, false>(vs, v_rs, Cv, Nk, j0, tid);
+        } else {                   // ragged last tile -> per-element bounds, zero fill
+            tile_fetch<KD, true>(ks, k_rs, KD, Nk, j0, tid);
+            tile_fetch<CVP, true>(vs, v_rs, Cv, Nk, j0, tid);
+        }
+    };
+
+    const int ntiles = (Nk + FWD_BK - 1) / FWD_BK;
+    fetch(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * FWD_BK;
+        __syncthreads();            // every wave is done reading the previous tile
+        tile_commit<KD>(ks, kt, tid);
+        tile_commit<CVP>(vs, vt, tid);
+        __syncthreads();
+        if (t + 1 < ntiles) fetch(j0 + FWD_BK);   // in flight under the MFMAs below
+
+        // ---- S^T tile: rows = keys (acc registers), cols = queries (lanes) -----------------
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KD / 2; ++kk)
+            s = mfma32(kt[(2 * kk + h) * FWD_LD + c], qreg[kk], s);
+
+        // ---- online softmax over the key axis ---------------------------------------------
+        float tmax = -INFINITY;
+        const bool ragged = (j0 + FWD_BK > Nk);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float x = s[r] * scale_log2;
+            if (ragged && (j0 + acc_row_base(r) + 4 * h >= Nk)) x = -INFINITY;
+            s[r] = x;
+            tmax = fmaxf(tmax, x);
+        }
+        tmax = fmaxf(tmax, swap_half(tmax));
+        const float m_new = fmaxf(m_run, tmax);   // finite: every tile holds >= 1 valid key
+        const float alpha = fast_exp2(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = fast_exp2(s[r] - m_new);
+            psum += s[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int cb = 0; cb < CVB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+
+        // ---- O^T += V^T . P^T : A = V^T[ch][key] from LDS, B = P^T (accumulator registers) --
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jj = acc_row_base(r) + 4 * h;
+#pragma unroll
+            for (int cb = 0; cb < CVB; ++cb)
+                o[cb] = mfma32(vt[(cb * 32 + c) * FWD_LD + jj], s[r], o[cb]);
+        }
+    }
+
+    // ---- epilogue: normalise, store channel-major [B,Cv,Nq], store row LSE ------------------
+    const float l_tot = l_run + swap_half(l_run);
+    const float inv_l = 1.0f / l_tot;
+    if (i_lane < Nq) {
+        float* out_b = out + (size_t)b * Cv * Nq;
+#pragma unroll
+        for (int cb = 0; cb < CVB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = cb * 32 + acc_row_base(r) + 4 * h;
+                if (ch < Cv) out_b[(size_t)ch * Nq + i_lane] = o[cb][r] * inv_l;
+            }
+        if (h == 0) lse[(size_t)b * Nq + i_lane] = (m_run + log2f(l_tot)) * kLn2;
+    }
+}
+
+template <int KD, int CVB>
+static int launch_fwd(const float* qn, const float* kn, const float* v, float* out, float* lse,
+                      int B, int Nq, int Nk, int Cv, float inv_t, hipStream_t stream) {
+    auto kern = corr_softmax_warp_fwd_kernel<KD, CVB>;
+    const size_t smem = (size_t)(KD + CVB * 32) * FWD_LD * sizeof(float);
+    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int nqb = (Nq + FWD_BQ - 1) / FWD_BQ;
+    hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, stream, qn, kn, v, out, lse, B, Nq,
+                       Nk, Cv, inv_t * kLog2e);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_corr_softmax_warp_fwd(const float* qn, const float* kn, const float* v,
+                                           float* out, float* lse, int B, int K, int Nq, int Nk,
+                                           int Cv, float inv_temperature, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(qn && kn && v && out && lse, COCOS_ERR_INVALID, "corr_softmax_warp_fwd: null pointer");
+    COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_fwd: bad dims B=%d Nq=%d Nk=%d Cv=%d", B, Nq, Nk, Cv);
+    COCOS_REQUIRE(K == 256, COCOS_ERR_UNSUPPORTED,
+                  "corr_softmax_warp_fwd: fused path needs K == 256 (got %d); use "
+                  "cocos_corr_materialize + cocos_row_softmax_fwd", K);
+    COCOS_REQUIRE(Cv <= 160, COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_fwd: Cv=%d > 160", Cv);
+    COCOS_REQUIRE((size_t)K * Nq * 4 < 0x7fffffffull && (size_t)K * Nk * 4 < 0x7fffffffull,
+                  COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_fwd: per-sample tensor exceeds 2 GiB");
+    hipStream_t s = as_stream(stream);
+    const int cvb = (Cv + 31) / 32;
+    switch (cvb) {
+        case 1: return launch_fwd<256, 1>(qn, kn, v, out, lse, B, Nq, Nk, Cv, inv_temperature, s);
+        case 2: return launch_fwd<256, 2>(qn, kn, v, out, lse, B, Nq, Nk, Cv, inv_temperature, s);
+        case 3: return launch_fwd<256, 3>(qn, kn, v, out, lse, B, Nq, Nk, Cv, inv_temperature, s);
+        case 4: return launch_fwd<256, 4>(qn, kn, v, out, lse, B, Nq, Nk, Cv, inv_temperature, s);
+        default: return launch_fwd<256, 5>(qn, kn, v, out, lse, B, Nq, Nk, Cv, inv_temperature, s);
+    }
+}

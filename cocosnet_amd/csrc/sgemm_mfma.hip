@@ -1,0 +1,214 @@
+// Batched exact-fp32 GEMM on v_mfma_f32_32x32x2_f32 for the MATERIALISED side of the path (gfx950):
+//   K3  cocos_corr_materialize      f = scale * qn^T kn          correspondence.py:291,:304
+//   K3b cocos_corr_materialize_bwd  autograd of :291
+//   K5  cocos_warp_materialized_*   P @ V and its gradients      correspondence.py:318
+// These run when the [B,HW,HW] matrix must exist in HBM: return_corr=True (:305-306), the
+// WTA_scale branch (:300-303) and match_kernel != 1 (K = 256*mk^2).  The K == 256 training /
+// inference path never comes here (see corr_fused_*.hip).
+//
+//   C[b][m][n] = scale * sum_k A(b,m,k) * B(b,k,n),     C row-major (n contiguous)
+//   A_KC: A stored [m][k] (k contiguous)  else [k][m] (m contiguous)
+//   B_KC: B stored [n][k] (k contiguous)  else [k][n] (n contiguous)
+// Tile 128x128 per workgroup, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles (64 accumulator
+// registers); K advances 16 per step through one LDS buffer that is refilled from registers
+// (loads for step t+1 are in flight under the 32 MFMAs of step t).  LDS images are always
+// [k][m] / [k][n], so operand reads are lane-contiguous (conflict-free); k-contiguous sources are
+// transposed by the staging write.
+#include "common.h"
+
+namespace cocos {
+
+constexpr int GM = 128, GN = 128, GK = 16;
+constexpr int GLD = 132;   // LDS row stride: 16-byte aligned rows, 2-way at worst on transposing writes
+
+struct GemmStage {
+    f32x4 r[2];
+};
+
+// Fetch a [GK x 128] operand slab into registers.  `KC`: source is k-contiguous ([mn][k]).
+template <bool KC, bool EDGE>
+__device__ __forceinline__ void gemm_fetch(GemmStage& st, __amdgpu_buffer_rsrc_t rs, int mn0,
+                                           int k0, int MN, int K, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = u * 256 + tid;
+        int mn, k;
+        if (KC) { mn = mn0 + (idx >> 2); k = k0 + (idx & 3) * 4; }
+        else    { k = k0 + (idx >> 5);  mn = mn0 + (idx & 31) * 4; }
+        if (!EDGE) {
+            const unsigned off = KC ? (unsigned)(mn * K + k) * 4u : (unsigned)(k * MN + mn) * 4u;
+            st.r[u] = buf_load4(rs, off);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int mm = KC ? mn : mn + e, kk = KC ? k + e : k;
+                unsigned off = KC ? (unsigned)(mm * K + kk) * 4u : (unsigned)(kk * MN + mm) * 4u;
+                if (mm >= MN || kk >= K) off = kBufOob;
+                st.r[u][e] = buf_load1(rs, off);
+            }
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void gemm_commit(const GemmStage& st, float* lds, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = u * 256 + tid;
+        if (KC) {
+            const int mn = idx >> 2, k = (idx & 3) * 4;
+            lds[(k + 0) * GLD + mn] = st.r[u].x;
+            lds[(k + 1) * GLD + mn] = st.r[u].y;
+            lds[(k + 2) * GLD + mn] = st.r[u].z;
+            lds[(k + 3) * GLD + mn] = st.r[u].w;
+        } else {
+            const int k = idx >> 5, mn = (idx & 31) * 4;
+            *reinterpret_cast<f32x4*>(lds + k * GLD + mn) = st.r[u];
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 1) void sgemm_mfma_kernel(const float* __restrict__ A,
+                                                            const float* __restrict__ Bm,
+                                                            float* __restrict__ C, int M, int N,
+                                                            int K, size_t strideA, size_t strideB,
+                                                            size_t strideC, float scale) {
+    __shared__ __attribute__((aligned(16))) float at[GK * GLD];
+    __shared__ __attribute__((aligned(16))) float bt[GK * GLD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(A + (size_t)b * strideA, (size_t)M * K * 4);
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(Bm + (size_t)b * strideB, (size_t)N * K * 4);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const bool interior = (m0 + GM <= M) && (n0 + GN <= N);
+    GemmStage sa, sb;
+    auto fetch = [&](int k0) {
+        if (interior && k0 + GK <= K) {
+            gemm_fetch<A_KC, false>(sa, a_rs, m0, k0, M, K, tid);
+            gemm_fetch<B_KC, false>(sb, b_rs, n0, k0, N, K, tid);
+        } else {
+            gemm_fetch<A_KC, true>(sa, a_rs, m0, k0, M, K, tid);
+            gemm_fetch<B_KC, true>(sb, b_rs, n0, k0, N, K, tid);
+        }
+    };
+
+    const int nsteps = (K + GK - 1) / GK;
+    fetch(0);
+    for (int t = 0; t < nsteps; ++t) {
+        __syncthreads();
+        gemm_commit<A_KC>(sa, at, tid);
+        gemm_commit<B_KC>(sb, bt, tid);
+        __syncthreads();
+        if (t + 1 < nsteps) fetch((t + 1) * GK);
+#pragma unroll
+        for (int kk = 0; kk < GK / 2; ++kk) {
+            const float a0 = at[(2 * kk + h) * GLD + wm * 64 + c];
+            const float a1 = at[(2 * kk + h) * GLD + wm * 64 + 32 + c];
+            const float b0 = bt[(2 * kk + h) * GLD + wn * 64 + c];
+            const float b1 = bt[(2 * kk + h) * GLD + wn * 64 + 32 + c];
+            acc[0][0] = mfma32(a0, b0, acc[0][0]);
+            acc[0][1] = mfma32(a0, b1, acc[0][1]);
+            acc[1][0] = mfma32(a1, b0, acc[1][0]);
+            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+        }
+    }
+
+    float* Cb = C + (size_t)b * strideC;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + acc_row_base(r) + 4 * h;
+                if (m < M && n < N) Cb[(size_t)m * N + n] = acc[i][j][r] * scale;
+            }
+        }
+}
+
+template <bool A_KC, bool B_KC>
+static int launch_gemm(const float* A, const float* Bm, float* C, int batch, int M, int N, int K,
+                       float scale, hipStream_t s) {
+    COCOS_REQUIRE((size_t)M * K * 4 < 0x7fffffffull && (size_t)N * K * 4 < 0x7fffffffull,
+                  COCOS_ERR_UNSUPPORTED, "sgemm: per-sample operand exceeds 2 GiB (M=%d N=%d K=%d)",
+                  M, N, K);
+    COCOS_REQUIRE(batch <= 65535 && (M + GM - 1) / GM <= 65535, COCOS_ERR_UNSUPPORTED,
+                  "sgemm: grid too large");
+    const dim3 grid((N + GN - 1) / GN, (M + GM - 1) / GM, batch);
+    hipLaunchKernelGGL((sgemm_mfma_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, A, Bm, C, M, N, K,
+                       (size_t)M * K, (size_t)N * K, (size_t)M * N, scale);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+}  // namespace cocos
+
+// f[b,i,j] = scale * sum_k qn[b,k,i] kn[b,k,j]        C[m=i][n=j], A=[k][m], B=[k][n]
+extern "C" int cocos_corr_materialize(const float* qn, const float* kn, float* f, int B, int K,
+                                      int Nq, int Nk, float scale, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(qn && kn && f, COCOS_ERR_INVALID, "corr_materialize: null pointer");
+    COCOS_REQUIRE(B >= 1 && K >= 1 && Nq >= 1 && Nk >= 1, COCOS_ERR_INVALID,
+                  "corr_materialize: bad dims B=%d K=%d Nq=%d Nk=%d", B, K, Nq, Nk);
+    return launch_gemm<false, false>(qn, kn, f, B, Nq, Nk, K, scale, as_stream(stream));
+}
+
+extern "C" int cocos_corr_materialize_bwd(const float* qn, const float* kn, const float* df,
+                                          float* dqn, float* dkn, int B, int K, int Nq, int Nk,
+                                          float scale, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(qn && kn && df, COCOS_ERR_INVALID, "corr_materialize_bwd: null pointer");
+    COCOS_REQUIRE(B >= 1 && K >= 1 && Nq >= 1 && Nk >= 1, COCOS_ERR_INVALID,
+                  "corr_materialize_bwd: bad dims B=%d K=%d Nq=%d Nk=%d", B, K, Nq, Nk);
+    hipStream_t s = as_stream(stream);
+    int rc = COCOS_OK;
+    // dqn[k][i] = sum_j kn[k][j] df[i][j] : C[m=k][n=i], A = kn [m][kk=j] (k-contig), B = df [n=i][kk=j] (k-contig)
+    if (dqn) rc = launch_gemm<true, true>(kn, df, dqn, B, K, Nq, Nk, scale, s);
+    if (rc != COCOS_OK) return rc;
+    // dkn[k][j] = sum_i qn[k][i] df[i][j] : C[m=k][n=j], A = qn [m][kk=i] (k-contig), B = df [kk=i][n=j] (n-contig)
+    if (dkn) rc = launch_gemm<true, false>(qn, df, dkn, B, K, Nk, Nq, scale, s);
+    return rc;
+}
+
+// out[b,c,i] = sum_j v[b,c,j] p[b,i,j] : C[m=c][n=i], A = v [m][kk=j] (k-contig), B = p [n=i][kk=j] (k-contig)
+extern "C" int cocos_warp_materialized_fwd(const float* p, const float* v, float* out, int B,
+                                           int Nq, int Nk, int Cv, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(p && v && out, COCOS_ERR_INVALID, "warp_materialized_fwd: null pointer");
+    COCOS_REQUIRE(B >= 1 && Cv >= 1 && Nq >= 1 && Nk >= 1, COCOS_ERR_INVALID,
+                  "warp_materialized_fwd: bad dims B=%d Cv=%d Nq=%d Nk=%d", B, Cv, Nq, Nk);
+    return launch_gemm<true, true>(v, p, out, B, Cv, Nq, Nk, 1.0f, as_stream(stream));
+}
+
+extern "C" int cocos_warp_materialized_bwd(const float* p, const float* v, const float* dout,
+                                           float* dp, float* dv, int B, int Nq, int Nk, int Cv,
+                                           cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(p && v && dout, COCOS_ERR_INVALID, "warp_materialized_bwd: null pointer");
+    COCOS_REQUIRE(B >= 1 && Cv >= 1 && Nq >= 1 && Nk >= 1, COCOS_ERR_INVALID,
+                  "warp_materialized_bwd: bad dims B=%d Cv=%d Nq=%d Nk=%d", B, Cv, Nq, Nk);
+    hipStream_t s = as_stream(stream);
+    int rc = COCOS_OK;
+    // dp[i][j] = sum_c dout[c][i] v[c][j] : C[m=i][n=j], A = dout [kk=c][m=i], B = v [kk=c][n=j]
+    if (dp) rc = launch_gemm<false, false>(dout, v, dp, B, Nq, Nk, Cv, 1.0f, s);
+    if (rc != COCOS_OK) return rc;
+    // dv[c][j] = sum_i dout[c][i] p[i][j] : C[m=c][n=j], A = dout [m=c][kk=i] (k-contig), B = p [kk=i][n=j]
+    if (dv) rc = launch_gemm<true, false>(dout, p, dv, B, Cv, Nk, Nq, 1.0f, s);
+    return rc;
+}

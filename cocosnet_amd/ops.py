@@ -1,0 +1,243 @@
+"""torch.autograd bindings of the HIP kernels (host side above the C ABI).
+
+PyTorch here is plumbing only: it owns device memory, the stream and the autograd graph; every
+piece of arithmetic on the path is a hand-written gfx950 kernel reached through ctypes.
+All feature tensors are channel-major [B, C, positions] fp32 — what `x.view(B, C, -1)` gives in
+the reference (models/networks/correspondence.py:274,284).
+"""
+from __future__ import annotations
+
+import sys
+
+import torch
+
+from . import _lib
+
+#: `sys.float_info.epsilon`, the constant the reference adds to the norm (correspondence.py:279,288)
+NORM_EPS = sys.float_info.epsilon
+#: widest V the fused kernel takes in one launch (5 blocks of 32 channels)
+MAX_FUSED_CV = 160
+#: channel count the fused kernels are specialised for (self.inter_channels, correspondence.py:170)
+FUSED_K = 256
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.CocosHipError(
+            f"{name}: expected a CUDA/HIP tensor; the correspondence hot path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------
+# K1  centre + L2-normalise            (correspondence.py:277-280, :287-289)
+# ------------------------------------------------------------------------------------------
+class _CenterL2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, center_over_channels: bool, eps: float):
+        x = _chk(x, "center_l2norm: x")
+        B, K, N = x.shape
+        y = torch.empty_like(x)
+        norm = torch.empty((B, N), device=x.device, dtype=torch.float32)
+        row_ws = None if center_over_channels else torch.empty((B, K), device=x.device,
+                                                                dtype=torch.float32)
+        _lib.call("cocos_center_l2norm_fwd", x.data_ptr(), y.data_ptr(), norm.data_ptr(),
+                  _ptr(row_ws), B, K, N, int(center_over_channels), float(eps), _stream())
+        ctx.save_for_backward(y, norm)
+        ctx.cfg = (bool(center_over_channels), float(eps))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, norm = ctx.saved_tensors
+        center_over_channels, eps = ctx.cfg
+        dy = _chk(dy, "center_l2norm: dy")
+        B, K, N = y.shape
+        dx = torch.empty_like(y)
+        col_ws = row_ws = None
+        if not center_over_channels:
+            col_ws = torch.empty((B, N), device=y.device, dtype=torch.float32)
+            row_ws = torch.empty((B, K), device=y.device, dtype=torch.float32)
+        _lib.call("cocos_center_l2norm_bwd", y.data_ptr(), norm.data_ptr(), dy.data_ptr(),
+                  dx.data_ptr(), _ptr(col_ws), _ptr(row_ws), B, K, N, int(center_over_channels),
+                  eps, _stream())
+        return dx, None, None
+
+
+def center_l2norm(x: torch.Tensor, center_over_channels: bool, eps: float = NORM_EPS):
+    """x [B,K,N] -> (x - mean) / (||x - mean||_2 over K + eps); mean over K (PONO_C) or over N."""
+    return _CenterL2Norm.apply(x, center_over_channels, eps)
+
+
+# ------------------------------------------------------------------------------------------
+# K2  fused correlation -> softmax -> warp     (correspondence.py:291,:304,:307,:318)
+# ------------------------------------------------------------------------------------------
+class _CorrSoftmaxWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qn, kn, v, inv_temperature: float):
+        qn, kn, v = _chk(qn, "qn"), _chk(kn, "kn"), _chk(v, "v")
+        B, K, Nq = qn.shape
+        Bk, Kk, Nk = kn.shape
+        Bv, Cv, Nv = v.shape
+        if (Bk, Kk) != (B, K) or (Bv, Nv) != (B, Nk):
+            raise ValueError(f"corr_softmax_warp: shape mismatch qn{tuple(qn.shape)} "
+                             f"kn{tuple(kn.shape)} v{tuple(v.shape)}")
+        out = torch.empty((B, Cv, Nq), device=qn.device, dtype=torch.float32)
+        lse = torch.empty((B, Nq), device=qn.device, dtype=torch.float32)
+        _lib.call("cocos_corr_softmax_warp_fwd", qn.data_ptr(), kn.data_ptr(), v.data_ptr(),
+                  out.data_ptr(), lse.data_ptr(), B, K, Nq, Nk, Cv, float(inv_temperature),
+                  _stream())
+        ctx.save_for_backward(qn, kn, v, out, lse)
+        ctx.inv_t = float(inv_temperature)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qn, kn, v, out, lse = ctx.saved_tensors
+        dout = _chk(dout, "dout")
+        B, K, Nq = qn.shape
+        Nk, Cv = kn.shape[2], v.shape[1]
+        need_q, need_k, need_v = ctx.needs_input_grad[:3]
+        dqn = torch.empty_like(qn) if need_q else None
+        dkn = torch.empty_like(kn) if (need_k or need_v) else None
+        dv = torch.empty_like(v) if need_v else None
+        lib = _lib.load()
+        nbytes = lib.cocos_corr_softmax_warp_bwd_workspace_bytes(B, K, Nq, Nk, Cv)
+        ws = torch.empty((max(nbytes, 4) + 3) // 4, device=qn.device, dtype=torch.float32)
+        _lib.call("cocos_corr_softmax_warp_bwd", qn.data_ptr(), kn.data_ptr(), v.data_ptr(),
+                  out.data_ptr(), lse.data_ptr(), dout.data_ptr(), _ptr(dqn), _ptr(dkn), _ptr(dv),
+                  ws.data_ptr(), ws.numel() * 4, B, K, Nq, Nk, Cv, ctx.inv_t, _stream())
+        return dqn, (dkn if need_k else None), dv, None
+
+
+def corr_softmax_warp(qn, kn, v, inv_temperature: float):
+    """out[b,c,i] = sum_j softmax_j(<qn[b,:,i], kn[b,:,j]> * inv_temperature) * v[b,c,j].
+
+    qn [B,256,Nq], kn [B,256,Nk], v [B,Cv,Nk] -> [B,Cv,Nq].  Wider V is processed in chunks of
+    160 channels (each chunk recomputes the logits; no materialisation)."""
+    Cv = v.shape[1]
+    if Cv <= MAX_FUSED_CV:
+        return _CorrSoftmaxWarp.apply(qn, kn, v, inv_temperature)
+    parts = [_CorrSoftmaxWarp.apply(qn, kn, v[:, c0:c0 + MAX_FUSED_CV], inv_temperature)
+             for c0 in range(0, Cv, MAX_FUSED_CV)]
+    return torch.cat(parts, dim=1)
+
+
+# ------------------------------------------------------------------------------------------
+# K3  materialised correlation          (correspondence.py:291 + :304; return_corr / WTA / mk != 1)
+# ------------------------------------------------------------------------------------------
+class _CorrMaterialize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qn, kn, scale: float):
+        qn, kn = _chk(qn, "qn"), _chk(kn, "kn")
+        B, K, Nq = qn.shape
+        Nk = kn.shape[2]
+        if kn.shape[:2] != (B, K):
+            raise ValueError(f"corr_materialize: shape mismatch qn{tuple(qn.shape)} kn{tuple(kn.shape)}")
+        f = torch.empty((B, Nq, Nk), device=qn.device, dtype=torch.float32)
+        _lib.call("cocos_corr_materialize", qn.data_ptr(), kn.data_ptr(), f.data_ptr(), B, K, Nq,
+                  Nk, float(scale), _stream())
+        ctx.save_for_backward(qn, kn)
+        ctx.scale = float(scale)
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        qn, kn = ctx.saved_tensors
+        df = _chk(df, "df")
+        B, K, Nq = qn.shape
+        Nk = kn.shape[2]
+        need_q, need_k = ctx.needs_input_grad[:2]
+        dqn = torch.empty_like(qn) if need_q else None
+        dkn = torch.empty_like(kn) if need_k else None
+        _lib.call("cocos_corr_materialize_bwd", qn.data_ptr(), kn.data_ptr(), df.data_ptr(),
+                  _ptr(dqn), _ptr(dkn), B, K, Nq, Nk, ctx.scale, _stream())
+        return dqn, dkn, None
+
+
+def corr_materialize(qn, kn, scale: float = 1.0):
+    """f[b,i,j] = scale * <qn[b,:,i], kn[b,:,j]>   -> [B,Nq,Nk] (any K)."""
+    return _CorrMaterialize.apply(qn, kn, scale)
+
+
+# ------------------------------------------------------------------------------------------
+# K4  row softmax on a materialised matrix   (correspondence.py:307)
+# ------------------------------------------------------------------------------------------
+class _RowSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s):
+        s = _chk(s, "row_softmax: s")
+        cols = s.shape[-1]
+        rows = s.numel() // cols
+        p = torch.empty_like(s)
+        _lib.call("cocos_row_softmax_fwd", s.data_ptr(), p.data_ptr(), rows, cols, _stream())
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        dp = _chk(dp, "row_softmax: dp")
+        cols = p.shape[-1]
+        rows = p.numel() // cols
+        ds = torch.empty_like(p)
+        _lib.call("cocos_row_softmax_bwd", p.data_ptr(), dp.data_ptr(), ds.data_ptr(), rows, cols,
+                  _stream())
+        return ds
+
+
+def row_softmax(s):
+    """softmax over the last dimension of a materialised matrix."""
+    return _RowSoftmax.apply(s)
+
+
+# ------------------------------------------------------------------------------------------
+# K5  P @ V on a materialised P            (correspondence.py:318 on the fallback path)
+# ------------------------------------------------------------------------------------------
+class _WarpMaterialized(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, v):
+        p, v = _chk(p, "p"), _chk(v, "v")
+        B, Nq, Nk = p.shape
+        Cv = v.shape[1]
+        if v.shape[0] != B or v.shape[2] != Nk:
+            raise ValueError(f"warp_materialized: shape mismatch p{tuple(p.shape)} v{tuple(v.shape)}")
+        out = torch.empty((B, Cv, Nq), device=p.device, dtype=torch.float32)
+        _lib.call("cocos_warp_materialized_fwd", p.data_ptr(), v.data_ptr(), out.data_ptr(), B, Nq,
+                  Nk, Cv, _stream())
+        ctx.save_for_backward(p, v)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        p, v = ctx.saved_tensors
+        dout = _chk(dout, "dout")
+        B, Nq, Nk = p.shape
+        Cv = v.shape[1]
+        need_p, need_v = ctx.needs_input_grad
+        dp = torch.empty_like(p) if need_p else None
+        dv = torch.empty_like(v) if need_v else None
+        _lib.call("cocos_warp_materialized_bwd", p.data_ptr(), v.data_ptr(), dout.data_ptr(),
+                  _ptr(dp), _ptr(dv), B, Nq, Nk, Cv, _stream())
+        return dp, dv
+
+
+def warp_materialized(p, v):
+    """out[b,c,i] = sum_j p[b,i,j] v[b,c,j]   (p [B,Nq,Nk], v [B,Cv,Nk]) -> [B,Cv,Nq]."""
+    return _WarpMaterialized.apply(p, v)
+
+
+def mfma_probe() -> torch.Tensor:
+    """Debug: the 64x16 accumulator image of one v_mfma_f32_32x32x2_f32 (see api_common.hip)."""
+    out = torch.empty((64, 16), device="cuda", dtype=torch.float32)
+    _lib.call("cocos_debug_mfma_probe", out.data_ptr(), _stream())
+    return out

@@ -1,0 +1,131 @@
+/*
+ * cocos_hip.h — C ABI of the MI355X-native (gfx950) correspondence hot path.
+ *
+ * The reference (microsoft/CoCosNet) has no FFI of its own: its hot path is a chain of
+ * ATen calls inside NoVGGCorrespondence.forward (models/networks/correspondence.py:271-372).
+ * This header is the boundary we introduce underneath that Python class contract; each entry
+ * point names the reference lines it replaces.  See INTEGRATION.md for the ctypes binding.
+ *
+ * Conventions (all entry points):
+ *   - plain C, no torch types; pointers are DEVICE pointers owned by the caller, fp32,
+ *     contiguous, 16-byte aligned; the library never allocates or frees device memory;
+ *   - "positions" are the flattened h*w feature grid; every feature tensor is CHANNEL-MAJOR
+ *     [B, C, positions] — exactly what `tensor.view(B, C, -1)` gives in the reference;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*), no hidden device sync;
+ *   - re-entrant / thread-safe (no global mutable state except a thread-local error string);
+ *   - return 0 on success, a negative code on failure (never throws):
+ *       -1 invalid argument, -2 unsupported shape, -3 HIP runtime error, -4 workspace too small.
+ */
+#ifndef COCOS_HIP_H
+#define COCOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COCOS_OK 0
+#define COCOS_ERR_INVALID (-1)
+#define COCOS_ERR_UNSUPPORTED (-2)
+#define COCOS_ERR_HIP (-3)
+#define COCOS_ERR_WORKSPACE (-4)
+
+typedef void* cocos_stream_t; /* hipStream_t */
+
+/* ABI version: major*10000 + minor*100 + patch. */
+int cocos_version(void);
+/* Message for the last failing call on this thread ("" if none). */
+const char* cocos_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------
+ * K1  centre + L2-normalise  (correspondence.py:277-280 for theta, :287-289 for phi)
+ *   x      [B,K,N]  raw theta/phi (after view or F.unfold)
+ *   y      [B,K,N]  out: (x - mean) / (||x - mean||_2 over K + eps)
+ *   norm   [B,N]    out: ||x - mean||_2 per position (saved for backward)
+ *   center_over_channels != 0  -> PONO_C: mean over K per position   (dim_mean = 1)
+ *                        == 0  -> mean over N per channel            (dim_mean = -1);
+ *                                 needs row_ws [B,K] floats of scratch.
+ *   eps = sys.float_info.epsilon (2.220446049250313e-16) in the reference.
+ * ------------------------------------------------------------------------------------- */
+int cocos_center_l2norm_fwd(const float* x, float* y, float* norm, float* row_ws,
+                            int B, int K, int N, int center_over_channels, float eps,
+                            cocos_stream_t stream);
+/* Backward of K1 (autograd of :277-280).  dy [B,K,N] -> dx [B,K,N].
+ * col_ws [B,N] and row_ws [B,K] floats of scratch are required when center_over_channels == 0
+ * (may be NULL otherwise). */
+int cocos_center_l2norm_bwd(const float* y, const float* norm, const float* dy, float* dx,
+                            float* col_ws, float* row_ws,
+                            int B, int K, int N, int center_over_channels, float eps,
+                            cocos_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K2  fused correlation -> /temperature -> softmax over key positions -> warp
+ *     (correspondence.py:281,291,304,307,318 and the extra P@V products at :334,:343-344,
+ *      :351-372; the HWxHW matrix never reaches HBM)
+ *   qn   [B,K,Nq]   normalised theta (query / content positions)
+ *   kn   [B,K,Nk]   normalised phi   (key / exemplar positions)
+ *   v    [B,Cv,Nk]  channels to warp (avg-pooled exemplar RGB, label maps, ... concatenated)
+ *   out  [B,Cv,Nq]  out[b,c,i] = sum_j softmax_j(qn[:,i].kn[:,j] * inv_temperature) * v[b,c,j]
+ *   lse  [B,Nq]     row log-sum-exp of the scaled logits (natural log), saved for backward
+ * The column softmax `softmax(f^T)` of :338/:351 is this same call with qn/kn swapped.
+ * Supported: K == 256 (match_kernel 1), 1 <= Cv <= 160, any Nq, Nk >= 1.
+ * ------------------------------------------------------------------------------------- */
+int cocos_corr_softmax_warp_fwd(const float* qn, const float* kn, const float* v,
+                                float* out, float* lse,
+                                int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
+                                cocos_stream_t stream);
+
+/* Backward of K2 (autograd of :291-318).  Recomputes logits tiles from qn/kn and `lse`.
+ *   dout [B,Cv,Nq] -> dqn [B,K,Nq], dkn [B,K,Nk], dv [B,Cv,Nk] (dv may be NULL: not needed)
+ *   ws: scratch of cocos_corr_softmax_warp_bwd_workspace_bytes() bytes. */
+size_t cocos_corr_softmax_warp_bwd_workspace_bytes(int B, int K, int Nq, int Nk, int Cv);
+int cocos_corr_softmax_warp_bwd(const float* qn, const float* kn, const float* v,
+                                const float* out, const float* lse, const float* dout,
+                                float* dqn, float* dkn, float* dv,
+                                void* ws, size_t ws_bytes,
+                                int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
+                                cocos_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K3  materialised correlation  f[b,i,j] = scale * sum_k qn[b,k,i] * kn[b,k,j]
+ *     (correspondence.py:291 + :304; needed by return_corr=True (:305-306), WTA_scale (:300-303)
+ *      and match_kernel != 1 where K = 256*mk^2)
+ *   f [B,Nq,Nk]; any K >= 1.
+ * ------------------------------------------------------------------------------------- */
+int cocos_corr_materialize(const float* qn, const float* kn, float* f,
+                           int B, int K, int Nq, int Nk, float scale, cocos_stream_t stream);
+
+/* K3b  gradients of K3 w.r.t. its operands (autograd of :291):
+ *   dqn[b,k,i] = scale * sum_j df[b,i,j] kn[b,k,j] ;  dkn[b,k,j] = scale * sum_i df[b,i,j] qn[b,k,i]
+ *   Either output may be NULL. */
+int cocos_corr_materialize_bwd(const float* qn, const float* kn, const float* df,
+                               float* dqn, float* dkn,
+                               int B, int K, int Nq, int Nk, float scale, cocos_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K4  row softmax over the last dimension of a materialised matrix (correspondence.py:307)
+ *     and its backward  ds = p * (dp - sum(p*dp)).  In-place (p == s, ds == dp) allowed.
+ * ------------------------------------------------------------------------------------- */
+int cocos_row_softmax_fwd(const float* s, float* p, int64_t rows, int cols, cocos_stream_t stream);
+int cocos_row_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, int cols,
+                          cocos_stream_t stream);
+
+/* K5  P @ V on a materialised P  (correspondence.py:318 on the fallback path)
+ *   p [B,Nq,Nk], v [B,Cv,Nk] -> out [B,Cv,Nq];  and its two gradients:
+ *   dp[b,i,j] = sum_c dout[b,c,i] v[b,c,j] ;  dv[b,c,j] = sum_i p[b,i,j] dout[b,c,i]. */
+int cocos_warp_materialized_fwd(const float* p, const float* v, float* out,
+                                int B, int Nq, int Nk, int Cv, cocos_stream_t stream);
+int cocos_warp_materialized_bwd(const float* p, const float* v, const float* dout,
+                                float* dp, float* dv,
+                                int B, int Nq, int Nk, int Cv, cocos_stream_t stream);
+
+/* Debug: runs one v_mfma_f32_32x32x2_f32 with known operands and dumps the 64x16 accumulator
+ * registers to out[64*16] so the host can verify the lane/register -> (row, col) map. */
+int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COCOS_HIP_H */
