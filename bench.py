@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""Benchmark of the MI355X-native correspondence hot path (driver contract: see README / DESIGN.md).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scope hotpath|netcorr] [--no-cpu-baseline]
+
+A "step" is ONE forward + backward pass of the hot path over one batch of synthetic ADE20k-shaped
+input (BASELINE.json configs[1]: 256x256 images, batch 8 per GPU, 64x64 feature grid, K = 256,
+V = 3 exemplar colours + 151 one-hot labels), inputs already resident in HBM:
+
+    theta/phi 1x1 convs (:272,:282) -> centre + L2-norm (:277-289) -> correlation / T -> softmax ->
+    warp of [rgb | ref_seg] (:291-336) -> nearest x4 up-sample (:327) -> loss = <out, G> -> backward
+    down to the gradients of the theta/phi weights and of the incoming features
+    -> (N > 1) RCCL all-reduce of the parameter gradients.
+
+`value` = images/s summed over all ranks (weak scaling: batch 8 per GPU whatever N).
+`--scope netcorr` times the whole drop-in NoVGGCorrespondence module (feature producers on stock
+PyTorch-ROCm) instead; it is reported for context in DESIGN.md and is not the headline line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
+BATCH_PER_GPU = 8
+IMG = 256
+DOWN = 4
+SEM_NC = 151
+KDIM = 256
+
+
+def build_inputs(device, scope):
+    g = torch.Generator(device=device).manual_seed(1234 + (torch.distributed.get_rank()
+                                                           if torch.distributed.is_initialized() else 0))
+    B, fh = BATCH_PER_GPU, IMG // DOWN
+    lab = torch.randint(0, SEM_NC, (B, 1, IMG // 16, IMG // 16), device=device, generator=g)
+    lab = lab.repeat_interleave(16, 2).repeat_interleave(16, 3)
+    seg = torch.zeros(B, SEM_NC, IMG, IMG, device=device).scatter_(1, lab, 1.0)
+    lab2 = torch.randint(0, SEM_NC, (B, 1, IMG // 16, IMG // 16), device=device, generator=g)
+    lab2 = lab2.repeat_interleave(16, 2).repeat_interleave(16, 3)
+    ref_seg = torch.zeros(B, SEM_NC, IMG, IMG, device=device).scatter_(1, lab2, 1.0)
+    ref_img = torch.rand(B, 3, IMG, IMG, device=device, generator=g) * 2 - 1
+    real_img = torch.rand(B, 3, IMG, IMG, device=device, generator=g) * 2 - 1
+    d = dict(seg=seg, ref_seg=ref_seg, ref_img=ref_img, real_img=real_img)
+    if scope == "hotpath":
+        cl = KDIM + SEM_NC   # 407 channels into theta/phi on ADE20k (--maskmix)
+        d["cont_features"] = torch.randn(B, cl, fh, fh, device=device, generator=g).requires_grad_(True)
+        d["ref_features"] = (0.3 * d["cont_features"].detach()[:, :, torch.randperm(fh, device=device, generator=g)]
+                             + torch.randn(B, cl, fh, fh, device=device, generator=g)).requires_grad_(True)
+    d["g_out"] = torch.randn(B, 3, IMG, IMG, device=device, generator=g)
+    d["g_mask"] = torch.randn(B, SEM_NC, fh, fh, device=device, generator=g)
+    return d
+
+
+class HotPathStep(torch.nn.Module):
+    """theta/phi projections + the HIP hot path (ADE20k flag set, match_kernel 1)."""
+
+    def __init__(self):
+        super().__init__()
+        from cocosnet_amd.hot_path import HotPathConfig
+        cl = KDIM + SEM_NC
+        self.theta = torch.nn.Conv2d(cl, KDIM, 1)
+        self.phi = torch.nn.Conv2d(cl, KDIM, 1)
+        self.cfg = HotPathConfig(match_kernel=1, PONO_C=True, down=DOWN, warp_mask_losstype="direct")
+
+    def forward(self, d):
+        from cocosnet_amd.hot_path import correspondence_hot_path
+        return correspondence_hot_path(self.theta(d["cont_features"]), self.phi(d["ref_features"]),
+                                       d["ref_img"], d["real_img"], d["seg"], d["ref_seg"], self.cfg)
+
+
+def make_step(scope, device):
+    if scope == "hotpath":
+        model = HotPathStep().to(device)
+        fwd = lambda d: model(d)
+    else:
+        from cocosnet_amd.correspondence import NoVGGCorrespondence, ade20k_options
+        opt = ade20k_options(match_kernel=1, isTrain=True)
+        model = NoVGGCorrespondence(opt).to(device)
+        model.init_weights(opt.init_type, opt.init_variance)
+        fwd = lambda d: model(d["ref_img"], d["real_img"], d["seg"], d["ref_seg"])
+    return model, fwd
+
+
+def cpu_baseline(n_images, seed=0):
+    """The oracle (numpy restatement of the reference, fp32, BLAS threads = host cores) timed on a
+    bounded sample of the same workload: forward + backward of the hot path from theta/phi on."""
+    import numpy as np
+    from oracle import corr_oracle as co
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    rs = np.random.RandomState(seed)
+    fh = IMG // DOWN
+    N = fh * fh
+    th = rs.standard_normal((1, KDIM, N)).astype(np.float32)
+    ph = rs.standard_normal((1, KDIM, N)).astype(np.float32)
+    v = rs.uniform(-1, 1, (1, 3 + SEM_NC, N)).astype(np.float32)
+    gout = rs.standard_normal((1, 3 + SEM_NC, N)).astype(np.float32)
+
+    def one():
+        qn, kn = co.center_l2norm(th, True), co.center_l2norm(ph, True)
+        out = co.corr_softmax_warp(qn, kn, v, np.float32(100.0))
+        dqn, dkn, _ = co.corr_softmax_warp_bwd(qn, kn, v, gout, np.float32(100.0))
+        return out, co.center_l2norm_bwd(th, dqn, True), co.center_l2norm_bwd(ph, dkn, True)
+    one()   # warm-up (BLAS thread pool, page faults)
+    t0 = time.perf_counter()
+    for _ in range(n_images):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": n_images / dt, "unit": "images/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n_images} images (batch 1 each) of the same workload through oracle/"
+                      f"corr_oracle.py in fp32 numpy: centre+L2norm, correlation, softmax, warp "
+                      f"(Cv=154), and their backward; {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scope", choices=("hotpath", "netcorr"), default="hotpath")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=6)
+    args = ap.parse_args()
+
+    from cocosnet_amd import dist as cdist
+    from cocosnet_amd import ops
+    rank, local_rank, world = cdist.init_from_env("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    model, fwd = make_step(args.scope, device)
+    if world > 1:   # identical replicas: broadcast rank 0's parameters once
+        for p in model.parameters():
+            torch.distributed.broadcast(p.data, 0)
+    buckets = cdist.GradBuckets(model.parameters())
+    d = build_inputs(device, args.scope)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        for k in ("cont_features", "ref_features"):
+            if k in d:
+                d[k].grad = None
+        out = fwd(d)
+        loss = (out["warp_out"] * d["g_out"]).sum() + (out["warp_mask"] * d["g_mask"]).sum()
+        loss.backward()
+        buckets.all_reduce_(world)
+
+    for _ in range(args.warmup):
+        step()
+    sync = lambda: (torch.distributed.barrier() if world > 1 else None, torch.cuda.synchronize())
+    sync()
+    with ops.KernelTimer() as kt:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt = time.perf_counter() - t0
+    kern = kt.summary()
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        N = (IMG // DOWN) ** 2
+        cv = 3 + SEM_NC
+        B = BATCH_PER_GPU
+        # algorithmic FLOPs per launch (no recompute counted): forward 2*HW^2*(K+Cv),
+        # backward 2*HW^2*(2K+Cv) split as dq: 2*HW^2*(K+Cv) [dP + dq], dkv: 2*HW^2*K [dk]
+        alg = {"corr_softmax_warp_fwd": 2.0 * N * N * (KDIM + cv) * B,
+               "corr_softmax_warp_bwd_dq": 2.0 * N * N * (KDIM + cv) * B,
+               "corr_softmax_warp_bwd_dkv": 2.0 * N * N * KDIM * B}
+        kernels = {}
+        for tag, flops in alg.items():
+            if tag in kern:
+                ms = kern[tag]["avg_ms"]
+                kernels[tag] = {"avg_ms": round(ms, 4), "calls": kern[tag]["calls"],
+                                "alg_tflops": round(flops / ms / 1e9, 2),
+                                "frac_fp32_mfma_peak": round(flops / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
+        roofline = None
+        if dom:
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["alg_tflops"],
+                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": kernels[dom]["frac_fp32_mfma_peak"], "traffic": None,
+                        "avg_launch_ms": kernels[dom]["avg_ms"],
+                        "note": "algorithmic FLOPs per launch / HIP-event time on torch's current "
+                                "stream; peak = dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.cpu_images)
+        images = BATCH_PER_GPU * world * args.steps
+        line = {
+            "metric": "images/sec fwd+bwd ADE20k 256x256 batch-8/GPU (correspondence hot path)",
+            "value": round(images / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"ADE20k 256x256 batch {BATCH_PER_GPU}/GPU, 64x64 grid (HW=4096), K=256, "
+                                   f"Cv=154 (rgb+151 labels), match_kernel 1, PONO_C, T=0.01; scope={args.scope}: "
+                                   + ("theta/phi 1x1 conv + centre/L2norm + fused corr-softmax-warp fwd+bwd"
+                                      if args.scope == "hotpath" else
+                                      "whole NoVGGCorrespondence module fwd+bwd (producers on PyTorch-ROCm)"),
+                       "global_batch": BATCH_PER_GPU * world, "parallelism": f"dp{world}",
+                       "grad_allreduce_bytes": buckets.nbytes() if world > 1 else 0},
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

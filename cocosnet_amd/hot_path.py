@@ -1,0 +1,203 @@
+"""Host-side orchestration of the correspondence hot path (correspondence.py:271-372).
+
+Takes the outputs of the `theta` / `phi` 1x1 convolutions and returns the reference's `coor_out`
+dictionary.  Every correlation / softmax / warp product is a HIP kernel call (cocosnet_amd.ops);
+the only PyTorch ops left are the tiny, shape-only ones the survey keeps on the stock backend:
+avg-pool / nearest-resize of the 3..151-channel inputs, fold/unfold of patches and the final
+x`down` up-sampling.
+
+Pass structure on the fused path (K == 256).  The reference materialises f once and reuses it;
+here each use is one fused launch that recomputes its logits tiles (f never reaches HBM), with all
+the channel groups that share a softmax concatenated into a single V:
+    R1  rows    softmax_j(f)    V = [exemplar rgb | ref_seg (direct mask)]        :318, :334
+    C1  columns softmax_i(f^T)  V = [seg (cycle mask) | y (warp_cycle) | real]    :338-343, :351-367
+        — the same kernel with theta/phi swapped (SURVEY.md §7 design notes)
+    R2  rows    softmax_j(f)    V = [C1's mask | C1's i2r]                        :344, :369
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+@dataclass
+class HotPathConfig:
+    """The `opt` fields the hot path reads, detached from argparse."""
+    match_kernel: int = 3
+    PONO_C: bool = False
+    down: int = 4
+    warp_patch: bool = False
+    warp_bilinear: bool = False
+    isTrain: bool = False
+    show_corr: bool = False
+    warp_mask_losstype: str = "none"
+    show_warpmask: bool = False
+    warp_cycle_w: float = 0.0
+    two_cycle: bool = False
+
+    @classmethod
+    def from_opt(cls, opt, down=None):
+        g = lambda k, d: getattr(opt, k, d)
+        return cls(match_kernel=int(g("match_kernel", 3)), PONO_C=bool(g("PONO_C", False)),
+                   down=int(down if down is not None else g("down", 4)),
+                   warp_patch=bool(g("warp_patch", False)),
+                   warp_bilinear=bool(g("warp_bilinear", False)), isTrain=bool(g("isTrain", False)),
+                   show_corr=bool(g("show_corr", False)),
+                   warp_mask_losstype=str(g("warp_mask_losstype", "none")),
+                   show_warpmask=bool(g("show_warpmask", False)),
+                   warp_cycle_w=float(g("warp_cycle_w", 0.0)), two_cycle=bool(g("two_cycle", False)))
+
+
+class _WTAScale(torch.autograd.Function):
+    """WTA_scale of the reference (correspondence.py:38-77): forward keeps each row's maxima and
+    multiplies the rest by `scale`; backward multiplies the gradient by 1 at the maxima and by the
+    reference's hard-coded 1e-4 elsewhere (:72) — NOT the true derivative, reproduced on purpose."""
+
+    @staticmethod
+    def forward(ctx, f, scale):
+        mask = f == f.max(dim=-1, keepdim=True)[0]
+        ctx.save_for_backward(mask)
+        return torch.where(mask, f, f * scale)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (mask,) = ctx.saved_tensors
+        return grad * torch.where(mask, 1.0, 1e-4).to(grad.dtype), None
+
+
+def _flat(x):
+    """[B,C,h,w] -> channel-major [B,C,h*w] (a view when contiguous)."""
+    return x.reshape(x.shape[0], x.shape[1], -1)
+
+
+def _upsample(y, down, bilinear):
+    if bilinear:   # nn.Upsample(scale_factor, mode='bilinear'), align_corners=False (:184-186)
+        return F.interpolate(y, scale_factor=down, mode="bilinear", align_corners=False)
+    return F.interpolate(y, scale_factor=down, mode="nearest")   # :188
+
+
+class _Attention:
+    """The two softmax directions of one correlation, fused or materialised."""
+
+    def __init__(self, qn, kn, inv_t, wta_scale_weight, fused):
+        self.qn, self.kn, self.inv_t = qn, kn, inv_t
+        self.fused = fused
+        self._p_row = self._p_col = self._f = None
+        if not fused:
+            if wta_scale_weight == 1:
+                self._f = ops.corr_materialize(qn, kn, inv_t)              # :291 + :304
+            else:
+                f = ops.corr_materialize(qn, kn, 1.0)                      # :291
+                self._f = _WTAScale.apply(f, wta_scale_weight) * inv_t     # :303-304
+
+    @property
+    def f_scaled(self):
+        return self._f
+
+    def rows(self, v):
+        """softmax over exemplar positions, then @ v   (f_div_C @ v, :307/:318)."""
+        if self.fused:
+            return ops.corr_softmax_warp(self.qn, self.kn, v, self.inv_t)
+        if self._p_row is None:
+            self._p_row = ops.row_softmax(self._f)
+        return ops.warp_materialized(self._p_row, v)
+
+    def cols(self, v):
+        """softmax over content positions of f^T, then @ v   (f_div_C_v @ v, :338/:351)."""
+        if self.fused:
+            return ops.corr_softmax_warp(self.kn, self.qn, v, self.inv_t)
+        if self._p_col is None:
+            self._p_col = ops.row_softmax(self._f.transpose(1, 2).contiguous())
+        return ops.warp_materialized(self._p_col, v)
+
+
+def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_seg_map,
+                            cfg: HotPathConfig, temperature=0.01, detach_flag=False,
+                            WTA_scale_weight=1, return_corr=False):
+    """correspondence.py:272-372 from the theta/phi conv outputs onward.
+
+    theta_raw, phi_raw: [B,256,h,w] CUDA fp32.  Returns the `coor_out` dict of the reference
+    (or the scaled correlation [B,HW,HW] when return_corr, :305-306)."""
+    B, C, fh, fw = theta_raw.shape
+    H, W = ref_img.shape[2], ref_img.shape[3]
+    down, mk = cfg.down, cfg.match_kernel
+    out = {}
+
+    # :272-289 — flatten / implicit 3x3 neighbourhood, centre, L2-normalise
+    if mk == 1:
+        theta, phi = _flat(theta_raw), _flat(phi_raw)
+    else:
+        theta = F.unfold(theta_raw, kernel_size=mk, padding=mk // 2)
+        phi = F.unfold(phi_raw, kernel_size=mk, padding=mk // 2)
+    qn = ops.center_l2norm(theta, cfg.PONO_C)
+    kn = ops.center_l2norm(phi, cfg.PONO_C)
+    if detach_flag:   # :292-293 `f = f.detach()`: nothing upstream of f receives a gradient
+        qn, kn = qn.detach(), kn.detach()
+
+    fused = (qn.shape[1] == ops.FUSED_K) and WTA_scale_weight == 1 and not return_corr
+    attn = _Attention(qn, kn, 1.0 / temperature, WTA_scale_weight, fused)
+    if return_corr:
+        return attn.f_scaled
+
+    # ---- R1: exemplar colours (+ direct mask) through the row softmax  (:309-336) ----------------
+    if cfg.warp_patch:
+        ref = F.unfold(ref_img, down, stride=down)                    # [B, 3*down^2, HW]
+    else:
+        ref = _flat(F.avg_pool2d(ref_img, down))                      # [B, 3, HW]
+    n_ref = ref.shape[1]
+    direct_mask = cfg.warp_mask_losstype == "direct" or cfg.show_warpmask
+    v_r1 = [ref]
+    if direct_mask:
+        ref_seg = F.interpolate(ref_seg_map, scale_factor=1 / down, mode="nearest")
+        v_r1.append(_flat(ref_seg))
+    o_r1 = attn.rows(torch.cat(v_r1, dim=1) if len(v_r1) > 1 else ref)
+    y = o_r1[:, :n_ref]                                               # [B, ch, HW]
+    if cfg.warp_patch:
+        y_img = F.fold(y, (H, W), down, stride=down)                  # reference hard-codes 256 (:321)
+    else:
+        y_img = y.reshape(B, n_ref, fh, fw)
+    if (not cfg.isTrain) and cfg.show_corr:
+        out["warp_out_bi"] = y_img if cfg.warp_patch else _upsample(y_img, down, True)
+    out["warp_out"] = y_img if cfg.warp_patch else _upsample(y_img, down, cfg.warp_bilinear)
+    if direct_mask:
+        out["warp_mask"] = o_r1[:, n_ref:].reshape(B, -1, fh, fw)
+
+    # ---- C1: everything that goes through the column softmax  (:337-343, :350-367) ---------------
+    cycle_mask = (not direct_mask) and cfg.warp_mask_losstype == "cycle"
+    want_cycle = cfg.warp_cycle_w > 0
+    want_two = want_cycle and cfg.two_cycle and not cfg.warp_patch
+    v_c1, names = [], []
+    if cycle_mask:
+        seg = F.interpolate(seg_map, scale_factor=1 / down, mode="nearest")
+        v_c1.append(_flat(seg)); names.append("mask")
+    if want_cycle:
+        yy = F.unfold(y_img, down, stride=down) if cfg.warp_patch else y
+        v_c1.append(yy); names.append("cycle")
+    if want_two:
+        v_c1.append(_flat(F.avg_pool2d(real_img, down))); names.append("i2r")
+    if v_c1:
+        o_c1 = attn.cols(torch.cat(v_c1, dim=1) if len(v_c1) > 1 else v_c1[0])
+        parts = dict(zip(names, torch.split(o_c1, [t.shape[1] for t in v_c1], dim=1)))
+        if want_cycle:
+            wc = parts["cycle"]
+            out["warp_cycle"] = (F.fold(wc, (H, W), down, stride=down) if cfg.warp_patch
+                                 else wc.reshape(B, -1, fh, fw))
+        if want_two:
+            out["warp_i2r"] = parts["i2r"].reshape(B, -1, fh, fw)
+
+        # ---- R2: second trip through the row softmax  (:344, :369) --------------------------------
+        v_r2 = [parts[n] for n in ("mask", "i2r") if n in parts]
+        if v_r2:
+            o_r2 = attn.rows(torch.cat(v_r2, dim=1) if len(v_r2) > 1 else v_r2[0])
+            pos = 0
+            if cycle_mask:
+                nm = parts["mask"].shape[1]
+                out["warp_mask"] = o_r2[:, :nm].reshape(B, nm, fh, fw)
+                pos = nm
+            if want_two:
+                out["warp_i2r2i"] = o_r2[:, pos:].reshape(B, -1, fh, fw)
+    return out

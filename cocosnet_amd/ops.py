@@ -25,6 +25,44 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Brackets every C-ABI call with HIP events on the stream the kernels are launched on (torch's
+    current stream) and reports the average device time per entry point — bench.py's live source
+    for `roofline.achieved`.  Use as a context manager; call summary() after a synchronize."""
+
+    active = None
+
+    def __init__(self):
+        self.events = {}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, evs in self.events.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[tag] = {"calls": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms)}
+        return out
+
+
+def _call(tag, name, *args):
+    t = KernelTimer.active
+    if t is None:
+        return _lib.call(name, *args)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call(name, *args)
+    e1.record()
+    t.events.setdefault(tag, []).append((e0, e1))
+
+
 def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise _lib.CocosHipError(
@@ -50,7 +88,7 @@ class _CenterL2Norm(torch.autograd.Function):
         norm = torch.empty((B, N), device=x.device, dtype=torch.float32)
         row_ws = None if center_over_channels else torch.empty((B, K), device=x.device,
                                                                 dtype=torch.float32)
-        _lib.call("cocos_center_l2norm_fwd", x.data_ptr(), y.data_ptr(), norm.data_ptr(),
+        _call("center_l2norm_fwd", "cocos_center_l2norm_fwd", x.data_ptr(), y.data_ptr(), norm.data_ptr(),
                   _ptr(row_ws), B, K, N, int(center_over_channels), float(eps), _stream())
         ctx.save_for_backward(y, norm)
         ctx.cfg = (bool(center_over_channels), float(eps))
@@ -67,7 +105,7 @@ class _CenterL2Norm(torch.autograd.Function):
         if not center_over_channels:
             col_ws = torch.empty((B, N), device=y.device, dtype=torch.float32)
             row_ws = torch.empty((B, K), device=y.device, dtype=torch.float32)
-        _lib.call("cocos_center_l2norm_bwd", y.data_ptr(), norm.data_ptr(), dy.data_ptr(),
+        _call("center_l2norm_bwd", "cocos_center_l2norm_bwd", y.data_ptr(), norm.data_ptr(), dy.data_ptr(),
                   dx.data_ptr(), _ptr(col_ws), _ptr(row_ws), B, K, N, int(center_over_channels),
                   eps, _stream())
         return dx, None, None
@@ -93,7 +131,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                              f"kn{tuple(kn.shape)} v{tuple(v.shape)}")
         out = torch.empty((B, Cv, Nq), device=qn.device, dtype=torch.float32)
         lse = torch.empty((B, Nq), device=qn.device, dtype=torch.float32)
-        _lib.call("cocos_corr_softmax_warp_fwd", qn.data_ptr(), kn.data_ptr(), v.data_ptr(),
+        _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd", qn.data_ptr(), kn.data_ptr(), v.data_ptr(),
                   out.data_ptr(), lse.data_ptr(), B, K, Nq, Nk, Cv, float(inv_temperature),
                   _stream())
         ctx.save_for_backward(qn, kn, v, out, lse)
@@ -113,9 +151,17 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         lib = _lib.load()
         nbytes = lib.cocos_corr_softmax_warp_bwd_workspace_bytes(B, K, Nq, Nk, Cv)
         ws = torch.empty((max(nbytes, 4) + 3) // 4, device=qn.device, dtype=torch.float32)
-        _lib.call("cocos_corr_softmax_warp_bwd", qn.data_ptr(), kn.data_ptr(), v.data_ptr(),
-                  out.data_ptr(), lse.data_ptr(), dout.data_ptr(), _ptr(dqn), _ptr(dkn), _ptr(dv),
-                  ws.data_ptr(), ws.numel() * 4, B, K, Nq, Nk, Cv, ctx.inv_t, _stream())
+        # two launches of the same entry point: the query side, then the key/value side — so that
+        # each kernel can be timed on its own (the C ABI skips a side whose output pointer is NULL)
+        common = (qn.data_ptr(), kn.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                  dout.data_ptr())
+        tail = (ws.data_ptr(), ws.numel() * 4, B, K, Nq, Nk, Cv, ctx.inv_t, _stream())
+        if dqn is not None:
+            _call("corr_softmax_warp_bwd_dq", "cocos_corr_softmax_warp_bwd", *common, _ptr(dqn), 0,
+                  0, *tail)
+        if dkn is not None:
+            _call("corr_softmax_warp_bwd_dkv", "cocos_corr_softmax_warp_bwd", *common, 0, _ptr(dkn),
+                  _ptr(dv), *tail)
         return dqn, (dkn if need_k else None), dv, None
 
 
@@ -144,7 +190,7 @@ class _CorrMaterialize(torch.autograd.Function):
         if kn.shape[:2] != (B, K):
             raise ValueError(f"corr_materialize: shape mismatch qn{tuple(qn.shape)} kn{tuple(kn.shape)}")
         f = torch.empty((B, Nq, Nk), device=qn.device, dtype=torch.float32)
-        _lib.call("cocos_corr_materialize", qn.data_ptr(), kn.data_ptr(), f.data_ptr(), B, K, Nq,
+        _call("corr_materialize", "cocos_corr_materialize", qn.data_ptr(), kn.data_ptr(), f.data_ptr(), B, K, Nq,
                   Nk, float(scale), _stream())
         ctx.save_for_backward(qn, kn)
         ctx.scale = float(scale)
@@ -159,7 +205,7 @@ class _CorrMaterialize(torch.autograd.Function):
         need_q, need_k = ctx.needs_input_grad[:2]
         dqn = torch.empty_like(qn) if need_q else None
         dkn = torch.empty_like(kn) if need_k else None
-        _lib.call("cocos_corr_materialize_bwd", qn.data_ptr(), kn.data_ptr(), df.data_ptr(),
+        _call("corr_materialize_bwd", "cocos_corr_materialize_bwd", qn.data_ptr(), kn.data_ptr(), df.data_ptr(),
                   _ptr(dqn), _ptr(dkn), B, K, Nq, Nk, ctx.scale, _stream())
         return dqn, dkn, None
 
@@ -179,7 +225,7 @@ class _RowSoftmax(torch.autograd.Function):
         cols = s.shape[-1]
         rows = s.numel() // cols
         p = torch.empty_like(s)
-        _lib.call("cocos_row_softmax_fwd", s.data_ptr(), p.data_ptr(), rows, cols, _stream())
+        _call("row_softmax_fwd", "cocos_row_softmax_fwd", s.data_ptr(), p.data_ptr(), rows, cols, _stream())
         ctx.save_for_backward(p)
         return p
 
@@ -190,7 +236,7 @@ class _RowSoftmax(torch.autograd.Function):
         cols = p.shape[-1]
         rows = p.numel() // cols
         ds = torch.empty_like(p)
-        _lib.call("cocos_row_softmax_bwd", p.data_ptr(), dp.data_ptr(), ds.data_ptr(), rows, cols,
+        _call("row_softmax_bwd", "cocos_row_softmax_bwd", p.data_ptr(), dp.data_ptr(), ds.data_ptr(), rows, cols,
                   _stream())
         return ds
 
@@ -212,7 +258,7 @@ class _WarpMaterialized(torch.autograd.Function):
         if v.shape[0] != B or v.shape[2] != Nk:
             raise ValueError(f"warp_materialized: shape mismatch p{tuple(p.shape)} v{tuple(v.shape)}")
         out = torch.empty((B, Cv, Nq), device=p.device, dtype=torch.float32)
-        _lib.call("cocos_warp_materialized_fwd", p.data_ptr(), v.data_ptr(), out.data_ptr(), B, Nq,
+        _call("warp_materialized_fwd", "cocos_warp_materialized_fwd", p.data_ptr(), v.data_ptr(), out.data_ptr(), B, Nq,
                   Nk, Cv, _stream())
         ctx.save_for_backward(p, v)
         return out
@@ -226,7 +272,7 @@ class _WarpMaterialized(torch.autograd.Function):
         need_p, need_v = ctx.needs_input_grad
         dp = torch.empty_like(p) if need_p else None
         dv = torch.empty_like(v) if need_v else None
-        _lib.call("cocos_warp_materialized_bwd", p.data_ptr(), v.data_ptr(), dout.data_ptr(),
+        _call("warp_materialized_bwd", "cocos_warp_materialized_bwd", p.data_ptr(), v.data_ptr(), dout.data_ptr(),
                   _ptr(dp), _ptr(dv), B, Nq, Nk, Cv, _stream())
         return dp, dv
 

@@ -1,0 +1,117 @@
+"""Pin the oracle (oracle/corr_oracle.py) against the reference's own outputs (tests/golden/).
+
+CPU only.  The fixtures were produced by running /root/reference's NoVGGCorrespondence.forward
+(oracle/make_golden.py); inputs are regenerated from the case seed.  Tolerances: the reference is
+fp32 and the oracle fp64, and T = 0.01 amplifies fp32 GEMM rounding 100x in the logits, so outputs
+agree to ~1e-6..1e-4 relative; gradients (backward GEMMs over fp32 P) to ~1e-4.
+"""
+import numpy as np
+import pytest
+
+from oracle import corr_oracle as co
+from oracle import golden_cases as gc
+
+FWD_TOL = 2e-4    # max-abs error relative to the tensor's max magnitude
+
+
+@pytest.mark.parametrize("name", sorted(gc.CASES))
+def test_oracle_forward_matches_reference(name):
+    c = gc.CASES[name]
+    inp = gc.make_inputs(name)
+    golden = gc.load_golden(name)
+    opt = co.default_opt(**gc.hot_path_flags(name))
+    res = co.hot_path_forward(inp.theta_raw, inp.phi_raw, inp.ref_img, inp.real_img, inp.seg_map,
+                              inp.ref_seg_map, opt, **c.get("fwd", {}))
+    if not isinstance(res, dict):
+        res = {"corr": res}
+    errs = gc.compare_with_golden(name, res, golden)
+    assert errs and max(errs.values()) < FWD_TOL, errs
+
+
+def test_golden_inputs_are_not_degenerate():
+    """The fixtures must exercise the softmax: rows neither uniform nor all one-hot."""
+    inp = gc.make_inputs("ade_mk1")
+    q = co.center_l2norm(inp.theta_raw.reshape(2, 256, -1).astype(np.float64), True)
+    k = co.center_l2norm(inp.phi_raw.reshape(2, 256, -1).astype(np.float64), True)
+    p = co.softmax(co.correlation(q, k) * 100.0)
+    row_max = p.max(-1)
+    assert 0.05 < np.median(row_max) < 0.999 and (row_max < 0.9).mean() > 0.2
+
+
+def _sum_pool(g, s):
+    B, C, H, W = g.shape
+    return g.reshape(B, C, H // s, s, W // s, s).sum(axis=(3, 5))
+
+
+@pytest.mark.parametrize("name", ["ade_mk1", "temp_005", "noponoc_mk1"])
+def test_oracle_backward_matches_reference_autograd(name):
+    """Chain the oracle's hand-derived backward pieces and compare with the gradients the
+    reference's autograd produced for loss = <warp_out, G1> + <warp_mask, G2>."""
+    c = gc.CASES[name]
+    inp = gc.make_inputs(name)
+    golden = gc.load_golden(name)
+    flags = gc.hot_path_flags(name)
+    inv_t = 1.0 / c.get("fwd", {}).get("temperature", 0.01)
+    B = c["B"]
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    theta = f64(inp.theta_raw).reshape(B, 256, -1)
+    phi = f64(inp.phi_raw).reshape(B, 256, -1)
+    qn, kn = co.center_l2norm(theta, flags["PONO_C"]), co.center_l2norm(phi, flags["PONO_C"])
+    ref = co.avg_pool2d(f64(inp.ref_img), 4).reshape(B, 3, -1)
+    seg = co.nearest_down(f64(inp.ref_seg_map), 4).reshape(B, c["nc"], -1)
+    v = np.concatenate([ref, seg], axis=1)
+    G = gc.grad_weights(name, {"warp_out": tuple(golden["shape__warp_out"]),
+                               "warp_mask": tuple(golden["shape__warp_mask"])})
+    d_y = _sum_pool(f64(G["warp_out"]), 4).reshape(B, 3, -1)          # nearest upsample backward
+    d_m = f64(G["warp_mask"]).reshape(B, c["nc"], -1)
+    dout = np.concatenate([d_y, d_m], axis=1)
+    dqn, dkn, _ = co.corr_softmax_warp_bwd(qn, kn, v, dout, inv_t)
+    dtheta = co.center_l2norm_bwd(theta, dqn, flags["PONO_C"]).reshape(inp.theta_raw.shape)
+    dphi = co.center_l2norm_bwd(phi, dkn, flags["PONO_C"]).reshape(inp.phi_raw.shape)
+    for got, key in ((dtheta, "grad__theta_raw"), (dphi, "grad__phi_raw")):
+        ref_g = golden[key].astype(np.float64)
+        err = np.abs(got - ref_g).max() / np.abs(ref_g).max()
+        assert err < 1e-3, (key, err)
+
+
+def test_oracle_backward_matches_finite_differences():
+    """Independent of any autograd: central differences on a tiny problem (fp64)."""
+    rs = np.random.RandomState(0)
+    q = rs.standard_normal((1, 8, 5)); k = rs.standard_normal((1, 8, 6)); v = rs.standard_normal((1, 2, 6))
+    g = rs.standard_normal((1, 2, 5))
+    loss = lambda qq, kk, vv: (co.corr_softmax_warp(co.center_l2norm(qq, True), co.center_l2norm(kk, True),
+                                                    vv, 7.0) * g).sum()
+    qn, kn = co.center_l2norm(q, True), co.center_l2norm(k, True)
+    dqn, dkn, dv = co.corr_softmax_warp_bwd(qn, kn, v, g, 7.0)
+    dq, dk = co.center_l2norm_bwd(q, dqn, True), co.center_l2norm_bwd(k, dkn, True)
+    h = 1e-6
+    for arr, grad, which in ((q, dq, 0), (k, dk, 1), (v, dv, 2)):
+        for idx in [(0, 1, 2), (0, 0, 0), (0, 1, 4)]:
+            a0 = arr[idx]
+            args = [q, k, v]
+            arr[idx] = a0 + h; lp = loss(*args)
+            arr[idx] = a0 - h; lm = loss(*args)
+            arr[idx] = a0
+            assert abs((lp - lm) / (2 * h) - grad[idx]) < 1e-6 * max(1.0, abs(grad[idx]))
+
+
+def test_wta_scale_rule():
+    f = np.array([[[1.0, 3.0, 2.0], [5.0, 5.0, -1.0]]])
+    out = co.wta_scale(f, 0.5)
+    assert np.allclose(out, [[[0.5, 3.0, 1.0], [5.0, 5.0, -0.5]]])
+    gi = co.wta_scale_bwd(f, np.ones_like(f))
+    assert np.allclose(gi, [[[1e-4, 1.0, 1e-4], [1.0, 1.0, 1e-4]]])
+
+
+def test_unfold_fold_roundtrip_and_ordering():
+    rs = np.random.RandomState(1)
+    x = rs.standard_normal((2, 3, 8, 8))
+    cols = co.unfold(x, 4, stride=4)
+    assert cols.shape == (2, 48, 4)
+    assert np.array_equal(co.fold(cols, (8, 8), 4, 4), x)
+    # channel ordering c*k*k + ky*k + kx, zero padding (F.unfold semantics)
+    u = co.unfold(x, 3, padding=1)
+    assert u.shape == (2, 27, 64)
+    assert u[0, 0 * 9 + 0 * 3 + 0, 0] == 0.0                      # top-left tap of position 0 is padding
+    assert u[1, 2 * 9 + 1 * 3 + 1, 9] == x[1, 2, 1, 1]            # centre tap
+    assert u[0, 1 * 9 + 2 * 3 + 2, 0] == x[0, 1, 1, 1]            # bottom-right tap of position 0
