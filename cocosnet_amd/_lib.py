@@ -77,6 +77,10 @@ def load() -> ctypes.CDLL:
                 raise CocosHipError(
                     f"{LIB_PATH} not found: build it with `python -m cocosnet_amd.build` "
                     "(there is no PyTorch/CPU fallback for the correspondence hot path)")
+            # PyTorch-ROCm bundles its own libamdhip64; import it FIRST so that this library binds
+            # to the same HIP runtime instance (two runtimes in one process = "no ROCm-capable
+            # device" on the second one, and torch's streams/pointers would be foreign to it).
+            import torch  # noqa: F401
             lib = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in _SIGNATURES.items():
                 fn = getattr(lib, name)   # AttributeError -> header and library disagree

@@ -1,0 +1,248 @@
+"""Feature producers that feed the correspondence hot path — plain PyTorch (stock MIOpen convs).
+
+These are the layers immediately BEFORE the path: the two domain adaptors
+(`AdaptiveFeatureGenerator`, reference models/networks/generator.py:91-160, built from
+`SPADEResnetBlock` architecture.py:19-95 and `SPADE` normalization.py:83-151) and the four
+`ResidualBlock`s (correspondence.py:13-36).  They are re-implemented here only so that the drop-in
+`NoVGGCorrespondence` is a standalone module whose `state_dict()` keys and shapes equal the
+reference's (`*_net_Corr.pth` checkpoints load unchanged); none of this is on the HIP path yet.
+
+Supported flag space = what the README commands use: spectral-norm convs (not --eqlr_sn), no apex,
+PONO or instance/batch/sync-batch parameter-free norms.  Unsupported flags raise immediately.
+"""
+from __future__ import annotations
+
+import re
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils import spectral_norm
+
+
+def positional_norm(x, eps=1e-5):
+    """PONO: normalise over the channel axis with the UNBIASED variance (normalization.py:63-68)."""
+    mu = x.mean(dim=1, keepdim=True)
+    sd = (x.var(dim=1, keepdim=True) + eps).sqrt()
+    return (x - mu) / sd
+
+
+def _param_free_norm(kind: str, channels: int):
+    if kind == "instance":
+        return nn.InstanceNorm2d(channels, affine=False)
+    if kind == "batch":
+        return nn.BatchNorm2d(channels, affine=False)
+    if kind == "syncbatch":
+        # the reference's Python-queue SynchronizedBatchNorm2d -> torch's SyncBatchNorm, whose
+        # statistics exchange is an RCCL all-reduce under backend "nccl" (same buffer names)
+        return nn.SyncBatchNorm(channels, affine=False)
+    raise ValueError(f"{kind} is not a recognised parameter-free norm for SPADE")
+
+
+class SPADE(nn.Module):
+    """norm(x) * (1 + gamma(seg)) + beta(seg); gamma/beta from a 2-layer conv net on the nearest-
+    resized label map, reflection padded (normalization.py:83-151)."""
+
+    def __init__(self, config_text: str, norm_nc: int, label_nc: int, pono: bool):
+        super().__init__()
+        m = re.search(r"spade(\D+)(\d)x\d", config_text)
+        if m is None:
+            raise ValueError(f"bad SPADE config {config_text!r}")
+        ks = int(m.group(2))
+        self.pono = bool(pono)
+        if not self.pono:
+            self.param_free_norm = _param_free_norm(m.group(1), norm_nc)
+        hidden = 128
+        self.mlp_shared = nn.Sequential(nn.ReflectionPad2d(ks // 2),
+                                        nn.Conv2d(label_nc, hidden, ks), nn.ReLU())
+        self.pad = nn.ReflectionPad2d(ks // 2)
+        self.mlp_gamma = nn.Conv2d(hidden, norm_nc, ks)
+        self.mlp_beta = nn.Conv2d(hidden, norm_nc, ks)
+
+    def forward(self, x, segmap):
+        xn = positional_norm(x) if self.pono else self.param_free_norm(x)
+        seg = F.interpolate(segmap, size=x.shape[2:], mode="nearest")
+        a = self.pad(self.mlp_shared(seg))
+        return xn * (1 + self.mlp_gamma(a)) + self.mlp_beta(a)
+
+
+class SELayer(nn.Module):
+    """Squeeze-and-excitation (architecture.py:183-198), only with --adaptor_se."""
+
+    def __init__(self, channel, reduction=16):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Sequential(nn.Linear(channel, channel // reduction, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(channel // reduction, channel, bias=False), nn.Sigmoid())
+
+    def forward(self, x):
+        w = self.fc(self.avg_pool(x).flatten(1))
+        return x * w[:, :, None, None]
+
+
+class Attention(nn.Module):
+    """Non-local block (architecture.py:97-127), only with --adaptor_nonlocal."""
+
+    def __init__(self, ch, use_sn):
+        super().__init__()
+        self.ch = ch
+        wrap = spectral_norm if use_sn else (lambda m: m)
+        self.theta = wrap(nn.Conv2d(ch, ch // 8, 1, bias=False))
+        self.phi = wrap(nn.Conv2d(ch, ch // 8, 1, bias=False))
+        self.g = wrap(nn.Conv2d(ch, ch // 2, 1, bias=False))
+        self.o = wrap(nn.Conv2d(ch // 2, ch, 1, bias=False))
+        self.gamma = nn.Parameter(torch.tensor(0.0), requires_grad=True)
+
+    def forward(self, x, y=None):
+        B, _, H, W = x.shape
+        theta = self.theta(x).view(B, self.ch // 8, H * W)
+        phi = F.max_pool2d(self.phi(x), [2, 2]).view(B, self.ch // 8, H * W // 4)
+        g = F.max_pool2d(self.g(x), [2, 2]).view(B, self.ch // 2, H * W // 4)
+        beta = F.softmax(torch.bmm(theta.transpose(1, 2), phi), -1)
+        o = self.o(torch.bmm(g, beta.transpose(1, 2)).view(B, self.ch // 2, H, W))
+        return self.gamma * o + x
+
+
+def _spade_label_nc(opt):
+    if "spade_ic" in opt:
+        return opt.spade_ic
+    t = opt.CBN_intype
+    return (3 if "warp" in t else 0) + (opt.semantic_nc if "mask" in t else 0)
+
+
+class SPADEResnetBlock(nn.Module):
+    """Pre-activation residual block with SPADE norms and reflection-padded 3x3 convs
+    (architecture.py:19-95)."""
+
+    def __init__(self, fin, fout, opt, use_se=False, dilation=1):
+        super().__init__()
+        self.learned_shortcut = fin != fout
+        fmid = min(fin, fout)
+        self.use_se = use_se
+        self.pad = nn.ReflectionPad2d(dilation)
+        self.conv_0 = nn.Conv2d(fin, fmid, 3, padding=0, dilation=dilation)
+        self.conv_1 = nn.Conv2d(fmid, fout, 3, padding=0, dilation=dilation)
+        if self.learned_shortcut:
+            self.conv_s = nn.Conv2d(fin, fout, 1, bias=False)
+        if "spectral" in opt.norm_G:
+            self.conv_0 = spectral_norm(self.conv_0)
+            self.conv_1 = spectral_norm(self.conv_1)
+            if self.learned_shortcut:
+                self.conv_s = spectral_norm(self.conv_s)
+        cfg = opt.norm_G.replace("spectral", "")
+        ic = _spade_label_nc(opt)
+        self.norm_0 = SPADE(cfg, fin, ic, opt.PONO)
+        self.norm_1 = SPADE(cfg, fmid, ic, opt.PONO)
+        if self.learned_shortcut:
+            self.norm_s = SPADE(cfg, fin, ic, opt.PONO)
+        if use_se:
+            self.se_layar = SELayer(fout)   # (sic) the reference's attribute name, kept for checkpoints
+
+    def forward(self, x, seg):
+        x_s = self.conv_s(self.norm_s(x, seg)) if self.learned_shortcut else x
+        dx = self.conv_0(self.pad(F.leaky_relu(self.norm_0(x, seg), 0.2)))
+        dx = self.conv_1(self.pad(F.leaky_relu(self.norm_1(dx, seg), 0.2)))
+        if self.use_se:
+            dx = self.se_layar(dx)
+        return x_s + dx
+
+
+def nonspade_norm_layer(opt, norm_type):
+    """`get_nonspade_norm_layer` (normalization.py:21-61): spectral norm on the conv, then an
+    optional instance / batch / sync-batch norm (which also drops the now-useless conv bias)."""
+    if getattr(opt, "eqlr_sn", False):
+        raise NotImplementedError("--eqlr_sn (EqualLR) is not supported by the MI355X drop-in")
+    if getattr(opt, "apex", False):
+        raise NotImplementedError("--apex is not supported (no apex on ROCm here)")
+
+    def wrap(layer):
+        sub = norm_type
+        if norm_type.startswith("spectral"):
+            layer = spectral_norm(layer)
+            sub = norm_type[len("spectral"):]
+        if sub in ("none", ""):
+            return layer
+        if getattr(layer, "bias", None) is not None:
+            delattr(layer, "bias")
+            layer.register_parameter("bias", None)
+        ch = layer.out_channels
+        if sub == "batch":
+            norm = nn.BatchNorm2d(ch, affine=True)
+        elif sub == "sync_batch":
+            norm = nn.SyncBatchNorm(ch, affine=True)
+        elif sub == "instance":
+            norm = nn.InstanceNorm2d(ch, affine=False)
+        else:
+            raise ValueError(f"normalization layer {sub} is not recognized")
+        return nn.Sequential(layer, norm)
+    return wrap
+
+
+class AdaptiveFeatureGenerator(nn.Module):
+    """Domain adaptor: 5 strided convs + 3 SPADE residual blocks -> [B, 4*ngf, H/down, W/down]
+    (generator.py:91-160).  Reads opt.spade_ic, which NoVGGCorrespondence sets around construction."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        nf = opt.ngf
+        wrap = nonspade_norm_layer(opt, opt.norm_E)
+        ak = opt.adaptor_kernel
+        self.layer1 = wrap(nn.Conv2d(opt.spade_ic, nf, 3, stride=1, padding=1))
+        self.layer2 = wrap(nn.Conv2d(nf, nf * 2, ak, stride=2, padding=1))
+        self.layer3 = wrap(nn.Conv2d(nf * 2, nf * 4, 3, stride=1, padding=1))
+        if opt.warp_stride == 2:
+            self.layer4 = wrap(nn.Conv2d(nf * 4, nf * 8, 3, stride=1, padding=1))
+        else:
+            self.layer4 = wrap(nn.Conv2d(nf * 4, nf * 8, ak, stride=2, padding=1))
+        self.layer5 = wrap(nn.Conv2d(nf * 8, nf * 8, 3, stride=1, padding=1))
+        self.actvn = nn.LeakyReLU(0.2, False)
+        self.head_0 = SPADEResnetBlock(8 * nf, 8 * nf, opt, use_se=opt.adaptor_se)
+        if opt.adaptor_nonlocal:
+            self.attn = Attention(8 * nf, False)
+        self.G_middle_0 = SPADEResnetBlock(8 * nf, 8 * nf, opt, use_se=opt.adaptor_se)
+        self.G_middle_1 = SPADEResnetBlock(8 * nf, 4 * nf, opt, use_se=opt.adaptor_se)
+        if opt.adaptor_res_deeper:
+            self.deeper0 = SPADEResnetBlock(4 * nf, 4 * nf, opt)
+            if opt.dilation_conv:
+                self.deeper1 = SPADEResnetBlock(4 * nf, 4 * nf, opt, dilation=2)
+                self.deeper2 = SPADEResnetBlock(4 * nf, 4 * nf, opt, dilation=4)
+                self.degridding0 = wrap(nn.Conv2d(nf * 4, nf * 4, 3, stride=1, padding=2, dilation=2))
+                self.degridding1 = wrap(nn.Conv2d(nf * 4, nf * 4, 3, stride=1, padding=1))
+            else:
+                self.deeper1 = SPADEResnetBlock(4 * nf, 4 * nf, opt)
+                self.deeper2 = SPADEResnetBlock(4 * nf, 4 * nf, opt)
+
+    def forward(self, x, seg):
+        x = self.layer1(x)
+        for layer in (self.layer2, self.layer3, self.layer4, self.layer5):
+            x = layer(self.actvn(x))
+        x = self.head_0(x, seg)
+        if self.opt.adaptor_nonlocal:
+            x = self.attn(x)
+        x = self.G_middle_1(self.G_middle_0(x, seg), seg)
+        if self.opt.adaptor_res_deeper:
+            x = self.deeper2(self.deeper1(self.deeper0(x, seg), seg), seg)
+            if self.opt.dilation_conv:
+                x = self.degridding1(self.degridding0(x))
+        return x
+
+
+class ResidualBlock(nn.Module):
+    """reflect-pad -> 3x3 conv -> InstanceNorm -> PReLU, twice, with a skip and ONE shared PReLU
+    (correspondence.py:13-36)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, stride=1):
+        super().__init__()
+        self.padding1 = nn.ReflectionPad2d(padding)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size, padding=0, stride=stride)
+        self.bn1 = nn.InstanceNorm2d(out_channels)
+        self.prelu = nn.PReLU()
+        self.padding2 = nn.ReflectionPad2d(padding)
+        self.conv2 = nn.Conv2d(in_channels, out_channels, kernel_size, padding=0, stride=stride)
+        self.bn2 = nn.InstanceNorm2d(out_channels)
+
+    def forward(self, x):
+        y = self.prelu(self.bn1(self.conv1(self.padding1(x))))
+        y = self.bn2(self.conv2(self.padding2(y)))
+        return self.prelu(y + x)
