@@ -248,3 +248,66 @@ def test_column_softmax_is_the_swapped_call(full_inputs):
     f = co.correlation(q1.double().cpu().numpy(), k1.double().cpu().numpy()) * 100.0
     ref = np.matmul(co.softmax(f.transpose(0, 2, 1)), x.double().cpu().numpy().transpose(0, 2, 1))
     assert rel(got, ref.transpose(0, 2, 1)) < OUT_TOL
+
+
+# ------------------------------------------------------------------ the drop-in module, end to end
+@pytest.mark.parametrize("flags,extra_keys", [
+    (dict(semantic_nc=6, match_kernel=1, maskmix=True, PONO=True, PONO_C=True,
+          warp_mask_losstype="direct"), {"warp_mask"}),
+    (dict(semantic_nc=4, match_kernel=3, maskmix=True, PONO=True, PONO_C=True,
+          warp_mask_losstype="direct"), {"warp_mask"}),
+    (dict(semantic_nc=5, match_kernel=1, maskmix=True, PONO=True, PONO_C=True, warp_bilinear=True,
+          adaptor_kernel=4, warp_cycle_w=1.0, two_cycle=True, isTrain=True, novgg_featpair=10.0),
+     {"warp_cycle", "warp_i2r", "warp_i2r2i", "loss_novgg_featpair"}),
+])
+def test_module_end_to_end(flags, extra_keys):
+    """NoVGGCorrespondence on the GPU: same dict keys/shapes as the reference, outputs equal to the
+    oracle applied to the module's own theta/phi projections, gradients reach the parameters."""
+    from cocosnet_amd import correspondence as cc
+    opt = cc.base_options(**flags)
+    torch.manual_seed(0)
+    net = cc.NoVGGCorrespondence(opt).to(DEV)
+    net.init_weights(opt.init_type, opt.init_variance)
+    net.eval()    # freezes spectral-norm power iteration so project() is repeatable
+    rs = np.random.RandomState(1)
+    size, nc = 64, flags["semantic_nc"]
+    img = rs.uniform(-1, 1, (2, 3, size, size)); real = rs.uniform(-1, 1, (2, 3, size, size))
+    lab = rs.randint(0, nc, (2, size // 8, size // 8)).repeat(8, 1).repeat(8, 2)
+    seg = (lab[:, None] == np.arange(nc)[None, :, None, None]).astype(np.float32)
+    ref_seg = seg[::-1].copy()
+    out = net(dev(img), dev(real), dev(seg), dev(ref_seg))
+    assert set(out) == {"warp_out"} | extra_keys
+    assert out["warp_out"].shape == (2, 3, size, size)
+    with torch.no_grad():
+        th, ph = net.project(dev(img), dev(real), dev(seg), dev(ref_seg))
+    oflags = dict(match_kernel=opt.match_kernel, PONO_C=opt.PONO_C, down=opt.down,
+                  warp_bilinear=opt.warp_bilinear, isTrain=opt.isTrain,
+                  warp_mask_losstype=opt.warp_mask_losstype, warp_cycle_w=opt.warp_cycle_w,
+                  two_cycle=opt.two_cycle)
+    ref = co.hot_path_forward(th.cpu().numpy(), ph.cpu().numpy(), img, real, seg, ref_seg,
+                              co.default_opt(**oflags))
+    for k, r in ref.items():
+        assert rel(out[k], r) < OUT_TOL, k
+    loss = sum(v.float().pow(2).sum() for v in out.values())
+    loss.backward()
+    for p in (net.theta.weight, net.phi.weight, net.layer[0].conv1.weight,
+              net.adaptive_model_img.layer1[0].weight_orig):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0
+
+
+def test_module_return_corr_and_wta_and_detach():
+    from cocosnet_amd import correspondence as cc
+    opt = cc.base_options(semantic_nc=3, match_kernel=1, maskmix=True, PONO=True, PONO_C=True)
+    torch.manual_seed(0)
+    net = cc.NoVGGCorrespondence(opt).to(DEV).eval()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    img = torch.rand(1, 3, 32, 32, device=DEV, generator=g) * 2 - 1
+    seg = torch.zeros(1, 3, 32, 32, device=DEV); seg[:, 1] = 1
+    corr = net(img, img, seg, seg, return_corr=True)
+    assert torch.is_tensor(corr) and corr.shape == (1, 64, 64)
+    assert float(corr.abs().max()) <= 100.0 * (1 + 1e-5)        # cosine / 0.01
+    o = net(img, img, seg, seg, WTA_scale_weight=0.5)
+    assert set(o) == {"warp_out"}
+    o = net(img, img, seg, seg, detach_flag=True)
+    o["warp_out"].sum().backward()
+    assert net.theta.weight.grad is None or float(net.theta.weight.grad.abs().max()) == 0.0

@@ -1,0 +1,112 @@
+"""CPU checks of the drop-in NoVGGCorrespondence module: checkpoint compatibility (state_dict names
+and shapes equal the reference's), the feature producers against the reference's own code (only
+where /root/reference exists, i.e. in the build container), and injection into the reference's
+`networks.define_Corr`.  The hot path itself needs a GPU and is covered by test_gpu_parity.py."""
+import argparse
+import json
+import os
+
+import pytest
+import torch
+
+from cocosnet_amd import correspondence as cc
+from oracle import ref_harness as rh
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "netcorr_state_dict_keys.json")
+needs_ref = pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present")
+
+
+def _opt(flags):
+    return cc.base_options(**flags)
+
+
+@pytest.mark.parametrize("name", ["ade20k", "celebahq_edge", "deepfashion", "no_pono_syncbn",
+                                  "all_adaptor_options"])
+def test_state_dict_names_and_shapes_equal_the_reference(name):
+    rec = json.load(open(GOLDEN))[name]
+    net = cc.NoVGGCorrespondence(_opt(rec["flags"]))
+    mine = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert mine == rec["state_dict"]
+
+
+def test_constructor_side_effects_on_opt():
+    opt = _opt(dict(semantic_nc=5, maskmix=True, PONO=True, warp_stride=2))
+    assert "down" not in opt
+    cc.NoVGGCorrespondence(opt)
+    assert opt.down == 2 and "spade_ic" not in opt
+    opt = _opt(dict(semantic_nc=5, PONO=True))
+    cc.NoVGGCorrespondence(opt)
+    assert opt.down == 4
+
+
+def test_unsupported_flags_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        cc.NoVGGCorrespondence(_opt(dict(semantic_nc=5, PONO=True, eqlr_sn=True)))
+    with pytest.raises(NotImplementedError):
+        cc.NoVGGCorrespondence(_opt(dict(semantic_nc=5, PONO=True, weight_domainC=1.0)))
+
+
+def test_forward_without_gpu_raises_instead_of_falling_back():
+    from cocosnet_amd._lib import CocosHipError
+    opt = _opt(dict(semantic_nc=4, maskmix=True, PONO=True, PONO_C=True, match_kernel=1, ngf=64))
+    net = cc.NoVGGCorrespondence(opt).eval()
+    x = torch.rand(1, 3, 32, 32) * 2 - 1
+    seg = torch.zeros(1, 4, 32, 32); seg[:, 0] = 1
+    with torch.no_grad(), pytest.raises(CocosHipError, match="no CPU fallback"):
+        net(x, x, seg, seg)
+
+
+def test_hot_path_config_from_opt():
+    from cocosnet_amd.hot_path import HotPathConfig
+    opt = cc.celebahq_edge_options(warp_cycle_w=1.0, two_cycle=True, isTrain=True)
+    cfg = HotPathConfig.from_opt(opt, down=4)
+    assert (cfg.match_kernel, cfg.PONO_C, cfg.warp_bilinear, cfg.warp_cycle_w, cfg.two_cycle) == \
+        (3, True, True, 1.0, True)
+    assert HotPathConfig.from_opt(argparse.Namespace()).down == 4
+
+
+@needs_ref
+@pytest.mark.parametrize("flags", [
+    dict(semantic_nc=6, maskmix=True, PONO=True, PONO_C=True, match_kernel=1),
+    dict(semantic_nc=4, maskmix=False, PONO=True, PONO_C=True, adaptor_kernel=4, warp_bilinear=True),
+    dict(semantic_nc=5, maskmix=True, PONO=False, use_coordconv=True, adaptor_se=True,
+         adaptor_nonlocal=True, adaptor_res_deeper=True, dilation_conv=True, warp_stride=2),
+])
+def test_producers_match_the_reference_code(flags):
+    """Load the reference's weights into the drop-in and compare theta_raw / phi_raw (the inputs of
+    the hot path) computed by both on CPU."""
+    ref = rh.build_reference_corr(rh.make_opt(**flags), seed=3).eval()
+    mine = cc.NoVGGCorrespondence(_opt(flags)).eval()
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(0)
+    size = 32
+    img = torch.rand(2, 3, size, size, generator=g) * 2 - 1
+    lab = torch.randint(0, flags["semantic_nc"], (2, 1, size, size), generator=g)
+    seg = torch.zeros(2, flags["semantic_nc"], size, size).scatter_(1, lab, 1.0)
+    ref_seg = seg.flip(0)
+    got = {}
+    hooks = [ref.theta.register_forward_hook(lambda m, i, o: got.__setitem__("theta", o.detach())),
+             ref.phi.register_forward_hook(lambda m, i, o: got.__setitem__("phi", o.detach()))]
+    with torch.no_grad():
+        ref(img, img, seg, ref_seg)
+        th, ph = mine.project(img, img, seg, ref_seg)
+    for h in hooks:
+        h.remove()
+    for a, b in ((th, got["theta"]), (ph, got["phi"])):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-5
+
+
+@needs_ref
+def test_install_into_reference_define_corr():
+    """The unmodified reference factory builds OUR class once it is injected."""
+    networks = rh.load_reference()
+    ref_corr = __import__("importlib").import_module("models.networks.correspondence")
+    original = ref_corr.NoVGGCorrespondence
+    try:
+        cls = cc.install_into_reference(networks)
+        net = rh.build_reference_corr(rh.make_opt(semantic_nc=5, match_kernel=1))
+        assert isinstance(net, cls) and isinstance(net, cc.NoVGGCorrespondence)
+        assert isinstance(net, networks.BaseNetwork)
+    finally:
+        ref_corr.NoVGGCorrespondence = original
