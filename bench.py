@@ -185,10 +185,11 @@ def main():
         cv = 3 + SEM_NC
         B = BATCH_PER_GPU
         # algorithmic FLOPs per launch (no recompute counted): forward 2*HW^2*(K+Cv),
-        # backward 2*HW^2*(2K+Cv) split as dq: 2*HW^2*(K+Cv) [dP + dq], dkv: 2*HW^2*K [dk]
+        # backward 2*HW^2*(2K+Cv) split as query side 2*HW^2*(K+Cv) [dP + dqn], key side 2*HW^2*K [dkn]
         alg = {"corr_softmax_warp_fwd": 2.0 * N * N * (KDIM + cv) * B,
-               "corr_softmax_warp_bwd_dq": 2.0 * N * N * (KDIM + cv) * B,
-               "corr_softmax_warp_bwd_dkv": 2.0 * N * N * KDIM * B}
+               "corr_softmax_warp_bwd_query": 2.0 * N * N * (KDIM + cv) * B,
+               "corr_softmax_warp_bwd_key_from_ds": 2.0 * N * N * KDIM * B,
+               "corr_softmax_warp_bwd_key": 2.0 * N * N * KDIM * B}
         kernels = {}
         for tag, flops in alg.items():
             if tag in kern:

@@ -19,6 +19,18 @@
 // resident-side gradients accumulate in registers with no atomics; two kernels, deterministic.
 #include "common.h"
 
+// sched_group_barrier pins (per loop, so they can be ablated at compile time)
+#ifndef COCOS_SGB_S
+#define COCOS_SGB_S 1
+#endif
+#ifndef COCOS_SGB_DP
+#define COCOS_SGB_DP 1
+#endif
+#ifndef COCOS_SGB_DX
+#define COCOS_SGB_DX 1
+#endif
+#define SGB(en, mask, n) do { if (en) __builtin_amdgcn_sched_group_barrier(mask, n, 0); } while (0)
+
 namespace cocos {
 
 constexpr int BWD_BR = 128;   // resident positions per workgroup
@@ -38,7 +50,7 @@ __global__ __launch_bounds__(256) void corr_bwd_prep_kernel(const float* __restr
     dvec[(size_t)b * Nq + i] = acc;
 }
 
-template <int KD, int CVB, bool STATS_RESIDENT, bool WITH_DC>
+template <int KD, int CVB, bool STATS_RESIDENT, bool WITH_DC, bool STORE_DS>
 __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
     const float* __restrict__ xr,    // resident X [B,KD,R]
     const float* __restrict__ cr,    // resident C [B,Cv,R]   (dq: dout, dkv: v)
@@ -48,6 +60,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
     const float* __restrict__ dvec,  // [B,Nq]
     float* __restrict__ dxr,         // out [B,KD,R]
     float* __restrict__ dcr,         // out [B,Cv,R] (WITH_DC)
+    float* __restrict__ dst,         // out [B,S,R]  (STORE_DS): dS^T / T, streamed-major
     int B, int R, int S, int Cv, float scale_log2, float inv_t) {
     constexpr int CVP = CVB * 32;
     constexpr int KB = KD / 32;
@@ -82,6 +95,9 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
 #pragma unroll
         for (int kk = 0; kk < KD / 2; ++kk)
             xreg[kk] = buf_load1(xr_rs, off + (unsigned)(2 * kk * R) * 4u);
+        // resident operand lives in the accumulator half of the register file (see the forward)
+#pragma unroll
+        for (int kk = 0; kk < KD / 2; ++kk) asm volatile("" : "+a"(xreg[kk]));
     }
     for (int idx = tid; idx < CVP * BWD_BR; idx += 256) {
         const int ch = idx >> 7, p = idx & 127;
@@ -140,21 +156,70 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
         if (t + 1 < ntiles) fetch(s0 + kTileCols);
 
         // ---- logits tile [streamed x resident] (recompute) ------------------------------------
+        // LDS operands are requested one batch ahead of the MFMAs that consume them and the
+        // interleave is pinned with sched_group_barrier (see the forward kernel for the why).
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        {
+            constexpr int NB = 8, NBATCH = KD / 2 / NB;
+            const float* xl = xt + h * BWD_LD + c;
+            float a[2][NB];
 #pragma unroll
-        for (int kk = 0; kk < KD / 2; ++kk)
-            s = mfma32(xt[(2 * kk + h) * BWD_LD + c], xreg[kk], s);
+            for (int u = 0; u < NB; ++u) a[0][u] = xl[(2 * u) * BWD_LD];
+            SGB(COCOS_SGB_S, 0x100, NB / 2);
+#pragma unroll
+            for (int bt = 0; bt < NBATCH; ++bt) {
+                if (bt + 1 < NBATCH) {
+#pragma unroll
+                    for (int u = 0; u < NB; ++u)
+                        a[(bt + 1) & 1][u] = xl[(2 * ((bt + 1) * NB + u)) * BWD_LD];
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) s = mfma32(a[bt & 1][u], xreg[bt * NB + u], s);
+#pragma unroll
+                for (int u = 0; u < NB / 2; ++u) {
+                    SGB(COCOS_SGB_S, 0x008, 2);
+                    SGB(COCOS_SGB_S, 0x100, 1);
+                }
+                if (COCOS_SGB_S) __builtin_amdgcn_sched_barrier(0);   // one region per batch
+            }
+        }
 
         // ---- dP tile = C_streamed^T . C_resident ------------------------------------------------
         f32x16 dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+        {
+            constexpr int NB = 4, NBATCH = CVP / 2 / NB;
+            const float* cl = ct + h * BWD_LD + c;
+            const float* rl = crs + h * BWD_BR + wave * 32 + c;
+            float a[2][NB], bb[2][NB];
 #pragma unroll
-        for (int cc = 0; cc < CVP / 2; ++cc)
-            dp = mfma32(ct[(2 * cc + h) * BWD_LD + c], crs[(2 * cc + h) * BWD_BR + wave * 32 + c],
-                        dp);
+            for (int u = 0; u < NB; ++u) {
+                a[0][u] = cl[(2 * u) * BWD_LD];
+                bb[0][u] = rl[(2 * u) * BWD_BR];
+            }
+            SGB(COCOS_SGB_DP, 0x100, NB + NB / 2);
+#pragma unroll
+            for (int bt = 0; bt < NBATCH; ++bt) {
+                if (bt + 1 < NBATCH) {
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        a[(bt + 1) & 1][u] = cl[(2 * ((bt + 1) * NB + u)) * BWD_LD];
+                        bb[(bt + 1) & 1][u] = rl[(2 * ((bt + 1) * NB + u)) * BWD_BR];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) dp = mfma32(a[bt & 1][u], bb[bt & 1][u], dp);
+#pragma unroll
+                for (int u = 0; u < NB / 2; ++u) {
+                    SGB(COCOS_SGB_DP, 0x008, 2);
+                    SGB(COCOS_SGB_DP, 0x100, 3);
+                }
+                if (COCOS_SGB_DP) __builtin_amdgcn_sched_barrier(0);   // one region per batch
+            }
+        }
 
         // ---- P = exp(S/T - lse),  dS = P * (dP - D) ---------------------------------------------
         const bool ragged = STATS_RESIDENT && (s0 + kTileCols > S);
@@ -170,17 +235,51 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
             s[r] = pv * (dp[r] - dd);                 // s now holds dS
         }
 
+        // ---- dS^T / T to HBM for the other side's GEMM (dq side only) -----------------------------
+        if (STORE_DS) {
+            float* d_b = dst + (size_t)b * S * R;
+            if (r_lane < R) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int sp = s0 + acc_row_base(r) + 4 * h;
+                    if (sp < S) d_b[(size_t)sp * R + r_lane] = s[r] * inv_t;
+                }
+            }
+        }
+
         // ---- resident-side gradients ------------------------------------------------------------
+        {
+            const float* xl = xt + c * BWD_LD + 4 * h;
+            const float* cl = ct + c * BWD_LD + 4 * h;
+            constexpr int NC = WITH_DC ? CVB : 0;
+            float xa[2][KB], ca[2][NC > 0 ? NC : 1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int sl = acc_row_base(r) + 4 * h;
+            for (int kb = 0; kb < KB; ++kb) xa[0][kb] = xl[kb * 32 * BWD_LD + acc_row_base(0)];
 #pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-                dx[kb] = mfma32(xt[(kb * 32 + c) * BWD_LD + sl], s[r], dx[kb]);
-            if (WITH_DC) {
+            for (int cb = 0; cb < NC; ++cb) ca[0][cb] = cl[cb * 32 * BWD_LD + acc_row_base(0)];
+            if (COCOS_SGB_DX) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int cb = 0; cb < CVB; ++cb)
-                    dc[cb] = mfma32(ct[(cb * 32 + c) * BWD_LD + sl], p[r], dc[cb]);
+            for (int r = 0; r < 16; ++r) {
+                if (r + 1 < 16) {
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb)
+                        xa[(r + 1) & 1][kb] = xl[kb * 32 * BWD_LD + acc_row_base(r + 1)];
+#pragma unroll
+                    for (int cb = 0; cb < NC; ++cb)
+                        ca[(r + 1) & 1][cb] = cl[cb * 32 * BWD_LD + acc_row_base(r + 1)];
+                }
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) dx[kb] = mfma32(xa[r & 1][kb], s[r], dx[kb]);
+#pragma unroll
+                for (int cb = 0; cb < NC; ++cb) dc[cb] = mfma32(ca[r & 1][cb], p[r], dc[cb]);
+                // coarse pin (a 1:1 MFMA/read pattern over these 16 x (KB+NC) pairs sends hipcc's
+                // group solver into minutes of compile time): half of this step's MFMAs, then ALL
+                // reads of the next step, then the other half -> every read leads its use by >= 4 MFMAs
+                SGB(COCOS_SGB_DX, 0x008, (KB + NC) / 2);
+                SGB(COCOS_SGB_DX, 0x100, KB + NC);
+                SGB(COCOS_SGB_DX, 0x008, (KB + NC) - (KB + NC) / 2);
+                // one scheduling region per step keeps the group solver's work linear
+                if (COCOS_SGB_DX) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -208,48 +307,124 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
     }
 }
 
-template <int KD, int CVB, bool STATS_RESIDENT, bool WITH_DC>
+template <int KD, int CVB, bool STATS_RESIDENT, bool WITH_DC, bool STORE_DS>
 static int launch_bwd_side(const float* xr, const float* cr, const float* xs, const float* cs,
-                           const float* lse, const float* dvec, float* dxr, float* dcr, int B,
-                           int R, int S, int Cv, float inv_t, hipStream_t stream) {
-    auto kern = corr_bwd_kernel<KD, CVB, STATS_RESIDENT, WITH_DC>;
+                           const float* lse, const float* dvec, float* dxr, float* dcr, float* dst,
+                           int B, int R, int S, int Cv, float inv_t, hipStream_t stream) {
+    auto kern = corr_bwd_kernel<KD, CVB, STATS_RESIDENT, WITH_DC, STORE_DS>;
     const size_t smem =
         ((size_t)(KD + CVB * 32) * BWD_LD + (size_t)CVB * 32 * BWD_BR + 64) * sizeof(float);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int nrb = (R + BWD_BR - 1) / BWD_BR;
     hipLaunchKernelGGL(kern, dim3(B * nrb), dim3(256), smem, stream, xr, cr, xs, cs, lse, dvec,
-                       dxr, dcr, B, R, S, Cv, inv_t * kLog2e, inv_t);
+                       dxr, dcr, dst, B, R, S, Cv, inv_t * kLog2e, inv_t);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
 
+// Strategy for the key side.  Recomputing the logits a second time (flash-style dkv kernel) costs
+// 2*HW^2*(K+Cv) extra fp32-MFMA FLOPs; on MI355X fp32 MFMA is only ~25 FLOP per HBM byte, so it is
+// cheaper to let the query-side kernel write dS^T/T once (4 bytes per logit) and get dkn from a
+// plain GEMM  dkn = qn . dS  that reads it back.  dv still needs P, which only the recompute
+// kernel has.
+int sgemm_dkn_from_ds(const float* qn, const float* dst, float* dkn, int B, int K, int Nq, int Nk,
+                      hipStream_t s);
+
 template <int CVB>
-static int launch_bwd(const float* qn, const float* kn, const float* v, const float* lse,
-                      const float* dout, const float* dvec, float* dqn, float* dkn, float* dv,
-                      int B, int Nq, int Nk, int Cv, float inv_t, hipStream_t s) {
-    int rc = COCOS_OK;
-    if (dqn) {
-        rc = launch_bwd_side<256, CVB, true, false>(qn, dout, kn, v, lse, dvec, dqn, nullptr, B,
-                                                    Nq, Nk, Cv, inv_t, s);
-        if (rc != COCOS_OK) return rc;
+static int launch_query_side(const float* qn, const float* kn, const float* v, const float* lse,
+                             const float* dout, const float* dvec, float* dqn, float* dst, int B,
+                             int Nq, int Nk, int Cv, float inv_t, hipStream_t s) {
+    return dst ? launch_bwd_side<256, CVB, true, false, true>(qn, dout, kn, v, lse, dvec, dqn, nullptr,
+                                                              dst, B, Nq, Nk, Cv, inv_t, s)
+               : launch_bwd_side<256, CVB, true, false, false>(qn, dout, kn, v, lse, dvec, dqn,
+                                                               nullptr, nullptr, B, Nq, Nk, Cv, inv_t, s);
+}
+
+template <int CVB>
+static int launch_key_side(const float* qn, const float* kn, const float* v, const float* lse,
+                           const float* dout, const float* dvec, float* dkn, float* dv, int B, int Nq,
+                           int Nk, int Cv, float inv_t, hipStream_t s) {
+    return dv ? launch_bwd_side<256, CVB, false, true, false>(kn, v, qn, dout, lse, dvec, dkn, dv,
+                                                              nullptr, B, Nk, Nq, Cv, inv_t, s)
+              : launch_bwd_side<256, CVB, false, false, false>(kn, v, qn, dout, lse, dvec, dkn, nullptr,
+                                                               nullptr, B, Nk, Nq, Cv, inv_t, s);
+}
+
+#define COCOS_DISPATCH_CVB(cvb, FN, ...)                  \
+    switch (cvb) {                                        \
+        case 1: return FN<1>(__VA_ARGS__);                \
+        case 2: return FN<2>(__VA_ARGS__);                \
+        case 3: return FN<3>(__VA_ARGS__);                \
+        case 4: return FN<4>(__VA_ARGS__);                \
+        default: return FN<5>(__VA_ARGS__);               \
     }
-    if (dv) {
-        rc = launch_bwd_side<256, CVB, false, true>(kn, v, qn, dout, lse, dvec, dkn, dv, B, Nk,
-                                                    Nq, Cv, inv_t, s);
-    } else if (dkn) {
-        rc = launch_bwd_side<256, CVB, false, false>(kn, v, qn, dout, lse, dvec, dkn, nullptr, B,
-                                                     Nk, Nq, Cv, inv_t, s);
-    }
-    return rc;
+
+static int check_dims(const char* who, int B, int K, int Nq, int Nk, int Cv) {
+    COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && B <= 65535, COCOS_ERR_INVALID,
+                  "%s: bad dims B=%d Nq=%d Nk=%d Cv=%d", who, B, Nq, Nk, Cv);
+    COCOS_REQUIRE(K == 256, COCOS_ERR_UNSUPPORTED, "%s: fused path needs K == 256 (got %d)", who, K);
+    COCOS_REQUIRE(Cv <= 160, COCOS_ERR_UNSUPPORTED, "%s: Cv=%d > 160", who, Cv);
+    COCOS_REQUIRE((size_t)K * Nq * 4 < 0x7fffffffull && (size_t)K * Nk * 4 < 0x7fffffffull,
+                  COCOS_ERR_UNSUPPORTED, "%s: per-sample tensor exceeds 2 GiB", who);
+    return COCOS_OK;
 }
 
 }  // namespace cocos
 
 extern "C" size_t cocos_corr_softmax_warp_bwd_workspace_bytes(int B, int K, int Nq, int Nk, int Cv) {
-    (void)K; (void)Nk; (void)Cv;
+    (void)K; (void)Cv; (void)Nk;
     if (B < 1 || Nq < 1) return 0;
     return (size_t)B * Nq * sizeof(float);   // D_i = sum_c dout*out
+}
+
+extern "C" int cocos_corr_softmax_warp_bwd_prepare(const float* out, const float* dout, float* dvec,
+                                                   int B, int Nq, int Cv, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(out && dout && dvec, COCOS_ERR_INVALID, "corr_softmax_warp_bwd_prepare: null pointer");
+    COCOS_REQUIRE(B >= 1 && Nq >= 1 && Cv >= 1 && B <= 65535, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_prepare: bad dims B=%d Nq=%d Cv=%d", B, Nq, Cv);
+    hipLaunchKernelGGL(corr_bwd_prep_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0,
+                       as_stream(stream), out, dout, dvec, Nq, Cv);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_corr_softmax_warp_bwd_query(const float* qn, const float* kn, const float* v,
+                                                 const float* lse, const float* dout,
+                                                 const float* dvec, float* dqn, float* ds_t, int B,
+                                                 int K, int Nq, int Nk, int Cv, float inv_temperature,
+                                                 cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(qn && kn && v && lse && dout && dvec && dqn, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_query: null pointer");
+    if (int rc = check_dims("corr_softmax_warp_bwd_query", B, K, Nq, Nk, Cv)) return rc;
+    COCOS_REQUIRE(!ds_t || (size_t)Nq * Nk * 4 < 0x7fffffffull, COCOS_ERR_UNSUPPORTED,
+                  "corr_softmax_warp_bwd_query: per-sample dS exceeds 2 GiB; pass ds_t = NULL");
+    COCOS_DISPATCH_CVB((Cv + 31) / 32, launch_query_side, qn, kn, v, lse, dout, dvec, dqn, ds_t, B,
+                       Nq, Nk, Cv, inv_temperature, as_stream(stream));
+}
+
+extern "C" int cocos_corr_softmax_warp_bwd_key(const float* qn, const float* kn, const float* v,
+                                               const float* lse, const float* dout, const float* dvec,
+                                               float* dkn, float* dv, int B, int K, int Nq, int Nk,
+                                               int Cv, float inv_temperature, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(qn && kn && v && lse && dout && dvec && dkn, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_key: null pointer");
+    if (int rc = check_dims("corr_softmax_warp_bwd_key", B, K, Nq, Nk, Cv)) return rc;
+    COCOS_DISPATCH_CVB((Cv + 31) / 32, launch_key_side, qn, kn, v, lse, dout, dvec, dkn, dv, B, Nq,
+                       Nk, Cv, inv_temperature, as_stream(stream));
+}
+
+extern "C" int cocos_corr_softmax_warp_bwd_key_from_ds(const float* qn, const float* ds_t, float* dkn,
+                                                       int B, int K, int Nq, int Nk,
+                                                       cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(qn && ds_t && dkn, COCOS_ERR_INVALID, "corr_softmax_warp_bwd_key_from_ds: null pointer");
+    COCOS_REQUIRE(B >= 1 && K >= 1 && Nq >= 1 && Nk >= 1, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_key_from_ds: bad dims B=%d K=%d Nq=%d Nk=%d", B, K, Nq, Nk);
+    return sgemm_dkn_from_ds(qn, ds_t, dkn, B, K, Nq, Nk, as_stream(stream));
 }
 
 extern "C" int cocos_corr_softmax_warp_bwd(const float* qn, const float* kn, const float* v,
@@ -260,29 +435,22 @@ extern "C" int cocos_corr_softmax_warp_bwd(const float* qn, const float* kn, con
     using namespace cocos;
     COCOS_REQUIRE(qn && kn && v && out && lse && dout, COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd: null input pointer");
-    COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && B <= 65535, COCOS_ERR_INVALID,
-                  "corr_softmax_warp_bwd: bad dims B=%d Nq=%d Nk=%d Cv=%d", B, Nq, Nk, Cv);
-    COCOS_REQUIRE(K == 256, COCOS_ERR_UNSUPPORTED,
-                  "corr_softmax_warp_bwd: fused path needs K == 256 (got %d)", K);
-    COCOS_REQUIRE(Cv <= 160, COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_bwd: Cv=%d > 160", Cv);
-    COCOS_REQUIRE((size_t)K * Nq * 4 < 0x7fffffffull && (size_t)K * Nk * 4 < 0x7fffffffull,
-                  COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_bwd: per-sample tensor exceeds 2 GiB");
+    if (int rc = check_dims("corr_softmax_warp_bwd", B, K, Nq, Nk, Cv)) return rc;
     COCOS_REQUIRE(!dv || dkn, COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd: dv requires dkn (they come out of the same kernel)");
     COCOS_REQUIRE(ws && ws_bytes >= cocos_corr_softmax_warp_bwd_workspace_bytes(B, K, Nq, Nk, Cv),
                   COCOS_ERR_WORKSPACE, "corr_softmax_warp_bwd: workspace too small (%zu bytes)",
                   ws_bytes);
-    hipStream_t s = as_stream(stream);
     float* dvec = static_cast<float*>(ws);
-    hipLaunchKernelGGL(corr_bwd_prep_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, s, out, dout,
-                       dvec, Nq, Cv);
-    COCOS_HIP_CHECK(hipGetLastError());
-    const int cvb = (Cv + 31) / 32;
-    switch (cvb) {
-        case 1: return launch_bwd<1>(qn, kn, v, lse, dout, dvec, dqn, dkn, dv, B, Nq, Nk, Cv, inv_temperature, s);
-        case 2: return launch_bwd<2>(qn, kn, v, lse, dout, dvec, dqn, dkn, dv, B, Nq, Nk, Cv, inv_temperature, s);
-        case 3: return launch_bwd<3>(qn, kn, v, lse, dout, dvec, dqn, dkn, dv, B, Nq, Nk, Cv, inv_temperature, s);
-        case 4: return launch_bwd<4>(qn, kn, v, lse, dout, dvec, dqn, dkn, dv, B, Nq, Nk, Cv, inv_temperature, s);
-        default: return launch_bwd<5>(qn, kn, v, lse, dout, dvec, dqn, dkn, dv, B, Nq, Nk, Cv, inv_temperature, s);
+    int rc = cocos_corr_softmax_warp_bwd_prepare(out, dout, dvec, B, Nq, Cv, stream);
+    if (rc != COCOS_OK) return rc;
+    if (dqn) {
+        rc = cocos_corr_softmax_warp_bwd_query(qn, kn, v, lse, dout, dvec, dqn, nullptr, B, K, Nq, Nk,
+                                               Cv, inv_temperature, stream);
+        if (rc != COCOS_OK) return rc;
     }
+    if (dkn)
+        rc = cocos_corr_softmax_warp_bwd_key(qn, kn, v, lse, dout, dvec, dkn, dv, B, K, Nq, Nk, Cv,
+                                             inv_temperature, stream);
+    return rc;
 }

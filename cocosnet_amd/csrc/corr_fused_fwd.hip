@@ -27,6 +27,7 @@ namespace cocos {
 constexpr int FWD_BQ = 128;          // query positions per workgroup
 constexpr int FWD_BK = kTileCols;    // key positions per tile
 constexpr int FWD_LD = kTileLd;      // LDS row stride (floats)
+constexpr float kRescaleThr = 8.0f;  // log2 units: rescale only when a row max grows by > 2^8
 
 template <int KD, int CVB>
 __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
@@ -61,6 +62,10 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
 #pragma unroll
         for (int kk = 0; kk < KD / 2; ++kk)
             qreg[kk] = buf_load1(q_rs, q_off + (unsigned)(2 * kk * Nq) * 4u);
+        // park the slice in the accumulator half of the register file (MFMA B operands may be
+        // AGPRs): frees 128 arch VGPRs so the LDS read-ahead below has registers to land in
+#pragma unroll
+        for (int kk = 0; kk < KD / 2; ++kk) asm volatile("" : "+a"(qreg[kk]));
     }
 
     f32x16 o[CVB];
@@ -95,12 +100,40 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
         if (t + 1 < ntiles) fetch(j0 + FWD_BK);   // in flight under the MFMAs below
 
         // ---- S^T tile: rows = keys (acc registers), cols = queries (lanes) -----------------
+        // A operands are read from LDS in batches of 8, one batch AHEAD of the MFMAs that consume
+        // them: with one read in flight per MFMA the ~100-cycle LDS latency would sit between every
+        // two dependent 64-cycle MFMAs (measured: 63 % of peak); batched, it is covered.
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        {
+            constexpr int NB = 8, NBATCH = KD / 2 / NB;
+            const float* kl = kt + h * FWD_LD + c;
+            float a[2][NB];
 #pragma unroll
-        for (int kk = 0; kk < KD / 2; ++kk)
-            s = mfma32(kt[(2 * kk + h) * FWD_LD + c], qreg[kk], s);
+            for (int u = 0; u < NB; ++u) a[0][u] = kl[(2 * u) * FWD_LD];
+            __builtin_amdgcn_sched_group_barrier(0x100, NB / 2, 0);   // lead: one batch of reads
+#pragma unroll
+            for (int bt = 0; bt < NBATCH; ++bt) {
+                if (bt + 1 < NBATCH) {
+#pragma unroll
+                    for (int u = 0; u < NB; ++u)
+                        a[(bt + 1) & 1][u] = kl[(2 * ((bt + 1) * NB + u)) * FWD_LD];
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) s = mfma32(a[bt & 1][u], qreg[bt * NB + u], s);
+                // pin the interleave: 2 MFMAs, then one LDS read of the NEXT batch (hipcc pairs the
+                // reads into ds_read2_b32), so every operand is requested >= 4 MFMAs before its use
+#pragma unroll
+                for (int u = 0; u < NB / 2; ++u) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                // one scheduling region per batch: hipcc's group solver is superlinear in the
+                // region size (minutes per kernel when a whole tile body is one region)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 
         // ---- online softmax over the key axis ---------------------------------------------
         float tmax = -INFINITY;
@@ -113,28 +146,54 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
             tmax = fmaxf(tmax, x);
         }
         tmax = fmaxf(tmax, swap_half(tmax));
-        const float m_new = fmaxf(m_run, tmax);   // finite: every tile holds >= 1 valid key
-        const float alpha = fast_exp2(m_run - m_new);
+        // Lazy rescale (guide T13): the running max only moves — and O, l are only rescaled —
+        // when some row's tile max exceeds it by more than 2^kRescaleThr.  O lives in AGPRs, so an
+        // unconditional rescale costs 2 register moves + 1 multiply per accumulator register per
+        // tile; with the threshold the branch is taken a handful of times per row.  p is then
+        // bounded by 2^kRescaleThr instead of 1, harmless in fp32.  The first tile always takes
+        // the branch (m_run = -inf), every tile holds >= 1 valid key so m_run becomes finite.
+        if (__any(tmax > m_run + kRescaleThr)) {
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = fast_exp2(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int cb = 0; cb < CVB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = fast_exp2(s[r] - m_new);
+            s[r] = fast_exp2(s[r] - m_run);
             psum += s[r];
         }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int cb = 0; cb < CVB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T += V^T . P^T : A = V^T[ch][key] from LDS, B = P^T (accumulator registers) --
+        // same read-ahead: the CVB operands of key-pair r+1 are fetched while pair r multiplies
+        {
+            const float* vl = vt + c * FWD_LD + 4 * h;
+            float va[2][CVB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int jj = acc_row_base(r) + 4 * h;
+            for (int cb = 0; cb < CVB; ++cb) va[0][cb] = vl[cb * 32 * FWD_LD + acc_row_base(0)];
+            __builtin_amdgcn_sched_group_barrier(0x100, CVB, 0);
 #pragma unroll
-            for (int cb = 0; cb < CVB; ++cb)
-                o[cb] = mfma32(vt[(cb * 32 + c) * FWD_LD + jj], s[r], o[cb]);
+            for (int r = 0; r < 16; ++r) {
+                if (r + 1 < 16) {
+#pragma unroll
+                    for (int cb = 0; cb < CVB; ++cb)
+                        va[(r + 1) & 1][cb] = vl[cb * 32 * FWD_LD + acc_row_base(r + 1)];
+                }
+#pragma unroll
+                for (int cb = 0; cb < CVB; ++cb) o[cb] = mfma32(va[r & 1][cb], s[r], o[cb]);
+#pragma unroll
+                for (int cb = 0; cb < CVB; ++cb) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 

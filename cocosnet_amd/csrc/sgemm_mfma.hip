@@ -18,11 +18,13 @@
 
 namespace cocos {
 
-constexpr int GM = 128, GN = 128, GK = 16;
+constexpr int GM = 128, GN = 128, GK = 32;
 constexpr int GLD = 132;   // LDS row stride: 16-byte aligned rows, 2-way at worst on transposing writes
 
+constexpr int GST = GK * 128 / 4 / 256;   // float4 per thread per operand slab
+
 struct GemmStage {
-    f32x4 r[2];
+    f32x4 r[GST];
 };
 
 // Fetch a [GK x 128] operand slab into registers.  `KC`: source is k-contiguous ([mn][k]).
@@ -30,10 +32,10 @@ template <bool KC, bool EDGE>
 __device__ __forceinline__ void gemm_fetch(GemmStage& st, __amdgpu_buffer_rsrc_t rs, int mn0,
                                            int k0, int MN, int K, int tid) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < GST; ++u) {
         const int idx = u * 256 + tid;
         int mn, k;
-        if (KC) { mn = mn0 + (idx >> 2); k = k0 + (idx & 3) * 4; }
+        if (KC) { mn = mn0 + idx / (GK / 4); k = k0 + (idx % (GK / 4)) * 4; }
         else    { k = k0 + (idx >> 5);  mn = mn0 + (idx & 31) * 4; }
         if (!EDGE) {
             const unsigned off = KC ? (unsigned)(mn * K + k) * 4u : (unsigned)(k * MN + mn) * 4u;
@@ -53,10 +55,10 @@ __device__ __forceinline__ void gemm_fetch(GemmStage& st, __amdgpu_buffer_rsrc_t
 template <bool KC>
 __device__ __forceinline__ void gemm_commit(const GemmStage& st, float* lds, int tid) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < GST; ++u) {
         const int idx = u * 256 + tid;
         if (KC) {
-            const int mn = idx >> 2, k = (idx & 3) * 4;
+            const int mn = idx / (GK / 4), k = (idx % (GK / 4)) * 4;
             lds[(k + 0) * GLD + mn] = st.r[u].x;
             lds[(k + 1) * GLD + mn] = st.r[u].y;
             lds[(k + 2) * GLD + mn] = st.r[u].z;
@@ -115,16 +117,27 @@ __global__ __launch_bounds__(256, 1) void sgemm_mfma_kernel(const float* __restr
         gemm_commit<B_KC>(sb, bt, tid);
         __syncthreads();
         if (t + 1 < nsteps) fetch((t + 1) * GK);
+        // operands of step kk+1 are requested while step kk multiplies (LDS latency ~100+ cycles
+        // would otherwise sit between the 64-cycle MFMAs); interleave pinned, one region per step
+        const float* al = at + h * GLD + wm * 64 + c;
+        const float* bl = bt + h * GLD + wn * 64 + c;
+        float av[2][2], bv[2][2];
+        av[0][0] = al[0]; av[0][1] = al[32]; bv[0][0] = bl[0]; bv[0][1] = bl[32];
 #pragma unroll
         for (int kk = 0; kk < GK / 2; ++kk) {
-            const float a0 = at[(2 * kk + h) * GLD + wm * 64 + c];
-            const float a1 = at[(2 * kk + h) * GLD + wm * 64 + 32 + c];
-            const float b0 = bt[(2 * kk + h) * GLD + wn * 64 + c];
-            const float b1 = bt[(2 * kk + h) * GLD + wn * 64 + 32 + c];
-            acc[0][0] = mfma32(a0, b0, acc[0][0]);
-            acc[0][1] = mfma32(a0, b1, acc[0][1]);
-            acc[1][0] = mfma32(a1, b0, acc[1][0]);
-            acc[1][1] = mfma32(a1, b1, acc[1][1]);
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < GK / 2) {
+                av[nxt][0] = al[(2 * kk + 2) * GLD]; av[nxt][1] = al[(2 * kk + 2) * GLD + 32];
+                bv[nxt][0] = bl[(2 * kk + 2) * GLD]; bv[nxt][1] = bl[(2 * kk + 2) * GLD + 32];
+            }
+            acc[0][0] = mfma32(av[cur][0], bv[cur][0], acc[0][0]);
+            acc[0][1] = mfma32(av[cur][0], bv[cur][1], acc[0][1]);
+            acc[1][0] = mfma32(av[cur][1], bv[cur][0], acc[1][0]);
+            acc[1][1] = mfma32(av[cur][1], bv[cur][1], acc[1][1]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -155,6 +168,13 @@ static int launch_gemm(const float* A, const float* Bm, float* C, int batch, int
                        (size_t)M * K, (size_t)N * K, (size_t)M * N, scale);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+// dkn[b,k,j] = sum_i qn[b,k,i] * dst[b,j,i]   (dst = dS^T / T written by the dq kernel)
+//   C[m=k][n=j], A = qn [m][kk=i] (k-contiguous), B = dst [n=j][kk=i] (k-contiguous)
+int sgemm_dkn_from_ds(const float* qn, const float* dst, float* dkn, int B, int K, int Nq, int Nk,
+                      hipStream_t s) {
+    return launch_gemm<true, true>(qn, dst, dkn, B, K, Nk, Nq, 1.0f, s);
 }
 
 }  // namespace cocos

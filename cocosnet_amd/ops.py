@@ -17,6 +17,9 @@ from . import _lib
 NORM_EPS = sys.float_info.epsilon
 #: widest V the fused kernel takes in one launch (5 blocks of 32 channels)
 MAX_FUSED_CV = 160
+#: largest dS^T scratch (bytes) the backward may allocate to replace the second logits recompute by
+#: a GEMM; above it (e.g. 128x128 grids at large batch) the flash-style key kernel is used
+MAX_DS_WORKSPACE_BYTES = 16 << 30
 #: channel count the fused kernels are specialised for (self.inter_channels, correspondence.py:170)
 FUSED_K = 256
 
@@ -148,20 +151,28 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         dqn = torch.empty_like(qn) if need_q else None
         dkn = torch.empty_like(kn) if (need_k or need_v) else None
         dv = torch.empty_like(v) if need_v else None
-        lib = _lib.load()
-        nbytes = lib.cocos_corr_softmax_warp_bwd_workspace_bytes(B, K, Nq, Nk, Cv)
-        ws = torch.empty((max(nbytes, 4) + 3) // 4, device=qn.device, dtype=torch.float32)
-        # two launches of the same entry point: the query side, then the key/value side — so that
-        # each kernel can be timed on its own (the C ABI skips a side whose output pointer is NULL)
-        common = (qn.data_ptr(), kn.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
-                  dout.data_ptr())
-        tail = (ws.data_ptr(), ws.numel() * 4, B, K, Nq, Nk, Cv, ctx.inv_t, _stream())
+        dvec = torch.empty((B, Nq), device=qn.device, dtype=torch.float32)
+        st = _stream()
+        _call("corr_softmax_warp_bwd_prepare", "cocos_corr_softmax_warp_bwd_prepare", out.data_ptr(),
+              dout.data_ptr(), dvec.data_ptr(), B, Nq, Cv, st)
+        common = (qn.data_ptr(), kn.data_ptr(), v.data_ptr(), lse.data_ptr(), dout.data_ptr(),
+                  dvec.data_ptr())
+        dims = (B, K, Nq, Nk, Cv, ctx.inv_t, st)
+        # key side: GEMM over a materialised dS^T when it pays and fits (see cocos_hip.h), else the
+        # flash-style kernel that recomputes the logits (always when dv is wanted: it needs P)
+        ds_bytes = B * Nq * Nk * 4
+        via_gemm = (dqn is not None and dkn is not None and dv is None
+                    and ds_bytes <= MAX_DS_WORKSPACE_BYTES and Nq * Nk * 4 < 2 ** 31 - 1)
+        ds_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if via_gemm else None
         if dqn is not None:
-            _call("corr_softmax_warp_bwd_dq", "cocos_corr_softmax_warp_bwd", *common, _ptr(dqn), 0,
-                  0, *tail)
-        if dkn is not None:
-            _call("corr_softmax_warp_bwd_dkv", "cocos_corr_softmax_warp_bwd", *common, 0, _ptr(dkn),
-                  _ptr(dv), *tail)
+            _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query", *common,
+                  _ptr(dqn), _ptr(ds_t), *dims)
+        if via_gemm:
+            _call("corr_softmax_warp_bwd_key_from_ds", "cocos_corr_softmax_warp_bwd_key_from_ds",
+                  qn.data_ptr(), ds_t.data_ptr(), dkn.data_ptr(), B, K, Nq, Nk, st)
+        elif dkn is not None:
+            _call("corr_softmax_warp_bwd_key", "cocos_corr_softmax_warp_bwd_key", *common, _ptr(dkn),
+                  _ptr(dv), *dims)
         return dqn, (dkn if need_k else None), dv, None
 
 

@@ -77,10 +77,33 @@ int cocos_corr_softmax_warp_fwd(const float* qn, const float* kn, const float* v
                                 int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
                                 cocos_stream_t stream);
 
-/* Backward of K2 (autograd of :291-318).  Recomputes logits tiles from qn/kn and `lse`.
- *   dout [B,Cv,Nq] -> dqn [B,K,Nq], dkn [B,K,Nk], dv [B,Cv,Nk] (dv may be NULL: not needed)
- *   ws: scratch of cocos_corr_softmax_warp_bwd_workspace_bytes() bytes. */
+/* Backward of K2 (autograd of :291-318), flash-style: the logits are recomputed from qn/kn and `lse`.
+ *   dout [B,Cv,Nq] -> dqn [B,K,Nq], dkn [B,K,Nk], dv [B,Cv,Nk]
+ * It is exposed in stages so that the caller picks the strategy for the key side:
+ *   prepare        dvec[b,i] = sum_c dout[b,c,i] * out[b,c,i]                      (always first)
+ *   query          dqn; optionally also writes ds_t [B,Nk,Nq] = (dS)^T / T
+ *   key            dkn (and dv if non-NULL) with a SECOND recomputation of the logits
+ *   key_from_ds    dkn = qn . dS as a plain fp32-MFMA GEMM over the ds_t written by `query`
+ * `query(ds_t) + key_from_ds` executes 2*HW^2*(K+Cv) fewer MFMA FLOPs per sample than `query + key`
+ * for 8 bytes of HBM traffic per logit — the faster choice on MI355X (fp32 MFMA is only ~25 FLOP per
+ * HBM byte) whenever B*Nq*Nk*4 bytes of scratch are available and dv is not needed.
+ * cocos_corr_softmax_warp_bwd is the all-in-one convenience (prepare + query + key; ws holds dvec:
+ * cocos_corr_softmax_warp_bwd_workspace_bytes() = B*Nq*4 bytes; dqn / dkn / dv may be NULL). */
 size_t cocos_corr_softmax_warp_bwd_workspace_bytes(int B, int K, int Nq, int Nk, int Cv);
+int cocos_corr_softmax_warp_bwd_prepare(const float* out, const float* dout, float* dvec,
+                                        int B, int Nq, int Cv, cocos_stream_t stream);
+int cocos_corr_softmax_warp_bwd_query(const float* qn, const float* kn, const float* v,
+                                      const float* lse, const float* dout, const float* dvec,
+                                      float* dqn, float* ds_t /* nullable */,
+                                      int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
+                                      cocos_stream_t stream);
+int cocos_corr_softmax_warp_bwd_key(const float* qn, const float* kn, const float* v,
+                                    const float* lse, const float* dout, const float* dvec,
+                                    float* dkn, float* dv /* nullable */,
+                                    int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
+                                    cocos_stream_t stream);
+int cocos_corr_softmax_warp_bwd_key_from_ds(const float* qn, const float* ds_t, float* dkn,
+                                            int B, int K, int Nq, int Nk, cocos_stream_t stream);
 int cocos_corr_softmax_warp_bwd(const float* qn, const float* kn, const float* v,
                                 const float* out, const float* lse, const float* dout,
                                 float* dqn, float* dkn, float* dv,

@@ -105,6 +105,22 @@ def test_fused_forward_backward_vs_oracle(B, Nq, Nk, Cv, peaked):
     assert rel(vv.grad, dv_ref) < OUT_TOL
 
 
+def test_key_side_strategies_agree(monkeypatch):
+    """dkn via GEMM over the materialised dS^T  ==  dkn via the second recompute kernel."""
+    from cocosnet_amd import ops
+    qn, kn, v = _qkv(2, 300, 260, 70, seed=11)
+    g = np.random.RandomState(8).standard_normal((2, 70, 300))
+    res = []
+    for limit in (16 << 30, 0):
+        monkeypatch.setattr(ops, "MAX_DS_WORKSPACE_BYTES", limit)
+        q, k = dev(qn, True), dev(kn, True)
+        ops.corr_softmax_warp(q, k, dev(v), 100.0).backward(dev(g))
+        res.append((q.grad.clone(), k.grad.clone()))
+    _, dk_ref, _ = co.corr_softmax_warp_bwd(qn, kn, v, g, 100.0)
+    assert rel(res[0][1], dk_ref) < OUT_TOL and rel(res[1][1], dk_ref) < OUT_TOL
+    assert rel(res[0][0], res[1][0].cpu().numpy()) < 1e-6
+
+
 def test_fused_chunks_wide_v():
     """Cv > 160 is processed in chunks by the host side; results identical to the oracle."""
     from cocosnet_amd import ops
@@ -309,5 +325,6 @@ def test_module_return_corr_and_wta_and_detach():
     o = net(img, img, seg, seg, WTA_scale_weight=0.5)
     assert set(o) == {"warp_out"}
     o = net(img, img, seg, seg, detach_flag=True)
-    o["warp_out"].sum().backward()
-    assert net.theta.weight.grad is None or float(net.theta.weight.grad.abs().max()) == 0.0
+    # f.detach() (:292-293) cuts the only path to the parameters: like the reference, the output
+    # then carries no autograd history at all
+    assert not o["warp_out"].requires_grad
