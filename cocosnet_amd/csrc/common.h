@@ -78,6 +78,15 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned by
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
 
+// uniform (SGPR) part of the offset in `soff`: lets one per-lane offset serve a whole tile
+__device__ __forceinline__ float buf_load1s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store1s(__amdgpu_buffer_rsrc_t r, float v, unsigned byte_off,
+                                            unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, (int)soff, 0);
+}
+
 // ---- LDS tile staging -------------------------------------------------------------------
 // A "tile" is ROWS channels x 32 positions of a channel-major tensor [rows][ncols], cut at
 // position j0.  256 threads fetch it into registers (one float4 per 32 rows per thread; the

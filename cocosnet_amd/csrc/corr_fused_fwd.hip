@@ -29,10 +29,12 @@ constexpr int FWD_BK = kTileCols;    // key positions per tile
 constexpr int FWD_LD = kTileLd;      // LDS row stride (floats)
 constexpr float kRescaleThr = 8.0f;  // log2 units: rescale only when a row max grows by > 2^8
 
-template <int KD, int CVB>
+template <int KD, int CVB, bool STORE_S>
 __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
     const float* __restrict__ qn, const float* __restrict__ kn, const float* __restrict__ v,
-    float* __restrict__ out, float* __restrict__ lse, int B, int Nq, int Nk, int Cv,
+    float* __restrict__ out, float* __restrict__ lse,
+    float* __restrict__ lg /* [B,Nk,Nq] scaled logits for the backward (STORE_S) */, int B, int Nq,
+    int Nk, int Cv,
     float scale_log2 /* inv_temperature * log2(e) */) {
     constexpr int CVP = CVB * 32;
     static_assert(KD % 32 == 0, "K must be a multiple of 32");
@@ -53,6 +55,14 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
     const __amdgpu_buffer_rsrc_t q_rs = make_rsrc(qn + (size_t)b * KD * Nq, (size_t)KD * Nq * 4);
     const __amdgpu_buffer_rsrc_t k_rs = make_rsrc(kn + (size_t)b * KD * Nk, (size_t)KD * Nk * 4);
     const __amdgpu_buffer_rsrc_t v_rs = make_rsrc(v + (size_t)b * Cv * Nk, (size_t)Cv * Nk * 4);
+
+    // training mode: the scaled logits (log2 domain) go to HBM once, key-major [Nk][Nq], so the
+    // query-side backward reads them back instead of recomputing K/2 MFMAs per tile: on MI355X a
+    // logit costs 512 fp32-MFMA FLOPs to recompute (3.3 ps at peak) but 8 bytes of HBM traffic to
+    // store + reload (1.3 ps at 6 TB/s), and the stores hide under the MFMAs anyway.
+    const __amdgpu_buffer_rsrc_t lg_rs = make_rsrc(STORE_S ? lg + (size_t)b * Nk * Nq : nullptr,
+                                                   STORE_S ? (size_t)Nk * Nq * 4 : 0);
+    const unsigned lg_lane_off = i_lane < Nq ? (unsigned)(4 * h * Nq + i_lane) * 4u : kBufOob;
 
     // ---- resident query slice: B operand  B[k = 2kk + h][col = query c] -------------------
     // (positions past Nq read 0 through the descriptor; their results are never stored)
@@ -145,6 +155,14 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
             s[r] = x;
             tmax = fmaxf(tmax, x);
         }
+        if (STORE_S) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jr = j0 + acc_row_base(r);
+                buf_store1s(lg_rs, s[r], (!ragged || jr + 4 * h < Nk) ? lg_lane_off : kBufOob,
+                            (unsigned)jr * (unsigned)Nq * 4u);
+            }
+        }
         tmax = fmaxf(tmax, swap_half(tmax));
         // Lazy rescale (guide T13): the running max only moves — and O, l are only rescaled —
         // when some row's tile max exceeds it by more than 2^kRescaleThr.  O lives in AGPRs, so an
@@ -213,25 +231,33 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
     }
 }
 
-template <int KD, int CVB>
-static int launch_fwd(const float* qn, const float* kn, const float* v, float* out, float* lse,
-                      int B, int Nq, int Nk, int Cv, float inv_t, hipStream_t stream) {
-    auto kern = corr_softmax_warp_fwd_kernel<KD, CVB>;
+template <int KD, int CVB, bool STORE_S>
+static int launch_fwd_k(const float* qn, const float* kn, const float* v, float* out, float* lse,
+                        float* lg, int B, int Nq, int Nk, int Cv, float inv_t, hipStream_t stream) {
+    auto kern = corr_softmax_warp_fwd_kernel<KD, CVB, STORE_S>;
     const size_t smem = (size_t)(KD + CVB * 32) * FWD_LD * sizeof(float);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int nqb = (Nq + FWD_BQ - 1) / FWD_BQ;
-    hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, stream, qn, kn, v, out, lse, B, Nq,
+    hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, stream, qn, kn, v, out, lse, lg, B, Nq,
                        Nk, Cv, inv_t * kLog2e);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
 
+template <int KD, int CVB>
+static int launch_fwd(const float* qn, const float* kn, const float* v, float* out, float* lse,
+                      float* lg, int B, int Nq, int Nk, int Cv, float inv_t, hipStream_t stream) {
+    return lg ? launch_fwd_k<KD, CVB, true>(qn, kn, v, out, lse, lg, B, Nq, Nk, Cv, inv_t, stream)
+              : launch_fwd_k<KD, CVB, false>(qn, kn, v, out, lse, nullptr, B, Nq, Nk, Cv, inv_t, stream);
+}
+
 }  // namespace cocos
 
 extern "C" int cocos_corr_softmax_warp_fwd(const float* qn, const float* kn, const float* v,
-                                           float* out, float* lse, int B, int K, int Nq, int Nk,
-                                           int Cv, float inv_temperature, cocos_stream_t stream) {
+                                           float* out, float* lse, float* logits_t, int B, int K,
+                                           int Nq, int Nk, int Cv, float inv_temperature,
+                                           cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(qn && kn && v && out && lse, COCOS_ERR_INVALID, "corr_softmax_warp_fwd: null pointer");
     COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1, COCOS_ERR_INVALID,
@@ -242,13 +268,15 @@ extern "C" int cocos_corr_softmax_warp_fwd(const float* qn, const float* kn, con
     COCOS_REQUIRE(Cv <= 160, COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_fwd: Cv=%d > 160", Cv);
     COCOS_REQUIRE((size_t)K * Nq * 4 < 0x7fffffffull && (size_t)K * Nk * 4 < 0x7fffffffull,
                   COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_fwd: per-sample tensor exceeds 2 GiB");
+    COCOS_REQUIRE(!logits_t || (size_t)Nq * Nk * 4 < 0x7fffffffull, COCOS_ERR_UNSUPPORTED,
+                  "corr_softmax_warp_fwd: per-sample logits exceed 2 GiB; pass logits_t = NULL");
     hipStream_t s = as_stream(stream);
     const int cvb = (Cv + 31) / 32;
     switch (cvb) {
-        case 1: return launch_fwd<256, 1>(qn, kn, v, out, lse, B, Nq, Nk, Cv, inv_temperature, s);
-        case 2: return launch_fwd<256, 2>(qn, kn, v, out, lse, B, Nq, Nk, Cv, inv_temperature, s);
-        case 3: return launch_fwd<256, 3>(qn, kn, v, out, lse, B, Nq, Nk, Cv, inv_temperature, s);
-        case 4: return launch_fwd<256, 4>(qn, kn, v, out, lse, B, Nq, Nk, Cv, inv_temperature, s);
-        default: return launch_fwd<256, 5>(qn, kn, v, out, lse, B, Nq, Nk, Cv, inv_temperature, s);
+        case 1: return launch_fwd<256, 1>(qn, kn, v, out, lse, logits_t, B, Nq, Nk, Cv, inv_temperature, s);
+        case 2: return launch_fwd<256, 2>(qn, kn, v, out, lse, logits_t, B, Nq, Nk, Cv, inv_temperature, s);
+        case 3: return launch_fwd<256, 3>(qn, kn, v, out, lse, logits_t, B, Nq, Nk, Cv, inv_temperature, s);
+        case 4: return launch_fwd<256, 4>(qn, kn, v, out, lse, logits_t, B, Nq, Nk, Cv, inv_temperature, s);
+        default: return launch_fwd<256, 5>(qn, kn, v, out, lse, logits_t, B, Nq, Nk, Cv, inv_temperature, s);
     }
 }

@@ -134,10 +134,16 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                              f"kn{tuple(kn.shape)} v{tuple(v.shape)}")
         out = torch.empty((B, Cv, Nq), device=qn.device, dtype=torch.float32)
         lse = torch.empty((B, Nq), device=qn.device, dtype=torch.float32)
-        _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd", qn.data_ptr(), kn.data_ptr(), v.data_ptr(),
-                  out.data_ptr(), lse.data_ptr(), B, K, Nq, Nk, Cv, float(inv_temperature),
-                  _stream())
+        # training: keep the scaled logits for the query-side backward (cheaper than recomputing
+        # them on fp32 MFMA, see corr_fused_fwd.hip); inference never materialises anything HWxHW
+        keep = (any(ctx.needs_input_grad[:2]) and B * Nq * Nk * 4 <= MAX_DS_WORKSPACE_BYTES
+                and Nq * Nk * 4 < 2 ** 31 - 1)
+        logits_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if keep else None
+        _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd", qn.data_ptr(), kn.data_ptr(),
+              v.data_ptr(), out.data_ptr(), lse.data_ptr(), _ptr(logits_t), B, K, Nq, Nk, Cv,
+              float(inv_temperature), _stream())
         ctx.save_for_backward(qn, kn, v, out, lse)
+        ctx.logits_t = logits_t
         ctx.inv_t = float(inv_temperature)
         return out
 
@@ -166,7 +172,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         ds_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if via_gemm else None
         if dqn is not None:
             _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query", *common,
-                  _ptr(dqn), _ptr(ds_t), *dims)
+                  _ptr(ctx.logits_t), _ptr(dqn), _ptr(ds_t), *dims)
         if via_gemm:
             _call("corr_softmax_warp_bwd_key_from_ds", "cocos_corr_softmax_warp_bwd_key_from_ds",
                   qn.data_ptr(), ds_t.data_ptr(), dkn.data_ptr(), B, K, Nq, Nk, st)

@@ -69,11 +69,14 @@ int cocos_center_l2norm_bwd(const float* y, const float* norm, const float* dy, 
  *   v    [B,Cv,Nk]  channels to warp (avg-pooled exemplar RGB, label maps, ... concatenated)
  *   out  [B,Cv,Nq]  out[b,c,i] = sum_j softmax_j(qn[:,i].kn[:,j] * inv_temperature) * v[b,c,j]
  *   lse  [B,Nq]     row log-sum-exp of the scaled logits (natural log), saved for backward
+ *   logits_t [B,Nk,Nq] or NULL: when given (training), the scaled logits * log2(e) are also
+ *                   written, key-major, for cocos_corr_softmax_warp_bwd_query to read back instead
+ *                   of recomputing them (inference passes NULL: nothing HWxHW reaches HBM)
  * The column softmax `softmax(f^T)` of :338/:351 is this same call with qn/kn swapped.
  * Supported: K == 256 (match_kernel 1), 1 <= Cv <= 160, any Nq, Nk >= 1.
  * ------------------------------------------------------------------------------------- */
 int cocos_corr_softmax_warp_fwd(const float* qn, const float* kn, const float* v,
-                                float* out, float* lse,
+                                float* out, float* lse, float* logits_t /* nullable */,
                                 int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
                                 cocos_stream_t stream);
 
@@ -81,7 +84,8 @@ int cocos_corr_softmax_warp_fwd(const float* qn, const float* kn, const float* v
  *   dout [B,Cv,Nq] -> dqn [B,K,Nq], dkn [B,K,Nk], dv [B,Cv,Nk]
  * It is exposed in stages so that the caller picks the strategy for the key side:
  *   prepare        dvec[b,i] = sum_c dout[b,c,i] * out[b,c,i]                      (always first)
- *   query          dqn; optionally also writes ds_t [B,Nk,Nq] = (dS)^T / T
+ *   query          dqn; reads the forward's logits_t if given (else recomputes the logits);
+ *                  optionally also writes ds_t [B,Nk,Nq] = (dS)^T / T
  *   key            dkn (and dv if non-NULL) with a SECOND recomputation of the logits
  *   key_from_ds    dkn = qn . dS as a plain fp32-MFMA GEMM over the ds_t written by `query`
  * `query(ds_t) + key_from_ds` executes 2*HW^2*(K+Cv) fewer MFMA FLOPs per sample than `query + key`
@@ -94,6 +98,7 @@ int cocos_corr_softmax_warp_bwd_prepare(const float* out, const float* dout, flo
                                         int B, int Nq, int Cv, cocos_stream_t stream);
 int cocos_corr_softmax_warp_bwd_query(const float* qn, const float* kn, const float* v,
                                       const float* lse, const float* dout, const float* dvec,
+                                      const float* logits_t /* nullable: from the forward */,
                                       float* dqn, float* ds_t /* nullable */,
                                       int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
                                       cocos_stream_t stream);

@@ -43,14 +43,14 @@ def test_version_and_error_string(hip_lib):
 
 def test_argument_validation_needs_no_gpu(hip_lib):
     """Null pointers / unsupported shapes are rejected before any HIP call is made."""
-    rc = hip_lib.cocos_corr_softmax_warp_fwd(None, None, None, None, None, 1, 256, 4, 4, 3,
+    rc = hip_lib.cocos_corr_softmax_warp_fwd(None, None, None, None, None, None, 1, 256, 4, 4, 3,
                                              ctypes.c_float(100.0), None)
     assert rc == -1 and b"null" in hip_lib.cocos_last_error_string()
     one = ctypes.c_void_p(16)
-    rc = hip_lib.cocos_corr_softmax_warp_fwd(one, one, one, one, one, 1, 2304, 4, 4, 3,
+    rc = hip_lib.cocos_corr_softmax_warp_fwd(one, one, one, one, one, None, 1, 2304, 4, 4, 3,
                                              ctypes.c_float(100.0), None)
     assert rc == -2 and b"K == 256" in hip_lib.cocos_last_error_string()
-    rc = hip_lib.cocos_corr_softmax_warp_fwd(one, one, one, one, one, 1, 256, 4, 4, 161,
+    rc = hip_lib.cocos_corr_softmax_warp_fwd(one, one, one, one, one, None, 1, 256, 4, 4, 161,
                                              ctypes.c_float(100.0), None)
     assert rc == -2
     assert hip_lib.cocos_corr_softmax_warp_bwd_workspace_bytes(8, 256, 4096, 4096, 154) == 8 * 4096 * 4
