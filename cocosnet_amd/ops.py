@@ -124,7 +124,7 @@ def center_l2norm(x: torch.Tensor, center_over_channels: bool, eps: float = NORM
 # ------------------------------------------------------------------------------------------
 class _CorrSoftmaxWarp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qn, kn, v, inv_temperature: float):
+    def forward(ctx, qn, kn, v, inv_temperature: float, keep_logits: bool):
         qn, kn, v = _chk(qn, "qn"), _chk(kn, "kn"), _chk(v, "v")
         B, K, Nq = qn.shape
         Bk, Kk, Nk = kn.shape
@@ -136,7 +136,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         lse = torch.empty((B, Nq), device=qn.device, dtype=torch.float32)
         # training: keep the scaled logits for the query-side backward (cheaper than recomputing
         # them on fp32 MFMA, see corr_fused_fwd.hip); inference never materialises anything HWxHW
-        keep = (any(ctx.needs_input_grad[:2]) and B * Nq * Nk * 4 <= MAX_DS_WORKSPACE_BYTES
+        keep = (keep_logits and B * Nq * Nk * 4 <= MAX_DS_WORKSPACE_BYTES
                 and Nq * Nk * 4 < 2 ** 31 - 1)
         logits_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if keep else None
         _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd", qn.data_ptr(), kn.data_ptr(),
@@ -179,7 +179,13 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         elif dkn is not None:
             _call("corr_softmax_warp_bwd_key", "cocos_corr_softmax_warp_bwd_key", *common, _ptr(dkn),
                   _ptr(dv), *dims)
-        return dqn, (dkn if need_k else None), dv, None
+        return dqn, (dkn if need_k else None), dv, None, None
+
+
+def _wants_logits(qn, kn):
+    # decided OUTSIDE the Function (inside it grad mode is always off): only a pass that will be
+    # differentiated w.r.t. theta/phi saves the logits; inference never materialises anything HWxHW
+    return torch.is_grad_enabled() and (qn.requires_grad or kn.requires_grad)
 
 
 def corr_softmax_warp(qn, kn, v, inv_temperature: float):
@@ -188,9 +194,10 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float):
     qn [B,256,Nq], kn [B,256,Nk], v [B,Cv,Nk] -> [B,Cv,Nq].  Wider V is processed in chunks of
     160 channels (each chunk recomputes the logits; no materialisation)."""
     Cv = v.shape[1]
+    keep = _wants_logits(qn, kn)
     if Cv <= MAX_FUSED_CV:
-        return _CorrSoftmaxWarp.apply(qn, kn, v, inv_temperature)
-    parts = [_CorrSoftmaxWarp.apply(qn, kn, v[:, c0:c0 + MAX_FUSED_CV], inv_temperature)
+        return _CorrSoftmaxWarp.apply(qn, kn, v, inv_temperature, keep)
+    parts = [_CorrSoftmaxWarp.apply(qn, kn, v[:, c0:c0 + MAX_FUSED_CV], inv_temperature, keep)
              for c0 in range(0, Cv, MAX_FUSED_CV)]
     return torch.cat(parts, dim=1)
 
