@@ -11,9 +11,9 @@
 // Decomposition (one workgroup = 4 waves = 128 query positions, 1 wave per SIMD):
 //   * each wave owns 32 query positions; its 32 x K query slice lives in registers as the MFMA
 //     B operand for the whole kernel (K/2 = 128 registers);
-//   * key tiles of 32 positions ([K][32] + the V tile [Cv][32]) stream through LDS, shared by
-//     the 4 waves; they are fetched into registers one tile ahead (loads in flight under the
-//     MFMAs) and written to a single LDS buffer between two barriers;
+//   * key tiles of 32 positions ([K][32] + the V tile [Cv][32]) stream through a double-buffered
+//     LDS ring shared by the 4 waves; global loads run 2-3 tiles ahead in staging registers; the
+//     logits of tile t+1 are computed WHILE tile t goes through the softmax (see "pipeline");
 //   * the wave computes S^T (32 keys x 32 queries) = K_tile^T . Q  — swapped operands, so that
 //     lane&31 indexes the QUERY: the softmax statistics (running max / sum) are one scalar per
 //     lane and the key axis runs over the 16 accumulator registers (+ the other half-wave);
@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
     static_assert(KD % 32 == 0, "K must be a multiple of 32");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* kt = smem;                    // [KD][FWD_LD]
-    float* vt = smem + KD * FWD_LD;      // [CVP][FWD_LD]
+    float* kt = smem;                        // [2][KD][FWD_LD]
+    float* vt = smem + 2 * KD * FWD_LD;      // [2][CVP][FWD_LD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -86,90 +86,134 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
     float m_run = -INFINITY;   // running max (log2 domain), per query lane
     float l_run = 0.f;         // running sum, partial over this half-wave's keys
 
-    // ---- register staging of the next key / V tile ----------------------------------------
+    // ---- pipeline --------------------------------------------------------------------------------
+    // LDS holds two key tiles and two V tiles.  Iteration t:
+    //     S(t+1) = K(t+1)^T Q        (MFMA, reads kt[(t+1)&1])     \  one instruction stream: the VALU
+    //     softmax of S(t) -> P(t)    (VALU, + logits store)         > work and the LDS commits ride in
+    //     commit K(t+2) -> kt[t&1], V(t+1) -> vt[(t+1)&1]          /  the gaps between the MFMAs
+    //     fetch  K(t+3), V(t+2)      (global -> staging registers, in flight until the next commit)
+    //     O += V(t)^T P(t)           (MFMA, reads vt[t&1])
+    //     barrier
+    // so the matrix pipe never waits for the softmax, and there is ONE barrier per tile.  Tiles past
+    // the end are fetched through the descriptors' bounds check (zeros) and multiplied for nothing
+    // (one tile per workgroup) — cheaper than a second, non-overlapped code path for the tail.
     TileRegs<KD> ks;
     TileRegs<CVP> vs;
-    auto fetch = [&](int j0) {
-        if (j0 + FWD_BK <= Nk) {   // wave-uniform: full tile -> 16-byte loads
-            tile_fetch<KD, false>(ks, k_rs, KD, Nk, j0, tid);
-            tile_fetch<CVP, false>(vs, v_rs, Cv, Nk, j0, tid);
-        } else {                   // ragged last tile -> per-element bounds, zero fill
-            tile_fetch<KD, true>(ks, k_rs, KD, Nk, j0, tid);
-            tile_fetch<CVP, true>(vs, v_rs, Cv, Nk, j0, tid);
+    auto fetch_k = [&](int j0) {
+        if (j0 + FWD_BK <= Nk) tile_fetch<KD, false>(ks, k_rs, KD, Nk, j0, tid);
+        else                   tile_fetch<KD, true>(ks, k_rs, KD, Nk, j0, tid);
+    };
+    auto fetch_v = [&](int j0) {
+        if (j0 + FWD_BK <= Nk) tile_fetch<CVP, false>(vs, v_rs, Cv, Nk, j0, tid);
+        else                   tile_fetch<CVP, true>(vs, v_rs, Cv, Nk, j0, tid);
+    };
+    // one float4 piece (32 rows) of a staged tile -> LDS
+    auto commit_piece = [&](const f32x4& x, float* tile, int u) {
+        float* d = tile + (u * 32 + (tid >> 3)) * FWD_LD + (tid & 7) * 4;
+        d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+    };
+
+    constexpr int NB = 8, NBATCH = KD / 2 / NB;   // 16 batches of 8 MFMAs per S tile
+    static_assert(NBATCH == 16, "hook schedule below is written for K = 256");
+    // One batch of S^T += K_tile^T Q with its LDS operands requested a batch ahead (pinned).
+    // `hook(bt)` injects the VALU / LDS-store work that should hide under this batch.
+    auto qk_tile = [&](const float* ktile, f32x16& acc, auto&& hook, int bt_lo, int bt_hi,
+                       float (&a)[2][NB]) {
+        const float* kl = ktile + h * FWD_LD + c;
+#pragma unroll
+        for (int bt = 0; bt < NBATCH; ++bt) {
+            if (bt < bt_lo || bt >= bt_hi) continue;
+            if (bt + 1 < NBATCH) {
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+                    a[(bt + 1) & 1][u] = kl[(2 * ((bt + 1) * NB + u)) * FWD_LD];
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) acc = mfma32(a[bt & 1][u], qreg[bt * NB + u], acc);
+            hook(bt);
+#pragma unroll
+            for (int u = 0; u < NB / 2; ++u) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            // one scheduling region per batch: hipcc's group solver is super-linear in region size
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto qk_lead = [&](const float* ktile, float (&a)[2][NB]) {
+        const float* kl = ktile + h * FWD_LD + c;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) a[0][u] = kl[(2 * u) * FWD_LD];
+        __builtin_amdgcn_sched_group_barrier(0x100, NB / 2, 0);
     };
 
     const int ntiles = (Nk + FWD_BK - 1) / FWD_BK;
-    fetch(0);
+    float* const kt0 = kt;
+    float* const kt1 = kt + KD * FWD_LD;
+    float* const vt0 = vt;
+    float* const vt1 = vt + CVP * FWD_LD;
+
+    // ---- prologue: K(0), K(1), V(0) resident; K(2), V(1) staged; S(0) computed ------------------
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    {
+        fetch_k(0);
+        tile_commit<KD>(ks, kt0, tid);
+        fetch_k(FWD_BK);
+        fetch_v(0);
+        __syncthreads();
+        float a[2][NB];
+        qk_lead(kt0, a);
+        qk_tile(kt0, s, [](int) {}, 0, NBATCH, a);
+        tile_commit<KD>(ks, kt1, tid);
+        tile_commit<CVP>(vs, vt0, tid);
+        fetch_k(2 * FWD_BK);
+        fetch_v(FWD_BK);
+        __syncthreads();
+    }
+
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * FWD_BK;
-        __syncthreads();            // every wave is done reading the previous tile
-        tile_commit<KD>(ks, kt, tid);
-        tile_commit<CVP>(vs, vt, tid);
-        __syncthreads();
-        if (t + 1 < ntiles) fetch(j0 + FWD_BK);   // in flight under the MFMAs below
-
-        // ---- S^T tile: rows = keys (acc registers), cols = queries (lanes) -----------------
-        // A operands are read from LDS in batches of 8, one batch AHEAD of the MFMAs that consume
-        // them: with one read in flight per MFMA the ~100-cycle LDS latency would sit between every
-        // two dependent 64-cycle MFMAs (measured: 63 % of peak); batched, it is covered.
-        f32x16 s;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        {
-            constexpr int NB = 8, NBATCH = KD / 2 / NB;
-            const float* kl = kt + h * FWD_LD + c;
-            float a[2][NB];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) a[0][u] = kl[(2 * u) * FWD_LD];
-            __builtin_amdgcn_sched_group_barrier(0x100, NB / 2, 0);   // lead: one batch of reads
-#pragma unroll
-            for (int bt = 0; bt < NBATCH; ++bt) {
-                if (bt + 1 < NBATCH) {
-#pragma unroll
-                    for (int u = 0; u < NB; ++u)
-                        a[(bt + 1) & 1][u] = kl[(2 * ((bt + 1) * NB + u)) * FWD_LD];
-                }
-#pragma unroll
-                for (int u = 0; u < NB; ++u) s = mfma32(a[bt & 1][u], qreg[bt * NB + u], s);
-                // pin the interleave: 2 MFMAs, then one LDS read of the NEXT batch (hipcc pairs the
-                // reads into ds_read2_b32), so every operand is requested >= 4 MFMAs before its use
-#pragma unroll
-                for (int u = 0; u < NB / 2; ++u) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                // one scheduling region per batch: hipcc's group solver is superlinear in the
-                // region size (minutes per kernel when a whole tile body is one region)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-
-        // ---- online softmax over the key axis ---------------------------------------------
-        float tmax = -INFINITY;
         const bool ragged = (j0 + FWD_BK > Nk);
+        float* const k_rd = (t & 1) ? kt0 : kt1;    // K(t+1)
+        float* const k_wr = (t & 1) ? kt1 : kt0;    // <- K(t+2)
+        float* const v_rd = (t & 1) ? vt1 : vt0;    // V(t)
+        float* const v_wr = (t & 1) ? vt0 : vt1;    // <- V(t+1)
+
+        f32x16 sn;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float x = s[r] * scale_log2;
-            if (ragged && (j0 + acc_row_base(r) + 4 * h >= Nk)) x = -INFINITY;
-            s[r] = x;
-            tmax = fmaxf(tmax, x);
-        }
-        if (STORE_S) {
+        for (int r = 0; r < 16; ++r) sn[r] = 0.f;
+        float tmax = -INFINITY, psum = 0.f;
+        float a[2][NB];
+        qk_lead(k_rd, a);
+
+        // batches 0..3: scale + mask + row max of S(t), four accumulator registers per batch;
+        // batches 3..15: one staged piece per batch goes to LDS (8 K pieces, then CVB V pieces)
+        auto commit_hook = [&](int bt) {
+            const int u = bt - 3;
+            if (u >= 0 && u < KD / 32) commit_piece(ks.r[u], k_wr, u);
+            else if (u >= KD / 32 && u - KD / 32 < CVB) commit_piece(vs.r[u - KD / 32], v_wr, u - KD / 32);
+        };
+        qk_tile(k_rd, sn, [&](int bt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jr = j0 + acc_row_base(r);
-                buf_store1s(lg_rs, s[r], (!ragged || jr + 4 * h < Nk) ? lg_lane_off : kBufOob,
-                            (unsigned)jr * (unsigned)Nq * 4u);
+            for (int q = 0; q < 4; ++q) {
+                const int r = bt * 4 + q;
+                float x = s[r] * scale_log2;
+                if (ragged && (j0 + acc_row_base(r) + 4 * h >= Nk)) x = -INFINITY;
+                s[r] = x;
+                tmax = fmaxf(tmax, x);
             }
-        }
+            commit_hook(bt);
+        }, 0, 4, a);
+
         tmax = fmaxf(tmax, swap_half(tmax));
         // Lazy rescale (guide T13): the running max only moves — and O, l are only rescaled —
         // when some row's tile max exceeds it by more than 2^kRescaleThr.  O lives in AGPRs, so an
         // unconditional rescale costs 2 register moves + 1 multiply per accumulator register per
         // tile; with the threshold the branch is taken a handful of times per row.  p is then
         // bounded by 2^kRescaleThr instead of 1, harmless in fp32.  The first tile always takes
-        // the branch (m_run = -inf), every tile holds >= 1 valid key so m_run becomes finite.
+        // the branch (m_run = -inf), every real tile holds >= 1 valid key so m_run becomes finite.
         if (__any(tmax > m_run + kRescaleThr)) {
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = fast_exp2(m_run - m_new);
@@ -180,18 +224,34 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
         }
-        float psum = 0.f;
+
+        // batches 4..11: two registers per batch: logits store (training), exponentiate, row sum
+        qk_tile(k_rd, sn, [&](int bt) {
+            if (bt < 12) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = fast_exp2(s[r] - m_run);
-            psum += s[r];
-        }
+                for (int q = 0; q < 2; ++q) {
+                    const int r = (bt - 4) * 2 + q;
+                    if (STORE_S) {
+                        const int jr = j0 + acc_row_base(r);
+                        buf_store1s(lg_rs, s[r], (!ragged || jr + 4 * h < Nk) ? lg_lane_off : kBufOob,
+                                    (unsigned)jr * (unsigned)Nq * 4u);
+                    }
+                    s[r] = fast_exp2(s[r] - m_run);
+                    psum += s[r];
+                }
+            }
+            commit_hook(bt);
+        }, 4, NBATCH, a);
         l_run += psum;
 
+        // staging registers are free again: next tiles' loads fly under the P.V MFMAs and the
+        // whole next iteration
+        fetch_k(j0 + 3 * FWD_BK);
+        fetch_v(j0 + 2 * FWD_BK);
+
         // ---- O^T += V^T . P^T : A = V^T[ch][key] from LDS, B = P^T (accumulator registers) --
-        // same read-ahead: the CVB operands of key-pair r+1 are fetched while pair r multiplies
         {
-            const float* vl = vt + c * FWD_LD + 4 * h;
+            const float* vl = v_rd + c * FWD_LD + 4 * h;
             float va[2][CVB];
 #pragma unroll
             for (int cb = 0; cb < CVB; ++cb) va[0][cb] = vl[cb * 32 * FWD_LD + acc_row_base(0)];
@@ -213,6 +273,8 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        __syncthreads();   // K(t+2), V(t+1) visible; K(t+1), V(t) no longer read by anyone
+        s = sn;
     }
 
     // ---- epilogue: normalise, store channel-major [B,Cv,Nq], store row LSE ------------------
@@ -235,7 +297,7 @@ template <int KD, int CVB, bool STORE_S>
 static int launch_fwd_k(const float* qn, const float* kn, const float* v, float* out, float* lse,
                         float* lg, int B, int Nq, int Nk, int Cv, float inv_t, hipStream_t stream) {
     auto kern = corr_softmax_warp_fwd_kernel<KD, CVB, STORE_S>;
-    const size_t smem = (size_t)(KD + CVB * 32) * FWD_LD * sizeof(float);
+    const size_t smem = (size_t)2 * (KD + CVB * 32) * FWD_LD * sizeof(float);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int nqb = (Nq + FWD_BQ - 1) / FWD_BQ;

@@ -19,12 +19,24 @@ q = nrm(torch.randn(B, 256, N, device=dev, generator=g)).requires_grad_(True)
 k = nrm(0.2 * q.detach() + torch.randn(B, 256, N, device=dev, generator=g)).requires_grad_(True)
 v = torch.rand(B, Cv, N, device=dev, generator=g) * 2 - 1
 go = torch.randn(B, Cv, N, device=dev, generator=g)
-with ops.KernelTimer() as kt:
-    for _ in range(a.iters):
-        q.grad = None; k.grad = None
-        ops.corr_softmax_warp(q, k, v, 100.0).backward(go)
+def train_step():
+    q.grad = None; k.grad = None
+    ops.corr_softmax_warp(q, k, v, 100.0).backward(go)
+
+def infer_step():
     with torch.no_grad():
+        ops.corr_softmax_warp(q, k, v, 100.0)
+
+for name, fn in (("train", train_step), ("infer", infer_step)):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    with ops.KernelTimer() as kt:
         for _ in range(a.iters):
-            ops.corr_softmax_warp(q, k, v, 100.0)          # inference flavour (no logits store)
-for tag, r in kt.summary().items():
-    print(f"{tag:40s} calls {r['calls']:3d} avg {r['avg_ms']:.4f} ms")
+            fn()
+    for tag, r in kt.summary().items():
+        fl = {"corr_softmax_warp_fwd": 2.0 * N * N * (256 + Cv) * B,
+              "corr_softmax_warp_bwd_query": 2.0 * N * N * (256 + Cv) * B,
+              "corr_softmax_warp_bwd_key_from_ds": 2.0 * N * N * 256 * B}.get(tag)
+        extra = f"  {fl / r['avg_ms'] / 1e9:6.1f} TF alg ({fl / r['avg_ms'] / 1e9 / 157.3 * 100:4.1f} % of fp32 MFMA peak)" if fl else ""
+        print(f"{name:6s} {tag:36s} calls {r['calls']:3d} avg {r['avg_ms']:.4f} ms{extra}")
