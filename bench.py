@@ -207,7 +207,7 @@ def main():
                         "note": "algorithmic FLOPs per launch / HIP-event time on torch's current "
                                 "stream; peak = dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N=1 only (bounded sample)
             cpu = cpu_baseline(args.cpu_images)
         images = BATCH_PER_GPU * world * args.steps
         line = {

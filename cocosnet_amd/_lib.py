@@ -32,7 +32,7 @@ _SIGNATURES = {
                                                     ctypes.c_float, _stream_t]),
     "cocos_corr_softmax_warp_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
     "cocos_corr_softmax_warp_bwd_prepare": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [_stream_t]),
-    "cocos_corr_softmax_warp_bwd_query": (ctypes.c_int, [_c_float_p] * 9 + [ctypes.c_int] * 5
+    "cocos_corr_softmax_warp_bwd_query": (ctypes.c_int, [_c_float_p] * 10 + [ctypes.c_int] * 5
                                           + [ctypes.c_float, _stream_t]),
     "cocos_corr_softmax_warp_bwd_key": (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_int] * 5
                                         + [ctypes.c_float, _stream_t]),

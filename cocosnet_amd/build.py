@@ -25,6 +25,7 @@ HIP_SOURCES = [
     "center_l2norm.hip",
     "corr_fused_fwd.hip",
     "corr_fused_bwd.hip",
+    "corr_fused_bwd_saved.hip",
     "sgemm_mfma.hip",
     "row_softmax.hip",
 ]

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void corr_bwd_prep_kernel(const float* __restr
     dvec[(size_t)b * Nq + i] = acc;
 }
 
-template <int KD, int CVB, bool STATS_RESIDENT, bool WITH_DC, bool STORE_DS, bool LOAD_S>
+template <int KD, int CVB, bool STATS_RESIDENT, bool WITH_DC, bool STORE_DS>
 __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
     const float* __restrict__ xr,    // resident X [B,KD,R]
     const float* __restrict__ cr,    // resident C [B,Cv,R]   (dq: dout, dkv: v)
@@ -61,9 +61,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
     float* __restrict__ dxr,         // out [B,KD,R]
     float* __restrict__ dcr,         // out [B,Cv,R] (WITH_DC)
     float* __restrict__ dst,         // out [B,S,R]  (STORE_DS): dS^T / T, streamed-major
-    const float* __restrict__ lg,    // in  [B,S,R]  (LOAD_S): logits * log2(e)/T saved by the forward
     int B, int R, int S, int Cv, float scale_log2, float inv_t) {
-    static_assert(!LOAD_S || STATS_RESIDENT, "saved logits are laid out for the query side only");
     constexpr int CVP = CVB * 32;
     constexpr int KB = KD / 32;
 
@@ -94,13 +92,11 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
     // half-wave's 4 rows; the tile / register part of the row index is wave-uniform (soffset)
     const __amdgpu_buffer_rsrc_t ds_rs = make_rsrc(STORE_DS ? dst + (size_t)b * S * R : nullptr,
                                                    STORE_DS ? (size_t)S * R * 4 : 0);
-    const __amdgpu_buffer_rsrc_t lg_rs = make_rsrc(LOAD_S ? lg + (size_t)b * S * R : nullptr,
-                                                   LOAD_S ? (size_t)S * R * 4 : 0);
     const unsigned sr_lane_off = r_lane < R ? (unsigned)(4 * h * R + r_lane) * 4u : kBufOob;
 
     // ---- resident operands ------------------------------------------------------------------
-    float xreg[LOAD_S ? 1 : KD / 2];
-    if (!LOAD_S) {
+    float xreg[KD / 2];
+    {
         const unsigned off = r_lane < R ? (unsigned)(h * R + r_lane) * 4u : kBufOob;
 #pragma unroll
         for (int kk = 0; kk < KD / 2; ++kk)
@@ -137,18 +133,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
     TileRegs<KD> xsr;
     TileRegs<CVP> csr;
     float stat_r = 0.f;
-    float sld[LOAD_S ? 16 : 1];      // saved logits of the next tile (same lane/register map as s)
     auto fetch = [&](int s0) {
-        if (LOAD_S) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int sp = s0 + acc_row_base(r);   // + 4h is in the lane offset
-                // rows past S: only the last tile can hold them; their value is irrelevant (P is
-                // masked below) but keep the address inside the buffer
-                sld[r] = buf_load1s(lg_rs, (s0 + kTileCols <= S || sp + 4 * h < S) ? sr_lane_off : kBufOob,
-                                    (unsigned)sp * (unsigned)R * 4u);
-            }
-        }
         if (s0 + kTileCols <= S) {
             tile_fetch<KD, false>(xsr, xs_rs, KD, S, s0, tid);
             tile_fetch<CVP, false>(csr, cs_rs, Cv, S, s0, tid);
@@ -174,17 +159,12 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
         tile_commit<CVP>(csr, ct, tid);
         if (!STATS_RESIDENT && tid < 64) st[tid] = stat_r;
         __syncthreads();   // also publishes `crs` on the first iteration
-        if (!LOAD_S && t + 1 < ntiles) fetch(s0 + kTileCols);
+        if (t + 1 < ntiles) fetch(s0 + kTileCols);
 
         // ---- logits tile [streamed x resident] (recompute) ------------------------------------
         // LDS operands are requested one batch ahead of the MFMAs that consume them and the
         // interleave is pinned with sched_group_barrier (see the forward kernel for the why).
         f32x16 s;
-        if (LOAD_S) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = sld[r];   // already scaled by log2(e)/T
-            if (t + 1 < ntiles) fetch(s0 + kTileCols);
-        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         {
@@ -210,7 +190,6 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
                 }
                 if (COCOS_SGB_S) __builtin_amdgcn_sched_barrier(0);   // one region per batch
             }
-        }
         }
 
         // ---- dP tile = C_streamed^T . C_resident ------------------------------------------------
@@ -256,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
             const int sl = acc_row_base(r) + 4 * h;   // streamed index inside the tile
             const float l2 = STATS_RESIDENT ? lse2_lane : st[sl];
             const float dd = STATS_RESIDENT ? d_lane : st[32 + sl];
-            float pv = fast_exp2((LOAD_S ? s[r] : s[r] * scale_log2) - l2);
+            float pv = fast_exp2(s[r] * scale_log2 - l2);
             if (ragged && (s0 + sl >= S)) pv = 0.f;   // zero-filled keys past the end
             p[r] = pv;
             s[r] = pv * (dp[r] - dd);                 // s now holds dS
@@ -333,19 +312,18 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_kernel(
     }
 }
 
-template <int KD, int CVB, bool STATS_RESIDENT, bool WITH_DC, bool STORE_DS, bool LOAD_S>
+template <int KD, int CVB, bool STATS_RESIDENT, bool WITH_DC, bool STORE_DS>
 static int launch_bwd_side(const float* xr, const float* cr, const float* xs, const float* cs,
                            const float* lse, const float* dvec, float* dxr, float* dcr, float* dst,
-                           const float* lg, int B, int R, int S, int Cv, float inv_t,
-                           hipStream_t stream) {
-    auto kern = corr_bwd_kernel<KD, CVB, STATS_RESIDENT, WITH_DC, STORE_DS, LOAD_S>;
+                           int B, int R, int S, int Cv, float inv_t, hipStream_t stream) {
+    auto kern = corr_bwd_kernel<KD, CVB, STATS_RESIDENT, WITH_DC, STORE_DS>;
     const size_t smem =
         ((size_t)(KD + CVB * 32) * BWD_LD + (size_t)CVB * 32 * BWD_BR + 64) * sizeof(float);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int nrb = (R + BWD_BR - 1) / BWD_BR;
     hipLaunchKernelGGL(kern, dim3(B * nrb), dim3(256), smem, stream, xr, cr, xs, cs, lse, dvec,
-                       dxr, dcr, dst, lg, B, R, S, Cv, inv_t * kLog2e, inv_t);
+                       dxr, dcr, dst, B, R, S, Cv, inv_t * kLog2e, inv_t);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -358,29 +336,29 @@ static int launch_bwd_side(const float* xr, const float* cr, const float* xs, co
 int sgemm_dkn_from_ds(const float* qn, const float* dst, float* dkn, int B, int K, int Nq, int Nk,
                       hipStream_t s);
 
+// query side with the forward's saved logits: corr_fused_bwd_saved.hip
+int launch_bwd_query_saved(const float* kn, const float* v, const float* outp, const float* dout,
+                           const float* lse, const float* lg, float* dqn, float* dst, int B, int Nq,
+                           int Nk, int Cv, float inv_t, hipStream_t s);
+
 template <int CVB>
 static int launch_query_side(const float* qn, const float* kn, const float* v, const float* lse,
-                             const float* dout, const float* dvec, float* dqn, float* dst,
-                             const float* lg, int B, int Nq, int Nk, int Cv, float inv_t,
-                             hipStream_t s) {
-#define COCOS_Q(DS, LS)                                                                              \
-    launch_bwd_side<256, CVB, true, false, DS, LS>(qn, dout, kn, v, lse, dvec, dqn, nullptr, dst, lg, \
-                                                   B, Nq, Nk, Cv, inv_t, s)
-    if (dst) return lg ? COCOS_Q(true, true) : COCOS_Q(true, false);
-    return lg ? COCOS_Q(false, true) : COCOS_Q(false, false);
-#undef COCOS_Q
+                             const float* dout, const float* dvec, float* dqn, float* dst, int B,
+                             int Nq, int Nk, int Cv, float inv_t, hipStream_t s) {
+    return dst ? launch_bwd_side<256, CVB, true, false, true>(qn, dout, kn, v, lse, dvec, dqn, nullptr,
+                                                              dst, B, Nq, Nk, Cv, inv_t, s)
+               : launch_bwd_side<256, CVB, true, false, false>(qn, dout, kn, v, lse, dvec, dqn,
+                                                               nullptr, nullptr, B, Nq, Nk, Cv, inv_t, s);
 }
 
 template <int CVB>
 static int launch_key_side(const float* qn, const float* kn, const float* v, const float* lse,
                            const float* dout, const float* dvec, float* dkn, float* dv, int B, int Nq,
                            int Nk, int Cv, float inv_t, hipStream_t s) {
-    return dv ? launch_bwd_side<256, CVB, false, true, false, false>(kn, v, qn, dout, lse, dvec, dkn, dv,
-                                                                     nullptr, nullptr, B, Nk, Nq, Cv,
-                                                                     inv_t, s)
-              : launch_bwd_side<256, CVB, false, false, false, false>(kn, v, qn, dout, lse, dvec, dkn,
-                                                                      nullptr, nullptr, nullptr, B, Nk,
-                                                                      Nq, Cv, inv_t, s);
+    return dv ? launch_bwd_side<256, CVB, false, true, false>(kn, v, qn, dout, lse, dvec, dkn, dv,
+                                                              nullptr, B, Nk, Nq, Cv, inv_t, s)
+              : launch_bwd_side<256, CVB, false, false, false>(kn, v, qn, dout, lse, dvec, dkn, nullptr,
+                                                               nullptr, B, Nk, Nq, Cv, inv_t, s);
 }
 
 #define COCOS_DISPATCH_CVB(cvb, FN, ...)                  \
@@ -423,19 +401,24 @@ extern "C" int cocos_corr_softmax_warp_bwd_prepare(const float* out, const float
 }
 
 extern "C" int cocos_corr_softmax_warp_bwd_query(const float* qn, const float* kn, const float* v,
-                                                 const float* lse, const float* dout,
-                                                 const float* dvec, const float* logits_t,
-                                                 float* dqn, float* ds_t, int B, int K, int Nq,
-                                                 int Nk, int Cv, float inv_temperature,
+                                                 const float* out, const float* lse,
+                                                 const float* dout, const float* dvec,
+                                                 const float* logits_t, float* dqn, float* ds_t, int B,
+                                                 int K, int Nq, int Nk, int Cv, float inv_temperature,
                                                  cocos_stream_t stream) {
     using namespace cocos;
-    COCOS_REQUIRE(qn && kn && v && lse && dout && dvec && dqn, COCOS_ERR_INVALID,
+    COCOS_REQUIRE(qn && kn && v && out && lse && dout && dqn, COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd_query: null pointer");
+    COCOS_REQUIRE(dvec || logits_t, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_query: dvec (from _prepare) is required without logits_t");
     if (int rc = check_dims("corr_softmax_warp_bwd_query", B, K, Nq, Nk, Cv)) return rc;
     COCOS_REQUIRE((!ds_t && !logits_t) || (size_t)Nq * Nk * 4 < 0x7fffffffull, COCOS_ERR_UNSUPPORTED,
                   "corr_softmax_warp_bwd_query: per-sample [Nk,Nq] matrix exceeds 2 GiB; pass NULL");
-    COCOS_DISPATCH_CVB((Cv + 31) / 32, launch_query_side, qn, kn, v, lse, dout, dvec, dqn, ds_t,
-                       logits_t, B, Nq, Nk, Cv, inv_temperature, as_stream(stream));
+    if (logits_t)
+        return launch_bwd_query_saved(kn, v, out, dout, lse, logits_t, dqn, ds_t, B, Nq, Nk, Cv,
+                                      inv_temperature, as_stream(stream));
+    COCOS_DISPATCH_CVB((Cv + 31) / 32, launch_query_side, qn, kn, v, lse, dout, dvec, dqn, ds_t, B,
+                       Nq, Nk, Cv, inv_temperature, as_stream(stream));
 }
 
 extern "C" int cocos_corr_softmax_warp_bwd_key(const float* qn, const float* kn, const float* v,
@@ -478,8 +461,8 @@ extern "C" int cocos_corr_softmax_warp_bwd(const float* qn, const float* kn, con
     int rc = cocos_corr_softmax_warp_bwd_prepare(out, dout, dvec, B, Nq, Cv, stream);
     if (rc != COCOS_OK) return rc;
     if (dqn) {
-        rc = cocos_corr_softmax_warp_bwd_query(qn, kn, v, lse, dout, dvec, nullptr, dqn, nullptr, B, K,
-                                               Nq, Nk, Cv, inv_temperature, stream);
+        rc = cocos_corr_softmax_warp_bwd_query(qn, kn, v, out, lse, dout, dvec, nullptr, dqn, nullptr,
+                                               B, K, Nq, Nk, Cv, inv_temperature, stream);
         if (rc != COCOS_OK) return rc;
     }
     if (dkn)

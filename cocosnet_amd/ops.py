@@ -157,28 +157,32 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         dqn = torch.empty_like(qn) if need_q else None
         dkn = torch.empty_like(kn) if (need_k or need_v) else None
         dv = torch.empty_like(v) if need_v else None
-        dvec = torch.empty((B, Nq), device=qn.device, dtype=torch.float32)
         st = _stream()
-        _call("corr_softmax_warp_bwd_prepare", "cocos_corr_softmax_warp_bwd_prepare", out.data_ptr(),
-              dout.data_ptr(), dvec.data_ptr(), B, Nq, Cv, st)
-        common = (qn.data_ptr(), kn.data_ptr(), v.data_ptr(), lse.data_ptr(), dout.data_ptr(),
-                  dvec.data_ptr())
-        dims = (B, K, Nq, Nk, Cv, ctx.inv_t, st)
+        logits_t = ctx.logits_t
         # key side: GEMM over a materialised dS^T when it pays and fits (see cocos_hip.h), else the
         # flash-style kernel that recomputes the logits (always when dv is wanted: it needs P)
         ds_bytes = B * Nq * Nk * 4
         via_gemm = (dqn is not None and dkn is not None and dv is None
                     and ds_bytes <= MAX_DS_WORKSPACE_BYTES and Nq * Nk * 4 < 2 ** 31 - 1)
+        key_recompute = dkn is not None and not via_gemm
+        dvec = None
+        if key_recompute or (dqn is not None and logits_t is None):
+            dvec = torch.empty((B, Nq), device=qn.device, dtype=torch.float32)
+            _call("corr_softmax_warp_bwd_prepare", "cocos_corr_softmax_warp_bwd_prepare",
+                  out.data_ptr(), dout.data_ptr(), dvec.data_ptr(), B, Nq, Cv, st)
+        dims = (B, K, Nq, Nk, Cv, ctx.inv_t, st)
         ds_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if via_gemm else None
         if dqn is not None:
-            _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query", *common,
-                  _ptr(ctx.logits_t), _ptr(dqn), _ptr(ds_t), *dims)
+            _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query", qn.data_ptr(),
+                  kn.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(),
+                  _ptr(dvec), _ptr(logits_t), _ptr(dqn), _ptr(ds_t), *dims)
         if via_gemm:
             _call("corr_softmax_warp_bwd_key_from_ds", "cocos_corr_softmax_warp_bwd_key_from_ds",
                   qn.data_ptr(), ds_t.data_ptr(), dkn.data_ptr(), B, K, Nq, Nk, st)
         elif dkn is not None:
-            _call("corr_softmax_warp_bwd_key", "cocos_corr_softmax_warp_bwd_key", *common, _ptr(dkn),
-                  _ptr(dv), *dims)
+            _call("corr_softmax_warp_bwd_key", "cocos_corr_softmax_warp_bwd_key", qn.data_ptr(),
+                  kn.data_ptr(), v.data_ptr(), lse.data_ptr(), dout.data_ptr(), dvec.data_ptr(),
+                  _ptr(dkn), _ptr(dv), *dims)
         return dqn, (dkn if need_k else None), dv, None, None
 
 

@@ -83,7 +83,8 @@ int cocos_corr_softmax_warp_fwd(const float* qn, const float* kn, const float* v
 /* Backward of K2 (autograd of :291-318), flash-style: the logits are recomputed from qn/kn and `lse`.
  *   dout [B,Cv,Nq] -> dqn [B,K,Nq], dkn [B,K,Nk], dv [B,Cv,Nk]
  * It is exposed in stages so that the caller picks the strategy for the key side:
- *   prepare        dvec[b,i] = sum_c dout[b,c,i] * out[b,c,i]                      (always first)
+ *   prepare        dvec[b,i] = sum_c dout[b,c,i] * out[b,c,i]      (needed by `key`, and by `query`
+ *                  when it has no saved logits; the saved-logits query kernel computes it itself)
  *   query          dqn; reads the forward's logits_t if given (else recomputes the logits);
  *                  optionally also writes ds_t [B,Nk,Nq] = (dS)^T / T
  *   key            dkn (and dv if non-NULL) with a SECOND recomputation of the logits
@@ -97,7 +98,8 @@ size_t cocos_corr_softmax_warp_bwd_workspace_bytes(int B, int K, int Nq, int Nk,
 int cocos_corr_softmax_warp_bwd_prepare(const float* out, const float* dout, float* dvec,
                                         int B, int Nq, int Cv, cocos_stream_t stream);
 int cocos_corr_softmax_warp_bwd_query(const float* qn, const float* kn, const float* v,
-                                      const float* lse, const float* dout, const float* dvec,
+                                      const float* out, const float* lse, const float* dout,
+                                      const float* dvec /* nullable when logits_t is given */,
                                       const float* logits_t /* nullable: from the forward */,
                                       float* dqn, float* ds_t /* nullable */,
                                       int B, int K, int Nq, int Nk, int Cv, float inv_temperature,

@@ -26,11 +26,13 @@ def _need_gpu(hip_lib):
         pytest.fail("GPU tests selected but no GPU is visible (the HIP path has no fallback)")
 
 
-def rel(x, ref):
+def rel(x, ref, floor=1e-30):
+    """max|x - ref| / (max|ref| + floor).  `floor` is an absolute scale for references that are
+    exactly zero by cancellation (e.g. d theta with a single key: dS = P (dP - D) = 0)."""
     x = x.detach().double().cpu().numpy() if torch.is_tensor(x) else np.asarray(x, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert x.shape == ref.shape, (x.shape, ref.shape)
-    return float(np.abs(x - ref).max() / (np.abs(ref).max() + 1e-30))
+    return float(np.abs(x - ref).max() / (np.abs(ref).max() + floor))
 
 
 def dev(a, grad=False):
@@ -100,9 +102,10 @@ def test_fused_forward_backward_vs_oracle(B, Nq, Nk, Cv, peaked):
     out.backward(dev(g))
     assert not torch.isnan(out).any()
     assert rel(out, out_ref) < OUT_TOL
-    assert rel(q.grad, dq_ref) < OUT_TOL
-    assert rel(k.grad, dk_ref) < OUT_TOL
-    assert rel(vv.grad, dv_ref) < OUT_TOL
+    # gradients of unit-norm features at T = 0.01 are O(1..100); 1e-3 is a safe absolute floor
+    assert rel(q.grad, dq_ref, floor=1e-3) < OUT_TOL
+    assert rel(k.grad, dk_ref, floor=1e-3) < OUT_TOL
+    assert rel(vv.grad, dv_ref, floor=1e-3) < OUT_TOL
 
 
 def test_key_side_strategies_agree(monkeypatch):
