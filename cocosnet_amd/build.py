@@ -40,13 +40,17 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin)")
 
 
+def _flags():
+    return HIP_FLAGS + os.environ.get("COCOS_EXTRA_HIPFLAGS", "").split()
+
+
 def _digest(paths) -> str:
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
             h.update(p.encode())
             h.update(f.read())
-    h.update(" ".join(HIP_FLAGS).encode())
+    h.update(" ".join(_flags()).encode())
     return h.hexdigest()
 
 
@@ -65,7 +69,7 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
-        cmd = [hipcc, *HIP_FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *_flags(), "-c", src, "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

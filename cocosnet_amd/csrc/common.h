@@ -124,6 +124,28 @@ __device__ __forceinline__ void tile_fetch(TileRegs<ROWS>& t, __amdgpu_buffer_rs
     }
 }
 
+// One float4 piece (rows u*32 .. u*32+31) of a tile.  EXACT = false: 16-byte loads with no column
+// check (caller guarantees ncols % 32 == 0, or masks whatever a ragged tile drags in); EXACT = true:
+// per-element bounds (zero fill), chosen per tile with a wave-uniform test.
+template <bool EXACT>
+__device__ __forceinline__ void tile_fetch_piece(f32x4& dst, __amdgpu_buffer_rsrc_t rs, int u,
+                                                 int rows_valid, int ncols, int j0, int tid) {
+    const int row = u * 32 + (tid >> 3), c4 = (tid & 7) * 4;
+    if (!EXACT || j0 + kTileCols <= ncols) {
+        unsigned off = (unsigned)(row * ncols + j0 + c4) * 4u;
+        if (row >= rows_valid) off = kBufOob;
+        dst = buf_load4(rs, off);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = j0 + c4 + e;
+            unsigned off = (unsigned)(row * ncols + col) * 4u;
+            if (row >= rows_valid || col >= ncols) off = kBufOob;
+            dst[e] = buf_load1(rs, off);
+        }
+    }
+}
+
 template <int ROWS>
 __device__ __forceinline__ void tile_commit(const TileRegs<ROWS>& t, float* lds, int tid) {
     float* d0 = lds + (tid >> 3) * kTileLd + (tid & 7) * 4;

@@ -22,7 +22,18 @@ namespace cocos {
 
 constexpr int BQS_LD = kTileLd;
 
-template <int KD, int CVB, bool STORE_DS>
+// Optional phase timing (build with -DCOCOS_DEBUG_TIMING): shader-clock ticks spent by wave 0 of
+// workgroup 0 in each phase of the tile loop, read back with cocos_debug_read_timing().
+#ifdef COCOS_DEBUG_TIMING
+__device__ long long g_phase_ticks[8];
+#define PHASE_T(var) const long long var = __builtin_readcyclecounter()
+#define PHASE_ADD(i, a, b) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_ticks[i] += (b) - (a); } while (0)
+#else
+#define PHASE_T(var) do {} while (0)
+#define PHASE_ADD(i, a, b) do {} while (0)
+#endif
+
+template <int KD, int CVB, bool STORE_DS, bool RAGGED>
 __global__ __launch_bounds__(256, 1) void corr_bwd_query_saved_kernel(
     const float* __restrict__ kn,    // [B,KD,Nk]
     const float* __restrict__ v,     // [B,Cv,Nk]
@@ -64,16 +75,23 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_saved_kernel(
 
     // ---- resident: dO slice (B operand of dP, k = channel pair), D and lse of the lane's query ---
     float gd[CVP / 2];
-    float d_lane = 0.f;
+    float d_lane;
     {
+        // D is subtracted from dP, which is nearly equal to it wherever P is peaked: accumulate it
+        // in fp64 (Cv/2 DFMAs per lane, once per kernel) so that the cancellation only sees dP's
+        // own fp32 rounding, exactly like the reference's softmax backward
+        double dacc = 0.0;
 #pragma unroll
         for (int cc = 0; cc < CVP / 2; ++cc) {
             const int ch = 2 * cc + h;
             const unsigned off = (live && ch < Cv) ? (unsigned)(ch * Nq + i_lane) * 4u : kBufOob;
             gd[cc] = buf_load1(g_rs, off);
-            d_lane += gd[cc] * buf_load1(o_rs, off);
+            dacc += (double)gd[cc] * (double)buf_load1(o_rs, off);
         }
-        d_lane += swap_half(d_lane);          // the other half-wave holds the other channel parity
+        // the other half-wave holds the other channel parity
+        const int lo = __shfl_xor((int)__double2loint(dacc), 32, 64);
+        const int hi = __shfl_xor((int)__double2hiint(dacc), 32, 64);
+        d_lane = (float)(dacc + __hiloint2double(hi, lo));
 #pragma unroll
         for (int cc = 0; cc < CVP / 2; ++cc) asm volatile("" : "+a"(gd[cc]));
     }
@@ -98,14 +116,23 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_saved_kernel(
         if (j0 + kTileCols <= Nk) tile_fetch<CVP, false>(cs, v_rs, Cv, Nk, j0, tid);
         else                      tile_fetch<CVP, true>(cs, v_rs, Cv, Nk, j0, tid);
     };
-    auto fetch_s = [&](int j0) {   // rows past Nk read 0 (bounds check); their P is masked below
-        const bool full = j0 + kTileCols <= Nk;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
+    // rows past Nk read 0 (bounds check); their P is masked in prob()
+    auto fetch_s_piece = [&](int r, int j0) {
+        {
             const int jr = j0 + acc_row_base(r);
-            const bool ok = jr < Nk && (full || jr + 4 * h < Nk);
-            sld[r] = buf_load1s(lg_rs, ok ? sr_lane_off : kBufOob, ok ? (unsigned)jr * (unsigned)Nq * 4u : 0u);
+            // NB: the scalar offset is NOT covered by the descriptor's bounds check (only the
+            // per-lane offset is), so rows that do not exist must be switched off explicitly —
+            // including the whole look-ahead tiles past the end
+            const bool ok = jr + 4 * h < Nk;
+            // the scalar offset must stay provably wave-uniform (a lane-dependent select here makes
+            // hipcc wrap every load in a waterfall loop: measured 4000 cycles per tile); rows that
+            // do not exist are switched off through the per-lane offset instead
+            sld[r] = buf_load1s(lg_rs, ok ? sr_lane_off : kBufOob, (unsigned)jr * (unsigned)Nq * 4u);
         }
+    };
+    auto fetch_s = [&](int j0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fetch_s_piece(r, j0);
     };
     auto commit_piece = [&](const f32x4& x, float* tile, int u) {
         float* d = tile + (u * 32 + (tid >> 3)) * LD + (tid & 7) * 4;
@@ -114,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_saved_kernel(
     // P(t) from the staged logits; keys past Nk (zero-filled K/V rows) must not contribute
     auto prob = [&](int r, int j0) {
         float pv = fast_exp2(sld[r] - lse2);
-        if (j0 + acc_row_base(r) + 4 * h >= Nk) pv = 0.f;
+        if (RAGGED && (j0 + acc_row_base(r) + 4 * h >= Nk)) pv = 0.f;
         return pv;
     };
     // dP tile = V_tile^T . dO  (A from LDS, B = resident dO), operands requested a batch ahead
@@ -177,6 +204,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_saved_kernel(
         float* const c_rd = (t & 1) ? ct0 : ct1;    // V(t+1)
         float* const c_wr = (t & 1) ? ct1 : ct0;    // <- V(t+2)
 
+        PHASE_T(tp0);
         // dS(t) = P(t) * (dP(t) - D)
         f32x16 ds;
 #pragma unroll
@@ -199,16 +227,24 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_saved_kernel(
                 }
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) dx[kb] = mfma32(xa[r & 1][kb], ds[r], dx[kb]);
-                // --- work hidden under this step's 8 MFMAs ---
+                // --- work hidden under this step's 8 MFMAs: one slice of everything, so that no
+                //     phase ever issues a burst of memory instructions (a burst of ~30 loads stalls
+                //     the in-order wave for 2-4k cycles while the L1 miss queue drains) ---
                 p[r] = prob(r, j0 + kTileCols);                         // P(t+1)[r]
+                fetch_s_piece(r, j0 + 2 * kTileCols);                   // S(t+2)[r] into the same register
                 if (STORE_DS) {
                     const int jr = j0 + acc_row_base(r);
-                    const bool ok = (j0 + kTileCols <= Nk) || (jr + 4 * h < Nk);
+                    const bool ok = !RAGGED || (j0 + kTileCols <= Nk) || (jr + 4 * h < Nk);
                     buf_store1s(ds_rs, ds[r] * inv_t, ok ? sr_lane_off : kBufOob,
                                 (unsigned)jr * (unsigned)Nq * 4u);
                 }
-                if (r < KB) commit_piece(xs.r[r], x_wr, r);              // K(t+1)
-                else if (r - KB < CVB) commit_piece(cs.r[r - KB], c_wr, r - KB);   // V(t+2)
+                if (r < KB) {
+                    commit_piece(xs.r[r], x_wr, r);                                        // K(t+1)
+                    tile_fetch_piece<RAGGED>(xs.r[r], k_rs, r, KD, Nk, j0 + 2 * kTileCols, tid);
+                } else if (r - KB < CVB) {
+                    commit_piece(cs.r[r - KB], c_wr, r - KB);                              // V(t+2)
+                    tile_fetch_piece<RAGGED>(cs.r[r - KB], v_rs, r - KB, Cv, Nk, j0 + 3 * kTileCols, tid);
+                }
                 __builtin_amdgcn_sched_group_barrier(0x008, KB / 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, KB, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, KB - KB / 2, 0);
@@ -216,16 +252,16 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_saved_kernel(
             }
         }
 
-        // staging registers are free: next tiles' loads fly for a whole iteration
-        fetch_x(j0 + 2 * kTileCols);
-        fetch_c(j0 + 3 * kTileCols);
-        fetch_s(j0 + 2 * kTileCols);
-
+        PHASE_T(tp1);
+        PHASE_T(tp2);
         // ---- dP(t+1) -------------------------------------------------------------------------------
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[r] = 0.f;
         dp_tile(c_rd, dp);
+        PHASE_T(tp3);
         __syncthreads();
+        PHASE_T(tp4);
+        PHASE_ADD(0, tp0, tp1); PHASE_ADD(1, tp1, tp2); PHASE_ADD(2, tp2, tp3); PHASE_ADD(3, tp3, tp4);
     }
 
     // ---- epilogue --------------------------------------------------------------------------------
@@ -241,11 +277,11 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_saved_kernel(
     }
 }
 
-template <int CVB, bool STORE_DS>
+template <int CVB, bool STORE_DS, bool RAGGED>
 static int launch_saved(const float* kn, const float* v, const float* outp, const float* dout,
                         const float* lse, const float* lg, float* dqn, float* dst, int B, int Nq,
                         int Nk, int Cv, float inv_t, hipStream_t s) {
-    auto kern = corr_bwd_query_saved_kernel<256, CVB, STORE_DS>;
+    auto kern = corr_bwd_query_saved_kernel<256, CVB, STORE_DS, RAGGED>;
     const size_t smem = (size_t)2 * (256 + CVB * 32) * BQS_LD * sizeof(float);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -256,19 +292,42 @@ static int launch_saved(const float* kn, const float* v, const float* outp, cons
     return COCOS_OK;
 }
 
+template <int CVB>
+static int launch_saved_cvb(const float* kn, const float* v, const float* outp, const float* dout,
+                            const float* lse, const float* lg, float* dqn, float* dst, int B, int Nq,
+                            int Nk, int Cv, float inv_t, hipStream_t s) {
+    // grids whose key count is a multiple of the 32-key tile (every power-of-two feature grid)
+    // take the branch-free variant; ragged key counts pay a uniform test per fetched piece
+    const bool ragged = (Nk % kTileCols) != 0;
+#define COCOS_GO(DS, RG) launch_saved<CVB, DS, RG>(kn, v, outp, dout, lse, lg, dqn, dst, B, Nq, Nk, Cv, inv_t, s)
+    if (dst) return ragged ? COCOS_GO(true, true) : COCOS_GO(true, false);
+    return ragged ? COCOS_GO(false, true) : COCOS_GO(false, false);
+#undef COCOS_GO
+}
+
 int launch_bwd_query_saved(const float* kn, const float* v, const float* outp, const float* dout,
                            const float* lse, const float* lg, float* dqn, float* dst, int B, int Nq,
                            int Nk, int Cv, float inv_t, hipStream_t s) {
-#define COCOS_CASE(N)                                                                             \
-    case N:                                                                                       \
-        return dst ? launch_saved<N, true>(kn, v, outp, dout, lse, lg, dqn, dst, B, Nq, Nk, Cv, inv_t, s) \
-                   : launch_saved<N, false>(kn, v, outp, dout, lse, lg, dqn, nullptr, B, Nq, Nk, Cv, inv_t, s);
     switch ((Cv + 31) / 32) {
-        COCOS_CASE(1) COCOS_CASE(2) COCOS_CASE(3) COCOS_CASE(4)
-        default: return dst ? launch_saved<5, true>(kn, v, outp, dout, lse, lg, dqn, dst, B, Nq, Nk, Cv, inv_t, s)
-                            : launch_saved<5, false>(kn, v, outp, dout, lse, lg, dqn, nullptr, B, Nq, Nk, Cv, inv_t, s);
+        case 1: return launch_saved_cvb<1>(kn, v, outp, dout, lse, lg, dqn, dst, B, Nq, Nk, Cv, inv_t, s);
+        case 2: return launch_saved_cvb<2>(kn, v, outp, dout, lse, lg, dqn, dst, B, Nq, Nk, Cv, inv_t, s);
+        case 3: return launch_saved_cvb<3>(kn, v, outp, dout, lse, lg, dqn, dst, B, Nq, Nk, Cv, inv_t, s);
+        case 4: return launch_saved_cvb<4>(kn, v, outp, dout, lse, lg, dqn, dst, B, Nq, Nk, Cv, inv_t, s);
+        default: return launch_saved_cvb<5>(kn, v, outp, dout, lse, lg, dqn, dst, B, Nq, Nk, Cv, inv_t, s);
     }
-#undef COCOS_CASE
 }
 
 }  // namespace cocos
+
+#ifdef COCOS_DEBUG_TIMING
+extern "C" int cocos_debug_read_timing(long long* host8, int reset) {
+    using namespace cocos;
+    COCOS_HIP_CHECK(hipDeviceSynchronize());
+    COCOS_HIP_CHECK(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_phase_ticks), 8 * sizeof(long long)));
+    if (reset) {
+        long long z[8] = {0};
+        COCOS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z)));
+    }
+    return COCOS_OK;
+}
+#endif

@@ -102,10 +102,13 @@ def test_fused_forward_backward_vs_oracle(B, Nq, Nk, Cv, peaked):
     out.backward(dev(g))
     assert not torch.isnan(out).any()
     assert rel(out, out_ref) < OUT_TOL
-    # gradients of unit-norm features at T = 0.01 are O(1..100); 1e-3 is a safe absolute floor
-    assert rel(q.grad, dq_ref, floor=1e-3) < OUT_TOL
-    assert rel(k.grad, dk_ref, floor=1e-3) < OUT_TOL
-    assert rel(vv.grad, dv_ref, floor=1e-3) < OUT_TOL
+    # Gradients of diffuse rows are O(1..100).  Where P is peaked (or there is a single key) the true
+    # gradient is ~0 by cancellation, dS = P (dP - D) with dP ~= D, and what is left is the fp32
+    # rounding of dP itself: eps * sum_c|g v| * inv_t * |k| ~ 1e-5..1e-4 absolute — the reference's
+    # fp32 softmax backward has the same residue.  floor = 0.5 turns OUT_TOL into 1e-4 absolute there.
+    assert rel(q.grad, dq_ref, floor=0.5) < OUT_TOL
+    assert rel(k.grad, dk_ref, floor=0.5) < OUT_TOL
+    assert rel(vv.grad, dv_ref, floor=0.05) < OUT_TOL
 
 
 def test_key_side_strategies_agree(monkeypatch):
