@@ -29,7 +29,7 @@ constexpr int FWD_BK = kTileCols;    // key positions per tile
 constexpr int FWD_LD = kTileLd;      // LDS row stride (floats)
 constexpr float kRescaleThr = 8.0f;  // log2 units: rescale only when a row max grows by > 2^8
 
-template <int KD, int CVB, bool STORE_S>
+template <int KD, int CVB, bool STORE_S, bool RAGGED>
 __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
     const float* __restrict__ qn, const float* __restrict__ kn, const float* __restrict__ v,
     float* __restrict__ out, float* __restrict__ lse,
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
 
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * FWD_BK;
-        const bool ragged = (j0 + FWD_BK > Nk);
+        const bool ragged = RAGGED && (j0 + FWD_BK > Nk);
         float* const k_rd = (t & 1) ? kt0 : kt1;    // K(t+1)
         float* const k_wr = (t & 1) ? kt1 : kt0;    // <- K(t+2)
         float* const v_rd = (t & 1) ? vt1 : vt0;    // V(t)
@@ -190,10 +190,19 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
 
         // batches 0..3: scale + mask + row max of S(t), four accumulator registers per batch;
         // batches 3..15: one staged piece per batch goes to LDS (8 K pieces, then CVB V pieces)
+        // ... and as soon as a staged piece is in LDS its registers take the next load (K three
+        // tiles ahead, V two): memory instructions are issued one at a time under the MFMAs, never
+        // as a burst (a burst of a dozen 1 KiB loads stalls the in-order wave for thousands of
+        // cycles while the L1 miss queue drains)
         auto commit_hook = [&](int bt) {
             const int u = bt - 3;
-            if (u >= 0 && u < KD / 32) commit_piece(ks.r[u], k_wr, u);
-            else if (u >= KD / 32 && u - KD / 32 < CVB) commit_piece(vs.r[u - KD / 32], v_wr, u - KD / 32);
+            if (u >= 0 && u < KD / 32) {
+                commit_piece(ks.r[u], k_wr, u);
+                tile_fetch_piece<RAGGED>(ks.r[u], k_rs, u, KD, Nk, j0 + 3 * FWD_BK, tid);
+            } else if (u >= KD / 32 && u - KD / 32 < CVB) {
+                commit_piece(vs.r[u - KD / 32], v_wr, u - KD / 32);
+                tile_fetch_piece<RAGGED>(vs.r[u - KD / 32], v_rs, u - KD / 32, Cv, Nk, j0 + 2 * FWD_BK, tid);
+            }
         };
         qk_tile(k_rd, sn, [&](int bt) {
 #pragma unroll
@@ -244,11 +253,6 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
         }, 4, NBATCH, a);
         l_run += psum;
 
-        // staging registers are free again: next tiles' loads fly under the P.V MFMAs and the
-        // whole next iteration
-        fetch_k(j0 + 3 * FWD_BK);
-        fetch_v(j0 + 2 * FWD_BK);
-
         // ---- O^T += V^T . P^T : A = V^T[ch][key] from LDS, B = P^T (accumulator registers) --
         {
             const float* vl = v_rd + c * FWD_LD + 4 * h;
@@ -293,10 +297,10 @@ __global__ __launch_bounds__(256, 1) void corr_softmax_warp_fwd_kernel(
     }
 }
 
-template <int KD, int CVB, bool STORE_S>
+template <int KD, int CVB, bool STORE_S, bool RAGGED>
 static int launch_fwd_k(const float* qn, const float* kn, const float* v, float* out, float* lse,
                         float* lg, int B, int Nq, int Nk, int Cv, float inv_t, hipStream_t stream) {
-    auto kern = corr_softmax_warp_fwd_kernel<KD, CVB, STORE_S>;
+    auto kern = corr_softmax_warp_fwd_kernel<KD, CVB, STORE_S, RAGGED>;
     const size_t smem = (size_t)2 * (KD + CVB * 32) * FWD_LD * sizeof(float);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -310,8 +314,13 @@ static int launch_fwd_k(const float* qn, const float* kn, const float* v, float*
 template <int KD, int CVB>
 static int launch_fwd(const float* qn, const float* kn, const float* v, float* out, float* lse,
                       float* lg, int B, int Nq, int Nk, int Cv, float inv_t, hipStream_t stream) {
-    return lg ? launch_fwd_k<KD, CVB, true>(qn, kn, v, out, lse, lg, B, Nq, Nk, Cv, inv_t, stream)
-              : launch_fwd_k<KD, CVB, false>(qn, kn, v, out, lse, nullptr, B, Nq, Nk, Cv, inv_t, stream);
+    // key counts that are a multiple of the 32-key tile (every power-of-two grid) get the variant
+    // without any ragged-tile test
+    const bool ragged = (Nk % FWD_BK) != 0;
+#define COCOS_GO(ST, RG) launch_fwd_k<KD, CVB, ST, RG>(qn, kn, v, out, lse, lg, B, Nq, Nk, Cv, inv_t, stream)
+    if (lg) return ragged ? COCOS_GO(true, true) : COCOS_GO(true, false);
+    return ragged ? COCOS_GO(false, true) : COCOS_GO(false, false);
+#undef COCOS_GO
 }
 
 }  // namespace cocos
