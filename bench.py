@@ -198,11 +198,23 @@ def main():
                                 "alg_tflops": round(flops / ms / 1e9, 2),
                                 "frac_fp32_mfma_peak": round(flops / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
+        # WRITE_SIZE, MI355X_MICROARCH.md), committed under profiles/ — they cannot be read live
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(REPO, "profiles", "r01_pmc_final.json")
+        pmc_key = {"corr_softmax_warp_fwd": "corr_softmax_warp_fwd_kernel<256, 5, true",
+                   "corr_softmax_warp_bwd_query": "corr_bwd_query_saved_kernel<256, 5, true",
+                   "corr_softmax_warp_bwd_key_from_ds": "sgemm_mfma_kernel<true, true>"}
+        if dom in pmc_key and os.path.exists(pmc_file):
+            for name, rec in json.load(open(pmc_file)).items():
+                if pmc_key[dom] in name:
+                    traffic, traffic_src = rec["hbm_bytes"], "profiles/r01_pmc_final.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes)"
         roofline = None
         if dom:
             roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["alg_tflops"],
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": kernels[dom]["frac_fp32_mfma_peak"], "traffic": None,
+                        "frac": kernels[dom]["frac_fp32_mfma_peak"], "traffic": traffic,
+                        "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                         "avg_launch_ms": kernels[dom]["avg_ms"],
                         "note": "algorithmic FLOPs per launch / HIP-event time on torch's current "
                                 "stream; peak = dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
