@@ -156,6 +156,120 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_kernel(
     }
 }
 
+// ---- register-resident PONO_C variants (K <= 512, K % 16 == 0, N % 4 == 0) ------------------------
+// A workgroup owns 64 consecutive positions; thread (pq = tid & 15, cg = tid >> 4) keeps the float4
+// of positions 4pq..4pq+3 for its K/16 channels in registers, so x (and dy, y) cross HBM exactly once;
+// the per-position sums over channels go through a 16 x 64 LDS reduction.
+constexpr int CNR_MAXI = 32;   // K / 16 <= 32
+
+template <int NQ>
+__device__ __forceinline__ void reduce_cg(f32x4 (&v)[NQ], float* red /*[NQ][16][64]*/, int cg, int pq) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) *reinterpret_cast<f32x4*>(red + (q * 16 + cg) * 64 + pq * 4) = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc += *reinterpret_cast<const f32x4*>(red + (q * 16 + g) * 64 + pq * 4);
+        v[q] = acc;
+    }
+}
+
+template <int NI>   // NI = K / 16
+__global__ __launch_bounds__(256) void center_l2norm_fwd_reg_kernel(const float* __restrict__ x,
+                                                                    float* __restrict__ y,
+                                                                    float* __restrict__ norm_out, int K,
+                                                                    int N, float eps) {
+    __shared__ __attribute__((aligned(16))) float red[16 * 64];
+    const int tid = threadIdx.x, pq = tid & 15, cg = tid >> 4;
+    const int b = blockIdx.y, n = blockIdx.x * 64 + pq * 4;
+    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(x + (size_t)b * K * N, (size_t)K * N * 4);
+    const bool ok = n < N;   // N % 4 == 0: a float4 is entirely in or out
+    f32x4 v[NI];
+    f32x4 s[1] = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        v[i] = buf_load4(x_rs, ok ? (unsigned)((cg + 16 * i) * N + n) * 4u : kBufOob);
+        s[0] += v[i];
+    }
+    reduce_cg<1>(s, red, cg, pq);
+    const f32x4 mean = s[0] * (1.0f / (float)K);
+    f32x4 ss[1] = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        v[i] -= mean;
+        ss[0] += v[i] * v[i];
+    }
+    reduce_cg<1>(ss, red, cg, pq);
+    f32x4 nrm, u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { nrm[e] = sqrtf(ss[0][e]); u[e] = 1.0f / (nrm[e] + eps); }
+    if (!ok) return;
+    float* yb = y + (size_t)b * K * N;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        *reinterpret_cast<f32x4*>(yb + (size_t)(cg + 16 * i) * N + n) = v[i] * u;
+    if (cg == 0) *reinterpret_cast<f32x4*>(norm_out + (size_t)b * N + n) = nrm;
+}
+
+template <int NI>
+__global__ __launch_bounds__(256) void center_l2norm_bwd_reg_kernel(const float* __restrict__ y,
+                                                                    const float* __restrict__ nrm_in,
+                                                                    const float* __restrict__ dy,
+                                                                    float* __restrict__ dx, int K, int N,
+                                                                    float eps) {
+    __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
+    const int tid = threadIdx.x, pq = tid & 15, cg = tid >> 4;
+    const int b = blockIdx.y, n = blockIdx.x * 64 + pq * 4;
+    const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(y + (size_t)b * K * N, (size_t)K * N * 4);
+    const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(dy + (size_t)b * K * N, (size_t)K * N * 4);
+    const bool ok = n < N;
+    f32x4 yy[NI], gg[NI];
+    f32x4 s[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const unsigned off = ok ? (unsigned)((cg + 16 * i) * N + n) * 4u : kBufOob;
+        yy[i] = buf_load4(y_rs, off);
+        gg[i] = buf_load4(g_rs, off);
+        s[0] += gg[i] * yy[i];
+        s[1] += gg[i];
+        s[2] += yy[i];
+    }
+    reduce_cg<3>(s, red, cg, pq);
+    if (!ok) return;
+    const f32x4 nrm = *reinterpret_cast<const f32x4*>(nrm_in + (size_t)b * N + n);
+    f32x4 u, g, m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u[e] = 1.0f / (nrm[e] + eps);
+        g[e] = nrm[e] > 0.f ? s[0][e] / nrm[e] : 0.f;
+        m[e] = (u[e] * s[1][e] - g[e] * s[2][e]) / (float)K;
+    }
+    float* dxb = dx + (size_t)b * K * N;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        *reinterpret_cast<f32x4*>(dxb + (size_t)(cg + 16 * i) * N + n) = u * gg[i] - g * yy[i] - m;
+}
+
+template <bool BWD>
+static bool launch_reg_variant(const float* a, const float* nrm_in, const float* dy, float* out,
+                               float* norm_out, int B, int K, int N, float eps, hipStream_t s) {
+    if (K % 16 != 0 || K / 16 > CNR_MAXI || N % 4 != 0 || !aligned16(a) || !aligned16(out)) return false;
+    const dim3 grid((N + 63) / 64, B);
+#define COCOS_NI(NI)                                                                                     \
+    case NI:                                                                                             \
+        if (BWD) hipLaunchKernelGGL(center_l2norm_bwd_reg_kernel<NI>, grid, dim3(256), 0, s, a, nrm_in, dy, out, K, N, eps); \
+        else hipLaunchKernelGGL(center_l2norm_fwd_reg_kernel<NI>, grid, dim3(256), 0, s, a, out, norm_out, K, N, eps);      \
+        return true;
+    switch (K / 16) {
+        COCOS_NI(1) COCOS_NI(2) COCOS_NI(4) COCOS_NI(8) COCOS_NI(16) COCOS_NI(32)
+        default: return false;
+    }
+#undef COCOS_NI
+}
+
 }  // namespace cocos
 
 extern "C" int cocos_center_l2norm_fwd(const float* x, float* y, float* norm, float* row_ws, int B,
@@ -168,8 +282,9 @@ extern "C" int cocos_center_l2norm_fwd(const float* x, float* y, float* norm, fl
     hipStream_t s = as_stream(stream);
     const dim3 grid((N + CN_POS - 1) / CN_POS, B);
     if (center_over_channels) {
-        hipLaunchKernelGGL(center_l2norm_fwd_kernel<true>, grid, dim3(256), 0, s, x, y, norm,
-                           (const float*)nullptr, K, N, eps);
+        if (!launch_reg_variant<false>(x, nullptr, nullptr, y, norm, B, K, N, eps, s))
+            hipLaunchKernelGGL(center_l2norm_fwd_kernel<true>, grid, dim3(256), 0, s, x, y, norm,
+                               (const float*)nullptr, K, N, eps);
     } else {
         COCOS_REQUIRE(row_ws, COCOS_ERR_INVALID,
                       "center_l2norm_fwd: row_ws [B*K] required when centring over positions");
@@ -194,8 +309,9 @@ extern "C" int cocos_center_l2norm_bwd(const float* y, const float* norm, const 
     hipStream_t s = as_stream(stream);
     const dim3 grid((N + CN_POS - 1) / CN_POS, B);
     if (center_over_channels) {
-        hipLaunchKernelGGL((center_l2norm_bwd_kernel<true, 1>), grid, dim3(256), 0, s, y, norm, dy,
-                           dx, (float*)nullptr, (const float*)nullptr, K, N, eps);
+        if (!launch_reg_variant<true>(y, norm, dy, dx, nullptr, B, K, N, eps, s))
+            hipLaunchKernelGGL((center_l2norm_bwd_kernel<true, 1>), grid, dim3(256), 0, s, y, norm,
+                               dy, dx, (float*)nullptr, (const float*)nullptr, K, N, eps);
     } else {
         COCOS_REQUIRE(col_ws && row_ws, COCOS_ERR_INVALID,
                       "center_l2norm_bwd: col_ws [B*N] and row_ws [B*K] required");
