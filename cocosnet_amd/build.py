@@ -27,6 +27,8 @@ HIP_SOURCES = [
     "corr_fused_bwd.hip",
     "corr_fused_bwd_saved.hip",
     "sgemm_mfma.hip",
+    "box3_unfold.hip",
+    "logits_softmax_warp.hip",
     "row_softmax.hip",
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",

@@ -1,0 +1,253 @@
+// match_kernel = 3 without the 9x blow-up (gfx950).
+//
+// The reference unfolds theta/phi into their zero-padded 3x3 neighbourhoods BEFORE centring and
+// normalising (correspondence.py:276-280, :286-289), i.e. K = 256*9 = 2304 channels, 9x the
+// memory and 9x the GEMM FLOPs of match_kernel 1.  With U_p the unfolded vector at position p:
+//
+//     <U_p, V_q> = sum_{d in 3x3} C_raw[p+d, q+d] * [p+d inside] * [q+d inside],   C_raw = theta_b^T phi_b
+//
+// (a 9-tap box filter ALONG THE DIAGONAL of the plain K = 256 correlation matrix), and centring +
+// normalising after the unfold is a rank-1 correction and two per-position scales (PONO_C case):
+//
+//     f[p,q] = ( boxdiag(C_raw)[p,q] - K mu_p nu_q ) * a_p * b_q,
+//     mu_p = mean(U_p), a_p = 1 / (||U_p - mu_p|| + eps)   (3x3 box sums of per-position channel sums /
+//     sums of squares — tiny [B,1,h,w] maps the host computes), nu_q, b_q likewise for phi.
+//
+// Verified against the unfolded formulation to 6e-16 in fp64 (oracle test).  boxdiag
+// is self-adjoint, so the backward uses the SAME kernel on G*a_p*b_q; the remaining gradients are
+// row / column reductions of G and G*f (box3_bwd_reduce).  Both kernels are HBM/L2-bound streaming
+// kernels: each output reads 9 diagonal neighbours (row segments, coalesced, L2-resident: the 64 MiB
+// matrix of a sample fits the 256 MiB Infinity Cache).
+#include "common.h"
+
+namespace cocos {
+
+// PRE = false (forward):  out = (boxdiag(in) - kc*mu_p*nu_q) * a_p * b_q * post
+// PRE = true  (backward): out = boxdiag(in * a_p * b_q * post)      (weights taken at the SOURCE element)
+template <bool PRE>
+__global__ __launch_bounds__(256) void box3_diag_kernel(const float* __restrict__ in,
+                                                        float* __restrict__ out,
+                                                        const float* __restrict__ mu,
+                                                        const float* __restrict__ nu,
+                                                        const float* __restrict__ av,
+                                                        const float* __restrict__ bv, int N, int h, int w,
+                                                        float kc, float post) {
+    const int b = blockIdx.z, p = blockIdx.y;
+    const int q0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (q0 >= N) return;
+    const int py = p / w, px = p - py * w;
+    const __amdgpu_buffer_rsrc_t in_rs = make_rsrc(in + (size_t)b * N * N, (size_t)N * N * 4);
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(bv + (size_t)b * N, (size_t)N * 4);
+    const float* a_b = av + (size_t)b * N;
+
+    int qy[4], qx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int q = q0 + e;
+        qy[e] = q / w;
+        qx[e] = q - qy[e] * w;
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            if ((unsigned)(py + dy) >= (unsigned)h || (unsigned)(px + dx) >= (unsigned)w) continue;   // uniform
+            const int sh = dy * w + dx;
+            const int ps = p + sh;
+            // 16-byte load at a 4-byte-aligned address; entries dragged in from outside the row /
+            // matrix are masked below (or come back 0 from the descriptor's bounds check)
+            const long long off = ((long long)ps * N + q0 + sh) * 4;
+            f32x4 x = (off >= 0) ? buf_load4(in_rs, (unsigned)off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (off < 0) {   // first row(s): the leading elements would sit before the matrix
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    x[e] = (off + 4 * e >= 0) ? buf_load1(in_rs, (unsigned)(off + 4 * e)) : 0.f;
+            }
+            f32x4 wgt = {1.f, 1.f, 1.f, 1.f};
+            if (PRE) {
+                const float as = a_b[ps] * post;
+                const long long boff = (long long)(q0 + sh) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    wgt[e] = as * ((boff + 4 * e >= 0) ? buf_load1(b_rs, (unsigned)(boff + 4 * e)) : 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = (unsigned)(qy[e] + dy) < (unsigned)h && (unsigned)(qx[e] + dx) < (unsigned)w;
+                acc[e] += ok ? x[e] * wgt[e] : 0.f;
+            }
+        }
+    }
+    if (!PRE) {
+        const float mp = mu[(size_t)b * N + p] * kc, ap = a_b[p] * post;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int q = q0 + e;
+            if (q < N) acc[e] = (acc[e] - mp * nu[(size_t)b * N + q]) * ap * bv[(size_t)b * N + q];
+        }
+    }
+    float* o = out + ((size_t)b * N + p) * N + q0;
+    if (q0 + 3 < N && (N & 3) == 0) {
+        *reinterpret_cast<f32x4*>(o) = acc;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (q0 + e < N) o[e] = acc[e];
+    }
+}
+
+// One pass over G (gradient w.r.t. the logits) and F (the forward's output) producing
+//   row sums   r1[p] = sum_q G[p,q] * b_q * nu_q      r2[p] = sum_q G[p,q] * F[p,q]
+//   col sums   c1[q] = sum_p G[p,q] * a_p * mu_p      c2[q] = sum_p G[p,q] * F[p,q]
+// A workgroup takes BX_RB rows x 1024 columns (one float4 of columns per thread): column sums are
+// thread-local over the rows, row sums are wave reductions parked in LDS (one barrier per
+// workgroup, none per row).  Both come out as partials — rows [N][N/1024], columns [N/BX_RB][N] —
+// and box3_finish_kernel adds them up: no atomics, deterministic.
+constexpr int BX_RB = 16;
+
+__global__ __launch_bounds__(256) void box3_bwd_reduce_kernel(
+    const float* __restrict__ G, const float* __restrict__ F, const float* __restrict__ mu,
+    const float* __restrict__ nu, const float* __restrict__ av, const float* __restrict__ bv,
+    float* __restrict__ r1p, float* __restrict__ r2p, float* __restrict__ c1p, float* __restrict__ c2p,
+    int N, int nchunk, int nrb) {
+    __shared__ float red[BX_RB][4][2];
+    const int b = blockIdx.z, rb = blockIdx.y, chunk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = chunk * 1024 + tid * 4;
+    const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(G + (size_t)b * N * N, (size_t)N * N * 4);
+    const __amdgpu_buffer_rsrc_t f_rs = make_rsrc(F + (size_t)b * N * N, (size_t)N * N * 4);
+    const float* mu_b = mu + (size_t)b * N;
+    const float* a_b = av + (size_t)b * N;
+    f32x4 wq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (q0 + e < N) wq[e] = bv[(size_t)b * N + q0 + e] * nu[(size_t)b * N + q0 + e];
+    const bool vec = (N & 3) == 0;
+    f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, c2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int i = 0; i < BX_RB; ++i) {
+        const int p = rb * BX_RB + i;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f}, f = {0.f, 0.f, 0.f, 0.f};
+        float amu = 0.f;
+        if (p < N) {   // uniform
+            amu = a_b[p] * mu_b[p];
+            if (vec) {
+                const unsigned off = q0 < N ? (unsigned)((size_t)p * N + q0) * 4u : kBufOob;
+                g = buf_load4(g_rs, off);
+                f = buf_load4(f_rs, off);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned off = q0 + e < N ? (unsigned)((size_t)p * N + q0 + e) * 4u : kBufOob;
+                    g[e] = buf_load1(g_rs, off);
+                    f[e] = buf_load1(f_rs, off);
+                }
+            }
+        }
+        c1 += g * amu;
+        c2 += g * f;
+        float s1 = g.x * wq.x + g.y * wq.y + g.z * wq.z + g.w * wq.w;
+        float s2 = g.x * f.x + g.y * f.y + g.z * f.z + g.w * f.w;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (lane == 0) { red[i][wave][0] = s1; red[i][wave][1] = s2; }
+    }
+    __syncthreads();
+    if (tid < BX_RB) {
+        const int p = rb * BX_RB + tid;
+        if (p < N) {
+            r1p[((size_t)b * N + p) * nchunk + chunk] = red[tid][0][0] + red[tid][1][0] + red[tid][2][0] + red[tid][3][0];
+            r2p[((size_t)b * N + p) * nchunk + chunk] = red[tid][0][1] + red[tid][1][1] + red[tid][2][1] + red[tid][3][1];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (q0 + e < N) {
+            c1p[((size_t)b * nrb + rb) * N + q0 + e] = c1[e];
+            c2p[((size_t)b * nrb + rb) * N + q0 + e] = c2[e];
+        }
+}
+
+// rows: r[p] = sum over column chunks; columns: c[q] = sum over row blocks
+__global__ __launch_bounds__(256) void box3_finish_kernel(const float* __restrict__ r1p,
+                                                          const float* __restrict__ r2p,
+                                                          const float* __restrict__ c1p,
+                                                          const float* __restrict__ c2p,
+                                                          float* __restrict__ r1, float* __restrict__ r2,
+                                                          float* __restrict__ c1, float* __restrict__ c2,
+                                                          int N, int nchunk, int nrb) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+        s1 += r1p[((size_t)b * N + i) * nchunk + k];
+        s2 += r2p[((size_t)b * N + i) * nchunk + k];
+    }
+    r1[(size_t)b * N + i] = s1;
+    r2[(size_t)b * N + i] = s2;
+    s1 = 0.f; s2 = 0.f;
+    for (int r = 0; r < nrb; ++r) {
+        s1 += c1p[((size_t)b * nrb + r) * N + i];
+        s2 += c2p[((size_t)b * nrb + r) * N + i];
+    }
+    c1[(size_t)b * N + i] = s1;
+    c2[(size_t)b * N + i] = s2;
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_box3_logits_fwd(const float* c_raw, const float* mu, const float* nu,
+                                     const float* a, const float* b, float* f, int B, int h, int w,
+                                     float k_unfolded, float scale, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(c_raw && mu && nu && a && b && f, COCOS_ERR_INVALID, "box3_logits_fwd: null pointer");
+    COCOS_REQUIRE(B >= 1 && h >= 1 && w >= 1 && B <= 65535, COCOS_ERR_INVALID,
+                  "box3_logits_fwd: bad dims B=%d h=%d w=%d", B, h, w);
+    const long long N = (long long)h * w;
+    COCOS_REQUIRE(N <= 65535 && N * N * 4 < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED,
+                  "box3_logits_fwd: grid %dx%d too large (per-sample matrix must stay below 2 GiB)", h, w);
+    const dim3 grid((unsigned)((N + 1023) / 1024), (unsigned)N, B);
+    hipLaunchKernelGGL(box3_diag_kernel<false>, grid, dim3(256), 0, as_stream(stream), c_raw, f, mu, nu,
+                       a, b, (int)N, h, w, k_unfolded, scale);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" size_t cocos_box3_logits_bwd_workspace_bytes(int B, int h, int w) {
+    const size_t N = (size_t)h * w;
+    const size_t nrb = (N + cocos::BX_RB - 1) / cocos::BX_RB, nchunk = (N + 1023) / 1024;
+    return 2 * (size_t)B * (nrb * N + N * nchunk) * sizeof(float);
+}
+
+extern "C" int cocos_box3_logits_bwd(const float* g, const float* f, const float* mu, const float* nu,
+                                     const float* a, const float* b, float* dc_raw, float* r1, float* r2,
+                                     float* c1, float* c2, void* ws, size_t ws_bytes, int B, int h, int w,
+                                     float scale, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(g && f && mu && nu && a && b && dc_raw && r1 && r2 && c1 && c2, COCOS_ERR_INVALID,
+                  "box3_logits_bwd: null pointer");
+    COCOS_REQUIRE(B >= 1 && h >= 1 && w >= 1 && B <= 65535, COCOS_ERR_INVALID,
+                  "box3_logits_bwd: bad dims B=%d h=%d w=%d", B, h, w);
+    const long long N = (long long)h * w;
+    COCOS_REQUIRE(N <= 65535 && N * N * 4 < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED,
+                  "box3_logits_bwd: grid %dx%d too large", h, w);
+    COCOS_REQUIRE(ws && ws_bytes >= cocos_box3_logits_bwd_workspace_bytes(B, h, w), COCOS_ERR_WORKSPACE,
+                  "box3_logits_bwd: workspace too small (%zu bytes)", ws_bytes);
+    hipStream_t s = as_stream(stream);
+    const int nrb = (int)((N + BX_RB - 1) / BX_RB), nchunk = (int)((N + 1023) / 1024);
+    float* c1p = static_cast<float*>(ws);
+    float* c2p = c1p + (size_t)B * nrb * N;
+    float* r1p = c2p + (size_t)B * nrb * N;
+    float* r2p = r1p + (size_t)B * N * nchunk;
+    const dim3 grid((unsigned)nchunk, (unsigned)N, B);
+    hipLaunchKernelGGL(box3_diag_kernel<true>, grid, dim3(256), 0, s, g, dc_raw, mu, nu, a, b, (int)N, h, w,
+                       0.f, scale);
+    hipLaunchKernelGGL(box3_bwd_reduce_kernel, dim3(nchunk, nrb, B), dim3(256), 0, s, g, f, mu, nu, a, b,
+                       r1p, r2p, c1p, c2p, (int)N, nchunk, nrb);
+    hipLaunchKernelGGL(box3_finish_kernel, dim3((unsigned)((N + 255) / 256), B), dim3(256), 0, s,
+                       (const float*)r1p, (const float*)r2p, (const float*)c1p, (const float*)c2p, r1, r2,
+                       c1, c2, (int)N, nchunk, nrb);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}

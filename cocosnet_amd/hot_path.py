@@ -81,38 +81,97 @@ def _upsample(y, down, bilinear):
 
 
 class _Attention:
-    """The two softmax directions of one correlation, fused or materialised."""
+    """The two softmax directions of one correlation.  Three back ends:
+       fused      K = 256 logits computed inside the kernels (match_kernel 1);
+       streamed   logits materialised once per orientation, softmax + warp fused (match_kernel 3);
+       generic    materialised logits -> row softmax -> GEMM (return_corr / WTA / everything else)."""
 
-    def __init__(self, qn, kn, inv_t, wta_scale_weight, fused):
+    def __init__(self, qn=None, kn=None, inv_t=1.0, f_scaled=None, logits_q=None, logits_k=None):
         self.qn, self.kn, self.inv_t = qn, kn, inv_t
-        self.fused = fused
-        self._p_row = self._p_col = self._f = None
-        if not fused:
-            if wta_scale_weight == 1:
-                self._f = ops.corr_materialize(qn, kn, inv_t)              # :291 + :304
-            else:
-                f = ops.corr_materialize(qn, kn, 1.0)                      # :291
-                self._f = _WTAScale.apply(f, wta_scale_weight) * inv_t     # :303-304
+        self.fused = qn is not None
+        self._f = f_scaled
+        self._lq, self._lk = logits_q, logits_k      # providers: query-major f / key-major f^T
+        self._cache = {}
+
+    def _get(self, name, fn):
+        if name not in self._cache:
+            self._cache[name] = fn()
+        return self._cache[name]
 
     @property
     def f_scaled(self):
-        return self._f
+        return self._f if self._f is not None else self._get("lq", self._lq)
 
     def rows(self, v):
         """softmax over exemplar positions, then @ v   (f_div_C @ v, :307/:318)."""
         if self.fused:
             return ops.corr_softmax_warp(self.qn, self.kn, v, self.inv_t)
-        if self._p_row is None:
-            self._p_row = ops.row_softmax(self._f)
-        return ops.warp_materialized(self._p_row, v)
+        if self._lk is not None:
+            return ops.logits_softmax_warp(self._get("lk", self._lk), v)
+        return ops.warp_materialized(self._get("p_row", lambda: ops.row_softmax(self._f)), v)
 
     def cols(self, v):
         """softmax over content positions of f^T, then @ v   (f_div_C_v @ v, :338/:351)."""
         if self.fused:
             return ops.corr_softmax_warp(self.kn, self.qn, v, self.inv_t)
-        if self._p_col is None:
-            self._p_col = ops.row_softmax(self._f.transpose(1, 2).contiguous())
-        return ops.warp_materialized(self._p_col, v)
+        if self._lq is not None:   # f itself is the key-major logit matrix of the swapped problem
+            return ops.logits_softmax_warp(self._get("lq", self._lq), v)
+        return ops.warp_materialized(
+            self._get("p_col", lambda: ops.row_softmax(self._f.transpose(1, 2).contiguous())), v)
+
+
+def _box_sum3(x):
+    """zero-padded 3x3 box SUM of a [B,1,h,w] map."""
+    return F.avg_pool2d(x, 3, stride=1, padding=1, divisor_override=1)
+
+
+def _unfold3_stats(x_raw, k_unfolded):
+    """mean and 1/(norm+eps) of the zero-padded 3x3-unfolded, centred vectors of x_raw [B,C,h,w]
+    WITHOUT unfolding: box sums of the per-position channel sums / sums of squares (:276-280)."""
+    s1 = x_raw.sum(dim=1, keepdim=True)
+    s2 = (x_raw * x_raw).sum(dim=1, keepdim=True)
+    mu = _box_sum3(s1) / k_unfolded
+    nrm = torch.sqrt(torch.clamp(_box_sum3(s2) - k_unfolded * mu * mu, min=0.0))
+    B = x_raw.shape[0]
+    return mu.reshape(B, -1), (1.0 / (nrm + ops.NORM_EPS)).reshape(B, -1)
+
+
+def _box3_logits(theta_raw, phi_raw, scale, transposed=False):
+    """match_kernel 3, PONO_C: f (or f^T) * scale from the K = 256 correlation, no unfold (K6)."""
+    B, C, fh, fw = theta_raw.shape
+    kc = float(C * 9)
+    mu, a = _unfold3_stats(theta_raw, kc)
+    nu, b = _unfold3_stats(phi_raw, kc)
+    if transposed:   # f^T[q,p]: the same operator with the roles of theta and phi exchanged
+        c_raw = ops.corr_materialize(_flat(phi_raw), _flat(theta_raw), 1.0)
+        return ops.box3_logits(c_raw, nu, mu, b, a, fh, fw, kc, scale)
+    c_raw = ops.corr_materialize(_flat(theta_raw), _flat(phi_raw), 1.0)
+    return ops.box3_logits(c_raw, mu, nu, a, b, fh, fw, kc, scale)
+
+
+def _scaled_logits(theta_raw, phi_raw, cfg, inv_t, detach_flag, wta):
+    """Materialised, query-major f_WTA / temperature (:272-304) for the generic back end."""
+    mk = cfg.match_kernel
+    wta_on = wta != 1
+    pre_scaled = not (wta_on or detach_flag)
+    if mk == 3 and cfg.PONO_C:
+        f = _box3_logits(theta_raw, phi_raw, inv_t if pre_scaled else 1.0)
+    else:
+        if mk == 1:
+            theta, phi = _flat(theta_raw), _flat(phi_raw)
+        else:
+            theta = F.unfold(theta_raw, kernel_size=mk, padding=mk // 2)
+            phi = F.unfold(phi_raw, kernel_size=mk, padding=mk // 2)
+        qn = ops.center_l2norm(theta, cfg.PONO_C)
+        kn = ops.center_l2norm(phi, cfg.PONO_C)
+        f = ops.corr_materialize(qn, kn, inv_t if pre_scaled else 1.0)      # :291 (+ :304)
+    if pre_scaled:
+        return f
+    if detach_flag:                                                          # :292-293
+        f = f.detach()
+    if wta_on:
+        f = _WTAScale.apply(f, wta)                                          # :300-303
+    return f * inv_t                                                         # :304
 
 
 def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_seg_map,
@@ -127,19 +186,25 @@ def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_
     down, mk = cfg.down, cfg.match_kernel
     out = {}
 
-    # :272-289 — flatten / implicit 3x3 neighbourhood, centre, L2-normalise
-    if mk == 1:
-        theta, phi = _flat(theta_raw), _flat(phi_raw)
+    inv_t = 1.0 / temperature
+    fused = (mk == 1) and (C == ops.FUSED_K) and WTA_scale_weight == 1 and not return_corr
+    if fused:
+        # :272-289 — flatten, centre, L2-normalise; the rest happens inside the fused kernels
+        qn = ops.center_l2norm(_flat(theta_raw), cfg.PONO_C)
+        kn = ops.center_l2norm(_flat(phi_raw), cfg.PONO_C)
+        if detach_flag:   # :292-293 `f = f.detach()`: nothing upstream of f receives a gradient
+            qn, kn = qn.detach(), kn.detach()
+        attn = _Attention(qn=qn, kn=kn, inv_t=inv_t)
+    elif mk == 3 and cfg.PONO_C and WTA_scale_weight == 1:
+        # the reference's default: 3x3 neighbourhoods.  Logits = diagonal box filter of the K = 256
+        # correlation, materialised once per orientation that is actually used, then streamed.
+        th, ph = (theta_raw.detach(), phi_raw.detach()) if detach_flag else (theta_raw, phi_raw)
+        attn = _Attention(inv_t=inv_t,
+                          logits_q=lambda: _box3_logits(th, ph, inv_t, transposed=False),
+                          logits_k=lambda: _box3_logits(th, ph, inv_t, transposed=True))
     else:
-        theta = F.unfold(theta_raw, kernel_size=mk, padding=mk // 2)
-        phi = F.unfold(phi_raw, kernel_size=mk, padding=mk // 2)
-    qn = ops.center_l2norm(theta, cfg.PONO_C)
-    kn = ops.center_l2norm(phi, cfg.PONO_C)
-    if detach_flag:   # :292-293 `f = f.detach()`: nothing upstream of f receives a gradient
-        qn, kn = qn.detach(), kn.detach()
-
-    fused = (qn.shape[1] == ops.FUSED_K) and WTA_scale_weight == 1 and not return_corr
-    attn = _Attention(qn, kn, 1.0 / temperature, WTA_scale_weight, fused)
+        attn = _Attention(inv_t=inv_t,
+                          f_scaled=_scaled_logits(theta_raw, phi_raw, cfg, inv_t, detach_flag, WTA_scale_weight))
     if return_corr:
         return attn.f_scaled
 

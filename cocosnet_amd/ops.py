@@ -310,6 +310,97 @@ def warp_materialized(p, v):
     return _WarpMaterialized.apply(p, v)
 
 
+# ------------------------------------------------------------------------------------------
+# K6  match_kernel = 3 logits from the K = 256 correlation (no unfold)   (correspondence.py:276-304)
+# ------------------------------------------------------------------------------------------
+class _Box3Logits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c_raw, mu, nu, a, b, h: int, w: int, k_unfolded: float, scale: float):
+        c_raw = _chk(c_raw, "c_raw")
+        mu, nu, a, b = (_chk(t, n) for t, n in ((mu, "mu"), (nu, "nu"), (a, "a"), (b, "b")))
+        B, N, _ = c_raw.shape
+        if N != h * w or any(t.shape != (B, N) for t in (mu, nu, a, b)):
+            raise ValueError("box3_logits: shape mismatch")
+        f = torch.empty_like(c_raw)
+        _call("box3_logits_fwd", "cocos_box3_logits_fwd", c_raw.data_ptr(), mu.data_ptr(), nu.data_ptr(),
+              a.data_ptr(), b.data_ptr(), f.data_ptr(), B, h, w, float(k_unfolded), float(scale), _stream())
+        ctx.save_for_backward(f, mu, nu, a, b)
+        ctx.cfg = (int(h), int(w), float(k_unfolded), float(scale))
+        return f
+
+    @staticmethod
+    def backward(ctx, g):
+        f, mu, nu, a, b = ctx.saved_tensors
+        h, w, kc, scale = ctx.cfg
+        g = _chk(g, "box3_logits: g")
+        B, N, _ = f.shape
+        dc = torch.empty_like(f)
+        r1, r2, c1, c2 = (torch.empty((B, N), device=f.device, dtype=torch.float32) for _ in range(4))
+        nbytes = _lib.load().cocos_box3_logits_bwd_workspace_bytes(B, h, w)
+        ws = torch.empty((nbytes + 3) // 4, device=f.device, dtype=torch.float32)
+        _call("box3_logits_bwd", "cocos_box3_logits_bwd", g.data_ptr(), f.data_ptr(), mu.data_ptr(),
+              nu.data_ptr(), a.data_ptr(), b.data_ptr(), dc.data_ptr(), r1.data_ptr(), r2.data_ptr(),
+              c1.data_ptr(), c2.data_ptr(), ws.data_ptr(), ws.numel() * 4, B, h, w, scale, _stream())
+        dmu = -kc * scale * a * r1
+        dnu = -kc * scale * b * c1
+        da = r2 / a
+        db = c2 / b
+        return dc, dmu, dnu, da, db, None, None, None, None
+
+
+def box3_logits(c_raw, mu, nu, a, b, h, w, k_unfolded, scale):
+    """scale * (diagonal 3x3 box filter of c_raw - k mu nu^T) * a b^T  -> [B,N,N]; see cocos_hip.h K6."""
+    return _Box3Logits.apply(c_raw, mu, nu, a, b, h, w, k_unfolded, scale)
+
+
+# ------------------------------------------------------------------------------------------
+# K7  softmax + warp from materialised key-major logits   (correspondence.py:307 + :318 ...)
+# ------------------------------------------------------------------------------------------
+class _LogitsSoftmaxWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits_t, v):
+        logits_t, v = _chk(logits_t, "logits_t"), _chk(v, "v")
+        B, Nk, Nq = logits_t.shape
+        Cv = v.shape[1]
+        if v.shape[0] != B or v.shape[2] != Nk:
+            raise ValueError(f"logits_softmax_warp: shape mismatch {tuple(logits_t.shape)} {tuple(v.shape)}")
+        out = torch.empty((B, Cv, Nq), device=v.device, dtype=torch.float32)
+        lse = torch.empty((B, Nq), device=v.device, dtype=torch.float32)
+        _call("logits_softmax_warp_fwd", "cocos_logits_softmax_warp_fwd", logits_t.data_ptr(), v.data_ptr(),
+              out.data_ptr(), lse.data_ptr(), B, Nq, Nk, Cv, _stream())
+        ctx.save_for_backward(logits_t, v, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        logits_t, v, out, lse = ctx.saved_tensors
+        dout = _chk(dout, "dout")
+        B, Nk, Nq = logits_t.shape
+        Cv = v.shape[1]
+        dlg = dv = None
+        if ctx.needs_input_grad[0]:
+            dlg = torch.empty_like(logits_t)
+            _call("logits_softmax_warp_bwd", "cocos_logits_softmax_warp_bwd", logits_t.data_ptr(), v.data_ptr(),
+                  out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dlg.data_ptr(), B, Nq, Nk, Cv, _stream())
+        if ctx.needs_input_grad[1]:
+            # dv[c,j] = sum_i P[i,j] dout[c,i] (cycle terms only): P^T is rebuilt once and contracted with
+            # the K5 GEMM; exp() here is the only non-HIP arithmetic, on a path no README command trains
+            p_t = torch.exp(logits_t - lse[:, None, :])
+            dv = torch.empty_like(v)
+            _call("warp_materialized_fwd", "cocos_warp_materialized_fwd", p_t.data_ptr(), dout.data_ptr(),
+                  dv.data_ptr(), B, Nk, Nq, Cv, _stream())
+        return dlg, dv
+
+
+def logits_softmax_warp(logits_t, v):
+    """out[b,c,i] = sum_j softmax_j(logits_t[b,j,i]) v[b,c,j]; logits_t [B,Nk,Nq] key-major, v [B,Cv,Nk]."""
+    Cv = v.shape[1]
+    if Cv <= MAX_FUSED_CV:
+        return _LogitsSoftmaxWarp.apply(logits_t, v)
+    return torch.cat([_LogitsSoftmaxWarp.apply(logits_t, v[:, c0:c0 + MAX_FUSED_CV])
+                      for c0 in range(0, Cv, MAX_FUSED_CV)], dim=1)
+
+
 def mfma_probe() -> torch.Tensor:
     """Debug: the 64x16 accumulator image of one v_mfma_f32_32x32x2_f32 (see api_common.hip)."""
     out = torch.empty((64, 16), device="cuda", dtype=torch.float32)

@@ -151,6 +151,39 @@ int cocos_warp_materialized_bwd(const float* p, const float* v, const float* dou
                                 float* dp, float* dv,
                                 int B, int Nq, int Nk, int Cv, cocos_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * K6  match_kernel = 3 without unfolding (correspondence.py:276-280,:286-289 + :291 + :304, PONO_C):
+ *     f[b,p,q] = scale * ( sum_{d in 3x3, p+d and q+d inside} c_raw[b,p+d,q+d] - k_unfolded*mu[b,p]*nu[b,q] )
+ *                      * a[b,p] * b[b,q]
+ *   c_raw [B,N,N] = theta_b^T phi_b (K = 256, cocos_corr_materialize), N = h*w;
+ *   mu, a / nu, b [B,N]: mean and 1/(norm+eps) of the unfolded, centred theta / phi vectors
+ *   (3x3 box sums of per-position channel sums — computed by the caller); k_unfolded = 256*9.
+ *   bwd: g = dL/df ->  dc_raw = boxdiag(g * a_p * b_q * scale)  and the four reductions
+ *        r1[p] = sum_q g b_q nu_q, r2[p] = sum_q g f, c1[q] = sum_p g a_p mu_p, c2[q] = sum_p g f
+ *        from which dmu = -k*scale*a*r1, da = r2/a, dnu = -k*scale*b*c1, db = c2/b.
+ * ------------------------------------------------------------------------------------- */
+int cocos_box3_logits_fwd(const float* c_raw, const float* mu, const float* nu, const float* a,
+                          const float* b, float* f, int B, int h, int w, float k_unfolded,
+                          float scale, cocos_stream_t stream);
+size_t cocos_box3_logits_bwd_workspace_bytes(int B, int h, int w);
+int cocos_box3_logits_bwd(const float* g, const float* f, const float* mu, const float* nu,
+                          const float* a, const float* b, float* dc_raw, float* r1, float* r2,
+                          float* c1, float* c2, void* ws, size_t ws_bytes, int B, int h, int w,
+                          float scale, cocos_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K7  softmax + warp from MATERIALISED, KEY-MAJOR logits (correspondence.py:307 + :318/:334/... and
+ *     their autograd in one streaming kernel each; P never reaches HBM).  Used by match_kernel = 3.
+ *   logits_t [B,Nk,Nq]: logits_t[b,j,i] = f[b,i,j] / temperature
+ *   fwd: out[b,c,i] = sum_j softmax_j(logits_t[b,j,i]) v[b,c,j];  lse [B,Nq]
+ *   bwd: dlogits_t[b,j,i] = P[i,j] * (sum_c dout[b,c,i] v[b,c,j] - sum_c dout[b,c,i] out[b,c,i])
+ * ------------------------------------------------------------------------------------- */
+int cocos_logits_softmax_warp_fwd(const float* logits_t, const float* v, float* out, float* lse,
+                                  int B, int Nq, int Nk, int Cv, cocos_stream_t stream);
+int cocos_logits_softmax_warp_bwd(const float* logits_t, const float* v, const float* out,
+                                  const float* lse, const float* dout, float* dlogits_t,
+                                  int B, int Nq, int Nk, int Cv, cocos_stream_t stream);
+
 /* Debug: runs one v_mfma_f32_32x32x2_f32 with known operands and dumps the 64x16 accumulator
  * registers to out[64*16] so the host can verify the lane/register -> (row, col) map. */
 int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);

@@ -334,3 +334,57 @@ def test_module_return_corr_and_wta_and_detach():
     # f.detach() (:292-293) cuts the only path to the parameters: like the reference, the output
     # then carries no autograd history at all
     assert not o["warp_out"].requires_grad
+
+
+# ------------------------------------------------------------------ match_kernel = 3 without unfolding
+@pytest.mark.parametrize("B,h,w", [(2, 12, 9), (1, 1, 1), (1, 3, 5), (1, 16, 16), (1, 7, 40)])
+def test_box3_logits_equal_the_unfolded_formulation(B, h, w):
+    """K6: diagonal box filter of the K=256 correlation + rank-1 correction == F.unfold -> centre ->
+    normalise -> matmul of the reference (:276-291), forward and all gradients (torch fp64 autograd
+    of the unfolded formulation is the checker here; the oracle pins the same forward on CPU)."""
+    import torch.nn.functional as F
+    from cocosnet_amd.hot_path import HotPathConfig, _scaled_logits
+    rs = np.random.RandomState(h * 31 + w)
+    th = rs.standard_normal((B, 256, h, w)) + 0.2
+    ph = 0.3 * th + rs.standard_normal((B, 256, h, w)) - 0.1
+    g = rs.standard_normal((B, h * w, h * w))
+    t64, p64 = (torch.from_numpy(x).requires_grad_(True) for x in (th, ph))
+
+    def unfolded(x):
+        u = F.unfold(x, 3, padding=1)
+        u = u - u.mean(dim=1, keepdim=True)
+        return u / (torch.norm(u, 2, 1, keepdim=True) + co.EPS)
+    f_ref = torch.matmul(unfolded(t64).permute(0, 2, 1), unfolded(p64)) / 0.01
+    (f_ref * torch.from_numpy(g)).sum().backward()
+    assert rel(f_ref, co.correlation(co.center_l2norm(co.unfold(th, 3, 1), True),
+                                     co.center_l2norm(co.unfold(ph, 3, 1), True)) * 100.0) < 1e-12
+    td, pd = dev(th, True), dev(ph, True)
+    cfg = HotPathConfig(match_kernel=3, PONO_C=True)
+    f = _scaled_logits(td, pd, cfg, 100.0, False, 1)
+    (f * dev(g)).sum().backward()
+    assert rel(f, f_ref.detach().numpy()) < 2e-5          # logits (cos * 100), fp32 GEMM + cancellation
+    assert rel(td.grad, t64.grad.numpy()) < GRAD_TOL
+    assert rel(pd.grad, p64.grad.numpy()) < GRAD_TOL
+
+
+@pytest.mark.parametrize("B,Nq,Nk,Cv", [(2, 64, 64, 3), (1, 1, 1, 1), (1, 129, 33, 5), (1, 200, 177, 154),
+                                         (1, 2025, 300, 40), (2, 96, 256, 160)])
+def test_logits_softmax_warp_vs_oracle(B, Nq, Nk, Cv):
+    """K7: streamed softmax + warp from key-major logits, forward and both gradients."""
+    from cocosnet_amd import ops
+    rs = np.random.RandomState(Nq + 3 * Nk)
+    f = rs.standard_normal((B, Nq, Nk)) * 6.0            # query-major logits, sigma ~ cos/0.01 at K=256
+    f[:, :, 0] += 25.0 * (rs.uniform(size=(B, Nq)) < 0.3)  # some peaked rows
+    v = rs.uniform(-1, 1, (B, Cv, Nk))
+    g = rs.standard_normal((B, Cv, Nq))
+    p = co.softmax(f)
+    out_ref = np.matmul(p, v.transpose(0, 2, 1)).transpose(0, 2, 1)
+    dp = np.matmul(g.transpose(0, 2, 1), v)
+    df_ref = p * (dp - (p * dp).sum(-1, keepdims=True))
+    dv_ref = np.matmul(g, p)
+    lt, vd = dev(f.transpose(0, 2, 1), True), dev(v, True)
+    out = ops.logits_softmax_warp(lt, vd)
+    out.backward(dev(g))
+    assert rel(out, out_ref) < OUT_TOL
+    assert rel(lt.grad, df_ref.transpose(0, 2, 1), floor=1e-3) < OUT_TOL
+    assert rel(vd.grad, dv_ref) < OUT_TOL
