@@ -65,13 +65,14 @@ def build_inputs(device, scope):
 class HotPathStep(torch.nn.Module):
     """theta/phi projections + the HIP hot path (ADE20k flag set, match_kernel 1)."""
 
-    def __init__(self):
+    def __init__(self, match_kernel=1):
         super().__init__()
         from cocosnet_amd.hot_path import HotPathConfig
         cl = KDIM + SEM_NC
         self.theta = torch.nn.Conv2d(cl, KDIM, 1)
         self.phi = torch.nn.Conv2d(cl, KDIM, 1)
-        self.cfg = HotPathConfig(match_kernel=1, PONO_C=True, down=DOWN, warp_mask_losstype="direct")
+        self.cfg = HotPathConfig(match_kernel=match_kernel, PONO_C=True, down=DOWN,
+                                 warp_mask_losstype="direct")
 
     def forward(self, d):
         from cocosnet_amd.hot_path import correspondence_hot_path
@@ -79,13 +80,13 @@ class HotPathStep(torch.nn.Module):
                                        d["ref_img"], d["real_img"], d["seg"], d["ref_seg"], self.cfg)
 
 
-def make_step(scope, device):
+def make_step(scope, device, match_kernel=1):
     if scope == "hotpath":
-        model = HotPathStep().to(device)
+        model = HotPathStep(match_kernel).to(device)
         fwd = lambda d: model(d)
     else:
         from cocosnet_amd.correspondence import NoVGGCorrespondence, ade20k_options
-        opt = ade20k_options(match_kernel=1, isTrain=True)
+        opt = ade20k_options(match_kernel=match_kernel, isTrain=True)
         model = NoVGGCorrespondence(opt).to(device)
         model.init_weights(opt.init_type, opt.init_variance)
         fwd = lambda d: model(d["ref_img"], d["real_img"], d["seg"], d["ref_seg"])
@@ -132,6 +133,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scope", choices=("hotpath", "netcorr"), default="hotpath")
+    ap.add_argument("--match-kernel", type=int, choices=(1, 3), default=1,
+                    help="1 = the north-star 64x64x256 correlation (headline); 3 = the reference's shipped "
+                         "default (3x3 neighbourhoods, K6/K7 kernels) — reported for context")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=6)
     args = ap.parse_args()
@@ -146,7 +150,7 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    model, fwd = make_step(args.scope, device)
+    model, fwd = make_step(args.scope, device, args.match_kernel)
     if world > 1:   # identical replicas: broadcast rank 0's parameters once
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)
@@ -186,7 +190,11 @@ def main():
         B = BATCH_PER_GPU
         # algorithmic FLOPs per launch (no recompute counted): forward 2*HW^2*(K+Cv),
         # backward 2*HW^2*(2K+Cv) split as query side 2*HW^2*(K+Cv) [dP + dqn], key side 2*HW^2*K [dkn]
-        alg = {"corr_softmax_warp_fwd": 2.0 * N * N * (KDIM + cv) * B,
+        alg = {"corr_materialize": 2.0 * N * N * KDIM * B,
+               "corr_materialize_bwd": 4.0 * N * N * KDIM * B,
+               "logits_softmax_warp_fwd": 2.0 * N * N * cv * B,
+               "logits_softmax_warp_bwd": 2.0 * N * N * cv * B,
+               "corr_softmax_warp_fwd": 2.0 * N * N * (KDIM + cv) * B,
                "corr_softmax_warp_bwd_query": 2.0 * N * N * (KDIM + cv) * B,
                "corr_softmax_warp_bwd_key_from_ds": 2.0 * N * N * KDIM * B,
                "corr_softmax_warp_bwd_key": 2.0 * N * N * KDIM * B}
@@ -229,7 +237,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"ADE20k 256x256 batch {BATCH_PER_GPU}/GPU, 64x64 grid (HW=4096), K=256, "
-                                   f"Cv=154 (rgb+151 labels), match_kernel 1, PONO_C, T=0.01; scope={args.scope}: "
+                                   f"Cv=154 (rgb+151 labels), match_kernel {args.match_kernel}, PONO_C, T=0.01; scope={args.scope}: "
                                    + ("theta/phi 1x1 conv + centre/L2norm + fused corr-softmax-warp fwd+bwd"
                                       if args.scope == "hotpath" else
                                       "whole NoVGGCorrespondence module fwd+bwd (producers on PyTorch-ROCm)"),

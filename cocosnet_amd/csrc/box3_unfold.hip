@@ -31,21 +31,34 @@ __global__ __launch_bounds__(256) void box3_diag_kernel(const float* __restrict_
                                                         const float* __restrict__ nu,
                                                         const float* __restrict__ av,
                                                         const float* __restrict__ bv, int N, int h, int w,
-                                                        float kc, float post) {
-    const int b = blockIdx.z, p = blockIdx.y;
-    const int q0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+                                                        int nchunk, float kc, float post) {
+    // XCD-aware decode: consecutive rows of one sample must share an XCD, because every output row
+    // re-reads its 8 diagonal neighbour rows (p +- 1, p +- w, p +- w +- 1) and L2 is per XCD — with the
+    // default round-robin placement each XCD streams the whole matrix (measured: 9x the traffic)
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = vb % nchunk;
+    const int p = (vb / nchunk) % N;
+    const int b = vb / (nchunk * N);
+    const int q0 = (chunk * 256 + threadIdx.x) * 4;
     if (q0 >= N) return;
     const int py = p / w, px = p - py * w;
     const __amdgpu_buffer_rsrc_t in_rs = make_rsrc(in + (size_t)b * N * N, (size_t)N * N * 4);
     const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(bv + (size_t)b * N, (size_t)N * 4);
     const float* a_b = av + (size_t)b * N;
 
-    int qy[4], qx[4];
+    // per-element validity of the three row taps / three column taps (one division per thread)
+    bool ry[4][3], cx[4][3];
+    {
+        int qy = q0 / w, qx = q0 - qy * w;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int q = q0 + e;
-        qy[e] = q / w;
-        qx[e] = q - qy[e] * w;
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                ry[e][d] = (unsigned)(qy + d - 1) < (unsigned)h;
+                cx[e][d] = (unsigned)(qx + d - 1) < (unsigned)w;
+            }
+            if (++qx == w) { qx = 0; ++qy; }
+        }
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -68,14 +81,17 @@ __global__ __launch_bounds__(256) void box3_diag_kernel(const float* __restrict_
             if (PRE) {
                 const float as = a_b[ps] * post;
                 const long long boff = (long long)(q0 + sh) * 4;
+                if (boff >= 0) {
+                    wgt = buf_load4(b_rs, (unsigned)boff) * as;
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    wgt[e] = as * ((boff + 4 * e >= 0) ? buf_load1(b_rs, (unsigned)(boff + 4 * e)) : 0.f);
+                    for (int e = 0; e < 4; ++e)
+                        wgt[e] = as * ((boff + 4 * e >= 0) ? buf_load1(b_rs, (unsigned)(boff + 4 * e)) : 0.f);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bool ok = (unsigned)(qy[e] + dy) < (unsigned)h && (unsigned)(qx[e] + dx) < (unsigned)w;
-                acc[e] += ok ? x[e] * wgt[e] : 0.f;
+                acc[e] += (ry[e][dy + 1] && cx[e][dx + 1]) ? x[e] * wgt[e] : 0.f;
             }
         }
     }
@@ -207,9 +223,10 @@ extern "C" int cocos_box3_logits_fwd(const float* c_raw, const float* mu, const 
     const long long N = (long long)h * w;
     COCOS_REQUIRE(N <= 65535 && N * N * 4 < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED,
                   "box3_logits_fwd: grid %dx%d too large (per-sample matrix must stay below 2 GiB)", h, w);
-    const dim3 grid((unsigned)((N + 1023) / 1024), (unsigned)N, B);
-    hipLaunchKernelGGL(box3_diag_kernel<false>, grid, dim3(256), 0, as_stream(stream), c_raw, f, mu, nu,
-                       a, b, (int)N, h, w, k_unfolded, scale);
+    const int nchunk = (int)((N + 1023) / 1024);
+    COCOS_REQUIRE((long long)nchunk * N * B < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "box3_logits_fwd: grid too large");
+    hipLaunchKernelGGL(box3_diag_kernel<false>, dim3((unsigned)(nchunk * N * B)), dim3(256), 0,
+                       as_stream(stream), c_raw, f, mu, nu, a, b, (int)N, h, w, nchunk, k_unfolded, scale);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -240,9 +257,9 @@ extern "C" int cocos_box3_logits_bwd(const float* g, const float* f, const float
     float* c2p = c1p + (size_t)B * nrb * N;
     float* r1p = c2p + (size_t)B * nrb * N;
     float* r2p = r1p + (size_t)B * N * nchunk;
-    const dim3 grid((unsigned)nchunk, (unsigned)N, B);
-    hipLaunchKernelGGL(box3_diag_kernel<true>, grid, dim3(256), 0, s, g, dc_raw, mu, nu, a, b, (int)N, h, w,
-                       0.f, scale);
+    COCOS_REQUIRE((long long)nchunk * N * B < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "box3_logits_bwd: grid too large");
+    hipLaunchKernelGGL(box3_diag_kernel<true>, dim3((unsigned)(nchunk * N * B)), dim3(256), 0, s, g, dc_raw,
+                       mu, nu, a, b, (int)N, h, w, nchunk, 0.f, scale);
     hipLaunchKernelGGL(box3_bwd_reduce_kernel, dim3(nchunk, nrb, B), dim3(256), 0, s, g, f, mu, nu, a, b,
                        r1p, r2p, c1p, c2p, (int)N, nchunk, nrb);
     hipLaunchKernelGGL(box3_finish_kernel, dim3((unsigned)((N + 255) / 256), B), dim3(256), 0, s,
