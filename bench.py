@@ -75,8 +75,11 @@ class HotPathStep(torch.nn.Module):
                                  warp_mask_losstype="direct")
 
     def forward(self, d):
+        from cocosnet_amd import ops
         from cocosnet_amd.hot_path import correspondence_hot_path
-        return correspondence_hot_path(self.theta(d["cont_features"]), self.phi(d["ref_features"]),
+        theta = ops.proj1x1(d["cont_features"], self.theta.weight, self.theta.bias)   # :272
+        phi = ops.proj1x1(d["ref_features"], self.phi.weight, self.phi.bias)          # :282
+        return correspondence_hot_path(theta, phi,
                                        d["ref_img"], d["real_img"], d["seg"], d["ref_seg"], self.cfg)
 
 

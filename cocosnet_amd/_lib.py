@@ -60,6 +60,9 @@ _SIGNATURES = {
     "cocos_warp_materialized_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int, ctypes.c_int,
                                                                       ctypes.c_int, ctypes.c_int,
                                                                       _stream_t]),
+    "cocos_proj1x1_fwd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 4 + [_stream_t]),
+    "cocos_proj1x1_bwd_partials": (ctypes.c_int, [ctypes.c_int] * 4),
+    "cocos_proj1x1_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [_stream_t]),
     "cocos_box3_logits_fwd": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 3
                               + [ctypes.c_float, ctypes.c_float, _stream_t]),
     "cocos_box3_logits_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),

@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn import init
 
+from . import ops
 from .hot_path import HotPathConfig, correspondence_hot_path
 from .producers import AdaptiveFeatureGenerator, ResidualBlock
 
@@ -147,7 +148,10 @@ class NoVGGCorrespondence(NetworkBase):
                 ref = self.layer(torch.cat((feat_img, ref_seg), 1))
         else:
             cont, ref = self.layer(feat_seg), self.layer(feat_img)
-        return self.theta(cont), self.phi(ref)
+        if cont.is_cuda:   # :272 / :282 on the fp32-MFMA GEMM (same parameters: checkpoints are unaffected)
+            return (ops.proj1x1(cont, self.theta.weight, self.theta.bias),
+                    ops.proj1x1(ref, self.phi.weight, self.phi.bias))
+        return self.theta(cont), self.phi(ref)   # CPU: producer parity tests only; the hot path needs a GPU
 
     def forward(self, ref_img, real_img, seg_map, ref_seg_map, temperature=0.01, detach_flag=False,
                 WTA_scale_weight=1, alpha=1, return_corr=False):

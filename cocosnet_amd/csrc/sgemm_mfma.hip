@@ -28,26 +28,49 @@ struct GemmStage {
 };
 
 // Fetch a [GK x 128] operand slab into registers.  `KC`: source is k-contiguous ([mn][k]).
+// !EDGE: the slab is entirely inside the matrix — one 16-byte load per piece, nothing else.
+// EDGE:  still one 16-byte load per piece (4-byte alignment is enough on gfx950) and no branches: a
+//        piece entirely outside the matrix is switched off through the descriptor (offset out of range
+//        -> zeros); a piece that straddles the ragged end of its row is masked element-wise after the
+//        load; a piece that would cross the END OF THE BUFFER is loaded from 1-3 elements earlier and
+//        shifted.  So Cin = 407 or Cv = 154 cost a few VALU ops per load, not 4 scalar loads.
 template <bool KC, bool EDGE>
-__device__ __forceinline__ void gemm_fetch(GemmStage& st, __amdgpu_buffer_rsrc_t rs, int mn0,
-                                           int k0, int MN, int K, int tid) {
+__device__ __forceinline__ void gemm_fetch(GemmStage& st, __amdgpu_buffer_rsrc_t rs, int mn0, int k0,
+                                           int MN, int K, int kend, int tid) {
+    // K = full reduction length (the row stride of k-contiguous sources); kend <= K = end of this
+    // workgroup's slice of it (split-K)
+    const int total = MN * K;
 #pragma unroll
     for (int u = 0; u < GST; ++u) {
         const int idx = u * 256 + tid;
         int mn, k;
         if (KC) { mn = mn0 + idx / (GK / 4); k = k0 + (idx % (GK / 4)) * 4; }
         else    { k = k0 + (idx >> 5);  mn = mn0 + (idx & 31) * 4; }
+        const int e0 = KC ? (mn * K + k) : (k * MN + mn);
         if (!EDGE) {
-            const unsigned off = KC ? (unsigned)(mn * K + k) * 4u : (unsigned)(k * MN + mn) * 4u;
-            st.r[u] = buf_load4(rs, off);
+            st.r[u] = buf_load4(rs, (unsigned)e0 * 4u);
         } else {
+            const int lim = KC ? kend : MN;         // extent of the contiguous direction
+            const int pos = KC ? k : mn;            // first of the 4 contiguous elements
+            const bool ok = (KC ? (mn < MN) : (k < kend)) && pos < lim;
+            f32x4 v;
+            if (total < 4) {                        // degenerate matrix (uniform branch): scalar loads
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int mm = KC ? mn : mn + e, kk = KC ? k + e : k;
-                unsigned off = KC ? (unsigned)(mm * K + kk) * 4u : (unsigned)(kk * MN + mm) * 4u;
-                if (mm >= MN || kk >= K) off = kBufOob;
-                st.r[u][e] = buf_load1(rs, off);
+                for (int e = 0; e < 4; ++e)
+                    v[e] = buf_load1(rs, (ok && pos + e < lim) ? (unsigned)(e0 + e) * 4u : kBufOob);
+                st.r[u] = v;
+                continue;
             }
+            const int sh = max(e0 + 4 - total, 0);  // 1..3 only for the last piece of the buffer
+            const f32x4 w = buf_load4(rs, ok ? (unsigned)(e0 - sh) * 4u : kBufOob);
+            v[0] = sh == 0 ? w[0] : sh == 1 ? w[1] : sh == 2 ? w[2] : w[3];
+            v[1] = sh == 0 ? w[1] : sh == 1 ? w[2] : w[3];
+            v[2] = sh == 0 ? w[2] : w[3];
+            v[3] = w[3];
+#pragma unroll
+            for (int e = 1; e < 4; ++e)
+                if (pos + e >= lim) v[e] = 0.f;
+            st.r[u] = v;
         }
     }
 }
@@ -75,7 +98,9 @@ __global__ __launch_bounds__(256, 1) void sgemm_mfma_kernel(const float* __restr
                                                             const float* __restrict__ Bm,
                                                             float* __restrict__ C, int M, int N,
                                                             int K, size_t strideA, size_t strideB,
-                                                            size_t strideC, float scale) {
+                                                            size_t strideC, float scale,
+                                                            const float* __restrict__ row_bias,
+                                                            int ksplit, int kchunk) {
     __shared__ __attribute__((aligned(16))) float at[GK * GLD];
     __shared__ __attribute__((aligned(16))) float bt[GK * GLD];
 
@@ -83,7 +108,9 @@ __global__ __launch_bounds__(256, 1) void sgemm_mfma_kernel(const float* __restr
     const int lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.z;
+    // split-K: blockIdx.z = sample * ksplit + slice; each slice writes its own C slab (partials)
+    const int b = blockIdx.z / ksplit;
+    const int kbeg = (blockIdx.z % ksplit) * kchunk, kend = min(K, kbeg + kchunk);
     const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
 
     const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(A + (size_t)b * strideA, (size_t)M * K * 4);
@@ -97,26 +124,24 @@ __global__ __launch_bounds__(256, 1) void sgemm_mfma_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const bool interior = (m0 + GM <= M) && (n0 + GN <= N);
+    const bool a_in = m0 + GM <= M, b_in = n0 + GN <= N;   // per operand: a ragged N does not slow A
     GemmStage sa, sb;
     auto fetch = [&](int k0) {
-        if (interior && k0 + GK <= K) {
-            gemm_fetch<A_KC, false>(sa, a_rs, m0, k0, M, K, tid);
-            gemm_fetch<B_KC, false>(sb, b_rs, n0, k0, N, K, tid);
-        } else {
-            gemm_fetch<A_KC, true>(sa, a_rs, m0, k0, M, K, tid);
-            gemm_fetch<B_KC, true>(sb, b_rs, n0, k0, N, K, tid);
-        }
+        const bool kfull = k0 + GK <= kend;
+        if (a_in && kfull) gemm_fetch<A_KC, false>(sa, a_rs, m0, k0, M, K, kend, tid);
+        else               gemm_fetch<A_KC, true>(sa, a_rs, m0, k0, M, K, kend, tid);
+        if (b_in && kfull) gemm_fetch<B_KC, false>(sb, b_rs, n0, k0, N, K, kend, tid);
+        else               gemm_fetch<B_KC, true>(sb, b_rs, n0, k0, N, K, kend, tid);
     };
 
-    const int nsteps = (K + GK - 1) / GK;
-    fetch(0);
+    const int nsteps = (max(kend - kbeg, 0) + GK - 1) / GK;
+    fetch(kbeg);
     for (int t = 0; t < nsteps; ++t) {
         __syncthreads();
         gemm_commit<A_KC>(sa, at, tid);
         gemm_commit<B_KC>(sb, bt, tid);
         __syncthreads();
-        if (t + 1 < nsteps) fetch((t + 1) * GK);
+        if (t + 1 < nsteps) fetch(kbeg + (t + 1) * GK);
         // operands of step kk+1 are requested while step kk multiplies (LDS latency ~100+ cycles
         // would otherwise sit between the 64-cycle MFMAs); interleave pinned, one region per step
         const float* al = at + h * GLD + wm * 64 + c;
@@ -141,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_mfma_kernel(const float* __restr
         }
     }
 
-    float* Cb = C + (size_t)b * strideC;
+    float* Cb = C + (size_t)blockIdx.z * strideC;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -150,22 +175,27 @@ __global__ __launch_bounds__(256, 1) void sgemm_mfma_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + i * 32 + acc_row_base(r) + 4 * h;
-                if (m < M && n < N) Cb[(size_t)m * N + n] = acc[i][j][r] * scale;
+                if (m < M && n < N)
+                    Cb[(size_t)m * N + n] = acc[i][j][r] * scale + (row_bias ? row_bias[m] : 0.f);
             }
         }
 }
 
 template <bool A_KC, bool B_KC>
 static int launch_gemm(const float* A, const float* Bm, float* C, int batch, int M, int N, int K,
-                       float scale, hipStream_t s) {
+                       float scale, hipStream_t s, bool shared_a = false,
+                       const float* row_bias = nullptr, int ksplit = 1) {
     COCOS_REQUIRE((size_t)M * K * 4 < 0x7fffffffull && (size_t)N * K * 4 < 0x7fffffffull,
                   COCOS_ERR_UNSUPPORTED, "sgemm: per-sample operand exceeds 2 GiB (M=%d N=%d K=%d)",
                   M, N, K);
-    COCOS_REQUIRE(batch <= 65535 && (M + GM - 1) / GM <= 65535, COCOS_ERR_UNSUPPORTED,
+    COCOS_REQUIRE((long long)batch * ksplit <= 65535 && (M + GM - 1) / GM <= 65535, COCOS_ERR_UNSUPPORTED,
                   "sgemm: grid too large");
-    const dim3 grid((N + GN - 1) / GN, (M + GM - 1) / GM, batch);
+    // ksplit > 1: C holds batch*ksplit partial slabs [M,N]; slices are whole K steps
+    const int kchunk = ((K + ksplit - 1) / ksplit + GK - 1) / GK * GK;
+    const dim3 grid((N + GN - 1) / GN, (M + GM - 1) / GM, batch * ksplit);
     hipLaunchKernelGGL((sgemm_mfma_kernel<A_KC, B_KC>), grid, dim3(256), 0, s, A, Bm, C, M, N, K,
-                       (size_t)M * K, (size_t)N * K, (size_t)M * N, scale);
+                       shared_a ? (size_t)0 : (size_t)M * K, (size_t)N * K, (size_t)M * N, scale, row_bias,
+                       ksplit, kchunk);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -230,5 +260,49 @@ extern "C" int cocos_warp_materialized_bwd(const float* p, const float* v, const
     if (rc != COCOS_OK) return rc;
     // dv[c][j] = sum_i dout[c][i] p[i][j] : C[m=c][n=j], A = dout [m=c][kk=i] (k-contig), B = p [kk=i][n=j]
     if (dv) rc = launch_gemm<true, false>(dout, p, dv, B, Cv, Nk, Nq, 1.0f, s);
+    return rc;
+}
+
+// ---- theta / phi 1x1 projections on the same GEMM (correspondence.py:272, :282 and their autograd) ----
+// y[b,co,n] = sum_ci w[co,ci] x[b,ci,n] + bias[co]          C[m=co][n], A = w [m][k] (shared), B = x [k][n]
+extern "C" int cocos_proj1x1_fwd(const float* x, const float* w, const float* bias, float* y, int B,
+                                 int Cin, int Cout, int N, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && w && y, COCOS_ERR_INVALID, "proj1x1_fwd: null pointer");
+    COCOS_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1 && N >= 1, COCOS_ERR_INVALID,
+                  "proj1x1_fwd: bad dims B=%d Cin=%d Cout=%d N=%d", B, Cin, Cout, N);
+    return launch_gemm<true, false>(w, x, y, B, Cout, N, Cin, 1.0f, as_stream(stream), true, bias);
+}
+
+// dx[b,ci,n] = sum_co w[co,ci] dy[b,co,n]                  C[m=ci][n], A = w [k=co][m=ci] (shared), B = dy [k][n]
+// dw_p[p,co,ci] = sum_{n in slice} dy[b,co,n] x[b,ci,n]    C[m=co][n=ci], A = dy [m][k=n], B = x [n=ci][k=n]
+//   The weight gradient is a [Cout,Cin] matrix reduced over B*N positions: 8 output tiles per sample
+//   would leave 3/4 of the chip idle, so the reduction is split (split-K) until the launch has >= 512
+//   workgroups; the caller adds the cocos_proj1x1_bwd_partials() slabs (and sums dy for the bias).
+static int proj1x1_ksplit(int B, int Cin, int Cout, int N) {
+    const long long tiles = (long long)((Cin + cocos::GN - 1) / cocos::GN) * ((Cout + cocos::GM - 1) / cocos::GM) * B;
+    int sp = (int)((512 + tiles - 1) / tiles);
+    const int max_sp = (N + 4 * cocos::GK - 1) / (4 * cocos::GK);      // at least 4 K steps per slice
+    if (sp > max_sp) sp = max_sp;
+    return sp < 1 ? 1 : sp;
+}
+
+extern "C" int cocos_proj1x1_bwd_partials(int B, int Cin, int Cout, int N) {
+    if (B < 1 || Cin < 1 || Cout < 1 || N < 1) return 0;
+    return B * proj1x1_ksplit(B, Cin, Cout, N);
+}
+
+extern "C" int cocos_proj1x1_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw_p,
+                                 int B, int Cin, int Cout, int N, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && w && dy, COCOS_ERR_INVALID, "proj1x1_bwd: null pointer");
+    COCOS_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1 && N >= 1, COCOS_ERR_INVALID,
+                  "proj1x1_bwd: bad dims B=%d Cin=%d Cout=%d N=%d", B, Cin, Cout, N);
+    hipStream_t s = as_stream(stream);
+    int rc = COCOS_OK;
+    if (dx) rc = launch_gemm<false, false>(w, dy, dx, B, Cin, N, Cout, 1.0f, s, true);
+    if (rc != COCOS_OK) return rc;
+    if (dw_p) rc = launch_gemm<true, true>(dy, x, dw_p, B, Cout, Cin, N, 1.0f, s, false, nullptr,
+                                           proj1x1_ksplit(B, Cin, Cout, N));
     return rc;
 }

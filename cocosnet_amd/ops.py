@@ -311,6 +311,51 @@ def warp_materialized(p, v):
 
 
 # ------------------------------------------------------------------------------------------
+# K0  theta / phi 1x1 projections            (correspondence.py:272, :282)
+# ------------------------------------------------------------------------------------------
+class _Proj1x1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _chk(x, "proj1x1: x")
+        w2 = _chk(weight.reshape(weight.shape[0], -1), "proj1x1: weight")
+        B, Cin, h, w = x.shape
+        Cout = w2.shape[0]
+        if w2.shape[1] != Cin:
+            raise ValueError(f"proj1x1: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}")
+        bb = None if bias is None else _chk(bias, "proj1x1: bias")
+        y = torch.empty((B, Cout, h, w), device=x.device, dtype=torch.float32)
+        _call("proj1x1_fwd", "cocos_proj1x1_fwd", x.data_ptr(), w2.data_ptr(), _ptr(bb), y.data_ptr(), B, Cin,
+              Cout, h * w, _stream())
+        ctx.save_for_backward(x, w2)
+        ctx.wshape = tuple(weight.shape)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        dy = _chk(dy, "proj1x1: dy")
+        B, Cin, h, w = x.shape
+        Cout = w2.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need_x else None
+        dwb = None
+        if need_w:
+            parts = _lib.load().cocos_proj1x1_bwd_partials(B, Cin, Cout, h * w)
+            dwb = torch.empty((parts, Cout, Cin), device=x.device, dtype=torch.float32)
+        _call("proj1x1_bwd", "cocos_proj1x1_bwd", x.data_ptr(), w2.data_ptr(), dy.data_ptr(), _ptr(dx),
+              _ptr(dwb), B, Cin, Cout, h * w, _stream())
+        dw = dwb.sum(0).reshape(ctx.wshape) if need_w else None            # [P,256,Cl] partials, small
+        db = dy.sum(dim=(0, 2, 3)) if (need_b and ctx.has_bias) else None
+        return dx, dw, db
+
+
+def proj1x1(x, weight, bias=None):
+    """nn.Conv2d(Cin, Cout, kernel_size=1) on the fp32-MFMA GEMM: x [B,Cin,h,w], weight [Cout,Cin,1,1]."""
+    return _Proj1x1.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------
 # K6  match_kernel = 3 logits from the K = 256 correlation (no unfold)   (correspondence.py:276-304)
 # ------------------------------------------------------------------------------------------
 class _Box3Logits(torch.autograd.Function):

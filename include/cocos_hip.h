@@ -152,6 +152,20 @@ int cocos_warp_materialized_bwd(const float* p, const float* v, const float* dou
                                 int B, int Nq, int Nk, int Cv, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * K0  theta / phi 1x1 projections (correspondence.py:272, :282: nn.Conv2d(Cl, 256, kernel_size=1))
+ *   fwd: y[b,co,n] = sum_ci w[co,ci] x[b,ci,n] + bias[co]      x [B,Cin,N], w [Cout,Cin], bias [Cout] or NULL
+ *   bwd: dx[b,ci,n] = sum_co w[co,ci] dy[b,co,n]  (dx may be NULL);
+ *        dw_p[p,co,ci] = sum_{n in slice p} dy[b,co,n] x[b,ci,n]  partial sums (may be NULL):
+ *        P = cocos_proj1x1_bwd_partials(B,Cin,Cout,N) slabs of [Cout,Cin] (sample x split-K slice, so the
+ *        launch fills the chip); the caller adds the P slabs, and sums dy over (b,n) for the bias gradient.
+ * ------------------------------------------------------------------------------------- */
+int cocos_proj1x1_fwd(const float* x, const float* w, const float* bias, float* y,
+                      int B, int Cin, int Cout, int N, cocos_stream_t stream);
+int cocos_proj1x1_bwd_partials(int B, int Cin, int Cout, int N);   /* 0 on bad dims */
+int cocos_proj1x1_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw_p,
+                      int B, int Cin, int Cout, int N, cocos_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * K6  match_kernel = 3 without unfolding (correspondence.py:276-280,:286-289 + :291 + :304, PONO_C):
  *     f[b,p,q] = scale * ( sum_{d in 3x3, p+d and q+d inside} c_raw[b,p+d,q+d] - k_unfolded*mu[b,p]*nu[b,q] )
  *                      * a[b,p] * b[b,q]

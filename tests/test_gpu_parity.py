@@ -388,3 +388,24 @@ def test_logits_softmax_warp_vs_oracle(B, Nq, Nk, Cv):
     assert rel(out, out_ref) < OUT_TOL
     assert rel(lt.grad, df_ref.transpose(0, 2, 1), floor=1e-3) < OUT_TOL
     assert rel(vd.grad, dv_ref) < OUT_TOL
+
+
+@pytest.mark.parametrize("B,Cin,Cout,h,w", [(2, 407, 256, 8, 8), (1, 5, 3, 3, 7), (2, 271, 256, 16, 9),
+                                             (2, 407, 256, 64, 64), (1, 130, 70, 23, 29), (1, 1, 1, 1, 1)])
+def test_proj1x1_equals_conv2d(B, Cin, Cout, h, w):
+    """K0: theta/phi 1x1 convolutions (:272,:282) on the fp32-MFMA GEMM vs torch's fp64 conv2d."""
+    import torch.nn.functional as F
+    from cocosnet_amd import ops
+    rs = np.random.RandomState(Cin)
+    x, wt, b = rs.standard_normal((B, Cin, h, w)), rs.standard_normal((Cout, Cin, 1, 1)) * 0.1, rs.standard_normal(Cout)
+    g = rs.standard_normal((B, Cout, h, w))
+    x64, w64, b64 = (torch.from_numpy(t).requires_grad_(True) for t in (x, wt, b))
+    y_ref = F.conv2d(x64, w64, b64)
+    y_ref.backward(torch.from_numpy(g))
+    xd, wd, bd = dev(x, True), dev(wt, True), dev(b, True)
+    y = ops.proj1x1(xd, wd, bd)
+    y.backward(dev(g))
+    assert rel(y, y_ref.detach().numpy()) < 1e-5
+    assert rel(xd.grad, x64.grad.numpy()) < 1e-5
+    assert rel(wd.grad, w64.grad.numpy()) < 1e-5
+    assert rel(bd.grad, b64.grad.numpy()) < 1e-5

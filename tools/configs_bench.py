@@ -1,0 +1,51 @@
+"""Hot-path timings (fwd+bwd from the theta/phi conv outputs on) for every BASELINE.json config shape."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cocosnet_amd import ops
+from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+
+def run(name, B, size, nc, seg_float, cfg, steps=5):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    fh = size // cfg.down
+    th = torch.randn(B, 256, fh, fh, device="cuda", generator=g).requires_grad_(True)
+    ph = (0.3 * th.detach() + torch.randn(B, 256, fh, fh, device="cuda", generator=g)).requires_grad_(True)
+    img = torch.rand(B, 3, size, size, device="cuda", generator=g) * 2 - 1
+    real = torch.rand(B, 3, size, size, device="cuda", generator=g) * 2 - 1
+    if seg_float:
+        seg = torch.rand(B, nc, size, size, device="cuda", generator=g)
+    else:
+        lab = torch.randint(0, nc, (B, 1, size, size), device="cuda", generator=g)
+        seg = torch.zeros(B, nc, size, size, device="cuda").scatter_(1, lab, 1.0)
+    def step():
+        th.grad = None; ph.grad = None
+        o = correspondence_hot_path(th, ph, img, real, seg, seg, cfg)
+        sum(v.pow(2).sum() for v in o.values()).backward()
+    for _ in range(2): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    with ops.KernelTimer() as kt:
+        for _ in range(steps): step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    ks = {k: round(v["total_ms"] / steps, 3) for k, v in kt.summary().items()}
+    mem = torch.cuda.max_memory_allocated() / 2**30
+    rec = {"config": name, "B": B, "grid": f"{fh}x{fh}", "ms_per_step": round(dt * 1e3, 3),
+           "images_per_s": round(B / dt, 1), "kernel_ms_per_step": ks, "peak_mem_GiB": round(mem, 2)}
+    print(json.dumps(rec), flush=True)
+    return rec
+
+out = []
+C = HotPathConfig
+out.append(run("cfg2 ADE20k 256^2 B=8 mk1 direct mask (headline)", 8, 256, 151, False,
+               C(match_kernel=1, PONO_C=True, warp_mask_losstype="direct", isTrain=True)))
+out.append(run("cfg2' same, match_kernel 3 (reference default)", 8, 256, 151, False,
+               C(match_kernel=3, PONO_C=True, warp_mask_losstype="direct", isTrain=True)))
+out.append(run("cfg3 CelebA-HQ edge 256^2 B=16 mk1 warp_cycle+two_cycle bilinear", 16, 256, 15, True,
+               C(match_kernel=1, PONO_C=True, warp_bilinear=True, warp_cycle_w=1.0, two_cycle=True, isTrain=True)))
+out.append(run("cfg3' same, match_kernel 3", 16, 256, 15, True,
+               C(match_kernel=3, PONO_C=True, warp_bilinear=True, warp_cycle_w=1.0, two_cycle=True, isTrain=True)))
+out.append(run("cfg5 DeepFashion 512^2 warp_patch, 128x128 grid, B=2 mk1", 2, 512, 20, True,
+               C(match_kernel=1, PONO_C=True, warp_bilinear=True, warp_patch=True, isTrain=True)))
+out.append(run("cfg5' 256^2 warp_stride 2 warp_patch, 128x128 grid, B=2 mk1", 2, 256, 20, True,
+               C(match_kernel=1, PONO_C=True, warp_bilinear=True, warp_patch=True, down=2, isTrain=True)))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/configs_bench.json", "w"), indent=1)
