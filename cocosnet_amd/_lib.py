@@ -70,6 +70,11 @@ _SIGNATURES = {
                               + [ctypes.c_int] * 3 + [ctypes.c_float, _stream_t]),
     "cocos_logits_softmax_warp_fwd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 4 + [_stream_t]),
     "cocos_logits_softmax_warp_bwd": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 4 + [_stream_t]),
+    "cocos_wta_scale_mask_bytes": (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_int]),
+    "cocos_wta_scale_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
+                                           ctypes.c_float, ctypes.c_float, _stream_t]),
+    "cocos_wta_scale_bwd": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, _c_float_p, ctypes.c_longlong, ctypes.c_int,
+                                           ctypes.c_float, _stream_t]),
     "cocos_debug_mfma_probe": (ctypes.c_int, [_c_float_p, _stream_t]),
 }
 

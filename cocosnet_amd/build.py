@@ -30,6 +30,7 @@ HIP_SOURCES = [
     "box3_unfold.hip",
     "logits_softmax_warp.hip",
     "row_softmax.hip",
+    "wta_scale.hip",
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              "-Wall", "-Wno-unused-function"]

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void center_l2norm_fwd_kernel(const float* __r
                                                                 float* __restrict__ y,
                                                                 float* __restrict__ norm_out,
                                                                 const float* __restrict__ row_mean,
-                                                                int K, int N, float eps) {
+                                                                int K, int N, float eps, bool center) {
     __shared__ float red[3 * 4 * CN_POS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void center_l2norm_fwd_kernel(const float* __r
     float* yb = y + (size_t)b * K * N;
 
     float mean = 0.f;
-    if (PONO_C) {
+    if (PONO_C && center) {   // !center: plain L2 normalisation (util.feature_normalize)
         float part[1] = {0.f};
         if (ok)
             for (int k = wave; k < K; k += 4) part[0] += xb[(size_t)k * N + n];
@@ -114,7 +114,7 @@ template <bool PONO_C, int PASS>
 __global__ __launch_bounds__(256) void center_l2norm_bwd_kernel(
     const float* __restrict__ y, const float* __restrict__ nrm_in, const float* __restrict__ dy,
     float* __restrict__ dx, float* __restrict__ acol, const float* __restrict__ row_mean, int K,
-    int N, float eps) {
+    int N, float eps, bool center) {
     __shared__ float red[3 * 4 * CN_POS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.y;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_kernel(
             return;
         }
         const float g = (nrm > 0.f) ? s[0] / nrm : 0.f;
-        const float mean_dxc = (u * s[1] - g * s[2]) / (float)K;
+        const float mean_dxc = center ? (u * s[1] - g * s[2]) / (float)K : 0.f;
         if (ok)
             for (int k = wave; k < K; k += 4)
                 dxb[(size_t)k * N + n] =
@@ -181,7 +181,7 @@ template <int NI>   // NI = K / 16
 __global__ __launch_bounds__(256) void center_l2norm_fwd_reg_kernel(const float* __restrict__ x,
                                                                     float* __restrict__ y,
                                                                     float* __restrict__ norm_out, int K,
-                                                                    int N, float eps) {
+                                                                    int N, float eps, bool center) {
     __shared__ __attribute__((aligned(16))) float red[16 * 64];
     const int tid = threadIdx.x, pq = tid & 15, cg = tid >> 4;
     const int b = blockIdx.y, n = blockIdx.x * 64 + pq * 4;
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256) void center_l2norm_fwd_reg_kernel(const float*
         v[i] = buf_load4(x_rs, ok ? (unsigned)((cg + 16 * i) * N + n) * 4u : kBufOob);
         s[0] += v[i];
     }
-    reduce_cg<1>(s, red, cg, pq);
-    const f32x4 mean = s[0] * (1.0f / (float)K);
+    if (center) reduce_cg<1>(s, red, cg, pq);          // uniform branch (kernel argument)
+    const f32x4 mean = s[0] * (center ? 1.0f / (float)K : 0.0f);
     f32x4 ss[1] = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_reg_kernel(const float*
                                                                     const float* __restrict__ nrm_in,
                                                                     const float* __restrict__ dy,
                                                                     float* __restrict__ dx, int K, int N,
-                                                                    float eps) {
+                                                                    float eps, bool center) {
     __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
     const int tid = threadIdx.x, pq = tid & 15, cg = tid >> 4;
     const int b = blockIdx.y, n = blockIdx.x * 64 + pq * 4;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_reg_kernel(const float*
     for (int e = 0; e < 4; ++e) {
         u[e] = 1.0f / (nrm[e] + eps);
         g[e] = nrm[e] > 0.f ? s[0][e] / nrm[e] : 0.f;
-        m[e] = (u[e] * s[1][e] - g[e] * s[2][e]) / (float)K;
+        m[e] = center ? (u[e] * s[1][e] - g[e] * s[2][e]) / (float)K : 0.f;
     }
     float* dxb = dx + (size_t)b * K * N;
 #pragma unroll
@@ -255,13 +255,13 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_reg_kernel(const float*
 
 template <bool BWD>
 static bool launch_reg_variant(const float* a, const float* nrm_in, const float* dy, float* out,
-                               float* norm_out, int B, int K, int N, float eps, hipStream_t s) {
+                               float* norm_out, int B, int K, int N, float eps, bool center, hipStream_t s) {
     if (K % 16 != 0 || K / 16 > CNR_MAXI || N % 4 != 0 || !aligned16(a) || !aligned16(out)) return false;
     const dim3 grid((N + 63) / 64, B);
 #define COCOS_NI(NI)                                                                                     \
     case NI:                                                                                             \
-        if (BWD) hipLaunchKernelGGL(center_l2norm_bwd_reg_kernel<NI>, grid, dim3(256), 0, s, a, nrm_in, dy, out, K, N, eps); \
-        else hipLaunchKernelGGL(center_l2norm_fwd_reg_kernel<NI>, grid, dim3(256), 0, s, a, out, norm_out, K, N, eps);      \
+        if (BWD) hipLaunchKernelGGL(center_l2norm_bwd_reg_kernel<NI>, grid, dim3(256), 0, s, a, nrm_in, dy, out, K, N, eps, center); \
+        else hipLaunchKernelGGL(center_l2norm_fwd_reg_kernel<NI>, grid, dim3(256), 0, s, a, out, norm_out, K, N, eps, center);      \
         return true;
     switch (K / 16) {
         COCOS_NI(1) COCOS_NI(2) COCOS_NI(4) COCOS_NI(8) COCOS_NI(16) COCOS_NI(32)
@@ -281,10 +281,13 @@ extern "C" int cocos_center_l2norm_fwd(const float* x, float* y, float* norm, fl
                   "center_l2norm_fwd: bad dims B=%d K=%d N=%d", B, K, N);
     hipStream_t s = as_stream(stream);
     const dim3 grid((N + CN_POS - 1) / CN_POS, B);
+    COCOS_REQUIRE(center_over_channels >= 0 && center_over_channels <= 2, COCOS_ERR_INVALID,
+                  "center_l2norm_fwd: mode %d (0 positions, 1 channels, 2 none)", center_over_channels);
+    const bool center = center_over_channels != COCOS_CENTER_NONE;
     if (center_over_channels) {
-        if (!launch_reg_variant<false>(x, nullptr, nullptr, y, norm, B, K, N, eps, s))
+        if (!launch_reg_variant<false>(x, nullptr, nullptr, y, norm, B, K, N, eps, center, s))
             hipLaunchKernelGGL(center_l2norm_fwd_kernel<true>, grid, dim3(256), 0, s, x, y, norm,
-                               (const float*)nullptr, K, N, eps);
+                               (const float*)nullptr, K, N, eps, center);
     } else {
         COCOS_REQUIRE(row_ws, COCOS_ERR_INVALID,
                       "center_l2norm_fwd: row_ws [B*K] required when centring over positions");
@@ -292,7 +295,7 @@ extern "C" int cocos_center_l2norm_fwd(const float* x, float* y, float* norm, fl
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                            row_ws, K, N, eps);
         hipLaunchKernelGGL(center_l2norm_fwd_kernel<false>, grid, dim3(256), 0, s, x, y, norm,
-                           (const float*)row_ws, K, N, eps);
+                           (const float*)row_ws, K, N, eps, true);
     }
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
@@ -308,19 +311,22 @@ extern "C" int cocos_center_l2norm_bwd(const float* y, const float* norm, const 
                   "center_l2norm_bwd: bad dims B=%d K=%d N=%d", B, K, N);
     hipStream_t s = as_stream(stream);
     const dim3 grid((N + CN_POS - 1) / CN_POS, B);
+    COCOS_REQUIRE(center_over_channels >= 0 && center_over_channels <= 2, COCOS_ERR_INVALID,
+                  "center_l2norm_bwd: mode %d (0 positions, 1 channels, 2 none)", center_over_channels);
+    const bool center = center_over_channels != COCOS_CENTER_NONE;
     if (center_over_channels) {
-        if (!launch_reg_variant<true>(y, norm, dy, dx, nullptr, B, K, N, eps, s))
+        if (!launch_reg_variant<true>(y, norm, dy, dx, nullptr, B, K, N, eps, center, s))
             hipLaunchKernelGGL((center_l2norm_bwd_kernel<true, 1>), grid, dim3(256), 0, s, y, norm,
-                               dy, dx, (float*)nullptr, (const float*)nullptr, K, N, eps);
+                               dy, dx, (float*)nullptr, (const float*)nullptr, K, N, eps, center);
     } else {
         COCOS_REQUIRE(col_ws && row_ws, COCOS_ERR_INVALID,
                       "center_l2norm_bwd: col_ws [B*N] and row_ws [B*K] required");
         hipLaunchKernelGGL((center_l2norm_bwd_kernel<false, 1>), grid, dim3(256), 0, s, y, norm,
-                           dy, dx, col_ws, (const float*)nullptr, K, N, eps);
+                           dy, dx, col_ws, (const float*)nullptr, K, N, eps, true);
         hipLaunchKernelGGL(row_mean_kernel<1>, dim3(B * K), dim3(256), 0, s, dy, y, norm,
                            (const float*)col_ws, row_ws, K, N, eps);
         hipLaunchKernelGGL((center_l2norm_bwd_kernel<false, 2>), grid, dim3(256), 0, s, y, norm,
-                           dy, dx, col_ws, (const float*)row_ws, K, N, eps);
+                           dy, dx, col_ws, (const float*)row_ws, K, N, eps, true);
     }
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;

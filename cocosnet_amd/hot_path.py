@@ -52,23 +52,6 @@ class HotPathConfig:
                    warp_cycle_w=float(g("warp_cycle_w", 0.0)), two_cycle=bool(g("two_cycle", False)))
 
 
-class _WTAScale(torch.autograd.Function):
-    """WTA_scale of the reference (correspondence.py:38-77): forward keeps each row's maxima and
-    multiplies the rest by `scale`; backward multiplies the gradient by 1 at the maxima and by the
-    reference's hard-coded 1e-4 elsewhere (:72) — NOT the true derivative, reproduced on purpose."""
-
-    @staticmethod
-    def forward(ctx, f, scale):
-        mask = f == f.max(dim=-1, keepdim=True)[0]
-        ctx.save_for_backward(mask)
-        return torch.where(mask, f, f * scale)
-
-    @staticmethod
-    def backward(ctx, grad):
-        (mask,) = ctx.saved_tensors
-        return grad * torch.where(mask, 1.0, 1e-4).to(grad.dtype), None
-
-
 def _flat(x):
     """[B,C,h,w] -> channel-major [B,C,h*w] (a view when contiguous)."""
     return x.reshape(x.shape[0], x.shape[1], -1)
@@ -170,8 +153,8 @@ def _scaled_logits(theta_raw, phi_raw, cfg, inv_t, detach_flag, wta):
     if detach_flag:                                                          # :292-293
         f = f.detach()
     if wta_on:
-        f = _WTAScale.apply(f, wta)                                          # :300-303
-    return f * inv_t                                                         # :304
+        return ops.wta_scale(f, wta, inv_t)                                  # :300-303 + :304 (K8)
+    return f * inv_t                                                         # :304 (detached: no graph)
 
 
 def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_seg_map,

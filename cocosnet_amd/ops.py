@@ -84,17 +84,18 @@ def _ptr(t):
 # ------------------------------------------------------------------------------------------
 class _CenterL2Norm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, center_over_channels: bool, eps: float):
+    def forward(ctx, x, center_over_channels: int, eps: float):
         x = _chk(x, "center_l2norm: x")
         B, K, N = x.shape
         y = torch.empty_like(x)
         norm = torch.empty((B, N), device=x.device, dtype=torch.float32)
+        center_over_channels = int(center_over_channels)      # 0 positions, 1 channels (PONO_C), 2 none
         row_ws = None if center_over_channels else torch.empty((B, K), device=x.device,
                                                                 dtype=torch.float32)
         _call("center_l2norm_fwd", "cocos_center_l2norm_fwd", x.data_ptr(), y.data_ptr(), norm.data_ptr(),
                   _ptr(row_ws), B, K, N, int(center_over_channels), float(eps), _stream())
         ctx.save_for_backward(y, norm)
-        ctx.cfg = (bool(center_over_channels), float(eps))
+        ctx.cfg = (center_over_channels, float(eps))
         return y
 
     @staticmethod
@@ -114,9 +115,17 @@ class _CenterL2Norm(torch.autograd.Function):
         return dx, None, None
 
 
-def center_l2norm(x: torch.Tensor, center_over_channels: bool, eps: float = NORM_EPS):
-    """x [B,K,N] -> (x - mean) / (||x - mean||_2 over K + eps); mean over K (PONO_C) or over N."""
-    return _CenterL2Norm.apply(x, center_over_channels, eps)
+def center_l2norm(x: torch.Tensor, center_over_channels, eps: float = NORM_EPS):
+    """x [B,K,N] -> (x - mean) / (||x - mean||_2 over K + eps); mean over K (True / 1: PONO_C), over N
+    (False / 0) or no centring at all (2)."""
+    return _CenterL2Norm.apply(x, int(center_over_channels), eps)
+
+
+def feature_normalize(x: torch.Tensor, eps: float = NORM_EPS):
+    """util.feature_normalize (util/util.py:31-34): x [B,C,h,w] / (||x||_2 over C + eps) — K1 without
+    the centring; used on the adaptor outputs right before the ResidualBlocks (correspondence.py:247-248)."""
+    B, C = x.shape[:2]
+    return _CenterL2Norm.apply(x.reshape(B, C, -1), 2, eps).reshape(x.shape)
 
 
 # ------------------------------------------------------------------------------------------
@@ -444,6 +453,43 @@ def logits_softmax_warp(logits_t, v):
         return _LogitsSoftmaxWarp.apply(logits_t, v)
     return torch.cat([_LogitsSoftmaxWarp.apply(logits_t, v[:, c0:c0 + MAX_FUSED_CV])
                       for c0 in range(0, Cv, MAX_FUSED_CV)], dim=1)
+
+
+# ------------------------------------------------------------------------------------------
+# K8  WTA_scale + /temperature on the materialised correlation   (correspondence.py:38-77, :300-304)
+# ------------------------------------------------------------------------------------------
+class _WTAScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, scale: float, post_scale: float):
+        f = _chk(f, "wta_scale: f")
+        cols = f.shape[-1]
+        rows = f.numel() // cols
+        nbytes = _lib.load().cocos_wta_scale_mask_bytes(rows, cols)
+        if nbytes < 0:
+            raise ValueError(f"wta_scale: bad shape {tuple(f.shape)}")
+        mask = torch.empty(nbytes, device=f.device, dtype=torch.uint8)      # 1 bit per element
+        y = torch.empty_like(f)
+        _call("wta_scale_fwd", "cocos_wta_scale_fwd", f.data_ptr(), y.data_ptr(), mask.data_ptr(), rows, cols,
+              float(scale), float(post_scale), _stream())
+        ctx.save_for_backward(mask)
+        ctx.post = float(post_scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = _chk(dy, "wta_scale: dy")
+        cols = dy.shape[-1]
+        dx = torch.empty_like(dy)
+        _call("wta_scale_bwd", "cocos_wta_scale_bwd", dy.data_ptr(), mask.data_ptr(), dx.data_ptr(),
+              dy.numel() // cols, cols, ctx.post, _stream())
+        return dx, None, None
+
+
+def wta_scale(f, scale: float, post_scale: float = 1.0):
+    """WTA_scale.apply(f, scale) * post_scale: each row's maxima kept, the rest multiplied by `scale`;
+    backward = grad * post_scale * (1 at the maxima, the reference's fixed 1e-4 elsewhere)."""
+    return _WTAScale.apply(f, scale, post_scale)
 
 
 def mfma_probe() -> torch.Tensor:

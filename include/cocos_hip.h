@@ -44,11 +44,17 @@ const char* cocos_last_error_string(void);
  *   x      [B,K,N]  raw theta/phi (after view or F.unfold)
  *   y      [B,K,N]  out: (x - mean) / (||x - mean||_2 over K + eps)
  *   norm   [B,N]    out: ||x - mean||_2 per position (saved for backward)
- *   center_over_channels != 0  -> PONO_C: mean over K per position   (dim_mean = 1)
+ *   center_over_channels == 1  -> PONO_C: mean over K per position   (dim_mean = 1)
  *                        == 0  -> mean over N per channel            (dim_mean = -1);
  *                                 needs row_ws [B,K] floats of scratch.
+ *                        == 2  -> no centring: y = x / (||x||_2 over K + eps), i.e.
+ *                                 util.feature_normalize (util/util.py:31-34) as applied to the adaptor
+ *                                 outputs at correspondence.py:247-248 (and :245 for the feature-pair loss)
  *   eps = sys.float_info.epsilon (2.220446049250313e-16) in the reference.
  * ------------------------------------------------------------------------------------- */
+#define COCOS_CENTER_POSITIONS 0
+#define COCOS_CENTER_CHANNELS 1
+#define COCOS_CENTER_NONE 2
 int cocos_center_l2norm_fwd(const float* x, float* y, float* norm, float* row_ws,
                             int B, int K, int N, int center_over_channels, float eps,
                             cocos_stream_t stream);
@@ -197,6 +203,19 @@ int cocos_logits_softmax_warp_fwd(const float* logits_t, const float* v, float* 
 int cocos_logits_softmax_warp_bwd(const float* logits_t, const float* v, const float* out,
                                   const float* lse, const float* dout, float* dlogits_t,
                                   int B, int Nq, int Nk, int Cv, cocos_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K8  WTA_scale (correspondence.py:38-77, applied :300-303) fused with the /temperature of :304,
+ *     on a materialised [rows, cols] correlation (rows = B*Nq):
+ *   fwd: y = (x == rowmax(x) ? x : x*scale) * post_scale;  mask = one BIT per element (x == rowmax),
+ *        64 columns per 64-bit word, cocos_wta_scale_mask_bytes(rows, cols) bytes (-1 on bad dims)
+ *   bwd: dx = dy * post_scale * (mask ? 1 : 1e-4)   — the reference's hard-coded 1e-4 (:72)
+ * ------------------------------------------------------------------------------------- */
+long long cocos_wta_scale_mask_bytes(long long rows, int cols);
+int cocos_wta_scale_fwd(const float* x, float* y, void* mask, long long rows, int cols,
+                        float scale, float post_scale, cocos_stream_t stream);
+int cocos_wta_scale_bwd(const float* dy, const void* mask, float* dx, long long rows, int cols,
+                        float post_scale, cocos_stream_t stream);
 
 /* Debug: runs one v_mfma_f32_32x32x2_f32 with known operands and dumps the 64x16 accumulator
  * registers to out[64*16] so the host can verify the lane/register -> (row, col) map. */

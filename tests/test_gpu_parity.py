@@ -409,3 +409,43 @@ def test_proj1x1_equals_conv2d(B, Cin, Cout, h, w):
     assert rel(xd.grad, x64.grad.numpy()) < 1e-5
     assert rel(wd.grad, w64.grad.numpy()) < 1e-5
     assert rel(bd.grad, b64.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("rows,cols", [(7, 4096), (3, 100), (2, 1), (5, 333), (1, 16384)])
+def test_wta_scale_kernel_matches_oracle(rows, cols):
+    """K8 vs the oracle's WTA rule (correspondence.py:47-58 fwd, :61-77 bwd), ties included; bit-exact."""
+    from cocosnet_amd import ops
+    rs = np.random.RandomState(cols)
+    f = rs.standard_normal((1, rows, cols)).astype(np.float32)
+    if cols > 8:
+        f[0, 0, 5] = f[0, 0, 3] = f[0, 0].max() + 1.0        # a tie: both maxima are kept
+    g = rs.standard_normal(f.shape).astype(np.float32)
+    fd = dev(f, True)
+    y = ops.wta_scale(fd, 0.5, 100.0)
+    y.backward(dev(g))
+    y_ref = (co.wta_scale(f.astype(np.float64), 0.5)).astype(np.float32) * np.float32(100.0)
+    dx_ref = co.wta_scale_bwd(f, g) * np.float32(100.0)
+    np.testing.assert_array_equal(y.detach().cpu().numpy(), y_ref)
+    np.testing.assert_allclose(fd.grad.cpu().numpy(), dx_ref, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("B,C,h,w", [(2, 256, 16, 16), (1, 7, 5, 3), (2, 64, 64, 64)])
+def test_feature_normalize_equals_reference_rule(B, C, h, w):
+    """K1 mode 2 (no centring) = util.feature_normalize (util/util.py:31-34), forward and backward."""
+    from cocosnet_amd import ops
+    import sys
+    rs = np.random.RandomState(C)
+    x, g = rs.standard_normal((B, C, h, w)), rs.standard_normal((B, C, h, w))
+    x[0, :, 0, 0] = 0.0                                           # a zero vector: 0 / (0 + eps) = 0
+    x64 = torch.from_numpy(x).requires_grad_(True)
+    y_ref = x64 / (torch.norm(x64, 2, 1, keepdim=True) + sys.float_info.epsilon)
+    y_ref.backward(torch.from_numpy(g))
+    xd = dev(x, True)
+    y = ops.feature_normalize(xd)
+    y.backward(dev(g))
+    assert rel(y, y_ref.detach().numpy()) < 1e-5
+    gref = x64.grad.numpy().copy()
+    got = xd.grad.cpu().numpy().astype(np.float64)
+    # the zero vector: torch's sub-gradient there is dy/eps (1e16-scale); compare the rest
+    gref[0, :, 0, 0] = got[0, :, 0, 0] = 0.0
+    assert np.abs(got - gref).max() / np.abs(gref).max() < 1e-5
