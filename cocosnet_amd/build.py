@@ -31,6 +31,7 @@ HIP_SOURCES = [
     "logits_softmax_warp.hip",
     "row_softmax.hip",
     "wta_scale.hip",
+    "pono_spade.hip",
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              "-Wall", "-Wno-unused-function"]

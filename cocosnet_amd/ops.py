@@ -492,6 +492,48 @@ def wta_scale(f, scale: float, post_scale: float = 1.0):
     return _WTAScale.apply(f, scale, post_scale)
 
 
+# ------------------------------------------------------------------------------------------
+# K9  PONO + SPADE modulation + LeakyReLU   (normalization.py:63-68,:148-151; architecture.py:88-95)
+# ------------------------------------------------------------------------------------------
+PONO_EPS = 1e-5   # PositionalNorm2d's epsilon (normalization.py:63)
+
+
+class _PonoSpade(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope: float, eps: float):
+        x, gamma, beta = _chk(x, "pono_spade: x"), _chk(gamma, "pono_spade: gamma"), _chk(beta, "pono_spade: beta")
+        if gamma.shape != x.shape or beta.shape != x.shape:
+            raise ValueError(f"pono_spade: x{tuple(x.shape)} gamma{tuple(gamma.shape)} beta{tuple(beta.shape)}")
+        B, C = x.shape[:2]
+        N = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        _call("pono_spade_fwd", "cocos_pono_spade_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+              y.data_ptr(), B, C, N, float(eps), float(slope), _stream())
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.cfg = (float(slope), float(eps))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        slope, eps = ctx.cfg
+        dy = _chk(dy, "pono_spade: dy")
+        B, C = x.shape[:2]
+        N = x.numel() // (B * C)
+        need_x, need_g, need_b = ctx.needs_input_grad[:3]
+        dx = torch.empty_like(x) if need_x else None
+        dg = torch.empty_like(x) if need_g else None
+        db = torch.empty_like(x) if need_b else None
+        _call("pono_spade_bwd", "cocos_pono_spade_bwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+              dy.data_ptr(), _ptr(dx), _ptr(dg), _ptr(db), B, C, N, eps, slope, _stream())
+        return dx, dg, db, None, None
+
+
+def pono_spade(x, gamma, beta, slope: float = 1.0, eps: float = PONO_EPS):
+    """leaky_relu(PositionalNorm2d(x) * (1 + gamma) + beta, slope) for x, gamma, beta [B,C,H,W]."""
+    return _PonoSpade.apply(x, gamma, beta, slope, eps)
+
+
 def mfma_probe() -> torch.Tensor:
     """Debug: the 64x16 accumulator image of one v_mfma_f32_32x32x2_f32 (see api_common.hip)."""
     out = torch.empty((64, 16), device="cuda", dtype=torch.float32)

@@ -217,6 +217,21 @@ int cocos_wta_scale_fwd(const float* x, float* y, void* mask, long long rows, in
 int cocos_wta_scale_bwd(const float* dy, const void* mask, float* dx, long long rows, int cols,
                         float post_scale, cocos_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * K9  PONO + SPADE modulation + LeakyReLU, fused (`--PONO` networks):
+ *     PositionalNorm2d (normalization.py:63-68) -> SPADE.forward's `normalized * (1 + gamma) + beta`
+ *     (normalization.py:148-151) -> the LeakyReLU(0.2) of SPADEResnetBlock.actvn (architecture.py:88-95)
+ *   x, gamma, beta, y [B,C,N] fp32 (N = H*W);  C >= 2 (unbiased variance over channels)
+ *   fwd: xn = (x - mean_C) / sqrt(var_C + eps);  z = xn*(1+gamma) + beta;  y = z > 0 ? z : slope*z
+ *        (slope = 1: no activation, as for norm_s)
+ *   bwd: dx, dgamma, dbeta from dy (any of the three may be NULL); statistics are recomputed from x.
+ * ------------------------------------------------------------------------------------- */
+int cocos_pono_spade_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                         int B, int C, int N, float eps, float slope, cocos_stream_t stream);
+int cocos_pono_spade_bwd(const float* x, const float* gamma, const float* beta, const float* dy,
+                         float* dx, float* dgamma, float* dbeta,
+                         int B, int C, int N, float eps, float slope, cocos_stream_t stream);
+
 /* Debug: runs one v_mfma_f32_32x32x2_f32 with known operands and dumps the 64x16 accumulator
  * registers to out[64*16] so the host can verify the lane/register -> (row, col) map. */
 int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);

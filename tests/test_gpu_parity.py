@@ -449,3 +449,27 @@ def test_feature_normalize_equals_reference_rule(B, C, h, w):
     # the zero vector: torch's sub-gradient there is dy/eps (1e16-scale); compare the rest
     gref[0, :, 0, 0] = got[0, :, 0, 0] = 0.0
     assert np.abs(got - gref).max() / np.abs(gref).max() < 1e-5
+
+
+@pytest.mark.parametrize("B,C,h,w,slope", [(2, 512, 16, 16, 0.2), (1, 64, 8, 12, 1.0), (2, 96, 7, 5, 0.2),
+                                           (1, 2, 3, 3, 0.2), (1, 1024, 8, 8, 0.2), (1, 100, 16, 16, 0.2)])
+def test_pono_spade_equals_torch_chain(B, C, h, w, slope):
+    """K9 vs PositionalNorm2d (normalization.py:63-68) -> SPADE modulation (:148-151) -> LeakyReLU
+    (architecture.py:88-95) in torch fp64, forward and all three gradients."""
+    import torch.nn.functional as F
+    from cocosnet_amd import ops
+    rs = np.random.RandomState(C + h)
+    x, ga, be, g = (rs.standard_normal((B, C, h, w)) for _ in range(4))
+    x64, g64, b64 = (torch.from_numpy(t).requires_grad_(True) for t in (x, ga, be))
+    xn = (x64 - x64.mean(1, keepdim=True)) / (x64.var(1, keepdim=True) + 1e-5).sqrt()
+    y_ref = F.leaky_relu(xn * (1 + g64) + b64, slope)
+    y_ref.backward(torch.from_numpy(g))
+    xd, gd, bd = dev(x, True), dev(ga, True), dev(be, True)
+    y = ops.pono_spade(xd, gd, bd, slope)
+    y.backward(dev(g))
+    assert rel(y, y_ref.detach().numpy()) < 1e-5
+    # dx = r*(dxn - mean(dxn) - xn*sum(dxn*xn)/(C-1)): O(1) terms that cancel almost completely for tiny C,
+    # so the error is measured against the operands' scale (floor), not against a near-zero result
+    assert rel(xd.grad, x64.grad.numpy(), floor=0.1) < 2e-5
+    assert rel(gd.grad, g64.grad.numpy()) < 1e-5
+    assert rel(bd.grad, b64.grad.numpy()) < 1e-5
