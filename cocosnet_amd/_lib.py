@@ -77,6 +77,10 @@ _SIGNATURES = {
                                            ctypes.c_float, _stream_t]),
     "cocos_pono_spade_fwd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [_stream_t]),
     "cocos_pono_spade_bwd": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [_stream_t]),
+    "cocos_split_f16": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4
+                        + [ctypes.c_float, _stream_t]),
+    "cocos_corr_softmax_warp_fwd_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 6 + [_c_float_p] * 3 + [ctypes.c_int] * 5
+                                          + [ctypes.c_float, ctypes.c_float, _stream_t]),
     "cocos_debug_mfma_probe": (ctypes.c_int, [_c_float_p, _stream_t]),
 }
 

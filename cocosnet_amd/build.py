@@ -24,6 +24,8 @@ HIP_SOURCES = [
     "api_common.hip",
     "center_l2norm.hip",
     "corr_fused_fwd.hip",
+    "corr_fused_fwd_f16x3.hip",
+    "split_f16.hip",
     "corr_fused_bwd.hip",
     "corr_fused_bwd_saved.hip",
     "sgemm_mfma.hip",

@@ -1,0 +1,336 @@
+// K2 forward, split-precision flavour: fused correlation -> softmax -> warp on v_mfma_f32_32x32x16_f16
+// with every fp32 operand carried as f16 hi + f16 lo and three MFMA terms per product (gfx950).
+//
+// Same contract as corr_fused_fwd.hip (correspondence.py:281,:291,:304,:307,:318,:334; fp32 in HBM at the
+// API, fp32 accumulate, fp32 out) — the difference is where the FLOPs run.  On MI355X the fp32 MFMA
+// (32x32x2, 64 cycles) tops out at 157 TFLOP/s nominal / 134 sustained, while the f16 MFMA (32x32x16, 32
+// cycles) issues 16x the FLOPs per cycle: computing   a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi   (the dropped
+// a_lo.b_lo term is 2^-22 relative) costs 3 instructions of 32 cycles per 16 k instead of 8 of 64 —
+// 5.3x fewer matrix-pipe cycles at fp32-class accuracy (measured against the fp64 oracle in
+// tests/test_gpu_parity.py; tools/probes/f16x3_rate.hip for the instruction rates on this box).
+// Plain f16/bf16 operands would NOT do: the logits are cos/0.01, a 2^-11 operand error becomes a
+// 5 % error in softmax weights.
+//
+// Operand planes are prepared once per tensor by cocos_split_f16 (split_f16.hip):
+//   q, k : [B, N, 256] position-major, pre-scaled by 2^4 (unit-norm columns -> lo plane stays normal)
+//   v    : [B, Cv, N]  channel-major
+// Decomposition (one workgroup = 4 waves = 128 queries, 1 wave/SIMD, as in the fp32 kernel):
+//   * S^T (32 keys x 32 queries) = K_tile . Q : A = key rows from LDS (one ds_read_b128 = 8 channels of
+//     one key), B = the wave's query slice, register-resident for the whole kernel (hi+lo: 128 VGPRs);
+//   * lane&31 = query, so the online-softmax statistics are per-lane scalars; the 16 accumulator
+//     registers of a lane are 16 keys.  P is split to f16 hi/lo IN REGISTERS and is directly the B
+//     operand of the P.V MFMAs: accumulator registers 8t..8t+7 are the 8 k-slots of step t — the k
+//     order inside an MFMA is free as long as A uses the same one, so the V tile is written to LDS with
+//     its keys permuted to match (commit_v) and no cross-lane movement is needed;
+//   * O^T (Cv x 32 queries) accumulates in 16*CVB fp32 registers.
+#include "common.h"
+
+namespace cocos {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SP_BQ = 128;               // queries per workgroup
+constexpr int SP_BK = 32;                // keys per tile
+constexpr int SP_KD = 256;               // channels
+constexpr int SP_KROW = SP_KD + 8;       // halfs per key row in LDS: 528 B -> conflict-free b128 reads
+constexpr int SP_VROW = 40;              // halfs per channel row of the V tile: 80 B -> conflict-free
+constexpr float kSplitRescaleThr = 8.0f; // as kRescaleThr: p <= 2^8, far inside f16 range
+
+__device__ __forceinline__ f32x16 mfma16h(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f16x8 buf_load_h8(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ u32x4 buf_load_u4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ u32x2 buf_load_u2(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+}
+
+// p (>= 0, <= 2^8) -> f16 hi (round toward zero, so lo >= 0) and f16 lo, two values per instruction
+__device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& lo) {
+    hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
+}
+
+template <int CVB, bool STORE_S, bool RAGGED>
+__global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
+    const _Float16* __restrict__ qh, const _Float16* __restrict__ ql, const _Float16* __restrict__ kh,
+    const _Float16* __restrict__ kl, const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
+    float* __restrict__ out, float* __restrict__ lse, float* __restrict__ lg, int B, int Nq, int Nk, int Cv,
+    float scale_log2 /* inv_temperature * log2(e) / (q_scale * k_scale) */) {
+    constexpr int CVP = CVB * 32;
+    constexpr int KPLANE = SP_BK * SP_KROW;          // halfs per K plane per buffer
+    constexpr int VPLANE = CVP * SP_VROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16* const kt = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][32 keys][KROW]
+    _Float16* const vt = kt + 2 * 2 * KPLANE;                      // [2 buf][hi|lo][CVP][VROW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+
+    const int nqb = (Nq + SP_BQ - 1) / SP_BQ;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vb / nqb, qb = vb % nqb;
+    const int i_lane = qb * SP_BQ + wave * 32 + c;   // this lane's query position
+
+    const size_t qbytes = (size_t)Nq * SP_KD * 2, kbytes = (size_t)Nk * SP_KD * 2, vbytes = (size_t)Cv * Nk * 2;
+    const __amdgpu_buffer_rsrc_t qh_rs = make_rsrc(qh + (size_t)b * Nq * SP_KD, qbytes);
+    const __amdgpu_buffer_rsrc_t ql_rs = make_rsrc(ql + (size_t)b * Nq * SP_KD, qbytes);
+    const __amdgpu_buffer_rsrc_t kh_rs = make_rsrc(kh + (size_t)b * Nk * SP_KD, kbytes);
+    const __amdgpu_buffer_rsrc_t kl_rs = make_rsrc(kl + (size_t)b * Nk * SP_KD, kbytes);
+    const __amdgpu_buffer_rsrc_t vh_rs = make_rsrc(vh + (size_t)b * Cv * Nk, vbytes);
+    const __amdgpu_buffer_rsrc_t vl_rs = make_rsrc(vl + (size_t)b * Cv * Nk, vbytes);
+    const __amdgpu_buffer_rsrc_t lg_rs = make_rsrc(STORE_S ? lg + (size_t)b * Nk * Nq : nullptr,
+                                                   STORE_S ? (size_t)Nk * Nq * 4 : 0);
+    const unsigned lg_lane_off = i_lane < Nq ? (unsigned)(4 * h * Nq + i_lane) * 4u : kBufOob;
+
+    // ---- resident query slice: B operand of step s = channels 16s + 8h .. +7 of query c ------------
+    f16x8 qhr[SP_KD / 16], qlr[SP_KD / 16];
+    {
+        const unsigned q_off = i_lane < Nq ? (unsigned)(i_lane * SP_KD + h * 8) * 2u : kBufOob;
+#pragma unroll
+        for (int s = 0; s < SP_KD / 16; ++s) {
+            qhr[s] = buf_load_h8(qh_rs, q_off + (unsigned)s * 32u);
+            qlr[s] = buf_load_h8(ql_rs, q_off + (unsigned)s * 32u);
+        }
+    }
+
+    f32x16 o[CVB];
+#pragma unroll
+    for (int cb = 0; cb < CVB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // ---- staging: global -> registers (in flight under the MFMAs of the previous tile) -> LDS -------
+    // K: 32 keys x 512 B per plane = 1024 16-byte chunks, 4 per thread; a key row is contiguous in HBM.
+    // V: CVP rows x 64 B per plane = CVP*8 8-byte chunks (4 keys), CVB per thread.
+    u32x4 kst[2][4];
+    u32x2 vst[2][CVB];
+    auto fetch_k = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = u * 256 + tid, key = g >> 5, cc = g & 31;
+            // rows past Nk lie past the end of the buffer: the descriptor returns zeros
+            const unsigned off = (unsigned)((j0 + key) * SP_KD + cc * 8) * 2u;
+            kst[0][u] = buf_load_u4(kh_rs, off);
+            kst[1][u] = buf_load_u4(kl_rs, off);
+        }
+    };
+    auto fetch_v = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < CVB; ++u) {
+            const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
+            unsigned off = (unsigned)(row * Nk + j0 + 4 * kq) * 2u;
+            if (row >= Cv || j0 + 4 * kq >= Nk) off = kBufOob;     // Nk % 4 == 0 (checked by the launcher)
+            vst[0][u] = buf_load_u2(vh_rs, off);
+            vst[1][u] = buf_load_u2(vl_rs, off);
+        }
+    };
+    auto commit_k = [&](int buf) {
+        _Float16* base = kt + buf * 2 * KPLANE;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = u * 256 + tid, key = g >> 5, cc = g & 31;
+            *reinterpret_cast<u32x4*>(base + key * SP_KROW + cc * 8) = kst[0][u];
+            *reinterpret_cast<u32x4*>(base + KPLANE + key * SP_KROW + cc * 8) = kst[1][u];
+        }
+    };
+    auto commit_v = [&](int buf) {
+        _Float16* base = vt + buf * 2 * VPLANE;
+#pragma unroll
+        for (int u = 0; u < CVB; ++u) {
+            const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
+            // keys 4kq..4kq+3 -> k-slots of the P.V MFMA (see header): step kq>>2, half kq&1, quad (kq>>1)&1
+            const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);
+            *reinterpret_cast<u32x2*>(base + row * SP_VROW + slot) = vst[0][u];
+            *reinterpret_cast<u32x2*>(base + VPLANE + row * SP_VROW + slot) = vst[1][u];
+        }
+    };
+
+    const int ntiles = (Nk + SP_BK - 1) / SP_BK;
+    fetch_k(0);
+    fetch_v(0);
+    commit_k(0);
+    commit_v(0);
+    fetch_k(SP_BK);
+    fetch_v(SP_BK);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * SP_BK, buf = t & 1;
+        const bool ragged = RAGGED && (j0 + SP_BK > Nk);
+
+        // ---- S^T = K_tile . Q : 16 k-steps x 3 terms, operands read one step ahead -------------------
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        {
+            const _Float16* kb = kt + buf * 2 * KPLANE + c * SP_KROW + h * 8;
+            f16x8 ah[2], al[2];
+            ah[0] = *reinterpret_cast<const f16x8*>(kb);
+            al[0] = *reinterpret_cast<const f16x8*>(kb + KPLANE);
+#pragma unroll
+            for (int s = 0; s < SP_KD / 16; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                if (s + 1 < SP_KD / 16) {
+                    ah[nxt] = *reinterpret_cast<const f16x8*>(kb + (s + 1) * 16);
+                    al[nxt] = *reinterpret_cast<const f16x8*>(kb + KPLANE + (s + 1) * 16);
+                }
+                s0 = mfma16h(ah[cur], qhr[s], s0);
+                s1 = mfma16h(ah[cur], qlr[s], s1);
+                s1 = mfma16h(al[cur], qhr[s], s1);
+            }
+        }
+
+        // next tile: staged registers -> the other LDS buffer (last read in iteration t-1, released by
+        // the barrier that ended it), then the loads of tile t+2 go out and fly under the rest of t
+        commit_k(buf ^ 1);
+        commit_v(buf ^ 1);
+        fetch_k(j0 + 2 * SP_BK);
+        fetch_v(j0 + 2 * SP_BK);
+
+        // ---- online softmax (log2 domain), lazy rescale as in the fp32 kernel -------------------------
+        float p[16];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float x = (s0[r] + s1[r]) * scale_log2;
+            if (ragged && (j0 + acc_row_base(r) + 4 * h >= Nk)) x = -INFINITY;
+            p[r] = x;
+            tmax = fmaxf(tmax, x);
+        }
+        tmax = fmaxf(tmax, swap_half(tmax));
+        if (__any(tmax > m_run + kSplitRescaleThr)) {
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = fast_exp2(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int cb = 0; cb < CVB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (STORE_S) {
+                const int jr = j0 + acc_row_base(r);
+                buf_store1s(lg_rs, p[r], (!ragged || jr + 4 * h < Nk) ? lg_lane_off : kBufOob,
+                            (unsigned)jr * (unsigned)Nq * 4u);
+            }
+            p[r] = fast_exp2(p[r] - m_run);
+            psum += p[r];
+        }
+        l_run += psum;
+
+        // P -> f16 hi/lo: registers 8t..8t+7 are the k-slots of P.V step t
+        f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                f16x2 a, bq;
+                split_pair(p[8 * tt + j], p[8 * tt + j + 1], a, bq);
+                ph[tt][j] = a[0]; ph[tt][j + 1] = a[1];
+                pl[tt][j] = bq[0]; pl[tt][j + 1] = bq[1];
+            }
+
+        // ---- O^T += V . P : A = V tile rows (channels) with permuted keys, B = P ---------------------
+        {
+            const _Float16* vbase = vt + buf * 2 * VPLANE + c * SP_VROW + h * 8;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int cb = 0; cb < CVB; ++cb) {
+                    const f16x8 a_h = *reinterpret_cast<const f16x8*>(vbase + cb * 32 * SP_VROW + tt * 16);
+                    const f16x8 a_l = *reinterpret_cast<const f16x8*>(vbase + VPLANE + cb * 32 * SP_VROW + tt * 16);
+                    o[cb] = mfma16h(a_h, ph[tt], o[cb]);
+                    o[cb] = mfma16h(a_h, pl[tt], o[cb]);
+                    o[cb] = mfma16h(a_l, ph[tt], o[cb]);
+                }
+        }
+        __syncthreads();   // tile t+1 visible; buffer `buf` free for the commit of tile t+2
+    }
+
+    // ---- epilogue: normalise, store channel-major [B,Cv,Nq], store row LSE --------------------------
+    const float l_tot = l_run + swap_half(l_run);
+    const float inv_l = 1.0f / l_tot;
+    if (i_lane < Nq) {
+        float* out_b = out + (size_t)b * Cv * Nq;
+#pragma unroll
+        for (int cb = 0; cb < CVB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = cb * 32 + acc_row_base(r) + 4 * h;
+                if (ch < Cv) out_b[(size_t)ch * Nq + i_lane] = o[cb][r] * inv_l;
+            }
+        if (h == 0) lse[(size_t)b * Nq + i_lane] = (m_run + log2f(l_tot)) * kLn2;
+    }
+}
+
+template <int CVB, bool STORE_S, bool RAGGED>
+static int launch_f16x3_k(const _Float16* qh, const _Float16* ql, const _Float16* kh, const _Float16* kl,
+                          const _Float16* vh, const _Float16* vl, float* out, float* lse, float* lg, int B,
+                          int Nq, int Nk, int Cv, float scale_log2, hipStream_t stream) {
+    auto kern = corr_fwd_f16x3_kernel<CVB, STORE_S, RAGGED>;
+    const size_t smem = (size_t)2 * 2 * (SP_BK * SP_KROW + CVB * 32 * SP_VROW) * sizeof(_Float16);
+    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int nqb = (Nq + SP_BQ - 1) / SP_BQ;
+    hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, stream, qh, ql, kh, kl, vh, vl, out, lse, lg, B,
+                       Nq, Nk, Cv, scale_log2);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void* kh,
+                                                 const void* kl, const void* vh, const void* vl, float* out,
+                                                 float* lse, float* logits_t, int B, int K, int Nq, int Nk,
+                                                 int Cv, float inv_temperature, float operand_scale,
+                                                 cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(qh && ql && kh && kl && vh && vl && out && lse, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_fwd_f16x3: null pointer");
+    COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && operand_scale > 0.f, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_fwd_f16x3: bad dims B=%d Nq=%d Nk=%d Cv=%d", B, Nq, Nk, Cv);
+    COCOS_REQUIRE(K == 256, COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_fwd_f16x3: needs K == 256 (got %d)", K);
+    COCOS_REQUIRE(Cv <= 160, COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_fwd_f16x3: Cv=%d > 160", Cv);
+    COCOS_REQUIRE(Nk % 4 == 0, COCOS_ERR_UNSUPPORTED,
+                  "corr_softmax_warp_fwd_f16x3: Nk=%d must be a multiple of 4 (use the fp32 entry point)", Nk);
+    COCOS_REQUIRE((size_t)K * Nq * 2 < 0x7fffffffull && (size_t)K * Nk * 2 < 0x7fffffffull,
+                  COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_fwd_f16x3: per-sample tensor exceeds 2 GiB");
+    COCOS_REQUIRE(!logits_t || (size_t)Nq * Nk * 4 < 0x7fffffffull, COCOS_ERR_UNSUPPORTED,
+                  "corr_softmax_warp_fwd_f16x3: per-sample logits exceed 2 GiB; pass logits_t = NULL");
+    for (const void* p : {qh, ql, kh, kl})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "corr_softmax_warp_fwd_f16x3: q/k planes must be 16-byte aligned");
+    for (const void* p : {vh, vl})
+        COCOS_REQUIRE((reinterpret_cast<uintptr_t>(p) & 7u) == 0, COCOS_ERR_INVALID,
+                      "corr_softmax_warp_fwd_f16x3: v planes must be 8-byte aligned");
+    hipStream_t s = as_stream(stream);
+    const float scale_log2 = inv_temperature * kLog2e / (operand_scale * operand_scale);
+    const bool ragged = (Nk % SP_BK) != 0;
+    const _Float16 *a = static_cast<const _Float16*>(qh), *b2 = static_cast<const _Float16*>(ql),
+                   *c2 = static_cast<const _Float16*>(kh), *d = static_cast<const _Float16*>(kl),
+                   *e = static_cast<const _Float16*>(vh), *f = static_cast<const _Float16*>(vl);
+#define COCOS_GO(CVB, ST, RG) \
+    launch_f16x3_k<CVB, ST, RG>(a, b2, c2, d, e, f, out, lse, logits_t, B, Nq, Nk, Cv, scale_log2, s)
+#define COCOS_CVB(CVB)                                                           \
+    case CVB:                                                                    \
+        if (logits_t) return ragged ? COCOS_GO(CVB, true, true) : COCOS_GO(CVB, true, false); \
+        return ragged ? COCOS_GO(CVB, false, true) : COCOS_GO(CVB, false, false);
+    switch ((Cv + 31) / 32) {
+        COCOS_CVB(1) COCOS_CVB(2) COCOS_CVB(3) COCOS_CVB(4)
+        default: COCOS_CVB(5)
+    }
+#undef COCOS_CVB
+#undef COCOS_GO
+}

@@ -1,0 +1,110 @@
+// K10: split an fp32 tensor into two f16 planes, x*scale ~= hi + lo, for the split-precision (f16x3)
+// correlation kernels (gfx950).  hi = rn_f16(x*scale), lo = rn_f16(x*scale - hi): together 22 mantissa
+// bits, so   a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi   (three v_mfma_f32_32x32x16_f16, fp32 accumulate)
+// reproduces the fp32 product to ~2^-22 relative — fp32-class accuracy at 16/3 the fp32-MFMA rate.
+// `scale` is a power of two chosen by the caller so that the lo plane stays in f16's normal range
+// (unit-norm columns: scale = 16) — exact, undone in the consumer's logit scale.
+//
+//   transpose = 0:  x [B,C,N] -> hi, lo [B,C,N]   (channel-major: the V operand, key-contiguous)
+//   transpose = 1:  x [B,C,N] -> hi, lo [B,N,C]   (position-major: Q/K operands want 8 consecutive
+//                                                  channels of one position per lane = one 16-byte load)
+// HBM-bound: 4 B read + 4 B written per element.
+#include "common.h"
+
+namespace cocos {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+__global__ __launch_bounds__(256) void split_f16_flat_kernel(const float* __restrict__ x,
+                                                             _Float16* __restrict__ hi,
+                                                             _Float16* __restrict__ lo, size_t n4, size_t n,
+                                                             float scale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4) * scale;
+        f16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { _Float16 a, b; split1(v[e], a, b); h[e] = a; l[e] = b; }
+        *reinterpret_cast<f16x4*>(hi + i * 4) = h;
+        *reinterpret_cast<f16x4*>(lo + i * 4) = l;
+    } else {                // tail (n % 4 elements), or every element when the pointers are not 16-byte aligned
+        const size_t j = n4 * 4 + (i - n4);
+        if (j < n) split1(x[j] * scale, hi[j], lo[j]);
+    }
+}
+
+// 64 channels x 64 positions per workgroup through an LDS transpose
+__global__ __launch_bounds__(256) void split_f16_transpose_kernel(const float* __restrict__ x,
+                                                                  _Float16* __restrict__ hi,
+                                                                  _Float16* __restrict__ lo, int C, int N,
+                                                                  float scale) {
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, c0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const float* xb = x + (size_t)b * C * N;
+    {
+        const int q = tid & 15, r = tid >> 4;   // 16 position quads x 16 rows, 4 sweeps
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ch = c0 + r + 16 * u, n = n0 + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                tile[r + 16 * u][4 * q + e] = (ch < C && n + e < N) ? xb[(size_t)ch * N + n + e] * scale : 0.f;
+        }
+    }
+    __syncthreads();
+    const int p = tid >> 2, cq = tid & 3;       // position, 16-channel chunk
+    const int n = n0 + p;
+    if (n >= N) return;
+    _Float16* hrow = hi + ((size_t)b * N + n) * C;
+    _Float16* lrow = lo + ((size_t)b * N + n) * C;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int cbase = cq * 16 + g * 8;
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { _Float16 a, b; split1(tile[cbase + e][p], a, b); h[e] = a; l[e] = b; }
+        if (c0 + cbase + 8 <= C && (C % 8) == 0) {
+            *reinterpret_cast<f16x8*>(hrow + c0 + cbase) = h;
+            *reinterpret_cast<f16x8*>(lrow + c0 + cbase) = l;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (c0 + cbase + e < C) { hrow[c0 + cbase + e] = h[e]; lrow[c0 + cbase + e] = l[e]; }
+        }
+    }
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_split_f16(const float* x, void* hi, void* lo, int B, int C, int N, int transpose,
+                               float scale, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && hi && lo, COCOS_ERR_INVALID, "split_f16: null pointer");
+    COCOS_REQUIRE(B >= 1 && C >= 1 && N >= 1 && B <= 65535, COCOS_ERR_INVALID,
+                  "split_f16: bad dims B=%d C=%d N=%d", B, C, N);
+    hipStream_t s = as_stream(stream);
+    _Float16* h = static_cast<_Float16*>(hi);
+    _Float16* l = static_cast<_Float16*>(lo);
+    if (!transpose) {
+        const size_t n = (size_t)B * C * N;
+        const bool vec = aligned16(x) && (reinterpret_cast<uintptr_t>(hi) & 7u) == 0 &&
+                         (reinterpret_cast<uintptr_t>(lo) & 7u) == 0;
+        const size_t n4 = vec ? n / 4 : 0;
+        const size_t blocks = (n4 + (n - 4 * n4) + 255) / 256;
+        COCOS_REQUIRE(blocks <= 0x7fffffffull, COCOS_ERR_UNSUPPORTED, "split_f16: tensor too large");
+        hipLaunchKernelGGL(split_f16_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, h, l, n4, n, scale);
+    } else {
+        COCOS_REQUIRE((C + 63) / 64 <= 65535, COCOS_ERR_UNSUPPORTED, "split_f16: C too large");
+        hipLaunchKernelGGL(split_f16_transpose_kernel, dim3((N + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, x,
+                           h, l, C, N, scale);
+    }
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}

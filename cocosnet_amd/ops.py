@@ -7,7 +7,9 @@ the reference (models/networks/correspondence.py:274,284).
 """
 from __future__ import annotations
 
+import os
 import sys
+import weakref
 
 import torch
 
@@ -22,6 +24,12 @@ MAX_FUSED_CV = 160
 MAX_DS_WORKSPACE_BYTES = 16 << 30
 #: channel count the fused kernels are specialised for (self.inter_channels, correspondence.py:170)
 FUSED_K = 256
+#: where the K2 forward's products run: "fp32" = v_mfma_f32_32x32x2_f32 (exact fp32 operands);
+#: "f16x3" = v_mfma_f32_32x32x16_f16 on f16 hi+lo planes, 3 terms per product, fp32 accumulate
+#: (fp32-class accuracy, ~1/5 of the matrix-pipe time).  Module attribute, read at call time.
+PRECISION = os.environ.get("COCOS_PRECISION", "fp32")
+#: power-of-two pre-scale of the unit-norm operands before the f16 split (keeps the lo plane normal)
+SPLIT_OPERAND_SCALE = 16.0
 
 
 def _stream():
@@ -131,9 +139,36 @@ def feature_normalize(x: torch.Tensor, eps: float = NORM_EPS):
 # ------------------------------------------------------------------------------------------
 # K2  fused correlation -> softmax -> warp     (correspondence.py:291,:304,:307,:318)
 # ------------------------------------------------------------------------------------------
+_split_cache = {}   # id(tensor) -> (weakref to it, version, transpose, scale, hi, lo)
+
+
+def split_f16(x: torch.Tensor, transpose: bool, scale: float = 1.0, cache: bool = False):
+    """x [B,C,N] fp32 -> (hi, lo) f16 planes with x*scale ~= hi + lo; [B,N,C] when `transpose`.
+    `cache`: reuse the planes while the same tensor object is unmodified (theta/phi feed up to three
+    launches per forward: row pass, column pass, second row pass)."""
+    x = _chk(x, "split_f16: x")
+    key = (x._version, bool(transpose), float(scale))
+    if cache:
+        hit = _split_cache.get(id(x))
+        if hit is not None and hit[0]() is x and hit[1] == key:
+            return hit[2], hit[3]
+    B, C, N = x.shape
+    shape = (B, N, C) if transpose else (B, C, N)
+    hi = torch.empty(shape, device=x.device, dtype=torch.float16)
+    lo = torch.empty(shape, device=x.device, dtype=torch.float16)
+    _call("split_f16", "cocos_split_f16", x.data_ptr(), hi.data_ptr(), lo.data_ptr(), B, C, N, int(bool(transpose)),
+          float(scale), _stream())
+    if cache:
+        if len(_split_cache) > 64:      # drop entries whose tensor is gone
+            for k in [k for k, h in _split_cache.items() if h[0]() is None]:
+                del _split_cache[k]
+        _split_cache[id(x)] = (weakref.ref(x), key, hi, lo)
+    return hi, lo
+
+
 class _CorrSoftmaxWarp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qn, kn, v, inv_temperature: float, keep_logits: bool):
+    def forward(ctx, qn, kn, v, inv_temperature: float, keep_logits: bool, planes=None):
         qn, kn, v = _chk(qn, "qn"), _chk(kn, "kn"), _chk(v, "v")
         B, K, Nq = qn.shape
         Bk, Kk, Nk = kn.shape
@@ -148,9 +183,15 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         keep = (keep_logits and B * Nq * Nk * 4 <= MAX_DS_WORKSPACE_BYTES
                 and Nq * Nk * 4 < 2 ** 31 - 1)
         logits_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if keep else None
-        _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd", qn.data_ptr(), kn.data_ptr(),
-              v.data_ptr(), out.data_ptr(), lse.data_ptr(), _ptr(logits_t), B, K, Nq, Nk, Cv,
-              float(inv_temperature), _stream())
+        if planes is not None:       # split-precision flavour: same outputs, f16x3 matrix products
+            qh, ql, kh, kl, vh, vl = planes
+            _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd_f16x3", qh.data_ptr(), ql.data_ptr(),
+                  kh.data_ptr(), kl.data_ptr(), vh.data_ptr(), vl.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                  _ptr(logits_t), B, K, Nq, Nk, Cv, float(inv_temperature), SPLIT_OPERAND_SCALE, _stream())
+        else:
+            _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd", qn.data_ptr(), kn.data_ptr(),
+                  v.data_ptr(), out.data_ptr(), lse.data_ptr(), _ptr(logits_t), B, K, Nq, Nk, Cv,
+                  float(inv_temperature), _stream())
         ctx.save_for_backward(qn, kn, v, out, lse)
         ctx.logits_t = logits_t
         ctx.inv_t = float(inv_temperature)
@@ -192,7 +233,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             _call("corr_softmax_warp_bwd_key", "cocos_corr_softmax_warp_bwd_key", qn.data_ptr(),
                   kn.data_ptr(), v.data_ptr(), lse.data_ptr(), dout.data_ptr(), dvec.data_ptr(),
                   _ptr(dkn), _ptr(dv), *dims)
-        return dqn, (dkn if need_k else None), dv, None, None
+        return dqn, (dkn if need_k else None), dv, None, None, None
 
 
 def _wants_logits(qn, kn):
@@ -208,11 +249,21 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float):
     160 channels (each chunk recomputes the logits; no materialisation)."""
     Cv = v.shape[1]
     keep = _wants_logits(qn, kn)
+    if PRECISION not in ("fp32", "f16x3"):
+        raise ValueError(f"cocosnet_amd.ops.PRECISION = {PRECISION!r}: expected 'fp32' or 'f16x3'")
+    split = PRECISION == "f16x3" and qn.shape[1] == FUSED_K and kn.shape[2] % 4 == 0
+
+    def run(vv):
+        planes = None
+        if split:   # operand planes: theta/phi once per forward (cached), V per launch
+            with torch.no_grad():
+                planes = (*split_f16(qn, True, SPLIT_OPERAND_SCALE, cache=True),
+                          *split_f16(kn, True, SPLIT_OPERAND_SCALE, cache=True), *split_f16(vv, False, 1.0))
+        return _CorrSoftmaxWarp.apply(qn, kn, vv, inv_temperature, keep, planes)
+
     if Cv <= MAX_FUSED_CV:
-        return _CorrSoftmaxWarp.apply(qn, kn, v, inv_temperature, keep)
-    parts = [_CorrSoftmaxWarp.apply(qn, kn, v[:, c0:c0 + MAX_FUSED_CV], inv_temperature, keep)
-             for c0 in range(0, Cv, MAX_FUSED_CV)]
-    return torch.cat(parts, dim=1)
+        return run(v)
+    return torch.cat([run(v[:, c0:c0 + MAX_FUSED_CV]) for c0 in range(0, Cv, MAX_FUSED_CV)], dim=1)
 
 
 # ------------------------------------------------------------------------------------------

@@ -86,6 +86,25 @@ int cocos_corr_softmax_warp_fwd(const float* qn, const float* kn, const float* v
                                 int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
                                 cocos_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * K2 forward, split-precision flavour (same reference lines, same outputs as the call above): the
+ * matrix products run on v_mfma_f32_32x32x16_f16 with every fp32 operand carried as two f16 planes,
+ * x*scale ~= hi + lo (22 mantissa bits), three MFMA terms per product, fp32 accumulation — fp32-class
+ * accuracy at ~1/5 of the fp32-MFMA pipe time on gfx950.
+ *   cocos_split_f16:  x [B,C,N] fp32 -> hi, lo (f16); transpose = 0: [B,C,N]; 1: [B,N,C]; `scale` must be
+ *                     a power of two (exact).
+ *   qh,ql [B,Nq,256]  kh,kl [B,Nk,256]  position-major planes of qn*operand_scale, kn*operand_scale
+ *   vh,vl [B,Cv,Nk]   channel-major planes of v (scale 1)
+ *   Supported: K == 256, 1 <= Cv <= 160, Nk % 4 == 0 (otherwise COCOS_ERR_UNSUPPORTED: use the fp32 call).
+ * ------------------------------------------------------------------------------------- */
+int cocos_split_f16(const float* x, void* hi, void* lo, int B, int C, int N, int transpose, float scale,
+                    cocos_stream_t stream);
+int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void* kh, const void* kl,
+                                      const void* vh, const void* vl,
+                                      float* out, float* lse, float* logits_t /* nullable */,
+                                      int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
+                                      float operand_scale, cocos_stream_t stream);
+
 /* Backward of K2 (autograd of :291-318), flash-style: the logits are recomputed from qn/kn and `lse`.
  *   dout [B,Cv,Nq] -> dqn [B,K,Nq], dkn [B,K,Nk], dv [B,Cv,Nk]
  * It is exposed in stages so that the caller picks the strategy for the key side:

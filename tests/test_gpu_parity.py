@@ -40,8 +40,17 @@ def dev(a, grad=False):
 
 
 # ------------------------------------------------------------------ golden fixtures (reference)
+@pytest.fixture(params=["fp32", "f16x3"])
+def precision(request, monkeypatch):
+    """Both flavours of the K2 forward: exact-fp32 MFMA and the split-precision f16x3 MFMA path (the
+    latter silently uses the fp32 kernel for shapes it does not take, e.g. Nk % 4 != 0)."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PRECISION", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name", sorted(gc.CASES))
-def test_hot_path_matches_reference_fixtures(name):
+def test_hot_path_matches_reference_fixtures(name, precision):
     from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
     c = gc.CASES[name]
     inp = gc.make_inputs(name)
@@ -90,8 +99,26 @@ FUSED_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("B,C,N,transpose,scale", [(2, 256, 64, True, 16.0), (1, 154, 100, False, 1.0),
+                                                   (1, 7, 5, True, 4.0), (2, 3, 33, False, 1.0),
+                                                   (1, 256, 4096, True, 16.0)])
+def test_split_f16_planes(B, C, N, transpose, scale):
+    """K10: hi + lo reproduces x*scale to 2^-21 relative (or f16's subnormal quantum), in the requested layout."""
+    from cocosnet_amd import ops
+    rs = np.random.RandomState(N)
+    x = (rs.standard_normal((B, C, N)) * rs.choice([1.0, 0.06, 1e-3], size=(B, C, N))).astype(np.float32)
+    hi, lo = ops.split_f16(dev(x), transpose, scale)
+    assert hi.dtype == torch.float16 and tuple(hi.shape) == ((B, N, C) if transpose else (B, C, N))
+    rec = hi.double().cpu().numpy() + lo.double().cpu().numpy()
+    ref = x.astype(np.float64) * scale
+    if transpose:
+        ref = ref.transpose(0, 2, 1)
+    err = np.abs(rec - ref)
+    assert (err <= np.maximum(np.abs(ref) * 2.0 ** -21, 2.0 ** -25)).all(), err.max()
+
+
 @pytest.mark.parametrize("B,Nq,Nk,Cv,peaked", FUSED_SHAPES)
-def test_fused_forward_backward_vs_oracle(B, Nq, Nk, Cv, peaked):
+def test_fused_forward_backward_vs_oracle(B, Nq, Nk, Cv, peaked, precision):
     from cocosnet_amd import ops
     qn, kn, v = _qkv(B, Nq, Nk, Cv, seed=Nq * 7 + Nk, peaked=peaked)
     g = np.random.RandomState(5).standard_normal((B, Cv, Nq))
