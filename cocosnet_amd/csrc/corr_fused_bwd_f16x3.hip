@@ -1,0 +1,373 @@
+// K2 backward, query side, split-precision flavour (training path with saved logits) — gfx950.
+//
+// Same math as corr_fused_bwd_saved.hip (autograd of correspondence.py:291-318 w.r.t. theta, plus the
+// dS^T matrix the key-side GEMM consumes), with both per-tile products on v_mfma_f32_32x32x16_f16 and
+// every fp32 operand carried as f16 hi + lo (three MFMA terms per product, fp32 accumulate; see
+// corr_fused_fwd_f16x3.hip for the arithmetic argument):
+//     dP'(t)  = V(t) . dO'                  A = V tile rows (keys) x 16 channels, B = resident dO' slice
+//     dS''(t) = P(t) * (dP'(t) - D') * c     P from the saved logits, D' = s_o * sum_c dO*out (fp64)
+//     dqn    += K(t) . dS''(t)               A = key tile rows (channels) x 16 permuted keys, B = dS''
+// Scaled domains (all powers of two, exact, undone in the epilogue / by the GEMM):
+//     dO' = s_o * dO   with s_o = 2^e from the tensor's |max| (device scalar written by cocos_split_f16_ex),
+//     dS'' = s_o * ds_shift * dS  with ds_shift = the power of two that keeps the worst case
+//            2 * CVP * 2^10 * max|v| * inv_t  below 2^15 (computed here from the device-side max|v|; the product
+//            s_o * ds_shift is written to `ds_scale_out` for the GEMM to undo),
+//     K planes = k_scale * kn.
+// The dS'' planes (f16 hi/lo, [B,Nk,Nq]) replace the fp32 dS^T/T matrix of the fp32 path: same bytes,
+// already in the operand format of the f16x3 key-side GEMM (hgemm_f16x3.hip).
+#include "common.h"
+
+namespace cocos {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BQH_KD = 256;
+constexpr int BQH_KROW = 40;     // halfs per channel row of the key tile (32 permuted keys + pad): 80 B
+
+__device__ __forceinline__ f32x16 bq_mfma(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 bq_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void bq_split_pair(float a, float b, f16x2& hi, f16x2& lo) {
+    hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
+}
+
+template <int CVB, bool STORE_DS, bool RAGGED>
+__global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
+    const _Float16* __restrict__ kch, const _Float16* __restrict__ kcl,   // [B,256,Nk] planes of k_scale*kn
+    const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] planes of v
+    const _Float16* __restrict__ gph, const _Float16* __restrict__ gpl,   // [B,Nq,CVP] planes of s_o*dout
+    const float* __restrict__ g_scale,                                     // s_o (device)
+    const float* __restrict__ outp, const float* __restrict__ dout,        // [B,Cv,Nq] fp32 (for D)
+    const float* __restrict__ lse, const float* __restrict__ lg,           // [B,Nq], [B,Nk,Nq]
+    float* __restrict__ dqn,                                               // out [B,256,Nq]
+    _Float16* __restrict__ dsh, _Float16* __restrict__ dsl,                // out [B,Nk,Nq] planes of dS''
+    const float* __restrict__ v_amax,                                      // max|v| (device)
+    float* __restrict__ ds_scale_out,                                      // out: s_o * ds_shift (device)
+    int B, int Nq, int Nk, int Cv, float inv_t, float k_scale) {
+    constexpr int CVP = CVB * 32;
+    constexpr int CVS = CVP / 16;                     // k-steps of the dP product
+    constexpr int KB = BQH_KD / 32;                   // channel blocks of dqn
+    constexpr int VROW = CVP + 8;                     // halfs per key row of the V tile
+    constexpr int VPLANE = 32 * VROW, KPLANE = BQH_KD * BQH_KROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16* const vt = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][32 keys][VROW]
+    _Float16* const kt = vt + 2 * 2 * VPLANE;                      // [2 buf][hi|lo][256 ch][KROW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+
+    const int nqb = (Nq + 127) / 128;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vb / nqb, q0 = (vb % nqb) * 128;
+    const int i_lane = q0 + wave * 32 + c;
+    const bool live = i_lane < Nq;
+
+    const size_t kbytes = (size_t)BQH_KD * Nk * 2, vbytes = (size_t)Nk * CVP * 2, gbytes = (size_t)Nq * CVP * 2;
+    const __amdgpu_buffer_rsrc_t kh_rs = make_rsrc(kch + (size_t)b * BQH_KD * Nk, kbytes);
+    const __amdgpu_buffer_rsrc_t kl_rs = make_rsrc(kcl + (size_t)b * BQH_KD * Nk, kbytes);
+    const __amdgpu_buffer_rsrc_t vh_rs = make_rsrc(vph + (size_t)b * Nk * CVP, vbytes);
+    const __amdgpu_buffer_rsrc_t vl_rs = make_rsrc(vpl + (size_t)b * Nk * CVP, vbytes);
+    const __amdgpu_buffer_rsrc_t gh_rs = make_rsrc(gph + (size_t)b * Nq * CVP, gbytes);
+    const __amdgpu_buffer_rsrc_t gl_rs = make_rsrc(gpl + (size_t)b * Nq * CVP, gbytes);
+    const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(outp + (size_t)b * Cv * Nq, (size_t)Cv * Nq * 4);
+    const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(dout + (size_t)b * Cv * Nq, (size_t)Cv * Nq * 4);
+    const __amdgpu_buffer_rsrc_t lg_rs = make_rsrc(lg + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
+    const __amdgpu_buffer_rsrc_t dh_rs = make_rsrc(STORE_DS ? dsh + (size_t)b * Nk * Nq : nullptr,
+                                                   STORE_DS ? (size_t)Nk * Nq * 2 : 0);
+    const __amdgpu_buffer_rsrc_t dl_rs = make_rsrc(STORE_DS ? dsl + (size_t)b * Nk * Nq : nullptr,
+                                                   STORE_DS ? (size_t)Nk * Nq * 2 : 0);
+    // [Nk][Nq] matrices: lane offset = query column + the half-wave's 4 rows; the tile/register part of
+    // the row index is wave-uniform and travels in the scalar offset (not bounds-checked: see fetch_s)
+    const unsigned sr_lane_off = live ? (unsigned)(4 * h * Nq + i_lane) * 4u : kBufOob;
+    const unsigned ds_lane_off = live ? (unsigned)(4 * h * Nq + i_lane) * 2u : kBufOob;
+
+    const float s_o = *g_scale;
+    float ds_shift;
+    {
+        const float bound = 2.0f * CVP * 1024.0f * fmaxf(*v_amax, 1e-30f) * inv_t;   // >= |dP' - D'| * inv_t
+        int e;
+        frexpf(bound * (1.0f / 32768.0f), &e);                                          // 2^e > bound / 2^15
+        ds_shift = ldexpf(1.0f, -min(max(e, -20), 60));
+        if (ds_scale_out && blockIdx.x == 0 && tid == 0) *ds_scale_out = s_o * ds_shift;
+    }
+
+    // ---- resident: dO' slice (B operand of dP'), D' and lse of the lane's query ---------------------
+    f16x8 goh[CVS], gol[CVS];
+    {
+        const unsigned off = live ? (unsigned)(i_lane * CVP + h * 8) * 2u : kBufOob;
+#pragma unroll
+        for (int u = 0; u < CVS; ++u) {
+            goh[u] = __builtin_bit_cast(f16x8, bq_load16(gh_rs, off + (unsigned)u * 32u));
+            gol[u] = __builtin_bit_cast(f16x8, bq_load16(gl_rs, off + (unsigned)u * 32u));
+        }
+    }
+    float d_lane;
+    {
+        // D in fp64 from the fp32 tensors (dP' - D' cancels wherever P is peaked); the two half-waves
+        // take alternate channels
+        double dacc = 0.0;
+        for (int ch = h; ch < Cv; ch += 2) {
+            const unsigned off = live ? (unsigned)(ch * Nq + i_lane) * 4u : kBufOob;
+            dacc += (double)buf_load1(g_rs, off) * (double)buf_load1(o_rs, off);
+        }
+        const int lo = __shfl_xor((int)__double2loint(dacc), 32, 64);
+        const int hi = __shfl_xor((int)__double2hiint(dacc), 32, 64);
+        d_lane = (float)((dacc + __hiloint2double(hi, lo)) * (double)s_o);
+    }
+    const float lse2 = live ? lse[(size_t)b * Nq + i_lane] * kLog2e : INFINITY;   // padded lanes: P = 0
+    const float cs = inv_t * ds_shift;
+
+    f32x16 dx[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx[kb][r] = 0.f;
+
+    // ---- staging ---------------------------------------------------------------------------------------
+    // V tile: 32 key rows x CVP*2 B per plane = 32*CVP/8 16-byte chunks; K tile: 256 channel rows x 64 B per
+    // plane = 1024 16-byte chunks (8 keys each), 4 per thread.
+    constexpr int VCH = 32 * CVP / 8;                 // chunks per V plane
+    constexpr int VPT = (VCH + 255) / 256;
+    u32x4 vst[2][VPT], kst[2][4];
+    auto fetch_v = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
+            // rows past Nk lie past the end of the buffer -> zeros
+            const unsigned off = g < VCH ? (unsigned)((j0 + key) * CVP + cc * 8) * 2u : kBufOob;
+            vst[0][u] = bq_load16(vh_rs, off);
+            vst[1][u] = bq_load16(vl_rs, off);
+        }
+    };
+    auto fetch_k = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = u * 256 + tid, row = g >> 2, k8 = g & 3;
+            unsigned off = (unsigned)(row * Nk + j0 + 8 * k8) * 2u;
+            if (j0 + 8 * k8 >= Nk) off = kBufOob;      // Nk % 8 == 0 (checked by the launcher)
+            kst[0][u] = bq_load16(kh_rs, off);
+            kst[1][u] = bq_load16(kl_rs, off);
+        }
+    };
+    auto commit_v = [&](int buf) {
+        _Float16* base = vt + buf * 2 * VPLANE;
+#pragma unroll
+        for (int u = 0; u < VPT; ++u) {
+            const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
+            if (g < VCH) {
+                *reinterpret_cast<u32x4*>(base + key * VROW + cc * 8) = vst[0][u];
+                *reinterpret_cast<u32x4*>(base + VPLANE + key * VROW + cc * 8) = vst[1][u];
+            }
+        }
+    };
+    auto commit_k = [&](int buf) {
+        _Float16* base = kt + buf * 2 * KPLANE;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = u * 256 + tid, row = g >> 2, k8 = g & 3;
+            // keys 8k8..8k8+3 and 8k8+4..8k8+7 -> k-slots of the dqn MFMA: the accumulator registers of dS''
+            // are the B operand, register 8t+j of half-wave hh <-> key 16t + 8(j>>2) + 4hh + (j&3)
+            const int kq = 2 * k8;                                       // first 4-key group (kq even)
+            const int slot0 = 16 * (kq >> 2) + 4 * ((kq >> 1) & 1);     // hh = 0
+            _Float16* d = base + row * BQH_KROW;
+            *reinterpret_cast<u32x2*>(d + slot0) = u32x2{kst[0][u].x, kst[0][u].y};
+            *reinterpret_cast<u32x2*>(d + slot0 + 8) = u32x2{kst[0][u].z, kst[0][u].w};   // kq+1: hh = 1
+            *reinterpret_cast<u32x2*>(d + KPLANE + slot0) = u32x2{kst[1][u].x, kst[1][u].y};
+            *reinterpret_cast<u32x2*>(d + KPLANE + slot0 + 8) = u32x2{kst[1][u].z, kst[1][u].w};
+        }
+    };
+    float sld[16];
+    auto fetch_s = [&](int j0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jr = j0 + acc_row_base(r);
+            // the scalar offset is NOT bounds-checked: rows that do not exist are switched off through the
+            // per-lane offset (which must not make the scalar part lane-dependent: waterfall loops)
+            sld[r] = buf_load1s(lg_rs, (jr + 4 * h < Nk) ? sr_lane_off : kBufOob, (unsigned)jr * (unsigned)Nq * 4u);
+        }
+    };
+
+    const int ntiles = (Nk + 31) / 32;
+    fetch_v(0);
+    fetch_k(0);
+    fetch_s(0);
+    commit_v(0);
+    commit_k(0);
+    fetch_v(32);
+    fetch_k(32);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * 32, buf = t & 1;
+
+        // ---- dP' = V(t) . dO' -----------------------------------------------------------------------------
+        f32x16 dp0, dp1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dp0[r] = 0.f; dp1[r] = 0.f; }
+        {
+            const _Float16* vb0 = vt + buf * 2 * VPLANE + c * VROW + h * 8;
+            f16x8 ah[2], al[2];
+            ah[0] = *reinterpret_cast<const f16x8*>(vb0);
+            al[0] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE);
+#pragma unroll
+            for (int u = 0; u < CVS; ++u) {
+                const int cur = u & 1, nxt = cur ^ 1;
+                if (u + 1 < CVS) {
+                    ah[nxt] = *reinterpret_cast<const f16x8*>(vb0 + (u + 1) * 16);
+                    al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
+                }
+                dp0 = bq_mfma(ah[cur], goh[u], dp0);
+                dp1 = bq_mfma(ah[cur], gol[u], dp1);
+                dp1 = bq_mfma(al[cur], goh[u], dp1);
+            }
+        }
+
+        // ---- dS'' = P * (dP' - D') * inv_t * ds_shift ----------------------------------------------------------
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float pv = fast_exp2(sld[r] - lse2);
+            if (RAGGED && (j0 + acc_row_base(r) + 4 * h >= Nk)) pv = 0.f;
+            ds[r] = pv * ((dp0[r] + dp1[r]) - d_lane) * cs;
+        }
+        fetch_s(j0 + 32);        // logits of tile t+1 fly under the dqn product
+
+        // split to f16 hi/lo, two values per 32-bit register (register r>>1, half r&1); registers 8t..8t+7
+        // are the k-slots of step t of the dqn product
+        unsigned hw[8], lw[8];
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            f16x2 a, bq;
+            bq_split_pair(ds[j], ds[j + 1], a, bq);
+            hw[j >> 1] = __builtin_bit_cast(unsigned, a);
+            lw[j >> 1] = __builtin_bit_cast(unsigned, bq);
+        }
+        f16x8 sh[2], sl[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            sh[tt] = __builtin_bit_cast(f16x8, u32x4{hw[4 * tt], hw[4 * tt + 1], hw[4 * tt + 2], hw[4 * tt + 3]});
+            sl[tt] = __builtin_bit_cast(f16x8, u32x4{lw[4 * tt], lw[4 * tt + 1], lw[4 * tt + 2], lw[4 * tt + 3]});
+        }
+        if (STORE_DS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jr = j0 + acc_row_base(r);
+                const bool ok = !RAGGED || (jr + 4 * h < Nk);
+                const unsigned lo = ok ? ds_lane_off : kBufOob, so = (unsigned)jr * (unsigned)Nq * 2u;
+                const unsigned short hv = (unsigned short)(hw[r >> 1] >> (16 * (r & 1)));
+                const unsigned short lv = (unsigned short)(lw[r >> 1] >> (16 * (r & 1)));
+                __builtin_amdgcn_raw_buffer_store_b16(hv, dh_rs, (int)lo, (int)so, 0);
+                __builtin_amdgcn_raw_buffer_store_b16(lv, dl_rs, (int)lo, (int)so, 0);
+            }
+        }
+
+        // next tile: staged registers -> the other buffer; loads of tile t+2 go out
+        commit_v(buf ^ 1);
+        commit_k(buf ^ 1);
+        fetch_v(j0 + 64);
+        fetch_k(j0 + 64);
+
+        // ---- dqn += K(t) . dS'' ---------------------------------------------------------------------------
+        {
+            const _Float16* kb0 = kt + buf * 2 * KPLANE + c * BQH_KROW + h * 8;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const f16x8 a_h = *reinterpret_cast<const f16x8*>(kb0 + kb * 32 * BQH_KROW + tt * 16);
+                    const f16x8 a_l = *reinterpret_cast<const f16x8*>(kb0 + KPLANE + kb * 32 * BQH_KROW + tt * 16);
+                    dx[kb] = bq_mfma(a_h, sh[tt], dx[kb]);
+                    dx[kb] = bq_mfma(a_h, sl[tt], dx[kb]);
+                    dx[kb] = bq_mfma(a_l, sh[tt], dx[kb]);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: undo the scales -----------------------------------------------------------------------
+    if (live) {
+        const float undo = 1.0f / (k_scale * s_o * ds_shift);
+        float* dx_b = dqn + (size_t)b * BQH_KD * Nq;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kb * 32 + acc_row_base(r) + 4 * h;
+                dx_b[(size_t)k * Nq + i_lane] = dx[kb][r] * undo;
+            }
+    }
+}
+
+template <int CVB>
+static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Float16* vph, const _Float16* vpl,
+                           const _Float16* gph, const _Float16* gpl, const float* g_scale, const float* outp,
+                           const float* dout, const float* lse, const float* lg, float* dqn, _Float16* dsh,
+                           _Float16* dsl, const float* v_amax, float* ds_scale_out, int B, int Nq, int Nk, int Cv,
+                           float inv_t, float k_scale, hipStream_t s) {
+    const bool ragged = (Nk % 32) != 0, store = dsh != nullptr;
+    const size_t smem = (size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) * sizeof(_Float16);
+    const int nqb = (Nq + 127) / 128;
+#define COCOS_GO(DS, RG)                                                                                     \
+    do {                                                                                                     \
+        auto kern = corr_bwd_query_f16x3_kernel<CVB, DS, RG>;                                                \
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
+        hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, s, kch, kcl, vph, vpl, gph, gpl, g_scale,   \
+                           outp, dout, lse, lg, dqn, dsh, dsl, v_amax, ds_scale_out, B, Nq, Nk, Cv, inv_t,    \
+                           k_scale);                                                                         \
+    } while (0)
+    if (store) { if (ragged) COCOS_GO(true, true); else COCOS_GO(true, false); }
+    else       { if (ragged) COCOS_GO(false, true); else COCOS_GO(false, false); }
+#undef COCOS_GO
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
+    const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
+    const float* g_scale_dev, const float* out, const float* dout, const float* lse, const float* logits_t,
+    float* dqn, void* dsh, void* dsl, const float* v_amax_dev, float* ds_scale_out_dev, int B, int K, int Nq,
+    int Nk, int Cv, int CvPad, float inv_temperature, float k_scale, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(kch && kcl && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse && logits_t && dqn &&
+                      v_amax_dev && ds_scale_out_dev,
+                  COCOS_ERR_INVALID, "corr_softmax_warp_bwd_query_f16x3: null pointer");
+    COCOS_REQUIRE((dsh == nullptr) == (dsl == nullptr), COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_query_f16x3: dsh and dsl must both be given or both be NULL");
+    COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && k_scale > 0.f, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_query_f16x3: bad dims B=%d Nq=%d Nk=%d Cv=%d", B, Nq, Nk, Cv);
+    COCOS_REQUIRE(K == 256 && Cv <= 160 && Nk % 8 == 0, COCOS_ERR_UNSUPPORTED,
+                  "corr_softmax_warp_bwd_query_f16x3: needs K == 256, Cv <= 160, Nk %% 8 == 0 (K=%d Cv=%d Nk=%d)",
+                  K, Cv, Nk);
+    const int cvb = (Cv + 31) / 32;
+    COCOS_REQUIRE(CvPad == cvb * 32, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_query_f16x3: CvPad=%d, expected %d (Cv rounded up to 32)", CvPad, cvb * 32);
+    COCOS_REQUIRE((size_t)Nq * Nk * 4 < 0x7fffffffull && (size_t)K * Nk * 2 < 0x7fffffffull &&
+                      (size_t)K * Nq * 4 < 0x7fffffffull,
+                  COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_bwd_query_f16x3: per-sample tensor exceeds 2 GiB");
+    for (const void* p : {kch, kcl, vph, vpl, gph, gpl})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "corr_softmax_warp_bwd_query_f16x3: planes must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+#define COCOS_ARGS                                                                                              \
+    static_cast<const _Float16*>(kch), static_cast<const _Float16*>(kcl), static_cast<const _Float16*>(vph),   \
+        static_cast<const _Float16*>(vpl), static_cast<const _Float16*>(gph), static_cast<const _Float16*>(gpl), \
+        g_scale_dev, out, dout, lse, logits_t, dqn, static_cast<_Float16*>(dsh), static_cast<_Float16*>(dsl),    \
+        v_amax_dev, ds_scale_out_dev, B, Nq, Nk, Cv, inv_temperature, k_scale, s
+    switch (cvb) {
+        case 1: return launch_bq_f16x3<1>(COCOS_ARGS);
+        case 2: return launch_bq_f16x3<2>(COCOS_ARGS);
+        case 3: return launch_bq_f16x3<3>(COCOS_ARGS);
+        case 4: return launch_bq_f16x3<4>(COCOS_ARGS);
+        default: return launch_bq_f16x3<5>(COCOS_ARGS);
+    }
+#undef COCOS_ARGS
+}

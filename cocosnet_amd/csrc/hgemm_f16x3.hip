@@ -1,0 +1,178 @@
+// Split-precision batched GEMM on v_mfma_f32_32x32x16_f16 (gfx950): both operands arrive as f16 hi + lo
+// planes, three MFMA terms per product, fp32 accumulate and output.
+//
+//   C[b][m][n] = (host_scale / *dev_scale) * sum_k A[b][m][k] * B[b][n][k]
+//   A planes [batch][M][K], B planes [batch][N][K]  (k contiguous), C fp32 [batch][M][N]
+//
+// Used as the key side of the K2 backward (autograd of correspondence.py:291 w.r.t. phi):
+//   dkn[c][j] = sum_i qn[c][i] * dS[i][j]   with  A = planes of k_scale*qn [256][Nq],
+//                                                 B = the dS'' planes [Nk][Nq] written by
+//                                                     corr_bwd_query_f16x3_kernel (already scaled by s_o*ds_shift)
+// At B=8, HW=4096 this is 68.7 GFLOP over a 512 MiB B operand that is read exactly once (the whole M = 256
+// extent sits in one workgroup tile): ~0.13 ms of matrix pipe at the sustained f16 rate against ~0.1 ms of
+// HBM — the fp32-MFMA version of the same product (sgemm_mfma.hip) is 0.56 ms.
+//
+// Tile 256 (M) x 128 (N) x 32 (K) per workgroup, 4 waves as 2 x 2, each wave 128 x 64 = 4 x 2 MFMA tiles
+// (128 accumulator registers).  LDS rows are 32 k-halfs + 8 pad = 80 B: the 16-byte operand reads of 16
+// consecutive rows fall into 16 distinct 4-bank groups (conflict-free).  Double-buffered; the loads of
+// k-block t+2 are in flight in registers while t multiplies.
+#include "common.h"
+
+namespace cocos {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HG_BM = 256, HG_BN = 128, HG_BK = 32;
+constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row
+
+__global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __restrict__ ah,
+                                                             const _Float16* __restrict__ al,
+                                                             const _Float16* __restrict__ bh,
+                                                             const _Float16* __restrict__ bl,
+                                                             float* __restrict__ C, int M, int N, int K,
+                                                             float host_scale,
+                                                             const float* __restrict__ dev_scale) {
+    constexpr int APLANE = HG_BM * HG_ROW, BPLANE = HG_BN * HG_ROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][256][ROW]
+    _Float16* const bt = at + 2 * 2 * APLANE;                      // [2 buf][hi|lo][128][ROW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int ntn = (N + HG_BN - 1) / HG_BN, ntm = (M + HG_BM - 1) / HG_BM;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vb / (ntn * ntm), rem = vb % (ntn * ntm);
+    const int m0 = (rem / ntn) * HG_BM, n0 = (rem % ntn) * HG_BN;
+
+    const size_t abytes = (size_t)M * K * 2, bbytes = (size_t)N * K * 2;
+    const __amdgpu_buffer_rsrc_t ah_rs = make_rsrc(ah + (size_t)b * M * K, abytes);
+    const __amdgpu_buffer_rsrc_t al_rs = make_rsrc(al + (size_t)b * M * K, abytes);
+    const __amdgpu_buffer_rsrc_t bh_rs = make_rsrc(bh + (size_t)b * N * K, bbytes);
+    const __amdgpu_buffer_rsrc_t bl_rs = make_rsrc(bl + (size_t)b * N * K, bbytes);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging: a row of a k-block is 64 B per plane = 4 chunks of 16 B (K % 8 == 0: chunks are whole)
+    u32x4 ast[2][4], bst[2][2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
+            unsigned off = (unsigned)((m0 + row) * K + k0 + kc * 8) * 2u;
+            if (m0 + row >= M || k0 + kc * 8 >= K) off = kBufOob;
+            ast[0][u] = __builtin_amdgcn_raw_buffer_load_b128(ah_rs, (int)off, 0, 0);
+            ast[1][u] = __builtin_amdgcn_raw_buffer_load_b128(al_rs, (int)off, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
+            unsigned off = (unsigned)((n0 + row) * K + k0 + kc * 8) * 2u;
+            if (n0 + row >= N || k0 + kc * 8 >= K) off = kBufOob;
+            bst[0][u] = __builtin_amdgcn_raw_buffer_load_b128(bh_rs, (int)off, 0, 0);
+            bst[1][u] = __builtin_amdgcn_raw_buffer_load_b128(bl_rs, (int)off, 0, 0);
+        }
+    };
+    auto commit = [&](int buf) {
+        _Float16* ab = at + buf * 2 * APLANE;
+        _Float16* bb = bt + buf * 2 * BPLANE;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
+            *reinterpret_cast<u32x4*>(ab + row * HG_ROW + kc * 8) = ast[0][u];
+            *reinterpret_cast<u32x4*>(ab + APLANE + row * HG_ROW + kc * 8) = ast[1][u];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
+            *reinterpret_cast<u32x4*>(bb + row * HG_ROW + kc * 8) = bst[0][u];
+            *reinterpret_cast<u32x4*>(bb + BPLANE + row * HG_ROW + kc * 8) = bst[1][u];
+        }
+    };
+
+    const int nsteps = (K + HG_BK - 1) / HG_BK;
+    fetch(0);
+    commit(0);
+    fetch(HG_BK);
+    __syncthreads();
+
+    for (int t = 0; t < nsteps; ++t) {
+        const int buf = t & 1;
+        const _Float16* ab = at + buf * 2 * APLANE + (wm * 128 + c) * HG_ROW + h * 8;
+        const _Float16* bb = bt + buf * 2 * BPLANE + (wn * 64 + c) * HG_ROW + h * 8;
+#pragma unroll
+        for (int s = 0; s < HG_BK / 16; ++s) {
+            f16x8 bvh[2], bvl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bvh[j] = *reinterpret_cast<const f16x8*>(bb + j * 32 * HG_ROW + s * 16);
+                bvl[j] = *reinterpret_cast<const f16x8*>(bb + BPLANE + j * 32 * HG_ROW + s * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f16x8 avh = *reinterpret_cast<const f16x8*>(ab + i * 32 * HG_ROW + s * 16);
+                const f16x8 avl = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * HG_ROW + s * 16);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, bvh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (s == 0) {   // the other buffer was released by the barrier that ended step t-1
+                commit(buf ^ 1);
+                fetch((t + 2) * HG_BK);
+            }
+        }
+        __syncthreads();
+    }
+
+    const float scale = host_scale / (dev_scale ? *dev_scale : 1.0f);
+    float* Cb = C + (size_t)b * M * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 128 + i * 32 + acc_row_base(r) + 4 * h;
+                if (m < M && n < N) Cb[(size_t)m * N + n] = acc[i][j][r] * scale;
+            }
+        }
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
+                                 float* c, int batch, int M, int N, int K, float host_scale,
+                                 const float* dev_scale, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(a_hi && a_lo && b_hi && b_lo && c, COCOS_ERR_INVALID, "hgemm_f16x3: null pointer");
+    COCOS_REQUIRE(batch >= 1 && M >= 1 && N >= 1 && K >= 1, COCOS_ERR_INVALID,
+                  "hgemm_f16x3: bad dims batch=%d M=%d N=%d K=%d", batch, M, N, K);
+    COCOS_REQUIRE(K % 8 == 0, COCOS_ERR_UNSUPPORTED, "hgemm_f16x3: K=%d must be a multiple of 8", K);
+    COCOS_REQUIRE((size_t)M * K * 2 < 0x7fffffffull && (size_t)N * K * 2 < 0x7fffffffull, COCOS_ERR_UNSUPPORTED,
+                  "hgemm_f16x3: per-sample operand exceeds 2 GiB");
+    for (const void* p : {a_hi, a_lo, b_hi, b_lo})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "hgemm_f16x3: planes must be 16-byte aligned");
+    const long long blocks = (long long)batch * ((N + HG_BN - 1) / HG_BN) * ((M + HG_BM - 1) / HG_BM);
+    COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "hgemm_f16x3: grid too large");
+    const size_t smem = (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16);
+    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hgemm_f16x3_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(hgemm_f16x3_kernel, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),
+                       static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
+                       static_cast<const _Float16*>(b_hi), static_cast<const _Float16*>(b_lo), c, M, N, K,
+                       host_scale, dev_scale);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}

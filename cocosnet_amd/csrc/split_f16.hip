@@ -21,11 +21,18 @@ __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
+__device__ __forceinline__ float scale_from_amax(float amax);
+
 __global__ __launch_bounds__(256) void split_f16_flat_kernel(const float* __restrict__ x,
                                                              _Float16* __restrict__ hi,
                                                              _Float16* __restrict__ lo, size_t n4, size_t n,
-                                                             float scale) {
+                                                             float scale, const float* __restrict__ amax_dev,
+                                                             float* __restrict__ scale_out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (amax_dev) {
+        scale = scale_from_amax(*amax_dev);
+        if (scale_out && i == 0) *scale_out = scale;
+    }
     if (i < n4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4) * scale;
         f16x4 h, l;
@@ -39,15 +46,31 @@ __global__ __launch_bounds__(256) void split_f16_flat_kernel(const float* __rest
     }
 }
 
-// 64 channels x 64 positions per workgroup through an LDS transpose
+// Scale from a device-side |x| maximum: the power of two that brings it into [2^9, 2^10) (1 if amax is 0
+// or not finite) — gradients have no a-priori magnitude, and the f16 planes need one.
+__device__ __forceinline__ float scale_from_amax(float amax) {
+    if (!(amax > 0.f) || !(amax < INFINITY)) return 1.0f;
+    int e;
+    frexpf(amax, &e);                 // amax = m * 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, 10 - e);      // amax * scale in [2^9, 2^10)
+}
+
+// 64 channels x 64 positions per workgroup through an LDS transpose; rows of the output are Cpad halfs
+// (channels C..Cpad-1 zero) so that a consumer can read whole 16-channel MFMA k-steps
 __global__ __launch_bounds__(256) void split_f16_transpose_kernel(const float* __restrict__ x,
                                                                   _Float16* __restrict__ hi,
                                                                   _Float16* __restrict__ lo, int C, int N,
-                                                                  float scale) {
+                                                                  int Cpad, float scale,
+                                                                  const float* __restrict__ amax_dev,
+                                                                  float* __restrict__ scale_out) {
     __shared__ float tile[64][65];
     const int tid = threadIdx.x;
     const int b = blockIdx.z, c0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const float* xb = x + (size_t)b * C * N;
+    if (amax_dev) {
+        scale = scale_from_amax(*amax_dev);
+        if (scale_out && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *scale_out = scale;
+    }
     {
         const int q = tid & 15, r = tid >> 4;   // 16 position quads x 16 rows, 4 sweeps
 #pragma unroll
@@ -62,34 +85,31 @@ __global__ __launch_bounds__(256) void split_f16_transpose_kernel(const float* _
     const int p = tid >> 2, cq = tid & 3;       // position, 16-channel chunk
     const int n = n0 + p;
     if (n >= N) return;
-    _Float16* hrow = hi + ((size_t)b * N + n) * C;
-    _Float16* lrow = lo + ((size_t)b * N + n) * C;
+    _Float16* hrow = hi + ((size_t)b * N + n) * Cpad;
+    _Float16* lrow = lo + ((size_t)b * N + n) * Cpad;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int cbase = cq * 16 + g * 8;
         f16x8 h, l;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { _Float16 a, b; split1(tile[cbase + e][p], a, b); h[e] = a; l[e] = b; }
-        if (c0 + cbase + 8 <= C && (C % 8) == 0) {
+        // channels >= C were loaded as zeros: they ARE the padding
+        if (c0 + cbase + 8 <= Cpad && (Cpad % 8) == 0) {
             *reinterpret_cast<f16x8*>(hrow + c0 + cbase) = h;
             *reinterpret_cast<f16x8*>(lrow + c0 + cbase) = l;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                if (c0 + cbase + e < C) { hrow[c0 + cbase + e] = h[e]; lrow[c0 + cbase + e] = l[e]; }
+                if (c0 + cbase + e < Cpad) { hrow[c0 + cbase + e] = h[e]; lrow[c0 + cbase + e] = l[e]; }
         }
     }
 }
 
 }  // namespace cocos
 
-extern "C" int cocos_split_f16(const float* x, void* hi, void* lo, int B, int C, int N, int transpose,
-                               float scale, cocos_stream_t stream) {
+static int split_f16_launch(const float* x, void* hi, void* lo, int B, int C, int N, int Cpad, int transpose,
+                            float scale, const float* amax_dev, float* scale_out, hipStream_t s) {
     using namespace cocos;
-    COCOS_REQUIRE(x && hi && lo, COCOS_ERR_INVALID, "split_f16: null pointer");
-    COCOS_REQUIRE(B >= 1 && C >= 1 && N >= 1 && B <= 65535, COCOS_ERR_INVALID,
-                  "split_f16: bad dims B=%d C=%d N=%d", B, C, N);
-    hipStream_t s = as_stream(stream);
     _Float16* h = static_cast<_Float16*>(hi);
     _Float16* l = static_cast<_Float16*>(lo);
     if (!transpose) {
@@ -99,12 +119,34 @@ extern "C" int cocos_split_f16(const float* x, void* hi, void* lo, int B, int C,
         const size_t n4 = vec ? n / 4 : 0;
         const size_t blocks = (n4 + (n - 4 * n4) + 255) / 256;
         COCOS_REQUIRE(blocks <= 0x7fffffffull, COCOS_ERR_UNSUPPORTED, "split_f16: tensor too large");
-        hipLaunchKernelGGL(split_f16_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, h, l, n4, n, scale);
+        hipLaunchKernelGGL(split_f16_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, h, l, n4, n, scale,
+                           amax_dev, scale_out);
     } else {
-        COCOS_REQUIRE((C + 63) / 64 <= 65535, COCOS_ERR_UNSUPPORTED, "split_f16: C too large");
-        hipLaunchKernelGGL(split_f16_transpose_kernel, dim3((N + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, x,
-                           h, l, C, N, scale);
+        COCOS_REQUIRE((Cpad + 63) / 64 <= 65535, COCOS_ERR_UNSUPPORTED, "split_f16: C too large");
+        COCOS_REQUIRE(aligned16(hi) && aligned16(lo), COCOS_ERR_INVALID, "split_f16: planes must be 16-byte aligned");
+        hipLaunchKernelGGL(split_f16_transpose_kernel, dim3((N + 63) / 64, (Cpad + 63) / 64, B), dim3(256), 0, s, x,
+                           h, l, C, N, Cpad, scale, amax_dev, scale_out);
     }
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+extern "C" int cocos_split_f16(const float* x, void* hi, void* lo, int B, int C, int N, int transpose,
+                               float scale, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && hi && lo, COCOS_ERR_INVALID, "split_f16: null pointer");
+    COCOS_REQUIRE(B >= 1 && C >= 1 && N >= 1 && B <= 65535, COCOS_ERR_INVALID,
+                  "split_f16: bad dims B=%d C=%d N=%d", B, C, N);
+    return split_f16_launch(x, hi, lo, B, C, N, C, transpose, scale, nullptr, nullptr, as_stream(stream));
+}
+
+extern "C" int cocos_split_f16_ex(const float* x, void* hi, void* lo, int B, int C, int N, int Cpad,
+                                  int transpose, float scale, const float* amax_dev, float* scale_out_dev,
+                                  cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && hi && lo, COCOS_ERR_INVALID, "split_f16_ex: null pointer");
+    COCOS_REQUIRE(B >= 1 && C >= 1 && N >= 1 && B <= 65535 && Cpad >= C, COCOS_ERR_INVALID,
+                  "split_f16_ex: bad dims B=%d C=%d N=%d Cpad=%d", B, C, N, Cpad);
+    COCOS_REQUIRE(transpose || Cpad == C, COCOS_ERR_INVALID, "split_f16_ex: padding only with transpose");
+    return split_f16_launch(x, hi, lo, B, C, N, Cpad, transpose, scale, amax_dev, scale_out_dev, as_stream(stream));
 }

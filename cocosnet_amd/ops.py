@@ -142,14 +142,27 @@ def feature_normalize(x: torch.Tensor, eps: float = NORM_EPS):
 _split_cache = {}   # id(tensor) -> (weakref to it, version, transpose, scale, hi, lo)
 
 
-def split_f16(x: torch.Tensor, transpose: bool, scale: float = 1.0, cache: bool = False):
+def split_f16(x: torch.Tensor, transpose: bool, scale: float = 1.0, cache: bool = False, cpad=None, amax=None):
     """x [B,C,N] fp32 -> (hi, lo) f16 planes with x*scale ~= hi + lo; [B,N,C] when `transpose`.
     `cache`: reuse the planes while the same tensor object is unmodified (theta/phi feed up to three
-    launches per forward: row pass, column pass, second row pass)."""
+    launches per forward: row pass, column pass, second row pass).
+    `cpad` (transpose only): rows padded with zero channels to cpad.  `amax`: a 1-element CUDA tensor
+    holding max|x|; the scale is then chosen on the device (power of two, max -> [2^9, 2^10)) and the
+    call returns (hi, lo, scale_tensor)."""
     x = _chk(x, "split_f16: x")
+    if cpad is not None or amax is not None:
+        B, C, N = x.shape
+        cp = C if cpad is None else int(cpad)
+        shape = (B, N, cp) if transpose else (B, C, N)
+        hi = torch.empty(shape, device=x.device, dtype=torch.float16)
+        lo = torch.empty(shape, device=x.device, dtype=torch.float16)
+        sc = torch.empty(1, device=x.device, dtype=torch.float32) if amax is not None else None
+        _call("split_f16", "cocos_split_f16_ex", x.data_ptr(), hi.data_ptr(), lo.data_ptr(), B, C, N, cp,
+              int(bool(transpose)), float(scale), _ptr(amax), _ptr(sc), _stream())
+        return (hi, lo, sc) if amax is not None else (hi, lo)
     key = (x._version, bool(transpose), float(scale))
     if cache:
-        hit = _split_cache.get(id(x))
+        hit = _split_cache.get((id(x), bool(transpose)))
         if hit is not None and hit[0]() is x and hit[1] == key:
             return hit[2], hit[3]
     B, C, N = x.shape
@@ -162,7 +175,7 @@ def split_f16(x: torch.Tensor, transpose: bool, scale: float = 1.0, cache: bool 
         if len(_split_cache) > 64:      # drop entries whose tensor is gone
             for k in [k for k, h in _split_cache.items() if h[0]() is None]:
                 del _split_cache[k]
-        _split_cache[id(x)] = (weakref.ref(x), key, hi, lo)
+        _split_cache[(id(x), bool(transpose))] = (weakref.ref(x), key, hi, lo)
     return hi, lo
 
 
@@ -184,7 +197,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                 and Nq * Nk * 4 < 2 ** 31 - 1)
         logits_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if keep else None
         if planes is not None:       # split-precision flavour: same outputs, f16x3 matrix products
-            qh, ql, kh, kl, vh, vl = planes
+            qh, ql, kh, kl, vh, vl = planes[:6]
             _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd_f16x3", qh.data_ptr(), ql.data_ptr(),
                   kh.data_ptr(), kl.data_ptr(), vh.data_ptr(), vl.data_ptr(), out.data_ptr(), lse.data_ptr(),
                   _ptr(logits_t), B, K, Nq, Nk, Cv, float(inv_temperature), SPLIT_OPERAND_SCALE, _stream())
@@ -195,6 +208,8 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         ctx.save_for_backward(qn, kn, v, out, lse)
         ctx.logits_t = logits_t
         ctx.inv_t = float(inv_temperature)
+        # channel-major planes of k_scale*qn, k_scale*kn for the split-precision backward (when given)
+        ctx.cplanes = planes[6:] if (planes is not None and len(planes) > 6 and keep) else None
         return out
 
     @staticmethod
@@ -221,6 +236,27 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             _call("corr_softmax_warp_bwd_prepare", "cocos_corr_softmax_warp_bwd_prepare",
                   out.data_ptr(), dout.data_ptr(), dvec.data_ptr(), B, Nq, Cv, st)
         dims = (B, K, Nq, Nk, Cv, ctx.inv_t, st)
+        if (ctx.cplanes is not None and via_gemm and logits_t is not None and Nk % 8 == 0 and Nq % 8 == 0
+                and Cv <= MAX_FUSED_CV):
+            # split-precision backward: both sides on the f16 MFMA, fp32-class accuracy (see cocos_hip.h)
+            qch, qcl, kch, kcl = ctx.cplanes
+            cvp = (Cv + 31) // 32 * 32
+            g_amax = dout.abs().amax().reshape(1)
+            v_amax = v.abs().amax().reshape(1)
+            gph, gpl, g_scale = split_f16(dout, True, cpad=cvp, amax=g_amax)
+            vph, vpl = split_f16(v, True, cpad=cvp)
+            dsh = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float16)
+            dsl = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float16)
+            ds_scale = torch.empty(1, device=qn.device, dtype=torch.float32)
+            _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3", kch.data_ptr(),
+                  kcl.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(),
+                  g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), logits_t.data_ptr(),
+                  dqn.data_ptr(), dsh.data_ptr(), dsl.data_ptr(), v_amax.data_ptr(), ds_scale.data_ptr(), B, K, Nq,
+                  Nk, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE, st)
+            _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
+                  dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 / SPLIT_OPERAND_SCALE,
+                  ds_scale.data_ptr(), st)
+            return dqn, (dkn if need_k else None), None, None, None, None
         ds_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if via_gemm else None
         if dqn is not None:
             _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query", qn.data_ptr(),
@@ -259,6 +295,9 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float):
             with torch.no_grad():
                 planes = (*split_f16(qn, True, SPLIT_OPERAND_SCALE, cache=True),
                           *split_f16(kn, True, SPLIT_OPERAND_SCALE, cache=True), *split_f16(vv, False, 1.0))
+                if keep:   # the backward wants the channel-major planes as well
+                    planes += (*split_f16(qn, False, SPLIT_OPERAND_SCALE, cache=True),
+                               *split_f16(kn, False, SPLIT_OPERAND_SCALE, cache=True))
         return _CorrSoftmaxWarp.apply(qn, kn, vv, inv_temperature, keep, planes)
 
     if Cv <= MAX_FUSED_CV:

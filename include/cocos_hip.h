@@ -105,6 +105,33 @@ int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void
                                       int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
                                       float operand_scale, cocos_stream_t stream);
 
+/* Split-precision backward of K2 (same reference lines as cocos_corr_softmax_warp_bwd_query / _bwd_key_from_ds):
+ *   cocos_split_f16_ex: as cocos_split_f16, plus (a) transposed rows padded with zero channels to Cpad halfs,
+ *       (b) when amax_dev != NULL the scale is chosen on the device as the power of two that brings
+ *       *amax_dev (= max|x|, e.g. torch's x.abs().amax()) into [2^9, 2^10), and written to *scale_out_dev.
+ *   cocos_corr_softmax_warp_bwd_query_f16x3:
+ *       kch,kcl [B,256,Nk]  channel-major planes of k_scale*kn
+ *       vph,vpl [B,Nk,CvPad] position-major planes of v;   gph,gpl [B,Nq,CvPad] of s_o*dout, s_o = *g_scale_dev
+ *       out, dout [B,Cv,Nq] fp32 (for D = sum_c dout*out, fp64);  lse, logits_t as saved by the forward
+ *       -> dqn [B,256,Nq] fp32;  dsh,dsl [B,Nk,Nq] planes of dS'' = s_o*ds_shift * dS^T/T (both NULL: skipped);
+ *          *ds_scale_out_dev = s_o*ds_shift (ds_shift is derived on the device from *v_amax_dev = max|v|)
+ *       Supported: K == 256, Cv <= 160, CvPad = Cv rounded up to 32, Nk % 8 == 0.
+ *   cocos_hgemm_f16x3: C[b][m][n] = host_scale / *dev_scale * sum_k A[b][m][k] B[b][n][k] on hi/lo planes
+ *       (k contiguous, K % 8 == 0); the key side is  dkn = hgemm(A = planes of k_scale*qn [256][Nq],
+ *       B = dS'' planes [Nk][Nq], host_scale = 1/k_scale, dev_scale = ds_scale_out_dev). */
+int cocos_split_f16_ex(const float* x, void* hi, void* lo, int B, int C, int N, int Cpad, int transpose,
+                       float scale, const float* amax_dev /* nullable */, float* scale_out_dev /* nullable */,
+                       cocos_stream_t stream);
+int cocos_corr_softmax_warp_bwd_query_f16x3(
+    const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
+    const float* g_scale_dev, const float* out, const float* dout, const float* lse, const float* logits_t,
+    float* dqn, void* dsh /* nullable */, void* dsl /* nullable */, const float* v_amax_dev,
+    float* ds_scale_out_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature,
+    float k_scale, cocos_stream_t stream);
+int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* c,
+                      int batch, int M, int N, int K, float host_scale, const float* dev_scale /* nullable */,
+                      cocos_stream_t stream);
+
 /* Backward of K2 (autograd of :291-318), flash-style: the logits are recomputed from qn/kn and `lse`.
  *   dout [B,Cv,Nq] -> dqn [B,K,Nq], dkn [B,K,Nk], dv [B,Cv,Nk]
  * It is exposed in stages so that the caller picks the strategy for the key side:

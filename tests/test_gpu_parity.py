@@ -138,6 +138,39 @@ def test_fused_forward_backward_vs_oracle(B, Nq, Nk, Cv, peaked, precision):
     assert rel(vv.grad, dv_ref, floor=0.05) < OUT_TOL
 
 
+@pytest.mark.parametrize("B,Nq,Nk,Cv,peaked", [(2, 64, 64, 3, False), (1, 200, 176, 5, False), (2, 256, 320, 32, False),
+                                                (1, 384, 384, 154, False), (1, 128, 256, 160, False),
+                                                (2, 384, 384, 40, True), (1, 8, 8, 1, False), (1, 1024, 1024, 154, False)])
+def test_fused_backward_theta_phi_only(B, Nq, Nk, Cv, peaked, precision):
+    """The training configuration: gradients w.r.t. theta/phi only (V comes from the inputs) — the path
+    that uses the saved logits + dS GEMM (fp32) or the f16x3 query kernel + f16x3 GEMM (split)."""
+    from cocosnet_amd import ops
+    qn, kn, v = _qkv(B, Nq, Nk, Cv, seed=Nq * 3 + Nk, peaked=peaked)
+    g = np.random.RandomState(6).standard_normal((B, Cv, Nq)) * 1e-3          # small gradients: exercises the scaling
+    dq_ref, dk_ref, _ = co.corr_softmax_warp_bwd(qn, kn, v, g, 100.0)
+    q, k = dev(qn, True), dev(kn, True)
+    out = ops.corr_softmax_warp(q, k, dev(v), 100.0)
+    out.backward(dev(g))
+    assert rel(out, co.corr_softmax_warp(qn, kn, v, 100.0)) < OUT_TOL
+    assert rel(q.grad, dq_ref, floor=0.5e-3) < OUT_TOL
+    assert rel(k.grad, dk_ref, floor=0.5e-3) < OUT_TOL
+
+
+@pytest.mark.parametrize("batch,M,N,K", [(2, 256, 128, 64), (1, 256, 4096, 512), (1, 100, 70, 40), (2, 300, 200, 8)])
+def test_hgemm_f16x3_matches_fp64(batch, M, N, K):
+    from cocosnet_amd import ops, _lib
+    rs = np.random.RandomState(M + K)
+    a, b = rs.standard_normal((batch, M, K)), rs.standard_normal((batch, N, K))
+    ah, al = ops.split_f16(dev(a), False, 4.0)
+    bh, bl = ops.split_f16(dev(b), False, 2.0)
+    c = torch.empty((batch, M, N), device=DEV, dtype=torch.float32)
+    sc = torch.full((1,), 2.0, device=DEV)
+    _lib.call("cocos_hgemm_f16x3", ah.data_ptr(), al.data_ptr(), bh.data_ptr(), bl.data_ptr(), c.data_ptr(), batch, M, N,
+              K, 0.25, sc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    ref = np.einsum("bmk,bnk->bmn", a, b)
+    assert rel(c, ref) < 2e-6
+
+
 def test_key_side_strategies_agree(monkeypatch):
     """dkn via GEMM over the materialised dS^T  ==  dkn via the second recompute kernel."""
     from cocosnet_amd import ops
