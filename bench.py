@@ -139,12 +139,18 @@ def main():
     ap.add_argument("--match-kernel", type=int, choices=(1, 3), default=1,
                     help="1 = the north-star 64x64x256 correlation (headline); 3 = the reference's shipped "
                          "default (3x3 neighbourhoods, K6/K7 kernels) — reported for context")
+    ap.add_argument("--precision", choices=("fp32", "f16x3"), default=None,
+                    help="where the K2 products run (default: cocosnet_amd.ops.PRECISION, i.e. $COCOS_PRECISION "
+                         "or the package default): fp32 = v_mfma_f32_32x32x2_f32, f16x3 = 3-term split on "
+                         "v_mfma_f32_32x32x16_f16 (fp32-class accuracy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=6)
     args = ap.parse_args()
 
     from cocosnet_amd import dist as cdist
     from cocosnet_amd import ops
+    if args.precision:
+        ops.PRECISION = args.precision
     rank, local_rank, world = cdist.init_from_env("nccl")
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -209,6 +215,8 @@ def main():
                                 "alg_tflops": round(flops / ms / 1e9, 2),
                                 "frac_fp32_mfma_peak": round(flops / ms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4)}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
+        # device time of EVERY C-ABI call per step (ms), so the part of the step outside the three big kernels is visible
+        per_step = {tag: round(rec["total_ms"] / args.steps, 4) for tag, rec in sorted(kern.items())}
         # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
         # WRITE_SIZE, MI355X_MICROARCH.md), committed under profiles/ — they cannot be read live
         traffic, traffic_src = None, None
@@ -246,7 +254,7 @@ def main():
                                       "whole NoVGGCorrespondence module fwd+bwd (producers on PyTorch-ROCm)"),
                        "global_batch": BATCH_PER_GPU * world, "parallelism": f"dp{world}",
                        "grad_allreduce_bytes": buckets.nbytes() if world > 1 else 0},
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "abi_calls_ms_per_step": per_step, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -57,6 +57,17 @@ __device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& l
     lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
 }
 
+// Optional phase timing (build with COCOS_EXTRA_HIPFLAGS=-DCOCOS_DEBUG_TIMING): shader-clock ticks spent by
+// wave 0 of workgroup 0 in each phase of the tile loop, read back with cocos_debug_read_timing_fwd_f16x3().
+#ifdef COCOS_DEBUG_TIMING
+__device__ long long g_phase_fwd_h[8];
+#define FPH_T(var) const long long var = __builtin_readcyclecounter()
+#define FPH_ADD(i, a, b) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_fwd_h[i] += (b) - (a); } while (0)
+#else
+#define FPH_T(var) do {} while (0)
+#define FPH_ADD(i, a, b) do {} while (0)
+#endif
+
 template <int CVB, bool STORE_S, bool RAGGED>
 __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     const _Float16* __restrict__ qh, const _Float16* __restrict__ ql, const _Float16* __restrict__ kh,
@@ -167,12 +178,35 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
         const int j0 = t * SP_BK, buf = t & 1;
         const bool ragged = RAGGED && (j0 + SP_BK > Nk);
 
-        // ---- S^T = K_tile . Q : 16 k-steps x 3 terms, operands read one step ahead -------------------
+        FPH_T(tp0);
+        // ---- S^T = K_tile . Q : 16 k-steps x 3 terms, operands read one step ahead.  Riding in the gaps:
+        //      the staged registers of tile t+1 go to the other LDS buffer (last read in iteration t-1, released
+        //      by the barrier that ended it) one 16-/8-byte piece per step, and each freed register immediately
+        //      takes its load for tile t+2 — memory instructions are never issued as a burst ------------------
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
         {
             const _Float16* kb = kt + buf * 2 * KPLANE + c * SP_KROW + h * 8;
+            _Float16* const kw = kt + (buf ^ 1) * 2 * KPLANE;
+            _Float16* const vw = vt + (buf ^ 1) * 2 * VPLANE;
+            const int jn = j0 + 2 * SP_BK;
+            auto piece = [&](int i) {
+                if (i < 8) {                                  // K pieces: plane i&1, chunk i>>1
+                    const int pl_ = i & 1, u = i >> 1;
+                    const int g = u * 256 + tid, key = g >> 5, cc = g & 31;
+                    *reinterpret_cast<u32x4*>(kw + pl_ * KPLANE + key * SP_KROW + cc * 8) = kst[pl_][u];
+                    kst[pl_][u] = buf_load_u4(pl_ ? kl_rs : kh_rs, (unsigned)((jn + key) * SP_KD + cc * 8) * 2u);
+                } else if (i - 8 < 2 * CVB) {                 // V pieces
+                    const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
+                    const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
+                    const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);
+                    *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + row * SP_VROW + slot) = vst[pl_][u];
+                    unsigned off = (unsigned)(row * Nk + jn + 4 * kq) * 2u;
+                    if (row >= Cv || jn + 4 * kq >= Nk) off = kBufOob;
+                    vst[pl_][u] = buf_load_u2(pl_ ? vl_rs : vh_rs, off);
+                }
+            };
             f16x8 ah[2], al[2];
             ah[0] = *reinterpret_cast<const f16x8*>(kb);
             al[0] = *reinterpret_cast<const f16x8*>(kb + KPLANE);
@@ -186,16 +220,14 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                 s0 = mfma16h(ah[cur], qhr[s], s0);
                 s1 = mfma16h(ah[cur], qlr[s], s1);
                 s1 = mfma16h(al[cur], qhr[s], s1);
+                // 8 + 2*CVB <= 18 pieces over 16 steps
+                piece(s);
+                if (s < 2) piece(16 + s);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-
-        // next tile: staged registers -> the other LDS buffer (last read in iteration t-1, released by
-        // the barrier that ended it), then the loads of tile t+2 go out and fly under the rest of t
-        commit_k(buf ^ 1);
-        commit_v(buf ^ 1);
-        fetch_k(j0 + 2 * SP_BK);
-        fetch_v(j0 + 2 * SP_BK);
-
+        FPH_T(tp1);
+        FPH_T(tp2);
         // ---- online softmax (log2 domain), lazy rescale as in the fp32 kernel -------------------------
         float p[16];
         float tmax = -INFINITY;
@@ -230,6 +262,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
         }
         l_run += psum;
 
+        FPH_T(tp3);
         // P -> f16 hi/lo: registers 8t..8t+7 are the k-slots of P.V step t
         f16x8 ph[2], pl[2];
 #pragma unroll
@@ -242,21 +275,32 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                 pl[tt][j] = bq[0]; pl[tt][j + 1] = bq[1];
             }
 
+        FPH_T(tp4);
         // ---- O^T += V . P : A = V tile rows (channels) with permuted keys, B = P ---------------------
         {
             const _Float16* vbase = vt + buf * 2 * VPLANE + c * SP_VROW + h * 8;
+            f16x8 a_h[2], a_l[2];
+            a_h[0] = *reinterpret_cast<const f16x8*>(vbase);
+            a_l[0] = *reinterpret_cast<const f16x8*>(vbase + VPLANE);
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int cb = 0; cb < CVB; ++cb) {
-                    const f16x8 a_h = *reinterpret_cast<const f16x8*>(vbase + cb * 32 * SP_VROW + tt * 16);
-                    const f16x8 a_l = *reinterpret_cast<const f16x8*>(vbase + VPLANE + cb * 32 * SP_VROW + tt * 16);
-                    o[cb] = mfma16h(a_h, ph[tt], o[cb]);
-                    o[cb] = mfma16h(a_h, pl[tt], o[cb]);
-                    o[cb] = mfma16h(a_l, ph[tt], o[cb]);
+            for (int i = 0; i < 2 * CVB; ++i) {               // i = tt * CVB + cb, operands one step ahead
+                const int tt = i / CVB, cb = i % CVB, cur = i & 1, nxt = cur ^ 1;
+                if (i + 1 < 2 * CVB) {
+                    const int t2 = (i + 1) / CVB, c2 = (i + 1) % CVB;
+                    a_h[nxt] = *reinterpret_cast<const f16x8*>(vbase + c2 * 32 * SP_VROW + t2 * 16);
+                    a_l[nxt] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + c2 * 32 * SP_VROW + t2 * 16);
                 }
+                o[cb] = mfma16h(a_h[cur], ph[tt], o[cb]);
+                o[cb] = mfma16h(a_h[cur], pl[tt], o[cb]);
+                o[cb] = mfma16h(a_l[cur], ph[tt], o[cb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        FPH_T(tp5);
         __syncthreads();   // tile t+1 visible; buffer `buf` free for the commit of tile t+2
+        FPH_T(tp6);
+        FPH_ADD(0, tp0, tp1); FPH_ADD(1, tp1, tp2); FPH_ADD(2, tp2, tp3); FPH_ADD(3, tp3, tp4);
+        FPH_ADD(4, tp4, tp5); FPH_ADD(5, tp5, tp6);
     }
 
     // ---- epilogue: normalise, store channel-major [B,Cv,Nq], store row LSE --------------------------
@@ -291,6 +335,19 @@ static int launch_f16x3_k(const _Float16* qh, const _Float16* ql, const _Float16
 }
 
 }  // namespace cocos
+
+#ifdef COCOS_DEBUG_TIMING
+extern "C" int cocos_debug_read_timing_fwd_f16x3(long long* host8, int reset) {
+    using namespace cocos;
+    COCOS_HIP_CHECK(hipDeviceSynchronize());
+    COCOS_HIP_CHECK(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_phase_fwd_h), 8 * sizeof(long long)));
+    if (reset) {
+        long long z[8] = {0};
+        COCOS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_fwd_h), z, sizeof(z)));
+    }
+    return COCOS_OK;
+}
+#endif
 
 extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void* kh,
                                                  const void* kl, const void* vh, const void* vl, float* out,
