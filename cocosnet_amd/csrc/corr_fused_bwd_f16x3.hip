@@ -58,6 +58,9 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* const vt = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][32 keys][VROW]
     _Float16* const kt = vt + 2 * 2 * VPLANE;                      // [2 buf][hi|lo][256 ch][KROW]
+    // per-wave transposition buffer for the dS'' stores: [hi|lo][32 keys][32 queries + 8 pad]
+    constexpr int DSROW = 40, DSPLANE = 32 * DSROW;
+    _Float16* const dstile = kt + 2 * 2 * KPLANE + (threadIdx.x >> 6) * 2 * DSPLANE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -86,7 +89,6 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     // [Nk][Nq] matrices: lane offset = query column + the half-wave's 4 rows; the tile/register part of
     // the row index is wave-uniform and travels in the scalar offset (not bounds-checked: see fetch_s)
     const unsigned sr_lane_off = live ? (unsigned)(4 * h * Nq + i_lane) * 4u : kBufOob;
-    const unsigned ds_lane_off = live ? (unsigned)(4 * h * Nq + i_lane) * 2u : kBufOob;
 
     const float s_o = *g_scale;
     float ds_shift;
@@ -237,7 +239,6 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             if (RAGGED && (j0 + acc_row_base(r) + 4 * h >= Nk)) pv = 0.f;
             ds[r] = pv * ((dp0[r] + dp1[r]) - d_lane) * cs;
         }
-        fetch_s(j0 + 32);        // logits of tile t+1 fly under the dqn product
 
         // split to f16 hi/lo, two values per 32-bit register (register r>>1, half r&1); registers 8t..8t+7
         // are the k-slots of step t of the dqn product
@@ -255,38 +256,78 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             sh[tt] = __builtin_bit_cast(f16x8, u32x4{hw[4 * tt], hw[4 * tt + 1], hw[4 * tt + 2], hw[4 * tt + 3]});
             sl[tt] = __builtin_bit_cast(f16x8, u32x4{lw[4 * tt], lw[4 * tt + 1], lw[4 * tt + 2], lw[4 * tt + 3]});
         }
-        if (STORE_DS) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int jr = j0 + acc_row_base(r);
-                const bool ok = !RAGGED || (jr + 4 * h < Nk);
-                const unsigned lo = ok ? ds_lane_off : kBufOob, so = (unsigned)jr * (unsigned)Nq * 2u;
-                const unsigned short hv = (unsigned short)(hw[r >> 1] >> (16 * (r & 1)));
-                const unsigned short lv = (unsigned short)(lw[r >> 1] >> (16 * (r & 1)));
-                __builtin_amdgcn_raw_buffer_store_b16(hv, dh_rs, (int)lo, (int)so, 0);
-                __builtin_amdgcn_raw_buffer_store_b16(lv, dl_rs, (int)lo, (int)so, 0);
-            }
-        }
-
-        // next tile: staged registers -> the other buffer; loads of tile t+2 go out
-        commit_v(buf ^ 1);
-        commit_k(buf ^ 1);
-        fetch_v(j0 + 64);
-        fetch_k(j0 + 64);
-
-        // ---- dqn += K(t) . dS'' ---------------------------------------------------------------------------
+        // ---- dqn += K(t) . dS'' : 16 steps (2 k-steps x 8 channel blocks), operands read one step ahead.
+        //      Riding in the gaps, one slice per step (never a burst of memory instructions): the dS'' stores of
+        //      register r, the logits load of tile t+1 into the same sld[r], one staged piece of tile t+1 to the
+        //      other LDS buffer and its reload for tile t+2 ------------------------------------------------------
         {
             const _Float16* kb0 = kt + buf * 2 * KPLANE + c * BQH_KROW + h * 8;
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) {
-                    const f16x8 a_h = *reinterpret_cast<const f16x8*>(kb0 + kb * 32 * BQH_KROW + tt * 16);
-                    const f16x8 a_l = *reinterpret_cast<const f16x8*>(kb0 + KPLANE + kb * 32 * BQH_KROW + tt * 16);
-                    dx[kb] = bq_mfma(a_h, sh[tt], dx[kb]);
-                    dx[kb] = bq_mfma(a_h, sl[tt], dx[kb]);
-                    dx[kb] = bq_mfma(a_l, sh[tt], dx[kb]);
+            _Float16* const vw = vt + (buf ^ 1) * 2 * VPLANE;
+            _Float16* const kw = kt + (buf ^ 1) * 2 * KPLANE;
+            const int jn = j0 + 64;
+            auto hook = [&](int i) {
+                if (STORE_DS) {
+                    // dS'' goes to HBM as 16-byte row pieces: each lane holds one QUERY column (16 keys), the
+                    // matrix is [key][query] — so the wave transposes its 32x32 tile through a private LDS
+                    // buffer: 2-byte LDS writes here (step i = register i), 4 b128 reads + 4 b128 global stores
+                    // at steps 12..15, instead of 32 two-byte global stores per lane and tile
+                    const int key = acc_row_base(i) + 4 * h;
+                    dstile[key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(hw[i >> 1] >> (16 * (i & 1))));
+                    dstile[DSPLANE + key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(lw[i >> 1] >> (16 * (i & 1))));
                 }
+                {   // logits of tile t+1, register i
+                    const int jr = j0 + 32 + acc_row_base(i);
+                    sld[i] = buf_load1s(lg_rs, (jr + 4 * h < Nk) ? sr_lane_off : kBufOob, (unsigned)jr * (unsigned)Nq * 4u);
+                }
+                if (i < 2 * VPT) {                            // V pieces: plane i&1, chunk i>>1
+                    const int pl_ = i & 1, u = i >> 1;
+                    const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
+                    if (g < VCH) *reinterpret_cast<u32x4*>(vw + pl_ * VPLANE + key * VROW + cc * 8) = vst[pl_][u];
+                    vst[pl_][u] = bq_load16(pl_ ? vl_rs : vh_rs,
+                                            g < VCH ? (unsigned)((jn + key) * CVP + cc * 8) * 2u : kBufOob);
+                } else if (i - 2 * VPT < 8) {                 // K pieces
+                    const int pl_ = (i - 2 * VPT) & 1, u = (i - 2 * VPT) >> 1;
+                    const int g = u * 256 + tid, row = g >> 2, k8 = g & 3;
+                    const int kq = 2 * k8, slot0 = 16 * (kq >> 2) + 4 * ((kq >> 1) & 1);
+                    _Float16* d = kw + pl_ * KPLANE + row * BQH_KROW;
+                    *reinterpret_cast<u32x2*>(d + slot0) = u32x2{kst[pl_][u].x, kst[pl_][u].y};
+                    *reinterpret_cast<u32x2*>(d + slot0 + 8) = u32x2{kst[pl_][u].z, kst[pl_][u].w};
+                    unsigned off = (unsigned)(row * Nk + jn + 8 * k8) * 2u;
+                    if (jn + 8 * k8 >= Nk) off = kBufOob;
+                    kst[pl_][u] = bq_load16(pl_ ? kl_rs : kh_rs, off);
+                }
+            };
+            static_assert(2 * VPT + 8 <= 16, "staging pieces must fit the 16 steps of the dqn product");
+            f16x8 a_h[2], a_l[2];
+            a_h[0] = *reinterpret_cast<const f16x8*>(kb0);
+            a_l[0] = *reinterpret_cast<const f16x8*>(kb0 + KPLANE);
+#pragma unroll
+            for (int i = 0; i < 2 * KB; ++i) {                // i = tt * KB + kb
+                const int tt = i / KB, kb = i % KB, cur = i & 1, nxt = cur ^ 1;
+                if (i + 1 < 2 * KB) {
+                    const int t2 = (i + 1) / KB, k2 = (i + 1) % KB;
+                    a_h[nxt] = *reinterpret_cast<const f16x8*>(kb0 + k2 * 32 * BQH_KROW + t2 * 16);
+                    a_l[nxt] = *reinterpret_cast<const f16x8*>(kb0 + KPLANE + k2 * 32 * BQH_KROW + t2 * 16);
+                }
+                dx[kb] = bq_mfma(a_h[cur], sh[tt], dx[kb]);
+                dx[kb] = bq_mfma(a_h[cur], sl[tt], dx[kb]);
+                dx[kb] = bq_mfma(a_l[cur], sh[tt], dx[kb]);
+                hook(i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (STORE_DS) {
+                // (LDS instructions of one wave execute in order: the 2-byte writes above are visible here)
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int key = pass * 16 + (lane >> 2), qc = (lane & 3) * 8;
+                    const u32x4 xh = *reinterpret_cast<const u32x4*>(dstile + key * DSROW + qc);
+                    const u32x4 xl = *reinterpret_cast<const u32x4*>(dstile + DSPLANE + key * DSROW + qc);
+                    const int row = j0 + key, col = q0 + wave * 32 + qc;        // Nq % 8 == 0: whole pieces
+                    const unsigned off = (row < Nk && col < Nq) ? (unsigned)(row * Nq + col) * 2u : kBufOob;
+                    __builtin_amdgcn_raw_buffer_store_b128(xh, dh_rs, (int)off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(xl, dl_rs, (int)off, 0, 0);
+                }
+            }
         }
         __syncthreads();
     }
@@ -312,7 +353,7 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                            _Float16* dsl, const float* v_amax, float* ds_scale_out, int B, int Nq, int Nk, int Cv,
                            float inv_t, float k_scale, hipStream_t s) {
     const bool ragged = (Nk % 32) != 0, store = dsh != nullptr;
-    const size_t smem = (size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) * sizeof(_Float16);
+    const size_t smem = ((size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) + 4 * 2 * 32 * 40) * sizeof(_Float16);
     const int nqb = (Nq + 127) / 128;
 #define COCOS_GO(DS, RG)                                                                                     \
     do {                                                                                                     \
@@ -345,9 +386,9 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
                   "corr_softmax_warp_bwd_query_f16x3: dsh and dsl must both be given or both be NULL");
     COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && k_scale > 0.f, COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd_query_f16x3: bad dims B=%d Nq=%d Nk=%d Cv=%d", B, Nq, Nk, Cv);
-    COCOS_REQUIRE(K == 256 && Cv <= 160 && Nk % 8 == 0, COCOS_ERR_UNSUPPORTED,
-                  "corr_softmax_warp_bwd_query_f16x3: needs K == 256, Cv <= 160, Nk %% 8 == 0 (K=%d Cv=%d Nk=%d)",
-                  K, Cv, Nk);
+    COCOS_REQUIRE(K == 256 && Cv <= 160 && Nk % 8 == 0 && (dsh == nullptr || Nq % 8 == 0), COCOS_ERR_UNSUPPORTED,
+                  "corr_softmax_warp_bwd_query_f16x3: needs K == 256, Cv <= 160, Nk %% 8 == 0 and (with dS planes) "
+                  "Nq %% 8 == 0 (K=%d Cv=%d Nk=%d Nq=%d)", K, Cv, Nk, Nq);
     const int cvb = (Cv + 31) / 32;
     COCOS_REQUIRE(CvPad == cvb * 32, COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd_query_f16x3: CvPad=%d, expected %d (Cv rounded up to 32)", CvPad, cvb * 32);

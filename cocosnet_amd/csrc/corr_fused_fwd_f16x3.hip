@@ -110,6 +110,13 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
             qhr[s] = buf_load_h8(qh_rs, q_off + (unsigned)s * 32u);
             qlr[s] = buf_load_h8(ql_rs, q_off + (unsigned)s * 32u);
         }
+        // park the slice in the accumulator half of the register file (MFMA B operands may be AGPRs): the
+        // arch VGPRs are needed for the staging registers and the LDS read-ahead
+#pragma unroll
+        for (int s = 0; s < SP_KD / 16; ++s) {
+            asm volatile("" : "+a"(qhr[s]));
+            asm volatile("" : "+a"(qlr[s]));
+        }
     }
 
     f32x16 o[CVB];
@@ -170,8 +177,26 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     fetch_v(0);
     commit_k(0);
     commit_v(0);
-    fetch_k(SP_BK);
-    fetch_v(SP_BK);
+    // tile 1: issued in the order in which the loop consumes its pieces (the s_waitcnt vmcnt the compiler
+    // puts in front of each LDS commit is the worst case over both ways into the loop)
+    auto fetch_piece = [&](int i, int j0) {
+        if (i < 8) {
+            const int pl_ = i & 1, u = i >> 1;
+            const int g = u * 256 + tid, key = g >> 5, cc = g & 31;
+            kst[pl_][u] = buf_load_u4(pl_ ? kl_rs : kh_rs, (unsigned)((j0 + key) * SP_KD + cc * 8) * 2u);
+        } else if (i - 8 < 2 * CVB) {
+            const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
+            const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
+            unsigned off = (unsigned)(row * Nk + j0 + 4 * kq) * 2u;
+            if (row >= Cv || j0 + 4 * kq >= Nk) off = kBufOob;
+            vst[pl_][u] = buf_load_u2(pl_ ? vl_rs : vh_rs, off);
+        }
+    };
+#pragma unroll
+    for (int sidx = 0; sidx < 16; ++sidx) {
+        fetch_piece(sidx, SP_BK);
+        if (sidx < 2) fetch_piece(16 + sidx, SP_BK);
+    }
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -207,15 +232,21 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                     vst[pl_][u] = buf_load_u2(pl_ ? vl_rs : vh_rs, off);
                 }
             };
-            f16x8 ah[2], al[2];
-            ah[0] = *reinterpret_cast<const f16x8*>(kb);
-            al[0] = *reinterpret_cast<const f16x8*>(kb + KPLANE);
+            // operands are requested RA steps ahead: with four waves on the LDS pipe a ds_read_b128 takes several
+            // hundred cycles to come back, far more than the 96 cycles of one step's MFMAs
+            constexpr int RA = 4, NS = SP_KD / 16;
+            f16x8 ah[RA], al[RA];
 #pragma unroll
-            for (int s = 0; s < SP_KD / 16; ++s) {
-                const int cur = s & 1, nxt = cur ^ 1;
-                if (s + 1 < SP_KD / 16) {
-                    ah[nxt] = *reinterpret_cast<const f16x8*>(kb + (s + 1) * 16);
-                    al[nxt] = *reinterpret_cast<const f16x8*>(kb + KPLANE + (s + 1) * 16);
+            for (int s = 0; s < RA - 1; ++s) {
+                ah[s] = *reinterpret_cast<const f16x8*>(kb + s * 16);
+                al[s] = *reinterpret_cast<const f16x8*>(kb + KPLANE + s * 16);
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int cur = s % RA;
+                if (s + RA - 1 < NS) {
+                    ah[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + (s + RA - 1) * 16);
+                    al[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + KPLANE + (s + RA - 1) * 16);
                 }
                 s0 = mfma16h(ah[cur], qhr[s], s0);
                 s1 = mfma16h(ah[cur], qlr[s], s1);
@@ -244,10 +275,16 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
             const float alpha = fast_exp2(m_run - m_new);
             l_run *= alpha;
             m_run = m_new;
+            // (the pins keep the AGPR -> VGPR copies of O inside this rarely taken branch: hipcc otherwise
+            //  hoists all of them above it, i.e. into every tile)
+#pragma unroll
+            for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
 #pragma unroll
             for (int cb = 0; cb < CVB; ++cb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+#pragma unroll
+            for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
         }
         float psum = 0.f;
 #pragma unroll
@@ -279,16 +316,19 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
         // ---- O^T += V . P : A = V tile rows (channels) with permuted keys, B = P ---------------------
         {
             const _Float16* vbase = vt + buf * 2 * VPLANE + c * SP_VROW + h * 8;
-            f16x8 a_h[2], a_l[2];
-            a_h[0] = *reinterpret_cast<const f16x8*>(vbase);
-            a_l[0] = *reinterpret_cast<const f16x8*>(vbase + VPLANE);
+            constexpr int RA = 4, NS = 2 * CVB;               // step i = tt * CVB + cb
+            f16x8 a_h[RA], a_l[RA];
 #pragma unroll
-            for (int i = 0; i < 2 * CVB; ++i) {               // i = tt * CVB + cb, operands one step ahead
-                const int tt = i / CVB, cb = i % CVB, cur = i & 1, nxt = cur ^ 1;
-                if (i + 1 < 2 * CVB) {
-                    const int t2 = (i + 1) / CVB, c2 = (i + 1) % CVB;
-                    a_h[nxt] = *reinterpret_cast<const f16x8*>(vbase + c2 * 32 * SP_VROW + t2 * 16);
-                    a_l[nxt] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + c2 * 32 * SP_VROW + t2 * 16);
+            for (int i = 0; i < RA - 1 && i < NS; ++i) {
+                a_h[i] = *reinterpret_cast<const f16x8*>(vbase + (i % CVB) * 32 * SP_VROW + (i / CVB) * 16);
+                a_l[i] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + (i % CVB) * 32 * SP_VROW + (i / CVB) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int tt = i / CVB, cb = i % CVB, cur = i % RA, n = i + RA - 1;
+                if (n < NS) {
+                    a_h[n % RA] = *reinterpret_cast<const f16x8*>(vbase + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
+                    a_l[n % RA] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
                 }
                 o[cb] = mfma16h(a_h[cur], ph[tt], o[cb]);
                 o[cb] = mfma16h(a_h[cur], pl[tt], o[cb]);
@@ -296,6 +336,10 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        // O's home is the accumulator file: without this the allocator keeps it in arch VGPRs for the (rare)
+        // rescale multiply and copies all 16*CVB registers to AGPRs and back around every QK loop
+#pragma unroll
+        for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
         FPH_T(tp5);
         __syncthreads();   // tile t+1 visible; buffer `buf` free for the commit of tile t+2
         FPH_T(tp6);

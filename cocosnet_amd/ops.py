@@ -27,7 +27,7 @@ FUSED_K = 256
 #: where the K2 forward's products run: "fp32" = v_mfma_f32_32x32x2_f32 (exact fp32 operands);
 #: "f16x3" = v_mfma_f32_32x32x16_f16 on f16 hi+lo planes, 3 terms per product, fp32 accumulate
 #: (fp32-class accuracy, ~1/5 of the matrix-pipe time).  Module attribute, read at call time.
-PRECISION = os.environ.get("COCOS_PRECISION", "fp32")
+PRECISION = os.environ.get("COCOS_PRECISION", "f16x3")
 #: power-of-two pre-scale of the unit-norm operands before the f16 split (keeps the lo plane normal)
 SPLIT_OPERAND_SCALE = 16.0
 

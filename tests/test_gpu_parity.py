@@ -184,7 +184,9 @@ def test_key_side_strategies_agree(monkeypatch):
         res.append((q.grad.clone(), k.grad.clone()))
     _, dk_ref, _ = co.corr_softmax_warp_bwd(qn, kn, v, g, 100.0)
     assert rel(res[0][1], dk_ref) < OUT_TOL and rel(res[1][1], dk_ref) < OUT_TOL
-    assert rel(res[0][0], res[1][0].cpu().numpy()) < 1e-6
+    # (the two runs reach dqn through different kernels — saved logits vs recomputed ones — each within 1e-5 of the oracle)
+    assert rel(res[0][0], res[1][0].cpu().numpy()) < 3e-5
+    assert rel(res[0][0], co.corr_softmax_warp_bwd(qn, kn, v, g, 100.0)[0]) < OUT_TOL
 
 
 def test_fused_chunks_wide_v():
