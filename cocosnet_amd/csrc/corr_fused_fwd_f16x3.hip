@@ -36,7 +36,12 @@ constexpr int SP_BK = 32;                // keys per tile
 constexpr int SP_KD = 256;               // channels
 constexpr int SP_KROW = SP_KD + 8;       // halfs per key row in LDS: 528 B -> conflict-free b128 reads
 constexpr int SP_VROW = 40;              // halfs per channel row of the V tile: 80 B -> conflict-free
-constexpr float kSplitRescaleThr = 8.0f; // as kRescaleThr: p <= 2^8, far inside f16 range
+// Lazy rescale threshold and the power-of-two bias of the exponent: p = 2^(x - m + kPBias) <= 2^(6+9) = 2^15
+// sits at the TOP of f16's range, so that the truncation floor of the hi/lo split (2^-24 absolute, one-sided)
+// is 2^-33 relative to a row maximum — thousands of tail keys cannot bias a row sum by more than ~1e-7.
+// Numerator (O) and denominator (l) carry the same factor, which cancels in out = O / l.
+constexpr float kSplitRescaleThr = 6.0f;
+constexpr float kPBias = 9.0f;
 
 __device__ __forceinline__ f32x16 mfma16h(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                 buf_store1s(lg_rs, p[r], (!ragged || jr + 4 * h < Nk) ? lg_lane_off : kBufOob,
                             (unsigned)jr * (unsigned)Nq * 4u);
             }
-            p[r] = fast_exp2(p[r] - m_run);
+            p[r] = fast_exp2(p[r] - m_run + kPBias);
             psum += p[r];
         }
         l_run += psum;
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                 const int ch = cb * 32 + acc_row_base(r) + 4 * h;
                 if (ch < Cv) out_b[(size_t)ch * Nq + i_lane] = o[cb][r] * inv_l;
             }
-        if (h == 0) lse[(size_t)b * Nq + i_lane] = (m_run + log2f(l_tot)) * kLn2;
+        if (h == 0) lse[(size_t)b * Nq + i_lane] = (m_run + log2f(l_tot) - kPBias) * kLn2;
     }
 }
 
