@@ -37,6 +37,15 @@ __device__ __forceinline__ void bq_split_pair(float a, float b, f16x2& hi, f16x2
     lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
 }
 
+#ifdef COCOS_DEBUG_TIMING
+__device__ long long g_phase_bq_h[8];
+#define BPH_T(var) const long long var = __builtin_readcyclecounter()
+#define BPH_ADD(i, a, b) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_bq_h[i] += (b) - (a); } while (0)
+#else
+#define BPH_T(var) do {} while (0)
+#define BPH_ADD(i, a, b) do {} while (0)
+#endif
+
 template <int CVB, bool STORE_DS, bool RAGGED>
 __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     const _Float16* __restrict__ kch, const _Float16* __restrict__ kcl,   // [B,256,Nk] planes of k_scale*kn
@@ -108,6 +117,12 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
         for (int u = 0; u < CVS; ++u) {
             goh[u] = __builtin_bit_cast(f16x8, bq_load16(gh_rs, off + (unsigned)u * 32u));
             gol[u] = __builtin_bit_cast(f16x8, bq_load16(gl_rs, off + (unsigned)u * 32u));
+        }
+        // park the slice in the accumulator file (MFMA B operands may be AGPRs)
+#pragma unroll
+        for (int u = 0; u < CVS; ++u) {
+            asm volatile("" : "+a"(goh[u]));
+            asm volatile("" : "+a"(gol[u]));
         }
     }
     float d_lane;
@@ -209,6 +224,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 32, buf = t & 1;
 
+        BPH_T(tp0);
         // ---- dP' = V(t) . dO' -----------------------------------------------------------------------------
         f32x16 dp0, dp1;
 #pragma unroll
@@ -231,6 +247,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             }
         }
 
+        BPH_T(tp1);
         // ---- dS'' = P * (dP' - D') * inv_t * ds_shift ----------------------------------------------------------
         float ds[16];
 #pragma unroll
@@ -256,6 +273,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             sh[tt] = __builtin_bit_cast(f16x8, u32x4{hw[4 * tt], hw[4 * tt + 1], hw[4 * tt + 2], hw[4 * tt + 3]});
             sl[tt] = __builtin_bit_cast(f16x8, u32x4{lw[4 * tt], lw[4 * tt + 1], lw[4 * tt + 2], lw[4 * tt + 3]});
         }
+        BPH_T(tp2);
         // ---- dqn += K(t) . dS'' : 16 steps (2 k-steps x 8 channel blocks), operands read one step ahead.
         //      Riding in the gaps, one slice per step (never a burst of memory instructions): the dS'' stores of
         //      register r, the logits load of tile t+1 into the same sld[r], one staged piece of tile t+1 to the
@@ -329,7 +347,14 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
                 }
             }
         }
+        // the dqn accumulators live in the accumulator file for the whole kernel (without the pins hipcc
+        // rotates them through other AGPR ranges: 64 v_accvgpr_mov per tile)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+a"(dx[kb]));
+        BPH_T(tp3);
         __syncthreads();
+        BPH_T(tp4);
+        BPH_ADD(0, tp0, tp1); BPH_ADD(1, tp1, tp2); BPH_ADD(2, tp2, tp3); BPH_ADD(3, tp3, tp4);
     }
 
     // ---- epilogue: undo the scales -----------------------------------------------------------------------
@@ -372,6 +397,19 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
 }
 
 }  // namespace cocos
+
+#ifdef COCOS_DEBUG_TIMING
+extern "C" int cocos_debug_read_timing_bwd_f16x3(long long* host8, int reset) {
+    using namespace cocos;
+    COCOS_HIP_CHECK(hipDeviceSynchronize());
+    COCOS_HIP_CHECK(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_phase_bq_h), 8 * sizeof(long long)));
+    if (reset) {
+        long long z[8] = {0};
+        COCOS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_bq_h), z, sizeof(z)));
+    }
+    return COCOS_OK;
+}
+#endif
 
 extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
     const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,

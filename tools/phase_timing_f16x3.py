@@ -20,3 +20,15 @@ for it in range(3):
     lib.cocos_debug_read_timing_fwd_f16x3(buf, 1)
     t = list(buf)[:6]
     print(" | ".join(f"{n} {x / 128:.0f}" for n, x in zip(names, t)), f"| total {sum(t) / 128:.0f} ticks/tile  (MFMA ideal: QK 1536, PV {32 * 6 * ((Cv + 31) // 32)})")
+
+# ---- backward (query side) ----
+q2 = q.detach().requires_grad_(True)
+k2 = k.detach().requires_grad_(True)
+go = torch.randn(B, Cv, N, device="cuda", generator=g)
+for it in range(3):
+    q2.grad = None; k2.grad = None
+    ops.corr_softmax_warp(q2, k2, v, 100.0).backward(go)
+    lib.cocos_debug_read_timing_bwd_f16x3(buf, 1)
+    t = list(buf)[:4]
+    print("bwd query: dP %.0f | dS+split %.0f | dQ (+stores, staging) %.0f | barrier %.0f | total %.0f ticks/tile (MFMA ideal: dP %d, dQ 1536)"
+          % (t[0] / 128, t[1] / 128, t[2] / 128, t[3] / 128, sum(t) / 128, 32 * 6 * ((Cv + 31) // 32)))
