@@ -31,6 +31,7 @@ HIP_SOURCES = [
     "corr_fused_bwd.hip",
     "corr_fused_bwd_saved.hip",
     "sgemm_mfma.hip",
+    "sgemm_f16x3.hip",
     "box3_unfold.hip",
     "logits_softmax_warp.hip",
     "row_softmax.hip",

@@ -28,6 +28,11 @@ FUSED_K = 256
 #: "f16x3" = v_mfma_f32_32x32x16_f16 on f16 hi+lo planes, 3 terms per product, fp32 accumulate
 #: (fp32-class accuracy, ~1/5 of the matrix-pipe time).  Module attribute, read at call time.
 PRECISION = os.environ.get("COCOS_PRECISION", "f16x3")
+#: K0 (theta/phi 1x1 projections): "fp32" = the fp32-MFMA GEMM (on par with rocBLAS); "f16x3" = the split GEMM
+#: of sgemm_f16x3.hip — correct and tested, but at K0's shapes (K = 256..407, 8-13 k-steps, a 33 MB output
+#: written in one burst by a single wave of workgroups) it is not faster end to end once the two max|x|
+#: passes are counted (measured 0.55 vs 0.52 ms per step), so it is not the default.
+PROJ_PRECISION = os.environ.get("COCOS_PROJ_PRECISION", "fp32")
 #: power-of-two pre-scale of the unit-norm operands before the f16 split (keeps the lo plane normal)
 SPLIT_OPERAND_SCALE = 16.0
 
@@ -412,6 +417,14 @@ def warp_materialized(p, v):
 # ------------------------------------------------------------------------------------------
 # K0  theta / phi 1x1 projections            (correspondence.py:272, :282)
 # ------------------------------------------------------------------------------------------
+def absmax(x: torch.Tensor) -> torch.Tensor:
+    """max|x| as a 1-element CUDA tensor (one pass, no host sync) — the scale source of the f16 splits."""
+    x = _chk(x, "absmax: x")
+    out = torch.empty(1, device=x.device, dtype=torch.float32)
+    _call("absmax", "cocos_absmax", x.data_ptr(), x.numel(), out.data_ptr(), _stream())
+    return out
+
+
 class _Proj1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -423,8 +436,16 @@ class _Proj1x1(torch.autograd.Function):
             raise ValueError(f"proj1x1: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}")
         bb = None if bias is None else _chk(bias, "proj1x1: bias")
         y = torch.empty((B, Cout, h, w), device=x.device, dtype=torch.float32)
-        _call("proj1x1_fwd", "cocos_proj1x1_fwd", x.data_ptr(), w2.data_ptr(), _ptr(bb), y.data_ptr(), B, Cin,
-              Cout, h * w, _stream())
+        split = PROJ_PRECISION == "f16x3" and min(Cin * Cout, Cin * h * w, Cout * h * w) >= 4
+        if split:      # products on the f16 MFMA, operands split on the fly (sgemm_f16x3.hip)
+            xa, wa = absmax(x), absmax(w2)
+            _call("proj1x1_fwd", "cocos_proj1x1_fwd_f16x3", x.data_ptr(), w2.data_ptr(), _ptr(bb), y.data_ptr(), B,
+                  Cin, Cout, h * w, xa.data_ptr(), wa.data_ptr(), _stream())
+            ctx.amax = (xa, wa)
+        else:
+            _call("proj1x1_fwd", "cocos_proj1x1_fwd", x.data_ptr(), w2.data_ptr(), _ptr(bb), y.data_ptr(), B, Cin,
+                  Cout, h * w, _stream())
+        ctx.split = split
         ctx.save_for_backward(x, w2)
         ctx.wshape = tuple(weight.shape)
         ctx.has_bias = bias is not None
@@ -439,11 +460,18 @@ class _Proj1x1(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad
         dx = torch.empty_like(x) if need_x else None
         dwb = None
+        sfx = "_f16x3" if ctx.split else ""
         if need_w:
-            parts = _lib.load().cocos_proj1x1_bwd_partials(B, Cin, Cout, h * w)
+            parts = getattr(_lib.load(), "cocos_proj1x1_bwd_partials" + sfx)(B, Cin, Cout, h * w)
             dwb = torch.empty((parts, Cout, Cin), device=x.device, dtype=torch.float32)
-        _call("proj1x1_bwd", "cocos_proj1x1_bwd", x.data_ptr(), w2.data_ptr(), dy.data_ptr(), _ptr(dx),
-              _ptr(dwb), B, Cin, Cout, h * w, _stream())
+        if ctx.split:
+            xa, wa = ctx.amax
+            ga = absmax(dy)
+            _call("proj1x1_bwd", "cocos_proj1x1_bwd_f16x3", x.data_ptr(), w2.data_ptr(), dy.data_ptr(), _ptr(dx),
+                  _ptr(dwb), B, Cin, Cout, h * w, xa.data_ptr(), wa.data_ptr(), ga.data_ptr(), _stream())
+        else:
+            _call("proj1x1_bwd", "cocos_proj1x1_bwd", x.data_ptr(), w2.data_ptr(), dy.data_ptr(), _ptr(dx),
+                  _ptr(dwb), B, Cin, Cout, h * w, _stream())
         dw = dwb.sum(0).reshape(ctx.wshape) if need_w else None            # [P,256,Cl] partials, small
         db = dy.sum(dim=(0, 2, 3)) if (need_b and ctx.has_bias) else None
         return dx, dw, db

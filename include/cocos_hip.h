@@ -217,6 +217,20 @@ int cocos_proj1x1_bwd_partials(int B, int Cin, int Cout, int N);   /* 0 on bad d
 int cocos_proj1x1_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw_p,
                       int B, int Cin, int Cout, int N, cocos_stream_t stream);
 
+/* K0 on the split-precision GEMM (sgemm_f16x3.hip): same contract, fp32 tensors in and out; the operands are
+ * split into f16 hi/lo on the fly inside the kernel (3 MFMA terms per product, fp32 accumulate).  Each operand
+ * is pre-scaled by a power of two derived from a device-side max|.| (x_amax, w_amax, dy_amax: 1-element device
+ * arrays, e.g. from cocos_absmax; NULL = the operand is already O(1)).
+ *   cocos_absmax: *out_dev = max|x[0..n)| (one pass; cleared by the call). */
+int cocos_absmax(const float* x, long long n, float* out_dev, cocos_stream_t stream);
+int cocos_proj1x1_fwd_f16x3(const float* x, const float* w, const float* bias, float* y,
+                            int B, int Cin, int Cout, int N, const float* x_amax, const float* w_amax,
+                            cocos_stream_t stream);
+int cocos_proj1x1_bwd_partials_f16x3(int B, int Cin, int Cout, int N);   /* 0 on bad dims */
+int cocos_proj1x1_bwd_f16x3(const float* x, const float* w, const float* dy, float* dx, float* dw_p,
+                            int B, int Cin, int Cout, int N, const float* x_amax, const float* w_amax,
+                            const float* dy_amax, cocos_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * K6  match_kernel = 3 without unfolding (correspondence.py:276-280,:286-289 + :291 + :304, PONO_C):
  *     f[b,p,q] = scale * ( sum_{d in 3x3, p+d and q+d inside} c_raw[b,p+d,q+d] - k_unfolded*mu[b,p]*nu[b,q] )

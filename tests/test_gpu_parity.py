@@ -46,6 +46,7 @@ def precision(request, monkeypatch):
     latter silently uses the fp32 kernel for shapes it does not take, e.g. Nk % 4 != 0)."""
     from cocosnet_amd import ops
     monkeypatch.setattr(ops, "PRECISION", request.param)
+    monkeypatch.setattr(ops, "PROJ_PRECISION", request.param)     # K0 on the split GEMM as well
     return request.param
 
 
@@ -454,7 +455,7 @@ def test_logits_softmax_warp_vs_oracle(B, Nq, Nk, Cv):
 
 @pytest.mark.parametrize("B,Cin,Cout,h,w", [(2, 407, 256, 8, 8), (1, 5, 3, 3, 7), (2, 271, 256, 16, 9),
                                              (2, 407, 256, 64, 64), (1, 130, 70, 23, 29), (1, 1, 1, 1, 1)])
-def test_proj1x1_equals_conv2d(B, Cin, Cout, h, w):
+def test_proj1x1_equals_conv2d(B, Cin, Cout, h, w, precision):
     """K0: theta/phi 1x1 convolutions (:272,:282) on the fp32-MFMA GEMM vs torch's fp64 conv2d."""
     import torch.nn.functional as F
     from cocosnet_amd import ops

@@ -3,7 +3,8 @@ Usage (GPU box): python tools/proj_bench.py [B Cin Cout h w]"""
 import sys
 import torch
 import torch.nn.functional as F
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cocosnet_amd import ops
 
 B, Cin, Cout, h, w = (int(a) for a in sys.argv[1:6]) if len(sys.argv) > 5 else (8, 407, 256, 64, 64)
