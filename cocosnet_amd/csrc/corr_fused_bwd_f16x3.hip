@@ -32,6 +32,9 @@ __device__ __forceinline__ f32x16 bq_mfma(f16x8 a, f16x8 b, f32x16 c) {
 __device__ __forceinline__ u32x4 bq_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
 }
+__device__ __forceinline__ u32x4 bq_load16s(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, (int)soff, 0);
+}
 __device__ __forceinline__ void bq_split_pair(float a, float b, f16x2& hi, f16x2& lo) {
     hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
     lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
@@ -200,6 +203,23 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             *reinterpret_cast<u32x2*>(d + KPLANE + slot0 + 8) = u32x2{kst[1][u].z, kst[1][u].w};
         }
     };
+    // Per-thread parts of the staging addresses do not depend on the tile: computed once; the tile-dependent
+    // part travels in the scalar offset of the buffer instruction (non-ragged key counts only: the scalar
+    // offset is not bounds-checked, so look-ahead tiles past the end are clamped to the last tile instead)
+    unsigned v_voff[VPT], k_voff[4];
+    int v_lds[VPT], k_lds[4];
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
+        v_voff[u] = g < VCH ? (unsigned)(key * CVP + cc * 8) * 2u : kBufOob;
+        v_lds[u] = key * VROW + cc * 8;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int g = u * 256 + tid, row = g >> 2, k8 = g & 3, kq = 2 * k8;
+        k_voff[u] = (unsigned)(row * Nk + 8 * k8) * 2u;
+        k_lds[u] = row * BQH_KROW + 16 * (kq >> 2) + 4 * ((kq >> 1) & 1);
+    }
     float sld[16];
     auto fetch_s = [&](int j0) {
 #pragma unroll
@@ -292,6 +312,24 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
                     const int key = acc_row_base(i) + 4 * h;
                     dstile[key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(hw[i >> 1] >> (16 * (i & 1))));
                     dstile[DSPLANE + key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(lw[i >> 1] >> (16 * (i & 1))));
+                }
+                if (!RAGGED) {
+                    // tile-uniform parts in SGPRs; look-ahead past the last tile re-reads the last tile
+                    const int jt1 = min(j0 + 32, Nk - 32), jt2 = min(jn, Nk - 32);
+                    sld[i] = buf_load1s(lg_rs, sr_lane_off, (unsigned)(jt1 + acc_row_base(i)) * (unsigned)Nq * 4u);
+                    if (i < 2 * VPT) {
+                        const int pl_ = i & 1, u = i >> 1;
+                        if (u * 256 + 255 < VCH || u * 256 + tid < VCH)
+                            *reinterpret_cast<u32x4*>(vw + pl_ * VPLANE + v_lds[u]) = vst[pl_][u];
+                        vst[pl_][u] = bq_load16s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jt2 * (unsigned)(CVP * 2));
+                    } else if (i - 2 * VPT < 8) {
+                        const int pl_ = (i - 2 * VPT) & 1, u = (i - 2 * VPT) >> 1;
+                        _Float16* d = kw + pl_ * KPLANE + k_lds[u];
+                        *reinterpret_cast<u32x2*>(d) = u32x2{kst[pl_][u].x, kst[pl_][u].y};
+                        *reinterpret_cast<u32x2*>(d + 8) = u32x2{kst[pl_][u].z, kst[pl_][u].w};
+                        kst[pl_][u] = bq_load16s(pl_ ? kl_rs : kh_rs, k_voff[u], (unsigned)jt2 * 2u);
+                    }
+                    return;
                 }
                 {   // logits of tile t+1, register i
                     const int jr = j0 + 32 + acc_row_base(i);
