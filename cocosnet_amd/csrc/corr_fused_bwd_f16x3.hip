@@ -49,7 +49,9 @@ __device__ long long g_phase_bq_h[8];
 #define BPH_ADD(i, a, b) do {} while (0)
 #endif
 
-template <int CVB, bool STORE_DS, bool RAGGED>
+constexpr float kPPlaneScale = 16384.0f;   // P in [0,1] -> planes of 2^14 * P (top of f16's range: floor 2^-38)
+
+template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED>
 __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     const _Float16* __restrict__ kch, const _Float16* __restrict__ kcl,   // [B,256,Nk] planes of k_scale*kn
     const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] planes of v
@@ -59,6 +61,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     const float* __restrict__ lse, const float* __restrict__ lg,           // [B,Nq], [B,Nk,Nq]
     float* __restrict__ dqn,                                               // out [B,256,Nq]
     _Float16* __restrict__ dsh, _Float16* __restrict__ dsl,                // out [B,Nk,Nq] planes of dS''
+    _Float16* __restrict__ psh, _Float16* __restrict__ psl,                // out [B,Nk,Nq] planes of 2^14 P (STORE_P)
     const float* __restrict__ v_amax,                                      // max|v| (device)
     float* __restrict__ ds_scale_out,                                      // out: s_o * ds_shift (device)
     int B, int Nq, int Nk, int Cv, float inv_t, float k_scale) {
@@ -98,6 +101,10 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
                                                    STORE_DS ? (size_t)Nk * Nq * 2 : 0);
     const __amdgpu_buffer_rsrc_t dl_rs = make_rsrc(STORE_DS ? dsl + (size_t)b * Nk * Nq : nullptr,
                                                    STORE_DS ? (size_t)Nk * Nq * 2 : 0);
+    const __amdgpu_buffer_rsrc_t ph_rs = make_rsrc(STORE_P ? psh + (size_t)b * Nk * Nq : nullptr,
+                                                   STORE_P ? (size_t)Nk * Nq * 2 : 0);
+    const __amdgpu_buffer_rsrc_t pl_rs = make_rsrc(STORE_P ? psl + (size_t)b * Nk * Nq : nullptr,
+                                                   STORE_P ? (size_t)Nk * Nq * 2 : 0);
     // [Nk][Nq] matrices: lane offset = query column + the half-wave's 4 rows; the tile/register part of
     // the row index is wave-uniform and travels in the scalar offset (not bounds-checked: see fetch_s)
     const unsigned sr_lane_off = live ? (unsigned)(4 * h * Nq + i_lane) * 4u : kBufOob;
@@ -270,11 +277,23 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
         BPH_T(tp1);
         // ---- dS'' = P * (dP' - D') * inv_t * ds_shift ----------------------------------------------------------
         float ds[16];
+        unsigned pwh[STORE_P ? 8 : 1], pwl[STORE_P ? 8 : 1];
+        float pprev = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float pv = fast_exp2(sld[r] - lse2);
             if (RAGGED && (j0 + acc_row_base(r) + 4 * h >= Nk)) pv = 0.f;
             ds[r] = pv * ((dp0[r] + dp1[r]) - d_lane) * cs;
+            if (STORE_P) {          // the key side of the cycle terms needs P itself (dV = dO . P)
+                if (r & 1) {
+                    f16x2 a, bq;
+                    bq_split_pair(pprev * kPPlaneScale, pv * kPPlaneScale, a, bq);
+                    pwh[r >> 1] = __builtin_bit_cast(unsigned, a);
+                    pwl[r >> 1] = __builtin_bit_cast(unsigned, bq);
+                } else {
+                    pprev = pv;
+                }
+            }
         }
 
         // split to f16 hi/lo, two values per 32-bit register (register r>>1, half r&1); registers 8t..8t+7
@@ -384,6 +403,26 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
                     __builtin_amdgcn_raw_buffer_store_b128(xl, dl_rs, (int)off, 0, 0);
                 }
             }
+            if (STORE_P) {
+                // same transposition for the P planes, through the same per-wave buffer (after the dS'' pieces
+                // have been read back; one wave's LDS instructions execute in order)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = acc_row_base(i) + 4 * h;
+                    dstile[key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(pwh[i >> 1] >> (16 * (i & 1))));
+                    dstile[DSPLANE + key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(pwl[i >> 1] >> (16 * (i & 1))));
+                }
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int key = pass * 16 + (lane >> 2), qc = (lane & 3) * 8;
+                    const u32x4 xh = *reinterpret_cast<const u32x4*>(dstile + key * DSROW + qc);
+                    const u32x4 xl = *reinterpret_cast<const u32x4*>(dstile + DSPLANE + key * DSROW + qc);
+                    const int row = j0 + key, col = q0 + wave * 32 + qc;
+                    const unsigned off = (row < Nk && col < Nq) ? (unsigned)(row * Nq + col) * 2u : kBufOob;
+                    __builtin_amdgcn_raw_buffer_store_b128(xh, ph_rs, (int)off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(xl, pl_rs, (int)off, 0, 0);
+                }
+            }
         }
         // the dqn accumulators live in the accumulator file for the whole kernel (without the pins hipcc
         // rotates them through other AGPR ranges: 64 v_accvgpr_mov per tile)
@@ -413,23 +452,28 @@ template <int CVB>
 static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Float16* vph, const _Float16* vpl,
                            const _Float16* gph, const _Float16* gpl, const float* g_scale, const float* outp,
                            const float* dout, const float* lse, const float* lg, float* dqn, _Float16* dsh,
-                           _Float16* dsl, const float* v_amax, float* ds_scale_out, int B, int Nq, int Nk, int Cv,
-                           float inv_t, float k_scale, hipStream_t s) {
-    const bool ragged = (Nk % 32) != 0, store = dsh != nullptr;
+                           _Float16* dsl, _Float16* psh, _Float16* psl, const float* v_amax, float* ds_scale_out,
+                           int B, int Nq, int Nk, int Cv, float inv_t, float k_scale, hipStream_t s) {
+    const bool ragged = (Nk % 32) != 0, store = dsh != nullptr, storep = psh != nullptr;
     const size_t smem = ((size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) + 4 * 2 * 32 * 40) * sizeof(_Float16);
     const int nqb = (Nq + 127) / 128;
 #define COCOS_GO(DS, RG)                                                                                     \
     do {                                                                                                     \
-        auto kern = corr_bwd_query_f16x3_kernel<CVB, DS, RG>;                                                \
+        if (storep) COCOS_GO2(DS, true, RG); else COCOS_GO2(DS, false, RG);                                  \
+    } while (0)
+#define COCOS_GO2(DS, SP, RG)                                                                                \
+    do {                                                                                                     \
+        auto kern = corr_bwd_query_f16x3_kernel<CVB, DS, SP, RG>;                                            \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
         hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, s, kch, kcl, vph, vpl, gph, gpl, g_scale,   \
-                           outp, dout, lse, lg, dqn, dsh, dsl, v_amax, ds_scale_out, B, Nq, Nk, Cv, inv_t,    \
-                           k_scale);                                                                         \
+                           outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, ds_scale_out, B, Nq, Nk, Cv, \
+                           inv_t, k_scale);                                                                  \
     } while (0)
     if (store) { if (ragged) COCOS_GO(true, true); else COCOS_GO(true, false); }
     else       { if (ragged) COCOS_GO(false, true); else COCOS_GO(false, false); }
 #undef COCOS_GO
+#undef COCOS_GO2
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -452,17 +496,18 @@ extern "C" int cocos_debug_read_timing_bwd_f16x3(long long* host8, int reset) {
 extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
     const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
     const float* g_scale_dev, const float* out, const float* dout, const float* lse, const float* logits_t,
-    float* dqn, void* dsh, void* dsl, const float* v_amax_dev, float* ds_scale_out_dev, int B, int K, int Nq,
-    int Nk, int Cv, int CvPad, float inv_temperature, float k_scale, cocos_stream_t stream) {
+    float* dqn, void* dsh, void* dsl, void* psh, void* psl, const float* v_amax_dev, float* ds_scale_out_dev,
+    int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(kch && kcl && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse && logits_t && dqn &&
                       v_amax_dev && ds_scale_out_dev,
                   COCOS_ERR_INVALID, "corr_softmax_warp_bwd_query_f16x3: null pointer");
-    COCOS_REQUIRE((dsh == nullptr) == (dsl == nullptr), COCOS_ERR_INVALID,
-                  "corr_softmax_warp_bwd_query_f16x3: dsh and dsl must both be given or both be NULL");
+    COCOS_REQUIRE((dsh == nullptr) == (dsl == nullptr) && (psh == nullptr) == (psl == nullptr), COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_query_f16x3: plane pointers come in hi/lo pairs");
     COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && k_scale > 0.f, COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd_query_f16x3: bad dims B=%d Nq=%d Nk=%d Cv=%d", B, Nq, Nk, Cv);
-    COCOS_REQUIRE(K == 256 && Cv <= 160 && Nk % 8 == 0 && (dsh == nullptr || Nq % 8 == 0), COCOS_ERR_UNSUPPORTED,
+    COCOS_REQUIRE(K == 256 && Cv <= 160 && Nk % 8 == 0 && ((dsh == nullptr && psh == nullptr) || Nq % 8 == 0),
+                  COCOS_ERR_UNSUPPORTED,
                   "corr_softmax_warp_bwd_query_f16x3: needs K == 256, Cv <= 160, Nk %% 8 == 0 and (with dS planes) "
                   "Nq %% 8 == 0 (K=%d Cv=%d Nk=%d Nq=%d)", K, Cv, Nk, Nq);
     const int cvb = (Cv + 31) / 32;
@@ -478,7 +523,8 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
     static_cast<const _Float16*>(kch), static_cast<const _Float16*>(kcl), static_cast<const _Float16*>(vph),   \
         static_cast<const _Float16*>(vpl), static_cast<const _Float16*>(gph), static_cast<const _Float16*>(gpl), \
         g_scale_dev, out, dout, lse, logits_t, dqn, static_cast<_Float16*>(dsh), static_cast<_Float16*>(dsl),    \
-        v_amax_dev, ds_scale_out_dev, B, Nq, Nk, Cv, inv_temperature, k_scale, s
+        static_cast<_Float16*>(psh), static_cast<_Float16*>(psl), v_amax_dev, ds_scale_out_dev, B, Nq, Nk, Cv,  \
+        inv_temperature, k_scale, s
     switch (cvb) {
         case 1: return launch_bq_f16x3<1>(COCOS_ARGS);
         case 2: return launch_bq_f16x3<2>(COCOS_ARGS);

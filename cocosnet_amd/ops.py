@@ -241,27 +241,35 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             _call("corr_softmax_warp_bwd_prepare", "cocos_corr_softmax_warp_bwd_prepare",
                   out.data_ptr(), dout.data_ptr(), dvec.data_ptr(), B, Nq, Cv, st)
         dims = (B, K, Nq, Nk, Cv, ctx.inv_t, st)
-        if (ctx.cplanes is not None and via_gemm and logits_t is not None and Nk % 8 == 0 and Nq % 8 == 0
-                and Cv <= MAX_FUSED_CV):
-            # split-precision backward: both sides on the f16 MFMA, fp32-class accuracy (see cocos_hip.h)
+        if (ctx.cplanes is not None and logits_t is not None and dqn is not None and dkn is not None
+                and ds_bytes <= MAX_DS_WORKSPACE_BYTES and Nq * Nk * 4 < 2 ** 31 - 1
+                and Nk % 8 == 0 and Nq % 8 == 0 and Cv <= MAX_FUSED_CV):
+            # split-precision backward: everything on the f16 MFMA, fp32-class accuracy (see cocos_hip.h)
             qch, qcl, kch, kcl = ctx.cplanes
             cvp = (Cv + 31) // 32 * 32
             g_amax = dout.abs().amax().reshape(1)
             v_amax = v.abs().amax().reshape(1)
             gph, gpl, g_scale = split_f16(dout, True, cpad=cvp, amax=g_amax)
             vph, vpl = split_f16(v, True, cpad=cvp)
-            dsh = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float16)
-            dsl = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float16)
+            half = dict(device=qn.device, dtype=torch.float16)
+            dsh, dsl = torch.empty((B, Nk, Nq), **half), torch.empty((B, Nk, Nq), **half)
+            psh = psl = None
+            if dv is not None:      # cycle terms: V itself is differentiated, the key side needs P as well
+                psh, psl = torch.empty((B, Nk, Nq), **half), torch.empty((B, Nk, Nq), **half)
             ds_scale = torch.empty(1, device=qn.device, dtype=torch.float32)
             _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3", kch.data_ptr(),
                   kcl.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(),
                   g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), logits_t.data_ptr(),
-                  dqn.data_ptr(), dsh.data_ptr(), dsl.data_ptr(), v_amax.data_ptr(), ds_scale.data_ptr(), B, K, Nq,
-                  Nk, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE, st)
+                  dqn.data_ptr(), dsh.data_ptr(), dsl.data_ptr(), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
+                  ds_scale.data_ptr(), B, K, Nq, Nk, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE, st)
             _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
                   dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 / SPLIT_OPERAND_SCALE,
                   ds_scale.data_ptr(), st)
-            return dqn, (dkn if need_k else None), None, None, None, None
+            if dv is not None:      # dv[c,j] = sum_i dout[c,i] P[i,j]
+                gch, gcl, _ = split_f16(dout, False, amax=g_amax)
+                _call("corr_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(),
+                      psl.data_ptr(), dv.data_ptr(), B, Cv, Nk, Nq, 1.0 / 16384.0, g_scale.data_ptr(), st)
+            return dqn, (dkn if need_k else None), dv, None, None, None
         ds_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if via_gemm else None
         if dqn is not None:
             _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query", qn.data_ptr(),

@@ -114,7 +114,10 @@ int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void
  *       vph,vpl [B,Nk,CvPad] position-major planes of v;   gph,gpl [B,Nq,CvPad] of s_o*dout, s_o = *g_scale_dev
  *       out, dout [B,Cv,Nq] fp32 (for D = sum_c dout*out, fp64);  lse, logits_t as saved by the forward
  *       -> dqn [B,256,Nq] fp32;  dsh,dsl [B,Nk,Nq] planes of dS'' = s_o*ds_shift * dS^T/T (both NULL: skipped);
- *          *ds_scale_out_dev = s_o*ds_shift (ds_shift is derived on the device from *v_amax_dev = max|v|)
+ *          *ds_scale_out_dev = s_o*ds_shift (ds_shift is derived on the device from *v_amax_dev = max|v|);
+ *          psh,psl [B,Nk,Nq] planes of 2^14 * P (both NULL: skipped) for the V gradient of the cycle terms:
+ *          dv = hgemm(A = channel-major planes of s_o*dout [Cv][Nq], B = P planes, host_scale = 2^-14,
+ *          dev_scale = g_scale_dev)
  *       Supported: K == 256, Cv <= 160, CvPad = Cv rounded up to 32, Nk % 8 == 0.
  *   cocos_hgemm_f16x3: C[b][m][n] = host_scale / *dev_scale * sum_k A[b][m][k] B[b][n][k] on hi/lo planes
  *       (k contiguous, K % 8 == 0); the key side is  dkn = hgemm(A = planes of k_scale*qn [256][Nq],
@@ -125,9 +128,9 @@ int cocos_split_f16_ex(const float* x, void* hi, void* lo, int B, int C, int N, 
 int cocos_corr_softmax_warp_bwd_query_f16x3(
     const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
     const float* g_scale_dev, const float* out, const float* dout, const float* lse, const float* logits_t,
-    float* dqn, void* dsh /* nullable */, void* dsl /* nullable */, const float* v_amax_dev,
-    float* ds_scale_out_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature,
-    float k_scale, cocos_stream_t stream);
+    float* dqn, void* dsh /* nullable */, void* dsl /* nullable */, void* psh /* nullable */,
+    void* psl /* nullable */, const float* v_amax_dev, float* ds_scale_out_dev,
+    int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale, cocos_stream_t stream);
 int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* c,
                       int batch, int M, int N, int K, float host_scale, const float* dev_scale /* nullable */,
                       cocos_stream_t stream);
