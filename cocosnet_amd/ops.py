@@ -177,10 +177,9 @@ def split_f16(x: torch.Tensor, transpose: bool, scale: float = 1.0, cache: bool 
     _call("split_f16", "cocos_split_f16", x.data_ptr(), hi.data_ptr(), lo.data_ptr(), B, C, N, int(bool(transpose)),
           float(scale), _stream())
     if cache:
-        if len(_split_cache) > 64:      # drop entries whose tensor is gone
-            for k in [k for k, h in _split_cache.items() if h[0]() is None]:
-                del _split_cache[k]
-        _split_cache[(id(x), bool(transpose))] = (weakref.ref(x), key, hi, lo)
+        ck = (id(x), bool(transpose))
+        # the entry (and its 2 x sizeof(x)/2 bytes of planes) goes away with the tensor it was made from
+        _split_cache[ck] = (weakref.ref(x, lambda _r, ck=ck: _split_cache.pop(ck, None)), key, hi, lo)
     return hi, lo
 
 

@@ -536,3 +536,21 @@ def test_pono_spade_equals_torch_chain(B, C, h, w, slope):
     assert rel(xd.grad, x64.grad.numpy(), floor=0.1) < 2e-5
     assert rel(gd.grad, g64.grad.numpy()) < 1e-5
     assert rel(bd.grad, b64.grad.numpy()) < 1e-5
+
+
+def test_split_plane_cache_follows_tensor_lifetime():
+    """The operand-plane cache must not keep planes of dead tensors alive (one entry per live tensor/layout)."""
+    import gc
+    from cocosnet_amd import ops
+    base = len(ops._split_cache)
+    for _ in range(5):
+        x = torch.randn(1, 256, 64, device=DEV)
+        h1, _ = ops.split_f16(x, True, 16.0, cache=True)
+        h2, _ = ops.split_f16(x, True, 16.0, cache=True)
+        assert h1.data_ptr() == h2.data_ptr()                 # second call is a cache hit
+        x.add_(1.0)                                           # in-place change invalidates the entry
+        h3, _ = ops.split_f16(x, True, 16.0, cache=True)
+        assert not torch.equal(h3, h1)
+        del x
+    gc.collect()
+    assert len(ops._split_cache) == base
