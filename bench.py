@@ -174,8 +174,9 @@ def main():
             if k in d:
                 d[k].grad = None
         out = fwd(d)
-        loss = (out["warp_out"] * d["g_out"]).sum() + (out["warp_mask"] * d["g_mask"]).sum()
-        loss.backward()
+        # backward of the synthetic loss <warp_out, G_out> + <warp_mask, G_mask>: its gradients w.r.t. the two
+        # outputs ARE the fixed tensors G, so they are fed to autograd directly (no loss kernels in the timing)
+        torch.autograd.backward([out["warp_out"], out["warp_mask"]], [d["g_out"], d["g_mask"]])
         buckets.all_reduce_(world)
 
     for _ in range(args.warmup):
