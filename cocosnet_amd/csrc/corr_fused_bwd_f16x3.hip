@@ -335,7 +335,15 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
                 if (!RAGGED) {
                     // tile-uniform parts in SGPRs; look-ahead past the last tile re-reads the last tile
                     const int jt1 = min(j0 + 32, Nk - 32), jt2 = min(jn, Nk - 32);
-                    sld[i] = buf_load1s(lg_rs, sr_lane_off, (unsigned)(jt1 + acc_row_base(i)) * (unsigned)Nq * 4u);
+                    // the logits stream from HBM (nothing re-reads them): all 16 loads of tile t+1 go out in the
+                    // first four steps, so that even the last one has most of this loop plus the next tile's dP
+                    // product (~5000 cycles) to arrive — spread over the 16 steps the last load had ~1100
+                    if (i < 2) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            sld[8 * i + q] = buf_load1s(lg_rs, sr_lane_off,
+                                                        (unsigned)(jt1 + acc_row_base(8 * i + q)) * (unsigned)Nq * 4u);
+                    }
                     if (i < 2 * VPT) {
                         const int pl_ = i & 1, u = i >> 1;
                         if (u * 256 + 255 < VCH || u * 256 + tid < VCH)
