@@ -12,19 +12,18 @@
 // extent sits in one workgroup tile): ~0.13 ms of matrix pipe at the sustained f16 rate against ~0.1 ms of
 // HBM — the fp32-MFMA version of the same product (sgemm_mfma.hip) is 0.56 ms.
 //
-// Tile 256 (M) x 128 (N) x 64 (K) per workgroup, 4 waves as 2 x 2, each wave 128 x 64 = 4 x 2 MFMA tiles
-// (128 accumulator registers).  LDS rows are 64 k-halfs + 8 pad = 144 B: the 16-byte operand reads of 16
-// consecutive rows fall into 16 distinct 4-bank groups (conflict-free).  K blocks of 64 make every global
-// load instruction read whole 128-byte row segments (with 32 the 64-byte pieces ran at 3.1 TB/s); LDS holds
-// one k-block, the next one is in flight in registers while this one multiplies.
+// Tile 256 (M) x 128 (N) x 32 (K) per workgroup, 4 waves as 2 x 2, each wave 128 x 64 = 4 x 2 MFMA tiles
+// (128 accumulator registers).  LDS rows are 32 k-halfs + 8 pad = 80 B: the 16-byte operand reads of 16
+// consecutive rows fall into 16 distinct 4-bank groups (conflict-free).  Double-buffered LDS plus two register
+// stages: the loads of k-blocks t+2 and t+3 are in flight while t multiplies.
 #include "common.h"
 
 namespace cocos {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int HG_BM = 256, HG_BN = 128, HG_BK = 64;
-constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row: 144 B -> conflict-free 16-byte operand reads
+constexpr int HG_BM = 256, HG_BN = 128, HG_BK = 32;
+constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row
 
 __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __restrict__ ah,
                                                              const _Float16* __restrict__ al,
@@ -35,8 +34,8 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                                                              const float* __restrict__ dev_scale) {
     constexpr int APLANE = HG_BM * HG_ROW, BPLANE = HG_BN * HG_ROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // [hi|lo][256][ROW]
-    _Float16* const bt = at + 2 * APLANE;                          // [hi|lo][128][ROW]
+    _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][256][ROW]
+    _Float16* const bt = at + 2 * 2 * APLANE;                      // [2 buf][hi|lo][128][ROW]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -62,53 +61,58 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Staging: a row of a k-block is 128 contiguous bytes per plane = 8 chunks of 16 B = 8 consecutive lanes, so
-    // every global load instruction reads whole 128-byte segments (K % 8 == 0: chunks are whole).  LDS holds ONE
-    // k-block (110 KB with both operands and planes); the next one waits in registers while this one multiplies.
-    constexpr int ANP = HG_BM * 8 / 256, BNP = HG_BN * 8 / 256;
-    u32x4 ast[2][ANP], bst[2][BNP];
-    auto fetch = [&](int k0) {
+    // staging: a row of a k-block is 64 B per plane = 4 chunks of 16 B (K % 8 == 0: chunks are whole).
+    // TWO register stages: LDS holds k-blocks t and t+1, the stages hold t+1 / t+2 resp. t+2 / t+3 in flight — the
+    // B planes stream from HBM and one step (~1.7 us) of look-ahead does not cover the latency.  No branch around
+    // the loads, so the compiler's vmcnt waits are exact.
+    struct Stage { u32x4 a[2][4], b[2][2]; };
+    Stage st0, st1;
+    auto fetch = [&](Stage& st, int k0) {
 #pragma unroll
-        for (int u = 0; u < ANP; ++u) {
-            const int g = u * 256 + tid, row = g >> 3, kc = g & 7;
+        for (int u = 0; u < 4; ++u) {
+            const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
             unsigned off = (unsigned)((m0 + row) * K + k0 + kc * 8) * 2u;
             if (m0 + row >= M || k0 + kc * 8 >= K) off = kBufOob;
-            ast[0][u] = __builtin_amdgcn_raw_buffer_load_b128(ah_rs, (int)off, 0, 0);
-            ast[1][u] = __builtin_amdgcn_raw_buffer_load_b128(al_rs, (int)off, 0, 0);
+            st.a[0][u] = __builtin_amdgcn_raw_buffer_load_b128(ah_rs, (int)off, 0, 0);
+            st.a[1][u] = __builtin_amdgcn_raw_buffer_load_b128(al_rs, (int)off, 0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < BNP; ++u) {
-            const int g = u * 256 + tid, row = g >> 3, kc = g & 7;
+        for (int u = 0; u < 2; ++u) {
+            const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
             unsigned off = (unsigned)((n0 + row) * K + k0 + kc * 8) * 2u;
             if (n0 + row >= N || k0 + kc * 8 >= K) off = kBufOob;
-            bst[0][u] = __builtin_amdgcn_raw_buffer_load_b128(bh_rs, (int)off, 0, 0);
-            bst[1][u] = __builtin_amdgcn_raw_buffer_load_b128(bl_rs, (int)off, 0, 0);
+            st.b[0][u] = __builtin_amdgcn_raw_buffer_load_b128(bh_rs, (int)off, 0, 0);
+            st.b[1][u] = __builtin_amdgcn_raw_buffer_load_b128(bl_rs, (int)off, 0, 0);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](const Stage& st, int buf) {
+        _Float16* ab = at + buf * 2 * APLANE;
+        _Float16* bb = bt + buf * 2 * BPLANE;
 #pragma unroll
-        for (int u = 0; u < ANP; ++u) {
-            const int g = u * 256 + tid, row = g >> 3, kc = g & 7;
-            *reinterpret_cast<u32x4*>(at + row * HG_ROW + kc * 8) = ast[0][u];
-            *reinterpret_cast<u32x4*>(at + APLANE + row * HG_ROW + kc * 8) = ast[1][u];
+        for (int u = 0; u < 4; ++u) {
+            const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
+            *reinterpret_cast<u32x4*>(ab + row * HG_ROW + kc * 8) = st.a[0][u];
+            *reinterpret_cast<u32x4*>(ab + APLANE + row * HG_ROW + kc * 8) = st.a[1][u];
         }
 #pragma unroll
-        for (int u = 0; u < BNP; ++u) {
-            const int g = u * 256 + tid, row = g >> 3, kc = g & 7;
-            *reinterpret_cast<u32x4*>(bt + row * HG_ROW + kc * 8) = bst[0][u];
-            *reinterpret_cast<u32x4*>(bt + BPLANE + row * HG_ROW + kc * 8) = bst[1][u];
+        for (int u = 0; u < 2; ++u) {
+            const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
+            *reinterpret_cast<u32x4*>(bb + row * HG_ROW + kc * 8) = st.b[0][u];
+            *reinterpret_cast<u32x4*>(bb + BPLANE + row * HG_ROW + kc * 8) = st.b[1][u];
         }
     };
 
     const int nsteps = (K + HG_BK - 1) / HG_BK;
-    fetch(0);
-    for (int t = 0; t < nsteps; ++t) {
-        __syncthreads();                      // everyone is done reading k-block t-1
-        commit();
-        __syncthreads();
-        fetch((t + 1) * HG_BK);               // in flight under the 96 MFMAs below (past the end: zeros)
-        const _Float16* ab = at + (wm * 128 + c) * HG_ROW + h * 8;
-        const _Float16* bb = bt + (wn * 64 + c) * HG_ROW + h * 8;
+    fetch(st0, 0);
+    fetch(st1, HG_BK);
+    commit(st0, 0);
+    fetch(st0, 2 * HG_BK);
+    __syncthreads();
+    // at the top of step t: LDS[t&1] = k-block t; st1 (t even) / st0 (t odd) holds t+1, the other stage t+2
+    auto step = [&](int t, Stage& st) {
+        const int buf = t & 1;
+        const _Float16* ab = at + buf * 2 * APLANE + (wm * 128 + c) * HG_ROW + h * 8;
+        const _Float16* bb = bt + buf * 2 * BPLANE + (wn * 64 + c) * HG_ROW + h * 8;
 #pragma unroll
         for (int s = 0; s < HG_BK / 16; ++s) {
             f16x8 bvh[2], bvl[2];
@@ -128,8 +132,19 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, bvh[j], acc[i][j], 0, 0, 0);
                 }
             }
+            if (s == 0) {   // the other buffer was released by the barrier that ended step t-1
+                commit(st, buf ^ 1);                 // k-block t+1
+                fetch(st, (t + 3) * HG_BK);          // k-block t+3 (past the end: zeros)
+            }
         }
+        __syncthreads();
+    };
+    int t = 0;
+    for (; t + 1 < nsteps; t += 2) {      // (no branch inside the pair: it would cost the exact vmcnt waits)
+        step(t, st1);
+        step(t + 1, st0);
     }
+    if (t < nsteps) step(t, st1);
 
     const float scale = host_scale / (dev_scale ? *dev_scale : 1.0f);
     float* Cb = C + (size_t)b * M * N;
@@ -162,7 +177,7 @@ extern "C" int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void*
         COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "hgemm_f16x3: planes must be 16-byte aligned");
     const long long blocks = (long long)batch * ((N + HG_BN - 1) / HG_BN) * ((M + HG_BM - 1) / HG_BM);
     COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "hgemm_f16x3: grid too large");
-    const size_t smem = (size_t)2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16);
+    const size_t smem = (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hgemm_f16x3_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(hgemm_f16x3_kernel, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),
