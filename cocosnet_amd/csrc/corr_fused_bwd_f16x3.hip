@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     _Float16* __restrict__ psh, _Float16* __restrict__ psl,                // out [B,Nk,Nq] planes of 2^14 P (STORE_P)
     const float* __restrict__ v_amax,                                      // max|v| (device)
     float* __restrict__ ds_scale_out,                                      // out: s_o * ds_shift (device)
-    int B, int Nq, int Nk, int Cv, float inv_t, float k_scale) {
+    int B, int Nq, int Nk, int Cv, float inv_t, float k_scale, int planes_blocked) {
     constexpr int CVP = CVB * 32;
     constexpr int CVS = CVP / 16;                     // k-steps of the dP product
     constexpr int KB = BQH_KD / 32;                   // channel blocks of dqn
@@ -406,7 +406,12 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
                     const u32x4 xh = *reinterpret_cast<const u32x4*>(dstile + key * DSROW + qc);
                     const u32x4 xl = *reinterpret_cast<const u32x4*>(dstile + DSPLANE + key * DSROW + qc);
                     const int row = j0 + key, col = q0 + wave * 32 + qc;        // Nq % 8 == 0: whole pieces
-                    const unsigned off = (row < Nk && col < Nq) ? (unsigned)(row * Nq + col) * 2u : kBufOob;
+                    // blocked layout ([128 keys][32 queries] blocks of 8 KB, see cocos_hip.h): the wave's whole
+                    // 32x32 tile is 2 KB contiguous, and a k-block of the key-side GEMM is one contiguous block
+                    const unsigned lin = planes_blocked
+                        ? (unsigned)(((row >> 7) * (Nq >> 5) + (col >> 5)) * 4096 + (row & 127) * 32 + (col & 31))
+                        : (unsigned)(row * Nq + col);
+                    const unsigned off = (row < Nk && col < Nq) ? lin * 2u : kBufOob;
                     __builtin_amdgcn_raw_buffer_store_b128(xh, dh_rs, (int)off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(xl, dl_rs, (int)off, 0, 0);
                 }
@@ -426,7 +431,10 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
                     const u32x4 xh = *reinterpret_cast<const u32x4*>(dstile + key * DSROW + qc);
                     const u32x4 xl = *reinterpret_cast<const u32x4*>(dstile + DSPLANE + key * DSROW + qc);
                     const int row = j0 + key, col = q0 + wave * 32 + qc;
-                    const unsigned off = (row < Nk && col < Nq) ? (unsigned)(row * Nq + col) * 2u : kBufOob;
+                    const unsigned lin = planes_blocked
+                        ? (unsigned)(((row >> 7) * (Nq >> 5) + (col >> 5)) * 4096 + (row & 127) * 32 + (col & 31))
+                        : (unsigned)(row * Nq + col);
+                    const unsigned off = (row < Nk && col < Nq) ? lin * 2u : kBufOob;
                     __builtin_amdgcn_raw_buffer_store_b128(xh, ph_rs, (int)off, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b128(xl, pl_rs, (int)off, 0, 0);
                 }
@@ -461,7 +469,7 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                            const _Float16* gph, const _Float16* gpl, const float* g_scale, const float* outp,
                            const float* dout, const float* lse, const float* lg, float* dqn, _Float16* dsh,
                            _Float16* dsl, _Float16* psh, _Float16* psl, const float* v_amax, float* ds_scale_out,
-                           int B, int Nq, int Nk, int Cv, float inv_t, float k_scale, hipStream_t s) {
+                           int B, int Nq, int Nk, int Cv, float inv_t, float k_scale, int blocked, hipStream_t s) {
     const bool ragged = (Nk % 32) != 0, store = dsh != nullptr, storep = psh != nullptr;
     const size_t smem = ((size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) + 4 * 2 * 32 * 40) * sizeof(_Float16);
     const int nqb = (Nq + 127) / 128;
@@ -476,7 +484,7 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
         hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, s, kch, kcl, vph, vpl, gph, gpl, g_scale,   \
                            outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, ds_scale_out, B, Nq, Nk, Cv, \
-                           inv_t, k_scale);                                                                  \
+                           inv_t, k_scale, blocked);                                                         \
     } while (0)
     if (store) { if (ragged) COCOS_GO(true, true); else COCOS_GO(true, false); }
     else       { if (ragged) COCOS_GO(false, true); else COCOS_GO(false, false); }
@@ -505,7 +513,8 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
     const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
     const float* g_scale_dev, const float* out, const float* dout, const float* lse, const float* logits_t,
     float* dqn, void* dsh, void* dsl, void* psh, void* psl, const float* v_amax_dev, float* ds_scale_out_dev,
-    int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale, cocos_stream_t stream) {
+    int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale, int planes_blocked,
+    cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(kch && kcl && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse && logits_t && dqn &&
                       v_amax_dev && ds_scale_out_dev,
@@ -518,6 +527,9 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
                   COCOS_ERR_UNSUPPORTED,
                   "corr_softmax_warp_bwd_query_f16x3: needs K == 256, Cv <= 160, Nk %% 8 == 0 and (with dS planes) "
                   "Nq %% 8 == 0 (K=%d Cv=%d Nk=%d Nq=%d)", K, Cv, Nk, Nq);
+    COCOS_REQUIRE(!planes_blocked || (Nk % 128 == 0 && Nq % 32 == 0), COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_query_f16x3: blocked planes need Nk %% 128 == 0 and Nq %% 32 == 0 (Nk=%d Nq=%d)",
+                  Nk, Nq);
     const int cvb = (Cv + 31) / 32;
     COCOS_REQUIRE(CvPad == cvb * 32, COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd_query_f16x3: CvPad=%d, expected %d (Cv rounded up to 32)", CvPad, cvb * 32);
@@ -532,7 +544,7 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
         static_cast<const _Float16*>(vpl), static_cast<const _Float16*>(gph), static_cast<const _Float16*>(gpl), \
         g_scale_dev, out, dout, lse, logits_t, dqn, static_cast<_Float16*>(dsh), static_cast<_Float16*>(dsl),    \
         static_cast<_Float16*>(psh), static_cast<_Float16*>(psl), v_amax_dev, ds_scale_out_dev, B, Nq, Nk, Cv,  \
-        inv_temperature, k_scale, s
+        inv_temperature, k_scale, planes_blocked, s
     switch (cvb) {
         case 1: return launch_bq_f16x3<1>(COCOS_ARGS);
         case 2: return launch_bq_f16x3<2>(COCOS_ARGS);

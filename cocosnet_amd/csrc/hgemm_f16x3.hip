@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                                                              const _Float16* __restrict__ bl,
                                                              float* __restrict__ C, int M, int N, int K,
                                                              float host_scale,
-                                                             const float* __restrict__ dev_scale) {
+                                                             const float* __restrict__ dev_scale, int b_blocked) {
     constexpr int APLANE = HG_BM * HG_ROW, BPLANE = HG_BN * HG_ROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][256][ROW]
@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
-            unsigned off = (unsigned)((n0 + row) * K + k0 + kc * 8) * 2u;
+            // b_blocked: B is stored as [N/128][K/32] blocks of [128][32] halfs (8 KB, contiguous) — exactly one
+            // (N tile, k-block) of this kernel; linear otherwise
+            unsigned off = b_blocked ? (unsigned)(((n0 >> 7) * (K >> 5) + (k0 >> 5)) * 4096 + row * 32 + kc * 8) * 2u
+                                     : (unsigned)((n0 + row) * K + k0 + kc * 8) * 2u;
             if (n0 + row >= N || k0 + kc * 8 >= K) off = kBufOob;
             st.b[0][u] = __builtin_amdgcn_raw_buffer_load_b128(bh_rs, (int)off, 0, 0);
             st.b[1][u] = __builtin_amdgcn_raw_buffer_load_b128(bl_rs, (int)off, 0, 0);
@@ -165,12 +168,14 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
 
 extern "C" int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
                                  float* c, int batch, int M, int N, int K, float host_scale,
-                                 const float* dev_scale, cocos_stream_t stream) {
+                                 const float* dev_scale, int b_blocked, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(a_hi && a_lo && b_hi && b_lo && c, COCOS_ERR_INVALID, "hgemm_f16x3: null pointer");
     COCOS_REQUIRE(batch >= 1 && M >= 1 && N >= 1 && K >= 1, COCOS_ERR_INVALID,
                   "hgemm_f16x3: bad dims batch=%d M=%d N=%d K=%d", batch, M, N, K);
     COCOS_REQUIRE(K % 8 == 0, COCOS_ERR_UNSUPPORTED, "hgemm_f16x3: K=%d must be a multiple of 8", K);
+    COCOS_REQUIRE(!b_blocked || (N % 128 == 0 && K % 32 == 0), COCOS_ERR_INVALID,
+                  "hgemm_f16x3: a blocked B operand needs N %% 128 == 0 and K %% 32 == 0 (N=%d K=%d)", N, K);
     COCOS_REQUIRE((size_t)M * K * 2 < 0x7fffffffull && (size_t)N * K * 2 < 0x7fffffffull, COCOS_ERR_UNSUPPORTED,
                   "hgemm_f16x3: per-sample operand exceeds 2 GiB");
     for (const void* p : {a_hi, a_lo, b_hi, b_lo})
@@ -183,7 +188,7 @@ extern "C" int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void*
     hipLaunchKernelGGL(hgemm_f16x3_kernel, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),
                        static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
                        static_cast<const _Float16*>(b_hi), static_cast<const _Float16*>(b_lo), c, M, N, K,
-                       host_scale, dev_scale);
+                       host_scale, dev_scale, b_blocked);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

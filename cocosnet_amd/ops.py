@@ -256,18 +256,19 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             if dv is not None:      # cycle terms: V itself is differentiated, the key side needs P as well
                 psh, psl = torch.empty((B, Nk, Nq), **half), torch.empty((B, Nk, Nq), **half)
             ds_scale = torch.empty(1, device=qn.device, dtype=torch.float32)
+            blocked = int(Nk % 128 == 0 and Nq % 32 == 0)     # tile-blocked [Nk][Nq] planes (see cocos_hip.h)
             _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3", kch.data_ptr(),
                   kcl.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(),
                   g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), logits_t.data_ptr(),
                   dqn.data_ptr(), dsh.data_ptr(), dsl.data_ptr(), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
-                  ds_scale.data_ptr(), B, K, Nq, Nk, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE, st)
+                  ds_scale.data_ptr(), B, K, Nq, Nk, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE, blocked, st)
             _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
                   dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 / SPLIT_OPERAND_SCALE,
-                  ds_scale.data_ptr(), st)
+                  ds_scale.data_ptr(), blocked, st)
             if dv is not None:      # dv[c,j] = sum_i dout[c,i] P[i,j]
                 gch, gcl, _ = split_f16(dout, False, amax=g_amax)
                 _call("corr_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(),
-                      psl.data_ptr(), dv.data_ptr(), B, Cv, Nk, Nq, 1.0 / 16384.0, g_scale.data_ptr(), st)
+                      psl.data_ptr(), dv.data_ptr(), B, Cv, Nk, Nq, 1.0 / 16384.0, g_scale.data_ptr(), blocked, st)
             return dqn, (dkn if need_k else None), dv, None, None, None
         ds_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if via_gemm else None
         if dqn is not None:

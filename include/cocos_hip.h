@@ -119,6 +119,10 @@ int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void
  *          dv = hgemm(A = channel-major planes of s_o*dout [Cv][Nq], B = P planes, host_scale = 2^-14,
  *          dev_scale = g_scale_dev)
  *       Supported: K == 256, Cv <= 160, CvPad = Cv rounded up to 32, Nk % 8 == 0.
+ *   planes_blocked / b_blocked != 0: the [Nk][Nq] planes (dS'', P) are stored as [Nk/128][Nq/32] blocks of
+ *       [128 keys][32 queries] halfs (8 KB each, contiguous) instead of row-major — the query kernel then writes
+ *       each wave's 32x32 tile as 2 KB contiguous and the GEMM reads one contiguous block per k-step (needs
+ *       Nk % 128 == 0, Nq % 32 == 0; both sides must agree).
  *   cocos_hgemm_f16x3: C[b][m][n] = host_scale / *dev_scale * sum_k A[b][m][k] B[b][n][k] on hi/lo planes
  *       (k contiguous, K % 8 == 0); the key side is  dkn = hgemm(A = planes of k_scale*qn [256][Nq],
  *       B = dS'' planes [Nk][Nq], host_scale = 1/k_scale, dev_scale = ds_scale_out_dev). */
@@ -130,10 +134,11 @@ int cocos_corr_softmax_warp_bwd_query_f16x3(
     const float* g_scale_dev, const float* out, const float* dout, const float* lse, const float* logits_t,
     float* dqn, void* dsh /* nullable */, void* dsl /* nullable */, void* psh /* nullable */,
     void* psl /* nullable */, const float* v_amax_dev, float* ds_scale_out_dev,
-    int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale, cocos_stream_t stream);
+    int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale,
+    int planes_blocked, cocos_stream_t stream);
 int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* c,
                       int batch, int M, int N, int K, float host_scale, const float* dev_scale /* nullable */,
-                      cocos_stream_t stream);
+                      int b_blocked, cocos_stream_t stream);
 
 /* Backward of K2 (autograd of :291-318), flash-style: the logits are recomputed from qn/kn and `lse`.
  *   dout [B,Cv,Nq] -> dqn [B,K,Nq], dkn [B,K,Nk], dv [B,Cv,Nk]

@@ -52,7 +52,7 @@ with torch.no_grad():
     vam = v_t.abs().amax().reshape(1)
     _lib.call("cocos_corr_softmax_warp_bwd_query_f16x3", kch.data_ptr(), kcl.data_ptr(), vph.data_ptr(), vpl.data_ptr(),
               gph.data_ptr(), gpl.data_ptr(), gsc.data_ptr(), o2.data_ptr(), g_t.data_ptr(), lse_t.data_ptr(), lg_t.data_ptr(),
-              dqn.data_ptr(), dsh.data_ptr(), dsl.data_ptr(), vam.data_ptr(), dsc.data_ptr(), B, 256, Nq, Nk, Cv, cvp, 100.0, 16.0, st)
+              dqn.data_ptr(), dsh.data_ptr(), dsl.data_ptr(), 0, 0, vam.data_ptr(), dsc.data_ptr(), B, 256, Nq, Nk, Cv, cvp, 100.0, 16.0, 0, st)
     torch.cuda.synchronize()
     print("g_scale", float(gsc), "ds_scale", float(dsc))
     rec = (dsh.double() + dsl.double()).cpu().numpy() / float(dsc)
@@ -62,7 +62,7 @@ with torch.no_grad():
     print("bad fraction", bad.mean(), "bad rows (keys)", np.unique(np.where(bad)[1])[:40], "bad cols (queries)", np.unique(np.where(bad)[2])[:40])
     dkn = torch.empty_like(kn_t)
     _lib.call("cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(), dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, 256, Nk, Nq,
-              1.0 / 16.0, dsc.data_ptr(), st)
+              1.0 / 16.0, dsc.data_ptr(), 0, st)
     print("dk err (manual)", np.abs(dkn.double().cpu().numpy() - dk_ref).max())
     dk_from_rec = np.einsum("bki,bji->bkj", qn, rec)
     print("dk from reconstructed planes err", np.abs(dk_from_rec - dk_ref).max())
