@@ -57,7 +57,9 @@ def _digest(paths) -> str:
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
-            h.update(p.encode())
+            # file NAME, not the absolute path: the stamp must stay valid when the tree is copied elsewhere
+            # (the prebuilt .so travels to the GPU box and must not be rebuilt there on every import)
+            h.update(os.path.basename(p).encode())
             h.update(f.read())
     h.update(" ".join(_flags()).encode())
     return h.hexdigest()
