@@ -235,7 +235,7 @@ def main():
         traffic, traffic_src = None, None
         pmc_file = os.path.join(REPO, "profiles", "r01_pmc_f16x3.json" if split else "r01_pmc_final.json")
         pmc_key = ({"corr_softmax_warp_fwd": "corr_fwd_f16x3_kernel<5, 1, 0>",
-                    "corr_softmax_warp_bwd_query": "corr_bwd_query_f16x3_kernel<5, 1, 0>",
+                    "corr_softmax_warp_bwd_query": "corr_bwd_query_f16x3_kernel<5, 1, 0, 0>",
                     "corr_softmax_warp_bwd_key_from_ds": "hgemm_f16x3_kernel"} if split else
                    {"corr_softmax_warp_fwd": "corr_softmax_warp_fwd_kernel<256, 5, true",
                     "corr_softmax_warp_bwd_query": "corr_bwd_query_saved_kernel<256, 5, true",
