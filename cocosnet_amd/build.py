@@ -37,6 +37,7 @@ HIP_SOURCES = [
     "row_softmax.hip",
     "wta_scale.hip",
     "pono_spade.hip",
+    "upsample_nearest.hip",
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              "-Wall", "-Wno-unused-function"]

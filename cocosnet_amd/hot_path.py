@@ -60,7 +60,9 @@ def _flat(x):
 def _upsample(y, down, bilinear):
     if bilinear:   # nn.Upsample(scale_factor, mode='bilinear'), align_corners=False (:184-186)
         return F.interpolate(y, scale_factor=down, mode="bilinear", align_corners=False)
-    return F.interpolate(y, scale_factor=down, mode="nearest")   # :188
+    if y.is_cuda and y.dtype == torch.float32 and (y.shape[3] * down) % 4 == 0:
+        return ops.upsample_nearest(y, down)                     # :188 (K11)
+    return F.interpolate(y, scale_factor=down, mode="nearest")
 
 
 class _Attention:

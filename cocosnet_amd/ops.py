@@ -246,8 +246,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             # split-precision backward: everything on the f16 MFMA, fp32-class accuracy (see cocos_hip.h)
             qch, qcl, kch, kcl = ctx.cplanes
             cvp = (Cv + 31) // 32 * 32
-            g_amax = dout.abs().amax().reshape(1)
-            v_amax = v.abs().amax().reshape(1)
+            g_amax, v_amax = absmax(dout), absmax(v)          # one pass each, no host sync
             gph, gpl, g_scale = split_f16(dout, True, cpad=cvp, amax=g_amax)
             vph, vpl = split_f16(v, True, cpad=cvp)
             half = dict(device=qn.device, dtype=torch.float16)
@@ -658,6 +657,35 @@ class _PonoSpade(torch.autograd.Function):
 def pono_spade(x, gamma, beta, slope: float = 1.0, eps: float = PONO_EPS):
     """leaky_relu(PositionalNorm2d(x) * (1 + gamma) + beta, slope) for x, gamma, beta [B,C,H,W]."""
     return _PonoSpade.apply(x, gamma, beta, slope, eps)
+
+
+# ------------------------------------------------------------------------------------------
+# K11 nearest-neighbour up-sampling of the warped image   (correspondence.py:188, :327)
+# ------------------------------------------------------------------------------------------
+class _UpsampleNearest(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale: int):
+        x = _chk(x, "upsample_nearest: x")
+        B, C, h, w = x.shape
+        y = torch.empty((B, C, h * scale, w * scale), device=x.device, dtype=torch.float32)
+        _call("upsample_nearest_fwd", "cocos_upsample_nearest_fwd", x.data_ptr(), y.data_ptr(), B * C, h, w, int(scale),
+              _stream())
+        ctx.cfg = (B, C, h, w, int(scale))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, h, w, scale = ctx.cfg
+        dy = _chk(dy, "upsample_nearest: dy")
+        dx = torch.empty((B, C, h, w), device=dy.device, dtype=torch.float32)
+        _call("upsample_nearest_bwd", "cocos_upsample_nearest_bwd", dy.data_ptr(), dx.data_ptr(), B * C, h, w, scale,
+              _stream())
+        return dx, None
+
+
+def upsample_nearest(x, scale: int):
+    """F.interpolate(x, scale_factor=scale, mode='nearest') for integer scales (x [B,C,h,w] fp32, (w*scale) % 4 == 0)."""
+    return _UpsampleNearest.apply(x, scale)
 
 
 def mfma_probe() -> torch.Tensor:

@@ -300,6 +300,14 @@ int cocos_pono_spade_bwd(const float* x, const float* gamma, const float* beta, 
                          float* dx, float* dgamma, float* dbeta,
                          int B, int C, int N, float eps, float slope, cocos_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * K11 nearest-neighbour up-sampling of the warped image (self.upsampling = nn.Upsample(scale_factor=down),
+ *     correspondence.py:188, applied at :327) and its backward.  x [planes,h,w] -> y [planes,h*scale,w*scale]
+ *     (planes = B*C);  bwd: dx[p,y,x] = sum of the scale x scale block of dy.  (w*scale) % 4 == 0.
+ * ------------------------------------------------------------------------------------- */
+int cocos_upsample_nearest_fwd(const float* x, float* y, int planes, int h, int w, int scale, cocos_stream_t stream);
+int cocos_upsample_nearest_bwd(const float* dy, float* dx, int planes, int h, int w, int scale, cocos_stream_t stream);
+
 /* Debug: runs one v_mfma_f32_32x32x2_f32 with known operands and dumps the 64x16 accumulator
  * registers to out[64*16] so the host can verify the lane/register -> (row, col) map. */
 int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);

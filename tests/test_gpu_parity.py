@@ -561,3 +561,19 @@ def test_split_plane_cache_follows_tensor_lifetime():
         del x
     gc.collect()
     assert len(ops._split_cache) == base
+
+
+@pytest.mark.parametrize("B,C,h,w,d", [(2, 3, 64, 64, 4), (1, 5, 7, 6, 2), (1, 1, 3, 4, 1), (2, 3, 16, 16, 4)])
+def test_upsample_nearest_matches_torch(B, C, h, w, d):
+    """K11 vs F.interpolate(mode='nearest') (nn.Upsample at correspondence.py:188), forward (bit-exact) and backward."""
+    import torch.nn.functional as F
+    from cocosnet_amd import ops
+    x = torch.randn(B, C, h, w, device=DEV, requires_grad=True)
+    g = torch.randn(B, C, h * d, w * d, device=DEV)
+    y = ops.upsample_nearest(x, d)
+    y.backward(g)
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = F.interpolate(x2, scale_factor=d, mode="nearest")
+    y2.backward(g)
+    assert torch.equal(y, y2)
+    assert rel(x.grad, x2.grad.cpu().numpy()) < 1e-6
