@@ -48,8 +48,12 @@ class KernelTimer:
 
     active = None
 
-    def __init__(self):
+    def __init__(self, tags=None):
+        """`tags`: only these entry-point tags are bracketed (every HIP event is a marker packet in the queue that
+        serialises the dispatch around it: ~3.5 us each, 8 % of the benchmark step when all ~40 calls are
+        bracketed); None = all."""
         self.events = {}
+        self.tags = None if tags is None else frozenset(tags)
 
     def __enter__(self):
         KernelTimer.active = self
@@ -69,7 +73,7 @@ class KernelTimer:
 
 def _call(tag, name, *args):
     t = KernelTimer.active
-    if t is None:
+    if t is None or (t.tags is not None and tag not in t.tags):
         return _lib.call(name, *args)
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
