@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
     // the loads, so the compiler's vmcnt waits are exact.
     struct Stage { u32x4 a[2][4], b[2][2]; };
     Stage st0, st1;
+    // (loads are issued in the order in which the step loop consumes them: A h0 l0 h1 l1 ..., then B)
     auto fetch = [&](Stage& st, int k0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -112,6 +113,30 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
     fetch(st0, 2 * HG_BK);
     __syncthreads();
     // at the top of step t: LDS[t&1] = k-block t; st1 (t even) / st0 (t odd) holds t+1, the other stage t+2
+    // one staged 16-byte piece (plane pl, chunk u of operand A or B) -> the other LDS buffer, and its register
+    // takes the load for k-block t+3: issued ONE piece at a time between MFMAs (12 pieces per step, one per
+    // (s, i) pair ... ) so that LDS writes and global loads overlap the matrix pipe instead of stalling the
+    // in-order wave as a block of 24 memory instructions
+    auto piece = [&](Stage& st, int idx, int buf, int k0) {
+        _Float16* ab = at + buf * 2 * APLANE;
+        _Float16* bb = bt + buf * 2 * BPLANE;
+        if (idx < 8) {                                   // A: plane idx & 1, chunk idx >> 1
+            const int pl = idx & 1, u = idx >> 1;
+            const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
+            *reinterpret_cast<u32x4*>(ab + pl * APLANE + row * HG_ROW + kc * 8) = st.a[pl][u];
+            unsigned off = (unsigned)((m0 + row) * K + k0 + kc * 8) * 2u;
+            if (m0 + row >= M || k0 + kc * 8 >= K) off = kBufOob;
+            st.a[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(pl ? al_rs : ah_rs, (int)off, 0, 0);
+        } else {                                         // B: plane (idx - 8) & 1, chunk (idx - 8) >> 1
+            const int pl = (idx - 8) & 1, u = (idx - 8) >> 1;
+            const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
+            *reinterpret_cast<u32x4*>(bb + pl * BPLANE + row * HG_ROW + kc * 8) = st.b[pl][u];
+            unsigned off = b_blocked ? (unsigned)(((n0 >> 7) * (K >> 5) + (k0 >> 5)) * 4096 + row * 32 + kc * 8) * 2u
+                                     : (unsigned)((n0 + row) * K + k0 + kc * 8) * 2u;
+            if (n0 + row >= N || k0 + kc * 8 >= K) off = kBufOob;
+            st.b[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(pl ? bl_rs : bh_rs, (int)off, 0, 0);
+        }
+    };
     auto step = [&](int t, Stage& st) {
         const int buf = t & 1;
         const _Float16* ab = at + buf * 2 * APLANE + (wm * 128 + c) * HG_ROW + h * 8;
@@ -133,11 +158,12 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvh[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, bvh[j], acc[i][j], 0, 0, 0);
+                    // 16 (s, i, j) slots per step, 12 pieces: k-block t+1 -> LDS[buf ^ 1] (released by the barrier
+                    // that ended step t-1), k-block t+3 -> the freed registers
+                    const int slot = (s * 4 + i) * 2 + j;
+                    if (slot < 12) piece(st, slot, buf ^ 1, (t + 3) * HG_BK);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-            if (s == 0) {   // the other buffer was released by the barrier that ended step t-1
-                commit(st, buf ^ 1);                 // k-block t+1
-                fetch(st, (t + 3) * HG_BK);          // k-block t+3 (past the end: zeros)
             }
         }
         __syncthreads();
