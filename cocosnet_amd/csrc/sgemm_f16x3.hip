@@ -94,6 +94,33 @@ struct XgStage {
             else      r[u] = xg_piece<KC>(rs, mn, k, MN, K, kend);
         }
     }
+    template <bool FAST>
+    __device__ __forceinline__ void fetch_piece(int u, __amdgpu_buffer_rsrc_t rs, int mn0, int k0, int MN, int K,
+                                                int kend, int tid) {
+        int mn, k;
+        if (KC) { const int idx = u * 256 + tid; mn = mn0 + (idx >> 3); k = k0 + (idx & 7) * 4; }
+        else    { k = k0 + (tid & 15) + 16 * (u & 1); mn = mn0 + ((tid >> 4) + 16 * (u >> 1)) * 4; }
+        if (FAST) r[u] = buf_load4(rs, (unsigned)(KC ? mn * K + k : k * MN + mn) * 4u);
+        else      r[u] = xg_piece<KC>(rs, mn, k, MN, K, kend);
+    }
+    __device__ __forceinline__ void commit_piece(int u, _Float16* tile, float s, int tid) const {
+        u32x2 hi, lo;
+        xg_split4(r[u], s, hi, lo);
+        if (KC) {
+            const int idx = u * 256 + tid, row = idx >> 3, kq = idx & 7;
+            _Float16* d = tile + row * XG_ROW + kq * 4;
+            *reinterpret_cast<u32x2*>(d) = hi;
+            *reinterpret_cast<u32x2*>(d + ROWS * XG_ROW) = lo;
+        } else {
+            const int k = (tid & 15) + 16 * (u & 1), row = ((tid >> 4) + 16 * (u >> 1)) * 4;
+            unsigned short* d = reinterpret_cast<unsigned short*>(tile) + row * XG_ROW + k;
+            unsigned short* dl = d + ROWS * XG_ROW;
+            d[0] = (unsigned short)hi.x;            d[XG_ROW] = (unsigned short)(hi.x >> 16);
+            d[2 * XG_ROW] = (unsigned short)hi.y;   d[3 * XG_ROW] = (unsigned short)(hi.y >> 16);
+            dl[0] = (unsigned short)lo.x;           dl[XG_ROW] = (unsigned short)(lo.x >> 16);
+            dl[2 * XG_ROW] = (unsigned short)lo.y;  dl[3 * XG_ROW] = (unsigned short)(lo.y >> 16);
+        }
+    }
     // planes: hi at `tile`, lo at `tile + ROWS * XG_ROW`
     __device__ __forceinline__ void commit(_Float16* tile, float s, int tid) const {
 #pragma unroll
@@ -192,20 +219,26 @@ __global__ __launch_bounds__(256, 1) void sgemm_f16x3_kernel(const float* __rest
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvh[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, bvh[j], acc[i][j], 0, 0, 0);
+                    mid((s * 4 + i) * 2 + j);          // one staged piece per MFMA triple (16 slots, 12 pieces)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (s == 0) mid();
         }
         __syncthreads();
     };
     // step t: multiply LDS[t&1]; commit the stage that holds tile t+1 into the other buffer (released by the
     // barrier that ended step t-1) and refill it with tile t+3 (FAST when that tile is a full interior block)
+    // (one piece = convert + LDS write of one staged float4, then its reload: the split's VALU work, the LDS
+    //  writes and the global loads ride between the MFMAs instead of stalling the in-order wave as one block)
 #define XG_STEP(FAST, T, SA, SB)                                                              \
-    compute((T) & 1, [&]() {                                                                  \
-        SA.commit(at + (((T) & 1) ^ 1) * 2 * APLANE, sa, tid);                                \
-        SB.commit(bt + (((T) & 1) ^ 1) * 2 * BPLANE, sb, tid);                                \
-        SA.template fetch<FAST>(a_rs, m0, kbeg + ((T) + 3) * XG_BK, M, K, kend, tid);         \
-        SB.template fetch<FAST>(b_rs, n0, kbeg + ((T) + 3) * XG_BK, N, K, kend, tid);         \
+    compute((T) & 1, [&](int slot) {                                                          \
+        if (slot < 8) {                                                                       \
+            SA.commit_piece(slot, at + (((T) & 1) ^ 1) * 2 * APLANE, sa, tid);                \
+            SA.template fetch_piece<FAST>(slot, a_rs, m0, kbeg + ((T) + 3) * XG_BK, M, K, kend, tid); \
+        } else if (slot < 12) {                                                               \
+            SB.commit_piece(slot - 8, bt + (((T) & 1) ^ 1) * 2 * BPLANE, sb, tid);            \
+            SB.template fetch_piece<FAST>(slot - 8, b_rs, n0, kbeg + ((T) + 3) * XG_BK, N, K, kend, tid); \
+        }                                                                                     \
     })
 
     // Pipeline: LDS holds tile t (being multiplied) and tile t+1; TWO register stages hold tiles t+1 / t+2 in
@@ -289,9 +322,20 @@ static int launch_gemm_f16x3(const float* A, const float* Bm, float* C, int batc
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, size_t n,
                                                      unsigned* __restrict__ out) {
     float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    // 8 independent 16-byte loads in flight per thread and iteration (a dependent load -> max chain runs at
+    // ~1.3 TB/s; this form is bandwidth-bound)
+    constexpr int U = 8;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t idx = i + (size_t)u * stride;
+            v[u] = idx < n4 ? *reinterpret_cast<const f32x4*>(x + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
     }
     if (blockIdx.x == 0)
         for (size_t j = n4 * 4 + threadIdx.x; j < n; j += 256) m = fmaxf(m, fabsf(x[j]));
@@ -326,7 +370,7 @@ extern "C" int cocos_absmax(const float* x, long long n, float* out_dev, cocos_s
     hipStream_t s = as_stream(stream);
     COCOS_HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(float), s));
     const size_t n4 = aligned16(x) ? (size_t)n / 4 : 0;
-    const unsigned blocks = (unsigned)std::min<size_t>(1024, (n4 + 255) / 256 + 1);
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, (n4 + 256 * 8 - 1) / (256 * 8) + 1);
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, (size_t)n,
                        reinterpret_cast<unsigned*>(out_dev));
     COCOS_HIP_CHECK(hipGetLastError());

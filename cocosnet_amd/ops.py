@@ -29,10 +29,10 @@ FUSED_K = 256
 #: (fp32-class accuracy, ~1/5 of the matrix-pipe time).  Module attribute, read at call time.
 PRECISION = os.environ.get("COCOS_PRECISION", "f16x3")
 #: K0 (theta/phi 1x1 projections): "fp32" = the fp32-MFMA GEMM (on par with rocBLAS); "f16x3" = the split GEMM
-#: of sgemm_f16x3.hip — correct and tested, but at K0's shapes (K = 256..407, 8-13 k-steps, a 33 MB output
-#: written in one burst by a single wave of workgroups) it is not faster end to end once the two max|x|
-#: passes are counted (measured 0.55 vs 0.52 ms per step), so it is not the default.
-PROJ_PRECISION = os.environ.get("COCOS_PROJ_PRECISION", "fp32")
+#: of sgemm_f16x3.hip (operands split on the fly, staged pieces converted/committed between MFMAs).  At K0's
+#: shapes (K = 256..407: 8-13 k-steps, a 33 MB output written in one burst) it gains less than the K2 kernels
+#: do and pays for the max|x| passes, but is ahead end to end (0.40 + 0.1 vs 0.51 ms per step).
+PROJ_PRECISION = os.environ.get("COCOS_PROJ_PRECISION", "f16x3")
 #: power-of-two pre-scale of the unit-norm operands before the f16 split (keeps the lo plane normal)
 SPLIT_OPERAND_SCALE = 16.0
 
