@@ -152,6 +152,7 @@ def main():
     from cocosnet_amd import ops
     if args.precision:
         ops.PRECISION = args.precision
+        ops.PROJ_PRECISION = args.precision      # K0 follows (COCOS_PROJ_PRECISION overrides it separately)
     rank, local_rank, world = cdist.init_from_env("nccl")
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

@@ -7,7 +7,7 @@
 set -u
 TAG=${1:-r01}; PREC=${2:-f16x3}
 R=$(pwd); O=$R/gpurun_out/prof_$TAG; mkdir -p $O
-export TMPDIR=/tmp COCOS_PRECISION=$PREC
+export TMPDIR=/tmp COCOS_PRECISION=$PREC COCOS_PROJ_PRECISION=$PREC
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
 python $R/tools/rocprof_summary.py "$(find $O/stats -name "*kernel_stats.csv" | head -1)" $O/${TAG}_bench_kernel_stats.txt > /dev/null 2>&1
