@@ -421,3 +421,34 @@ extern "C" int cocos_proj1x1_bwd_f16x3(const float* x, const float* w, const flo
                                                  proj1x1_ksplit_f16x3(B, Cin, Cout, N), dy_amax, x_amax);
     return rc;
 }
+
+// ---- K3 on the split-precision GEMM (same contract as cocos_corr_materialize / _bwd in sgemm_mfma.hip) --------
+// f[b,i,j] = scale * sum_k qn[b,k,i] kn[b,k,j]        C[m=i][n=j], A=[k][m], B=[k][n]
+extern "C" int cocos_corr_materialize_f16x3(const float* qn, const float* kn, float* f, int B, int K, int Nq,
+                                            int Nk, float scale, const float* q_amax, const float* k_amax,
+                                            cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(qn && kn && f, COCOS_ERR_INVALID, "corr_materialize_f16x3: null pointer");
+    COCOS_REQUIRE(B >= 1 && K >= 1 && Nq >= 1 && Nk >= 1, COCOS_ERR_INVALID,
+                  "corr_materialize_f16x3: bad dims B=%d K=%d Nq=%d Nk=%d", B, K, Nq, Nk);
+    return launch_gemm_f16x3<false, false>(qn, kn, f, B, Nq, Nk, K, scale, as_stream(stream), false, nullptr, 1,
+                                           q_amax, k_amax);
+}
+
+extern "C" int cocos_corr_materialize_bwd_f16x3(const float* qn, const float* kn, const float* df, float* dqn,
+                                                float* dkn, int B, int K, int Nq, int Nk, float scale,
+                                                const float* q_amax, const float* k_amax, const float* df_amax,
+                                                cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(qn && kn && df, COCOS_ERR_INVALID, "corr_materialize_bwd_f16x3: null pointer");
+    COCOS_REQUIRE(B >= 1 && K >= 1 && Nq >= 1 && Nk >= 1, COCOS_ERR_INVALID,
+                  "corr_materialize_bwd_f16x3: bad dims B=%d K=%d Nq=%d Nk=%d", B, K, Nq, Nk);
+    hipStream_t s = as_stream(stream);
+    int rc = COCOS_OK;
+    // dqn[k][i] = sum_j kn[k][j] df[i][j] : C[m=k][n=i], A = kn [m][kk=j] (k-contig), B = df [n=i][kk=j] (k-contig)
+    if (dqn) rc = launch_gemm_f16x3<true, true>(kn, df, dqn, B, K, Nq, Nk, scale, s, false, nullptr, 1, k_amax, df_amax);
+    if (rc != COCOS_OK) return rc;
+    // dkn[k][j] = sum_i qn[k][i] df[i][j] : C[m=k][n=j], A = qn [m][kk=i] (k-contig), B = df [kk=i][n=j] (n-contig)
+    if (dkn) rc = launch_gemm_f16x3<true, false>(qn, df, dkn, B, K, Nk, Nq, scale, s, false, nullptr, 1, q_amax, df_amax);
+    return rc;
+}

@@ -333,7 +333,13 @@ class _CorrMaterialize(torch.autograd.Function):
         if kn.shape[:2] != (B, K):
             raise ValueError(f"corr_materialize: shape mismatch qn{tuple(qn.shape)} kn{tuple(kn.shape)}")
         f = torch.empty((B, Nq, Nk), device=qn.device, dtype=torch.float32)
-        _call("corr_materialize", "cocos_corr_materialize", qn.data_ptr(), kn.data_ptr(), f.data_ptr(), B, K, Nq,
+        ctx.amax = None
+        if PRECISION == "f16x3" and min(K * Nq, K * Nk) >= 4:      # split GEMM (sgemm_f16x3.hip)
+            ctx.amax = (absmax(qn), absmax(kn))
+            _call("corr_materialize", "cocos_corr_materialize_f16x3", qn.data_ptr(), kn.data_ptr(), f.data_ptr(), B, K,
+                  Nq, Nk, float(scale), ctx.amax[0].data_ptr(), ctx.amax[1].data_ptr(), _stream())
+        else:
+            _call("corr_materialize", "cocos_corr_materialize", qn.data_ptr(), kn.data_ptr(), f.data_ptr(), B, K, Nq,
                   Nk, float(scale), _stream())
         ctx.save_for_backward(qn, kn)
         ctx.scale = float(scale)
@@ -348,7 +354,14 @@ class _CorrMaterialize(torch.autograd.Function):
         need_q, need_k = ctx.needs_input_grad[:2]
         dqn = torch.empty_like(qn) if need_q else None
         dkn = torch.empty_like(kn) if need_k else None
-        _call("corr_materialize_bwd", "cocos_corr_materialize_bwd", qn.data_ptr(), kn.data_ptr(), df.data_ptr(),
+        if ctx.amax is not None and Nq * Nk >= 4:
+            qa, ka = ctx.amax
+            ga = absmax(df)
+            _call("corr_materialize_bwd", "cocos_corr_materialize_bwd_f16x3", qn.data_ptr(), kn.data_ptr(),
+                  df.data_ptr(), _ptr(dqn), _ptr(dkn), B, K, Nq, Nk, ctx.scale, qa.data_ptr(), ka.data_ptr(),
+                  ga.data_ptr(), _stream())
+        else:
+            _call("corr_materialize_bwd", "cocos_corr_materialize_bwd", qn.data_ptr(), kn.data_ptr(), df.data_ptr(),
                   _ptr(dqn), _ptr(dkn), B, K, Nq, Nk, ctx.scale, _stream())
         return dqn, dkn, None
 

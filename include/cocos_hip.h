@@ -235,6 +235,13 @@ int cocos_proj1x1_fwd_f16x3(const float* x, const float* w, const float* bias, f
                             int B, int Cin, int Cout, int N, const float* x_amax, const float* w_amax,
                             cocos_stream_t stream);
 int cocos_proj1x1_bwd_partials_f16x3(int B, int Cin, int Cout, int N);   /* 0 on bad dims */
+/* K3 (cocos_corr_materialize / _bwd: correspondence.py:291 (+:304) and its autograd) on the same split GEMM;
+ * q_amax, k_amax, df_amax: device-side max|.| of the operands (NULL = O(1)). */
+int cocos_corr_materialize_f16x3(const float* qn, const float* kn, float* f, int B, int K, int Nq, int Nk,
+                                 float scale, const float* q_amax, const float* k_amax, cocos_stream_t stream);
+int cocos_corr_materialize_bwd_f16x3(const float* qn, const float* kn, const float* df, float* dqn, float* dkn,
+                                     int B, int K, int Nq, int Nk, float scale, const float* q_amax,
+                                     const float* k_amax, const float* df_amax, cocos_stream_t stream);
 int cocos_proj1x1_bwd_f16x3(const float* x, const float* w, const float* dy, float* dx, float* dw_p,
                             int B, int Cin, int Cout, int N, const float* x_amax, const float* w_amax,
                             const float* dy_amax, cocos_stream_t stream);
