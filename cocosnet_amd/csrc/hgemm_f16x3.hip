@@ -1,7 +1,7 @@
 // Split-precision batched GEMM on v_mfma_f32_32x32x16_f16 (gfx950): both operands arrive as f16 hi + lo
 // planes, three MFMA terms per product, fp32 accumulate and output.
 //
-//   C[b][m][n] = (host_scale / *dev_scale) * sum_k A[b][m][k] * B[b][n][k]
+//   C[b][m][n] = host_scale / (*dev_scale * *dev_scale2) * sum_k A[b][m][k] * B[b][n][k]   (NULL scale = 1)
 //   A planes [batch][M][K], B planes [batch][N][K]  (k contiguous), C fp32 [batch][M][N]
 //
 // Used as the key side of the K2 backward (autograd of correspondence.py:291 w.r.t. phi):
@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                                                              const _Float16* __restrict__ bl,
                                                              float* __restrict__ C, int M, int N, int K,
                                                              float host_scale,
-                                                             const float* __restrict__ dev_scale, int b_blocked) {
+                                                             const float* __restrict__ dev_scale,
+                                                             const float* __restrict__ dev_scale2, int b_blocked) {
     constexpr int APLANE = HG_BM * HG_ROW, BPLANE = HG_BN * HG_ROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][256][ROW]
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
     }
     if (t < nsteps) step(t, st1);
 
-    const float scale = host_scale / (dev_scale ? *dev_scale : 1.0f);
+    const float scale = host_scale / ((dev_scale ? *dev_scale : 1.0f) * (dev_scale2 ? *dev_scale2 : 1.0f));
     float* Cb = C + (size_t)b * M * N;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
 
 extern "C" int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
                                  float* c, int batch, int M, int N, int K, float host_scale,
-                                 const float* dev_scale, int b_blocked, cocos_stream_t stream) {
+                                 const float* dev_scale, const float* dev_scale2, int b_blocked,
+                                 cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(a_hi && a_lo && b_hi && b_lo && c, COCOS_ERR_INVALID, "hgemm_f16x3: null pointer");
     COCOS_REQUIRE(batch >= 1 && M >= 1 && N >= 1 && K >= 1, COCOS_ERR_INVALID,
@@ -214,7 +216,7 @@ extern "C" int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void*
     hipLaunchKernelGGL(hgemm_f16x3_kernel, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),
                        static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
                        static_cast<const _Float16*>(b_hi), static_cast<const _Float16*>(b_lo), c, M, N, K,
-                       host_scale, dev_scale, b_blocked);
+                       host_scale, dev_scale, dev_scale2, b_blocked);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

@@ -267,11 +267,11 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                   ds_scale.data_ptr(), B, K, Nq, Nk, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE, blocked, st)
             _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
                   dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 / SPLIT_OPERAND_SCALE,
-                  ds_scale.data_ptr(), blocked, st)
+                  ds_scale.data_ptr(), 0, blocked, st)
             if dv is not None:      # dv[c,j] = sum_i dout[c,i] P[i,j]
                 gch, gcl, _ = split_f16(dout, False, amax=g_amax)
                 _call("corr_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(),
-                      psl.data_ptr(), dv.data_ptr(), B, Cv, Nk, Nq, 1.0 / 16384.0, g_scale.data_ptr(), blocked, st)
+                      psl.data_ptr(), dv.data_ptr(), B, Cv, Nk, Nq, 1.0 / 16384.0, g_scale.data_ptr(), 0, blocked, st)
             return dqn, (dkn if need_k else None), dv, None, None, None
         ds_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if via_gemm else None
         if dqn is not None:
@@ -334,10 +334,18 @@ class _CorrMaterialize(torch.autograd.Function):
             raise ValueError(f"corr_materialize: shape mismatch qn{tuple(qn.shape)} kn{tuple(kn.shape)}")
         f = torch.empty((B, Nq, Nk), device=qn.device, dtype=torch.float32)
         ctx.amax = None
-        if PRECISION == "f16x3" and min(K * Nq, K * Nk) >= 4:      # split GEMM (sgemm_f16x3.hip)
+        if PRECISION == "f16x3" and min(K * Nq, K * Nk) >= 4:
             ctx.amax = (absmax(qn), absmax(kn))
-            _call("corr_materialize", "cocos_corr_materialize_f16x3", qn.data_ptr(), kn.data_ptr(), f.data_ptr(), B, K,
-                  Nq, Nk, float(scale), ctx.amax[0].data_ptr(), ctx.amax[1].data_ptr(), _stream())
+            if K % 8 == 0:
+                # both operands are k-major [K][positions]: the split GEMM would transpose them through 2-byte LDS
+                # writes; position-major planes + the planes GEMM do the same product in half the time
+                qh, ql, qs = split_f16(qn, True, amax=ctx.amax[0])
+                kh, kl, ks = split_f16(kn, True, amax=ctx.amax[1])
+                _call("corr_materialize", "cocos_hgemm_f16x3", qh.data_ptr(), ql.data_ptr(), kh.data_ptr(), kl.data_ptr(),
+                      f.data_ptr(), B, Nq, Nk, K, float(scale), qs.data_ptr(), ks.data_ptr(), 0, _stream())
+            else:                                                   # split GEMM (sgemm_f16x3.hip)
+                _call("corr_materialize", "cocos_corr_materialize_f16x3", qn.data_ptr(), kn.data_ptr(), f.data_ptr(), B,
+                      K, Nq, Nk, float(scale), ctx.amax[0].data_ptr(), ctx.amax[1].data_ptr(), _stream())
         else:
             _call("corr_materialize", "cocos_corr_materialize", qn.data_ptr(), kn.data_ptr(), f.data_ptr(), B, K, Nq,
                   Nk, float(scale), _stream())

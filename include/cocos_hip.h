@@ -123,7 +123,7 @@ int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void
  *       [128 keys][32 queries] halfs (8 KB each, contiguous) instead of row-major — the query kernel then writes
  *       each wave's 32x32 tile as 2 KB contiguous and the GEMM reads one contiguous block per k-step (needs
  *       Nk % 128 == 0, Nq % 32 == 0; both sides must agree).
- *   cocos_hgemm_f16x3: C[b][m][n] = host_scale / *dev_scale * sum_k A[b][m][k] B[b][n][k] on hi/lo planes
+ *   cocos_hgemm_f16x3: C[b][m][n] = host_scale / (*dev_scale * *dev_scale2) * sum_k A[b][m][k] B[b][n][k] on hi/lo planes
  *       (k contiguous, K % 8 == 0); the key side is  dkn = hgemm(A = planes of k_scale*qn [256][Nq],
  *       B = dS'' planes [Nk][Nq], host_scale = 1/k_scale, dev_scale = ds_scale_out_dev). */
 int cocos_split_f16_ex(const float* x, void* hi, void* lo, int B, int C, int N, int Cpad, int transpose,
@@ -138,7 +138,7 @@ int cocos_corr_softmax_warp_bwd_query_f16x3(
     int planes_blocked, cocos_stream_t stream);
 int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* c,
                       int batch, int M, int N, int K, float host_scale, const float* dev_scale /* nullable */,
-                      int b_blocked, cocos_stream_t stream);
+                      const float* dev_scale2 /* nullable */, int b_blocked, cocos_stream_t stream);
 
 /* Backward of K2 (autograd of :291-318), flash-style: the logits are recomputed from qn/kn and `lse`.
  *   dout [B,Cv,Nq] -> dqn [B,K,Nq], dkn [B,K,Nk], dv [B,Cv,Nk]

@@ -167,7 +167,7 @@ def test_hgemm_f16x3_matches_fp64(batch, M, N, K):
     c = torch.empty((batch, M, N), device=DEV, dtype=torch.float32)
     sc = torch.full((1,), 2.0, device=DEV)
     _lib.call("cocos_hgemm_f16x3", ah.data_ptr(), al.data_ptr(), bh.data_ptr(), bl.data_ptr(), c.data_ptr(), batch, M, N,
-              K, 0.25, sc.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+              K, 0.25, sc.data_ptr(), 0, 0, torch.cuda.current_stream().cuda_stream)
     ref = np.einsum("bmk,bnk->bmn", a, b)
     assert rel(c, ref) < 2e-6
     if N % 128 == 0 and K % 32 == 0:   # the tile-blocked B layout ([N/128][K/32] blocks of [128][32]) gives the same result
@@ -175,7 +175,7 @@ def test_hgemm_f16x3_matches_fp64(batch, M, N, K):
         bhb, blb = blk(bh), blk(bl)
         c2 = torch.empty_like(c)
         _lib.call("cocos_hgemm_f16x3", ah.data_ptr(), al.data_ptr(), bhb.data_ptr(), blb.data_ptr(), c2.data_ptr(), batch,
-                  M, N, K, 0.25, sc.data_ptr(), 1, torch.cuda.current_stream().cuda_stream)
+                  M, N, K, 0.25, sc.data_ptr(), 0, 1, torch.cuda.current_stream().cuda_stream)
         assert torch.equal(c, c2)
 
 

@@ -62,7 +62,7 @@ with torch.no_grad():
     print("bad fraction", bad.mean(), "bad rows (keys)", np.unique(np.where(bad)[1])[:40], "bad cols (queries)", np.unique(np.where(bad)[2])[:40])
     dkn = torch.empty_like(kn_t)
     _lib.call("cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(), dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, 256, Nk, Nq,
-              1.0 / 16.0, dsc.data_ptr(), 0, st)
+              1.0 / 16.0, dsc.data_ptr(), 0, 0, st)
     print("dk err (manual)", np.abs(dkn.double().cpu().numpy() - dk_ref).max())
     dk_from_rec = np.einsum("bki,bji->bkj", qn, rec)
     print("dk from reconstructed planes err", np.abs(dk_from_rec - dk_ref).max())
