@@ -34,6 +34,7 @@ HIP_SOURCES = [
     "sgemm_f16x3.hip",
     "box3_unfold.hip",
     "logits_softmax_warp.hip",
+    "logits_softmax_warp_f16x3.hip",
     "row_softmax.hip",
     "wta_scale.hip",
     "pono_spade.hip",

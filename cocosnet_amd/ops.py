@@ -570,8 +570,15 @@ class _LogitsSoftmaxWarp(torch.autograd.Function):
             raise ValueError(f"logits_softmax_warp: shape mismatch {tuple(logits_t.shape)} {tuple(v.shape)}")
         out = torch.empty((B, Cv, Nq), device=v.device, dtype=torch.float32)
         lse = torch.empty((B, Nq), device=v.device, dtype=torch.float32)
-        _call("logits_softmax_warp_fwd", "cocos_logits_softmax_warp_fwd", logits_t.data_ptr(), v.data_ptr(),
-              out.data_ptr(), lse.data_ptr(), B, Nq, Nk, Cv, _stream())
+        split = PRECISION == "f16x3" and Nk % 4 == 0 and Cv <= MAX_FUSED_CV and Nq * Nk * 4 < 2 ** 31 - 1
+        if split:      # P.V on the f16 MFMA (logits_softmax_warp_f16x3.hip)
+            vh, vl = split_f16(v, False, 1.0)
+            _call("logits_softmax_warp_fwd", "cocos_logits_softmax_warp_fwd_f16x3", logits_t.data_ptr(), vh.data_ptr(),
+                  vl.data_ptr(), out.data_ptr(), lse.data_ptr(), B, Nq, Nk, Cv, _stream())
+        else:
+            _call("logits_softmax_warp_fwd", "cocos_logits_softmax_warp_fwd", logits_t.data_ptr(), v.data_ptr(),
+                  out.data_ptr(), lse.data_ptr(), B, Nq, Nk, Cv, _stream())
+        ctx.split = split
         ctx.save_for_backward(logits_t, v, out, lse)
         return out
 
@@ -584,8 +591,16 @@ class _LogitsSoftmaxWarp(torch.autograd.Function):
         dlg = dv = None
         if ctx.needs_input_grad[0]:
             dlg = torch.empty_like(logits_t)
-            _call("logits_softmax_warp_bwd", "cocos_logits_softmax_warp_bwd", logits_t.data_ptr(), v.data_ptr(),
-                  out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dlg.data_ptr(), B, Nq, Nk, Cv, _stream())
+            if ctx.split:
+                cvp = (Cv + 31) // 32 * 32
+                gph, gpl, gs = split_f16(dout, True, cpad=cvp, amax=absmax(dout))
+                vph, vpl = split_f16(v, True, cpad=cvp)
+                _call("logits_softmax_warp_bwd", "cocos_logits_softmax_warp_bwd_f16x3", logits_t.data_ptr(),
+                      vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(), gs.data_ptr(), out.data_ptr(),
+                      dout.data_ptr(), lse.data_ptr(), dlg.data_ptr(), B, Nq, Nk, Cv, cvp, _stream())
+            else:
+                _call("logits_softmax_warp_bwd", "cocos_logits_softmax_warp_bwd", logits_t.data_ptr(), v.data_ptr(),
+                      out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dlg.data_ptr(), B, Nq, Nk, Cv, _stream())
         if ctx.needs_input_grad[1]:
             # dv[c,j] = sum_i P[i,j] dout[c,i] (cycle terms only): P^T is rebuilt once and contracted with
             # the K5 GEMM; exp() here is the only non-HIP arithmetic, on a path no README command trains

@@ -315,6 +315,17 @@ int cocos_pono_spade_bwd(const float* x, const float* gamma, const float* beta, 
 int cocos_upsample_nearest_fwd(const float* x, float* y, int planes, int h, int w, int scale, cocos_stream_t stream);
 int cocos_upsample_nearest_bwd(const float* dy, float* dx, int planes, int h, int w, int scale, cocos_stream_t stream);
 
+/* K7 on the f16 MFMA (same contract as cocos_logits_softmax_warp_fwd / _bwd; operand planes as for K2's split flavour):
+ *   fwd: vh,vl [B,Cv,Nk] channel-major planes of v; Nk % 4 == 0
+ *   bwd: vph,vpl [B,Nk,CvPad] and gph,gpl [B,Nq,CvPad] position-major planes of v and of (*g_scale_dev)*dout
+ *        (cocos_split_f16_ex), out/dout fp32 for D; writes dlogits_t fp32. */
+int cocos_logits_softmax_warp_fwd_f16x3(const float* logits_t, const void* vh, const void* vl, float* out, float* lse,
+                                        int B, int Nq, int Nk, int Cv, cocos_stream_t stream);
+int cocos_logits_softmax_warp_bwd_f16x3(const float* logits_t, const void* vph, const void* vpl, const void* gph,
+                                        const void* gpl, const float* g_scale_dev, const float* out, const float* dout,
+                                        const float* lse, float* dlogits_t, int B, int Nq, int Nk, int Cv, int CvPad,
+                                        cocos_stream_t stream);
+
 /* Debug: runs one v_mfma_f32_32x32x2_f32 with known operands and dumps the 64x16 accumulator
  * registers to out[64*16] so the host can verify the lane/register -> (row, col) map. */
 int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);

@@ -439,7 +439,7 @@ def test_box3_logits_equal_the_unfolded_formulation(B, h, w):
 
 @pytest.mark.parametrize("B,Nq,Nk,Cv", [(2, 64, 64, 3), (1, 1, 1, 1), (1, 129, 33, 5), (1, 200, 177, 154),
                                          (1, 2025, 300, 40), (2, 96, 256, 160)])
-def test_logits_softmax_warp_vs_oracle(B, Nq, Nk, Cv):
+def test_logits_softmax_warp_vs_oracle(B, Nq, Nk, Cv, precision):
     """K7: streamed softmax + warp from key-major logits, forward and both gradients."""
     from cocosnet_amd import ops
     rs = np.random.RandomState(Nq + 3 * Nk)
