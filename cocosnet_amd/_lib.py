@@ -102,6 +102,8 @@ _SIGNATURES = {
                                                            _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),
     "cocos_logits_softmax_warp_bwd_f16x3": (ctypes.c_int, [_c_float_p] + [ctypes.c_void_p] * 4 + [_c_float_p] * 5
                                             + [ctypes.c_int] * 5 + [_stream_t]),
+    "cocos_unfold3_stats_fwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_float] * 2 + [_stream_t]),
+    "cocos_unfold3_stats_bwd": (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float, _stream_t]),
     "cocos_debug_mfma_probe": (ctypes.c_int, [_c_float_p, _stream_t]),
 }
 

@@ -33,6 +33,7 @@ HIP_SOURCES = [
     "sgemm_mfma.hip",
     "sgemm_f16x3.hip",
     "box3_unfold.hip",
+    "unfold3_stats.hip",
     "logits_softmax_warp.hip",
     "logits_softmax_warp_f16x3.hip",
     "row_softmax.hip",

@@ -113,6 +113,8 @@ def _box_sum3(x):
 def _unfold3_stats(x_raw, k_unfolded):
     """mean and 1/(norm+eps) of the zero-padded 3x3-unfolded, centred vectors of x_raw [B,C,h,w]
     WITHOUT unfolding: box sums of the per-position channel sums / sums of squares (:276-280)."""
+    if x_raw.is_cuda and x_raw.dtype == torch.float32:
+        return ops.unfold3_stats(x_raw, k_unfolded)                  # K12: one pass over x, fwd and bwd
     s1 = x_raw.sum(dim=1, keepdim=True)
     s2 = (x_raw * x_raw).sum(dim=1, keepdim=True)
     mu = _box_sum3(s1) / k_unfolded

@@ -558,6 +558,44 @@ def box3_logits(c_raw, mu, nu, a, b, h, w, k_unfolded, scale):
 
 
 # ------------------------------------------------------------------------------------------
+# K12 statistics of the 3x3-unfolded vectors without unfolding   (correspondence.py:276-280, match_kernel 3)
+# ------------------------------------------------------------------------------------------
+class _Unfold3Stats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k_unfolded: float, eps: float):
+        x = _chk(x, "unfold3_stats: x")
+        B, C, h, w = x.shape
+        mk = lambda: torch.empty((B, h * w), device=x.device, dtype=torch.float32)
+        mu, a, nrm = mk(), mk(), mk()
+        ws = torch.empty(2 * B * h * w, device=x.device, dtype=torch.float32)
+        _call("unfold3_stats_fwd", "cocos_unfold3_stats_fwd", x.data_ptr(), mu.data_ptr(), a.data_ptr(), nrm.data_ptr(),
+              ws.data_ptr(), B, C, h, w, float(k_unfolded), float(eps), _stream())
+        ctx.save_for_backward(x, mu, a, nrm)
+        ctx.kc = float(k_unfolded)
+        ctx.mark_non_differentiable(nrm)
+        return mu, a, nrm
+
+    @staticmethod
+    def backward(ctx, dmu, da, _dnrm):
+        x, mu, a, nrm = ctx.saved_tensors
+        B, C, h, w = x.shape
+        dmu = None if dmu is None else _chk(dmu, "unfold3_stats: dmu")
+        da = None if da is None else _chk(da, "unfold3_stats: da")
+        dx = torch.empty_like(x)
+        ws = torch.empty(2 * B * h * w, device=x.device, dtype=torch.float32)
+        _call("unfold3_stats_bwd", "cocos_unfold3_stats_bwd", x.data_ptr(), mu.data_ptr(), a.data_ptr(), nrm.data_ptr(),
+              _ptr(dmu), _ptr(da), dx.data_ptr(), ws.data_ptr(), B, C, h, w, ctx.kc, _stream())
+        return dx, None, None
+
+
+def unfold3_stats(x, k_unfolded: float, eps: float = NORM_EPS):
+    """(mu, a) [B,h*w] of the zero-padded 3x3-unfolded, centred vectors of x [B,C,h,w]: mean over the 9*C entries and
+    1 / (L2 norm of the centred vector + eps)."""
+    mu, a, _ = _Unfold3Stats.apply(x, k_unfolded, eps)
+    return mu, a
+
+
+# ------------------------------------------------------------------------------------------
 # K7  softmax + warp from materialised key-major logits   (correspondence.py:307 + :318 ...)
 # ------------------------------------------------------------------------------------------
 class _LogitsSoftmaxWarp(torch.autograd.Function):

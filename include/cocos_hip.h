@@ -326,6 +326,19 @@ int cocos_logits_softmax_warp_bwd_f16x3(const float* logits_t, const void* vph, 
                                         const float* lse, float* dlogits_t, int B, int Nq, int Nk, int Cv, int CvPad,
                                         cocos_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * K12 statistics of the zero-padded 3x3-unfolded, centred feature vectors without unfolding (match_kernel 3 with
+ *     PONO_C: correspondence.py:276-280 / :286-289), feeding K6:
+ *   fwd: x [B,C,h,w] -> mu[b,p] = mean of the 9*C unfolded entries at p, nrm[b,p] = ||U_p - mu||_2,
+ *        a[b,p] = 1/(nrm + eps);  k_unfolded = 9*C;  ws: 2*B*h*w floats of scratch
+ *   bwd: dmu, da (either may be NULL) -> dx [B,C,h,w] (written, not accumulated);  ws: 2*B*h*w floats
+ * ------------------------------------------------------------------------------------- */
+int cocos_unfold3_stats_fwd(const float* x, float* mu, float* a, float* nrm, float* ws,
+                            int B, int C, int h, int w, float k_unfolded, float eps, cocos_stream_t stream);
+int cocos_unfold3_stats_bwd(const float* x, const float* mu, const float* a, const float* nrm,
+                            const float* dmu, const float* da, float* dx, float* ws,
+                            int B, int C, int h, int w, float k_unfolded, cocos_stream_t stream);
+
 /* Debug: runs one v_mfma_f32_32x32x2_f32 with known operands and dumps the 64x16 accumulator
  * registers to out[64*16] so the host can verify the lane/register -> (row, col) map. */
 int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);

@@ -577,3 +577,26 @@ def test_upsample_nearest_matches_torch(B, C, h, w, d):
     y2.backward(g)
     assert torch.equal(y, y2)
     assert rel(x.grad, x2.grad.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("B,C,h,w", [(2, 256, 8, 8), (1, 5, 3, 7), (1, 256, 64, 64), (2, 16, 1, 1)])
+def test_unfold3_stats_match_unfolded_reference(B, C, h, w):
+    """K12 vs the reference's own formulation (correspondence.py:276-280 with PONO_C): F.unfold(k=3, padding=1),
+    centre over the 9*C entries, L2 norm — in torch fp64 with autograd."""
+    import sys
+    import torch.nn.functional as F
+    from cocosnet_amd import ops
+    rs = np.random.RandomState(C * h + w)
+    x = rs.standard_normal((B, C, h, w))
+    gm, ga = rs.standard_normal((B, h * w)), rs.standard_normal((B, h * w))
+    x64 = torch.from_numpy(x).requires_grad_(True)
+    U = F.unfold(x64, kernel_size=3, padding=1)                    # [B, 9C, hw]
+    mu_ref = U.mean(dim=1)
+    a_ref = 1.0 / (torch.norm(U - mu_ref[:, None, :], 2, 1) + sys.float_info.epsilon)
+    (mu_ref * torch.from_numpy(gm) + a_ref * torch.from_numpy(ga)).sum().backward()
+    xd = dev(x, True)
+    mu, a = ops.unfold3_stats(xd, float(9 * C))
+    (mu * dev(gm) + a * dev(ga)).sum().backward()
+    assert rel(mu, mu_ref.detach().numpy()) < 1e-5
+    assert rel(a, a_ref.detach().numpy()) < 1e-4
+    assert rel(xd.grad, x64.grad.numpy()) < 1e-4
