@@ -36,7 +36,7 @@ __global__ void mfma_probe_kernel(float* out) {
 
 }  // namespace cocos
 
-extern "C" int cocos_version(void) { return 210; /* 0.2.1: + K0 proj1x1 (split-K weight gradient), K6 box3 logits, K7 logits_softmax_warp */ }
+extern "C" int cocos_version(void) { return 300; /* 0.3.0: split-precision (f16x3) flavour of K2, K3, K7, K0; operand planes; K8-K12 */ }
 
 extern "C" const char* cocos_last_error_string(void) { return cocos::last_error().c_str(); }
 
