@@ -600,3 +600,38 @@ def test_unfold3_stats_match_unfolded_reference(B, C, h, w):
     assert rel(mu, mu_ref.detach().numpy()) < 1e-5
     assert rel(a, a_ref.detach().numpy()) < 1e-4
     assert rel(xd.grad, x64.grad.numpy()) < 1e-4
+
+
+def _random_split_shapes():
+    rs = np.random.RandomState(2024)
+    shapes = []
+    for _ in range(14):
+        nq = int(rs.choice([8, 24, 32, 64, 96, 128, 136, 256, 264, 384]))
+        nk = int(rs.choice([8, 32, 40, 128, 160, 256, 384, 392]))
+        cv = int(rs.choice([1, 3, 17, 32, 33, 64, 100, 154, 160]))
+        shapes.append((int(rs.randint(1, 3)), nq, nk, cv, bool(rs.randint(0, 2)), bool(rs.randint(0, 2))))
+    return shapes
+
+
+@pytest.mark.parametrize("B,Nq,Nk,Cv,peaked,with_dv", _random_split_shapes())
+def test_split_flavour_agrees_with_fp32_flavour(B, Nq, Nk, Cv, peaked, with_dv, monkeypatch):
+    """Randomised shapes (multiples of 8: the split backward's domain; some hit the tile-blocked plane layout, some the
+    ragged-tile variants): the f16x3 flavour and the exact-fp32-MFMA flavour give the same outputs and gradients."""
+    from cocosnet_amd import ops
+    qn, kn, v = _qkv(B, Nq, Nk, Cv, seed=Nq + 3 * Nk + Cv, peaked=peaked)
+    g = np.random.RandomState(Cv).standard_normal((B, Cv, Nq)) * 0.05
+    res = {}
+    for prec in ("fp32", "f16x3"):
+        monkeypatch.setattr(ops, "PRECISION", prec)
+        q, k, vv = dev(qn, True), dev(kn, True), dev(v, with_dv)
+        out = ops.corr_softmax_warp(q, k, vv, 100.0)
+        out.backward(dev(g))
+        res[prec] = (out.detach(), q.grad, k.grad, vv.grad if with_dv else None)
+    a, b = res["fp32"], res["f16x3"]
+    assert rel(b[0], a[0].cpu().numpy()) < 2e-5
+    # floor: where P is peaked the true gradient is ~0 by cancellation and what each flavour returns is its own
+    # rounding residue (1e-6..1e-5 absolute here); diffuse rows have O(1) gradients
+    assert rel(b[1], a[1].cpu().numpy(), floor=0.1) < OUT_TOL
+    assert rel(b[2], a[2].cpu().numpy(), floor=0.1) < OUT_TOL
+    if with_dv:
+        assert rel(b[3], a[3].cpu().numpy(), floor=0.005) < OUT_TOL
