@@ -56,6 +56,13 @@ __device__ __forceinline__ u32x2 buf_load_u2(__amdgpu_buffer_rsrc_t r, unsigned 
     return __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
 }
 
+__device__ __forceinline__ u32x4 buf_load_u4s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, (int)soff, 0);
+}
+__device__ __forceinline__ u32x2 buf_load_u2s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, (int)soff, 0);
+}
+
 // p (>= 0, <= 2^8) -> f16 hi (round toward zero, so lo >= 0) and f16 lo, two values per instruction
 __device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& lo) {
     hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
@@ -177,6 +184,24 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
         }
     };
 
+    // Tile-invariant parts of the staging addresses (computed once); the tile-dependent part travels in the
+    // scalar offset of the buffer instruction — non-ragged key counts only: the scalar offset is not bounds-
+    // checked, so look-ahead tiles past the end are clamped to the last tile instead
+    unsigned k_voff[4], v_voff[CVB];
+    int k_lds[4], v_lds[CVB];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int g = u * 256 + tid, key = g >> 5, cc = g & 31;
+        k_voff[u] = (unsigned)(key * SP_KD + cc * 8) * 2u;
+        k_lds[u] = key * SP_KROW + cc * 8;
+    }
+#pragma unroll
+    for (int u = 0; u < CVB; ++u) {
+        const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
+        v_voff[u] = row < Cv ? (unsigned)(row * Nk + 4 * kq) * 2u : kBufOob;
+        v_lds[u] = row * SP_VROW + 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);
+    }
+
     const int ntiles = (Nk + SP_BK - 1) / SP_BK;
     fetch_k(0);
     fetch_v(0);
@@ -222,6 +247,19 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
             _Float16* const vw = vt + (buf ^ 1) * 2 * VPLANE;
             const int jn = j0 + 2 * SP_BK;
             auto piece = [&](int i) {
+                if (!RAGGED) {
+                    const int jc = min(jn, Nk - SP_BK);       // look-ahead past the end re-reads the last tile
+                    if (i < 8) {
+                        const int pl_ = i & 1, u = i >> 1;
+                        *reinterpret_cast<u32x4*>(kw + pl_ * KPLANE + k_lds[u]) = kst[pl_][u];
+                        kst[pl_][u] = buf_load_u4s(pl_ ? kl_rs : kh_rs, k_voff[u], (unsigned)jc * (unsigned)(SP_KD * 2));
+                    } else if (i - 8 < 2 * CVB) {
+                        const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
+                        *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + v_lds[u]) = vst[pl_][u];
+                        vst[pl_][u] = buf_load_u2s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jc * 2u);
+                    }
+                    return;
+                }
                 if (i < 8) {                                  // K pieces: plane i&1, chunk i>>1
                     const int pl_ = i & 1, u = i >> 1;
                     const int g = u * 256 + tid, key = g >> 5, cc = g & 31;
