@@ -39,6 +39,7 @@ HIP_SOURCES = [
     "row_softmax.hip",
     "wta_scale.hip",
     "pono_spade.hip",
+    "instnorm_prelu.hip",
     "upsample_nearest.hip",
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",

@@ -766,6 +766,53 @@ def upsample_nearest(x, scale: int):
     return _UpsampleNearest.apply(x, scale)
 
 
+# ------------------------------------------------------------------------------------------
+# K13 InstanceNorm (+ residual) + PReLU of the ResidualBlocks   (correspondence.py:13-36)
+# ------------------------------------------------------------------------------------------
+INSTNORM_EPS = 1e-5   # nn.InstanceNorm2d default
+
+
+class _InstNormPReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, weight, eps: float):
+        x = _chk(x, "instnorm_prelu: x")
+        res = None if residual is None else _chk(residual, "instnorm_prelu: residual")
+        w = _chk(weight, "instnorm_prelu: weight")
+        if w.numel() != 1:
+            raise ValueError("instnorm_prelu: nn.PReLU() with a single parameter expected")
+        if res is not None and res.shape != x.shape:
+            raise ValueError(f"instnorm_prelu: residual {tuple(res.shape)} vs x {tuple(x.shape)}")
+        B, C = x.shape[:2]
+        N = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        _call("instnorm_prelu_fwd", "cocos_instnorm_prelu_fwd", x.data_ptr(), _ptr(res), w.data_ptr(), y.data_ptr(),
+              B * C, N, float(eps), _stream())
+        ctx.save_for_backward(x, res, w)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, w = ctx.saved_tensors
+        dy = _chk(dy, "instnorm_prelu: dy")
+        B, C = x.shape[:2]
+        N = x.numel() // (B * C)
+        need_x, need_r, need_w = ctx.needs_input_grad[:3]
+        dx = torch.empty_like(x) if need_x else None
+        dr = torch.empty_like(x) if (need_r and res is not None) else None
+        dap = torch.empty(B * C, device=x.device, dtype=torch.float32) if need_w else None
+        _call("instnorm_prelu_bwd", "cocos_instnorm_prelu_bwd", x.data_ptr(), _ptr(res), w.data_ptr(), dy.data_ptr(),
+              _ptr(dx), _ptr(dr), _ptr(dap), B * C, N, ctx.eps, _stream())
+        dw = dap.sum().reshape(w.shape) if need_w else None
+        return dx, dr, dw, None
+
+
+def instnorm_prelu(x, residual, weight, eps: float = INSTNORM_EPS):
+    """prelu(InstanceNorm2d(x) [+ residual], weight) for x [B,C,h,w]: nn.InstanceNorm2d(affine=False) statistics per
+    (sample, channel) plane, nn.PReLU() with one parameter."""
+    return _InstNormPReLU.apply(x, residual, weight, eps)
+
+
 def mfma_probe() -> torch.Tensor:
     """Debug: the 64x16 accumulator image of one v_mfma_f32_32x32x2_f32 (see api_common.hip)."""
     out = torch.empty((64, 16), device="cuda", dtype=torch.float32)

@@ -249,6 +249,10 @@ class ResidualBlock(nn.Module):
         self.bn2 = nn.InstanceNorm2d(out_channels)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32:
+            from . import ops            # K13: InstanceNorm (+ skip) + PReLU in one HBM pass each
+            y = ops.instnorm_prelu(self.conv1(self.padding1(x)), None, self.prelu.weight, self.bn1.eps)
+            return ops.instnorm_prelu(self.conv2(self.padding2(y)), x, self.prelu.weight, self.bn2.eps)
         y = self.prelu(self.bn1(self.conv1(self.padding1(x))))
         y = self.bn2(self.conv2(self.padding2(y)))
         return self.prelu(y + x)

@@ -339,6 +339,19 @@ int cocos_unfold3_stats_bwd(const float* x, const float* mu, const float* a, con
                             const float* dmu, const float* da, float* dx, float* ws,
                             int B, int C, int h, int w, float k_unfolded, cocos_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * K13 InstanceNorm2d(affine=False) (+ residual) + PReLU of the ResidualBlocks in front of theta/phi
+ *     (correspondence.py:13-36: `prelu(bn1(conv1(..)))` at :29 and `prelu(bn2(conv2(..)) + x)` at :31-33):
+ *   x, residual (nullable), y: [planes, N] with planes = B*C, N = h*w;  prelu_weight: 1 float (nn.PReLU())
+ *   fwd: z = (x - mean)/sqrt(biased var + eps) (+ residual);  y = z > 0 ? z : a*z
+ *   bwd: dx, dresidual (nullable, = dz), da_partials [planes] (nullable; the caller sums them)
+ * ------------------------------------------------------------------------------------- */
+int cocos_instnorm_prelu_fwd(const float* x, const float* residual, const float* prelu_weight, float* y,
+                             int planes, int N, float eps, cocos_stream_t stream);
+int cocos_instnorm_prelu_bwd(const float* x, const float* residual, const float* prelu_weight, const float* dy,
+                             float* dx, float* dresidual, float* da_partials, int planes, int N, float eps,
+                             cocos_stream_t stream);
+
 /* Debug: runs one v_mfma_f32_32x32x2_f32 with known operands and dumps the 64x16 accumulator
  * registers to out[64*16] so the host can verify the lane/register -> (row, col) map. */
 int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);

@@ -635,3 +635,26 @@ def test_split_flavour_agrees_with_fp32_flavour(B, Nq, Nk, Cv, peaked, with_dv, 
     assert rel(b[2], a[2].cpu().numpy(), floor=0.1) < OUT_TOL
     if with_dv:
         assert rel(b[3], a[3].cpu().numpy(), floor=0.005) < OUT_TOL
+
+
+@pytest.mark.parametrize("B,C,h,w,with_res", [(2, 407, 16, 16, True), (1, 5, 7, 3, False), (2, 8, 64, 64, True),
+                                              (1, 3, 130, 130, True), (1, 2, 1, 2, False)])
+def test_instnorm_prelu_equals_torch_chain(B, C, h, w, with_res):
+    """K13 vs nn.InstanceNorm2d -> (+ skip) -> nn.PReLU() (ResidualBlock, correspondence.py:13-36) in torch fp64."""
+    import torch.nn.functional as F
+    from cocosnet_amd import ops
+    rs = np.random.RandomState(C + h)
+    x, r, g = (rs.standard_normal((B, C, h, w)) for _ in range(3))
+    a = np.array([0.25])
+    x64, r64, a64 = (torch.from_numpy(t).requires_grad_(True) for t in (x, r, a))
+    z = F.instance_norm(x64, eps=1e-5) + (r64 if with_res else 0.0)
+    y_ref = F.prelu(z, a64)
+    y_ref.backward(torch.from_numpy(g))
+    xd, rd, ad = dev(x, True), dev(r, True), dev(a, True)
+    y = ops.instnorm_prelu(xd, rd if with_res else None, ad)
+    y.backward(dev(g))
+    assert rel(y, y_ref.detach().numpy()) < 1e-5
+    assert rel(xd.grad, x64.grad.numpy(), floor=0.05) < 5e-5
+    assert rel(ad.grad, a64.grad.numpy(), floor=1.0) < 5e-5
+    if with_res:
+        assert rel(rd.grad, r64.grad.numpy()) < 1e-5
