@@ -145,7 +145,8 @@ def main():
                          "or the package default): fp32 = v_mfma_f32_32x32x2_f32, f16x3 = 3-term split on "
                          "v_mfma_f32_32x32x16_f16 (fp32-class accuracy)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=6)
+    ap.add_argument("--cpu-images", type=int, default=20,
+                    help="size of the bounded CPU-baseline sample (about 10 s of wall time on the GPU box host)")
     args = ap.parse_args()
 
     from cocosnet_amd import dist as cdist
