@@ -75,7 +75,7 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     srcs = [os.path.join(CSRC_DIR, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(CSRC_DIR, "common.h"),
                    os.path.join(REPO_DIR, "include", "cocos_hip.h")]
-    stamp = os.path.join(OBJ_DIR, "build.sha256")
+    stamp = LIB_PATH + ".sha256"      # next to the library: it travels with it (obj/ does not have to)
     want = _digest(deps)
     if (not force and os.path.exists(LIB_PATH) and os.path.exists(stamp)
             and open(stamp).read().strip() == want):
