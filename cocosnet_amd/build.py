@@ -32,6 +32,7 @@ HIP_SOURCES = [
     "corr_fused_bwd_saved.hip",
     "sgemm_mfma.hip",
     "sgemm_f16x3.hip",
+    "proj_stream_f16x3.hip",
     "box3_unfold.hip",
     "unfold3_stats.hip",
     "logits_softmax_warp.hip",

@@ -33,6 +33,9 @@ PRECISION = os.environ.get("COCOS_PRECISION", "f16x3")
 #: shapes (K = 256..407: 8-13 k-steps, a 33 MB output written in one burst) it gains less than the K2 kernels
 #: do and pays for the max|x| passes, but is ahead end to end (0.40 + 0.1 vs 0.51 ms per step).
 PROJ_PRECISION = os.environ.get("COCOS_PROJ_PRECISION", "f16x3")
+#: K0 at the reference's own shape (256 -> 256 channels, HW % 64 == 0): y = W x and dx = W^T dy on the streaming
+#: kernel (proj_stream_f16x3.hip: weight planes resident in the accumulator file, x / y touched once)
+PROJ_STREAM = os.environ.get("COCOS_PROJ_STREAM", "1") != "0"
 #: power-of-two pre-scale of the unit-norm operands before the f16 split (keeps the lo plane normal)
 SPLIT_OPERAND_SCALE = 16.0
 
@@ -469,15 +472,28 @@ class _Proj1x1(torch.autograd.Function):
         bb = None if bias is None else _chk(bias, "proj1x1: bias")
         y = torch.empty((B, Cout, h, w), device=x.device, dtype=torch.float32)
         split = PROJ_PRECISION == "f16x3" and min(Cin * Cout, Cin * h * w, Cout * h * w) >= 4
+        # the reference's shapes (<= 416 input channels, grid a multiple of 64 positions): weight planes resident in
+        # the accumulator file, x and y streamed once (proj_stream_f16x3.hip)
+        lib = _lib.load()
+        stream = (split and PROJ_STREAM and (h * w) % 64 == 0 and lib.cocos_proj1x1_stream_kpad(Cin) != 0
+                  and lib.cocos_proj1x1_stream_kpad(Cout) != 0)
         if split:      # products on the f16 MFMA, operands split on the fly (sgemm_f16x3.hip)
             xa, wa = absmax(x), absmax(w2)
-            _call("proj1x1_fwd", "cocos_proj1x1_fwd_f16x3", x.data_ptr(), w2.data_ptr(), _ptr(bb), y.data_ptr(), B,
-                  Cin, Cout, h * w, xa.data_ptr(), wa.data_ptr(), _stream())
+            if stream:
+                # A = W as planes [Cout][Kpad]: the split kernel transposes, so it is fed W^T (100 K elements)
+                wh, wl, ws = split_f16(w2.t().contiguous().unsqueeze(0), transpose=True,
+                                       cpad=lib.cocos_proj1x1_stream_kpad(Cin), amax=wa)
+                _call("proj1x1_fwd", "cocos_proj1x1_stream_f16x3", x.data_ptr(), wh.data_ptr(), wl.data_ptr(),
+                      ws.data_ptr(), _ptr(bb), y.data_ptr(), B, Cin, Cout, h * w, xa.data_ptr(), _stream())
+            else:
+                _call("proj1x1_fwd", "cocos_proj1x1_fwd_f16x3", x.data_ptr(), w2.data_ptr(), _ptr(bb), y.data_ptr(),
+                      B, Cin, Cout, h * w, xa.data_ptr(), wa.data_ptr(), _stream())
             ctx.amax = (xa, wa)
         else:
             _call("proj1x1_fwd", "cocos_proj1x1_fwd", x.data_ptr(), w2.data_ptr(), _ptr(bb), y.data_ptr(), B, Cin,
                   Cout, h * w, _stream())
         ctx.split = split
+        ctx.stream = stream
         ctx.save_for_backward(x, w2)
         ctx.wshape = tuple(weight.shape)
         ctx.has_bias = bias is not None
@@ -499,8 +515,17 @@ class _Proj1x1(torch.autograd.Function):
         if ctx.split:
             xa, wa = ctx.amax
             ga = absmax(dy)
-            _call("proj1x1_bwd", "cocos_proj1x1_bwd_f16x3", x.data_ptr(), w2.data_ptr(), dy.data_ptr(), _ptr(dx),
-                  _ptr(dwb), B, Cin, Cout, h * w, xa.data_ptr(), wa.data_ptr(), ga.data_ptr(), _stream())
+            dx_gemm = dx
+            if ctx.stream and need_x:     # dx = W^T dy, same streaming kernel with the transposed weight planes
+                th, tl, ts = split_f16(w2.unsqueeze(0), transpose=True,
+                                       cpad=_lib.load().cocos_proj1x1_stream_kpad(Cout), amax=wa)
+                _call("proj1x1_bwd", "cocos_proj1x1_stream_f16x3", dy.data_ptr(), th.data_ptr(), tl.data_ptr(),
+                      ts.data_ptr(), None, dx.data_ptr(), B, Cout, Cin, h * w, ga.data_ptr(), _stream())
+                dx_gemm = None
+            if dx_gemm is not None or dwb is not None:
+                _call("proj1x1_bwd", "cocos_proj1x1_bwd_f16x3", x.data_ptr(), w2.data_ptr(), dy.data_ptr(),
+                      _ptr(dx_gemm), _ptr(dwb), B, Cin, Cout, h * w, xa.data_ptr(), wa.data_ptr(), ga.data_ptr(),
+                      _stream())
         else:
             _call("proj1x1_bwd", "cocos_proj1x1_bwd", x.data_ptr(), w2.data_ptr(), dy.data_ptr(), _ptr(dx),
                   _ptr(dwb), B, Cin, Cout, h * w, _stream())

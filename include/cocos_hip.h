@@ -245,6 +245,17 @@ int cocos_corr_materialize_bwd_f16x3(const float* qn, const float* kn, const flo
 int cocos_proj1x1_bwd_f16x3(const float* x, const float* w, const float* dy, float* dx, float* dw_p,
                             int B, int Cin, int Cout, int N, const float* x_amax, const float* w_amax,
                             const float* dy_amax, cocos_stream_t stream);
+/* K0 streaming form (correspondence.py:272,:282 at the reference's shapes: 256 or 256+151 channels -> 256):
+ *     y[b,m,n] = (sum_k A[m,k] x[b,k,n]) / (*a_scale_dev * x_scale) + bias[m]
+ * A = the weight (forward) or its transpose (input gradient) as f16 hi/lo planes [M][Kpad], zero beyond K, from
+ * cocos_split_f16_ex(transpose = 1, Cpad = Kpad) of the k-major matrix [K][M] (its scale goes to a_scale_dev);
+ * Kpad = cocos_proj1x1_stream_kpad(K) (0: K not supported).  x fp32 [B,K,N] is split in flight with the
+ * power-of-two scale from x_amax (NULL = 1).  A stays in registers, x and y are touched once (HBM-bound).
+ * COCOS_ERR_UNSUPPORTED unless K <= 416 and N % 64 == 0 (callers then use cocos_proj1x1_fwd_f16x3 / _bwd_f16x3). */
+int cocos_proj1x1_stream_kpad(int K);
+int cocos_proj1x1_stream_f16x3(const float* x, const void* a_hi, const void* a_lo, const float* a_scale_dev,
+                               const float* bias, float* y, int B, int K, int M, int N, const float* x_amax,
+                               cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K6  match_kernel = 3 without unfolding (correspondence.py:276-280,:286-289 + :291 + :304, PONO_C):

@@ -461,9 +461,12 @@ def test_logits_softmax_warp_vs_oracle(B, Nq, Nk, Cv, precision):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,h,w", [(2, 407, 256, 8, 8), (1, 5, 3, 3, 7), (2, 271, 256, 16, 9),
-                                             (2, 407, 256, 64, 64), (1, 130, 70, 23, 29), (1, 1, 1, 1, 1)])
+                                             (2, 407, 256, 64, 64), (1, 130, 70, 23, 29), (1, 1, 1, 1, 1),
+                                             (3, 256, 256, 16, 16), (1, 64, 96, 8, 8), (2, 300, 407, 8, 16),
+                                             (5, 416, 130, 8, 24), (1, 3, 2, 8, 8)])
 def test_proj1x1_equals_conv2d(B, Cin, Cout, h, w, precision):
-    """K0: theta/phi 1x1 convolutions (:272,:282) on the fp32-MFMA GEMM vs torch's fp64 conv2d."""
+    """K0: theta/phi 1x1 convolutions (:272,:282) vs torch's fp64 conv2d — the fp32-MFMA GEMM, the split GEMM and
+    (grids that are a multiple of 64 positions, <= 416 channels) the streaming kernel with register-resident weights."""
     import torch.nn.functional as F
     from cocosnet_amd import ops
     rs = np.random.RandomState(Cin)
@@ -479,6 +482,26 @@ def test_proj1x1_equals_conv2d(B, Cin, Cout, h, w, precision):
     assert rel(xd.grad, x64.grad.numpy()) < 1e-5
     assert rel(wd.grad, w64.grad.numpy()) < 1e-5
     assert rel(bd.grad, b64.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("B,Cin,Cout,h,w", [(2, 407, 256, 16, 16), (9, 256, 256, 8, 8)])
+def test_proj1x1_streaming_and_gemm_forms_agree(B, Cin, Cout, h, w, monkeypatch):
+    """The streaming K0 kernel and the general split GEMM are the same arithmetic (f16 hi/lo, 3 MFMA terms): their
+    results agree to fp32 rounding of the accumulation order, for tiles that wrap over images and ragged K."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PROJ_PRECISION", "f16x3")
+    rs = np.random.RandomState(B + Cin)
+    x, wt, b = rs.standard_normal((B, Cin, h, w)) * 37.0, rs.standard_normal((Cout, Cin, 1, 1)) * 1e-3, rs.standard_normal(Cout)
+    g = rs.standard_normal((B, Cout, h, w)) * 1e-4
+    res = []
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "PROJ_STREAM", flag)
+        xd, wd, bd = dev(x, True), dev(wt, True), dev(b, True)
+        y = ops.proj1x1(xd, wd, bd)
+        y.backward(dev(g))
+        res.append((y.detach().cpu().numpy(), xd.grad.cpu().numpy(), wd.grad.cpu().numpy()))
+    for a, c in zip(*res):
+        assert rel(a, c) < 2e-6
 
 
 @pytest.mark.parametrize("rows,cols", [(7, 4096), (3, 100), (2, 1), (5, 333), (1, 16384)])
