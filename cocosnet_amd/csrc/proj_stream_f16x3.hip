@@ -133,26 +133,47 @@ __global__ __launch_bounds__(256, 1) void proj_stream_f16x3_kernel(
     }
 
     // ---- A: this wave's 32*RB rows of both planes [M][KP], resident in the accumulator file ------------------
+    // A fragment load straight from memory takes 16 bytes from each of 64 different rows: with 26-32 KB of rows
+    // per wave and plane the 128-byte lines are evicted from L1 before their other seven pieces are asked for
+    // (up to 8x over-fetch from L2).  The wave's rows are one contiguous
+    // slab instead: it is read in whole lines, parked in the (still unused) x buffers — rows padded like the x
+    // rows, which makes the fragment reads conflict-free — and picked up from there, one plane after the other.
     f16x8 ah[RB][KS], al[RB][KS];
     {
-        const __amdgpu_buffer_rsrc_t ah_rs = make_rsrc(a_hi, (size_t)M * KP * 2), al_rs = make_rsrc(a_lo, (size_t)M * KP * 2);
+        constexpr int CPR = KP / 8;                              // 16-byte chunks per row
+        constexpr int NCH = 32 * RB * CPR / 64;                  // chunks per lane
+        static_assert(32 * RB * CPR % 64 == 0, "slab must divide among the lanes");
+        static_assert(4 * 32 * RB * XROW <= 2 * 2 * PLANE, "the four slabs must fit into the x buffers");
+        _Float16* const slab = xt + wave * 32 * RB * XROW;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int pl = 0; pl < 2; ++pl) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(pl ? a_lo : a_hi, (size_t)M * KP * 2);
+            u32x4 v[NCH];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int row = m_wave + rb * 32 + c;
-                const unsigned off = row < M ? (unsigned)(row * KP + ks * 16 + h * 8) * 2u : kBufOob;
-                ah[rb][ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(ah_rs, (int)off, 0, 0));
-                al[rb][ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(al_rs, (int)off, 0, 0));
+            for (int i = 0; i < NCH; ++i)
+                v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((unsigned)m_wave * CPR + lane + 64 * i) * 16u), 0, 0);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int q = lane + 64 * i;
+                *reinterpret_cast<u32x4*>(slab + (q / CPR) * XROW + (q % CPR) * 8) = v[i];
             }
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                asm volatile("" : "+a"(ah[rb][ks]));
-                asm volatile("" : "+a"(al[rb][ks]));
-            }
+                for (int ks = 0; ks < KS; ++ks) {
+                    const f16x8 f = *reinterpret_cast<const f16x8*>(slab + (rb * 32 + c) * XROW + ks * 16 + h * 8);
+                    if (pl) al[rb][ks] = f; else ah[rb][ks] = f;
+                }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (pl) asm volatile("" : "+a"(al[rb][ks]));
+                    else    asm volatile("" : "+a"(ah[rb][ks]));
+                }
+        }
     }
+    __syncthreads();                                             // slabs consumed: the buffers now belong to x
     if (tid < 128 * RB) {
         const int m = blockIdx.y * 128 * RB + tid;
         bias_s[tid] = (bias && m < M) ? bias[m] : 0.f;
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void proj_stream_f16x3_kernel(
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
-        constexpr int RA = 3;
+        constexpr int RA = 3;                        // operand read-ahead in k steps (deeper: measured neutral)
         f16x8 bh[RA], bl[RA];
 #pragma unroll
         for (int s = 0; s < RA - 1; ++s) {

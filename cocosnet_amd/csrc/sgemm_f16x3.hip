@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_f16x3_kernel(const float* __rest
                                                              float scale, const float* __restrict__ row_bias,
                                                              int ksplit, int kchunk,
                                                              const float* __restrict__ a_amax,
-                                                             const float* __restrict__ b_amax) {
+                                                             const float* __restrict__ b_amax, int gx, int gy) {
     constexpr int APLANE = XG_BM * XG_ROW, BPLANE = XG_BN * XG_ROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][256][ROW]
@@ -172,9 +172,14 @@ __global__ __launch_bounds__(256, 1) void sgemm_f16x3_kernel(const float* __rest
     const int lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.z / ksplit;
-    const int kbeg = (blockIdx.z % ksplit) * kchunk, kend = min(K, kbeg + kchunk);
-    const int m0 = blockIdx.y * XG_BM, n0 = blockIdx.x * XG_BN;
+    // 1-D grid, XCD-aware: consecutive virtual ids (the column tiles that share one A row tile, then the row
+    // tiles that share the batch item / k slice) run on the same XCD and meet in its L2 — with the hardware's
+    // round-robin placement every XCD fetched the shared operand from HBM for itself (dw of K0: dy read 4 times)
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = vb % gx, by = (vb / gx) % gy, bz = vb / (gx * gy);
+    const int b = bz / ksplit;
+    const int kbeg = (bz % ksplit) * kchunk, kend = min(K, kbeg + kchunk);
+    const int m0 = by * XG_BM, n0 = bx * XG_BN;
 
     const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(A + (size_t)b * strideA, (size_t)M * K * 4);
     const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(Bm + (size_t)b * strideB, (size_t)N * K * 4);
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void sgemm_f16x3_kernel(const float* __rest
     XPH_T(xp2);
 
     const float oscale = scale / (sa * sb);
-    float* Cb = C + (size_t)blockIdx.z * strideC;
+    float* Cb = C + (size_t)bz * strideC;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -304,16 +309,16 @@ static int launch_gemm_f16x3(const float* A, const float* Bm, float* C, int batc
     COCOS_REQUIRE((long long)M * K >= 4 && (long long)N * K >= 4, COCOS_ERR_UNSUPPORTED,
                   "sgemm_f16x3: operands with fewer than 4 elements are not supported (M=%d N=%d K=%d): use the "
                   "fp32 entry point", M, N, K);
-    COCOS_REQUIRE((long long)batch * ksplit <= 65535 && (M + XG_BM - 1) / XG_BM <= 65535, COCOS_ERR_UNSUPPORTED,
-                  "sgemm_f16x3: grid too large");
+    const long long gx = (N + XG_BN - 1) / XG_BN, gy = (M + XG_BM - 1) / XG_BM, gz = (long long)batch * ksplit;
+    COCOS_REQUIRE(gx * gy * gz <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "sgemm_f16x3: grid too large");
     auto kern = sgemm_f16x3_kernel<A_KC, B_KC>;
     const size_t smem = (size_t)2 * 2 * (XG_BM + XG_BN) * XG_ROW * sizeof(_Float16);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int kchunk = ((K + ksplit - 1) / ksplit + XG_BK - 1) / XG_BK * XG_BK;
-    const dim3 grid((N + XG_BN - 1) / XG_BN, (M + XG_BM - 1) / XG_BM, batch * ksplit);
+    const dim3 grid((unsigned)(gx * gy * gz));
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, A, Bm, C, M, N, K, shared_a ? (size_t)0 : (size_t)M * K,
-                       (size_t)N * K, (size_t)M * N, scale, row_bias, ksplit, kchunk, a_amax, b_amax);
+                       (size_t)N * K, (size_t)M * N, scale, row_bias, ksplit, kchunk, a_amax, b_amax, (int)gx, (int)gy);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -364,17 +369,27 @@ extern "C" int cocos_debug_read_timing_xg(long long* host8, int reset) {
 }
 #endif
 
-extern "C" int cocos_absmax(const float* x, long long n, float* out_dev, cocos_stream_t stream) {
+static int absmax_launch(const float* x, long long n, float* inout_dev, bool zero_first, hipStream_t s) {
     using namespace cocos;
-    COCOS_REQUIRE(x && out_dev && n >= 1, COCOS_ERR_INVALID, "absmax: bad arguments");
-    hipStream_t s = as_stream(stream);
-    COCOS_HIP_CHECK(hipMemsetAsync(out_dev, 0, sizeof(float), s));
+    COCOS_REQUIRE(x && inout_dev && n >= 1, COCOS_ERR_INVALID, "absmax: bad arguments");
+    if (zero_first) COCOS_HIP_CHECK(hipMemsetAsync(inout_dev, 0, sizeof(float), s));
     const size_t n4 = aligned16(x) ? (size_t)n / 4 : 0;
     const unsigned blocks = (unsigned)std::min<size_t>(2048, (n4 + 256 * 8 - 1) / (256 * 8) + 1);
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, (size_t)n,
-                       reinterpret_cast<unsigned*>(out_dev));
+                       reinterpret_cast<unsigned*>(inout_dev));
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+extern "C" int cocos_absmax(const float* x, long long n, float* out_dev, cocos_stream_t stream) {
+    return absmax_launch(x, n, out_dev, true, cocos::as_stream(stream));
+}
+
+// *inout_dev = max(*inout_dev, max|x|): no memset in front of the kernel (a 5 us fill each on the hot path, which
+// needs eight of these per step) — the caller hands in a cell that already holds a non-negative finite value,
+// e.g. one of a pre-zeroed pool, or the maximum of another part of the same virtual tensor
+extern "C" int cocos_absmax_accumulate(const float* x, long long n, float* inout_dev, cocos_stream_t stream) {
+    return absmax_launch(x, n, inout_dev, false, cocos::as_stream(stream));
 }
 
 // ---- K0 on the split-precision GEMM (same contract as cocos_proj1x1_fwd / _bwd in sgemm_mfma.hip) -------------

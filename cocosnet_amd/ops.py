@@ -452,11 +452,26 @@ def warp_materialized(p, v):
 # ------------------------------------------------------------------------------------------
 # K0  theta / phi 1x1 projections            (correspondence.py:272, :282)
 # ------------------------------------------------------------------------------------------
+_zero_pool = {}      # (device, stream) -> [zeros tensor, next free cell]
+
+
+def _zero_cell(device) -> torch.Tensor:
+    """A 1-element fp32 tensor holding 0, from a pool zeroed 4096 cells at a time on the current stream (one fill
+    per ~500 steps instead of a 5 us memset in front of each of the eight max|x| passes of a step)."""
+    key = (device, _stream())
+    ent = _zero_pool.get(key)
+    if ent is None or ent[1] >= ent[0].numel():
+        ent = _zero_pool[key] = [torch.zeros(4096, device=device, dtype=torch.float32), 0]
+    cell = ent[0][ent[1]:ent[1] + 1]
+    ent[1] += 1
+    return cell
+
+
 def absmax(x: torch.Tensor) -> torch.Tensor:
     """max|x| as a 1-element CUDA tensor (one pass, no host sync) — the scale source of the f16 splits."""
     x = _chk(x, "absmax: x")
-    out = torch.empty(1, device=x.device, dtype=torch.float32)
-    _call("absmax", "cocos_absmax", x.data_ptr(), x.numel(), out.data_ptr(), _stream())
+    out = _zero_cell(x.device)
+    _call("absmax", "cocos_absmax_accumulate", x.data_ptr(), x.numel(), out.data_ptr(), _stream())
     return out
 
 

@@ -231,6 +231,9 @@ int cocos_proj1x1_bwd(const float* x, const float* w, const float* dy, float* dx
  * arrays, e.g. from cocos_absmax; NULL = the operand is already O(1)).
  *   cocos_absmax: *out_dev = max|x[0..n)| (one pass; cleared by the call). */
 int cocos_absmax(const float* x, long long n, float* out_dev, cocos_stream_t stream);
+/* *inout_dev = max(*inout_dev, max|x|) without the memset cocos_absmax puts in front: the cell must hold a finite
+ * value >= 0 (pre-zeroed pool; or the running maximum over the parts of a virtually concatenated tensor). */
+int cocos_absmax_accumulate(const float* x, long long n, float* inout_dev, cocos_stream_t stream);
 int cocos_proj1x1_fwd_f16x3(const float* x, const float* w, const float* bias, float* y,
                             int B, int Cin, int Cout, int N, const float* x_amax, const float* w_amax,
                             cocos_stream_t stream);

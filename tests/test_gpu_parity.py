@@ -484,6 +484,24 @@ def test_proj1x1_equals_conv2d(B, Cin, Cout, h, w, precision):
     assert rel(bd.grad, b64.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("n", [1, 3, 4, 1000, 4097, 1 << 20])
+def test_absmax_and_accumulate(n):
+    """max|x| passes that feed the power-of-two scales of the f16 splits: exact, any length / alignment; the
+    accumulate form continues from the value already in the cell (cells come from a pre-zeroed pool)."""
+    from cocosnet_amd import ops, _lib
+    rs = np.random.RandomState(n)
+    x = (rs.standard_normal(n + 1) * 10.0 ** rs.randint(-3, 4)).astype(np.float32)
+    xd = dev(x)
+    for view in (xd[:n], xd[1:]):             # second view: not 16-byte aligned
+        a = ops.absmax(view)
+        assert float(a) == float(view.abs().max())
+    cell = torch.full((1,), 1e30, device=DEV)
+    _lib.call("cocos_absmax_accumulate", xd.data_ptr(), n, cell.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert float(cell) == np.float32(1e30)
+    _lib.call("cocos_absmax", xd.data_ptr(), n, cell.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert float(cell) == float(xd[:n].abs().max())
+
+
 @pytest.mark.parametrize("B,Cin,Cout,h,w", [(2, 407, 256, 16, 16), (9, 256, 256, 8, 8)])
 def test_proj1x1_streaming_and_gemm_forms_agree(B, Cin, Cout, h, w, monkeypatch):
     """The streaming K0 kernel and the general split GEMM are the same arithmetic (f16 hi/lo, 3 MFMA terms): their

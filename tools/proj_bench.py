@@ -44,5 +44,6 @@ gf = 2.0 * B * Cin * Cout * h * w / 1e9
 print(f"proj1x1 B={B} Cin={Cin} Cout={Cout} {h}x{w}: fwd ours {t_f_ours*1e3:.0f} us ({gf/t_f_ours:.1f} TF/s... GF/ms) "
       f"torch {t_f_ref*1e3:.0f} us | fwd+bwd ours {t_ours*1e3:.0f} us torch {t_ref*1e3:.0f} us")
 with ops.KernelTimer() as kt:
-    fwd_bwd(ops.proj1x1)()
+    for _ in range(10):
+        fwd_bwd(ops.proj1x1)()
 print({k: round(v["avg_ms"] * 1e3) for k, v in kt.summary().items()}, "us")
