@@ -26,6 +26,8 @@ _SIGNATURES = {
                                                 _c_float_p, _c_float_p,
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_float, _stream_t]),
+    "cocos_center_l2norm_bwd_amax": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 4
+                                     + [ctypes.c_float, _c_float_p, _stream_t]),
     "cocos_corr_softmax_warp_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                                     _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int,

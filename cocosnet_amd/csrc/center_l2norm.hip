@@ -219,8 +219,11 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_reg_kernel(const float*
                                                                     const float* __restrict__ nrm_in,
                                                                     const float* __restrict__ dy,
                                                                     float* __restrict__ dx, int K, int N,
-                                                                    float eps, bool center) {
+                                                                    float eps, bool center,
+                                                                    unsigned* __restrict__ dx_amax) {
     __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
+    __shared__ unsigned blk_amax;
+    if (dx_amax && threadIdx.x == 0) blk_amax = 0u;     // (made visible by the barrier inside reduce_cg)
     const int tid = threadIdx.x, pq = tid & 15, cg = tid >> 4;
     const int b = blockIdx.y, n = blockIdx.x * 64 + pq * 4;
     const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(y + (size_t)b * K * N, (size_t)K * N * 4);
@@ -238,8 +241,8 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_reg_kernel(const float*
         s[2] += yy[i];
     }
     reduce_cg<3>(s, red, cg, pq);
-    if (!ok) return;
-    const f32x4 nrm = *reinterpret_cast<const f32x4*>(nrm_in + (size_t)b * N + n);
+    if (!ok && !dx_amax) return;
+    const f32x4 nrm = ok ? *reinterpret_cast<const f32x4*>(nrm_in + (size_t)b * N + n) : f32x4{1.f, 1.f, 1.f, 1.f};
     f32x4 u, g, m;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -248,19 +251,31 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_reg_kernel(const float*
         m[e] = center ? (u[e] * s[1][e] - g[e] * s[2][e]) / (float)K : 0.f;
     }
     float* dxb = dx + (size_t)b * K * N;
+    float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
-        *reinterpret_cast<f32x4*>(dxb + (size_t)(cg + 16 * i) * N + n) = u * gg[i] - g * yy[i] - m;
+    for (int i = 0; i < NI; ++i) {
+        const f32x4 d = u * gg[i] - g * yy[i] - m;
+        if (ok) *reinterpret_cast<f32x4*>(dxb + (size_t)(cg + 16 * i) * N + n) = d;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
+    }
+    // max|dx| as a by-product (the consumer, K0's backward, needs it for the scale of its f16 split and would
+    // otherwise read all of dx once more): non-negative floats order like their bit patterns
+    if (dx_amax) {
+        if (ok) atomicMax(&blk_amax, __float_as_uint(amax));
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(dx_amax, blk_amax);
+    }
 }
 
 template <bool BWD>
 static bool launch_reg_variant(const float* a, const float* nrm_in, const float* dy, float* out,
-                               float* norm_out, int B, int K, int N, float eps, bool center, hipStream_t s) {
+                               float* norm_out, int B, int K, int N, float eps, bool center, hipStream_t s,
+                               unsigned* dx_amax = nullptr) {
     if (K % 16 != 0 || K / 16 > CNR_MAXI || N % 4 != 0 || !aligned16(a) || !aligned16(out)) return false;
     const dim3 grid((N + 63) / 64, B);
 #define COCOS_NI(NI)                                                                                     \
     case NI:                                                                                             \
-        if (BWD) hipLaunchKernelGGL(center_l2norm_bwd_reg_kernel<NI>, grid, dim3(256), 0, s, a, nrm_in, dy, out, K, N, eps, center); \
+        if (BWD) hipLaunchKernelGGL(center_l2norm_bwd_reg_kernel<NI>, grid, dim3(256), 0, s, a, nrm_in, dy, out, K, N, eps, center, dx_amax); \
         else hipLaunchKernelGGL(center_l2norm_fwd_reg_kernel<NI>, grid, dim3(256), 0, s, a, out, norm_out, K, N, eps, center);      \
         return true;
     switch (K / 16) {
@@ -301,10 +316,11 @@ extern "C" int cocos_center_l2norm_fwd(const float* x, float* y, float* norm, fl
     return COCOS_OK;
 }
 
-extern "C" int cocos_center_l2norm_bwd(const float* y, const float* norm, const float* dy,
-                                       float* dx, float* col_ws, float* row_ws, int B, int K,
-                                       int N, int center_over_channels, float eps,
-                                       cocos_stream_t stream) {
+extern "C" int cocos_absmax_accumulate(const float* x, long long n, float* inout_dev, cocos_stream_t stream);
+
+static int center_l2norm_bwd_impl(const float* y, const float* norm, const float* dy, float* dx, float* col_ws,
+                                  float* row_ws, int B, int K, int N, int center_over_channels, float eps,
+                                  float* dx_amax_inout, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(y && norm && dy && dx, COCOS_ERR_INVALID, "center_l2norm_bwd: null pointer");
     COCOS_REQUIRE(B >= 1 && K >= 1 && N >= 1 && B <= 65535, COCOS_ERR_INVALID,
@@ -314,8 +330,12 @@ extern "C" int cocos_center_l2norm_bwd(const float* y, const float* norm, const 
     COCOS_REQUIRE(center_over_channels >= 0 && center_over_channels <= 2, COCOS_ERR_INVALID,
                   "center_l2norm_bwd: mode %d (0 positions, 1 channels, 2 none)", center_over_channels);
     const bool center = center_over_channels != COCOS_CENTER_NONE;
+    bool amax_done = false;
     if (center_over_channels) {
-        if (!launch_reg_variant<true>(y, norm, dy, dx, nullptr, B, K, N, eps, center, s))
+        if (launch_reg_variant<true>(y, norm, dy, dx, nullptr, B, K, N, eps, center, s,
+                                     reinterpret_cast<unsigned*>(dx_amax_inout)))
+            amax_done = true;
+        else
             hipLaunchKernelGGL((center_l2norm_bwd_kernel<true, 1>), grid, dim3(256), 0, s, y, norm,
                                dy, dx, (float*)nullptr, (const float*)nullptr, K, N, eps, center);
     } else {
@@ -329,5 +349,26 @@ extern "C" int cocos_center_l2norm_bwd(const float* y, const float* norm, const 
                            dy, dx, col_ws, (const float*)row_ws, K, N, eps, true);
     }
     COCOS_HIP_CHECK(hipGetLastError());
+    if (dx_amax_inout && !amax_done)         // shapes the fused kernel does not take: one separate pass
+        return cocos_absmax_accumulate(dx, (long long)B * K * N, dx_amax_inout, stream);
     return COCOS_OK;
+}
+
+extern "C" int cocos_center_l2norm_bwd(const float* y, const float* norm, const float* dy,
+                                       float* dx, float* col_ws, float* row_ws, int B, int K,
+                                       int N, int center_over_channels, float eps,
+                                       cocos_stream_t stream) {
+    return center_l2norm_bwd_impl(y, norm, dy, dx, col_ws, row_ws, B, K, N, center_over_channels, eps, nullptr,
+                                  stream);
+}
+
+// Same, and on return *dx_amax_inout = max(*dx_amax_inout, max|dx|) (cell must hold a finite value >= 0): the scale
+// source of K0's backward, produced while dx is written instead of by another pass over it.
+extern "C" int cocos_center_l2norm_bwd_amax(const float* y, const float* norm, const float* dy, float* dx,
+                                            float* col_ws, float* row_ws, int B, int K, int N,
+                                            int center_over_channels, float eps, float* dx_amax_inout,
+                                            cocos_stream_t stream) {
+    COCOS_REQUIRE(dx_amax_inout, COCOS_ERR_INVALID, "center_l2norm_bwd_amax: null amax cell");
+    return center_l2norm_bwd_impl(y, norm, dy, dx, col_ws, row_ws, B, K, N, center_over_channels, eps,
+                                  dx_amax_inout, stream);
 }

@@ -129,7 +129,14 @@ class _CenterL2Norm(torch.autograd.Function):
         if not center_over_channels:
             col_ws = torch.empty((B, N), device=y.device, dtype=torch.float32)
             row_ws = torch.empty((B, K), device=y.device, dtype=torch.float32)
-        _call("center_l2norm_bwd", "cocos_center_l2norm_bwd", y.data_ptr(), norm.data_ptr(), dy.data_ptr(),
+        if PROJ_PRECISION == "f16x3":      # max|dx| as a by-product: K0's backward (the usual consumer) needs it
+            cell = _zero_cell(dx.device)
+            _call("center_l2norm_bwd", "cocos_center_l2norm_bwd_amax", y.data_ptr(), norm.data_ptr(), dy.data_ptr(),
+                  dx.data_ptr(), _ptr(col_ws), _ptr(row_ws), B, K, N, int(center_over_channels), eps,
+                  cell.data_ptr(), _stream())
+            _remember_amax(dx, cell)
+        else:
+            _call("center_l2norm_bwd", "cocos_center_l2norm_bwd", y.data_ptr(), norm.data_ptr(), dy.data_ptr(),
                   dx.data_ptr(), _ptr(col_ws), _ptr(row_ws), B, K, N, int(center_over_channels),
                   eps, _stream())
         return dx, None, None
@@ -453,6 +460,33 @@ def warp_materialized(p, v):
 # K0  theta / phi 1x1 projections            (correspondence.py:272, :282)
 # ------------------------------------------------------------------------------------------
 _zero_pool = {}      # (device, stream) -> [zeros tensor, next free cell]
+_known_amax = {}     # storage pointer -> (the tensor, its version, amax cell); at most _KNOWN_AMAX_MAX entries
+
+
+_KNOWN_AMAX_MAX = 2
+
+
+def _remember_amax(t: torch.Tensor, cell: torch.Tensor):
+    """A producer kernel computed max|t| while writing t: keep it for the consumer (autograd hands the gradient on
+    as a view of the same storage).  The entry holds the tensor itself, so its address cannot be recycled for other
+    data while the entry exists; it is dropped when the consumer picks it up, or when two younger ones arrive."""
+    while len(_known_amax) >= _KNOWN_AMAX_MAX:
+        _known_amax.pop(next(iter(_known_amax)))
+    _known_amax[t.untyped_storage().data_ptr()] = (t, t._version, cell)
+
+
+def _recall_amax(t: torch.Tensor, consume: bool = True):
+    key = t.untyped_storage().data_ptr()
+    ent = _known_amax.get(key)
+    if ent is None:
+        return None
+    if consume:
+        del _known_amax[key]
+    src, version, cell = ent
+    if (t.numel() != src.numel() or t.storage_offset() != src.storage_offset() or not t.is_contiguous()
+            or t._version != version or src._version != version):
+        return None
+    return cell
 
 
 def _zero_cell(device) -> torch.Tensor:
@@ -529,7 +563,9 @@ class _Proj1x1(torch.autograd.Function):
             dwb = torch.empty((parts, Cout, Cin), device=x.device, dtype=torch.float32)
         if ctx.split:
             xa, wa = ctx.amax
-            ga = absmax(dy)
+            ga = _recall_amax(dy)            # left by the kernel that wrote dy (K1's backward), else one pass
+            if ga is None:
+                ga = absmax(dy)
             dx_gemm = dx
             if ctx.stream and need_x:     # dx = W^T dy, same streaming kernel with the transposed weight planes
                 th, tl, ts = split_f16(w2.unsqueeze(0), transpose=True,

@@ -65,6 +65,12 @@ int cocos_center_l2norm_bwd(const float* y, const float* norm, const float* dy, 
                             float* col_ws, float* row_ws,
                             int B, int K, int N, int center_over_channels, float eps,
                             cocos_stream_t stream);
+/* Same as cocos_center_l2norm_bwd, and on return *dx_amax_inout = max(*dx_amax_inout, max|dx|) (the cell must hold
+ * a finite value >= 0, e.g. 0): the consumer of dx on the hot path — the backward of the theta/phi projection,
+ * correspondence.py:272,:282 — needs it for the scale of its f16 split; produced while dx is written. */
+int cocos_center_l2norm_bwd_amax(const float* y, const float* norm, const float* dy, float* dx, float* col_ws,
+                                 float* row_ws, int B, int K, int N, int center_over_channels, float eps,
+                                 float* dx_amax_inout, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K2  fused correlation -> /temperature -> softmax over key positions -> warp

@@ -502,6 +502,55 @@ def test_absmax_and_accumulate(n):
     assert float(cell) == float(xd[:n].abs().max())
 
 
+@pytest.mark.parametrize("B,K,N,mode", [(2, 256, 4096, 1), (1, 64, 100, 1), (2, 37, 50, 1), (2, 32, 64, 0), (1, 16, 8, 2)])
+def test_center_l2norm_bwd_amax_byproduct(B, K, N, mode):
+    """K1's backward leaves max|dx| in the caller's cell (fused in the register kernel, a separate pass for the
+    shapes that kernel does not take): exact, and it continues from the value already in the cell."""
+    from cocosnet_amd import ops, _lib
+    rs = np.random.RandomState(K + N)
+    x, g = dev(rs.standard_normal((B, K, N)) * 3.0, True), dev(rs.standard_normal((B, K, N)) * 1e-3)
+    seen = []
+
+    def hook(grad):       # what the next backward node receives: a view of the tensor K1's backward wrote
+        v = grad.reshape(B, K, -1, 1)
+        seen.append((ops._recall_amax(v, consume=False), float(grad.abs().max())))
+        cell = ops._recall_amax(v)
+        assert ops._recall_amax(v) is None                                  # picked up once
+        ops._remember_amax(grad, cell)
+        grad.mul_(2.0)                                                      # modified in place: no longer valid
+        seen.append((ops._recall_amax(grad), None))
+        return grad
+
+    x2 = x * 1.0
+    x2.register_hook(hook)
+    ops.center_l2norm(x2, mode).backward(g)
+    (cell, ref), (stale, _) = seen
+    assert cell is not None and float(cell) == ref
+    assert stale is None
+
+
+def test_proj1x1_backward_reuses_the_producers_amax(monkeypatch):
+    """theta -> centre/L2-norm (the hot path's order): the projection's backward takes max|dy| from K1's backward
+    instead of reading dy once more — two max|x| passes (input, weight) instead of three, same gradients."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PROJ_PRECISION", "f16x3")
+    rs = np.random.RandomState(5)
+    x, wt = rs.standard_normal((2, 407, 8, 8)), rs.standard_normal((256, 407, 1, 1)) * 0.05
+    g = rs.standard_normal((2, 256, 64))
+    grads = []
+    for reuse in (True, False):
+        if not reuse:
+            monkeypatch.setattr(ops, "_recall_amax", lambda t: None)
+        xd, wd = dev(x, True), dev(wt, True)
+        with ops.KernelTimer(tags=("absmax",)) as kt:
+            th = ops.proj1x1(xd, wd, None)
+            ops.center_l2norm(th.view(2, 256, -1), 1).backward(dev(g))
+        assert kt.summary()["absmax"]["calls"] == (2 if reuse else 3)
+        grads.append((xd.grad.cpu().numpy(), wd.grad.cpu().numpy()))
+    np.testing.assert_array_equal(grads[0][0], grads[1][0])
+    np.testing.assert_array_equal(grads[0][1], grads[1][1])
+
+
 @pytest.mark.parametrize("B,Cin,Cout,h,w", [(2, 407, 256, 16, 16), (9, 256, 256, 8, 8)])
 def test_proj1x1_streaming_and_gemm_forms_agree(B, Cin, Cout, h, w, monkeypatch):
     """The streaming K0 kernel and the general split GEMM are the same arithmetic (f16 hi/lo, 3 MFMA terms): their
