@@ -95,6 +95,8 @@ _SIGNATURES = {
     "cocos_proj1x1_fwd_f16x3": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 4 + [_c_float_p] * 2 + [_stream_t]),
     "cocos_proj1x1_bwd_partials_f16x3": (ctypes.c_int, [ctypes.c_int] * 4),
     "cocos_proj1x1_stream_kpad": (ctypes.c_int, [ctypes.c_int]),
+    "cocos_proj1x1_dw_partials_f16x3": (ctypes.c_int, [ctypes.c_int] * 4),
+    "cocos_proj1x1_dw_f16x3": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 4 + [_c_float_p] * 2 + [_stream_t]),
     "cocos_proj1x1_stream_f16x3": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p,
                                                   _c_float_p] + [ctypes.c_int] * 4 + [_c_float_p, _stream_t]),
     "cocos_proj1x1_bwd_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [_stream_t]),

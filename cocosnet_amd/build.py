@@ -33,6 +33,7 @@ HIP_SOURCES = [
     "sgemm_mfma.hip",
     "sgemm_f16x3.hip",
     "proj_stream_f16x3.hip",
+    "proj_dw_f16x3.hip",
     "box3_unfold.hip",
     "unfold3_stats.hip",
     "logits_softmax_warp.hip",
@@ -45,6 +46,10 @@ HIP_SOURCES = [
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              "-Wall", "-Wno-unused-function"]
+#: per-file additions.  proj_dw: 224 accumulator registers per lane — with the default AGPR form of the MFMA results
+#: hipcc also parks the staged global loads in the accumulator file, runs out of it and spills accumulators to
+#: scratch inside the k loop (every reload is an s_waitcnt vmcnt(0): the prefetch is gone); VGPR form has no spills.
+FILE_FLAGS = {"proj_dw_f16x3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _hipcc() -> str:
@@ -67,6 +72,7 @@ def _digest(paths) -> str:
             h.update(os.path.basename(p).encode())
             h.update(f.read())
     h.update(" ".join(_flags()).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -85,7 +91,7 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
-        cmd = [hipcc, *_flags(), "-c", src, "-o", obj]
+        cmd = [hipcc, *_flags(), *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -222,8 +222,6 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_reg_kernel(const float*
                                                                     float eps, bool center,
                                                                     unsigned* __restrict__ dx_amax) {
     __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
-    __shared__ unsigned blk_amax;
-    if (dx_amax && threadIdx.x == 0) blk_amax = 0u;     // (made visible by the barrier inside reduce_cg)
     const int tid = threadIdx.x, pq = tid & 15, cg = tid >> 4;
     const int b = blockIdx.y, n = blockIdx.x * 64 + pq * 4;
     const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(y + (size_t)b * K * N, (size_t)K * N * 4);
@@ -261,9 +259,8 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_reg_kernel(const float*
     // max|dx| as a by-product (the consumer, K0's backward, needs it for the scale of its f16 split and would
     // otherwise read all of dx once more): non-negative floats order like their bit patterns
     if (dx_amax) {
-        if (ok) atomicMax(&blk_amax, __float_as_uint(amax));
-        __syncthreads();
-        if (threadIdx.x == 0) atomicMax(dx_amax, blk_amax);
+        const float wmax = wave_max_dpp(ok ? amax : 0.f);
+        if ((threadIdx.x & 63) == 0) atomicMax(dx_amax, __float_as_uint(wmax));
     }
 }
 

@@ -51,6 +51,24 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // Exchange with the other half-wave (lane ^ 32).
 __device__ __forceinline__ float swap_half(float x) { return __shfl_xor(x, 32, 64); }
 
+// max over the 64 lanes of a wave, result in every lane: DPP inside the rows of 16, read-lane across the four rows
+// (no LDS traffic, ~12 instructions)
+__device__ __forceinline__ float wave_max_dpp(float v) {
+#define COCOS_DPP_MAX(ctrl) \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false)))
+    COCOS_DPP_MAX(0xB1);     // quad_perm [1,0,3,2]
+    COCOS_DPP_MAX(0x4E);     // quad_perm [2,3,0,1]
+    COCOS_DPP_MAX(0x141);    // row_half_mirror
+    COCOS_DPP_MAX(0x140);    // row_mirror
+#undef COCOS_DPP_MAX
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 // XCD-aware block remap (guide T1, bijective form).  Consecutive *virtual* ids end up on the
 // same XCD, so blocks that stream the same batch item's key/value tiles share one 4 MiB L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

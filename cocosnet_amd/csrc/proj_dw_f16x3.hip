@@ -1,0 +1,334 @@
+// K0 weight gradient (and bias gradient) as a streaming reduction (gfx950):
+//     dw[m,c] = sum_{b,n} dy[b,m,n] x[b,c,n]        db[m] = sum_{b,n} dy[b,m,n]
+// for the theta / phi projections of correspondence.py:272,:282 (M = 256 output channels, C = 256 (+151) inputs,
+// reduction over B*HW = 32 k positions).  Both operands are big (85 MB together), the result is tiny: the job is
+// to read dy and x ONCE, at full memory speed, with all 256 CUs, and to keep the partial results small.
+//
+// The general split GEMM (sgemm_f16x3.hip, 256 x 128 tiles, split-K 8) reads and re-splits dy once per column
+// tile (4x), and its bias gradient is a separate pass over dy.  Here a workgroup owns 128 rows of dy x ALL rows
+// of x (accumulators: 64 x 224 per wave = 224 AGPRs) for a chunk of positions, so x is read by the two
+// row-halves (the second one from L2: they run on the same XCD) and dy exactly once; db falls out of the dy
+// staging (a running sum per staged row).  The 2 x S partial tiles go to a workspace and are summed by a second,
+// bandwidth-bound kernel (S = 128 chunks at the reference's size: 53 MB, written and read once, mostly in the
+// memory-side cache).
+//
+// Pipeline per workgroup: a k-step is 16 positions.  LDS holds k-steps t (being multiplied) and t+1 (committed
+// meanwhile: fp32 -> f16 hi/lo planes, rows of 16 + 8 pad halfs = conflict-free 16-byte operand reads); two
+// register stages hold t+2 / t+3 in flight, so a global load has two k-steps to arrive.  Staging pieces (one
+// float4 = 4 positions of one row) are converted, committed and re-loaded one at a time between the MFMA triples.
+// Arithmetic as everywhere on the split path: a.b ~= ah.bh + ah.bl + al.bh, v_mfma_f32_32x32x16_f16, fp32 accumulate.
+#include <algorithm>
+
+#include "common.h"
+
+namespace cocos {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int DW_BK = 16, DW_ROW = DW_BK + 8;      // positions per k-step; halfs per LDS row
+constexpr int DW_MROWS = 128;                      // dy rows per workgroup
+
+__device__ __forceinline__ float dw_scale_from_amax(const float* amax) {
+    if (!amax) return 1.0f;
+    const float a = *amax;
+    if (!(a > 0.f) || !(a < INFINITY)) return 1.0f;
+    int e;
+    frexpf(a, &e);
+    return ldexpf(1.0f, 10 - e);
+}
+
+__device__ __forceinline__ void dw_split4(const f32x4& x, float s, u32x2& hi, u32x2& lo) {
+    const float a = x[0] * s, b = x[1] * s, c = x[2] * s, d = x[3] * s;
+    const f16x2 h0 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    const f16x2 h1 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(c, d));
+    const f16x2 l0 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a - (float)h0[0], b - (float)h0[1]));
+    const f16x2 l1 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(c - (float)h1[0], d - (float)h1[1]));
+    hi = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+    lo = u32x2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+}
+
+// CBW = 32-column blocks (rows of x) per wave: the workgroup covers 2 * CBW * 32 rows of x
+template <int CBW>
+__global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ ws_dw, float* __restrict__ ws_db,
+    int M, int C, int N, int chunks_per_img, int chunk_len, const float* __restrict__ dy_amax,
+    const float* __restrict__ x_amax) {
+    constexpr int XROWS = 2 * CBW * 32;                           // x rows staged per k-step
+    constexpr int APLANE = DW_MROWS * DW_ROW, BPLANE = XROWS * DW_ROW;
+    constexpr int BUF = 2 * (APLANE + BPLANE);                    // halfs per LDS buffer: A hi, A lo, B hi, B lo
+    constexpr int NPA = DW_MROWS * 4 / 256;                       // float4 pieces per thread and k-step: dy
+    constexpr int NPB = (XROWS * 4 + 255) / 256;                  //                                      x
+    constexpr int NP = NPA + NPB;
+    constexpr int SLOTS = 2 * CBW;                                // MFMA triples per k-step and wave
+    static_assert(NP <= SLOTS, "more staging pieces than MFMA steps to carry them");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16* const lds = reinterpret_cast<_Float16*>(smem_raw);  // [2 buf][A hi | A lo | B hi | B lo]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    // chunk (blockIdx.x) x row half (blockIdx.y); the halves of one chunk are 8k blocks apart = same XCD
+    const int s_idx = blockIdx.x, mh = blockIdx.y;
+    const int b = s_idx / chunks_per_img;
+    const int n_beg = (s_idx - b * chunks_per_img) * chunk_len, n_end = min(N, n_beg + chunk_len);
+    const int nsteps = (max(n_end - n_beg, 0) + DW_BK - 1) / DW_BK;
+    const int m0 = mh * DW_MROWS;
+
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(dy + (size_t)b * M * N, (size_t)M * N * 4);
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(x + (size_t)b * C * N, (size_t)C * N * 4);
+    const float sa = dw_scale_from_amax(dy_amax), sb = dw_scale_from_amax(x_amax);
+
+    // ---- staging: piece p of this thread = 4 consecutive positions (kq) of one row -----------------------------
+    // piece p covers row p*64 + (tid >> 2) of its operand (dy rows first, then x rows), positions kq*4 .. +3 of the
+    // k-step with kq = tid & 3 for every piece: one LDS address register + immediates, one position test per step
+    static_assert((XROWS * 4) % 256 == 0 && (DW_MROWS * 4) % 256 == 0, "whole pieces only");
+    const int kq = tid & 3, prow = tid >> 2;
+    unsigned voff[NP];                       // per-lane byte offset of (row, kq*4) in its image; kBufOob: row absent
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const bool isA = p < NPA;
+        const int grow = isA ? m0 + p * 64 + prow : (p - NPA) * 64 + prow;
+        voff[p] = (grow < (isA ? M : C)) ? (unsigned)(grow * N + kq * 4) * 4u : kBufOob;
+    }
+    _Float16* const lds_t = lds + prow * DW_ROW + kq * 4;         // + buffer, operand, plane, p*64 rows: constants
+    f32x4 st[2][NP];
+    float dbsum[NPA];
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) dbsum[p] = 0.f;
+
+    auto fetch_piece = [&](f32x4 (&sg)[NP], int p, int t) {       // k-step t (beyond the chunk: zeros)
+        const int n = n_beg + t * DW_BK;                          // uniform; + kq*4 per lane
+        const bool ok = (t < nsteps) && (n + kq * 4 < n_end);
+        sg[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            p < NPA ? a_rs : b_rs, (int)(ok ? voff[p] : kBufOob), n * 4, 0));
+    };
+    auto commit_piece = [&](const f32x4 (&sg)[NP], int p, int buf) {
+        u32x2 hi, lo;
+        dw_split4(sg[p], p < NPA ? sa : sb, hi, lo);
+        if (p < NPA) dbsum[p] += (sg[p][0] + sg[p][1]) + (sg[p][2] + sg[p][3]);
+        _Float16* d = lds_t + buf * BUF + (p < NPA ? p * 64 * DW_ROW : 2 * APLANE + (p - NPA) * 64 * DW_ROW);
+        *reinterpret_cast<u32x2*>(d) = hi;
+        *reinterpret_cast<u32x2*>(d + (p < NPA ? APLANE : BPLANE)) = lo;
+    };
+
+    f32x16 acc[2][CBW];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+
+    // one k-step: this wave's 64 x (CBW*32) block += A(64 x 16) . B(16 x CBW*32); hook(slot) after every MFMA triple
+    auto kstep = [&](int buf, auto&& hook) {
+        const _Float16* ab = lds + buf * BUF + (wm * 64 + c) * DW_ROW + h * 8;
+        const _Float16* bb = lds + buf * BUF + 2 * APLANE + (wn * CBW * 32 + c) * DW_ROW + h * 8;
+        f16x8 ah[2], al[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            ah[rb] = *reinterpret_cast<const f16x8*>(ab + rb * 32 * DW_ROW);
+            al[rb] = *reinterpret_cast<const f16x8*>(ab + APLANE + rb * 32 * DW_ROW);
+        }
+        constexpr int RA = 2;
+        f16x8 bh[RA], bl[RA];
+#pragma unroll
+        for (int i = 0; i < RA - 1 && i < CBW; ++i) {
+            bh[i] = *reinterpret_cast<const f16x8*>(bb + i * 32 * DW_ROW);
+            bl[i] = *reinterpret_cast<const f16x8*>(bb + BPLANE + i * 32 * DW_ROW);
+        }
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+            const int cur = cb % RA, nx = cb + RA - 1;
+            if (nx < CBW) {
+                bh[nx % RA] = *reinterpret_cast<const f16x8*>(bb + nx * 32 * DW_ROW);
+                bl[nx % RA] = *reinterpret_cast<const f16x8*>(bb + BPLANE + nx * 32 * DW_ROW);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], bh[cur], acc[rb][cb], 0, 0, 0);
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], bl[cur], acc[rb][cb], 0, 0, 0);
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rb], bh[cur], acc[rb][cb], 0, 0, 0);
+                hook(cb * 2 + rb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    };
+
+    // prologue (loads in the order in which the loop consumes them: stage 0 = k-step 0, stage 1 = 1, stage 0 = 2)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) fetch_piece(st[0], p, 0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) fetch_piece(st[1], p, 1);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) commit_piece(st[0], p, 0);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) fetch_piece(st[0], p, 2);
+    __syncthreads();
+
+    // k-step t: multiply LDS[t&1]; commit stage (t+1)&1 (= k-step t+1) to the other buffer, refill it with t+3
+    for (int t = 0; t < nsteps; t += 2) {
+        kstep(0, [&](int slot) {
+            if (slot < NP) {
+                commit_piece(st[1], slot, 1);
+                fetch_piece(st[1], slot, t + 3);
+            }
+        });
+        if (t + 1 < nsteps)
+            kstep(1, [&](int slot) {
+                if (slot < NP) {
+                    commit_piece(st[0], slot, 0);
+                    fetch_piece(st[0], slot, t + 4);
+                }
+            });
+    }
+
+    // ---- partial tile -> workspace [S][M][C] (lane = x row, register = dy row: 128-byte row segments) ----------
+    const float oscale = 1.0f / (sa * sb);
+    float* wsb = ws_dw + (size_t)s_idx * M * C;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) {
+            const int ci = (wn * CBW + cb) * 32 + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + rb * 32 + acc_row_base(r) + 4 * h;
+                if (m < M && ci < C) wsb[(size_t)m * C + ci] = acc[rb][cb][r] * oscale;
+            }
+        }
+    // ---- bias gradient: a dy row was staged by 4 neighbouring lanes (kq = lane & 3) ----------------------------
+    if (ws_db) {
+#pragma unroll
+        for (int p = 0; p < NPA; ++p) {
+            float v = dbsum[p];
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+            const int row = m0 + p * 64 + prow;
+            if ((tid & 3) == 0 && row < M) ws_db[(size_t)s_idx * M + row] = v;
+        }
+    }
+}
+
+// out[i] = sum_s ws[s][i]  (i < n: the partial tiles of the kernel above); db likewise.  Bandwidth-bound: a block
+// takes 64 float4 columns, its four 64-thread groups each sum a quarter of the S partials (8 loads in flight),
+// the quarters meet in LDS.
+__global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                             int S, size_t n, const float* __restrict__ ws_db,
+                                                             float* __restrict__ db, int M) {
+    __shared__ __attribute__((aligned(16))) float red[3 * 64 * 4];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const size_t i4 = ((size_t)blockIdx.x * 64 + col) * 4;
+    const bool vec = (n & 3) == 0;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (i4 < n) {
+        const int per = (S + 3) / 4, s0 = grp * per, s1 = min(S, s0 + per);
+        if (vec) {
+            f32x4 t[8];
+            int s = s0;
+            for (; s + 8 <= s1; s += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(ws + (size_t)(s + u) * n + i4);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += t[u];
+            }
+            for (; s < s1; ++s) a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * n + i4);
+        } else {
+            for (int s = s0; s < s1; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i4 + e < n) a[e] += ws[(size_t)s * n + i4 + e];
+        }
+    }
+    if (grp > 0) *reinterpret_cast<f32x4*>(red + ((grp - 1) * 64 + col) * 4) = a;
+    __syncthreads();
+    if (grp == 0 && i4 < n) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) a += *reinterpret_cast<const f32x4*>(red + (g * 64 + col) * 4);
+        if (vec) *reinterpret_cast<f32x4*>(out + i4) = a;
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i4 + e < n) out[i4 + e] = a[e];
+        }
+    }
+    // db: row m is summed by block m (mod grid): its S partials one per thread, then a tree in LDS — as a serial
+    // loop in one thread this was 128 dependent L2 round trips, the longest pole of the whole kernel
+    if (db) {
+        for (int m = blockIdx.x; m < M; m += gridDim.x) {
+            float v = 0.f;
+            for (int s = threadIdx.x; s < S; s += 256) v += ws_db[(size_t)s * M + m];
+            __syncthreads();
+            red[threadIdx.x] = v;
+            __syncthreads();
+#pragma unroll
+            for (int w = 128; w >= 1; w >>= 1) {
+                if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) db[m] = red[0];
+        }
+    }
+}
+
+static bool dw_plan(int B, int C, int M, int N, int* chunks_per_img, int* chunk_len, int* cbw) {
+    if (M < 1 || M > 2 * DW_MROWS || C < 1 || C > 448 || N % 4 != 0 || B < 1) return false;
+    *cbw = C <= 256 ? 4 : 7;
+    const int mhalves = (M + DW_MROWS - 1) / DW_MROWS;
+    // ~256 workgroups, a multiple of 8 chunks so that the row halves of a chunk share an XCD; >= 4 k-steps each
+    int want = std::max(1, (256 / mhalves) / B);
+    const int max_chunks = std::max(1, N / (4 * DW_BK));
+    want = std::min(want, max_chunks);
+    int len = (N + want - 1) / want;
+    len = (len + DW_BK - 1) / DW_BK * DW_BK;
+    *chunk_len = len;
+    *chunks_per_img = (N + len - 1) / len;
+    return true;
+}
+
+}  // namespace cocos
+
+// Workspace sizing: number of partial tiles S (0: shape not supported, use cocos_proj1x1_bwd_f16x3);
+// ws_dw = S*M*C floats, ws_db = S*M floats.
+extern "C" int cocos_proj1x1_dw_partials_f16x3(int B, int C, int M, int N) {
+    int cpi, len, cbw;
+    if (!cocos::dw_plan(B, C, M, N, &cpi, &len, &cbw)) return 0;
+    return B * cpi;
+}
+
+extern "C" int cocos_proj1x1_dw_f16x3(const float* dy, const float* x, float* ws_dw, float* ws_db, float* dw,
+                                      float* db, int B, int C, int M, int N, const float* dy_amax,
+                                      const float* x_amax, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(dy && x && ws_dw && dw, COCOS_ERR_INVALID, "proj1x1_dw_f16x3: null pointer");
+    COCOS_REQUIRE((db == nullptr) == (ws_db == nullptr), COCOS_ERR_INVALID,
+                  "proj1x1_dw_f16x3: db and ws_db go together");
+    int cpi, len, cbw;
+    COCOS_REQUIRE(dw_plan(B, C, M, N, &cpi, &len, &cbw), COCOS_ERR_UNSUPPORTED,
+                  "proj1x1_dw_f16x3: needs M <= 256, C <= 448, N %% 4 == 0 (got M=%d C=%d N=%d): use "
+                  "cocos_proj1x1_bwd_f16x3", M, C, N);
+    COCOS_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws_dw) && aligned16(dw), COCOS_ERR_INVALID,
+                  "proj1x1_dw_f16x3: pointers must be 16-byte aligned");
+    COCOS_REQUIRE((size_t)M * N * 4 < 0x7fffffffull && (size_t)C * N * 4 < 0x7fffffffull, COCOS_ERR_UNSUPPORTED,
+                  "proj1x1_dw_f16x3: one sample exceeds 2 GiB");
+    hipStream_t s = as_stream(stream);
+    const int S = B * cpi, mhalves = (M + DW_MROWS - 1) / DW_MROWS;
+    const dim3 grid(S, mhalves);
+    auto launch = [&](auto kern, int xrows) -> int {
+        const size_t smem = (size_t)2 * 2 * (DW_MROWS + xrows) * DW_ROW * sizeof(_Float16);
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, dy, x, ws_dw, ws_db, M, C, N, cpi, len, dy_amax, x_amax);
+        return COCOS_OK;
+    };
+    const int rc = cbw == 4 ? launch(proj_dw_f16x3_kernel<4>, 256) : launch(proj_dw_f16x3_kernel<7>, 448);
+    if (rc != COCOS_OK) return rc;
+    COCOS_HIP_CHECK(hipGetLastError());
+    const size_t n = (size_t)M * C;
+    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws_dw, dw, S, n,
+                       ws_db, db, M);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}

@@ -554,34 +554,56 @@ class _Proj1x1(torch.autograd.Function):
         dy = _chk(dy, "proj1x1: dy")
         B, Cin, h, w = x.shape
         Cout = w2.shape[0]
+        N = h * w
         need_x, need_w, need_b = ctx.needs_input_grad
+        need_b = need_b and ctx.has_bias
+        lib = _lib.load()
         dx = torch.empty_like(x) if need_x else None
-        dwb = None
-        sfx = "_f16x3" if ctx.split else ""
-        if need_w:
-            parts = getattr(_lib.load(), "cocos_proj1x1_bwd_partials" + sfx)(B, Cin, Cout, h * w)
-            dwb = torch.empty((parts, Cout, Cin), device=x.device, dtype=torch.float32)
+        dw = db = None
         if ctx.split:
             xa, wa = ctx.amax
             ga = _recall_amax(dy)            # left by the kernel that wrote dy (K1's backward), else one pass
             if ga is None:
                 ga = absmax(dy)
-            dx_gemm = dx
+            dx_gemm, dw_gemm = need_x, need_w
             if ctx.stream and need_x:     # dx = W^T dy, same streaming kernel with the transposed weight planes
-                th, tl, ts = split_f16(w2.unsqueeze(0), transpose=True,
-                                       cpad=_lib.load().cocos_proj1x1_stream_kpad(Cout), amax=wa)
+                th, tl, ts = split_f16(w2.unsqueeze(0), transpose=True, cpad=lib.cocos_proj1x1_stream_kpad(Cout),
+                                       amax=wa)
                 _call("proj1x1_bwd", "cocos_proj1x1_stream_f16x3", dy.data_ptr(), th.data_ptr(), tl.data_ptr(),
-                      ts.data_ptr(), None, dx.data_ptr(), B, Cout, Cin, h * w, ga.data_ptr(), _stream())
-                dx_gemm = None
-            if dx_gemm is not None or dwb is not None:
+                      ts.data_ptr(), None, dx.data_ptr(), B, Cout, Cin, N, ga.data_ptr(), _stream())
+                dx_gemm = False
+            parts = lib.cocos_proj1x1_dw_partials_f16x3(B, Cin, Cout, N) if (need_w and PROJ_STREAM) else 0
+            if parts:                     # dw (and db) in one pass over dy and x (proj_dw_f16x3.hip)
+                ws = torch.empty((parts, Cout, Cin), device=x.device, dtype=torch.float32)
+                wsb = torch.empty((parts, Cout), device=x.device, dtype=torch.float32) if need_b else None
+                dw = torch.empty((Cout, Cin), device=x.device, dtype=torch.float32)
+                db = torch.empty(Cout, device=x.device, dtype=torch.float32) if need_b else None
+                _call("proj1x1_bwd", "cocos_proj1x1_dw_f16x3", dy.data_ptr(), x.data_ptr(), ws.data_ptr(), _ptr(wsb),
+                      dw.data_ptr(), _ptr(db), B, Cin, Cout, N, ga.data_ptr(), xa.data_ptr(), _stream())
+                dw_gemm = False
+            if dx_gemm or dw_gemm:
+                dwb = None
+                if dw_gemm:
+                    dwb = torch.empty((lib.cocos_proj1x1_bwd_partials_f16x3(B, Cin, Cout, N), Cout, Cin),
+                                      device=x.device, dtype=torch.float32)
                 _call("proj1x1_bwd", "cocos_proj1x1_bwd_f16x3", x.data_ptr(), w2.data_ptr(), dy.data_ptr(),
-                      _ptr(dx_gemm), _ptr(dwb), B, Cin, Cout, h * w, xa.data_ptr(), wa.data_ptr(), ga.data_ptr(),
-                      _stream())
+                      dx.data_ptr() if dx_gemm else None, _ptr(dwb), B, Cin, Cout, N, xa.data_ptr(), wa.data_ptr(),
+                      ga.data_ptr(), _stream())
+                if dw_gemm:
+                    dw = dwb.sum(0)                                         # [P,256,Cl] partials, small
         else:
+            dwb = None
+            if need_w:
+                dwb = torch.empty((lib.cocos_proj1x1_bwd_partials(B, Cin, Cout, N), Cout, Cin), device=x.device,
+                                  dtype=torch.float32)
             _call("proj1x1_bwd", "cocos_proj1x1_bwd", x.data_ptr(), w2.data_ptr(), dy.data_ptr(), _ptr(dx),
-                  _ptr(dwb), B, Cin, Cout, h * w, _stream())
-        dw = dwb.sum(0).reshape(ctx.wshape) if need_w else None            # [P,256,Cl] partials, small
-        db = dy.sum(dim=(0, 2, 3)) if (need_b and ctx.has_bias) else None
+                  _ptr(dwb), B, Cin, Cout, N, _stream())
+            if need_w:
+                dw = dwb.sum(0)
+        if need_w:
+            dw = dw.reshape(ctx.wshape)
+        if need_b and db is None:
+            db = dy.sum(dim=(0, 2, 3))
         return dx, dw, db
 
 

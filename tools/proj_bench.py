@@ -35,11 +35,12 @@ def fwd_bwd(f):
     return run
 
 
+NO_TORCH = os.environ.get("COCOS_BENCH_NO_TORCH") == "1"     # (MIOpen's first-call search costs seconds of GPU time)
 with torch.no_grad():
     t_f_ours = bench(lambda: ops.proj1x1(x, wt, b))
-    t_f_ref = bench(lambda: F.conv2d(x, wt, b))
+    t_f_ref = float("nan") if NO_TORCH else bench(lambda: F.conv2d(x, wt, b))
 t_ours = bench(fwd_bwd(ops.proj1x1))
-t_ref = bench(fwd_bwd(F.conv2d))
+t_ref = float("nan") if NO_TORCH else bench(fwd_bwd(F.conv2d))
 gf = 2.0 * B * Cin * Cout * h * w / 1e9
 print(f"proj1x1 B={B} Cin={Cin} Cout={Cout} {h}x{w}: fwd ours {t_f_ours*1e3:.0f} us ({gf/t_f_ours:.1f} TF/s... GF/ms) "
       f"torch {t_f_ref*1e3:.0f} us | fwd+bwd ours {t_ours*1e3:.0f} us torch {t_ref*1e3:.0f} us")
