@@ -186,8 +186,11 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(
     }
 
     // ---- partial tile -> workspace [S][M][C] (lane = x row, register = dy row: 128-byte row segments) ----------
+    // (rows padded to whole 128-byte lines: a 32-lane store then never leaves a line half written, which would cost
+    //  a read of the line first — 407-float rows did, measured as 2x the algorithmic read traffic)
     const float oscale = 1.0f / (sa * sb);
-    float* wsb = ws_dw + (size_t)s_idx * M * C;
+    const int CP = (C + 31) / 32 * 32;
+    float* wsb = ws_dw + (size_t)s_idx * M * CP;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + rb * 32 + acc_row_base(r) + 4 * h;
-                if (m < M && ci < C) wsb[(size_t)m * C + ci] = acc[rb][cb][r] * oscale;
+                if (m < M && ci < CP) wsb[(size_t)m * CP + ci] = acc[rb][cb][r] * oscale;
             }
         }
     // ---- bias gradient: a dy row was staged by 4 neighbouring lanes (kq = lane & 3) ----------------------------
@@ -212,47 +215,38 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(
     }
 }
 
-// out[i] = sum_s ws[s][i]  (i < n: the partial tiles of the kernel above); db likewise.  Bandwidth-bound: a block
-// takes 64 float4 columns, its four 64-thread groups each sum a quarter of the S partials (8 loads in flight),
-// the quarters meet in LDS.
+// dw[m][c] = sum_s ws[s][m][c]  (partial tiles of the kernel above, rows padded to CP floats); db likewise.
+// Bandwidth-bound: a block takes 64 float4 columns, its four 64-thread groups each sum a quarter of the S partials
+// (8 loads in flight), the quarters meet in LDS.
 __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
-                                                             int S, size_t n, const float* __restrict__ ws_db,
-                                                             float* __restrict__ db, int M) {
+                                                             int S, int M, int C, int CP,
+                                                             const float* __restrict__ ws_db, float* __restrict__ db) {
     __shared__ __attribute__((aligned(16))) float red[3 * 64 * 4];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const size_t i4 = ((size_t)blockIdx.x * 64 + col) * 4;
-    const bool vec = (n & 3) == 0;
+    const size_t n = (size_t)M * CP;                               // floats per partial tile
+    const size_t i4 = ((size_t)blockIdx.x * 64 + col) * 4;         // padded index of this thread's float4
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     if (i4 < n) {
         const int per = (S + 3) / 4, s0 = grp * per, s1 = min(S, s0 + per);
-        if (vec) {
-            f32x4 t[8];
-            int s = s0;
-            for (; s + 8 <= s1; s += 8) {
+        f32x4 t[8];
+        int s = s0;
+        for (; s + 8 <= s1; s += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(ws + (size_t)(s + u) * n + i4);
+            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(ws + (size_t)(s + u) * n + i4);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a += t[u];
-            }
-            for (; s < s1; ++s) a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * n + i4);
-        } else {
-            for (int s = s0; s < s1; ++s)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (i4 + e < n) a[e] += ws[(size_t)s * n + i4 + e];
+            for (int u = 0; u < 8; ++u) a += t[u];
         }
+        for (; s < s1; ++s) a += *reinterpret_cast<const f32x4*>(ws + (size_t)s * n + i4);
     }
     if (grp > 0) *reinterpret_cast<f32x4*>(red + ((grp - 1) * 64 + col) * 4) = a;
     __syncthreads();
     if (grp == 0 && i4 < n) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) a += *reinterpret_cast<const f32x4*>(red + (g * 64 + col) * 4);
-        if (vec) *reinterpret_cast<f32x4*>(out + i4) = a;
-        else {
+        const int m = (int)(i4 / CP), c0 = (int)(i4 - (size_t)m * CP);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (i4 + e < n) out[i4 + e] = a[e];
-        }
+        for (int e = 0; e < 4; ++e)
+            if (c0 + e < C) out[(size_t)m * C + c0 + e] = a[e];
     }
     // db: row m is summed by block m (mod grid): its S partials one per thread, then a tree in LDS — as a serial
     // loop in one thread this was 128 dependent L2 round trips, the longest pole of the whole kernel
@@ -291,7 +285,7 @@ static bool dw_plan(int B, int C, int M, int N, int* chunks_per_img, int* chunk_
 }  // namespace cocos
 
 // Workspace sizing: number of partial tiles S (0: shape not supported, use cocos_proj1x1_bwd_f16x3);
-// ws_dw = S*M*C floats, ws_db = S*M floats.
+// ws_dw = S*M*roundup(C,32) floats, ws_db = S*M floats.
 extern "C" int cocos_proj1x1_dw_partials_f16x3(int B, int C, int M, int N) {
     int cpi, len, cbw;
     if (!cocos::dw_plan(B, C, M, N, &cpi, &len, &cbw)) return 0;
@@ -326,9 +320,10 @@ extern "C" int cocos_proj1x1_dw_f16x3(const float* dy, const float* x, float* ws
     const int rc = cbw == 4 ? launch(proj_dw_f16x3_kernel<4>, 256) : launch(proj_dw_f16x3_kernel<7>, 448);
     if (rc != COCOS_OK) return rc;
     COCOS_HIP_CHECK(hipGetLastError());
-    const size_t n = (size_t)M * C;
-    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws_dw, dw, S, n,
-                       ws_db, db, M);
+    const int CP = (C + 31) / 32 * 32;
+    const size_t n = (size_t)M * CP;
+    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws_dw, dw, S, M, C, CP,
+                       ws_db, db);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

@@ -574,7 +574,7 @@ class _Proj1x1(torch.autograd.Function):
                 dx_gemm = False
             parts = lib.cocos_proj1x1_dw_partials_f16x3(B, Cin, Cout, N) if (need_w and PROJ_STREAM) else 0
             if parts:                     # dw (and db) in one pass over dy and x (proj_dw_f16x3.hip)
-                ws = torch.empty((parts, Cout, Cin), device=x.device, dtype=torch.float32)
+                ws = torch.empty((parts, Cout, (Cin + 31) // 32 * 32), device=x.device, dtype=torch.float32)
                 wsb = torch.empty((parts, Cout), device=x.device, dtype=torch.float32) if need_b else None
                 dw = torch.empty((Cout, Cin), device=x.device, dtype=torch.float32)
                 db = torch.empty(Cout, device=x.device, dtype=torch.float32) if need_b else None

@@ -269,7 +269,7 @@ int cocos_proj1x1_stream_f16x3(const float* x, const void* a_hi, const void* a_l
  *     dw[m,c] = sum_{b,n} dy[b,m,n] x[b,c,n]      db[m] = sum_{b,n} dy[b,m,n]   (db, ws_db: both or neither NULL)
  * dy [B,M,N], x [B,C,N] fp32, read once; f16x3 products with the power-of-two scales from dy_amax / x_amax.
  * S = cocos_proj1x1_dw_partials_f16x3(B, C, M, N) partial tiles go through the caller's workspace
- * (ws_dw: S*M*C floats, ws_db: S*M floats) and are summed on the device; S = 0: shape not supported
+ * (ws_dw: S*M*roundup(C,32) floats, ws_db: S*M floats) and are summed on the device; S = 0: shape not supported
  * (needs M <= 256, C <= 448, N % 4 == 0) -> cocos_proj1x1_bwd_f16x3. */
 int cocos_proj1x1_dw_partials_f16x3(int B, int C, int M, int N);
 int cocos_proj1x1_dw_f16x3(const float* dy, const float* x, float* ws_dw, float* ws_db, float* dw, float* db,
