@@ -28,13 +28,13 @@ FUSED_K = 256
 #: "f16x3" = v_mfma_f32_32x32x16_f16 on f16 hi+lo planes, 3 terms per product, fp32 accumulate
 #: (fp32-class accuracy, ~1/5 of the matrix-pipe time).  Module attribute, read at call time.
 PRECISION = os.environ.get("COCOS_PRECISION", "f16x3")
-#: K0 (theta/phi 1x1 projections): "fp32" = the fp32-MFMA GEMM (on par with rocBLAS); "f16x3" = the split GEMM
-#: of sgemm_f16x3.hip (operands split on the fly, staged pieces converted/committed between MFMAs).  At K0's
-#: shapes (K = 256..407: 8-13 k-steps, a 33 MB output written in one burst) it gains less than the K2 kernels
-#: do and pays for the max|x| passes, but is ahead end to end (0.40 + 0.1 vs 0.51 ms per step).
+#: K0 (theta/phi 1x1 projections): "fp32" = the fp32-MFMA GEMM (on par with rocBLAS); "f16x3" = split products on
+#: the f16 MFMA — the streaming kernels below at the reference's shapes, else the split GEMM of sgemm_f16x3.hip
+#: (operands split on the fly, staged pieces converted/committed between MFMAs).
 PROJ_PRECISION = os.environ.get("COCOS_PROJ_PRECISION", "f16x3")
-#: K0 at the reference's own shape (256 -> 256 channels, HW % 64 == 0): y = W x and dx = W^T dy on the streaming
-#: kernel (proj_stream_f16x3.hip: weight planes resident in the accumulator file, x / y touched once)
+#: K0 at the reference's own shapes (<= 416 input channels, HW % 64 == 0): y = W x and dx = W^T dy on the streaming
+#: kernel (proj_stream_f16x3.hip: weight planes resident in the accumulator file, x / y touched once), dw + db as one
+#: streaming reduction (proj_dw_f16x3.hip).  "0" = the general split GEMM everywhere (A/B, tests).
 PROJ_STREAM = os.environ.get("COCOS_PROJ_STREAM", "1") != "0"
 #: power-of-two pre-scale of the unit-norm operands before the f16 split (keeps the lo plane normal)
 SPLIT_OPERAND_SCALE = 16.0
