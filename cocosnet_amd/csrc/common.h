@@ -51,6 +51,17 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // Exchange with the other half-wave (lane ^ 32).
 __device__ __forceinline__ float swap_half(float x) { return __shfl_xor(x, 32, 64); }
 
+// Two fp32 values -> packed f16 hi (rounded toward zero, so the residual keeps the sign) and packed f16 lo = x - hi.
+// The residual is one v_fma_mix_f32 per value: the f16 -> f32 conversion of hi rides in the instruction (from the
+// plain C expression hipcc makes v_cvt_f32_f16 + v_sub_f32 — 16 more instructions per 32x32 tile of P or dS).
+__device__ __forceinline__ void split_pair_rtz(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(hi));
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+
 // max over the 64 lanes of a wave, result in every lane: DPP inside the rows of 16, read-lane across the four rows
 // (no LDS traffic, ~12 instructions)
 __device__ __forceinline__ float wave_max_dpp(float v) {

@@ -36,8 +36,10 @@ __device__ __forceinline__ u32x4 bq_load16s(__amdgpu_buffer_rsrc_t r, unsigned o
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, (int)soff, 0);
 }
 __device__ __forceinline__ void bq_split_pair(float a, float b, f16x2& hi, f16x2& lo) {
-    hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
-    lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
+    unsigned h, l;
+    split_pair_rtz(a, b, h, l);
+    hi = __builtin_bit_cast(f16x2, h);
+    lo = __builtin_bit_cast(f16x2, l);
 }
 
 #ifdef COCOS_DEBUG_TIMING
@@ -253,9 +255,9 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
 
         BPH_T(tp0);
         // ---- dP' = V(t) . dO' -----------------------------------------------------------------------------
-        f32x16 dp0, dp1;
+        f32x16 dp0;     // one accumulator for the three terms of a product (fp32 adds either way)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dp0[r] = 0.f; dp1[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) dp0[r] = 0.f;
         {
             const _Float16* vb0 = vt + buf * 2 * VPLANE + c * VROW + h * 8;
             f16x8 ah[2], al[2];
@@ -269,8 +271,8 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
                     al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
                 }
                 dp0 = bq_mfma(ah[cur], goh[u], dp0);
-                dp1 = bq_mfma(ah[cur], gol[u], dp1);
-                dp1 = bq_mfma(al[cur], goh[u], dp1);
+                dp0 = bq_mfma(ah[cur], gol[u], dp0);
+                dp0 = bq_mfma(al[cur], goh[u], dp0);
             }
         }
 
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
         for (int r = 0; r < 16; ++r) {
             float pv = fast_exp2(sld[r] - lse2);
             if (RAGGED && (j0 + acc_row_base(r) + 4 * h >= Nk)) pv = 0.f;
-            ds[r] = pv * ((dp0[r] + dp1[r]) - d_lane) * cs;
+            ds[r] = pv * (dp0[r] - d_lane) * cs;
             if (STORE_P) {          // the key side of the cycle terms needs P itself (dV = dO . P)
                 if (r & 1) {
                     f16x2 a, bq;

@@ -65,8 +65,10 @@ __device__ __forceinline__ u32x2 buf_load_u2s(__amdgpu_buffer_rsrc_t r, unsigned
 
 // p (>= 0, <= 2^8) -> f16 hi (round toward zero, so lo >= 0) and f16 lo, two values per instruction
 __device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& lo) {
-    hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
-    lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
+    unsigned h, l;
+    split_pair_rtz(a, b, h, l);
+    hi = __builtin_bit_cast(f16x2, h);
+    lo = __builtin_bit_cast(f16x2, l);
 }
 
 // Optional phase timing (build with COCOS_EXTRA_HIPFLAGS=-DCOCOS_DEBUG_TIMING): shader-clock ticks spent by
@@ -238,9 +240,9 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
         //      the staged registers of tile t+1 go to the other LDS buffer (last read in iteration t-1, released
         //      by the barrier that ended it) one 16-/8-byte piece per step, and each freed register immediately
         //      takes its load for tile t+2 — memory instructions are never issued as a burst ------------------
-        f32x16 s0, s1;
+        f32x16 s0;     // all three terms of a product go into ONE accumulator (fp32 adds either way): no 16 adds per tile
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) s0[r] = 0.f;
         {
             const _Float16* kb = kt + buf * 2 * KPLANE + c * SP_KROW + h * 8;
             _Float16* const kw = kt + (buf ^ 1) * 2 * KPLANE;
@@ -292,8 +294,8 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                     al[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + KPLANE + (s + RA - 1) * 16);
                 }
                 s0 = mfma16h(ah[cur], qhr[s], s0);
-                s1 = mfma16h(ah[cur], qlr[s], s1);
-                s1 = mfma16h(al[cur], qhr[s], s1);
+                s0 = mfma16h(ah[cur], qlr[s], s0);
+                s0 = mfma16h(al[cur], qhr[s], s0);
                 // 8 + 2*CVB <= 18 pieces over 16 steps
                 piece(s);
                 if (s < 2) piece(16 + s);
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float x = (s0[r] + s1[r]) * scale_log2;
+            float x = s0[r] * scale_log2;
             if (ragged && (j0 + acc_row_base(r) + 4 * h >= Nk)) x = -INFINITY;
             p[r] = x;
             tmax = fmaxf(tmax, x);
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
             for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
         }
         float psum = 0.f;
+        const float mb = m_run - kPBias;      // one subtraction per element instead of two
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if (STORE_S) {
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                 buf_store1s(lg_rs, p[r], (!ragged || jr + 4 * h < Nk) ? lg_lane_off : kBufOob,
                             (unsigned)jr * (unsigned)Nq * 4u);
             }
-            p[r] = fast_exp2(p[r] - m_run + kPBias);
+            p[r] = fast_exp2(p[r] - mb);
             psum += p[r];
         }
         l_run += psum;

@@ -26,8 +26,10 @@ __device__ __forceinline__ f32x16 lw_mfma(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ void lw_split_pair(float a, float b, f16x2& hi, f16x2& lo) {
-    hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
-    lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a - (float)hi[0], b - (float)hi[1]));
+    unsigned h, l;
+    split_pair_rtz(a, b, h, l);
+    hi = __builtin_bit_cast(f16x2, h);
+    lo = __builtin_bit_cast(f16x2, l);
 }
 
 // ---------------------------------------------------------------------------------------------------------
