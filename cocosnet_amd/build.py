@@ -43,6 +43,7 @@ HIP_SOURCES = [
     "pono_spade.hip",
     "instnorm_prelu.hip",
     "upsample_nearest.hip",
+    "warp_values.hip",
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              "-Wall", "-Wno-unused-function"]

@@ -52,6 +52,10 @@ class HotPathConfig:
                    warp_cycle_w=float(g("warp_cycle_w", 0.0)), two_cycle=bool(g("two_cycle", False)))
 
 
+def _hip_fp32(t):
+    return t is not None and t.is_cuda and t.dtype == torch.float32
+
+
 def _flat(x):
     """[B,C,h,w] -> channel-major [B,C,h*w] (a view when contiguous)."""
     return x.reshape(x.shape[0], x.shape[1], -1)
@@ -196,17 +200,24 @@ def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_
         return attn.f_scaled
 
     # ---- R1: exemplar colours (+ direct mask) through the row softmax  (:309-336) ----------------
-    if cfg.warp_patch:
-        ref = F.unfold(ref_img, down, stride=down)                    # [B, 3*down^2, HW]
-    else:
-        ref = _flat(F.avg_pool2d(ref_img, down))                      # [B, 3, HW]
-    n_ref = ref.shape[1]
     direct_mask = cfg.warp_mask_losstype == "direct" or cfg.show_warpmask
-    v_r1 = [ref]
-    if direct_mask:
-        ref_seg = F.interpolate(ref_seg_map, scale_factor=1 / down, mode="nearest")
-        v_r1.append(_flat(ref_seg))
-    o_r1 = attn.rows(torch.cat(v_r1, dim=1) if len(v_r1) > 1 else ref)
+    fused_values = (ops.WARP_VALUES_FUSED and direct_mask and not cfg.warp_patch and _hip_fp32(ref_img) and _hip_fp32(ref_seg_map)
+                    and not (ref_img.requires_grad or ref_seg_map.requires_grad) and H % down == 0 and W % down == 0)
+    if fused_values:
+        n_ref = ref_img.shape[1]
+        v1 = _flat(ops.warp_values(ref_img, ref_seg_map, down))       # pooled image + sampled mask in one kernel (K14)
+    else:
+        if cfg.warp_patch:
+            ref = F.unfold(ref_img, down, stride=down)                    # [B, 3*down^2, HW]
+        else:
+            ref = _flat(F.avg_pool2d(ref_img, down))                      # [B, 3, HW]
+        n_ref = ref.shape[1]
+        v_r1 = [ref]
+        if direct_mask:
+            ref_seg = F.interpolate(ref_seg_map, scale_factor=1 / down, mode="nearest")
+            v_r1.append(_flat(ref_seg))
+        v1 = torch.cat(v_r1, dim=1) if len(v_r1) > 1 else ref
+    o_r1 = attn.rows(v1)
     y = o_r1[:, :n_ref]                                               # [B, ch, HW]
     if cfg.warp_patch:
         y_img = F.fold(y, (H, W), down, stride=down)                  # reference hard-codes 256 (:321)

@@ -864,6 +864,26 @@ def upsample_nearest(x, scale: int):
     return _UpsampleNearest.apply(x, scale)
 
 
+#: build the first row pass's value tensor with K14 instead of avg_pool2d + interpolate + cat ("0": framework ops)
+WARP_VALUES_FUSED = os.environ.get("COCOS_WARP_VALUES", "1") != "0"
+
+
+def warp_values(img, seg_map, down: int):
+    """torch.cat((F.avg_pool2d(img, down), F.interpolate(seg_map, scale_factor=1/down, mode='nearest')), 1) in one
+    kernel (K14; correspondence.py:314, :318-319, :331-334): img [B,Ci,H,W], seg_map [B,Cs,H,W] or None -> [B,Ci+Cs,
+    H/down,W/down].  Forward only: the exemplar image and its label map are data (callers with gradients use torch)."""
+    img = _chk(img, "warp_values: img")
+    B, Ci, H, W = img.shape
+    seg = None if seg_map is None else _chk(seg_map, "warp_values: seg_map")
+    Cs = 0 if seg is None else seg.shape[1]
+    if seg is not None and (seg.shape[0], seg.shape[2], seg.shape[3]) != (B, H, W):
+        raise ValueError(f"warp_values: seg_map {tuple(seg.shape)} does not match img {tuple(img.shape)}")
+    out = torch.empty((B, Ci + Cs, H // down, W // down), device=img.device, dtype=torch.float32)
+    _call("warp_values", "cocos_warp_values", img.data_ptr(), _ptr(seg), out.data_ptr(), B, Ci, Cs, H, W, int(down),
+          _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # K13 InstanceNorm (+ residual) + PReLU of the ResidualBlocks   (correspondence.py:13-36)
 # ------------------------------------------------------------------------------------------

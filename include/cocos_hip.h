@@ -345,6 +345,15 @@ int cocos_pono_spade_bwd(const float* x, const float* gamma, const float* beta, 
 int cocos_upsample_nearest_fwd(const float* x, float* y, int planes, int h, int w, int scale, cocos_stream_t stream);
 int cocos_upsample_nearest_bwd(const float* dy, float* dx, int planes, int h, int w, int scale, cocos_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * K14  value tensor of the first row pass in one kernel (correspondence.py:314, :318-319, :331-334):
+ *     out[b, 0:Ci]     = F.avg_pool2d(img, down)                          img [B,Ci,H,W]
+ *     out[b, Ci:Ci+Cs] = F.interpolate(seg, scale_factor=1/down, 'nearest') = seg[.., y*down, x*down]
+ *   out [B, Ci+Cs, H/down, W/down] (= torch.cat of the two); either part may be absent (count 0, NULL pointer).
+ *   Forward only (the exemplar image and its label map are data).  H, W multiples of down. */
+int cocos_warp_values(const float* img, const float* seg, float* out, int B, int Ci, int Cs, int H, int W,
+                      int down, cocos_stream_t stream);
+
 /* K7 on the f16 MFMA (same contract as cocos_logits_softmax_warp_fwd / _bwd; operand planes as for K2's split flavour):
  *   fwd: vh,vl [B,Cv,Nk] channel-major planes of v; Nk % 4 == 0
  *   bwd: vph,vpl [B,Nk,CvPad] and gph,gpl [B,Nq,CvPad] position-major planes of v and of (*g_scale_dev)*dout

@@ -484,6 +484,33 @@ def test_proj1x1_equals_conv2d(B, Cin, Cout, h, w, precision):
     assert rel(bd.grad, b64.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("B,Ci,Cs,H,W,down", [(2, 3, 151, 64, 64, 4), (1, 3, 5, 12, 20, 2), (2, 2, 0, 8, 8, 4),
+                                               (1, 0, 7, 9, 6, 3), (1, 3, 4, 16, 12, 1), (1, 1, 2, 8, 12, 4)])
+def test_warp_values_equals_pool_interpolate_cat(B, Ci, Cs, H, W, down):
+    """K14 = torch.cat((F.avg_pool2d(img, down), F.interpolate(seg, scale_factor=1/down, 'nearest')), 1)
+    (correspondence.py:314, :318-319, :331-334): sampled label maps bit-exact, means to fp32 rounding."""
+    import torch.nn.functional as F
+    from cocosnet_amd import ops, _lib
+    rs = np.random.RandomState(H * W + down)
+    img = dev(rs.standard_normal((B, max(Ci, 1), H, W)))[:, :Ci].contiguous()
+    seg = dev(rs.standard_normal((B, max(Cs, 1), H, W)))[:, :Cs].contiguous()
+    parts = []
+    if Ci:
+        parts.append(F.avg_pool2d(img, down))
+    if Cs:
+        parts.append(F.interpolate(seg, scale_factor=1 / down, mode="nearest") if down > 1 else seg)
+    ref = torch.cat(parts, 1)
+    if Ci and Cs:
+        out = ops.warp_values(img, seg, down)
+    else:                                                 # one part absent: straight through the C ABI
+        out = torch.empty_like(ref)
+        _lib.call("cocos_warp_values", img.data_ptr() if Ci else None, seg.data_ptr() if Cs else None, out.data_ptr(),
+                  B, Ci, Cs, H, W, down, torch.cuda.current_stream().cuda_stream)
+    assert out.shape == ref.shape
+    np.testing.assert_array_equal(out[:, Ci:].cpu().numpy(), ref[:, Ci:].cpu().numpy())
+    np.testing.assert_allclose(out[:, :Ci].cpu().numpy(), ref[:, :Ci].cpu().numpy(), rtol=0, atol=1e-6)
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 1000, 4097, 1 << 20])
 def test_absmax_and_accumulate(n):
     """max|x| passes that feed the power-of-two scales of the f16 splits: exact, any length / alignment; the
