@@ -259,8 +259,14 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_reg_kernel(const float*
     // max|dx| as a by-product (the consumer, K0's backward, needs it for the scale of its f16 split and would
     // otherwise read all of dx once more): non-negative floats order like their bit patterns
     if (dx_amax) {
+        // one same-address atomic per WORKGROUP: they serialise at the memory side (~10 ns each) — one per wave
+        // (2048 per launch) put 16 us on the critical path, 512 of them hide under the kernel
         const float wmax = wave_max_dpp(ok ? amax : 0.f);
-        if ((threadIdx.x & 63) == 0) atomicMax(dx_amax, __float_as_uint(wmax));
+        __syncthreads();                                  // (red[] was last read in reduce_cg)
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wmax;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(dx_amax, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
     }
 }
 

@@ -374,7 +374,7 @@ static int absmax_launch(const float* x, long long n, float* inout_dev, bool zer
     COCOS_REQUIRE(x && inout_dev && n >= 1, COCOS_ERR_INVALID, "absmax: bad arguments");
     if (zero_first) COCOS_HIP_CHECK(hipMemsetAsync(inout_dev, 0, sizeof(float), s));
     const size_t n4 = aligned16(x) ? (size_t)n / 4 : 0;
-    const unsigned blocks = (unsigned)std::min<size_t>(2048, (n4 + 256 * 8 - 1) / (256 * 8) + 1);
+    const unsigned blocks = (unsigned)std::min<size_t>(512, (n4 + 256 * 8 - 1) / (256 * 8) + 1);   // one same-address atomic each
     hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, s, x, n4, (size_t)n,
                        reinterpret_cast<unsigned*>(inout_dev));
     COCOS_HIP_CHECK(hipGetLastError());
