@@ -85,6 +85,8 @@ _SIGNATURES = {
                                           + [ctypes.c_float, ctypes.c_float, _stream_t]),
     "cocos_split_f16_ex": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5
                            + [ctypes.c_float, _c_float_p, _c_float_p, _stream_t]),
+    "cocos_split_f16_rows": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3
+                             + [ctypes.c_float, _c_float_p, _c_float_p, _stream_t]),
     "cocos_corr_softmax_warp_bwd_query_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 6 + [_c_float_p] * 6
                                                 + [ctypes.c_void_p] * 4 + [_c_float_p] * 2 + [ctypes.c_int] * 6
                                                 + [ctypes.c_float, ctypes.c_float, ctypes.c_int, _stream_t]),

@@ -107,6 +107,30 @@ __global__ __launch_bounds__(256) void split_f16_transpose_kernel(const float* _
 
 }  // namespace cocos
 
+namespace cocos {
+
+// rows x cols (row-major) -> planes rows x cols_pad, zero beyond cols: the register-resident operand of the K0
+// streaming kernel (a weight matrix, k-contiguous, rows padded to whole 16-wide MFMA k-steps)
+__global__ __launch_bounds__(256) void split_f16_rows_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
+                                                             _Float16* __restrict__ lo, int rows, int cols,
+                                                             int cols_pad, float scale,
+                                                             const float* __restrict__ amax_dev,
+                                                             float* __restrict__ scale_out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (amax_dev) {
+        scale = scale_from_amax(*amax_dev);
+        if (scale_out && i == 0) *scale_out = scale;
+    }
+    if (i >= (size_t)rows * cols_pad) return;
+    const int r = (int)(i / cols_pad), c = (int)(i - (size_t)r * cols_pad);
+    _Float16 a = (_Float16)0.f, b = (_Float16)0.f;
+    if (c < cols) split1(x[(size_t)r * cols + c] * scale, a, b);
+    hi[i] = a;
+    lo[i] = b;
+}
+
+}  // namespace cocos
+
 static int split_f16_launch(const float* x, void* hi, void* lo, int B, int C, int N, int Cpad, int transpose,
                             float scale, const float* amax_dev, float* scale_out, hipStream_t s) {
     using namespace cocos;
@@ -149,4 +173,21 @@ extern "C" int cocos_split_f16_ex(const float* x, void* hi, void* lo, int B, int
                   "split_f16_ex: bad dims B=%d C=%d N=%d Cpad=%d", B, C, N, Cpad);
     COCOS_REQUIRE(transpose || Cpad == C, COCOS_ERR_INVALID, "split_f16_ex: padding only with transpose");
     return split_f16_launch(x, hi, lo, B, C, N, Cpad, transpose, scale, amax_dev, scale_out_dev, as_stream(stream));
+}
+
+// 2-D form with padded rows: x [rows][cols] -> hi, lo [rows][cols_pad] (zero beyond cols), x*scale ~= hi + lo with
+// the scale chosen as in cocos_split_f16_ex (amax_dev != NULL: power of two from *amax_dev, written to scale_out_dev).
+extern "C" int cocos_split_f16_rows(const float* x, void* hi, void* lo, int rows, int cols, int cols_pad, float scale,
+                                    const float* amax_dev, float* scale_out_dev, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && hi && lo, COCOS_ERR_INVALID, "split_f16_rows: null pointer");
+    COCOS_REQUIRE(rows >= 1 && cols >= 1 && cols_pad >= cols, COCOS_ERR_INVALID,
+                  "split_f16_rows: bad dims rows=%d cols=%d cols_pad=%d", rows, cols, cols_pad);
+    const size_t n = (size_t)rows * cols_pad;
+    COCOS_REQUIRE((n + 255) / 256 <= 0x7fffffffull, COCOS_ERR_UNSUPPORTED, "split_f16_rows: tensor too large");
+    hipLaunchKernelGGL(split_f16_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x,
+                       static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), rows, cols, cols_pad, scale, amax_dev,
+                       scale_out_dev);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
 }

@@ -529,9 +529,13 @@ class _Proj1x1(torch.autograd.Function):
         if split:      # products on the f16 MFMA, operands split on the fly (sgemm_f16x3.hip)
             xa, wa = absmax(x), absmax(w2)
             if stream:
-                # A = W as planes [Cout][Kpad]: the split kernel transposes, so it is fed W^T (100 K elements)
-                wh, wl, ws = split_f16(w2.t().contiguous().unsqueeze(0), transpose=True,
-                                       cpad=lib.cocos_proj1x1_stream_kpad(Cin), amax=wa)
+                # A = W as planes [Cout][Kpad], rows zero-padded to whole MFMA k-steps
+                kp = lib.cocos_proj1x1_stream_kpad(Cin)
+                wh = torch.empty((Cout, kp), device=x.device, dtype=torch.float16)
+                wl = torch.empty((Cout, kp), device=x.device, dtype=torch.float16)
+                ws = torch.empty(1, device=x.device, dtype=torch.float32)
+                _call("split_f16", "cocos_split_f16_rows", w2.data_ptr(), wh.data_ptr(), wl.data_ptr(), Cout, Cin, kp,
+                      1.0, wa.data_ptr(), ws.data_ptr(), _stream())
                 _call("proj1x1_fwd", "cocos_proj1x1_stream_f16x3", x.data_ptr(), wh.data_ptr(), wl.data_ptr(),
                       ws.data_ptr(), _ptr(bb), y.data_ptr(), B, Cin, Cout, h * w, xa.data_ptr(), _stream())
             else:

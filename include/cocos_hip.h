@@ -135,6 +135,10 @@ int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void
 int cocos_split_f16_ex(const float* x, void* hi, void* lo, int B, int C, int N, int Cpad, int transpose,
                        float scale, const float* amax_dev /* nullable */, float* scale_out_dev /* nullable */,
                        cocos_stream_t stream);
+/* 2-D form with padded rows: x [rows][cols] -> hi, lo [rows][cols_pad], zero beyond cols (scale as in _ex): the
+ * weight planes [M][Kpad] of cocos_proj1x1_stream_f16x3 straight from the weight matrix. */
+int cocos_split_f16_rows(const float* x, void* hi, void* lo, int rows, int cols, int cols_pad, float scale,
+                         const float* amax_dev, float* scale_out_dev, cocos_stream_t stream);
 int cocos_corr_softmax_warp_bwd_query_f16x3(
     const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
     const float* g_scale_dev, const float* out, const float* dout, const float* lse, const float* logits_t,

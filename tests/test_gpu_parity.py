@@ -511,6 +511,26 @@ def test_warp_values_equals_pool_interpolate_cat(B, Ci, Cs, H, W, down):
     np.testing.assert_allclose(out[:, :Ci].cpu().numpy(), ref[:, :Ci].cpu().numpy(), rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("rows,cols,pad", [(256, 407, 416), (3, 5, 16), (7, 16, 16), (1, 1, 256)])
+def test_split_f16_rows_padded_planes(rows, cols, pad):
+    """Weight planes of the K0 streaming kernel: x [rows][cols] -> f16 hi/lo [rows][pad], zero beyond cols,
+    hi + lo = x * scale to 2^-22 with the power-of-two scale taken from the device-side max|x|."""
+    from cocosnet_amd import ops, _lib
+    rs = np.random.RandomState(rows + cols)
+    x = (rs.standard_normal((rows, cols)) * 0.037).astype(np.float32)
+    xd = dev(x)
+    hi = torch.full((rows, pad), 7.0, device=DEV, dtype=torch.float16)
+    lo = torch.full((rows, pad), 7.0, device=DEV, dtype=torch.float16)
+    sc = torch.zeros(1, device=DEV)
+    _lib.call("cocos_split_f16_rows", xd.data_ptr(), hi.data_ptr(), lo.data_ptr(), rows, cols, pad, 1.0,
+              ops.absmax(xd).data_ptr(), sc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    scale = float(sc)
+    assert scale == 2.0 ** np.round(np.log2(scale)) and 512.0 <= np.abs(x).max() * scale < 1024.0
+    rec = hi.double().cpu().numpy() + lo.double().cpu().numpy()
+    assert np.all(rec[:, cols:] == 0.0)
+    np.testing.assert_allclose(rec[:, :cols], x.astype(np.float64) * scale, rtol=2.0 ** -21, atol=2.0 ** -24)
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 1000, 4097, 1 << 20])
 def test_absmax_and_accumulate(n):
     """max|x| passes that feed the power-of-two scales of the f16 splits: exact, any length / alignment; the
