@@ -407,7 +407,7 @@ def test_module_return_corr_and_wta_and_detach():
 
 
 # ------------------------------------------------------------------ match_kernel = 3 without unfolding
-@pytest.mark.parametrize("B,h,w", [(2, 12, 9), (1, 1, 1), (1, 3, 5), (1, 16, 16), (1, 7, 40)])
+@pytest.mark.parametrize("B,h,w", [(2, 12, 9), (1, 1, 1), (1, 3, 5), (1, 16, 16), (1, 7, 40), (1, 32, 48), (2, 33, 31)])
 def test_box3_logits_equal_the_unfolded_formulation(B, h, w):
     """K6: diagonal box filter of the K=256 correlation + rank-1 correction == F.unfold -> centre ->
     normalise -> matmul of the reference (:276-291), forward and all gradients (torch fp64 autograd
