@@ -70,6 +70,8 @@ _SIGNATURES = {
     "cocos_box3_logits_bwd_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "cocos_box3_logits_bwd": (ctypes.c_int, [_c_float_p] * 11 + [ctypes.c_void_p, ctypes.c_size_t]
                               + [ctypes.c_int] * 3 + [ctypes.c_float, _stream_t]),
+    "cocos_box3_logits_bwd_amax": (ctypes.c_int, [_c_float_p] * 11 + [ctypes.c_void_p, ctypes.c_size_t]
+                                   + [ctypes.c_int] * 3 + [ctypes.c_float, _c_float_p, _stream_t]),
     "cocos_logits_softmax_warp_fwd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 4 + [_stream_t]),
     "cocos_logits_softmax_warp_bwd": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 4 + [_stream_t]),
     "cocos_wta_scale_mask_bytes": (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_int]),

@@ -126,7 +126,9 @@ template <bool PRE>
 __global__ __launch_bounds__(256) void box3_walk_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const float* __restrict__ mu, const float* __restrict__ nu,
                                                         const float* __restrict__ av, const float* __restrict__ bv,
-                                                        int N, int h, int w, int nchunk, int nrb, float kc, float post) {
+                                                        int N, int h, int w, int nchunk, int nrb, float kc, float post,
+                                                        float* __restrict__ out_amax) {
+    __shared__ float amax_red[4];
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
     const int chunk = vb % nchunk;
     const int rb = (vb / nchunk) % nrb;
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(256) void box3_walk_kernel(const float* __restrict_
     const int rows = min(BX_WR, N - p0);
     // diagonal of element e of this thread: q - (p - p0) = qs + e, qs in [-(BX_WR-1), N)
     const int qs = (chunk * 256 + (int)threadIdx.x) * 4 - (BX_WR - 1);
-    if (qs >= N) return;
+    if (qs >= N && !out_amax) return;
+    float amax = 0.f;
     const __amdgpu_buffer_rsrc_t in_rs = make_rsrc(in + (size_t)b * N * N, (size_t)N * N * 4);
     const __amdgpu_buffer_rsrc_t out_rs = make_rsrc(out + (size_t)b * N * N, (size_t)N * N * 4);
     const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(bv + (size_t)b * N, (size_t)N * 4);
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(256) void box3_walk_kernel(const float* __restrict_
     int py = p0 / w, px = p0 - py * w;
 
     // windows: win[dy][0..2] = diagonal elements at steps i-1, i, i+1 (rows p0+i+dy*w+{-1,0,1})
+    // (a fourth, look-ahead element per diagonal was measured: slightly slower, more so with the PRE weights)
     f32x4 win[3][3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void box3_walk_kernel(const float* __restrict_
         win[d][1] = load_diag(p0 + sh, qs + sh);
         win[d][2] = load_diag(p0 + sh + 1, qs + sh + 1);
     }
-    for (int i = 0; i < rows; ++i) {
+    for (int i = 0; i < (qs < N ? rows : 0); ++i) {
         const int p = p0 + i, q0 = qs + i;
         f32x4 nxt[3];
 #pragma unroll
@@ -214,11 +218,14 @@ __global__ __launch_bounds__(256) void box3_walk_kernel(const float* __restrict_
         const unsigned ooff = (unsigned)(((long long)p * N + q0) * 4);
         if (q0 >= 0 && q0 + 3 < N) {
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), out_rs, (int)ooff, 0, 0);
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(acc[0]), fabsf(acc[1]))), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if ((unsigned)(q0 + e) < (unsigned)N)
+                if ((unsigned)(q0 + e) < (unsigned)N) {
                     out[((size_t)b * N + p) * N + q0 + e] = acc[e];
+                    amax = fmaxf(amax, fabsf(acc[e]));
+                }
         }
         // one step down the diagonals
 #pragma unroll
@@ -227,6 +234,17 @@ __global__ __launch_bounds__(256) void box3_walk_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (++qx[e] == w) { qx[e] = 0; ++qy[e]; }
+    }
+    // max|out| as a by-product (the consumer of dc_raw, the K3 backward, scales its f16 split with it and would
+    // otherwise read the whole matrix once more).  One value per workgroup into a partial array, no atomics: 5120
+    // same-address atomics serialise into ~50 us at the memory side (measured: they cost what the saved pass cost);
+    // the launcher folds the partials with one tiny max pass.
+    if (out_amax) {
+        const float wmax = wave_max_dpp(amax);
+        if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = wmax;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            out_amax[blockIdx.x] = fmaxf(fmaxf(amax_red[0], amax_red[1]), fmaxf(amax_red[2], amax_red[3]));
     }
 }
 
@@ -346,22 +364,29 @@ extern "C" int cocos_box3_logits_fwd(const float* c_raw, const float* mu, const 
         const int nrb = (int)((N + BX_WR - 1) / BX_WR), nck = (int)((N + BX_WR - 1 + 1023) / 1024);
         COCOS_REQUIRE((long long)nck * nrb * B < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "box3_logits_fwd: grid too large");
         hipLaunchKernelGGL(box3_walk_kernel<false>, dim3((unsigned)(nck * nrb * B)), dim3(256), 0, as_stream(stream),
-                           c_raw, f, mu, nu, a, b, (int)N, h, w, nck, nrb, k_unfolded, scale);
+                           c_raw, f, mu, nu, a, b, (int)N, h, w, nck, nrb, k_unfolded, scale, (float*)nullptr);
     }
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
 
+static size_t box3_walk_blocks(int B, size_t N) {
+    return ((N + cocos::BX_WR - 1 + 1023) / 1024) * ((N + cocos::BX_WR - 1) / cocos::BX_WR) * (size_t)B;
+}
+
 extern "C" size_t cocos_box3_logits_bwd_workspace_bytes(int B, int h, int w) {
     const size_t N = (size_t)h * w;
     const size_t nrb = (N + cocos::BX_RB - 1) / cocos::BX_RB, nchunk = (N + 1023) / 1024;
-    return 2 * (size_t)B * (nrb * N + N * nchunk) * sizeof(float);
+    // row / column partial sums, + one partial maximum per workgroup of the box kernel (the _amax form)
+    return (2 * (size_t)B * (nrb * N + N * nchunk) + box3_walk_blocks(B, N)) * sizeof(float);
 }
 
-extern "C" int cocos_box3_logits_bwd(const float* g, const float* f, const float* mu, const float* nu,
-                                     const float* a, const float* b, float* dc_raw, float* r1, float* r2,
-                                     float* c1, float* c2, void* ws, size_t ws_bytes, int B, int h, int w,
-                                     float scale, cocos_stream_t stream) {
+extern "C" int cocos_absmax_accumulate(const float* x, long long n, float* inout_dev, cocos_stream_t stream);
+
+static int box3_logits_bwd_impl(const float* g, const float* f, const float* mu, const float* nu, const float* a,
+                                const float* b, float* dc_raw, float* r1, float* r2, float* c1, float* c2, void* ws,
+                                size_t ws_bytes, int B, int h, int w, float scale, float* dc_amax_inout,
+                                cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(g && f && mu && nu && a && b && dc_raw && r1 && r2 && c1 && c2, COCOS_ERR_INVALID,
                   "box3_logits_bwd: null pointer");
@@ -378,11 +403,16 @@ extern "C" int cocos_box3_logits_bwd(const float* g, const float* f, const float
     float* c2p = c1p + (size_t)B * nrb * N;
     float* r1p = c2p + (size_t)B * nrb * N;
     float* r2p = r1p + (size_t)B * N * nchunk;
+    float* amax_part = r2p + (size_t)B * N * nchunk;
     COCOS_REQUIRE((long long)nchunk * N * B < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "box3_logits_bwd: grid too large");
     {
         const int nrw = (int)((N + BX_WR - 1) / BX_WR), nck = (int)((N + BX_WR - 1 + 1023) / 1024);
         hipLaunchKernelGGL(box3_walk_kernel<true>, dim3((unsigned)(nck * nrw * B)), dim3(256), 0, s, g, dc_raw, mu, nu,
-                           a, b, (int)N, h, w, nck, nrw, 0.f, scale);
+                           a, b, (int)N, h, w, nck, nrw, 0.f, scale, dc_amax_inout ? amax_part : (float*)nullptr);
+        if (dc_amax_inout) {
+            const int rc = cocos_absmax_accumulate(amax_part, (long long)nck * nrw * B, dc_amax_inout, stream);
+            if (rc != COCOS_OK) return rc;
+        }
     }
     hipLaunchKernelGGL(box3_bwd_reduce_kernel, dim3(nchunk, nrb, B), dim3(256), 0, s, g, f, mu, nu, a, b,
                        r1p, r2p, c1p, c2p, (int)N, nchunk, nrb);
@@ -391,4 +421,22 @@ extern "C" int cocos_box3_logits_bwd(const float* g, const float* f, const float
                        c1, c2, (int)N, nchunk, nrb);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+extern "C" int cocos_box3_logits_bwd(const float* g, const float* f, const float* mu, const float* nu,
+                                     const float* a, const float* b, float* dc_raw, float* r1, float* r2,
+                                     float* c1, float* c2, void* ws, size_t ws_bytes, int B, int h, int w,
+                                     float scale, cocos_stream_t stream) {
+    return box3_logits_bwd_impl(g, f, mu, nu, a, b, dc_raw, r1, r2, c1, c2, ws, ws_bytes, B, h, w, scale, nullptr,
+                                stream);
+}
+
+// Same, and on return *dc_amax_inout = max(*dc_amax_inout, max|dc_raw|) (cell must hold a finite value >= 0).
+extern "C" int cocos_box3_logits_bwd_amax(const float* g, const float* f, const float* mu, const float* nu,
+                                          const float* a, const float* b, float* dc_raw, float* r1, float* r2,
+                                          float* c1, float* c2, void* ws, size_t ws_bytes, int B, int h, int w,
+                                          float scale, float* dc_amax_inout, cocos_stream_t stream) {
+    COCOS_REQUIRE(dc_amax_inout, COCOS_ERR_INVALID, "box3_logits_bwd_amax: null amax cell");
+    return box3_logits_bwd_impl(g, f, mu, nu, a, b, dc_raw, r1, r2, c1, c2, ws, ws_bytes, B, h, w, scale,
+                                dc_amax_inout, stream);
 }

@@ -374,7 +374,9 @@ class _CorrMaterialize(torch.autograd.Function):
         dkn = torch.empty_like(kn) if need_k else None
         if ctx.amax is not None and Nq * Nk >= 4:
             qa, ka = ctx.amax
-            ga = absmax(df)
+            ga = _recall_amax(df)            # left by the kernel that wrote df (K6's backward), else one pass
+            if ga is None:
+                ga = absmax(df)
             _call("corr_materialize_bwd", "cocos_corr_materialize_bwd_f16x3", qn.data_ptr(), kn.data_ptr(),
                   df.data_ptr(), _ptr(dqn), _ptr(dkn), B, K, Nq, Nk, ctx.scale, qa.data_ptr(), ka.data_ptr(),
                   ga.data_ptr(), _stream())
@@ -644,9 +646,17 @@ class _Box3Logits(torch.autograd.Function):
         r1, r2, c1, c2 = (torch.empty((B, N), device=f.device, dtype=torch.float32) for _ in range(4))
         nbytes = _lib.load().cocos_box3_logits_bwd_workspace_bytes(B, h, w)
         ws = torch.empty((nbytes + 3) // 4, device=f.device, dtype=torch.float32)
-        _call("box3_logits_bwd", "cocos_box3_logits_bwd", g.data_ptr(), f.data_ptr(), mu.data_ptr(),
-              nu.data_ptr(), a.data_ptr(), b.data_ptr(), dc.data_ptr(), r1.data_ptr(), r2.data_ptr(),
-              c1.data_ptr(), c2.data_ptr(), ws.data_ptr(), ws.numel() * 4, B, h, w, scale, _stream())
+        if PRECISION == "f16x3":          # max|dc| as a by-product: the K3 backward (the consumer) scales its split with it
+            cell = _zero_cell(dc.device)
+            _call("box3_logits_bwd", "cocos_box3_logits_bwd_amax", g.data_ptr(), f.data_ptr(), mu.data_ptr(),
+                  nu.data_ptr(), a.data_ptr(), b.data_ptr(), dc.data_ptr(), r1.data_ptr(), r2.data_ptr(),
+                  c1.data_ptr(), c2.data_ptr(), ws.data_ptr(), ws.numel() * 4, B, h, w, scale, cell.data_ptr(),
+                  _stream())
+            _remember_amax(dc, cell)
+        else:
+            _call("box3_logits_bwd", "cocos_box3_logits_bwd", g.data_ptr(), f.data_ptr(), mu.data_ptr(),
+                  nu.data_ptr(), a.data_ptr(), b.data_ptr(), dc.data_ptr(), r1.data_ptr(), r2.data_ptr(),
+                  c1.data_ptr(), c2.data_ptr(), ws.data_ptr(), ws.numel() * 4, B, h, w, scale, _stream())
         dmu = -kc * scale * a * r1
         dnu = -kc * scale * b * c1
         da = r2 / a

@@ -299,6 +299,12 @@ int cocos_box3_logits_bwd(const float* g, const float* f, const float* mu, const
                           const float* a, const float* b, float* dc_raw, float* r1, float* r2,
                           float* c1, float* c2, void* ws, size_t ws_bytes, int B, int h, int w,
                           float scale, cocos_stream_t stream);
+/* Same, and on return *dc_amax_inout = max(*dc_amax_inout, max|dc_raw|) (the cell must hold a finite value >= 0): the
+ * scale source of the K3 backward that consumes dc_raw, produced while it is written. */
+int cocos_box3_logits_bwd_amax(const float* g, const float* f, const float* mu, const float* nu,
+                               const float* a, const float* b, float* dc_raw, float* r1, float* r2,
+                               float* c1, float* c2, void* ws, size_t ws_bytes, int B, int h, int w,
+                               float scale, float* dc_amax_inout, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K7  softmax + warp from MATERIALISED, KEY-MAJOR logits (correspondence.py:307 + :318/:334/... and

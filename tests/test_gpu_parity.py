@@ -549,6 +549,25 @@ def test_absmax_and_accumulate(n):
     assert float(cell) == float(xd[:n].abs().max())
 
 
+@pytest.mark.parametrize("B,h,w", [(2, 12, 9), (1, 32, 48)])
+def test_box3_logits_bwd_amax_byproduct(B, h, w, monkeypatch):
+    """K6's backward leaves max|dc_raw| for the K3 backward that consumes it (exact)."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    rs = np.random.RandomState(h + w)
+    N = h * w
+    c = dev(rs.standard_normal((B, N, N)), True)
+    mu, nu = dev(rs.standard_normal((B, N)) * 0.1), dev(rs.standard_normal((B, N)) * 0.1)
+    a, b = dev(rs.uniform(0.5, 2.0, (B, N))), dev(rs.uniform(0.5, 2.0, (B, N)))
+    seen = []
+    c2 = c * 1.0
+    c2.register_hook(lambda g: seen.append((ops._recall_amax(g, consume=False), float(g.abs().max()))))
+    f = ops.box3_logits(c2, mu, nu, a, b, h, w, 2304.0, 100.0)
+    f.backward(dev(rs.standard_normal((B, N, N)) * 1e-3))
+    cell, ref = seen[0]
+    assert cell is not None and float(cell) == ref
+
+
 @pytest.mark.parametrize("B,K,N,mode", [(2, 256, 4096, 1), (1, 64, 100, 1), (2, 37, 50, 1), (2, 32, 64, 0), (1, 16, 8, 2)])
 def test_center_l2norm_bwd_amax_byproduct(B, K, N, mode):
     """K1's backward leaves max|dx| in the caller's cell (fused in the register kernel, a separate pass for the
