@@ -16,108 +16,21 @@
 // Verified against the unfolded formulation to 6e-16 in fp64 (oracle test).  boxdiag
 // is self-adjoint, so the backward uses the SAME kernel on G*a_p*b_q; the remaining gradients are
 // row / column reductions of G and G*f (box3_bwd_reduce).  Both kernels are HBM/L2-bound streaming
-// kernels: each output reads 9 diagonal neighbours (row segments, coalesced, L2-resident: the 64 MiB
-// matrix of a sample fits the 256 MiB Infinity Cache).
+// kernels.
 #include "common.h"
 
 namespace cocos {
 
 // PRE = false (forward):  out = (boxdiag(in) - kc*mu_p*nu_q) * a_p * b_q * post
 // PRE = true  (backward): out = boxdiag(in * a_p * b_q * post)      (weights taken at the SOURCE element)
-template <bool PRE>
-__global__ __launch_bounds__(256) void box3_diag_kernel(const float* __restrict__ in,
-                                                        float* __restrict__ out,
-                                                        const float* __restrict__ mu,
-                                                        const float* __restrict__ nu,
-                                                        const float* __restrict__ av,
-                                                        const float* __restrict__ bv, int N, int h, int w,
-                                                        int nchunk, float kc, float post) {
-    // XCD-aware decode: consecutive rows of one sample must share an XCD, because every output row
-    // re-reads its 8 diagonal neighbour rows (p +- 1, p +- w, p +- w +- 1) and L2 is per XCD — with the
-    // default round-robin placement each XCD streams the whole matrix (measured: 9x the traffic)
-    const int vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int chunk = vb % nchunk;
-    const int p = (vb / nchunk) % N;
-    const int b = vb / (nchunk * N);
-    const int q0 = (chunk * 256 + threadIdx.x) * 4;
-    if (q0 >= N) return;
-    const int py = p / w, px = p - py * w;
-    const __amdgpu_buffer_rsrc_t in_rs = make_rsrc(in + (size_t)b * N * N, (size_t)N * N * 4);
-    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(bv + (size_t)b * N, (size_t)N * 4);
-    const float* a_b = av + (size_t)b * N;
-
-    // per-element validity of the three row taps / three column taps (one division per thread)
-    bool ry[4][3], cx[4][3];
-    {
-        int qy = q0 / w, qx = q0 - qy * w;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                ry[e][d] = (unsigned)(qy + d - 1) < (unsigned)h;
-                cx[e][d] = (unsigned)(qx + d - 1) < (unsigned)w;
-            }
-            if (++qx == w) { qx = 0; ++qy; }
-        }
-    }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            if ((unsigned)(py + dy) >= (unsigned)h || (unsigned)(px + dx) >= (unsigned)w) continue;   // uniform
-            const int sh = dy * w + dx;
-            const int ps = p + sh;
-            // 16-byte load at a 4-byte-aligned address; entries dragged in from outside the row /
-            // matrix are masked below (or come back 0 from the descriptor's bounds check)
-            const long long off = ((long long)ps * N + q0 + sh) * 4;
-            f32x4 x = (off >= 0) ? buf_load4(in_rs, (unsigned)off) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (off < 0) {   // first row(s): the leading elements would sit before the matrix
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    x[e] = (off + 4 * e >= 0) ? buf_load1(in_rs, (unsigned)(off + 4 * e)) : 0.f;
-            }
-            f32x4 wgt = {1.f, 1.f, 1.f, 1.f};
-            if (PRE) {
-                const float as = a_b[ps] * post;
-                const long long boff = (long long)(q0 + sh) * 4;
-                if (boff >= 0) {
-                    wgt = buf_load4(b_rs, (unsigned)boff) * as;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        wgt[e] = as * ((boff + 4 * e >= 0) ? buf_load1(b_rs, (unsigned)(boff + 4 * e)) : 0.f);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[e] += (ry[e][dy + 1] && cx[e][dx + 1]) ? x[e] * wgt[e] : 0.f;
-            }
-        }
-    }
-    if (!PRE) {
-        const float mp = mu[(size_t)b * N + p] * kc, ap = a_b[p] * post;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int q = q0 + e;
-            if (q < N) acc[e] = (acc[e] - mp * nu[(size_t)b * N + q]) * ap * bv[(size_t)b * N + q];
-        }
-    }
-    float* o = out + ((size_t)b * N + p) * N + q0;
-    if (q0 + 3 < N && (N & 3) == 0) {
-        *reinterpret_cast<f32x4*>(o) = acc;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (q0 + e < N) o[e] = acc[e];
-    }
-}
-
-// The same operator, walking DOWN THE DIAGONAL: the nine taps of an output are three runs of three consecutive
+//
+// The operator walks DOWN THE DIAGONAL: the nine taps of an output are three runs of three consecutive
 // elements of three diagonals (one per dy), and the output one step further down the diagonal (p+1, q+1) uses two
 // of each run again.  A thread owns four neighbouring diagonals and walks BX_WR rows down them with a three-deep
-// register window per dy: THREE 16-byte loads per four outputs instead of nine (the first version above is
-// L2-bandwidth-bound on its 9x re-reads: 4.8 GB through L2 for a 0.5 GB matrix).  The validity of a tap belongs
+// register window per dy: THREE 16-byte loads per four outputs instead of nine.  (The first version gave every
+// output its nine taps straight from L2 — one workgroup per matrix row, XCD-aware so that the neighbour rows met
+// in one L2 — and was L2-bandwidth-bound on those re-reads: 4.8 GB through L2 for a 0.5 GB matrix, 0.58 ms.)
+// The validity of a tap belongs
 // to the OUTPUT position ((py+dy, px+dx) and (qy+dy, qx+dx) inside the h x w grid), so masks are applied when a
 // window element is used, not when it is loaded; whatever a load drags in from outside the matrix is masked too.
 constexpr int BX_WR = 32;      // rows per workgroup walk

@@ -294,7 +294,7 @@ static int launch_proj_stream(const float* x, const void* a_hi, const void* a_lo
 }  // namespace cocos
 
 extern "C" int cocos_proj1x1_stream_kpad(int K) {
-    return K >= 1 && K <= 256 ? 256 : K <= 416 ? 416 : 0;
+    return K < 1 ? 0 : K <= 256 ? 256 : K <= 416 ? 416 : 0;
 }
 
 // y[b,m,n] = (sum_k A[m,k] x[b,k,n]) / (a_scale * x_scale) + bias[m]

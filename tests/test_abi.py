@@ -58,6 +58,45 @@ def test_argument_validation_needs_no_gpu(hip_lib):
     assert rc == -1
 
 
+def test_k0_streaming_planners_and_validation_need_no_gpu(hip_lib):
+    """Host-side planning of the K0 streaming kernels: padded k extent of the register-resident weight planes,
+    number of partial tiles of the weight-gradient reduction (0 = shape goes to the general split GEMM), and the
+    argument checks that run before any HIP call."""
+    kpad = hip_lib.cocos_proj1x1_stream_kpad
+    assert [kpad(k) for k in (1, 64, 256, 257, 407, 416, 417, 0, -3)] == [256, 256, 256, 416, 416, 416, 0, 0, 0]
+    parts = hip_lib.cocos_proj1x1_dw_partials_f16x3
+    assert parts(8, 407, 256, 4096) == 128            # the benchmark shape: 16 chunks of 256 positions per image
+    assert parts(8, 256, 256, 4096) == 128
+    assert parts(1, 3, 2, 64) == 1                    # tiny grids: one chunk
+    assert parts(5, 416, 130, 192) == 15              # >= 4 k-steps (64 positions) per chunk
+    assert parts(2, 300, 407, 128) == 0               # more than 256 output channels
+    assert parts(2, 449, 256, 128) == 0               # more than 448 input channels
+    assert parts(1, 5, 3, 21) == 0                    # HW not a multiple of 4
+    one = ctypes.c_void_p(16)
+    f = ctypes.c_float
+    rc = hip_lib.cocos_proj1x1_stream_f16x3(one, one, one, None, None, one, 2, 417, 256, 64, None, None)
+    assert rc == -2 and b"K <= 416" in hip_lib.cocos_last_error_string()
+    rc = hip_lib.cocos_proj1x1_stream_f16x3(one, one, one, None, None, one, 2, 256, 256, 100, None, None)
+    assert rc == -2
+    rc = hip_lib.cocos_proj1x1_stream_f16x3(None, one, one, None, None, one, 2, 256, 256, 64, None, None)
+    assert rc == -1
+    rc = hip_lib.cocos_proj1x1_dw_f16x3(one, one, one, None, one, one, 2, 256, 256, 64, None, None, None)
+    assert rc == -1 and b"go together" in hip_lib.cocos_last_error_string()
+    rc = hip_lib.cocos_proj1x1_dw_f16x3(one, one, one, None, one, None, 2, 256, 300, 64, None, None, None)
+    assert rc == -2
+    rc = hip_lib.cocos_warp_values(one, one, one, 1, 3, 5, 10, 10, 4, None)
+    assert rc == -2 and b"multiple of down" in hip_lib.cocos_last_error_string()
+    rc = hip_lib.cocos_warp_values(None, one, one, 1, 3, 5, 8, 8, 4, None)
+    assert rc == -1
+    rc = hip_lib.cocos_split_f16_rows(one, one, one, 4, 8, 7, f(1.0), None, None, None)
+    assert rc == -1
+    rc = hip_lib.cocos_absmax_accumulate(one, 0, one, None)
+    assert rc == -1
+    rc = hip_lib.cocos_center_l2norm_bwd_amax(one, one, one, one, None, None, 1, 16, 8, 1, f(1e-16), None, None)
+    assert rc == -1 and b"amax" in hip_lib.cocos_last_error_string()
+    assert hip_lib.cocos_box3_logits_bwd_workspace_bytes(8, 64, 64) > 2 * 8 * (256 * 4096 + 4096 * 4) * 4
+
+
 def test_product_path_fails_loudly_on_cpu_tensors(hip_lib):
     from cocosnet_amd import _lib, ops
     x = torch.randn(1, 256, 8)
