@@ -1,0 +1,56 @@
+"""CPU checks of host-side plumbing that carries no arithmetic of its own but decides which device buffers the
+kernels see: the autograd node that splits the row pass's output, the pool of pre-zeroed max|x| cells and the table
+that hands a producer's max|x| to the consumer of the same storage."""
+import torch
+
+from cocosnet_amd import hot_path, ops
+
+
+def test_split_channels_forward_views_and_single_cat_backward():
+    x = torch.randn(2, 7, 5, dtype=torch.float64, requires_grad=True)
+    a, b = hot_path._split_channels(x, 3)
+    assert a.shape == (2, 3, 5) and b.shape == (2, 4, 5)
+    assert torch.equal(a, x[:, :3]) and torch.equal(b, x[:, 3:])
+    ga, gb = torch.randn_like(a), torch.randn_like(b)
+    (a * ga).sum().backward(retain_graph=True)              # only one output used: the other half is zeros
+    assert torch.equal(x.grad[:, :3], ga) and torch.count_nonzero(x.grad[:, 3:]) == 0
+    x.grad = None
+    ((a * ga).sum() + (b * gb).sum()).backward()
+    assert torch.equal(x.grad, torch.cat((ga, gb), 1))
+    # same gradients as plain slicing
+    y = x.detach().clone().requires_grad_(True)
+    ((y[:, :3] * ga).sum() + (y[:, 3:] * gb).sum()).backward()
+    assert torch.equal(x.grad, y.grad)
+
+
+def test_zero_cells_are_distinct_zeroed_and_refilled(monkeypatch):
+    monkeypatch.setattr(ops, "_stream", lambda: 0)
+    monkeypatch.setattr(ops, "_zero_pool", {})
+    dev = torch.device("cpu")
+    cells = [ops._zero_cell(dev) for _ in range(4096 + 3)]    # crosses one refill of the pool
+    assert all(c.shape == (1,) and float(c) == 0.0 for c in cells)
+    ptrs = {c.data_ptr() for c in cells}
+    assert len(ptrs) == len(cells)
+    cells[0].fill_(5.0)                                        # cells are views: writing one leaves the others alone
+    assert float(cells[1]) == 0.0
+
+
+def test_amax_table_is_keyed_by_storage_version_and_consumed_once(monkeypatch):
+    monkeypatch.setattr(ops, "_known_amax", {})
+    t = torch.randn(2, 3, 4)
+    cell = torch.tensor([1.5])
+    ops._remember_amax(t, cell)
+    view = t.reshape(2, 12)                                    # what autograd hands to the next node
+    assert ops._recall_amax(view, consume=False) is cell
+    assert ops._recall_amax(t[:, 1:]) is None                  # a different window of the storage: not it
+    ops._remember_amax(t, cell)
+    assert ops._recall_amax(view) is cell and ops._recall_amax(view) is None     # picked up once
+    ops._remember_amax(t, cell)
+    t.add_(1.0)                                                # modified in place after the producer ran
+    assert ops._recall_amax(t) is None
+    # bounded: two younger entries evict the oldest (and release the tensor it held)
+    a, b, c = (torch.randn(4) for _ in range(3))
+    for x in (a, b, c):
+        ops._remember_amax(x, cell)
+    assert ops._recall_amax(a) is None and ops._recall_amax(b) is cell and ops._recall_amax(c) is cell
+    assert len(ops._known_amax) == 0
