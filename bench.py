@@ -2,6 +2,7 @@
 """Benchmark of the MI355X-native correspondence hot path (driver contract: see README / DESIGN.md).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scope hotpath|netcorr] [--no-cpu-baseline]
+                    [--grad-payload path|netcorr|full] [--no-extras]
 
 A "step" is ONE forward + backward pass of the hot path over one batch of synthetic ADE20k-shaped
 input (BASELINE.json configs[1]: 256x256 images, batch 8 per GPU, 64x64 feature grid, K = 256,
@@ -12,7 +13,11 @@ V = 3 exemplar colours + 151 one-hot labels), inputs already resident in HBM:
     down to the gradients of the theta/phi weights and of the incoming features
     -> (N > 1) RCCL all-reduce of the parameter gradients.
 
-`value` = images/s summed over all ranks (weak scaling: batch 8 per GPU whatever N).
+`value` = images/s summed over all ranks (weak scaling: batch 8 per GPU whatever N).  The same JSON line also
+carries, measured in the same process after the headline window: the exact-fp32-MFMA flavour (`flavours.fp32`), a
+>= 300-step stability window (`stability`), and the CPU baseline (the reference's torch op sequence on all host cores,
+plus the numpy port).  `--grad-payload` sizes the gradient exchange of N > 1 runs like BASELINE config 4 (netCorr's
+59 M or the full G+Corr 156 M fp32 parameters) — the hot path alone exchanges only theta/phi's 0.8 MB.
 `--scope netcorr` times the whole drop-in NoVGGCorrespondence module (feature producers on stock
 PyTorch-ROCm) instead; it is reported for context in DESIGN.md and is not the headline line.
 """
@@ -97,9 +102,9 @@ def make_step(scope, device, match_kernel=1):
     return model, fwd
 
 
-def cpu_baseline(n_images, seed=0):
-    """The oracle (numpy restatement of the reference, fp32, BLAS threads = host cores) timed on a
-    bounded sample of the same workload: forward + backward of the hot path from theta/phi on."""
+def cpu_baseline_numpy(n_images, seed=0):
+    """The numpy oracle (fp32, BLAS threads = host cores) on a bounded sample: forward + backward of the hot path
+    from theta/phi on, batch 1 per call."""
     import numpy as np
     from oracle import corr_oracle as co
     try:
@@ -126,9 +131,141 @@ def cpu_baseline(n_images, seed=0):
         one()
     dt = time.perf_counter() - t0
     return {"value": n_images / dt, "unit": "images/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n_images} images (batch 1 each) of the same workload through oracle/"
-                      f"corr_oracle.py in fp32 numpy: centre+L2norm, correlation, softmax, warp "
-                      f"(Cv=154), and their backward; {dt:.1f} s wall"}
+            "sample": f"{n_images} images (batch 1 each) through oracle/corr_oracle.py in fp32 numpy: centre+L2norm, "
+                      f"correlation, softmax, warp (Cv=154), and their backward; {dt:.1f} s wall"}
+
+
+def cpu_baseline(runs=10, batch=2, seed=0):
+    """The reference's own op sequence for the same workload on the host cores: correspondence.py:272-336 as restated
+    on torch CPU tensors by oracle/torch_ref.py (torch matmul / softmax / avg_pool / interpolate, fp32, materialised
+    f [B,HW,HW] exactly like the reference), theta/phi 1x1 convs included, forward + autograd backward, batch 2,
+    torch.set_num_threads(all cores), median of `runs` after 3 warm-ups."""
+    import statistics
+    from oracle import corr_oracle as co
+    from oracle import torch_ref as tr
+    cores = os.cpu_count() or 1
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        g = torch.Generator().manual_seed(seed)
+        fh = IMG // DOWN
+        cl = KDIM + SEM_NC
+        theta, phi = torch.nn.Conv2d(cl, KDIM, 1), torch.nn.Conv2d(cl, KDIM, 1)
+        cont = torch.randn(batch, cl, fh, fh, generator=g, requires_grad=True)
+        refx = torch.randn(batch, cl, fh, fh, generator=g, requires_grad=True)
+        img = torch.rand(batch, 3, IMG, IMG, generator=g) * 2 - 1
+        lab = torch.randint(0, SEM_NC, (batch, 1, IMG // 16, IMG // 16), generator=g)
+        lab = lab.repeat_interleave(16, 2).repeat_interleave(16, 3)
+        seg = torch.zeros(batch, SEM_NC, IMG, IMG).scatter_(1, lab, 1.0)
+        g_out = torch.randn(batch, 3, IMG, IMG, generator=g)
+        g_mask = torch.randn(batch, SEM_NC, fh, fh, generator=g)
+        opt = co.default_opt(match_kernel=1, PONO_C=True, down=DOWN, warp_mask_losstype="direct")
+
+        def one():
+            for t in (cont, refx, *theta.parameters(), *phi.parameters()):
+                t.grad = None
+            out = tr.hot_path(theta(cont), phi(refx), img, img, seg, seg, opt)
+            torch.autograd.backward([out["warp_out"], out["warp_mask"]], [g_out, g_mask])
+        for _ in range(3):
+            one()
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            one()
+            ts.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(prev)
+    med = statistics.median(ts)
+    return {"value": batch / med, "unit": "images/s", "cores": int(cores), "kind": "port",
+            "sample": f"median of {runs} steps (after 3 warm-ups) of batch {batch}: the reference's torch op sequence "
+                      f"(correspondence.py:272-336 restated in oracle/torch_ref.py, fp32, materialised [B,4096,4096] "
+                      f"correlation) incl. the theta/phi 1x1 convs, forward + autograd backward, "
+                      f"torch.set_num_threads({cores}); {sum(ts):.1f} s of timed CPU work"}
+
+
+HOT_TAGS = ("corr_softmax_warp_fwd", "corr_softmax_warp_bwd_query", "corr_softmax_warp_bwd_key_from_ds",
+            "corr_softmax_warp_bwd_key", "corr_materialize", "corr_materialize_bwd", "logits_softmax_warp_fwd",
+            "logits_softmax_warp_bwd")
+SPLIT_TAGS = ("corr_softmax_warp_fwd", "corr_softmax_warp_bwd_query", "corr_softmax_warp_bwd_key_from_ds")
+#: parameter counts of BASELINE config 4's exchange (SURVEY §8e): theta/phi only (what the hot path owns),
+#: netCorr (59 M), netG + netCorr (156 M)
+PAYLOAD_PARAMS = {"path": 0, "netcorr": 59_000_000, "full": 156_000_000}
+PMC_FILE = {"f16x3": "r02_pmc_f16x3.json", "fp32": "r01_pmc_final.json"}
+PMC_KEY = {"f16x3": {"corr_softmax_warp_fwd": "corr_fwd_f16x3_kernel<5, 1, 0>",
+                     "corr_softmax_warp_bwd_query": "corr_bwd_query_f16x3_kernel<5, 1, 0, 0>",
+                     "corr_softmax_warp_bwd_key_from_ds": "hgemm_f16x3_kernel"},
+           "fp32": {"corr_softmax_warp_fwd": "corr_softmax_warp_fwd_kernel<256, 5, true",
+                    "corr_softmax_warp_bwd_query": "corr_bwd_query_saved_kernel<256, 5, true",
+                    "corr_softmax_warp_bwd_key_from_ds": "sgemm_mfma_kernel<true, true>"}}
+
+
+def kernel_table(kern, precision):
+    """Per-kernel algorithmic TFLOP/s from the live HIP-event times (forward 2*HW^2*(K+Cv), backward
+    split as query side 2*HW^2*(K+Cv) [dP + dqn] and key side 2*HW^2*K [dkn]; no recompute counted)."""
+    N = (IMG // DOWN) ** 2
+    cv = 3 + SEM_NC
+    B = BATCH_PER_GPU
+    alg = {"corr_materialize": 2.0 * N * N * KDIM * B,
+           "corr_materialize_bwd": 4.0 * N * N * KDIM * B,
+           "logits_softmax_warp_fwd": 2.0 * N * N * cv * B,
+           "logits_softmax_warp_bwd": 2.0 * N * N * cv * B,
+           "corr_softmax_warp_fwd": 2.0 * N * N * (KDIM + cv) * B,
+           "corr_softmax_warp_bwd_query": 2.0 * N * N * (KDIM + cv) * B,
+           "corr_softmax_warp_bwd_key_from_ds": 2.0 * N * N * KDIM * B,
+           "corr_softmax_warp_bwd_key": 2.0 * N * N * KDIM * B}
+    # which matrix instruction the three K2 kernels issue: the split-precision flavour computes every
+    # fp32-accurate product with 3 f16 MFMAs (hi*hi + hi*lo + lo*hi), so its roofline is the dense f16 MFMA
+    # peak divided by 3; the other entry points (materialised family) stay on fp32 MFMA
+    split = precision == "f16x3"
+    kernels = {}
+    for tag, flops in alg.items():
+        if tag in kern:
+            ms = kern[tag]["avg_ms"]
+            tf = flops / ms / 1e9
+            kernels[tag] = {"avg_ms": round(ms, 4), "calls": kern[tag]["calls"], "alg_tflops": round(tf, 2),
+                            "frac_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+            if split and tag in SPLIT_TAGS:
+                kernels[tag].update({"mfma": "v_mfma_f32_32x32x16_f16 x3 (f16 hi/lo split, fp32 accumulate)",
+                                     "issued_tflops": round(3 * tf, 1),
+                                     "frac_f16_mfma_peak": round(3 * tf / F16_MFMA_PEAK_TFLOPS, 4)})
+            else:
+                kernels[tag]["mfma"] = "v_mfma_f32_32x32x2_f32"
+    return kernels
+
+
+def roofline_of(kernels, precision):
+    """The `roofline` object of the dominant kernel (longest average launch)."""
+    if not kernels:
+        return None
+    dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+    split = precision == "f16x3"
+    # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
+    # WRITE_SIZE, MI355X_MICROARCH.md), committed under profiles/ — they cannot be read live
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(REPO, "profiles", PMC_FILE[precision])
+    if dom in PMC_KEY[precision] and os.path.exists(pmc_file):
+        for name, rec in json.load(open(pmc_file)).items():
+            if PMC_KEY[precision][dom] in name:
+                traffic = rec["hbm_bytes"]
+                traffic_src = f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes)"
+    if split and dom in SPLIT_TAGS:
+        peak = F16_MFMA_PEAK_TFLOPS / 3.0
+        return {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["alg_tflops"], "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(kernels[dom]["alg_tflops"] / peak, 4), "traffic": traffic,
+                "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                "avg_launch_ms": kernels[dom]["avg_ms"], "issued_tflops": kernels[dom]["issued_tflops"],
+                "vs_fp32_mfma_peak": kernels[dom]["frac_fp32_mfma_peak"],
+                "note": "achieved = ALGORITHMIC fp32 FLOPs per launch / HIP-event time on torch's current stream. Each "
+                        "fp32-accurate product is 3 v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi of f16 hi/lo "
+                        f"operand planes, fp32 accumulate), so peak = dense f16 MFMA peak {F16_MFMA_PEAK_TFLOPS:.0f} / 3; "
+                        f"frac is identical to issued FLOPs / {F16_MFMA_PEAK_TFLOPS:.0f}. vs_fp32_mfma_peak = achieved / "
+                        "157.3 (the exact-fp32 MFMA this kernel replaces; flavours.fp32 in this line is that flavour, "
+                        "same process, same box)."}
+    return {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["alg_tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": kernels[dom]["frac_fp32_mfma_peak"], "traffic": traffic,
+            "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "avg_launch_ms": kernels[dom]["avg_ms"],
+            "note": "algorithmic FLOPs per launch / HIP-event time on torch's current stream; peak = dense fp32 MFMA "
+                    "(v_mfma_f32_32x32x2_f32)"}
 
 
 def main():
@@ -144,9 +281,16 @@ def main():
                     help="where the K2 products run (default: cocosnet_amd.ops.PRECISION, i.e. $COCOS_PRECISION "
                          "or the package default): fp32 = v_mfma_f32_32x32x2_f32, f16x3 = 3-term split on "
                          "v_mfma_f32_32x32x16_f16 (fp32-class accuracy)")
+    ap.add_argument("--grad-payload", choices=tuple(PAYLOAD_PARAMS), default="path",
+                    help="N > 1: size of the per-step gradient all-reduce.  path = theta/phi only (0.8 MB, what the hot "
+                         "path owns); netcorr / full add fp32 stand-in parameters so that the exchange is netCorr's 237 MB "
+                         "or BASELINE config 4's 624 MB (their gradients are written every step, in backward order)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=20,
-                    help="size of the bounded CPU-baseline sample (about 10 s of wall time on the GPU box host)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the second flavour and the stability window (headline window + roofline only)")
+    ap.add_argument("--stability-steps", type=int, default=300)
+    ap.add_argument("--cpu-runs", type=int, default=10, help="timed runs of the torch CPU baseline (batch 2 each)")
+    ap.add_argument("--cpu-images", type=int, default=10, help="images of the numpy CPU baseline (batch 1 each)")
     args = ap.parse_args()
 
     from cocosnet_amd import dist as cdist
@@ -163,127 +307,98 @@ def main():
     torch.cuda.set_device(device)
 
     model, fwd = make_step(args.scope, device, args.match_kernel)
+    # stand-ins for the rest of the replica's parameters (BASELINE config 4): fp32 tensors whose gradients are written
+    # every step by autograd — first in backward order, like the generator's — and exchanged with the real ones
+    extra = []
+    if world > 1 and PAYLOAD_PARAMS[args.grad_payload]:
+        own = sum(p.numel() for p in model.parameters())
+        left = max(PAYLOAD_PARAMS[args.grad_payload] - own, 0)
+        while left > 0:
+            n = min(left, 16 << 20)                      # 64 MiB tensors: one bucket each
+            extra.append(torch.nn.Parameter(torch.zeros(n, device=device)))
+            left -= n
+    params = list(model.parameters()) + extra
     if world > 1:   # identical replicas: broadcast rank 0's parameters once
         for p in model.parameters():
             torch.distributed.broadcast(p.data, 0)
-    buckets = cdist.GradBuckets(model.parameters())
+    # N = 1: no exchange, gradients are plain tensors (p.grad = None per step, as the reference's optimizer.zero_grad
+    # does); N > 1: flat buckets, p.grad views, hook-driven overlap
+    buckets = cdist.GradBuckets(params) if world > 1 else None
     d = build_inputs(device, args.scope)
+    ones = [torch.ones((), device=device) for _ in extra]
 
     def step():
-        for p in model.parameters():
-            p.grad = None
+        if buckets is not None:
+            buckets.zero_grad()
+        else:
+            for p in params:
+                p.grad = None
         for k in ("cont_features", "ref_features"):
             if k in d:
                 d[k].grad = None
         out = fwd(d)
         # backward of the synthetic loss <warp_out, G_out> + <warp_mask, G_mask>: its gradients w.r.t. the two
-        # outputs ARE the fixed tensors G, so they are fed to autograd directly (no loss kernels in the timing)
-        torch.autograd.backward([out["warp_out"], out["warp_mask"]], [d["g_out"], d["g_mask"]])
-        buckets.all_reduce_(world)
+        # outputs ARE the fixed tensors G, so they are fed to autograd directly (no loss kernels in the timing).
+        # Gradient buckets leave for the all-reduce from autograd's hooks, while backward is still running.
+        roots = [out["warp_out"], out["warp_mask"]] + [e.sum() for e in extra]
+        torch.autograd.backward(roots, [d["g_out"], d["g_mask"]] + ones)
+        if buckets is not None:
+            buckets.finish(world)
 
-    for _ in range(args.warmup):
-        step()
     sync = lambda: (torch.distributed.barrier() if world > 1 else None, torch.cuda.synchronize())
-    sync()
-    # Live HIP-event timing inside the timed region, but only around the kernels the roofline is about: every
-    # event is a marker packet that serialises dispatch (~3.5 us); bracketing all ~40 C-ABI calls of a step costs
-    # 8 % of it.  The complete per-call breakdown comes from one extra, untimed step afterwards.
-    hot = ("corr_softmax_warp_fwd", "corr_softmax_warp_bwd_query", "corr_softmax_warp_bwd_key_from_ds",
-           "corr_softmax_warp_bwd_key", "corr_materialize", "corr_materialize_bwd", "logits_softmax_warp_fwd",
-           "logits_softmax_warp_bwd")
-    with ops.KernelTimer(tags=hot) as kt:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+
+    def window(steps, warmup, tags=HOT_TAGS):
+        """W untimed steps, then exactly `steps` timed ones between barrier + synchronize; MAX over ranks."""
+        for _ in range(warmup):
             step()
         sync()
-        dt = time.perf_counter() - t0
-    kern = kt.summary()
+        # Live HIP-event timing inside the timed region, but only around the kernels the roofline is about: every
+        # event is a marker packet that serialises dispatch (~3.5 us); bracketing all ~40 C-ABI calls of a step
+        # costs 8 % of it.  The complete per-call breakdown comes from one extra, untimed step afterwards.
+        with ops.KernelTimer(tags=tags) as kt:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            sync()
+            dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, kt.summary()
+
+    headline_precision = ops.PRECISION
+    dt, kern = window(args.steps, args.warmup)
     with ops.KernelTimer() as kt_all:
         step()
     kern_all = kt_all.summary()
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+
+    # ---- extras, same process / same box, after the headline window (N = 1 only) --------------------------------
+    flavours, stability = {}, None
+    if world == 1 and not args.no_extras and args.scope == "hotpath":
+        sdt, _ = window(args.stability_steps, 0, tags=())
+        stability = {"steps": args.stability_steps, "ms_per_step": round(sdt / args.stability_steps * 1e3, 4),
+                     "images_per_s": round(BATCH_PER_GPU * args.stability_steps / sdt, 1),
+                     "note": "untimed-contract window right after the headline one: no HIP events, same step"}
+        other = "fp32" if headline_precision == "f16x3" else "f16x3"
+        ops.PRECISION = ops.PROJ_PRECISION = other
+        odt, okern = window(args.steps, 3)
+        ok = kernel_table(okern, other)
+        flavours[other] = {"ms_per_step": round(odt / args.steps * 1e3, 4),
+                           "images_per_s": round(BATCH_PER_GPU * args.steps / odt, 1), "steps": args.steps,
+                           "kernels": ok, "roofline": roofline_of(ok, other)}
+        ops.PRECISION = ops.PROJ_PRECISION = headline_precision
 
     if rank == 0:
-        N = (IMG // DOWN) ** 2
-        cv = 3 + SEM_NC
-        B = BATCH_PER_GPU
-        # algorithmic FLOPs per launch (no recompute counted): forward 2*HW^2*(K+Cv),
-        # backward 2*HW^2*(2K+Cv) split as query side 2*HW^2*(K+Cv) [dP + dqn], key side 2*HW^2*K [dkn]
-        alg = {"corr_materialize": 2.0 * N * N * KDIM * B,
-               "corr_materialize_bwd": 4.0 * N * N * KDIM * B,
-               "logits_softmax_warp_fwd": 2.0 * N * N * cv * B,
-               "logits_softmax_warp_bwd": 2.0 * N * N * cv * B,
-               "corr_softmax_warp_fwd": 2.0 * N * N * (KDIM + cv) * B,
-               "corr_softmax_warp_bwd_query": 2.0 * N * N * (KDIM + cv) * B,
-               "corr_softmax_warp_bwd_key_from_ds": 2.0 * N * N * KDIM * B,
-               "corr_softmax_warp_bwd_key": 2.0 * N * N * KDIM * B}
-        # which matrix instruction the three K2 kernels issue: the split-precision flavour computes every
-        # fp32-accurate product with 3 f16 MFMAs (hi*hi + hi*lo + lo*hi), so its roofline is the dense f16 MFMA
-        # peak divided by 3; the other entry points (materialised family, K0) stay on fp32 MFMA
-        split = ops.PRECISION == "f16x3"
-        split_tags = ("corr_softmax_warp_fwd", "corr_softmax_warp_bwd_query", "corr_softmax_warp_bwd_key_from_ds")
-        kernels = {}
-        for tag, flops in alg.items():
-            if tag in kern:
-                ms = kern[tag]["avg_ms"]
-                tf = flops / ms / 1e9
-                kernels[tag] = {"avg_ms": round(ms, 4), "calls": kern[tag]["calls"], "alg_tflops": round(tf, 2),
-                                "frac_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
-                if split and tag in split_tags:
-                    kernels[tag].update({"mfma": "v_mfma_f32_32x32x16_f16 x3 (f16 hi/lo split, fp32 accumulate)",
-                                         "issued_tflops": round(3 * tf, 1),
-                                         "frac_f16_mfma_peak": round(3 * tf / F16_MFMA_PEAK_TFLOPS, 4)})
-                else:
-                    kernels[tag]["mfma"] = "v_mfma_f32_32x32x2_f32"
-        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"]) if kernels else None
+        split = headline_precision == "f16x3"
+        kernels = kernel_table(kern, headline_precision)
+        roofline = roofline_of(kernels, headline_precision)
         # device time of EVERY C-ABI call per step (ms), so the part of the step outside the three big kernels is visible
         per_step = {tag: round(rec["total_ms"], 4) for tag, rec in sorted(kern_all.items())}
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 +
-        # WRITE_SIZE, MI355X_MICROARCH.md), committed under profiles/ — they cannot be read live
-        traffic, traffic_src = None, None
-        pmc_file = os.path.join(REPO, "profiles", "r01_pmc_f16x3.json" if split else "r01_pmc_final.json")
-        pmc_key = ({"corr_softmax_warp_fwd": "corr_fwd_f16x3_kernel<5, 1, 0>",
-                    "corr_softmax_warp_bwd_query": "corr_bwd_query_f16x3_kernel<5, 1, 0, 0>",
-                    "corr_softmax_warp_bwd_key_from_ds": "hgemm_f16x3_kernel"} if split else
-                   {"corr_softmax_warp_fwd": "corr_softmax_warp_fwd_kernel<256, 5, true",
-                    "corr_softmax_warp_bwd_query": "corr_bwd_query_saved_kernel<256, 5, true",
-                    "corr_softmax_warp_bwd_key_from_ds": "sgemm_mfma_kernel<true, true>"})
-        if dom in pmc_key and os.path.exists(pmc_file):
-            for name, rec in json.load(open(pmc_file)).items():
-                if pmc_key[dom] in name:
-                    traffic = rec["hbm_bytes"]
-                    traffic_src = f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes)"
-        roofline = None
-        if dom and split and dom in split_tags:
-            peak = F16_MFMA_PEAK_TFLOPS / 3.0
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["alg_tflops"],
-                        "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(kernels[dom]["alg_tflops"] / peak, 4), "traffic": traffic,
-                        "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                        "avg_launch_ms": kernels[dom]["avg_ms"],
-                        "issued_tflops": kernels[dom]["issued_tflops"],
-                        "vs_fp32_mfma_peak": kernels[dom]["frac_fp32_mfma_peak"],
-                        "note": "achieved = ALGORITHMIC fp32 FLOPs per launch / HIP-event time on torch's current "
-                                "stream. Each fp32-accurate product is 3 v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + "
-                                "lo*hi of f16 hi/lo operand planes, fp32 accumulate), so peak = dense f16 MFMA peak "
-                                f"{F16_MFMA_PEAK_TFLOPS:.0f} / 3; frac is identical to issued FLOPs / {F16_MFMA_PEAK_TFLOPS:.0f}. "
-                                "Sustained chip-wide issue ceiling measured by tools/probes/f16x3_rate: ~1550 TFLOP/s "
-                                "(power), i.e. 0.62 of nominal. vs_fp32_mfma_peak = achieved / 157.3 (the exact-fp32 "
-                                "MFMA this kernel replaces; --precision fp32 runs that flavour)."}
-        elif dom:
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["alg_tflops"],
-                        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": kernels[dom]["frac_fp32_mfma_peak"], "traffic": traffic,
-                        "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                        "avg_launch_ms": kernels[dom]["avg_ms"],
-                        "note": "algorithmic FLOPs per launch / HIP-event time on torch's current "
-                                "stream; peak = dense fp32 MFMA (v_mfma_f32_32x32x2_f32)"}
         cpu = None
         if not args.no_cpu_baseline and world == 1:   # reported at N=1 only (bounded sample)
-            cpu = cpu_baseline(args.cpu_images)
+            cpu = cpu_baseline(args.cpu_runs)
+            cpu["numpy_port"] = cpu_baseline_numpy(args.cpu_images)
         images = BATCH_PER_GPU * world * args.steps
         line = {
             "metric": "images/sec fwd+bwd ADE20k 256x256 batch-8/GPU (correspondence hot path)",
@@ -294,13 +409,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"ADE20k 256x256 batch {BATCH_PER_GPU}/GPU, 64x64 grid (HW=4096), K=256, "
                                    f"Cv=154 (rgb+151 labels), match_kernel {args.match_kernel}, PONO_C, T=0.01; "
-                                   f"precision={ops.PRECISION}; scope={args.scope}: "
+                                   f"precision={headline_precision}; scope={args.scope}: "
                                    + ("theta/phi 1x1 conv + centre/L2norm + fused corr-softmax-warp fwd+bwd"
                                       if args.scope == "hotpath" else
                                       "whole NoVGGCorrespondence module fwd+bwd (producers on PyTorch-ROCm)"),
                        "global_batch": BATCH_PER_GPU * world, "parallelism": f"dp{world}",
-                       "grad_allreduce_bytes": buckets.nbytes() if world > 1 else 0},
-            "roofline": roofline, "kernels": kernels, "abi_calls_ms_per_step": per_step, "cpu_baseline": cpu,
+                       "grad_payload": args.grad_payload,
+                       "grad_allreduce_bytes": buckets.nbytes() if buckets is not None else 0,
+                       "grad_allreduce": "bucketed (64 MiB), launched from post-accumulate-grad hooks during backward, "
+                                         "in place on flat fp32 gradient buffers" if world > 1 else None},
+            "roofline": roofline, "kernels": kernels, "abi_calls_ms_per_step": per_step,
+            "flavours": flavours, "stability": stability, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -83,14 +83,17 @@ _SIGNATURES = {
     "cocos_pono_spade_bwd": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [_stream_t]),
     "cocos_split_f16": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4
                         + [ctypes.c_float, _stream_t]),
-    "cocos_corr_softmax_warp_fwd_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 6 + [_c_float_p] * 3 + [ctypes.c_int] * 5
-                                          + [ctypes.c_float, ctypes.c_float, _stream_t]),
+    "cocos_corr_softmax_warp_saved_logits_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "cocos_corr_softmax_warp_fwd_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 6 + [_c_float_p] * 2 + [ctypes.c_void_p,
+                                                                                                 _c_float_p]
+                                          + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_float, _stream_t]),
     "cocos_split_f16_ex": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5
                            + [ctypes.c_float, _c_float_p, _c_float_p, _stream_t]),
     "cocos_split_f16_rows": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3
                              + [ctypes.c_float, _c_float_p, _c_float_p, _stream_t]),
-    "cocos_corr_softmax_warp_bwd_query_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 6 + [_c_float_p] * 6
-                                                + [ctypes.c_void_p] * 4 + [_c_float_p] * 2 + [ctypes.c_int] * 6
+    "cocos_corr_softmax_warp_bwd_query_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 6 + [_c_float_p] * 4
+                                                + [ctypes.c_void_p, _c_float_p]
+                                                + [ctypes.c_void_p] * 4 + [_c_float_p] * 3 + [ctypes.c_int] * 6
                                                 + [ctypes.c_float, ctypes.c_float, ctypes.c_int, _stream_t]),
     "cocos_hgemm_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 4 + [_c_float_p] + [ctypes.c_int] * 4
                           + [ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_int, _stream_t]),
@@ -112,8 +115,8 @@ _SIGNATURES = {
     "cocos_corr_materialize_bwd_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_float]
                                          + [_c_float_p] * 3 + [_stream_t]),
     "cocos_logits_softmax_warp_fwd_f16x3": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p,
-                                                           _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),
-    "cocos_logits_softmax_warp_bwd_f16x3": (ctypes.c_int, [_c_float_p] + [ctypes.c_void_p] * 4 + [_c_float_p] * 5
+                                                           _c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),
+    "cocos_logits_softmax_warp_bwd_f16x3": (ctypes.c_int, [_c_float_p] + [ctypes.c_void_p] * 4 + [_c_float_p] * 6
                                             + [ctypes.c_int] * 5 + [_stream_t]),
     "cocos_unfold3_stats_fwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_float] * 2 + [_stream_t]),
     "cocos_unfold3_stats_bwd": (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float, _stream_t]),

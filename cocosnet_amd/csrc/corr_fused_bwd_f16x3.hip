@@ -4,17 +4,31 @@
 // dS^T matrix the key-side GEMM consumes), with both per-tile products on v_mfma_f32_32x32x16_f16 and
 // every fp32 operand carried as f16 hi + lo (three MFMA terms per product, fp32 accumulate; see
 // corr_fused_fwd_f16x3.hip for the arithmetic argument):
-//     dP'(t)  = V(t) . dO'                  A = V tile rows (keys) x 16 channels, B = resident dO' slice
-//     dS''(t) = P(t) * (dP'(t) - D') * c     P from the saved logits, D' = s_o * sum_c dO*out (fp64)
+//     dP'(t)  = V'(t) . dO'                 A = V tile rows (keys) x 16 channels, B = resident dO' slice
+//     dS''(t) = P(t) * (dP'(t) - D') * c     P from the saved logits, D' = s_o * s_v * sum_c dO*out (fp64)
 //     dqn    += K(t) . dS''(t)               A = key tile rows (channels) x 16 permuted keys, B = dS''
 // Scaled domains (all powers of two, exact, undone in the epilogue / by the GEMM):
 //     dO' = s_o * dO   with s_o = 2^e from the tensor's |max| (device scalar written by cocos_split_f16_ex),
-//     dS'' = s_o * ds_shift * dS  with ds_shift = the power of two that keeps the worst case
-//            2 * CVP * 2^10 * max|v| * inv_t  below 2^15 (computed here from the device-side max|v|; the product
-//            s_o * ds_shift is written to `ds_scale_out` for the GEMM to undo),
+//     V'  = s_v * V    likewise (V has no a-priori magnitude in a general forward() call; NULL pointer = 1),
+//     dS'' = s_o * s_v * ds_shift * dS  with ds_shift = the power of two that keeps the worst case
+//            2 * CVP * 2^10 * max|V'| * inv_t  below 2^15 (computed here from the device-side max|v|; the product
+//            s_o * s_v * ds_shift is written to `ds_scale_out` for the GEMM to undo),
 //     K planes = k_scale * kn.
 // The dS'' planes (f16 hi/lo, [B,Nk,Nq]) replace the fp32 dS^T/T matrix of the fp32 path: same bytes,
 // already in the operand format of the f16x3 key-side GEMM (hgemm_f16x3.hip).
+//
+// Schedule (round 2).  A wave is alone on its SIMD (Q-side residents + accumulators = ~430 registers), so
+// nothing but the instruction order overlaps the matrix pipe with the rest.  Round 1 ran, per 32-key tile,
+// [30 MFMAs of dP'] -> [~150 VALU: exp, dS, f16 split; no MFMA] -> [48 MFMAs of dqn]; the VALU stretch and the
+// pipeline drain around it left the matrix pipe idle for ~1/4 of the tile.  Now the tile loop is skewed by one
+// stage: iteration t issues the dP' MFMAs of tile t, then the dqn MFMAs of tile t-1 with the VALU work of tile
+// t sliced into their gaps (one accumulator register per MFMA step: the two are independent, so the in-order
+// wave keeps the matrix pipe busy while the VALU runs).  Costs 32 more registers (dS'' operands and logits
+// double-buffered, all statically named: the loop is unrolled by two).
+// The saved logits arrive in the forward's private tile-blocked layout: four 16-byte loads per lane and tile
+// (fully contiguous 1 KB per instruction) instead of sixteen 4-byte ones, requested a whole iteration ahead.
+#include <type_traits>
+
 #include "common.h"
 
 namespace cocos {
@@ -35,12 +49,6 @@ __device__ __forceinline__ u32x4 bq_load16(__amdgpu_buffer_rsrc_t r, unsigned of
 __device__ __forceinline__ u32x4 bq_load16s(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, (int)soff, 0);
 }
-__device__ __forceinline__ void bq_split_pair(float a, float b, f16x2& hi, f16x2& lo) {
-    unsigned h, l;
-    split_pair_rtz(a, b, h, l);
-    hi = __builtin_bit_cast(f16x2, h);
-    lo = __builtin_bit_cast(f16x2, l);
-}
 
 #ifdef COCOS_DEBUG_TIMING
 __device__ long long g_phase_bq_h[8];
@@ -53,19 +61,25 @@ __device__ long long g_phase_bq_h[8];
 
 constexpr float kPPlaneScale = 16384.0f;   // P in [0,1] -> planes of 2^14 * P (top of f16's range: floor 2^-38)
 
+// one tile's dS'' (and optionally P) as MFMA B operands / packed store words
+struct DsRegs {
+    unsigned hw[8], lw[8];     // f16 hi / lo, two values per register: register j>>1, half j&1
+};
+
 template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED>
 __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     const _Float16* __restrict__ kch, const _Float16* __restrict__ kcl,   // [B,256,Nk] planes of k_scale*kn
-    const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] planes of v
+    const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] planes of s_v*v
     const _Float16* __restrict__ gph, const _Float16* __restrict__ gpl,   // [B,Nq,CVP] planes of s_o*dout
     const float* __restrict__ g_scale,                                     // s_o (device)
     const float* __restrict__ outp, const float* __restrict__ dout,        // [B,Cv,Nq] fp32 (for D)
-    const float* __restrict__ lse, const float* __restrict__ lg,           // [B,Nq], [B,Nk,Nq]
+    const float* __restrict__ lse, const float* __restrict__ lg,           // [B,Nq]; saved logits (blocked, see fwd)
     float* __restrict__ dqn,                                               // out [B,256,Nq]
     _Float16* __restrict__ dsh, _Float16* __restrict__ dsl,                // out [B,Nk,Nq] planes of dS''
     _Float16* __restrict__ psh, _Float16* __restrict__ psl,                // out [B,Nk,Nq] planes of 2^14 P (STORE_P)
     const float* __restrict__ v_amax,                                      // max|v| (device)
-    float* __restrict__ ds_scale_out,                                      // out: s_o * ds_shift (device)
+    const float* __restrict__ v_scale,                                     // s_v (device) or NULL
+    float* __restrict__ ds_scale_out,                                      // out: s_o * s_v * ds_shift (device)
     int B, int Nq, int Nk, int Cv, float inv_t, float k_scale, int planes_blocked) {
     constexpr int CVP = CVB * 32;
     constexpr int CVS = CVP / 16;                     // k-steps of the dP product
@@ -75,8 +89,12 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* const vt = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][32 keys][VROW]
     _Float16* const kt = vt + 2 * 2 * VPLANE;                      // [2 buf][hi|lo][256 ch][KROW]
-    // per-wave transposition buffer for the dS'' stores: [hi|lo][32 keys][32 queries + 8 pad]
-    constexpr int DSROW = 40, DSPLANE = 32 * DSROW;
+    // per-wave transposition buffer for the dS'' stores: [hi|lo][32 keys][32 queries].  Rows of exactly 64 B: the
+    // 16-byte read-back of a b128 lane group touches rows {0,3,5,6} / {1,2,4,7} (+8..), i.e. 16-dword windows at
+    // dwords {0,48,16,32} of the 64-bank row — conflict-free (the 80-byte rows of round 1 were 2-way: 8.4 M conflict
+    // cycles per launch); the 2-byte writes of one register go to two rows 4 apart from the two half-waves, which
+    // are separate lane groups.
+    constexpr int DSROW = 32, DSPLANE = 32 * DSROW;
     _Float16* const dstile = kt + 2 * 2 * KPLANE + (threadIdx.x >> 6) * 2 * DSPLANE;
 
     const int tid = threadIdx.x;
@@ -88,6 +106,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     const int b = vb / nqb, q0 = (vb % nqb) * 128;
     const int i_lane = q0 + wave * 32 + c;
     const bool live = i_lane < Nq;
+    const int ntiles = (Nk + 31) / 32;
 
     const size_t kbytes = (size_t)BQH_KD * Nk * 2, vbytes = (size_t)Nk * CVP * 2, gbytes = (size_t)Nq * CVP * 2;
     const __amdgpu_buffer_rsrc_t kh_rs = make_rsrc(kch + (size_t)b * BQH_KD * Nk, kbytes);
@@ -98,7 +117,11 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     const __amdgpu_buffer_rsrc_t gl_rs = make_rsrc(gpl + (size_t)b * Nq * CVP, gbytes);
     const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(outp + (size_t)b * Cv * Nq, (size_t)Cv * Nq * 4);
     const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(dout + (size_t)b * Cv * Nq, (size_t)Cv * Nq * 4);
-    const __amdgpu_buffer_rsrc_t lg_rs = make_rsrc(lg + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
+    // saved logits: per sample ntiles x nqblk blocks of 4 KB = [k = 0..3][lane][4 accumulator registers]
+    const int nqblk = (Nq + 31) / 32;
+    const size_t lg_bytes = (size_t)ntiles * nqblk * 4096;
+    const __amdgpu_buffer_rsrc_t lg_rs = make_rsrc(reinterpret_cast<const char*>(lg) + (size_t)b * lg_bytes, lg_bytes);
+    const unsigned lg_lane_off = live ? (unsigned)(((q0 >> 5) + wave) * 4096 + lane * 16) : kBufOob;
     const __amdgpu_buffer_rsrc_t dh_rs = make_rsrc(STORE_DS ? dsh + (size_t)b * Nk * Nq : nullptr,
                                                    STORE_DS ? (size_t)Nk * Nq * 2 : 0);
     const __amdgpu_buffer_rsrc_t dl_rs = make_rsrc(STORE_DS ? dsl + (size_t)b * Nk * Nq : nullptr,
@@ -107,18 +130,16 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
                                                    STORE_P ? (size_t)Nk * Nq * 2 : 0);
     const __amdgpu_buffer_rsrc_t pl_rs = make_rsrc(STORE_P ? psl + (size_t)b * Nk * Nq : nullptr,
                                                    STORE_P ? (size_t)Nk * Nq * 2 : 0);
-    // [Nk][Nq] matrices: lane offset = query column + the half-wave's 4 rows; the tile/register part of
-    // the row index is wave-uniform and travels in the scalar offset (not bounds-checked: see fetch_s)
-    const unsigned sr_lane_off = live ? (unsigned)(4 * h * Nq + i_lane) * 4u : kBufOob;
 
-    const float s_o = *g_scale;
+    const float s_v = v_scale ? *v_scale : 1.0f;
+    const float s_ov = *g_scale * s_v;                 // scale of dP' = V' . dO'
     float ds_shift;
     {
-        const float bound = 2.0f * CVP * 1024.0f * fmaxf(*v_amax, 1e-30f) * inv_t;   // >= |dP' - D'| * inv_t
+        const float bound = 2.0f * CVP * 1024.0f * fmaxf(*v_amax * s_v, 1e-30f) * inv_t;   // >= |dP' - D'| * inv_t
         int e;
         frexpf(bound * (1.0f / 32768.0f), &e);                                          // 2^e > bound / 2^15
         ds_shift = ldexpf(1.0f, -min(max(e, -20), 60));
-        if (ds_scale_out && blockIdx.x == 0 && tid == 0) *ds_scale_out = s_o * ds_shift;
+        if (ds_scale_out && blockIdx.x == 0 && tid == 0) *ds_scale_out = s_ov * ds_shift;
     }
 
     // ---- resident: dO' slice (B operand of dP'), D' and lse of the lane's query ---------------------
@@ -148,10 +169,15 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
         }
         const int lo = __shfl_xor((int)__double2loint(dacc), 32, 64);
         const int hi = __shfl_xor((int)__double2hiint(dacc), 32, 64);
-        d_lane = (float)((dacc + __hiloint2double(hi, lo)) * (double)s_o);
+        d_lane = (float)((dacc + __hiloint2double(hi, lo)) * (double)s_ov);
     }
-    const float lse2 = live ? lse[(size_t)b * Nq + i_lane] * kLog2e : INFINITY;   // padded lanes: P = 0
+    // P * cs in ONE exponential: the factor cs = inv_t * ds_shift of dS'' rides in the exponent,
+    //   p_c = 2^(raw * scale_log2 - (lse * log2 e - log2 cs)),   dS'' = p_c * (dP' - D')
+    // (raw = the forward's accumulator, k_scale^2 * cos; padded lanes: lse2c = +inf -> p_c = 0)
     const float cs = inv_t * ds_shift;
+    const float scale_log2 = inv_t * kLog2e / (k_scale * k_scale);
+    const float nlse2c = live ? log2f(cs) - lse[(size_t)b * Nq + i_lane] * kLog2e : -INFINITY;
+    const float p_from_pc = kPPlaneScale / cs;        // STORE_P: 2^14 * P = p_c * (2^14 / cs)
 
     f32x16 dx[KB];
 #pragma unroll
@@ -196,13 +222,13 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             }
         }
     };
+    // keys 8k8..8k8+3 and 8k8+4..8k8+7 -> k-slots of the dqn MFMA: the accumulator registers of dS''
+    // are the B operand, register 8t+j of half-wave hh <-> key 16t + 8(j>>2) + 4hh + (j&3)
     auto commit_k = [&](int buf) {
         _Float16* base = kt + buf * 2 * KPLANE;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int g = u * 256 + tid, row = g >> 2, k8 = g & 3;
-            // keys 8k8..8k8+3 and 8k8+4..8k8+7 -> k-slots of the dqn MFMA: the accumulator registers of dS''
-            // are the B operand, register 8t+j of half-wave hh <-> key 16t + 8(j>>2) + 4hh + (j&3)
             const int kq = 2 * k8;                                       // first 4-key group (kq even)
             const int slot0 = 16 * (kq >> 2) + 4 * ((kq >> 1) & 1);     // hh = 0
             _Float16* d = base + row * BQH_KROW;
@@ -229,232 +255,241 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
         k_voff[u] = (unsigned)(row * Nk + 8 * k8) * 2u;
         k_lds[u] = row * BQH_KROW + 16 * (kq >> 2) + 4 * ((kq >> 1) & 1);
     }
-    float sld[16];
-    auto fetch_s = [&](int j0) {
+    // logits of tile tt (clamped to the last tile: look-ahead loads past the end are harmless re-reads),
+    // register group k (accumulator registers 4k..4k+3): one contiguous 1 KB per wave-instruction
+    auto load_s = [&](f32x4& dst, int tt, int k) {
+        const int tc = min(tt, ntiles - 1);
+        dst = __builtin_bit_cast(f32x4, bq_load16s(lg_rs, lg_lane_off, (unsigned)(tc * nqblk) * 4096u + (unsigned)k * 1024u));
+    };
+
+    // one staged piece of the V tile (i < 2*VPT) or of the K tile (2*VPT <= i < 2*VPT + 8) to LDS, and the reload of
+    // its register with the tile after: V(tv) -> vt[bufv], then V(tv + 1) requested; K(tk) -> kt[bufk], then K(tk + 1)
+    auto stage_piece = [&](int i, int tv, int tk) {
+        _Float16* const vw = vt + (tv & 1) * 2 * VPLANE;
+        _Float16* const kw = kt + (tk & 1) * 2 * KPLANE;
+        if (i < 2 * VPT) {
+            const int pl_ = i & 1, u = i >> 1;
+            if (!RAGGED) {
+                const int jn = min((tv + 1) * 32, Nk - 32);
+                if (u * 256 + 255 < VCH || u * 256 + tid < VCH)
+                    *reinterpret_cast<u32x4*>(vw + pl_ * VPLANE + v_lds[u]) = vst[pl_][u];
+                vst[pl_][u] = bq_load16s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jn * (unsigned)(CVP * 2));
+            } else {
+                const int jn = (tv + 1) * 32;
+                const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
+                if (g < VCH) *reinterpret_cast<u32x4*>(vw + pl_ * VPLANE + key * VROW + cc * 8) = vst[pl_][u];
+                vst[pl_][u] = bq_load16(pl_ ? vl_rs : vh_rs,
+                                        g < VCH ? (unsigned)((jn + key) * CVP + cc * 8) * 2u : kBufOob);
+            }
+        } else if (i - 2 * VPT < 8) {
+            const int pl_ = (i - 2 * VPT) & 1, u = (i - 2 * VPT) >> 1;
+            if (!RAGGED) {
+                const int jn = min((tk + 1) * 32, Nk - 32);
+                _Float16* d = kw + pl_ * KPLANE + k_lds[u];
+                *reinterpret_cast<u32x2*>(d) = u32x2{kst[pl_][u].x, kst[pl_][u].y};
+                *reinterpret_cast<u32x2*>(d + 8) = u32x2{kst[pl_][u].z, kst[pl_][u].w};
+                kst[pl_][u] = bq_load16s(pl_ ? kl_rs : kh_rs, k_voff[u], (unsigned)jn * 2u);
+            } else {
+                const int jn = (tk + 1) * 32;
+                const int g = u * 256 + tid, row = g >> 2, k8 = g & 3;
+                const int kq = 2 * k8, slot0 = 16 * (kq >> 2) + 4 * ((kq >> 1) & 1);
+                _Float16* d = kw + pl_ * KPLANE + row * BQH_KROW;
+                *reinterpret_cast<u32x2*>(d + slot0) = u32x2{kst[pl_][u].x, kst[pl_][u].y};
+                *reinterpret_cast<u32x2*>(d + slot0 + 8) = u32x2{kst[pl_][u].z, kst[pl_][u].w};
+                unsigned off = (unsigned)(row * Nk + jn + 8 * k8) * 2u;
+                if (jn + 8 * k8 >= Nk) off = kBufOob;
+                kst[pl_][u] = bq_load16(pl_ ? kl_rs : kh_rs, off);
+            }
+        }
+    };
+    static_assert(2 * VPT + 8 <= 3 * CVS / 2 + 16, "staging pieces must fit the MFMA steps of an iteration");
+
+    // ---- dP'(t) = V'(t) . dO' : CVS steps of 3 MFMAs; staging pieces ride in the gaps ------------------------
+    // STAGE_K: the K tile of `t` goes to LDS as well (not in the first iteration: K(0) is committed by the prologue)
+    auto phase_dp = [&](f32x16& dp0, int t, auto stage_k) {
+        constexpr bool STAGE_K = decltype(stage_k)::value;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int jr = j0 + acc_row_base(r);
-            // the scalar offset is NOT bounds-checked: rows that do not exist are switched off through the
-            // per-lane offset (which must not make the scalar part lane-dependent: waterfall loops)
-            sld[r] = buf_load1s(lg_rs, (jr + 4 * h < Nk) ? sr_lane_off : kBufOob, (unsigned)jr * (unsigned)Nq * 4u);
+        for (int r = 0; r < 16; ++r) dp0[r] = 0.f;
+        const _Float16* vb0 = vt + (t & 1) * 2 * VPLANE + c * VROW + h * 8;
+        f16x8 ah[2], al[2];
+        ah[0] = *reinterpret_cast<const f16x8*>(vb0);
+        al[0] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE);
+        // (2*VPT + 8) pieces over CVS steps
+        constexpr int NP = 2 * VPT + (STAGE_K ? 8 : 0);
+        constexpr int PER = (NP + CVS - 1) / CVS;
+#pragma unroll
+        for (int u = 0; u < CVS; ++u) {
+            const int cur = u & 1, nxt = cur ^ 1;
+            if (u + 1 < CVS) {
+                ah[nxt] = *reinterpret_cast<const f16x8*>(vb0 + (u + 1) * 16);
+                al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
+            }
+            dp0 = bq_mfma(ah[cur], goh[u], dp0);
+            dp0 = bq_mfma(ah[cur], gol[u], dp0);
+            dp0 = bq_mfma(al[cur], goh[u], dp0);
+#pragma unroll
+            for (int q = 0; q < PER; ++q)
+                if (u * PER + q < NP) stage_piece(u * PER + q, t + 1, t);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    const int ntiles = (Nk + 31) / 32;
-    fetch_v(0);
-    fetch_k(0);
-    fetch_s(0);
-    commit_v(0);
-    commit_k(0);
-    fetch_v(32);
-    fetch_k(32);
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const int j0 = t * 32, buf = t & 1;
-
-        BPH_T(tp0);
-        // ---- dP' = V(t) . dO' -----------------------------------------------------------------------------
-        f32x16 dp0;     // one accumulator for the three terms of a product (fp32 adds either way)
+    // ---- VALU slice r of tile t: dS''[r] from logit register r; pairs are split to f16 hi/lo at odd r ----------
+    auto valu_slice = [&](int r, int t, const f32x4 (&s)[4], const f32x16& dp0, float (&dsv)[2], float (&pv)[2],
+                          DsRegs& out, DsRegs& pout) {
+        float pc = fast_exp2(__builtin_fmaf(s[r >> 2][r & 3], scale_log2, nlse2c));
+        if (RAGGED && (t * 32 + acc_row_base(r) + 4 * h >= Nk)) pc = 0.f;
+        dsv[r & 1] = pc * (dp0[r] - d_lane);
+        if (STORE_P) pv[r & 1] = pc * p_from_pc;
+        if (r & 1) {
+            split_pair_rtz(dsv[0], dsv[1], out.hw[r >> 1], out.lw[r >> 1]);
+            if (STORE_P) split_pair_rtz(pv[0], pv[1], pout.hw[r >> 1], pout.lw[r >> 1]);
+        }
+        if (STORE_DS && (r & 1)) {
+            // dS'' goes to HBM as 16-byte row pieces: each lane holds one QUERY column (16 keys), the matrix is
+            // [key][query] — the wave transposes its 32x32 tile through its private LDS buffer (2-byte writes here,
+            // 4 b128 reads + 4 b128 global stores after the last slice)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dp0[r] = 0.f;
-        {
-            const _Float16* vb0 = vt + buf * 2 * VPLANE + c * VROW + h * 8;
-            f16x8 ah[2], al[2];
-            ah[0] = *reinterpret_cast<const f16x8*>(vb0);
-            al[0] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE);
-#pragma unroll
-            for (int u = 0; u < CVS; ++u) {
-                const int cur = u & 1, nxt = cur ^ 1;
-                if (u + 1 < CVS) {
-                    ah[nxt] = *reinterpret_cast<const f16x8*>(vb0 + (u + 1) * 16);
-                    al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
-                }
-                dp0 = bq_mfma(ah[cur], goh[u], dp0);
-                dp0 = bq_mfma(ah[cur], gol[u], dp0);
-                dp0 = bq_mfma(al[cur], goh[u], dp0);
+            for (int e = 0; e < 2; ++e) {
+                const int rr = r - 1 + e, key = acc_row_base(rr) + 4 * h;
+                dstile[key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(out.hw[r >> 1] >> (16 * e)));
+                dstile[DSPLANE + key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(out.lw[r >> 1] >> (16 * e)));
             }
         }
-
-        BPH_T(tp1);
-        // ---- dS'' = P * (dP' - D') * inv_t * ds_shift ----------------------------------------------------------
-        float ds[16];
-        unsigned pwh[STORE_P ? 8 : 1], pwl[STORE_P ? 8 : 1];
-        float pprev = 0.f;
+    };
+    // the wave's transposed 32x32 tile: LDS -> 16-byte row pieces of the [Nk][Nq] planes
+    auto store_planes = [&](int t, __amdgpu_buffer_rsrc_t h_rs, __amdgpu_buffer_rsrc_t l_rs) {
+        // (LDS instructions of one wave execute in order: the 2-byte writes above are visible here)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float pv = fast_exp2(sld[r] - lse2);
-            if (RAGGED && (j0 + acc_row_base(r) + 4 * h >= Nk)) pv = 0.f;
-            ds[r] = pv * (dp0[r] - d_lane) * cs;
-            if (STORE_P) {          // the key side of the cycle terms needs P itself (dV = dO . P)
-                if (r & 1) {
-                    f16x2 a, bq;
-                    bq_split_pair(pprev * kPPlaneScale, pv * kPPlaneScale, a, bq);
-                    pwh[r >> 1] = __builtin_bit_cast(unsigned, a);
-                    pwl[r >> 1] = __builtin_bit_cast(unsigned, bq);
-                } else {
-                    pprev = pv;
-                }
-            }
+        for (int pass = 0; pass < 2; ++pass) {
+            const int key = pass * 16 + (lane >> 2), qc = (lane & 3) * 8;
+            const u32x4 xh = *reinterpret_cast<const u32x4*>(dstile + key * DSROW + qc);
+            const u32x4 xl = *reinterpret_cast<const u32x4*>(dstile + DSPLANE + key * DSROW + qc);
+            const int row = t * 32 + key, col = q0 + wave * 32 + qc;        // Nq % 8 == 0: whole pieces
+            // blocked layout ([128 keys][32 queries] blocks of 8 KB, see cocos_hip.h): the wave's whole
+            // 32x32 tile is 2 KB contiguous, and a k-block of the key-side GEMM is one contiguous block
+            const unsigned lin = planes_blocked
+                ? (unsigned)(((row >> 7) * (Nq >> 5) + (col >> 5)) * 4096 + (row & 127) * 32 + (col & 31))
+                : (unsigned)(row * Nq + col);
+            const unsigned off = (row < Nk && col < Nq) ? lin * 2u : kBufOob;
+            __builtin_amdgcn_raw_buffer_store_b128(xh, h_rs, (int)off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(xl, l_rs, (int)off, 0, 0);
         }
-
-        // split to f16 hi/lo, two values per 32-bit register (register r>>1, half r&1); registers 8t..8t+7
-        // are the k-slots of step t of the dqn product
-        unsigned hw[8], lw[8];
+    };
+    auto store_p_tile = [&](int t, const DsRegs& pr) {
+        // same transposition for the P planes, through the same per-wave buffer (after the dS'' pieces have been
+        // read back; one wave's LDS instructions execute in order)
 #pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-            f16x2 a, bq;
-            bq_split_pair(ds[j], ds[j + 1], a, bq);
-            hw[j >> 1] = __builtin_bit_cast(unsigned, a);
-            lw[j >> 1] = __builtin_bit_cast(unsigned, bq);
+        for (int i = 0; i < 16; ++i) {
+            const int key = acc_row_base(i) + 4 * h;
+            dstile[key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(pr.hw[i >> 1] >> (16 * (i & 1))));
+            dstile[DSPLANE + key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(pr.lw[i >> 1] >> (16 * (i & 1))));
         }
+        store_planes(t, ph_rs, pl_rs);
+    };
+
+    // ---- dqn += K(t-1) . dS''(t-1) : 16 steps of 3 MFMAs (2 k-steps x 8 channel blocks), operands one step ahead;
+    //      WITH_VALU: slice i of tile t's VALU work and, as its logit registers are consumed, the loads of tile
+    //      t + 2's logits into them ride in the gaps -------------------------------------------------------------------
+    auto phase_dqn = [&](int t, const DsRegs& prev, auto with_valu, f32x4 (&s)[4], const f32x16& dp0, DsRegs& cur,
+                         DsRegs& pcur) {
+        constexpr bool WITH_VALU = decltype(with_valu)::value;
         f16x8 sh[2], sl[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            sh[tt] = __builtin_bit_cast(f16x8, u32x4{hw[4 * tt], hw[4 * tt + 1], hw[4 * tt + 2], hw[4 * tt + 3]});
-            sl[tt] = __builtin_bit_cast(f16x8, u32x4{lw[4 * tt], lw[4 * tt + 1], lw[4 * tt + 2], lw[4 * tt + 3]});
+            sh[tt] = __builtin_bit_cast(f16x8, u32x4{prev.hw[4 * tt], prev.hw[4 * tt + 1], prev.hw[4 * tt + 2], prev.hw[4 * tt + 3]});
+            sl[tt] = __builtin_bit_cast(f16x8, u32x4{prev.lw[4 * tt], prev.lw[4 * tt + 1], prev.lw[4 * tt + 2], prev.lw[4 * tt + 3]});
         }
-        BPH_T(tp2);
-        // ---- dqn += K(t) . dS'' : 16 steps (2 k-steps x 8 channel blocks), operands read one step ahead.
-        //      Riding in the gaps, one slice per step (never a burst of memory instructions): the dS'' stores of
-        //      register r, the logits load of tile t+1 into the same sld[r], one staged piece of tile t+1 to the
-        //      other LDS buffer and its reload for tile t+2 ------------------------------------------------------
-        {
-            const _Float16* kb0 = kt + buf * 2 * KPLANE + c * BQH_KROW + h * 8;
-            _Float16* const vw = vt + (buf ^ 1) * 2 * VPLANE;
-            _Float16* const kw = kt + (buf ^ 1) * 2 * KPLANE;
-            const int jn = j0 + 64;
-            auto hook = [&](int i) {
-                if (STORE_DS) {
-                    // dS'' goes to HBM as 16-byte row pieces: each lane holds one QUERY column (16 keys), the
-                    // matrix is [key][query] — so the wave transposes its 32x32 tile through a private LDS
-                    // buffer: 2-byte LDS writes here (step i = register i), 4 b128 reads + 4 b128 global stores
-                    // at steps 12..15, instead of 32 two-byte global stores per lane and tile
-                    const int key = acc_row_base(i) + 4 * h;
-                    dstile[key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(hw[i >> 1] >> (16 * (i & 1))));
-                    dstile[DSPLANE + key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(lw[i >> 1] >> (16 * (i & 1))));
-                }
-                if (!RAGGED) {
-                    // tile-uniform parts in SGPRs; look-ahead past the last tile re-reads the last tile
-                    const int jt1 = min(j0 + 32, Nk - 32), jt2 = min(jn, Nk - 32);
-                    // the logits stream from HBM (nothing re-reads them): all 16 loads of tile t+1 go out in the
-                    // first four steps, so that even the last one has most of this loop plus the next tile's dP
-                    // product (~5000 cycles) to arrive — spread over the 16 steps the last load had ~1100
-                    if (i < 2) {
+        const _Float16* kb0 = kt + ((t - 1) & 1) * 2 * KPLANE + c * BQH_KROW + h * 8;
+        f16x8 a_h[2], a_l[2];
+        a_h[0] = *reinterpret_cast<const f16x8*>(kb0);
+        a_l[0] = *reinterpret_cast<const f16x8*>(kb0 + KPLANE);
+        float dsv[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
 #pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            sld[8 * i + q] = buf_load1s(lg_rs, sr_lane_off,
-                                                        (unsigned)(jt1 + acc_row_base(8 * i + q)) * (unsigned)Nq * 4u);
-                    }
-                    if (i < 2 * VPT) {
-                        const int pl_ = i & 1, u = i >> 1;
-                        if (u * 256 + 255 < VCH || u * 256 + tid < VCH)
-                            *reinterpret_cast<u32x4*>(vw + pl_ * VPLANE + v_lds[u]) = vst[pl_][u];
-                        vst[pl_][u] = bq_load16s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jt2 * (unsigned)(CVP * 2));
-                    } else if (i - 2 * VPT < 8) {
-                        const int pl_ = (i - 2 * VPT) & 1, u = (i - 2 * VPT) >> 1;
-                        _Float16* d = kw + pl_ * KPLANE + k_lds[u];
-                        *reinterpret_cast<u32x2*>(d) = u32x2{kst[pl_][u].x, kst[pl_][u].y};
-                        *reinterpret_cast<u32x2*>(d + 8) = u32x2{kst[pl_][u].z, kst[pl_][u].w};
-                        kst[pl_][u] = bq_load16s(pl_ ? kl_rs : kh_rs, k_voff[u], (unsigned)jt2 * 2u);
-                    }
-                    return;
-                }
-                {   // logits of tile t+1, register i
-                    const int jr = j0 + 32 + acc_row_base(i);
-                    sld[i] = buf_load1s(lg_rs, (jr + 4 * h < Nk) ? sr_lane_off : kBufOob, (unsigned)jr * (unsigned)Nq * 4u);
-                }
-                if (i < 2 * VPT) {                            // V pieces: plane i&1, chunk i>>1
-                    const int pl_ = i & 1, u = i >> 1;
-                    const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
-                    if (g < VCH) *reinterpret_cast<u32x4*>(vw + pl_ * VPLANE + key * VROW + cc * 8) = vst[pl_][u];
-                    vst[pl_][u] = bq_load16(pl_ ? vl_rs : vh_rs,
-                                            g < VCH ? (unsigned)((jn + key) * CVP + cc * 8) * 2u : kBufOob);
-                } else if (i - 2 * VPT < 8) {                 // K pieces
-                    const int pl_ = (i - 2 * VPT) & 1, u = (i - 2 * VPT) >> 1;
-                    const int g = u * 256 + tid, row = g >> 2, k8 = g & 3;
-                    const int kq = 2 * k8, slot0 = 16 * (kq >> 2) + 4 * ((kq >> 1) & 1);
-                    _Float16* d = kw + pl_ * KPLANE + row * BQH_KROW;
-                    *reinterpret_cast<u32x2*>(d + slot0) = u32x2{kst[pl_][u].x, kst[pl_][u].y};
-                    *reinterpret_cast<u32x2*>(d + slot0 + 8) = u32x2{kst[pl_][u].z, kst[pl_][u].w};
-                    unsigned off = (unsigned)(row * Nk + jn + 8 * k8) * 2u;
-                    if (jn + 8 * k8 >= Nk) off = kBufOob;
-                    kst[pl_][u] = bq_load16(pl_ ? kl_rs : kh_rs, off);
-                }
-            };
-            static_assert(2 * VPT + 8 <= 16, "staging pieces must fit the 16 steps of the dqn product");
-            f16x8 a_h[2], a_l[2];
-            a_h[0] = *reinterpret_cast<const f16x8*>(kb0);
-            a_l[0] = *reinterpret_cast<const f16x8*>(kb0 + KPLANE);
-#pragma unroll
-            for (int i = 0; i < 2 * KB; ++i) {                // i = tt * KB + kb
-                const int tt = i / KB, kb = i % KB, cur = i & 1, nxt = cur ^ 1;
-                if (i + 1 < 2 * KB) {
-                    const int t2 = (i + 1) / KB, k2 = (i + 1) % KB;
-                    a_h[nxt] = *reinterpret_cast<const f16x8*>(kb0 + k2 * 32 * BQH_KROW + t2 * 16);
-                    a_l[nxt] = *reinterpret_cast<const f16x8*>(kb0 + KPLANE + k2 * 32 * BQH_KROW + t2 * 16);
-                }
-                dx[kb] = bq_mfma(a_h[cur], sh[tt], dx[kb]);
-                dx[kb] = bq_mfma(a_h[cur], sl[tt], dx[kb]);
-                dx[kb] = bq_mfma(a_l[cur], sh[tt], dx[kb]);
-                hook(i);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 2 * KB; ++i) {                // i = tt * KB + kb
+            const int tt = i / KB, kb = i % KB, cur_ = i & 1, nxt = cur_ ^ 1;
+            if (i + 1 < 2 * KB) {
+                const int t2 = (i + 1) / KB, k2 = (i + 1) % KB;
+                a_h[nxt] = *reinterpret_cast<const f16x8*>(kb0 + k2 * 32 * BQH_KROW + t2 * 16);
+                a_l[nxt] = *reinterpret_cast<const f16x8*>(kb0 + KPLANE + k2 * 32 * BQH_KROW + t2 * 16);
             }
-            if (STORE_DS) {
-                // (LDS instructions of one wave execute in order: the 2-byte writes above are visible here)
-#pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-                    const int key = pass * 16 + (lane >> 2), qc = (lane & 3) * 8;
-                    const u32x4 xh = *reinterpret_cast<const u32x4*>(dstile + key * DSROW + qc);
-                    const u32x4 xl = *reinterpret_cast<const u32x4*>(dstile + DSPLANE + key * DSROW + qc);
-                    const int row = j0 + key, col = q0 + wave * 32 + qc;        // Nq % 8 == 0: whole pieces
-                    // blocked layout ([128 keys][32 queries] blocks of 8 KB, see cocos_hip.h): the wave's whole
-                    // 32x32 tile is 2 KB contiguous, and a k-block of the key-side GEMM is one contiguous block
-                    const unsigned lin = planes_blocked
-                        ? (unsigned)(((row >> 7) * (Nq >> 5) + (col >> 5)) * 4096 + (row & 127) * 32 + (col & 31))
-                        : (unsigned)(row * Nq + col);
-                    const unsigned off = (row < Nk && col < Nq) ? lin * 2u : kBufOob;
-                    __builtin_amdgcn_raw_buffer_store_b128(xh, dh_rs, (int)off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(xl, dl_rs, (int)off, 0, 0);
-                }
+            dx[kb] = bq_mfma(a_h[cur_], sh[tt], dx[kb]);
+            dx[kb] = bq_mfma(a_h[cur_], sl[tt], dx[kb]);
+            dx[kb] = bq_mfma(a_l[cur_], sh[tt], dx[kb]);
+            if (WITH_VALU) {
+                valu_slice(i, t, s, dp0, dsv, pv, cur, pcur);
+                if ((i & 3) == 3) load_s(s[i >> 2], t + 2, i >> 2);      // registers 4k..4k+3 are free again
             }
-            if (STORE_P) {
-                // same transposition for the P planes, through the same per-wave buffer (after the dS'' pieces
-                // have been read back; one wave's LDS instructions execute in order)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int key = acc_row_base(i) + 4 * h;
-                    dstile[key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(pwh[i >> 1] >> (16 * (i & 1))));
-                    dstile[DSPLANE + key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(pwl[i >> 1] >> (16 * (i & 1))));
-                }
-#pragma unroll
-                for (int pass = 0; pass < 2; ++pass) {
-                    const int key = pass * 16 + (lane >> 2), qc = (lane & 3) * 8;
-                    const u32x4 xh = *reinterpret_cast<const u32x4*>(dstile + key * DSROW + qc);
-                    const u32x4 xl = *reinterpret_cast<const u32x4*>(dstile + DSPLANE + key * DSROW + qc);
-                    const int row = j0 + key, col = q0 + wave * 32 + qc;
-                    const unsigned lin = planes_blocked
-                        ? (unsigned)(((row >> 7) * (Nq >> 5) + (col >> 5)) * 4096 + (row & 127) * 32 + (col & 31))
-                        : (unsigned)(row * Nq + col);
-                    const unsigned off = (row < Nk && col < Nq) ? lin * 2u : kBufOob;
-                    __builtin_amdgcn_raw_buffer_store_b128(xh, ph_rs, (int)off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(xl, pl_rs, (int)off, 0, 0);
-                }
-            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // the dqn accumulators live in the accumulator file for the whole kernel (without the pins hipcc
         // rotates them through other AGPR ranges: 64 v_accvgpr_mov per tile)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+a"(dx[kb]));
+    };
+
+    // ---- prologue: V(0), K(0) in LDS; V(1), K(1) staged in registers; logits of tiles 0 and 1 requested -----------
+    f32x4 sA[4], sB[4];
+    fetch_v(0);
+    fetch_k(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_s(sA[k], 0, k);
+    commit_v(0);
+    commit_k(0);
+    fetch_v(RAGGED ? 32 : min(32, Nk - 32));
+    fetch_k(RAGGED ? 32 : min(32, Nk - 32));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_s(sB[k], 1, k);
+    __syncthreads();
+
+    DsRegs dA, dB, pA, pB;
+    f32x16 dp0;
+    using std::false_type;
+    using std::true_type;
+
+    // iteration 0: dP'(0), then tile 0's VALU work on its own (there is no dqn product to hide it under yet)
+    {
+        phase_dp(dp0, 0, false_type{});
+        float dsv[2], pv[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            valu_slice(r, 0, sA, dp0, dsv, pv, dA, pA);
+            if ((r & 3) == 3) load_s(sA[r >> 2], 2, r >> 2);
+        }
+        if (STORE_DS) store_planes(0, dh_rs, dl_rs);
+        if (STORE_P) store_p_tile(0, pA);
+        __syncthreads();
+    }
+    // iterations 1 .. ntiles-1, two per trip so that every register set is named statically:
+    //   odd t : logits sB -> dS'' dB, dqn of tile t-1 from dA;   even t: logits sA -> dA, dqn from dB
+    auto iter = [&](int t, f32x4 (&s)[4], const DsRegs& prev, DsRegs& cur, DsRegs& pcur) {
+        BPH_T(tp0);
+        phase_dp(dp0, t, true_type{});
+        BPH_T(tp1);
+        phase_dqn(t, prev, true_type{}, s, dp0, cur, pcur);
+        BPH_T(tp2);
+        if (STORE_DS) store_planes(t, dh_rs, dl_rs);
+        if (STORE_P) store_p_tile(t, pcur);
         BPH_T(tp3);
         __syncthreads();
         BPH_T(tp4);
         BPH_ADD(0, tp0, tp1); BPH_ADD(1, tp1, tp2); BPH_ADD(2, tp2, tp3); BPH_ADD(3, tp3, tp4);
+    };
+    int t = 1;
+    for (; t + 1 < ntiles; t += 2) {
+        iter(t, sB, dA, dB, pB);
+        iter(t + 1, sA, dB, dA, pA);
+    }
+    if (t < ntiles) {
+        iter(t, sB, dA, dB, pB);
+        phase_dqn(ntiles, dB, false_type{}, sA, dp0, dA, pA);
+    } else {
+        phase_dqn(ntiles, dA, false_type{}, sB, dp0, dB, pB);
     }
 
     // ---- epilogue: undo the scales -----------------------------------------------------------------------
     if (live) {
-        const float undo = 1.0f / (k_scale * s_o * ds_shift);
+        const float undo = 1.0f / (k_scale * s_ov * ds_shift);
         float* dx_b = dqn + (size_t)b * BQH_KD * Nq;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
@@ -470,10 +505,11 @@ template <int CVB>
 static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Float16* vph, const _Float16* vpl,
                            const _Float16* gph, const _Float16* gpl, const float* g_scale, const float* outp,
                            const float* dout, const float* lse, const float* lg, float* dqn, _Float16* dsh,
-                           _Float16* dsl, _Float16* psh, _Float16* psl, const float* v_amax, float* ds_scale_out,
-                           int B, int Nq, int Nk, int Cv, float inv_t, float k_scale, int blocked, hipStream_t s) {
+                           _Float16* dsl, _Float16* psh, _Float16* psl, const float* v_amax, const float* v_scale,
+                           float* ds_scale_out, int B, int Nq, int Nk, int Cv, float inv_t, float k_scale, int blocked,
+                           hipStream_t s) {
     const bool ragged = (Nk % 32) != 0, store = dsh != nullptr, storep = psh != nullptr;
-    const size_t smem = ((size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) + 4 * 2 * 32 * 40) * sizeof(_Float16);
+    const size_t smem = ((size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) + 4 * 2 * 32 * 32) * sizeof(_Float16);
     const int nqb = (Nq + 127) / 128;
 #define COCOS_GO(DS, RG)                                                                                     \
     do {                                                                                                     \
@@ -485,8 +521,8 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
         hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, s, kch, kcl, vph, vpl, gph, gpl, g_scale,   \
-                           outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, ds_scale_out, B, Nq, Nk, Cv, \
-                           inv_t, k_scale, blocked);                                                         \
+                           outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, B, Nq, \
+                           Nk, Cv, inv_t, k_scale, blocked);                                                 \
     } while (0)
     if (store) { if (ragged) COCOS_GO(true, true); else COCOS_GO(true, false); }
     else       { if (ragged) COCOS_GO(false, true); else COCOS_GO(false, false); }
@@ -513,17 +549,17 @@ extern "C" int cocos_debug_read_timing_bwd_f16x3(long long* host8, int reset) {
 
 extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
     const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
-    const float* g_scale_dev, const float* out, const float* dout, const float* lse, const float* logits_t,
-    float* dqn, void* dsh, void* dsl, void* psh, void* psl, const float* v_amax_dev, float* ds_scale_out_dev,
-    int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale, int planes_blocked,
-    cocos_stream_t stream) {
+    const float* g_scale_dev, const float* out, const float* dout, const float* lse, const void* saved_logits,
+    float* dqn, void* dsh, void* dsl, void* psh, void* psl, const float* v_amax_dev, const float* v_scale_dev,
+    float* ds_scale_out_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale,
+    int planes_blocked, cocos_stream_t stream) {
     using namespace cocos;
-    COCOS_REQUIRE(kch && kcl && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse && logits_t && dqn &&
+    COCOS_REQUIRE(kch && kcl && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse && saved_logits && dqn &&
                       v_amax_dev && ds_scale_out_dev,
                   COCOS_ERR_INVALID, "corr_softmax_warp_bwd_query_f16x3: null pointer");
     COCOS_REQUIRE((dsh == nullptr) == (dsl == nullptr) && (psh == nullptr) == (psl == nullptr), COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd_query_f16x3: plane pointers come in hi/lo pairs");
-    COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && k_scale > 0.f, COCOS_ERR_INVALID,
+    COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && k_scale > 0.f && inv_temperature > 0.f, COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd_query_f16x3: bad dims B=%d Nq=%d Nk=%d Cv=%d", B, Nq, Nk, Cv);
     COCOS_REQUIRE(K == 256 && Cv <= 160 && Nk % 8 == 0 && ((dsh == nullptr && psh == nullptr) || Nq % 8 == 0),
                   COCOS_ERR_UNSUPPORTED,
@@ -535,18 +571,19 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
     const int cvb = (Cv + 31) / 32;
     COCOS_REQUIRE(CvPad == cvb * 32, COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd_query_f16x3: CvPad=%d, expected %d (Cv rounded up to 32)", CvPad, cvb * 32);
-    COCOS_REQUIRE((size_t)Nq * Nk * 4 < 0x7fffffffull && (size_t)K * Nk * 2 < 0x7fffffffull &&
-                      (size_t)K * Nq * 4 < 0x7fffffffull,
+    COCOS_REQUIRE(cocos_corr_softmax_warp_saved_logits_bytes(1, Nq, Nk) < 0x7fffffffull &&
+                      (size_t)K * Nk * 2 < 0x7fffffffull && (size_t)K * Nq * 4 < 0x7fffffffull,
                   COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_bwd_query_f16x3: per-sample tensor exceeds 2 GiB");
-    for (const void* p : {kch, kcl, vph, vpl, gph, gpl})
-        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "corr_softmax_warp_bwd_query_f16x3: planes must be 16-byte aligned");
+    for (const void* p : {kch, kcl, vph, vpl, gph, gpl, saved_logits})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID,
+                      "corr_softmax_warp_bwd_query_f16x3: planes and saved logits must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
 #define COCOS_ARGS                                                                                              \
     static_cast<const _Float16*>(kch), static_cast<const _Float16*>(kcl), static_cast<const _Float16*>(vph),   \
         static_cast<const _Float16*>(vpl), static_cast<const _Float16*>(gph), static_cast<const _Float16*>(gpl), \
-        g_scale_dev, out, dout, lse, logits_t, dqn, static_cast<_Float16*>(dsh), static_cast<_Float16*>(dsl),    \
-        static_cast<_Float16*>(psh), static_cast<_Float16*>(psl), v_amax_dev, ds_scale_out_dev, B, Nq, Nk, Cv,  \
-        inv_temperature, k_scale, planes_blocked, s
+        g_scale_dev, out, dout, lse, static_cast<const float*>(saved_logits), dqn, static_cast<_Float16*>(dsh),  \
+        static_cast<_Float16*>(dsl), static_cast<_Float16*>(psh), static_cast<_Float16*>(psl), v_amax_dev,      \
+        v_scale_dev, ds_scale_out_dev, B, Nq, Nk, Cv, inv_temperature, k_scale, planes_blocked, s
     switch (cvb) {
         case 1: return launch_bq_f16x3<1>(COCOS_ARGS);
         case 2: return launch_bq_f16x3<2>(COCOS_ARGS);

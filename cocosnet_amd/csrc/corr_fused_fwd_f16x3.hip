@@ -22,7 +22,14 @@
 //     operand of the P.V MFMAs: accumulator registers 8t..8t+7 are the 8 k-slots of step t — the k
 //     order inside an MFMA is free as long as A uses the same one, so the V tile is written to LDS with
 //     its keys permuted to match (commit_v) and no cross-lane movement is needed;
-//   * O^T (Cv x 32 queries) accumulates in 16*CVB fp32 registers.
+//   * O^T (Cv x 32 queries) accumulates in 16*CVB fp32 registers.  The LAST row of the padded V tile (channel
+//     32*CVB - 1, always a padding channel: CVB = Cv/32 + 1) is a row of ones, so the softmax denominator
+//     l = sum_j p_j comes out of the P.V MFMAs as one more output row instead of 16 VALU adds per tile — and
+//     numerator and denominator see exactly the same hi+lo truncation of P.
+//   * training: the raw accumulator (k_scale^2 * cos) of every tile is kept for the query-side backward in a
+//     PRIVATE tile-blocked layout — [key tile][32-query block][k = 0..3][lane][4 registers] — so that a wave
+//     stores (and the backward loads) its 32x32 tile as four fully contiguous 1 KB instructions instead of
+//     sixteen 4-byte-per-lane ones (the store tail of round 1 was instruction-bound, not bandwidth-bound).
 #include "common.h"
 
 namespace cocos {
@@ -86,8 +93,8 @@ template <int CVB, bool STORE_S, bool RAGGED>
 __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     const _Float16* __restrict__ qh, const _Float16* __restrict__ ql, const _Float16* __restrict__ kh,
     const _Float16* __restrict__ kl, const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
-    float* __restrict__ out, float* __restrict__ lse, float* __restrict__ lg, int B, int Nq, int Nk, int Cv,
-    float scale_log2 /* inv_temperature * log2(e) / (q_scale * k_scale) */) {
+    float* __restrict__ out, float* __restrict__ lse, float* __restrict__ lg, const float* __restrict__ v_scale,
+    int B, int Nq, int Nk, int Cv, float scale_log2 /* inv_temperature * log2(e) / (q_scale * k_scale) */) {
     constexpr int CVP = CVB * 32;
     constexpr int KPLANE = SP_BK * SP_KROW;          // halfs per K plane per buffer
     constexpr int VPLANE = CVP * SP_VROW;
@@ -111,9 +118,12 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     const __amdgpu_buffer_rsrc_t kl_rs = make_rsrc(kl + (size_t)b * Nk * SP_KD, kbytes);
     const __amdgpu_buffer_rsrc_t vh_rs = make_rsrc(vh + (size_t)b * Cv * Nk, vbytes);
     const __amdgpu_buffer_rsrc_t vl_rs = make_rsrc(vl + (size_t)b * Cv * Nk, vbytes);
-    const __amdgpu_buffer_rsrc_t lg_rs = make_rsrc(STORE_S ? lg + (size_t)b * Nk * Nq : nullptr,
-                                                   STORE_S ? (size_t)Nk * Nq * 4 : 0);
-    const unsigned lg_lane_off = i_lane < Nq ? (unsigned)(4 * h * Nq + i_lane) * 4u : kBufOob;
+    // saved logits, tile-blocked (see header): per sample ntiles x nqblk blocks of 4 KB
+    const int nqblk = (Nq + 31) / 32;
+    const size_t lg_bytes = (size_t)((Nk + SP_BK - 1) / SP_BK) * nqblk * 4096;
+    const __amdgpu_buffer_rsrc_t lg_rs = make_rsrc(STORE_S ? reinterpret_cast<const char*>(lg) + (size_t)b * lg_bytes : nullptr,
+                                                   STORE_S ? lg_bytes : 0);
+    const unsigned lg_lane_off = i_lane < Nq ? (unsigned)((qb * 4 + wave) * 4096 + lane * 16) : kBufOob;
 
     // ---- resident query slice: B operand of step s = channels 16s + 8h .. +7 of query c ------------
     f16x8 qhr[SP_KD / 16], qlr[SP_KD / 16];
@@ -138,7 +148,10 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     for (int cb = 0; cb < CVB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY;
+    // the thread that stages the last row of the padded V tile writes ones into its hi plane (see header)
+    const bool ones_thread = tid >= 248;
+    const u32x2 kOnes2 = u32x2{0x3C003C00u, 0x3C003C00u};
 
     // ---- staging: global -> registers (in flight under the MFMAs of the previous tile) -> LDS -------
     // K: 32 keys x 512 B per plane = 1024 16-byte chunks, 4 per thread; a key row is contiguous in HBM.
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
             const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
             // keys 4kq..4kq+3 -> k-slots of the P.V MFMA (see header): step kq>>2, half kq&1, quad (kq>>1)&1
             const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);
-            *reinterpret_cast<u32x2*>(base + row * SP_VROW + slot) = vst[0][u];
+            *reinterpret_cast<u32x2*>(base + row * SP_VROW + slot) = (u == CVB - 1 && ones_thread) ? kOnes2 : vst[0][u];
             *reinterpret_cast<u32x2*>(base + VPLANE + row * SP_VROW + slot) = vst[1][u];
         }
     };
@@ -257,7 +270,8 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                         kst[pl_][u] = buf_load_u4s(pl_ ? kl_rs : kh_rs, k_voff[u], (unsigned)jc * (unsigned)(SP_KD * 2));
                     } else if (i - 8 < 2 * CVB) {
                         const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
-                        *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + v_lds[u]) = vst[pl_][u];
+                        *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + v_lds[u]) =
+                            (pl_ == 0 && u == CVB - 1 && ones_thread) ? kOnes2 : vst[pl_][u];
                         vst[pl_][u] = buf_load_u2s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jc * 2u);
                     }
                     return;
@@ -271,7 +285,8 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                     const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
                     const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
                     const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);
-                    *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + row * SP_VROW + slot) = vst[pl_][u];
+                    *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + row * SP_VROW + slot) =
+                        (pl_ == 0 && u == CVB - 1 && ones_thread) ? kOnes2 : vst[pl_][u];
                     unsigned off = (unsigned)(row * Nk + jn + 4 * kq) * 2u;
                     if (row >= Cv || jn + 4 * kq >= Nk) off = kBufOob;
                     vst[pl_][u] = buf_load_u2(pl_ ? vl_rs : vh_rs, off);
@@ -305,23 +320,24 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
         FPH_T(tp1);
         FPH_T(tp2);
         // ---- online softmax (log2 domain), lazy rescale as in the fp32 kernel -------------------------
-        float p[16];
-        float tmax = -INFINITY;
+        // The row maximum is taken on the raw accumulator (scale_log2 > 0) and scaled once; the exponent is one
+        // fma per element: p = 2^(s * scale_log2 - (m - kPBias)).
+        if (ragged) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float x = s0[r] * scale_log2;
-            if (ragged && (j0 + acc_row_base(r) + 4 * h >= Nk)) x = -INFINITY;
-            p[r] = x;
-            tmax = fmaxf(tmax, x);
+            for (int r = 0; r < 16; ++r)
+                if (j0 + acc_row_base(r) + 4 * h >= Nk) s0[r] = -INFINITY;
         }
-        tmax = fmaxf(tmax, swap_half(tmax));
+        float tmax = s0[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s0[r]);
+        tmax = fmaxf(tmax, swap_half(tmax)) * scale_log2;
         if (__any(tmax > m_run + kSplitRescaleThr)) {
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = fast_exp2(m_run - m_new);
-            l_run *= alpha;
             m_run = m_new;
             // (the pins keep the AGPR -> VGPR copies of O inside this rarely taken branch: hipcc otherwise
-            //  hoists all of them above it, i.e. into every tile)
+            //  hoists all of them above it, i.e. into every tile).  The ones row of V makes l one of O's rows:
+            //  it is rescaled with the rest.
 #pragma unroll
             for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
 #pragma unroll
@@ -331,19 +347,19 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
 #pragma unroll
             for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
         }
-        float psum = 0.f;
-        const float mb = m_run - kPBias;      // one subtraction per element instead of two
+        if (STORE_S) {
+            // the wave's 32x32 tile of raw logits: four contiguous 1 KB stores (registers 4k..4k+3 of every lane)
+            const unsigned soff = (unsigned)(t * nqblk) * 4096u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (STORE_S) {
-                const int jr = j0 + acc_row_base(r);
-                buf_store1s(lg_rs, p[r], (!ragged || jr + 4 * h < Nk) ? lg_lane_off : kBufOob,
-                            (unsigned)jr * (unsigned)Nq * 4u);
-            }
-            p[r] = fast_exp2(p[r] - mb);
-            psum += p[r];
+            for (int k = 0; k < 4; ++k)
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    __builtin_bit_cast(u32x4, f32x4{s0[4 * k], s0[4 * k + 1], s0[4 * k + 2], s0[4 * k + 3]}), lg_rs,
+                    (int)lg_lane_off, (int)(soff + (unsigned)k * 1024u), 0);
         }
-        l_run += psum;
+        float p[16];
+        const float nmb = kPBias - m_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = fast_exp2(__builtin_fmaf(s0[r], scale_log2, nmb));
 
         FPH_T(tp3);
         // P -> f16 hi/lo: registers 8t..8t+7 are the k-slots of P.V step t
@@ -394,8 +410,10 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     }
 
     // ---- epilogue: normalise, store channel-major [B,Cv,Nq], store row LSE --------------------------
-    const float l_tot = l_run + swap_half(l_run);
-    const float inv_l = 1.0f / l_tot;
+    // l = the ones row of O: channel 32*CVB - 1 = register 15 of the upper half-wave's lanes
+    const float l_own = o[CVB - 1][15];
+    const float l_tot = h ? l_own : swap_half(l_own);
+    const float inv_l = (v_scale ? 1.0f / *v_scale : 1.0f) / l_tot;
     if (i_lane < Nq) {
         float* out_b = out + (size_t)b * Cv * Nq;
 #pragma unroll
@@ -411,15 +429,15 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
 
 template <int CVB, bool STORE_S, bool RAGGED>
 static int launch_f16x3_k(const _Float16* qh, const _Float16* ql, const _Float16* kh, const _Float16* kl,
-                          const _Float16* vh, const _Float16* vl, float* out, float* lse, float* lg, int B,
-                          int Nq, int Nk, int Cv, float scale_log2, hipStream_t stream) {
+                          const _Float16* vh, const _Float16* vl, float* out, float* lse, float* lg,
+                          const float* v_scale, int B, int Nq, int Nk, int Cv, float scale_log2, hipStream_t stream) {
     auto kern = corr_fwd_f16x3_kernel<CVB, STORE_S, RAGGED>;
     const size_t smem = (size_t)2 * 2 * (SP_BK * SP_KROW + CVB * 32 * SP_VROW) * sizeof(_Float16);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int nqb = (Nq + SP_BQ - 1) / SP_BQ;
-    hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, stream, qh, ql, kh, kl, vh, vl, out, lse, lg, B,
-                       Nq, Nk, Cv, scale_log2);
+    hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, stream, qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale,
+                       B, Nq, Nk, Cv, scale_log2);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -439,42 +457,52 @@ extern "C" int cocos_debug_read_timing_fwd_f16x3(long long* host8, int reset) {
 }
 #endif
 
+extern "C" size_t cocos_corr_softmax_warp_saved_logits_bytes(int B, int Nq, int Nk) {
+    if (B < 1 || Nq < 1 || Nk < 1) return 0;
+    return (size_t)B * ((Nk + 31) / 32) * ((Nq + 31) / 32) * 4096;
+}
+
 extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void* kh,
                                                  const void* kl, const void* vh, const void* vl, float* out,
-                                                 float* lse, float* logits_t, int B, int K, int Nq, int Nk,
-                                                 int Cv, float inv_temperature, float operand_scale,
-                                                 cocos_stream_t stream) {
+                                                 float* lse, void* saved_logits, const float* v_scale_dev, int B,
+                                                 int K, int Nq, int Nk, int Cv, float inv_temperature,
+                                                 float operand_scale, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(qh && ql && kh && kl && vh && vl && out && lse, COCOS_ERR_INVALID,
                   "corr_softmax_warp_fwd_f16x3: null pointer");
-    COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && operand_scale > 0.f, COCOS_ERR_INVALID,
-                  "corr_softmax_warp_fwd_f16x3: bad dims B=%d Nq=%d Nk=%d Cv=%d", B, Nq, Nk, Cv);
+    COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && operand_scale > 0.f && inv_temperature > 0.f,
+                  COCOS_ERR_INVALID, "corr_softmax_warp_fwd_f16x3: bad dims B=%d Nq=%d Nk=%d Cv=%d", B, Nq, Nk, Cv);
     COCOS_REQUIRE(K == 256, COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_fwd_f16x3: needs K == 256 (got %d)", K);
-    COCOS_REQUIRE(Cv <= 160, COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_fwd_f16x3: Cv=%d > 160", Cv);
+    COCOS_REQUIRE(Cv <= 159, COCOS_ERR_UNSUPPORTED,
+                  "corr_softmax_warp_fwd_f16x3: Cv=%d > 159 (one padding channel carries the row sums)", Cv);
     COCOS_REQUIRE(Nk % 4 == 0, COCOS_ERR_UNSUPPORTED,
                   "corr_softmax_warp_fwd_f16x3: Nk=%d must be a multiple of 4 (use the fp32 entry point)", Nk);
     COCOS_REQUIRE((size_t)K * Nq * 2 < 0x7fffffffull && (size_t)K * Nk * 2 < 0x7fffffffull,
                   COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_fwd_f16x3: per-sample tensor exceeds 2 GiB");
-    COCOS_REQUIRE(!logits_t || (size_t)Nq * Nk * 4 < 0x7fffffffull, COCOS_ERR_UNSUPPORTED,
-                  "corr_softmax_warp_fwd_f16x3: per-sample logits exceed 2 GiB; pass logits_t = NULL");
+    COCOS_REQUIRE(!saved_logits || cocos_corr_softmax_warp_saved_logits_bytes(1, Nq, Nk) < 0x7fffffffull,
+                  COCOS_ERR_UNSUPPORTED,
+                  "corr_softmax_warp_fwd_f16x3: per-sample logits exceed 2 GiB; pass saved_logits = NULL");
     for (const void* p : {qh, ql, kh, kl})
         COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "corr_softmax_warp_fwd_f16x3: q/k planes must be 16-byte aligned");
     for (const void* p : {vh, vl})
         COCOS_REQUIRE((reinterpret_cast<uintptr_t>(p) & 7u) == 0, COCOS_ERR_INVALID,
                       "corr_softmax_warp_fwd_f16x3: v planes must be 8-byte aligned");
+    COCOS_REQUIRE(!saved_logits || aligned16(saved_logits), COCOS_ERR_INVALID,
+                  "corr_softmax_warp_fwd_f16x3: saved_logits must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
     const float scale_log2 = inv_temperature * kLog2e / (operand_scale * operand_scale);
     const bool ragged = (Nk % SP_BK) != 0;
+    float* lgp = static_cast<float*>(saved_logits);
     const _Float16 *a = static_cast<const _Float16*>(qh), *b2 = static_cast<const _Float16*>(ql),
                    *c2 = static_cast<const _Float16*>(kh), *d = static_cast<const _Float16*>(kl),
                    *e = static_cast<const _Float16*>(vh), *f = static_cast<const _Float16*>(vl);
 #define COCOS_GO(CVB, ST, RG) \
-    launch_f16x3_k<CVB, ST, RG>(a, b2, c2, d, e, f, out, lse, logits_t, B, Nq, Nk, Cv, scale_log2, s)
+    launch_f16x3_k<CVB, ST, RG>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, B, Nq, Nk, Cv, scale_log2, s)
 #define COCOS_CVB(CVB)                                                           \
     case CVB:                                                                    \
-        if (logits_t) return ragged ? COCOS_GO(CVB, true, true) : COCOS_GO(CVB, true, false); \
+        if (lgp) return ragged ? COCOS_GO(CVB, true, true) : COCOS_GO(CVB, true, false); \
         return ragged ? COCOS_GO(CVB, false, true) : COCOS_GO(CVB, false, false);
-    switch ((Cv + 31) / 32) {
+    switch (Cv / 32 + 1) {       // one more channel than Cv: the ones row (see the kernel header)
         COCOS_CVB(1) COCOS_CVB(2) COCOS_CVB(3) COCOS_CVB(4)
         default: COCOS_CVB(5)
     }

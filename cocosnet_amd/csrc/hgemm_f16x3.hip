@@ -25,6 +25,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int HG_BM = 256, HG_BN = 128, HG_BK = 32;
 constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row
 
+// EXACT: M % 256 == 0, N % 128 == 0, K % 32 == 0 — no bounds tests at all.  With them hipcc wraps every staged load in
+// an exec-mask region (s_and_saveexec / s_or per load: ~120 scalar instructions per k-step of 96 MFMAs).
+template <bool EXACT>
 __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __restrict__ ah,
                                                              const _Float16* __restrict__ al,
                                                              const _Float16* __restrict__ bh,
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
         for (int u = 0; u < 4; ++u) {
             const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
             unsigned off = (unsigned)((m0 + row) * K + k0 + kc * 8) * 2u;
-            if (m0 + row >= M || k0 + kc * 8 >= K) off = kBufOob;
+            if (!EXACT && (m0 + row >= M || k0 + kc * 8 >= K)) off = kBufOob;
             st.a[0][u] = __builtin_amdgcn_raw_buffer_load_b128(ah_rs, (int)off, 0, 0);
             st.a[1][u] = __builtin_amdgcn_raw_buffer_load_b128(al_rs, (int)off, 0, 0);
         }
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
             // (N tile, k-block) of this kernel; linear otherwise
             unsigned off = b_blocked ? (unsigned)(((n0 >> 7) * (K >> 5) + (k0 >> 5)) * 4096 + row * 32 + kc * 8) * 2u
                                      : (unsigned)((n0 + row) * K + k0 + kc * 8) * 2u;
-            if (n0 + row >= N || k0 + kc * 8 >= K) off = kBufOob;
+            if (!EXACT && (n0 + row >= N || k0 + kc * 8 >= K)) off = kBufOob;
             st.b[0][u] = __builtin_amdgcn_raw_buffer_load_b128(bh_rs, (int)off, 0, 0);
             st.b[1][u] = __builtin_amdgcn_raw_buffer_load_b128(bl_rs, (int)off, 0, 0);
         }
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
             const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
             *reinterpret_cast<u32x4*>(ab + pl * APLANE + row * HG_ROW + kc * 8) = st.a[pl][u];
             unsigned off = (unsigned)((m0 + row) * K + k0 + kc * 8) * 2u;
-            if (m0 + row >= M || k0 + kc * 8 >= K) off = kBufOob;
+            if (!EXACT && (m0 + row >= M || k0 + kc * 8 >= K)) off = kBufOob;
             st.a[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(pl ? al_rs : ah_rs, (int)off, 0, 0);
         } else {                                         // B: plane (idx - 8) & 1, chunk (idx - 8) >> 1
             const int pl = (idx - 8) & 1, u = (idx - 8) >> 1;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
             *reinterpret_cast<u32x4*>(bb + pl * BPLANE + row * HG_ROW + kc * 8) = st.b[pl][u];
             unsigned off = b_blocked ? (unsigned)(((n0 >> 7) * (K >> 5) + (k0 >> 5)) * 4096 + row * 32 + kc * 8) * 2u
                                      : (unsigned)((n0 + row) * K + k0 + kc * 8) * 2u;
-            if (n0 + row >= N || k0 + kc * 8 >= K) off = kBufOob;
+            if (!EXACT && (n0 + row >= N || k0 + kc * 8 >= K)) off = kBufOob;
             st.b[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(pl ? bl_rs : bh_rs, (int)off, 0, 0);
         }
     };
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 128 + i * 32 + acc_row_base(r) + 4 * h;
-                if (m < M && n < N) Cb[(size_t)m * N + n] = acc[i][j][r] * scale;
+                if (EXACT || (m < M && n < N)) Cb[(size_t)m * N + n] = acc[i][j][r] * scale;
             }
         }
 }
@@ -211,9 +214,11 @@ extern "C" int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void*
     const long long blocks = (long long)batch * ((N + HG_BN - 1) / HG_BN) * ((M + HG_BM - 1) / HG_BM);
     COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "hgemm_f16x3: grid too large");
     const size_t smem = (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16);
-    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(hgemm_f16x3_kernel),
+    const bool exact = M % HG_BM == 0 && N % HG_BN == 0 && K % HG_BK == 0;
+    auto kern = exact ? hgemm_f16x3_kernel<true> : hgemm_f16x3_kernel<false>;
+    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(hgemm_f16x3_kernel, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),
                        static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
                        static_cast<const _Float16*>(b_hi), static_cast<const _Float16*>(b_lo), c, M, N, K,
                        host_scale, dev_scale, dev_scale2, b_blocked);

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256, 1) void lsw_fwd_f16x3_kernel(const float* __re
                                                                const _Float16* __restrict__ vh,       // [B,Cv,Nk]
                                                                const _Float16* __restrict__ vl,
                                                                float* __restrict__ out, float* __restrict__ lse,
+                                                               const float* __restrict__ v_scale,     // s_v or NULL
                                                                int B, int Nq, int Nk, int Cv) {
     constexpr int CVP = CVB * 32, VPLANE = CVP * LW_VROW;
     __shared__ __attribute__((aligned(16))) _Float16 vt[2 * 2 * VPLANE];   // [2 buf][hi|lo][CVP][VROW]
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void lsw_fwd_f16x3_kernel(const float* __re
     }
 
     const float l_tot = l_run + swap_half(l_run);
-    const float inv_l = 1.0f / l_tot;
+    const float inv_l = (v_scale ? 1.0f / *v_scale : 1.0f) / l_tot;     // the V planes hold s_v * v
     if (live) {
         float* out_b = out + (size_t)b * Cv * Nq;
 #pragma unroll
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256, 1) void lsw_bwd_f16x3_kernel(
     const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] position-major planes of v
     const _Float16* __restrict__ gph, const _Float16* __restrict__ gpl,   // [B,Nq,CVP] planes of s_o*dout
     const float* __restrict__ g_scale,                                     // s_o (device)
+    const float* __restrict__ v_scale,                                     // s_v (device) or NULL: vph/vpl hold s_v * v
     const float* __restrict__ outp, const float* __restrict__ dout,        // [B,Cv,Nq] fp32 (for D)
     const float* __restrict__ lse, float* __restrict__ dlg,                // [B,Nq]; out [B,Nk,Nq]
     int B, int Nq, int Nk, int Cv) {
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void lsw_bwd_f16x3_kernel(
     const __amdgpu_buffer_rsrc_t dl_rs = make_rsrc(dlg + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
     const unsigned lane_off = live ? (unsigned)(4 * h * Nq + i_lane) * 4u : kBufOob;
 
-    const float s_o = *g_scale;
+    const float s_o = *g_scale * (v_scale ? *v_scale : 1.0f);      // scale of dP' = V' . dO'
     f16x8 goh[CVS], gol[CVS];
     {
         const unsigned off = live ? (unsigned)(i_lane * CVP + h * 8) * 2u : kBufOob;
@@ -339,22 +341,22 @@ __global__ __launch_bounds__(256, 1) void lsw_bwd_f16x3_kernel(
 }
 
 template <int CVB>
-static int lsw_fwd_launch(const float* lg, const _Float16* vh, const _Float16* vl, float* out, float* lse, int B, int Nq,
-                          int Nk, int Cv, hipStream_t s) {
+static int lsw_fwd_launch(const float* lg, const _Float16* vh, const _Float16* vl, float* out, float* lse,
+                          const float* vs, int B, int Nq, int Nk, int Cv, hipStream_t s) {
     const int nqb = (Nq + 127) / 128;
-    if (Nk % 32) hipLaunchKernelGGL((lsw_fwd_f16x3_kernel<CVB, true>), dim3(B * nqb), dim3(256), 0, s, lg, vh, vl, out, lse, B, Nq, Nk, Cv);
-    else         hipLaunchKernelGGL((lsw_fwd_f16x3_kernel<CVB, false>), dim3(B * nqb), dim3(256), 0, s, lg, vh, vl, out, lse, B, Nq, Nk, Cv);
+    if (Nk % 32) hipLaunchKernelGGL((lsw_fwd_f16x3_kernel<CVB, true>), dim3(B * nqb), dim3(256), 0, s, lg, vh, vl, out, lse, vs, B, Nq, Nk, Cv);
+    else         hipLaunchKernelGGL((lsw_fwd_f16x3_kernel<CVB, false>), dim3(B * nqb), dim3(256), 0, s, lg, vh, vl, out, lse, vs, B, Nq, Nk, Cv);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
 
 template <int CVB>
 static int lsw_bwd_launch(const float* lg, const _Float16* vph, const _Float16* vpl, const _Float16* gph,
-                          const _Float16* gpl, const float* gs, const float* outp, const float* dout, const float* lse,
-                          float* dlg, int B, int Nq, int Nk, int Cv, hipStream_t s) {
+                          const _Float16* gpl, const float* gs, const float* vs, const float* outp, const float* dout,
+                          const float* lse, float* dlg, int B, int Nq, int Nk, int Cv, hipStream_t s) {
     const int nqb = (Nq + 127) / 128;
-    if (Nk % 32) hipLaunchKernelGGL((lsw_bwd_f16x3_kernel<CVB, true>), dim3(B * nqb), dim3(256), 0, s, lg, vph, vpl, gph, gpl, gs, outp, dout, lse, dlg, B, Nq, Nk, Cv);
-    else         hipLaunchKernelGGL((lsw_bwd_f16x3_kernel<CVB, false>), dim3(B * nqb), dim3(256), 0, s, lg, vph, vpl, gph, gpl, gs, outp, dout, lse, dlg, B, Nq, Nk, Cv);
+    if (Nk % 32) hipLaunchKernelGGL((lsw_bwd_f16x3_kernel<CVB, true>), dim3(B * nqb), dim3(256), 0, s, lg, vph, vpl, gph, gpl, gs, vs, outp, dout, lse, dlg, B, Nq, Nk, Cv);
+    else         hipLaunchKernelGGL((lsw_bwd_f16x3_kernel<CVB, false>), dim3(B * nqb), dim3(256), 0, s, lg, vph, vpl, gph, gpl, gs, vs, outp, dout, lse, dlg, B, Nq, Nk, Cv);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -362,7 +364,8 @@ static int lsw_bwd_launch(const float* lg, const _Float16* vph, const _Float16* 
 }  // namespace cocos
 
 extern "C" int cocos_logits_softmax_warp_fwd_f16x3(const float* logits_t, const void* vh, const void* vl, float* out,
-                                                   float* lse, int B, int Nq, int Nk, int Cv, cocos_stream_t stream) {
+                                                   float* lse, const float* v_scale_dev, int B, int Nq, int Nk, int Cv,
+                                                   cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(logits_t && vh && vl && out && lse, COCOS_ERR_INVALID, "logits_softmax_warp_fwd_f16x3: null pointer");
     COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1, COCOS_ERR_INVALID,
@@ -372,17 +375,18 @@ extern "C" int cocos_logits_softmax_warp_fwd_f16x3(const float* logits_t, const 
     const _Float16 *a = static_cast<const _Float16*>(vh), *b2 = static_cast<const _Float16*>(vl);
     hipStream_t s = as_stream(stream);
     switch ((Cv + 31) / 32) {
-        case 1: return lsw_fwd_launch<1>(logits_t, a, b2, out, lse, B, Nq, Nk, Cv, s);
-        case 2: return lsw_fwd_launch<2>(logits_t, a, b2, out, lse, B, Nq, Nk, Cv, s);
-        case 3: return lsw_fwd_launch<3>(logits_t, a, b2, out, lse, B, Nq, Nk, Cv, s);
-        case 4: return lsw_fwd_launch<4>(logits_t, a, b2, out, lse, B, Nq, Nk, Cv, s);
-        default: return lsw_fwd_launch<5>(logits_t, a, b2, out, lse, B, Nq, Nk, Cv, s);
+        case 1: return lsw_fwd_launch<1>(logits_t, a, b2, out, lse, v_scale_dev, B, Nq, Nk, Cv, s);
+        case 2: return lsw_fwd_launch<2>(logits_t, a, b2, out, lse, v_scale_dev, B, Nq, Nk, Cv, s);
+        case 3: return lsw_fwd_launch<3>(logits_t, a, b2, out, lse, v_scale_dev, B, Nq, Nk, Cv, s);
+        case 4: return lsw_fwd_launch<4>(logits_t, a, b2, out, lse, v_scale_dev, B, Nq, Nk, Cv, s);
+        default: return lsw_fwd_launch<5>(logits_t, a, b2, out, lse, v_scale_dev, B, Nq, Nk, Cv, s);
     }
 }
 
 extern "C" int cocos_logits_softmax_warp_bwd_f16x3(const float* logits_t, const void* vph, const void* vpl,
                                                    const void* gph, const void* gpl, const float* g_scale_dev,
-                                                   const float* out, const float* dout, const float* lse,
+                                                   const float* v_scale_dev, const float* out, const float* dout,
+                                                   const float* lse,
                                                    float* dlogits_t, int B, int Nq, int Nk, int Cv, int CvPad,
                                                    cocos_stream_t stream) {
     using namespace cocos;
@@ -398,7 +402,7 @@ extern "C" int cocos_logits_softmax_warp_bwd_f16x3(const float* logits_t, const 
     hipStream_t s = as_stream(stream);
 #define COCOS_ARGS                                                                                              \
     logits_t, static_cast<const _Float16*>(vph), static_cast<const _Float16*>(vpl), static_cast<const _Float16*>(gph), \
-        static_cast<const _Float16*>(gpl), g_scale_dev, out, dout, lse, dlogits_t, B, Nq, Nk, Cv, s
+        static_cast<const _Float16*>(gpl), g_scale_dev, v_scale_dev, out, dout, lse, dlogits_t, B, Nq, Nk, Cv, s
     switch (cvb) {
         case 1: return lsw_bwd_launch<1>(COCOS_ARGS);
         case 2: return lsw_bwd_launch<2>(COCOS_ARGS);

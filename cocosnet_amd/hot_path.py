@@ -105,6 +105,9 @@ class _Attention:
         self._f = f_scaled
         self._lq, self._lk = logits_q, logits_k      # providers: query-major f / key-major f^T
         self._cache = {}
+        # f16 operand planes of theta/phi, shared by the row / column / second row pass of THIS forward call
+        # (per-call object: nothing is cached across calls or threads)
+        self._planes = ops.OperandPlanes() if self.fused else None
 
     def _get(self, name, fn):
         if name not in self._cache:
@@ -118,7 +121,7 @@ class _Attention:
     def rows(self, v):
         """softmax over exemplar positions, then @ v   (f_div_C @ v, :307/:318)."""
         if self.fused:
-            return ops.corr_softmax_warp(self.qn, self.kn, v, self.inv_t)
+            return ops.corr_softmax_warp(self.qn, self.kn, v, self.inv_t, self._planes)
         if self._lk is not None:
             return ops.logits_softmax_warp(self._get("lk", self._lk), v)
         return ops.warp_materialized(self._get("p_row", lambda: ops.row_softmax(self._f)), v)
@@ -126,7 +129,7 @@ class _Attention:
     def cols(self, v):
         """softmax over content positions of f^T, then @ v   (f_div_C_v @ v, :338/:351)."""
         if self.fused:
-            return ops.corr_softmax_warp(self.kn, self.qn, v, self.inv_t)
+            return ops.corr_softmax_warp(self.kn, self.qn, v, self.inv_t, self._planes)
         if self._lq is not None:   # f itself is the key-major logit matrix of the swapped problem
             return ops.logits_softmax_warp(self._get("lq", self._lq), v)
         return ops.warp_materialized(

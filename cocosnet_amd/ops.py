@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import os
 import sys
-import weakref
+import threading
 
 import torch
 
@@ -19,6 +19,8 @@ from . import _lib
 NORM_EPS = sys.float_info.epsilon
 #: widest V the fused kernel takes in one launch (5 blocks of 32 channels)
 MAX_FUSED_CV = 160
+#: ... of the split-precision forward: one padding channel of the V tile carries the softmax row sums
+MAX_FUSED_SPLIT_CV = 159
 #: largest dS^T scratch (bytes) the backward may allocate to replace the second logits recompute by
 #: a GEMM; above it (e.g. 128x128 grids at large batch) the flash-style key kernel is used
 MAX_DS_WORKSPACE_BYTES = 16 << 30
@@ -129,7 +131,9 @@ class _CenterL2Norm(torch.autograd.Function):
         if not center_over_channels:
             col_ws = torch.empty((B, N), device=y.device, dtype=torch.float32)
             row_ws = torch.empty((B, K), device=y.device, dtype=torch.float32)
-        if PROJ_PRECISION == "f16x3":      # max|dx| as a by-product: K0's backward (the usual consumer) needs it
+        # max|dx| as a by-product: K0's backward (the consumer on the theta/phi path) needs it.  Mode 2
+        # (feature_normalize) feeds MIOpen convolutions: nobody would pick the value up
+        if PROJ_PRECISION == "f16x3" and center_over_channels != 2:
             cell = _zero_cell(dx.device)
             _call("center_l2norm_bwd", "cocos_center_l2norm_bwd_amax", y.data_ptr(), norm.data_ptr(), dy.data_ptr(),
                   dx.data_ptr(), _ptr(col_ws), _ptr(row_ws), B, K, N, int(center_over_channels), eps,
@@ -158,19 +162,35 @@ def feature_normalize(x: torch.Tensor, eps: float = NORM_EPS):
 # ------------------------------------------------------------------------------------------
 # K2  fused correlation -> softmax -> warp     (correspondence.py:291,:304,:307,:318)
 # ------------------------------------------------------------------------------------------
-_split_cache = {}   # id(tensor) -> (weakref to it, version, transpose, scale, hi, lo)
+class OperandPlanes:
+    """f16 hi/lo operand planes of the theta/phi tensors of ONE forward call, made on first use and shared by the up
+    to three launches that read them (row pass, column pass, second row pass).  Owned by the caller (hot_path's
+    _Attention), so there is no process-global cache: under the reference's DataParallelWithCallback every replica
+    thread has its own object (SURVEY.md §8b threading contract)."""
+
+    def __init__(self):
+        self._planes = {}
+
+    def get(self, x: torch.Tensor, transpose: bool, scale: float):
+        key = (id(x), bool(transpose), float(scale))
+        ent = self._planes.get(key)
+        if ent is None or ent[0] is not x or ent[1] != x._version:
+            hi, lo = split_f16(x, transpose, scale)
+            ent = self._planes[key] = (x, x._version, hi, lo)     # holds x: its id cannot be recycled meanwhile
+        return ent[2], ent[3]
+
+    def __len__(self):
+        return len(self._planes)
 
 
-def split_f16(x: torch.Tensor, transpose: bool, scale: float = 1.0, cache: bool = False, cpad=None, amax=None):
+def split_f16(x: torch.Tensor, transpose: bool, scale: float = 1.0, cpad=None, amax=None):
     """x [B,C,N] fp32 -> (hi, lo) f16 planes with x*scale ~= hi + lo; [B,N,C] when `transpose`.
-    `cache`: reuse the planes while the same tensor object is unmodified (theta/phi feed up to three
-    launches per forward: row pass, column pass, second row pass).
     `cpad` (transpose only): rows padded with zero channels to cpad.  `amax`: a 1-element CUDA tensor
     holding max|x|; the scale is then chosen on the device (power of two, max -> [2^9, 2^10)) and the
     call returns (hi, lo, scale_tensor)."""
     x = _chk(x, "split_f16: x")
+    B, C, N = x.shape
     if cpad is not None or amax is not None:
-        B, C, N = x.shape
         cp = C if cpad is None else int(cpad)
         shape = (B, N, cp) if transpose else (B, C, N)
         hi = torch.empty(shape, device=x.device, dtype=torch.float16)
@@ -179,22 +199,18 @@ def split_f16(x: torch.Tensor, transpose: bool, scale: float = 1.0, cache: bool 
         _call("split_f16", "cocos_split_f16_ex", x.data_ptr(), hi.data_ptr(), lo.data_ptr(), B, C, N, cp,
               int(bool(transpose)), float(scale), _ptr(amax), _ptr(sc), _stream())
         return (hi, lo, sc) if amax is not None else (hi, lo)
-    key = (x._version, bool(transpose), float(scale))
-    if cache:
-        hit = _split_cache.get((id(x), bool(transpose)))
-        if hit is not None and hit[0]() is x and hit[1] == key:
-            return hit[2], hit[3]
-    B, C, N = x.shape
     shape = (B, N, C) if transpose else (B, C, N)
     hi = torch.empty(shape, device=x.device, dtype=torch.float16)
     lo = torch.empty(shape, device=x.device, dtype=torch.float16)
     _call("split_f16", "cocos_split_f16", x.data_ptr(), hi.data_ptr(), lo.data_ptr(), B, C, N, int(bool(transpose)),
           float(scale), _stream())
-    if cache:
-        ck = (id(x), bool(transpose))
-        # the entry (and its 2 x sizeof(x)/2 bytes of planes) goes away with the tensor it was made from
-        _split_cache[ck] = (weakref.ref(x, lambda _r, ck=ck: _split_cache.pop(ck, None)), key, hi, lo)
     return hi, lo
+
+
+def _split_bwd_ok(B, Nq, Nk, Cv):
+    """Shapes the split-precision K2 backward takes (cocos_corr_softmax_warp_bwd_query_f16x3 + the planes GEMM)."""
+    return (Nk % 8 == 0 and Nq % 8 == 0 and Cv <= MAX_FUSED_CV and B * Nq * Nk * 4 <= MAX_DS_WORKSPACE_BYTES
+            and _lib.load().cocos_corr_softmax_warp_saved_logits_bytes(1, Nq, Nk) < 2 ** 31 - 1)
 
 
 class _CorrSoftmaxWarp(torch.autograd.Function):
@@ -209,17 +225,24 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                              f"kn{tuple(kn.shape)} v{tuple(v.shape)}")
         out = torch.empty((B, Cv, Nq), device=qn.device, dtype=torch.float32)
         lse = torch.empty((B, Nq), device=qn.device, dtype=torch.float32)
-        # training: keep the scaled logits for the query-side backward (cheaper than recomputing
-        # them on fp32 MFMA, see corr_fused_fwd.hip); inference never materialises anything HWxHW
-        keep = (keep_logits and B * Nq * Nk * 4 <= MAX_DS_WORKSPACE_BYTES
-                and Nq * Nk * 4 < 2 ** 31 - 1)
-        logits_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if keep else None
+        # training: keep the logits for the query-side backward (cheaper than recomputing them, see
+        # corr_fused_fwd.hip); inference never materialises anything HWxHW
+        logits_t = None
+        ctx.split = planes is not None
+        ctx.v_amax = None
         if planes is not None:       # split-precision flavour: same outputs, f16x3 matrix products
-            qh, ql, kh, kl, vh, vl = planes[:6]
+            qh, ql, kh, kl, vh, vl, v_scale, v_amax = planes[:8]
+            if keep_logits:          # the forward's private tile-blocked layout (cocos_hip.h), opaque here
+                nbytes = _lib.load().cocos_corr_softmax_warp_saved_logits_bytes(B, Nq, Nk)
+                logits_t = torch.empty(nbytes // 4, device=qn.device, dtype=torch.float32)
             _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd_f16x3", qh.data_ptr(), ql.data_ptr(),
                   kh.data_ptr(), kl.data_ptr(), vh.data_ptr(), vl.data_ptr(), out.data_ptr(), lse.data_ptr(),
-                  _ptr(logits_t), B, K, Nq, Nk, Cv, float(inv_temperature), SPLIT_OPERAND_SCALE, _stream())
+                  _ptr(logits_t), v_scale.data_ptr(), B, K, Nq, Nk, Cv, float(inv_temperature),
+                  SPLIT_OPERAND_SCALE, _stream())
+            ctx.v_amax = v_amax
         else:
+            keep = (keep_logits and B * Nq * Nk * 4 <= MAX_DS_WORKSPACE_BYTES and Nq * Nk * 4 < 2 ** 31 - 1)
+            logits_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if keep else None
             _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd", qn.data_ptr(), kn.data_ptr(),
                   v.data_ptr(), out.data_ptr(), lse.data_ptr(), _ptr(logits_t), B, K, Nq, Nk, Cv,
                   float(inv_temperature), _stream())
@@ -227,7 +250,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         ctx.logits_t = logits_t
         ctx.inv_t = float(inv_temperature)
         # channel-major planes of k_scale*qn, k_scale*kn for the split-precision backward (when given)
-        ctx.cplanes = planes[6:] if (planes is not None and len(planes) > 6 and keep) else None
+        ctx.cplanes = planes[8:] if (planes is not None and len(planes) > 8 and logits_t is not None) else None
         return out
 
     @staticmethod
@@ -242,6 +265,42 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         dv = torch.empty_like(v) if need_v else None
         st = _stream()
         logits_t = ctx.logits_t
+        if ctx.split and logits_t is not None:
+            # split-precision backward: everything on the f16 MFMA, fp32-class accuracy (see cocos_hip.h).  The
+            # forward only takes this flavour (and saves its private logits layout) for shapes this branch takes.
+            qch, qcl, kch, kcl = ctx.cplanes
+            cvp = (Cv + 31) // 32 * 32
+            g_amax, v_amax = absmax(dout), ctx.v_amax         # max|v| was taken once, by the forward
+            gph, gpl, g_scale = split_f16(dout, True, cpad=cvp, amax=g_amax)
+            vph, vpl, v_scale = split_f16(v, True, cpad=cvp, amax=v_amax)
+            half = dict(device=qn.device, dtype=torch.float16)
+            want_k = dkn is not None
+            dsh = dsl = psh = psl = None
+            if want_k:
+                dsh, dsl = torch.empty((B, Nk, Nq), **half), torch.empty((B, Nk, Nq), **half)
+            if dv is not None:      # cycle terms: V itself is differentiated, the key side needs P as well
+                psh, psl = torch.empty((B, Nk, Nq), **half), torch.empty((B, Nk, Nq), **half)
+            ds_scale = torch.empty(1, device=qn.device, dtype=torch.float32)
+            blocked = int(Nk % 128 == 0 and Nq % 32 == 0)     # tile-blocked [Nk][Nq] planes (see cocos_hip.h)
+            if dqn is None:          # the query kernel always accumulates dqn; scratch when nobody wants it
+                dqn_buf = torch.empty_like(qn)
+            else:
+                dqn_buf = dqn
+            _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3", kch.data_ptr(),
+                  kcl.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(),
+                  g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), logits_t.data_ptr(),
+                  dqn_buf.data_ptr(), _ptr(dsh), _ptr(dsl), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
+                  v_scale.data_ptr(), ds_scale.data_ptr(), B, K, Nq, Nk, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE,
+                  blocked, st)
+            if want_k:
+                _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
+                      dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 / SPLIT_OPERAND_SCALE,
+                      ds_scale.data_ptr(), 0, blocked, st)
+            if dv is not None:      # dv[c,j] = sum_i dout[c,i] P[i,j]
+                gch, gcl, _ = split_f16(dout, False, amax=g_amax)
+                _call("corr_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(),
+                      psl.data_ptr(), dv.data_ptr(), B, Cv, Nk, Nq, 1.0 / 16384.0, g_scale.data_ptr(), 0, blocked, st)
+            return dqn, (dkn if need_k else None), dv, None, None, None
         # key side: GEMM over a materialised dS^T when it pays and fits (see cocos_hip.h), else the
         # flash-style kernel that recomputes the logits (always when dv is wanted: it needs P)
         ds_bytes = B * Nq * Nk * 4
@@ -254,35 +313,6 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             _call("corr_softmax_warp_bwd_prepare", "cocos_corr_softmax_warp_bwd_prepare",
                   out.data_ptr(), dout.data_ptr(), dvec.data_ptr(), B, Nq, Cv, st)
         dims = (B, K, Nq, Nk, Cv, ctx.inv_t, st)
-        if (ctx.cplanes is not None and logits_t is not None and dqn is not None and dkn is not None
-                and ds_bytes <= MAX_DS_WORKSPACE_BYTES and Nq * Nk * 4 < 2 ** 31 - 1
-                and Nk % 8 == 0 and Nq % 8 == 0 and Cv <= MAX_FUSED_CV):
-            # split-precision backward: everything on the f16 MFMA, fp32-class accuracy (see cocos_hip.h)
-            qch, qcl, kch, kcl = ctx.cplanes
-            cvp = (Cv + 31) // 32 * 32
-            g_amax, v_amax = absmax(dout), absmax(v)          # one pass each, no host sync
-            gph, gpl, g_scale = split_f16(dout, True, cpad=cvp, amax=g_amax)
-            vph, vpl = split_f16(v, True, cpad=cvp)
-            half = dict(device=qn.device, dtype=torch.float16)
-            dsh, dsl = torch.empty((B, Nk, Nq), **half), torch.empty((B, Nk, Nq), **half)
-            psh = psl = None
-            if dv is not None:      # cycle terms: V itself is differentiated, the key side needs P as well
-                psh, psl = torch.empty((B, Nk, Nq), **half), torch.empty((B, Nk, Nq), **half)
-            ds_scale = torch.empty(1, device=qn.device, dtype=torch.float32)
-            blocked = int(Nk % 128 == 0 and Nq % 32 == 0)     # tile-blocked [Nk][Nq] planes (see cocos_hip.h)
-            _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3", kch.data_ptr(),
-                  kcl.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(),
-                  g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), logits_t.data_ptr(),
-                  dqn.data_ptr(), dsh.data_ptr(), dsl.data_ptr(), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
-                  ds_scale.data_ptr(), B, K, Nq, Nk, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE, blocked, st)
-            _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
-                  dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 / SPLIT_OPERAND_SCALE,
-                  ds_scale.data_ptr(), 0, blocked, st)
-            if dv is not None:      # dv[c,j] = sum_i dout[c,i] P[i,j]
-                gch, gcl, _ = split_f16(dout, False, amax=g_amax)
-                _call("corr_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(),
-                      psl.data_ptr(), dv.data_ptr(), B, Cv, Nk, Nq, 1.0 / 16384.0, g_scale.data_ptr(), 0, blocked, st)
-            return dqn, (dkn if need_k else None), dv, None, None, None
         ds_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if via_gemm else None
         if dqn is not None:
             _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query", qn.data_ptr(),
@@ -304,31 +334,45 @@ def _wants_logits(qn, kn):
     return torch.is_grad_enabled() and (qn.requires_grad or kn.requires_grad)
 
 
-def corr_softmax_warp(qn, kn, v, inv_temperature: float):
+def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes | None = None):
     """out[b,c,i] = sum_j softmax_j(<qn[b,:,i], kn[b,:,j]> * inv_temperature) * v[b,c,j].
 
     qn [B,256,Nq], kn [B,256,Nk], v [B,Cv,Nk] -> [B,Cv,Nq].  Wider V is processed in chunks of
-    160 channels (each chunk recomputes the logits; no materialisation)."""
-    Cv = v.shape[1]
+    159 channels (each chunk recomputes the logits; no materialisation).  `planes`: the caller's per-forward
+    OperandPlanes (theta/phi planes shared by several launches); None = made for this call only."""
+    B, K, Nq = qn.shape
+    Nk, Cv = kn.shape[2], v.shape[1]
     keep = _wants_logits(qn, kn)
     if PRECISION not in ("fp32", "f16x3"):
         raise ValueError(f"cocosnet_amd.ops.PRECISION = {PRECISION!r}: expected 'fp32' or 'f16x3'")
-    split = PRECISION == "f16x3" and qn.shape[1] == FUSED_K and kn.shape[2] % 4 == 0
+    chunk = min(Cv, MAX_FUSED_SPLIT_CV)
+    # the split flavour saves its logits in a private layout only its own backward reads: a training pass takes it
+    # only for shapes that backward takes too (otherwise the exact-fp32 kernels run, forward and backward)
+    split = (PRECISION == "f16x3" and K == FUSED_K and Nk % 4 == 0
+             and (not keep or _split_bwd_ok(B, Nq, Nk, chunk)))
+    if planes is None:
+        planes = OperandPlanes()
 
     def run(vv):
-        planes = None
-        if split:   # operand planes: theta/phi once per forward (cached), V per launch
+        pl = None
+        if split:   # operand planes: theta/phi once per forward (shared through `planes`), V per launch
             with torch.no_grad():
-                planes = (*split_f16(qn, True, SPLIT_OPERAND_SCALE, cache=True),
-                          *split_f16(kn, True, SPLIT_OPERAND_SCALE, cache=True), *split_f16(vv, False, 1.0))
+                # V has no a-priori magnitude in a general forward() call: its planes are normalised by a
+                # device-side power of two like every other operand (one max|v| pass, reused by the backward)
+                v_amax = _recall_amax(vv)
+                if v_amax is None:
+                    v_amax = absmax(vv)
+                vh, vl, v_scale = split_f16(vv, False, amax=v_amax)
+                pl = (*planes.get(qn, True, SPLIT_OPERAND_SCALE), *planes.get(kn, True, SPLIT_OPERAND_SCALE),
+                      vh, vl, v_scale, v_amax)
                 if keep:   # the backward wants the channel-major planes as well
-                    planes += (*split_f16(qn, False, SPLIT_OPERAND_SCALE, cache=True),
-                               *split_f16(kn, False, SPLIT_OPERAND_SCALE, cache=True))
-        return _CorrSoftmaxWarp.apply(qn, kn, vv, inv_temperature, keep, planes)
+                    pl += (*planes.get(qn, False, SPLIT_OPERAND_SCALE), *planes.get(kn, False, SPLIT_OPERAND_SCALE))
+        return _CorrSoftmaxWarp.apply(qn, kn, vv, inv_temperature, keep, pl)
 
-    if Cv <= MAX_FUSED_CV:
+    limit = MAX_FUSED_SPLIT_CV if split else MAX_FUSED_CV
+    if Cv <= limit:
         return run(v)
-    return torch.cat([run(v[:, c0:c0 + MAX_FUSED_CV]) for c0 in range(0, Cv, MAX_FUSED_CV)], dim=1)
+    return torch.cat([run(v[:, c0:c0 + limit]) for c0 in range(0, Cv, limit)], dim=1)
 
 
 # ------------------------------------------------------------------------------------------
@@ -461,29 +505,39 @@ def warp_materialized(p, v):
 # ------------------------------------------------------------------------------------------
 # K0  theta / phi 1x1 projections            (correspondence.py:272, :282)
 # ------------------------------------------------------------------------------------------
-_zero_pool = {}      # (device, stream) -> [zeros tensor, next free cell]
-_known_amax = {}     # storage pointer -> (the tensor, its version, amax cell); at most _KNOWN_AMAX_MAX entries
+class _ThreadState(threading.local):
+    """Host-side scratch that must not be shared between threads (SURVEY.md §8b threading contract: under the
+    reference's DataParallelWithCallback every replica's forward runs in its own Python thread, and autograd runs
+    each device's backward in its own thread): the pool of pre-zeroed max|x| cells and the producer -> consumer
+    max|x| table.  threading.local gives every thread its own instance; no locks on the hot path."""
+
+    def __init__(self):
+        self.zero_pool = {}      # (device, stream) -> [zeros tensor, next free cell]
+        self.known_amax = {}     # (device, storage pointer) -> (the tensor, its version, amax cell)
 
 
-_KNOWN_AMAX_MAX = 2
+_tls = _ThreadState()
+_KNOWN_AMAX_MAX = 2      # entries per thread
 
 
 def _remember_amax(t: torch.Tensor, cell: torch.Tensor):
     """A producer kernel computed max|t| while writing t: keep it for the consumer (autograd hands the gradient on
-    as a view of the same storage).  The entry holds the tensor itself, so its address cannot be recycled for other
-    data while the entry exists; it is dropped when the consumer picks it up, or when two younger ones arrive."""
-    while len(_known_amax) >= _KNOWN_AMAX_MAX:
-        _known_amax.pop(next(iter(_known_amax)))
-    _known_amax[t.untyped_storage().data_ptr()] = (t, t._version, cell)
+    as a view of the same storage; producer and consumer of one device's backward run in the same thread).  The entry
+    holds the tensor itself, so its address cannot be recycled for other data while the entry exists; it is dropped
+    when the consumer picks it up, or when two younger ones arrive — producers only register tensors whose consumer
+    is one of our own kernels (K0 / K3), so at most two gradients per thread outlive their step."""
+    table = _tls.known_amax
+    while len(table) >= _KNOWN_AMAX_MAX:
+        table.pop(next(iter(table)), None)
+    table[(t.device, t.untyped_storage().data_ptr())] = (t, t._version, cell)
 
 
 def _recall_amax(t: torch.Tensor, consume: bool = True):
-    key = t.untyped_storage().data_ptr()
-    ent = _known_amax.get(key)
+    table = _tls.known_amax
+    key = (t.device, t.untyped_storage().data_ptr())
+    ent = table.pop(key, None) if consume else table.get(key)
     if ent is None:
         return None
-    if consume:
-        del _known_amax[key]
     src, version, cell = ent
     if (t.numel() != src.numel() or t.storage_offset() != src.storage_offset() or not t.is_contiguous()
             or t._version != version or src._version != version):
@@ -492,12 +546,13 @@ def _recall_amax(t: torch.Tensor, consume: bool = True):
 
 
 def _zero_cell(device) -> torch.Tensor:
-    """A 1-element fp32 tensor holding 0, from a pool zeroed 4096 cells at a time on the current stream (one fill
-    per ~500 steps instead of a 5 us memset in front of each of the eight max|x| passes of a step)."""
+    """A 1-element fp32 tensor holding 0, from a per-thread pool zeroed 4096 cells at a time on the current stream
+    (one fill per ~500 steps instead of a 5 us memset in front of each of the max|x| passes of a step)."""
+    pool = _tls.zero_pool
     key = (device, _stream())
-    ent = _zero_pool.get(key)
+    ent = pool.get(key)
     if ent is None or ent[1] >= ent[0].numel():
-        ent = _zero_pool[key] = [torch.zeros(4096, device=device, dtype=torch.float32), 0]
+        ent = pool[key] = [torch.zeros(4096, device=device, dtype=torch.float32), 0]
     cell = ent[0][ent[1]:ent[1] + 1]
     ent[1] += 1
     return cell
@@ -614,7 +669,8 @@ class _Proj1x1(torch.autograd.Function):
 
 
 def proj1x1(x, weight, bias=None):
-    """nn.Conv2d(Cin, Cout, kernel_size=1) on the fp32-MFMA GEMM: x [B,Cin,h,w], weight [Cout,Cin,1,1]."""
+    """nn.Conv2d(Cin, Cout, kernel_size=1): x [B,Cin,h,w], weight [Cout,Cin,1,1].  PROJ_PRECISION "f16x3" (default):
+    the streaming split-precision kernels at the reference's shapes, else the split GEMM; "fp32": the fp32-MFMA GEMM."""
     return _Proj1x1.apply(x, weight, bias)
 
 
@@ -721,10 +777,14 @@ class _LogitsSoftmaxWarp(torch.autograd.Function):
         out = torch.empty((B, Cv, Nq), device=v.device, dtype=torch.float32)
         lse = torch.empty((B, Nq), device=v.device, dtype=torch.float32)
         split = PRECISION == "f16x3" and Nk % 4 == 0 and Cv <= MAX_FUSED_CV and Nq * Nk * 4 < 2 ** 31 - 1
-        if split:      # P.V on the f16 MFMA (logits_softmax_warp_f16x3.hip)
-            vh, vl = split_f16(v, False, 1.0)
+        ctx.v_amax = None
+        if split:      # P.V on the f16 MFMA (logits_softmax_warp_f16x3.hip); V planes normalised on the device
+            ctx.v_amax = _recall_amax(v)
+            if ctx.v_amax is None:
+                ctx.v_amax = absmax(v)
+            vh, vl, v_scale = split_f16(v, False, amax=ctx.v_amax)
             _call("logits_softmax_warp_fwd", "cocos_logits_softmax_warp_fwd_f16x3", logits_t.data_ptr(), vh.data_ptr(),
-                  vl.data_ptr(), out.data_ptr(), lse.data_ptr(), B, Nq, Nk, Cv, _stream())
+                  vl.data_ptr(), out.data_ptr(), lse.data_ptr(), v_scale.data_ptr(), B, Nq, Nk, Cv, _stream())
         else:
             _call("logits_softmax_warp_fwd", "cocos_logits_softmax_warp_fwd", logits_t.data_ptr(), v.data_ptr(),
                   out.data_ptr(), lse.data_ptr(), B, Nq, Nk, Cv, _stream())
@@ -744,10 +804,10 @@ class _LogitsSoftmaxWarp(torch.autograd.Function):
             if ctx.split:
                 cvp = (Cv + 31) // 32 * 32
                 gph, gpl, gs = split_f16(dout, True, cpad=cvp, amax=absmax(dout))
-                vph, vpl = split_f16(v, True, cpad=cvp)
+                vph, vpl, v_scale = split_f16(v, True, cpad=cvp, amax=ctx.v_amax)
                 _call("logits_softmax_warp_bwd", "cocos_logits_softmax_warp_bwd_f16x3", logits_t.data_ptr(),
-                      vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(), gs.data_ptr(), out.data_ptr(),
-                      dout.data_ptr(), lse.data_ptr(), dlg.data_ptr(), B, Nq, Nk, Cv, cvp, _stream())
+                      vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(), gs.data_ptr(), v_scale.data_ptr(),
+                      out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dlg.data_ptr(), B, Nq, Nk, Cv, cvp, _stream())
             else:
                 _call("logits_softmax_warp_bwd", "cocos_logits_softmax_warp_bwd", logits_t.data_ptr(), v.data_ptr(),
                       out.data_ptr(), lse.data_ptr(), dout.data_ptr(), dlg.data_ptr(), B, Nq, Nk, Cv, _stream())

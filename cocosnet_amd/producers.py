@@ -33,9 +33,10 @@ def _param_free_norm(kind: str, channels: int):
     if kind == "batch":
         return nn.BatchNorm2d(channels, affine=False)
     if kind == "syncbatch":
-        # the reference's Python-queue SynchronizedBatchNorm2d -> torch's SyncBatchNorm, whose
-        # statistics exchange is an RCCL all-reduce under backend "nccl" (same buffer names)
-        return nn.SyncBatchNorm(channels, affine=False)
+        # the reference's Python-queue SynchronizedBatchNorm2d -> statistics all-reduced over the process group
+        # (RCCL over xGMI under backend "nccl"; same buffer names, so checkpoints load) — cocosnet_amd/dist.py
+        from .dist import SyncBatchNorm2d
+        return SyncBatchNorm2d(channels, affine=False)
     raise ValueError(f"{kind} is not a recognised parameter-free norm for SPADE")
 
 
@@ -175,7 +176,8 @@ def nonspade_norm_layer(opt, norm_type):
         if sub == "batch":
             norm = nn.BatchNorm2d(ch, affine=True)
         elif sub == "sync_batch":
-            norm = nn.SyncBatchNorm(ch, affine=True)
+            from .dist import SyncBatchNorm2d
+            norm = SyncBatchNorm2d(ch, affine=True)
         elif sub == "instance":
             norm = nn.InstanceNorm2d(ch, affine=False)
         else:

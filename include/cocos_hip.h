@@ -100,14 +100,24 @@ int cocos_corr_softmax_warp_fwd(const float* qn, const float* kn, const float* v
  *   cocos_split_f16:  x [B,C,N] fp32 -> hi, lo (f16); transpose = 0: [B,C,N]; 1: [B,N,C]; `scale` must be
  *                     a power of two (exact).
  *   qh,ql [B,Nq,256]  kh,kl [B,Nk,256]  position-major planes of qn*operand_scale, kn*operand_scale
- *   vh,vl [B,Cv,Nk]   channel-major planes of v (scale 1)
- *   Supported: K == 256, 1 <= Cv <= 160, Nk % 4 == 0 (otherwise COCOS_ERR_UNSUPPORTED: use the fp32 call).
+ *   vh,vl [B,Cv,Nk]   channel-major planes of v * s_v, s_v = *v_scale_dev (a power of two, e.g. the one
+ *                     cocos_split_f16_ex derives from max|v|; NULL = 1): V has no a-priori magnitude in a general
+ *                     forward() call, so its planes are normalised like every other operand and the epilogue
+ *                     undoes the scale
+ *   saved_logits      NULL (inference: nothing HWxHW reaches HBM) or cocos_corr_softmax_warp_saved_logits_bytes()
+ *                     bytes, 16-byte aligned (training): the raw logits accumulator of every 32x32 tile in a
+ *                     PRIVATE tile-blocked layout ([key tile][32-query block][k][lane][4]: four contiguous 1 KB
+ *                     stores per wave and tile), read back only by cocos_corr_softmax_warp_bwd_query_f16x3
+ *   Supported: K == 256, 1 <= Cv <= 159 (one padding channel of the V tile carries the row sums), Nk % 4 == 0
+ *   (otherwise COCOS_ERR_UNSUPPORTED: use the fp32 call).
  * ------------------------------------------------------------------------------------- */
 int cocos_split_f16(const float* x, void* hi, void* lo, int B, int C, int N, int transpose, float scale,
                     cocos_stream_t stream);
+size_t cocos_corr_softmax_warp_saved_logits_bytes(int B, int Nq, int Nk);
 int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void* kh, const void* kl,
                                       const void* vh, const void* vl,
-                                      float* out, float* lse, float* logits_t /* nullable */,
+                                      float* out, float* lse, void* saved_logits /* nullable */,
+                                      const float* v_scale_dev /* nullable */,
                                       int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
                                       float operand_scale, cocos_stream_t stream);
 
@@ -117,10 +127,11 @@ int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void
  *       *amax_dev (= max|x|, e.g. torch's x.abs().amax()) into [2^9, 2^10), and written to *scale_out_dev.
  *   cocos_corr_softmax_warp_bwd_query_f16x3:
  *       kch,kcl [B,256,Nk]  channel-major planes of k_scale*kn
- *       vph,vpl [B,Nk,CvPad] position-major planes of v;   gph,gpl [B,Nq,CvPad] of s_o*dout, s_o = *g_scale_dev
- *       out, dout [B,Cv,Nq] fp32 (for D = sum_c dout*out, fp64);  lse, logits_t as saved by the forward
- *       -> dqn [B,256,Nq] fp32;  dsh,dsl [B,Nk,Nq] planes of dS'' = s_o*ds_shift * dS^T/T (both NULL: skipped);
- *          *ds_scale_out_dev = s_o*ds_shift (ds_shift is derived on the device from *v_amax_dev = max|v|);
+ *       vph,vpl [B,Nk,CvPad] position-major planes of s_v*v, s_v = *v_scale_dev (NULL = 1);
+ *       gph,gpl [B,Nq,CvPad] of s_o*dout, s_o = *g_scale_dev
+ *       out, dout [B,Cv,Nq] fp32 (for D = sum_c dout*out, fp64);  lse, saved_logits as left by the f16x3 forward
+ *       -> dqn [B,256,Nq] fp32;  dsh,dsl [B,Nk,Nq] planes of dS'' = s_o*s_v*ds_shift * dS^T/T (both NULL: skipped);
+ *          *ds_scale_out_dev = s_o*s_v*ds_shift (ds_shift is derived on the device from *v_amax_dev = max|v|);
  *          psh,psl [B,Nk,Nq] planes of 2^14 * P (both NULL: skipped) for the V gradient of the cycle terms:
  *          dv = hgemm(A = channel-major planes of s_o*dout [Cv][Nq], B = P planes, host_scale = 2^-14,
  *          dev_scale = g_scale_dev)
@@ -141,9 +152,10 @@ int cocos_split_f16_rows(const float* x, void* hi, void* lo, int rows, int cols,
                          const float* amax_dev, float* scale_out_dev, cocos_stream_t stream);
 int cocos_corr_softmax_warp_bwd_query_f16x3(
     const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
-    const float* g_scale_dev, const float* out, const float* dout, const float* lse, const float* logits_t,
+    const float* g_scale_dev, const float* out, const float* dout, const float* lse, const void* saved_logits,
     float* dqn, void* dsh /* nullable */, void* dsl /* nullable */, void* psh /* nullable */,
-    void* psl /* nullable */, const float* v_amax_dev, float* ds_scale_out_dev,
+    void* psl /* nullable */, const float* v_amax_dev, const float* v_scale_dev /* nullable */,
+    float* ds_scale_out_dev,
     int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale,
     int planes_blocked, cocos_stream_t stream);
 int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* c,
@@ -365,15 +377,16 @@ int cocos_warp_values(const float* img, const float* seg, float* out, int B, int
                       int down, cocos_stream_t stream);
 
 /* K7 on the f16 MFMA (same contract as cocos_logits_softmax_warp_fwd / _bwd; operand planes as for K2's split flavour):
- *   fwd: vh,vl [B,Cv,Nk] channel-major planes of v; Nk % 4 == 0
- *   bwd: vph,vpl [B,Nk,CvPad] and gph,gpl [B,Nq,CvPad] position-major planes of v and of (*g_scale_dev)*dout
+ *   fwd: vh,vl [B,Cv,Nk] channel-major planes of s_v*v, s_v = *v_scale_dev (NULL = 1; undone in the epilogue); Nk % 4 == 0
+ *   bwd: vph,vpl [B,Nk,CvPad] and gph,gpl [B,Nq,CvPad] position-major planes of s_v*v and of (*g_scale_dev)*dout
  *        (cocos_split_f16_ex), out/dout fp32 for D; writes dlogits_t fp32. */
 int cocos_logits_softmax_warp_fwd_f16x3(const float* logits_t, const void* vh, const void* vl, float* out, float* lse,
-                                        int B, int Nq, int Nk, int Cv, cocos_stream_t stream);
-int cocos_logits_softmax_warp_bwd_f16x3(const float* logits_t, const void* vph, const void* vpl, const void* gph,
-                                        const void* gpl, const float* g_scale_dev, const float* out, const float* dout,
-                                        const float* lse, float* dlogits_t, int B, int Nq, int Nk, int Cv, int CvPad,
+                                        const float* v_scale_dev /* nullable */, int B, int Nq, int Nk, int Cv,
                                         cocos_stream_t stream);
+int cocos_logits_softmax_warp_bwd_f16x3(const float* logits_t, const void* vph, const void* vpl, const void* gph,
+                                        const void* gpl, const float* g_scale_dev, const float* v_scale_dev /* nullable */,
+                                        const float* out, const float* dout, const float* lse, float* dlogits_t, int B,
+                                        int Nq, int Nk, int Cv, int CvPad, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K12 statistics of the zero-padded 3x3-unfolded, centred feature vectors without unfolding (match_kernel 3 with

@@ -1,7 +1,8 @@
-"""world_size-2 `gloo` test of the data-parallel gradient exchange (cocosnet_amd/dist.py) on CPU.
-The same code runs over RCCL (`nccl`) on the GPU box; here it proves the bucketing / averaging /
-sharding logic: after all_reduce_ every rank holds the mean of the per-rank gradients, which equals
-the gradient of the mean loss over the GLOBAL batch."""
+"""world_size-2 `gloo` tests of the data-parallel exchange (cocosnet_amd/dist.py) on CPU.
+The same code runs over RCCL (`nccl`) on the GPU box; here it proves the bucketing / hook-driven overlap /
+averaging / sharding logic and the Sync-BN statistics exchange: after finish() every rank holds the mean of the
+per-rank gradients, which equals the gradient of the mean loss over the GLOBAL batch; SyncBatchNorm2d over two ranks
+equals nn.BatchNorm2d over the concatenated batch (output, input gradient, running statistics)."""
 import os
 import socket
 
@@ -27,7 +28,7 @@ def _data(global_batch=4):
     return torch.randn(global_batch, 5, 6, 6, generator=g), torch.randn(global_batch, 3, 6, 6, generator=g)
 
 
-def _worker(rank, world, port, bucket_bytes, ret):
+def _worker(rank, world, port, bucket_bytes, overlap, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from cocosnet_amd import dist as cdist
@@ -36,29 +37,46 @@ def _worker(rank, world, port, bucket_bytes, ret):
     model = _model()
     x, y = _data()
     lo, hi = cdist.shard_batch(x.shape[0], rank, world)
-    loss = ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean()
-    loss.backward()
-    buckets = cdist.GradBuckets(model.parameters(), bucket_bytes=bucket_bytes)
-    buckets.all_reduce_()
-    ret[rank] = [p.grad.clone() for p in model.parameters()]
+    buckets = cdist.GradBuckets(model.parameters(), bucket_bytes=bucket_bytes, overlap=overlap)
+    launched_during_backward = []
+    for step in range(2):                       # second step: buffers are reused, zero_grad() re-arms the hooks
+        buckets.zero_grad()
+        if step == 1:
+            list(model.parameters())[0].grad = None            # a caller that still does `p.grad = None`
+        loss = ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean()
+        loss.backward()
+        launched_during_backward.append(sum(buckets._launched))
+        buckets.finish()
+    ret[rank] = ([p.grad.clone() for p in model.parameters()], launched_during_backward,
+                 all(p.grad.data_ptr() >= buckets._flat[buckets._bucket_of[p]].data_ptr() for p in model.parameters()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucket_bytes", [64, 1 << 20])   # many tiny buckets / one bucket
-def test_gradient_allreduce_equals_global_batch_gradient(bucket_bytes):
+@pytest.mark.parametrize("bucket_bytes,overlap", [(64, True), (1 << 20, True), (64, False)])
+def test_gradient_allreduce_equals_global_batch_gradient(bucket_bytes, overlap):
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, bucket_bytes, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, bucket_bytes, overlap, ret), nprocs=world, join=True)
     model = _model()
     x, y = _data()
     ((model(x) - y) ** 2).mean().backward()
     ref = [p.grad for p in model.parameters()]
+    n_buckets = None
     for rank in range(world):
-        for a, b in zip(ret[rank], ref):
+        grads, launched, views = ret[rank]
+        for a, b in zip(grads, ref):
             assert torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+        assert views                                            # gradients live in the flat buckets (no copy in/out)
+        if overlap:                                             # every bucket left from a hook, i.e. DURING backward
+            assert launched[0] > 0 and launched[0] == launched[1]
+            n_buckets = launched[0]
+        else:
+            assert launched == [0, 0]
+    if overlap and bucket_bytes == 64:
+        assert n_buckets > 1
 
 
 def test_bucket_layout_and_sharding():
@@ -68,7 +86,81 @@ def test_bucket_layout_and_sharding():
     assert sum(len(x) for x in b.buckets) == len(list(model.parameters()))
     assert b.buckets[0][0] is list(model.parameters())[-1]          # reverse (gradient-ready) order
     assert b.nbytes() == sum(p.numel() for p in model.parameters()) * 4
+    # p.grad is a view into its bucket; single-process finish() is a no-op that leaves the sums alone
+    x, y = _data()
+    b.zero_grad()
+    ((model(x) - y) ** 2).mean().backward()
+    flat_sum = sum(float(f.abs().sum()) for f in b._flat)
+    assert flat_sum > 0 and abs(flat_sum - sum(float(p.grad.abs().sum()) for p in model.parameters())) < 1e-4
+    b.finish()
     assert cdist.shard_batch(64, 3, 8) == (24, 32)
     with pytest.raises(ValueError):
         cdist.shard_batch(10, 0, 4)
     assert cdist.init_from_env() == (0, 0, 1) or os.environ.get("WORLD_SIZE", "1") != "1"
+
+
+# ---------------------------------------------------------------------------------- Sync-BN statistics
+def _bn_data():
+    g = torch.Generator().manual_seed(2)
+    return torch.randn(6, 4, 5, 3, generator=g) * 2 + 0.5, torch.randn(6, 4, 5, 3, generator=g)
+
+
+def _bn_worker(rank, world, port, affine, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from cocosnet_amd import dist as cdist
+    cdist.init_from_env("gloo")
+    torch.manual_seed(3)
+    bn = cdist.SyncBatchNorm2d(4, affine=affine)
+    if affine:
+        with torch.no_grad():
+            bn.weight.copy_(torch.tensor([1.5, 0.5, -1.0, 2.0])); bn.bias.copy_(torch.tensor([0.1, -0.2, 0.3, 0.0]))
+    x, g = _bn_data()
+    lo, hi = (0, 2) if rank == 0 else (2, 6)            # UNEVEN shards: the count is part of the exchange
+    xs = x[lo:hi].clone().requires_grad_(True)
+    y = bn(xs)
+    y.backward(g[lo:hi])
+    wg = bn.weight.grad.clone() if affine else None
+    bn.eval()
+    ye = bn(x[:1])
+    ret[rank] = (y.detach(), xs.grad, wg, bn.running_mean.clone(), bn.running_var.clone(), ye.detach(),
+                 int(bn.num_batches_tracked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("affine", [False, True])
+def test_sync_batchnorm_equals_batchnorm_over_the_global_batch(affine):
+    """The reference without --PONO normalises SPADE with SynchronizedBatchNorm2d (normalization.py:101): statistics
+    over the GLOBAL batch.  Two ranks with 2 + 4 samples == nn.BatchNorm2d on all 6."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bn_worker, args=(world, port, affine, ret), nprocs=world, join=True)
+    x, g = _bn_data()
+    ref = torch.nn.BatchNorm2d(4, affine=affine)
+    if affine:
+        with torch.no_grad():
+            ref.weight.copy_(torch.tensor([1.5, 0.5, -1.0, 2.0])); ref.bias.copy_(torch.tensor([0.1, -0.2, 0.3, 0.0]))
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g)
+    ref.eval()
+    for rank, (lo, hi) in enumerate(((0, 2), (2, 6))):
+        y, dx, wg, rm, rv, ye, nb = ret[rank]
+        assert torch.allclose(y, yr[lo:hi].detach(), atol=1e-5)
+        assert torch.allclose(dx, xr.grad[lo:hi], atol=1e-5)
+        assert torch.allclose(rm, ref.running_mean, atol=1e-6) and torch.allclose(rv, ref.running_var, atol=1e-5)
+        assert torch.allclose(ye, ref(x[:1]).detach(), atol=1e-5) and nb == 1
+    if affine:      # local sums; the gradient all-reduce (GradBuckets) adds them up
+        assert torch.allclose(ret[0][2] + ret[1][2], ref.weight.grad, atol=1e-4)
+
+
+def test_sync_batchnorm_single_process_and_state_dict_names():
+    from cocosnet_amd import dist as cdist
+    bn, ref = cdist.SyncBatchNorm2d(3), torch.nn.BatchNorm2d(3)
+    assert set(bn.state_dict()) == set(ref.state_dict())           # reference checkpoints load unchanged
+    x = torch.randn(4, 3, 2, 2)
+    assert torch.allclose(bn(x), ref(x), atol=1e-5)
+    assert torch.allclose(bn.running_var, ref.running_var, atol=1e-6)

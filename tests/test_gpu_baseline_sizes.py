@@ -1,0 +1,416 @@
+"""GPU parity at BASELINE.json's REAL sizes (run with `-m gpu` on an MI355X), against fp64 oracles.
+
+Round-1 VERDICT, "what's weak" 1-3: the configurations that are benchmarked must also be CHECKED —
+  (i)   the exact bench.py step (B=8, HW=4096, Cl=407, Cv=154, gradients of theta/phi only, K0 -> K1 -> K2 and back),
+        outputs and every gradient, both arithmetic flavours;
+  (ii)  BASELINE config 3 (CelebA-HQ edge, B=16, warp_cycle + two_cycle, bilinear) — first and last sample;
+  (iii) BASELINE config 5 (128x128 grid, HW=16384): forward and theta-gradient on sampled query rows, the key side
+        against the independent exact-fp32 recompute kernels (the fallback above MAX_DS_WORKSPACE_BYTES), at size;
+  (iv)  operand-range robustness of the split flavour: V scaled by 1e5 / 1e-6, a gradient with 1e6 dynamic range;
+plus the boundary contract: two Python threads on two streams (the reference's DataParallelWithCallback threading
+model) and a stand-in for the callers at pix2pix_model.py:303-337.
+
+Checker: oracle/torch_ref.py (torch CPU autograd in float64, pinned to the reference's fixtures by
+tests/test_oracle_golden.py) and oracle/corr_oracle.py.  Tolerances as in test_gpu_parity.py:
+max|x - ref| / max|ref| < 2e-4 (north_star: 1e-3).
+"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import corr_oracle as co
+from oracle import torch_ref as tr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(hip_lib):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (the HIP path has no fallback)")
+
+
+@pytest.fixture(params=["f16x3", "fp32"])
+def precision(request, monkeypatch):
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PRECISION", request.param)
+    monkeypatch.setattr(ops, "PROJ_PRECISION", request.param)
+    return request.param
+
+
+def rel(x, ref, floor=1e-30):
+    x = x.detach().double().cpu().numpy() if torch.is_tensor(x) else np.asarray(x, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert x.shape == ref.shape, (x.shape, ref.shape)
+    return float(np.abs(x - ref).max() / (np.abs(ref).max() + floor))
+
+
+def dev(a, grad=False):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV).requires_grad_(grad)
+
+
+def nrm(x):
+    return co.center_l2norm(x, True)
+
+
+# ------------------------------------------------------------------ (i) the bench.py step itself
+@pytest.fixture(scope="module")
+def bench_oracle():
+    """fp64 oracle of bench.py's step on bench.py's own inputs: theta/phi 1x1 convs -> hot path (ADE20k flags) ->
+    loss <warp_out, G_out> + <warp_mask, G_mask>, sample by sample (the path is per-sample; the weight gradients
+    are the sum over the batch).  Returns the module state, the inputs and every reference tensor."""
+    import bench
+    torch.manual_seed(0)
+    device = torch.device(DEV)
+    model = bench.HotPathStep(1).to(device)
+    d = bench.build_inputs(device, "hotpath")
+    opt = co.default_opt(match_kernel=1, PONO_C=True, down=bench.DOWN, warp_mask_losstype="direct")
+    f64 = lambda t: t.detach().double().cpu().numpy()
+    Wt, bt, Wp, bp = (f64(p) for p in (model.theta.weight, model.theta.bias, model.phi.weight, model.phi.bias))
+    Wt, Wp = Wt.reshape(Wt.shape[0], -1), Wp.reshape(Wp.shape[0], -1)
+    B = d["cont_features"].shape[0]
+    fh = d["cont_features"].shape[2]
+    ref = dict(warp_out=[], warp_mask=[], dcont=[], dref=[], dWt=0.0, dbt=0.0, dWp=0.0, dbp=0.0)
+    for b in range(B):
+        xc, xr = f64(d["cont_features"][b]).reshape(-1, fh * fh), f64(d["ref_features"][b]).reshape(-1, fh * fh)
+        theta = (Wt @ xc + bt[:, None]).reshape(1, -1, fh, fh)            # :272
+        phi = (Wp @ xr + bp[:, None]).reshape(1, -1, fh, fh)              # :282
+        sl = slice(b, b + 1)
+        outs, dth, dph = tr.forward_backward(
+            theta, phi, f64(d["ref_img"][sl]), f64(d["real_img"][sl]), f64(d["seg"][sl]), f64(d["ref_seg"][sl]), opt,
+            {"warp_out": f64(d["g_out"][sl]), "warp_mask": f64(d["g_mask"][sl])})
+        dth, dph = dth.reshape(-1, fh * fh), dph.reshape(-1, fh * fh)
+        ref["warp_out"].append(outs["warp_out"][0]); ref["warp_mask"].append(outs["warp_mask"][0])
+        ref["dcont"].append((Wt.T @ dth).reshape(-1, fh, fh)); ref["dref"].append((Wp.T @ dph).reshape(-1, fh, fh))
+        ref["dWt"] = ref["dWt"] + dth @ xc.T; ref["dbt"] = ref["dbt"] + dth.sum(1)
+        ref["dWp"] = ref["dWp"] + dph @ xr.T; ref["dbp"] = ref["dbp"] + dph.sum(1)
+    for k in ("warp_out", "warp_mask", "dcont", "dref"):
+        ref[k] = np.stack(ref[k])
+    return model, d, ref
+
+
+def test_bench_configuration_forward_and_all_gradients_vs_fp64(bench_oracle, precision):
+    """B=8, HW=4096, Cl=407, Cv=154: the step bench.py times, output for output and gradient for gradient (the
+    theta/phi-only backward: saved logits -> query kernel in the blocked layout -> planes GEMM over all 8 samples,
+    then K1 and K0 backward)."""
+    model, d, ref = bench_oracle
+    for p in model.parameters():
+        p.grad = None
+    for k in ("cont_features", "ref_features"):
+        d[k].grad = None
+    out = model(d)
+    torch.autograd.backward([out["warp_out"], out["warp_mask"]], [d["g_out"], d["g_mask"]])
+    assert rel(out["warp_out"], ref["warp_out"]) < TOL
+    assert rel(out["warp_mask"], ref["warp_mask"]) < TOL
+    assert rel(d["cont_features"].grad, ref["dcont"]) < TOL
+    assert rel(d["ref_features"].grad, ref["dref"]) < TOL
+    W = model.theta.weight.shape
+    assert rel(model.theta.weight.grad, ref["dWt"].reshape(W)) < TOL
+    assert rel(model.phi.weight.grad, ref["dWp"].reshape(W)) < TOL
+    assert rel(model.theta.bias.grad, ref["dbt"]) < TOL
+    assert rel(model.phi.bias.grad, ref["dbp"]) < TOL
+
+
+# ------------------------------------------------------------------ (ii) BASELINE config 3: CelebA-HQ edge, B = 16, cycle terms
+def test_config3_celeba_cycle_b16_first_and_last_sample(precision):
+    """README.md:106 flags (--warp_bilinear --warp_cycle_w 1) + two_cycle, 15 float label channels, B=16, 64x64 grid:
+    R1 / C1 / R2 passes with V differentiated (P planes + second GEMM); outputs and d theta / d phi of samples 0 and
+    15 against torch-fp64 autograd of the reference formulation."""
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    B, S, d = 16, 256, 4
+    fh = S // d
+    g = torch.Generator(device=DEV).manual_seed(3)
+    th = torch.randn(B, 256, fh, fh, device=DEV, generator=g)
+    perm = torch.randperm(fh * fh, device=DEV, generator=g)
+    ph = (0.25 * th.reshape(B, 256, -1)[:, :, perm].reshape(B, 256, fh, fh)
+          + torch.randn(B, 256, fh, fh, device=DEV, generator=g))
+    ref_img = torch.rand(B, 3, S, S, device=DEV, generator=g) * 2 - 1
+    real_img = torch.rand(B, 3, S, S, device=DEV, generator=g) * 2 - 1
+    seg = torch.rand(B, 15, S, S, device=DEV, generator=g)
+    ref_seg = torch.rand(B, 15, S, S, device=DEV, generator=g)
+    flags = dict(match_kernel=1, PONO_C=True, down=d, warp_bilinear=True, isTrain=True, warp_mask_losstype="none",
+                 warp_cycle_w=1.0, two_cycle=True)
+    th.requires_grad_(True); ph.requires_grad_(True)
+    out = correspondence_hot_path(th, ph, ref_img, real_img, seg, ref_seg, HotPathConfig(**flags))
+    assert set(out) == {"warp_out", "warp_cycle", "warp_i2r", "warp_i2r2i"}
+    G = {k: torch.randn(v.shape, device=DEV, generator=g) for k, v in sorted(out.items())}
+    torch.autograd.backward([out[k] for k in sorted(out)], [G[k] for k in sorted(out)])
+    f64 = lambda t: t.detach().double().cpu().numpy()
+    for b in (0, B - 1):
+        sl = slice(b, b + 1)
+        outs, dth, dph = tr.forward_backward(f64(th[sl]), f64(ph[sl]), f64(ref_img[sl]), f64(real_img[sl]), f64(seg[sl]),
+                                             f64(ref_seg[sl]), co.default_opt(**flags), {k: f64(G[k][sl]) for k in G})
+        for k in outs:
+            assert rel(out[k][sl], outs[k]) < TOL, (b, k)
+        assert rel(th.grad[sl], dth) < TOL, b
+        assert rel(ph.grad[sl], dph) < TOL, b
+
+
+# ------------------------------------------------------------------ (iii) BASELINE config 5: 128x128 grid, HW = 16384
+def _rows_oracle(qn, kn, v, g, idx, inv_t):
+    """fp64 out[:, idx] and dqn[:, idx] of ONE sample: both depend on the sampled query rows only."""
+    q = qn[:, idx]                                                   # [K, S]
+    f = (q.T @ kn) * inv_t                                           # [S, Nk]
+    p = co.softmax(f, axis=-1)
+    out = (p @ v.T).T                                                # [Cv, S]
+    dp = g[:, idx].T @ v                                             # [S, Nk]
+    ds = p * (dp - (p * dp).sum(-1, keepdims=True)) * inv_t
+    return out, kn @ ds.T                                            # [K, S]
+
+
+def test_config5_hw16384_sampled_rows_and_key_side_vs_recompute(monkeypatch):
+    """DeepFashion --warp_patch at 512x512: 128x128 grid, Cv = 48, saved logits = 1 GiB per sample (just below the 2^31
+    per-sample guards).  Forward and d theta on sampled query rows vs fp64; d phi (a sum over ALL queries) against the
+    exact-fp32 recompute kernels — the path taken above MAX_DS_WORKSPACE_BYTES — which also exercises that fallback
+    at size.  Both flavours in one test (the comparison IS between them)."""
+    from cocosnet_amd import ops
+    B, N, Cv = 2, 16384, 48
+    g = torch.Generator(device=DEV).manual_seed(5)
+    q = torch.randn(B, 256, N, device=DEV, generator=g)
+    k = 0.25 * q[:, :, torch.randperm(N, device=DEV, generator=g)] + torch.randn(B, 256, N, device=DEV, generator=g)
+    q = q - q.mean(1, keepdim=True); q = q / q.norm(dim=1, keepdim=True)
+    k = k - k.mean(1, keepdim=True); k = k / k.norm(dim=1, keepdim=True)
+    v = torch.rand(B, Cv, N, device=DEV, generator=g) * 2 - 1
+    go = torch.randn(B, Cv, N, device=DEV, generator=g)
+    res = {}
+    for name, prec, limit in (("split", "f16x3", 16 << 30), ("recompute", "fp32", 0)):
+        monkeypatch.setattr(ops, "PRECISION", prec)
+        monkeypatch.setattr(ops, "MAX_DS_WORKSPACE_BYTES", limit)
+        qq, kk = q.clone().requires_grad_(True), k.clone().requires_grad_(True)
+        with ops.KernelTimer() as kt:
+            o = ops.corr_softmax_warp(qq, kk, v, 100.0)
+            o.backward(go)
+        tags = set(kt.summary())
+        res[name] = (o.detach(), qq.grad, kk.grad, tags)
+    assert "corr_softmax_warp_bwd_key_from_ds" in res["split"][3]          # saved logits + planes GEMM
+    assert "corr_softmax_warp_bwd_key" in res["recompute"][3]              # flash-style fallback
+    idx = np.arange(7, N, 509)
+    f64 = lambda t: t.double().cpu().numpy()
+    for b in range(B):
+        o_ref, dq_ref = _rows_oracle(f64(q[b]), f64(k[b]), f64(v[b]), f64(go[b]), idx, 100.0)
+        for name in res:
+            assert rel(res[name][0][b][:, idx], o_ref) < TOL, (name, b)
+            assert rel(res[name][1][b][:, idx], dq_ref) < TOL, (name, b)
+    assert rel(res["split"][2], f64(res["recompute"][2])) < TOL
+    assert rel(res["split"][0], f64(res["recompute"][0])) < 1e-4
+
+
+def test_config5_warp_patch_512_through_the_hot_path():
+    """The 512x512 --warp_patch route end to end (F.unfold / F.fold with the TRUE image size — the reference hard-codes
+    256 at :321 and fails there): B=1, warp_cycle on, outputs + d theta / d phi vs torch-fp64 autograd."""
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    S, d = 512, 4
+    fh = S // d
+    g = torch.Generator(device=DEV).manual_seed(9)
+    th = torch.randn(1, 256, fh, fh, device=DEV, generator=g)
+    ph = 0.25 * th.flip(3) + torch.randn(1, 256, fh, fh, device=DEV, generator=g)
+    ref_img = torch.rand(1, 3, S, S, device=DEV, generator=g) * 2 - 1
+    seg = torch.rand(1, 20, S, S, device=DEV, generator=g)
+    flags = dict(match_kernel=1, PONO_C=True, down=d, warp_patch=True, warp_bilinear=True, isTrain=True,
+                 warp_mask_losstype="none", warp_cycle_w=1.0)
+    th.requires_grad_(True); ph.requires_grad_(True)
+    out = correspondence_hot_path(th, ph, ref_img, ref_img, seg, seg, HotPathConfig(**flags))
+    assert out["warp_out"].shape == (1, 3, S, S) and out["warp_cycle"].shape == (1, 3, S, S)
+    G = {k: torch.randn(v.shape, device=DEV, generator=g) for k, v in sorted(out.items())}
+    torch.autograd.backward([out[k] for k in sorted(out)], [G[k] for k in sorted(out)])
+    f64 = lambda t: t.detach().double().cpu().numpy()
+    outs, dth, dph = tr.forward_backward(f64(th), f64(ph), f64(ref_img), f64(ref_img), f64(seg), f64(seg),
+                                         co.default_opt(**flags), {k: f64(G[k]) for k in G})
+    for kk in outs:
+        assert rel(out[kk], outs[kk]) < TOL, kk
+    assert rel(th.grad, dth) < TOL and rel(ph.grad, dph) < TOL
+
+
+# ------------------------------------------------------------------ (iv) operand ranges of the split flavour
+@pytest.mark.parametrize("vscale", [1e5, 1e-6, 1.0])
+def test_split_flavour_is_scale_free_in_v(vscale, monkeypatch):
+    """forward() is a general contract: V (and with it dP) may have any magnitude.  The split kernels normalise the
+    V planes by a device-side power of two, so |V| ~ 1e5 (beyond f16's 65504) and ~ 1e-6 (f16 subnormals) give the
+    same relative accuracy as |V| ~ 1: out, d theta, d phi, dV against fp64."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    rs = np.random.RandomState(17)
+    B, Nq, Nk, Cv = 1, 512, 640, 37
+    qn, kn = nrm(rs.standard_normal((B, 256, Nq))), nrm(rs.standard_normal((B, 256, Nk)))
+    kn[:, :, :300] = nrm(qn[:, :, :300] + 0.08 * rs.standard_normal((B, 256, 300)))
+    v = rs.uniform(-1, 1, (B, Cv, Nk)) * vscale
+    g = rs.standard_normal((B, Cv, Nq))
+    o_ref = co.corr_softmax_warp(qn, kn, v, 100.0)
+    dq_ref, dk_ref, dv_ref = co.corr_softmax_warp_bwd(qn, kn, v, g, 100.0)
+    for need_v in (False, True):
+        q, k, vv = dev(qn, True), dev(kn, True), dev(v, need_v)
+        o = ops.corr_softmax_warp(q, k, vv, 100.0)
+        o.backward(dev(g))
+        assert torch.isfinite(o).all()
+        assert rel(o, o_ref) < TOL
+        assert rel(q.grad, dq_ref) < TOL and rel(k.grad, dk_ref) < TOL
+        if need_v:
+            assert rel(vv.grad, dv_ref) < TOL
+
+
+def test_split_flavour_gradient_with_1e6_dynamic_range(monkeypatch):
+    """A gradient whose per-channel magnitudes span 1e6 within one tensor: one power-of-two scale protects the
+    maximum; the small channels contribute below the fp32 rounding of the large ones, so the result still agrees with
+    fp64 at the usual max-norm tolerance (and nothing overflows or flushes to a wrong value)."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    rs = np.random.RandomState(23)
+    B, Nq, Nk, Cv = 1, 384, 512, 64
+    qn, kn = nrm(rs.standard_normal((B, 256, Nq))), nrm(rs.standard_normal((B, 256, Nk)))
+    v = rs.uniform(-1, 1, (B, Cv, Nk))
+    g = rs.standard_normal((B, Cv, Nq)) * (10.0 ** rs.uniform(-6, 0, (1, Cv, 1)))
+    dq_ref, dk_ref, _ = co.corr_softmax_warp_bwd(qn, kn, v, g, 100.0)
+    q, k = dev(qn, True), dev(kn, True)
+    ops.corr_softmax_warp(q, k, dev(v), 100.0).backward(dev(g))
+    assert rel(q.grad, dq_ref) < TOL and rel(k.grad, dk_ref) < TOL
+    # and with the small channels alone (the scale follows the tensor): full relative accuracy again
+    small = np.argsort(np.abs(g).max(axis=(0, 2)))[: Cv // 2]
+    g2 = np.zeros_like(g); g2[:, small] = g[:, small]
+    dq2, dk2, _ = co.corr_softmax_warp_bwd(qn, kn, v, g2, 100.0)
+    q, k = dev(qn, True), dev(kn, True)
+    ops.corr_softmax_warp(q, k, dev(v), 100.0).backward(dev(g2))
+    assert rel(q.grad, dq2) < TOL and rel(k.grad, dk2) < TOL
+
+
+def test_rescale_branch_is_forced_and_exact(precision):
+    """guide rule: a rare data-dependent branch needs its own test.  One key per query is spiked LATE in the key
+    order (tiles 10 / 11 of 12) for two wave's worth of queries: their row maxima jump from ~25 to 100 — far more than
+    the lazy-rescale threshold — after O and the running row sum (the ones row of V in the split flavour) have
+    accumulated for ten tiles; the other waves of the same workgroups never take the branch."""
+    from cocosnet_amd import ops
+    rs = np.random.RandomState(31)
+    B, Nq, Nk, Cv = 1, 256, 384, 35
+    qn, kn = nrm(rs.standard_normal((B, 256, Nq))), nrm(rs.standard_normal((B, 256, Nk)))
+    kn[0, :, 352:384] = qn[0, :, 0:32]          # queries 0..31 (workgroup 0, wave 0): exact match in key tile 11
+    kn[0, :, 320:352] = qn[0, :, 128:160]       # queries 128..159 (workgroup 1, wave 0): in key tile 10
+    v = rs.uniform(-1, 1, (B, Cv, Nk))
+    g = rs.standard_normal((B, Cv, Nq))
+    o_ref = co.corr_softmax_warp(qn, kn, v, 100.0)
+    dq_ref, dk_ref, _ = co.corr_softmax_warp_bwd(qn, kn, v, g, 100.0)
+    q, k = dev(qn, True), dev(kn, True)
+    o = ops.corr_softmax_warp(q, k, dev(v), 100.0)
+    o.backward(dev(g))
+    assert rel(o, o_ref) < TOL
+    assert rel(q.grad, dq_ref, floor=0.5) < TOL and rel(k.grad, dk_ref, floor=0.5) < TOL
+
+
+# ------------------------------------------------------------------ boundary: threads + streams, callers
+def test_two_threads_two_streams_match_single_threaded_results(precision):
+    """SURVEY §8b threading contract: under DataParallelWithCallback each replica's forward runs in its own Python
+    thread (here additionally on its own stream), backward in autograd's device thread.  Host-side scratch is
+    per-thread / per-call, so two concurrent forward+backward passes give bitwise the single-threaded results."""
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    cfg = HotPathConfig(match_kernel=1, PONO_C=True, down=4, warp_mask_losstype="direct")
+
+    def make(seed):
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        th = torch.randn(2, 256, 32, 32, device=DEV, generator=g)
+        ph = 0.3 * th.flip(2) + torch.randn(2, 256, 32, 32, device=DEV, generator=g)
+        img = torch.rand(2, 3, 128, 128, device=DEV, generator=g) * 2 - 1
+        lab = torch.randint(0, 9, (2, 1, 128, 128), device=DEV, generator=g)
+        seg = torch.zeros(2, 9, 128, 128, device=DEV).scatter_(1, lab, 1.0)
+        return th, ph, img, seg, torch.randn(2, 3, 128, 128, device=DEV, generator=g)
+
+    def run(inp, stream=None):
+        th, ph, img, seg, gout = inp
+        th, ph = th.clone().requires_grad_(True), ph.clone().requires_grad_(True)
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            for _ in range(3):
+                th.grad = ph.grad = None
+                out = correspondence_hot_path(th, ph, img, img, seg, seg, cfg)
+                (out["warp_out"] * gout).sum().add(out["warp_mask"].pow(2).sum()).backward()
+            if stream is not None:
+                stream.synchronize()
+        return out["warp_out"].detach().clone(), th.grad.clone(), ph.grad.clone()
+
+    inputs = [make(1), make(2)]
+    torch.cuda.synchronize()
+    serial = [run(i) for i in inputs]
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+
+    def worker(i):
+        try:
+            results[i] = run(inputs[i], torch.cuda.Stream())
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for a, b in zip(serial, results):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
+class _StandInCaller:
+    """What Pix2PixModel does with the correspondence network (pix2pix_model.py:303-337), without the rest of the
+    model: pick CBN_in from coor_out per opt.CBN_intype, merge the dicts, keep the tensors alive for the D step."""
+
+    def __init__(self, net, opt):
+        self.net, self.opt, self.alpha = net, opt, 1
+
+    def _cbn_in(self, coor_out, input_semantics):
+        if self.opt.CBN_intype == "mask":
+            return input_semantics
+        if self.opt.CBN_intype == "warp":
+            return coor_out["warp_out"]
+        return torch.cat((coor_out["warp_out"], input_semantics), dim=1)          # 'warp_mask' (:317-318)
+
+    def generate_fake(self, input_semantics, real_image, ref_semantics, ref_image):
+        coor_out = self.net(ref_image, real_image, input_semantics, ref_semantics, alpha=self.alpha)      # :308
+        fake = self._cbn_in(coor_out, input_semantics).mean(1, keepdim=True)     # stand-in for netG(...)
+        return {**{"fake_image": fake}, **coor_out}                               # :322
+
+    def inference(self, input_semantics, ref_semantics, ref_image):
+        coor_out = self.net(ref_image, None, input_semantics, ref_semantics, alpha=self.alpha)           # :327
+        fake = self._cbn_in(coor_out, input_semantics).mean(1, keepdim=True)
+        return {**{"fake_image": fake}, **coor_out}                               # :336
+
+
+def test_drop_in_behaves_for_the_reference_callers():
+    """a16: the dict contract the callers rely on — `warp_out` concatenable with the label map (same H, W, device,
+    dtype, contiguous NCHW), real_img=None at inference, `alpha` accepted, outputs usable after a second forward
+    (the trainer keeps `out` across the D step), gradients reach the parameters through CBN_in."""
+    from cocosnet_amd import correspondence as cc
+    opt = cc.ade20k_options(semantic_nc=7, match_kernel=1, isTrain=True)
+    torch.manual_seed(0)
+    net = cc.NoVGGCorrespondence(opt).to(DEV)
+    net.init_weights(opt.init_type, opt.init_variance)
+    caller = _StandInCaller(net, opt)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    img = torch.rand(2, 3, 64, 64, device=DEV, generator=g) * 2 - 1
+    real = torch.rand(2, 3, 64, 64, device=DEV, generator=g) * 2 - 1
+    lab = torch.randint(0, 7, (2, 1, 64, 64), device=DEV, generator=g)
+    seg = torch.zeros(2, 7, 64, 64, device=DEV).scatter_(1, lab, 1.0)
+    seg_before = seg.clone()
+    out = caller.generate_fake(seg, real, seg.flip(0), img)
+    assert {"fake_image", "warp_out", "warp_mask"} <= set(out)
+    assert out["warp_out"].shape == (2, 3, 64, 64) and out["warp_out"].is_contiguous()
+    assert out["warp_out"].dtype == torch.float32 and out["warp_out"].device == seg.device
+    first = {k: v.detach().clone() for k, v in out.items()}
+    out2 = caller.generate_fake(seg, real, seg.flip(0), img)                  # D step: a second forward
+    for k in first:                                                            # the kept tensors were not overwritten
+        assert torch.equal(out[k].detach(), first[k]), k
+    loss = out["fake_image"].pow(2).sum() + torch.log(out["warp_mask"] + 1e-10).mul(seg[:, :, ::4, ::4]).sum()
+    loss.backward()                                                            # :276 takes log(warp_mask + 1e-10)
+    assert net.theta.weight.grad is not None and float(net.theta.weight.grad.abs().max()) > 0
+    assert torch.equal(seg, seg_before)                                        # inputs are not mutated
+    del out2
+    net.eval()
+    opt.isTrain = False
+    with torch.no_grad():
+        inf = caller.inference(seg, seg.flip(0), img)                          # real_img = None (:327)
+    assert set(inf) >= {"fake_image", "warp_out", "warp_mask"} and torch.isfinite(inf["fake_image"]).all()
+    for intype in ("mask", "warp"):
+        opt.CBN_intype = intype
+        with torch.no_grad():
+            assert caller.inference(seg, seg.flip(0), img)["fake_image"].shape == (2, 1, 64, 64)

@@ -701,22 +701,27 @@ def test_pono_spade_equals_torch_chain(B, C, h, w, slope):
     assert rel(bd.grad, b64.grad.numpy()) < 1e-5
 
 
-def test_split_plane_cache_follows_tensor_lifetime():
-    """The operand-plane cache must not keep planes of dead tensors alive (one entry per live tensor/layout)."""
-    import gc
+def test_operand_planes_are_shared_within_a_forward_only():
+    """theta/phi planes are made once per forward call (OperandPlanes, owned by the caller) and shared by its
+    launches; nothing is cached across calls (no process-global state: SURVEY §8b threading contract)."""
     from cocosnet_amd import ops
-    base = len(ops._split_cache)
-    for _ in range(5):
-        x = torch.randn(1, 256, 64, device=DEV)
-        h1, _ = ops.split_f16(x, True, 16.0, cache=True)
-        h2, _ = ops.split_f16(x, True, 16.0, cache=True)
-        assert h1.data_ptr() == h2.data_ptr()                 # second call is a cache hit
-        x.add_(1.0)                                           # in-place change invalidates the entry
-        h3, _ = ops.split_f16(x, True, 16.0, cache=True)
+    x = torch.randn(1, 256, 64, device=DEV)
+    pl = ops.OperandPlanes()
+    with ops.KernelTimer(tags=("split_f16",)) as kt:
+        h1, _ = pl.get(x, True, 16.0)
+        h2, _ = pl.get(x, True, 16.0)
+        assert h1.data_ptr() == h2.data_ptr()                 # second request: the same planes
+        x.add_(1.0)                                           # in-place change invalidates them
+        h3, _ = pl.get(x, True, 16.0)
         assert not torch.equal(h3, h1)
-        del x
-    gc.collect()
-    assert len(ops._split_cache) == base
+    assert kt.summary()["split_f16"]["calls"] == 2
+    qn, kn, v = _qkv(1, 64, 64, 3, seed=1)
+    q, k = dev(qn, True), dev(kn, True)
+    shared = ops.OperandPlanes()
+    with ops.KernelTimer(tags=("split_f16",)) as kt:
+        ops.corr_softmax_warp(q, k, dev(v), 100.0, shared)            # q, k: 2 layouts each (training) + V
+        ops.corr_softmax_warp(k, q, dev(v), 100.0, shared)            # column pass: only V is new
+    assert kt.summary()["split_f16"]["calls"] == (4 + 1) + 1 if ops.PRECISION == "f16x3" else True
 
 
 @pytest.mark.parametrize("B,C,h,w,d", [(2, 3, 64, 64, 4), (1, 5, 7, 6, 2), (1, 1, 3, 4, 1), (2, 3, 16, 16, 4)])

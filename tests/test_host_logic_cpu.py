@@ -25,7 +25,7 @@ def test_split_channels_forward_views_and_single_cat_backward():
 
 def test_zero_cells_are_distinct_zeroed_and_refilled(monkeypatch):
     monkeypatch.setattr(ops, "_stream", lambda: 0)
-    monkeypatch.setattr(ops, "_zero_pool", {})
+    monkeypatch.setattr(ops._tls, "zero_pool", {})
     dev = torch.device("cpu")
     cells = [ops._zero_cell(dev) for _ in range(4096 + 3)]    # crosses one refill of the pool
     assert all(c.shape == (1,) and float(c) == 0.0 for c in cells)
@@ -36,7 +36,7 @@ def test_zero_cells_are_distinct_zeroed_and_refilled(monkeypatch):
 
 
 def test_amax_table_is_keyed_by_storage_version_and_consumed_once(monkeypatch):
-    monkeypatch.setattr(ops, "_known_amax", {})
+    monkeypatch.setattr(ops._tls, "known_amax", {})
     t = torch.randn(2, 3, 4)
     cell = torch.tensor([1.5])
     ops._remember_amax(t, cell)
@@ -53,4 +53,56 @@ def test_amax_table_is_keyed_by_storage_version_and_consumed_once(monkeypatch):
     for x in (a, b, c):
         ops._remember_amax(x, cell)
     assert ops._recall_amax(a) is None and ops._recall_amax(b) is cell and ops._recall_amax(c) is cell
-    assert len(ops._known_amax) == 0
+    assert len(ops._tls.known_amax) == 0
+
+
+def test_host_scratch_is_per_thread():
+    """SURVEY §8b threading contract: the reference's DataParallelWithCallback runs every replica's forward in its own
+    Python thread and autograd runs every device's backward in its own thread — the max|x| table and the zero-cell
+    pool must not be shared between them (round-1 ADVICE: KeyError / StopIteration under concurrent backward)."""
+    import threading
+    t = torch.randn(8)
+    cell = torch.tensor([2.0])
+    ops._remember_amax(t, cell)
+    seen, errors = {}, []
+
+    def worker(i):
+        try:
+            seen[i] = ops._recall_amax(t, consume=False)          # another thread's entry is invisible here
+            mine = torch.randn(4)
+            for _ in range(2000):                                 # hammer the table: no shared dict to corrupt
+                ops._remember_amax(mine, cell)
+                assert ops._recall_amax(mine) is cell
+        except Exception as e:                                    # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [th.start() for th in threads]
+    [th.join() for th in threads]
+    assert not errors, errors
+    assert all(v is None for v in seen.values())
+    assert ops._recall_amax(t) is cell                            # the registering thread still finds its own
+
+
+def test_operand_planes_are_per_call_objects(monkeypatch):
+    """The f16 operand planes of theta/phi live in an object the caller owns (one per forward call) — not in a
+    process-global cache keyed on id(tensor)."""
+    calls = []
+
+    def fake_split(x, transpose, scale=1.0, cpad=None, amax=None):
+        calls.append((id(x), transpose, scale))
+        return torch.zeros(1), torch.zeros(1)
+
+    monkeypatch.setattr(ops, "split_f16", fake_split)
+    x = torch.randn(1, 4, 3)
+    pl = ops.OperandPlanes()
+    a = pl.get(x, True, 16.0)
+    b = pl.get(x, True, 16.0)
+    assert a[0] is b[0] and len(calls) == 1                       # second request: same planes
+    pl.get(x, False, 16.0)
+    assert len(calls) == 2 and len(pl) == 2                       # other layout: its own planes
+    x.add_(1.0)
+    pl.get(x, True, 16.0)
+    assert len(calls) == 3                                        # modified in place: planes rebuilt
+    assert len(ops.OperandPlanes()) == 0                          # a new call starts empty
+    assert not hasattr(ops, "_split_cache")

@@ -115,3 +115,42 @@ def test_unfold_fold_roundtrip_and_ordering():
     assert u[0, 0 * 9 + 0 * 3 + 0, 0] == 0.0                      # top-left tap of position 0 is padding
     assert u[1, 2 * 9 + 1 * 3 + 1, 9] == x[1, 2, 1, 1]            # centre tap
     assert u[0, 1 * 9 + 2 * 3 + 2, 0] == x[0, 1, 1, 1]            # bottom-right tap of position 0
+
+
+# ------------------------------------------------------------------ the torch-autograd oracle (oracle/torch_ref.py)
+@pytest.mark.parametrize("name", sorted(gc.CASES))
+def test_torch_oracle_matches_reference_outputs_and_autograd(name):
+    """oracle/torch_ref.py (fp64, torch CPU autograd) against the reference's own outputs AND, for the cases that
+    store them, the reference's autograd gradients of loss = sum_k <out_k, G_k> — every flag set, incl. the cycle
+    terms / column softmax / patches / WTA whose backward the numpy oracle does not restate."""
+    import torch
+    from oracle import torch_ref as tr
+    c = gc.CASES[name]
+    inp = gc.make_inputs(name)
+    golden = gc.load_golden(name)
+    opt = co.default_opt(**gc.hot_path_flags(name))
+    shapes = {f.split("__", 1)[1]: tuple(golden[f]) for f in golden.files if f.startswith("shape__")}
+    G = gc.grad_weights(name, shapes) if c.get("grads") else {}
+    outs, dth, dph = tr.forward_backward(inp.theta_raw, inp.phi_raw, inp.ref_img, inp.real_img, inp.seg_map,
+                                         inp.ref_seg_map, opt, G if G else {k: np.zeros(s, np.float32) for k, s in shapes.items()},
+                                         **c.get("fwd", {}))
+    errs = gc.compare_with_golden(name, outs, golden)
+    assert errs and max(errs.values()) < FWD_TOL, errs
+    if c.get("grads"):
+        for got, key in ((dth, "grad__theta_raw"), (dph, "grad__phi_raw")):
+            ref_g = golden[key].astype(np.float64)
+            err = np.abs(got - ref_g).max() / np.abs(ref_g).max()
+            assert err < 1e-3, (key, err)
+
+
+def test_torch_oracle_agrees_with_numpy_oracle_fp64():
+    """Two independent restatements of the same lines: outputs to 1e-12, row-pass gradients to 1e-10."""
+    from oracle import torch_ref as tr
+    inp = gc.make_inputs("celeba_cycle")
+    opt = co.default_opt(**gc.hot_path_flags("celeba_cycle"))
+    ref = co.hot_path_forward(inp.theta_raw, inp.phi_raw, inp.ref_img, inp.real_img, inp.seg_map, inp.ref_seg_map, opt)
+    outs, _, _ = tr.forward_backward(inp.theta_raw, inp.phi_raw, inp.ref_img, inp.real_img, inp.seg_map,
+                                     inp.ref_seg_map, opt, {k: np.zeros_like(v) for k, v in ref.items()})
+    assert set(outs) == set(ref)
+    for k in ref:
+        assert np.abs(outs[k] - ref[k]).max() < 1e-11, k
