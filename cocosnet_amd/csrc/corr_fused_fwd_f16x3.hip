@@ -411,8 +411,11 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
 
     // ---- epilogue: normalise, store channel-major [B,Cv,Nq], store row LSE --------------------------
     // l = the ones row of O: channel 32*CVB - 1 = register 15 of the upper half-wave's lanes
+    // (the exchange is executed by ALL lanes before the select: a cross-lane read under a divergent `h ? :` would read
+    //  inactive source lanes, i.e. zeros)
     const float l_own = o[CVB - 1][15];
-    const float l_tot = h ? l_own : swap_half(l_own);
+    const float l_other = swap_half(l_own);
+    const float l_tot = h ? l_own : l_other;
     const float inv_l = (v_scale ? 1.0f / *v_scale : 1.0f) / l_tot;
     if (i_lane < Nq) {
         float* out_b = out + (size_t)b * Cv * Nq;

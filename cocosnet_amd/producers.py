@@ -60,17 +60,11 @@ class SPADE(nn.Module):
         self.mlp_gamma = nn.Conv2d(hidden, norm_nc, ks)
         self.mlp_beta = nn.Conv2d(hidden, norm_nc, ks)
 
-    def forward(self, x, segmap, slope: float = 1.0):
-        """`slope` != 1 folds the LeakyReLU that SPADEResnetBlock applies right after (architecture.py:88-95)."""
-        seg = F.interpolate(segmap, size=x.shape[2:], mode="nearest")
-        a = self.pad(self.mlp_shared(seg))
-        gamma, beta = self.mlp_gamma(a), self.mlp_beta(a)
-        if self.pono and x.is_cuda and x.dtype == torch.float32:
-            from . import ops                       # K9: one HBM pass for norm + modulate + activation
-            return ops.pono_spade(x, gamma, beta, slope)
-        xn = positional_norm(x) if self.pono else self.param_free_norm(x)
-        y = xn * (1 + gamma) + beta
-        return y if slope == 1.0 else F.leaky_relu(y, slope)
+    def forward(self, x, segmap, similarity_map=None, slope: float = 1.0):
+        """`slope` != 1 folds the LeakyReLU that SPADEResnetBlock applies right after (architecture.py:88-95).
+        Shared with the hook for the reference's own SPADE (cocosnet_amd/spade.py)."""
+        from .spade import spade_forward
+        return spade_forward(self, x, segmap, similarity_map, slope)
 
 
 class SELayer(nn.Module):
@@ -147,8 +141,8 @@ class SPADEResnetBlock(nn.Module):
 
     def forward(self, x, seg):
         x_s = self.conv_s(self.norm_s(x, seg)) if self.learned_shortcut else x
-        dx = self.conv_0(self.pad(self.norm_0(x, seg, 0.2)))       # norm -> LeakyReLU(0.2) -> pad -> conv
-        dx = self.conv_1(self.pad(self.norm_1(dx, seg, 0.2)))
+        dx = self.conv_0(self.pad(self.norm_0(x, seg, slope=0.2)))       # norm -> LeakyReLU(0.2) -> pad -> conv
+        dx = self.conv_1(self.pad(self.norm_1(dx, seg, slope=0.2)))
         if self.use_se:
             dx = self.se_layar(dx)
         return x_s + dx

@@ -591,7 +591,10 @@ def test_center_l2norm_bwd_amax_byproduct(B, K, N, mode):
     x2.register_hook(hook)
     ops.center_l2norm(x2, mode).backward(g)
     (cell, ref), (stale, _) = seen
-    assert cell is not None and float(cell) == ref
+    if mode == 2:      # feature_normalize feeds framework convolutions: nobody would pick the value up, none is left
+        assert cell is None
+    else:
+        assert cell is not None and float(cell) == ref
     assert stale is None
 
 

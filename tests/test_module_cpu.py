@@ -110,3 +110,61 @@ def test_install_into_reference_define_corr():
         assert isinstance(net, networks.BaseNetwork)
     finally:
         ref_corr.NoVGGCorrespondence = original
+
+
+@needs_ref
+@pytest.mark.parametrize("pono", [True, False])
+def test_install_spade_into_reference(pono, monkeypatch):
+    """§8(f) rank 1 reaches the reference's OWN generator: after install_spade_into_reference(networks) the
+    reference's SPADE / SPADEResnetBlock classes (netG's `SPADEGenerator` and the adaptors are built from them) run
+    the fused forward.  On CPU it must reproduce the original arithmetic (outputs and gradients); with a CUDA-fp32
+    input it must hand PositionalNorm + modulation + LeakyReLU to K9 as ONE call."""
+    import importlib
+    from cocosnet_amd import ops, spade
+    networks = rh.load_reference()
+    arch = importlib.import_module("models.networks.architecture")
+    opt = rh.make_opt(semantic_nc=5, PONO=pono, norm_G="spectralspadeinstance3x3")
+    opt.spade_ic = 5
+    torch.manual_seed(0)
+    blk = arch.SPADEResnetBlock(16, 8, opt).eval()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 16, 8, 8, generator=g)
+    seg = torch.rand(2, 5, 32, 32, generator=g)
+
+    def run():
+        xx = x.clone().requires_grad_(True)
+        y = blk(xx, seg)
+        y.pow(2).sum().backward()
+        return y.detach(), xx.grad.clone(), blk.norm_0.mlp_gamma.weight.grad.clone()
+
+    ref = run()
+    blk.zero_grad()
+    try:
+        SP, RB = spade.install_spade_into_reference(networks)
+        assert SP.forward is spade.spade_forward and RB.forward is spade.spade_resnet_block_forward
+        got = run()
+        for a, b in zip(got, ref):
+            assert torch.allclose(a, b, atol=1e-5, rtol=1e-5)
+        # the dispatch on a GPU tensor: one fused call per (norm, activation) pair, slope 0.2; 1.0 on the shortcut
+        calls = []
+
+        def fake_pono_spade(xx, gamma, beta, slope=1.0, eps=1e-5):
+            calls.append(slope)
+            mu = xx.mean(1, keepdim=True)
+            y = (xx - mu) / xx.var(1, keepdim=True).add(eps).sqrt() * (1 + gamma) + beta
+            return torch.nn.functional.leaky_relu(y, slope) if slope != 1.0 else y
+
+        monkeypatch.setattr(spade, "_hip_ok", lambda *ts: True)
+        monkeypatch.setattr(ops, "pono_spade", fake_pono_spade)
+        with torch.no_grad():
+            y2 = blk(x, seg)
+        if pono:
+            assert sorted(calls) == [0.2, 0.2, 1.0]
+            assert torch.allclose(y2, ref[0], atol=1e-5, rtol=1e-5)
+        else:
+            assert calls == []                    # instance-norm SPADE: statistics stay with nn.InstanceNorm2d
+    finally:
+        spade.uninstall_spade_from_reference(networks)
+    assert not hasattr(arch.SPADEResnetBlock, "_cocos_reference_forward")
+    y3 = blk(x, seg)
+    assert torch.allclose(y3.detach(), ref[0], atol=1e-6)
