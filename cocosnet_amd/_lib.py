@@ -10,7 +10,7 @@ import os
 import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "lib", "libcocos_hip.so")
+LIB_PATH = os.environ.get("COCOS_LIB_PATH") or os.path.join(_PKG_DIR, "lib", "libcocos_hip.so")
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as integers
 _stream_t = ctypes.c_void_p

@@ -17,8 +17,10 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libcocos_hip.so")
-OBJ_DIR = os.path.join(LIB_DIR, "obj")
+#: COCOS_LIB_NAME builds a second library next to the product one (e.g. a -DCOCOS_DEBUG_TIMING build for
+#: tools/phase_timing_f16x3.py); cocosnet_amd._lib loads it when COCOS_LIB_PATH points at it
+LIB_PATH = os.path.join(LIB_DIR, os.environ.get("COCOS_LIB_NAME", "libcocos_hip.so"))
+OBJ_DIR = os.path.join(LIB_DIR, "obj" + ("" if "COCOS_LIB_NAME" not in os.environ else "_" + os.environ["COCOS_LIB_NAME"]))
 
 HIP_SOURCES = [
     "api_common.hip",

@@ -30,5 +30,7 @@ for it in range(3):
     ops.corr_softmax_warp(q2, k2, v, 100.0).backward(go)
     lib.cocos_debug_read_timing_bwd_f16x3(buf, 1)
     t = list(buf)[:4]
-    print("bwd query: dP %.0f | dS+split %.0f | dQ (+stores, staging) %.0f | barrier %.0f | total %.0f ticks/tile (MFMA ideal: dP %d, dQ 1536)"
-          % (t[0] / 128, t[1] / 128, t[2] / 128, t[3] / 128, sum(t) / 128, 32 * 6 * ((Cv + 31) // 32)))
+    # (round 2: iteration t = dP'(t) with the staging pieces | dqn(t-1) with tile t's VALU sliced in | plane stores |
+    #  barrier; the first iteration is not instrumented: 127 per workgroup)
+    print("bwd query: dP+staging %.0f | dqn+VALU %.0f | dS'' plane stores %.0f | barrier %.0f | total %.0f ticks/tile (MFMA ideal: dP %d, dQ 1536)"
+          % (t[0] / 127, t[1] / 127, t[2] / 127, t[3] / 127, sum(t) / 127, 32 * 6 * ((Cv + 31) // 32)))

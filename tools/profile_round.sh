@@ -19,3 +19,8 @@ python $R/tools/pmc_to_json.py $O/${TAG}_pmc.json $(find $O/pmc_a $O/pmc_b $O/pm
 tail -3 $O/bench_under_rocprof.log | cut -c1-300
 head -20 $O/${TAG}_bench_kernel_stats.txt
 cat $O/${TAG}_pmc.txt | cut -c1-400
+# 3. per-phase shader-clock ticks of the K2 split kernels (needs the -DCOCOS_DEBUG_TIMING library next to the product one:
+#    COCOS_LIB_NAME=libcocos_hip_dbg.so COCOS_EXTRA_HIPFLAGS=-DCOCOS_DEBUG_TIMING python -m cocosnet_amd.build)
+if [ -f $R/cocosnet_amd/lib/libcocos_hip_dbg.so ]; then
+  cd $R; COCOS_LIB_PATH=$R/cocosnet_amd/lib/libcocos_hip_dbg.so timeout 200 python tools/phase_timing_f16x3.py 154 train > $O/${TAG}_phase_timing.txt 2>&1; cat $O/${TAG}_phase_timing.txt
+fi
