@@ -50,6 +50,14 @@ __device__ __forceinline__ u32x4 bq_load16s(__amdgpu_buffer_rsrc_t r, unsigned o
     return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, (int)soff, 0);
 }
 
+// Ablation builds (debug only, results are WRONG): -DCOCOS_ABLATE=<bits>  1: no tile staging, 2: no operand re-reads
+// from LDS, 4: no exp/split arithmetic, 8: no dS'' transposition + plane stores, 16: no logits loads
+#ifndef COCOS_ABLATE
+#define COCOS_ABLATE 0
+#endif
+// cache policy of the HWxHW streams (saved logits, dS'' / P planes): written once, read once by another kernel — `nt`
+// (aux bit 1) keeps them from evicting the key/value tiles that the 32 workgroups of a sample share in their XCD's L2
+#define COCOS_STREAM_AUX ((COCOS_ABLATE & 256) ? 0 : 2)
 #ifdef COCOS_DEBUG_TIMING
 __device__ long long g_phase_bq_h[8];
 #define BPH_T(var) const long long var = __builtin_readcyclecounter()
@@ -258,19 +266,22 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     // logits of tile tt (clamped to the last tile: look-ahead loads past the end are harmless re-reads),
     // register group k (accumulator registers 4k..4k+3): one contiguous 1 KB per wave-instruction
     auto load_s = [&](f32x4& dst, int tt, int k) {
-        const int tc = min(tt, ntiles - 1);
-        dst = __builtin_bit_cast(f32x4, bq_load16s(lg_rs, lg_lane_off, (unsigned)(tc * nqblk) * 4096u + (unsigned)k * 1024u));
+        if ((COCOS_ABLATE & 16) && tt > 1) return;
+        const int tc = (COCOS_ABLATE & 128) ? (tt & 1) : min(tt, ntiles - 1);
+        dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            lg_rs, (int)lg_lane_off, (int)((unsigned)(tc * nqblk) * 4096u + (unsigned)k * 1024u), COCOS_STREAM_AUX));
     };
 
     // one staged piece of the V tile (i < 2*VPT) or of the K tile (2*VPT <= i < 2*VPT + 8) to LDS, and the reload of
     // its register with the tile after: V(tv) -> vt[bufv], then V(tv + 1) requested; K(tk) -> kt[bufk], then K(tk + 1)
     auto stage_piece = [&](int i, int tv, int tk) {
+        if (COCOS_ABLATE & 1) return;
         _Float16* const vw = vt + (tv & 1) * 2 * VPLANE;
         _Float16* const kw = kt + (tk & 1) * 2 * KPLANE;
         if (i < 2 * VPT) {
             const int pl_ = i & 1, u = i >> 1;
             if (!RAGGED) {
-                const int jn = min((tv + 1) * 32, Nk - 32);
+                const int jn = (COCOS_ABLATE & 64) ? 32 : min((tv + 1) * 32, Nk - 32);
                 if (u * 256 + 255 < VCH || u * 256 + tid < VCH)
                     *reinterpret_cast<u32x4*>(vw + pl_ * VPLANE + v_lds[u]) = vst[pl_][u];
                 vst[pl_][u] = bq_load16s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jn * (unsigned)(CVP * 2));
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
         } else if (i - 2 * VPT < 8) {
             const int pl_ = (i - 2 * VPT) & 1, u = (i - 2 * VPT) >> 1;
             if (!RAGGED) {
-                const int jn = min((tk + 1) * 32, Nk - 32);
+                const int jn = (COCOS_ABLATE & 64) ? 32 : min((tk + 1) * 32, Nk - 32);
                 _Float16* d = kw + pl_ * KPLANE + k_lds[u];
                 *reinterpret_cast<u32x2*>(d) = u32x2{kst[pl_][u].x, kst[pl_][u].y};
                 *reinterpret_cast<u32x2*>(d + 8) = u32x2{kst[pl_][u].z, kst[pl_][u].w};
@@ -302,25 +313,29 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             }
         }
     };
-    static_assert(2 * VPT + 8 <= 3 * CVS / 2 + 16, "staging pieces must fit the MFMA steps of an iteration");
+    static_assert(2 * VPT <= 4 * CVS, "value-tile pieces must fit the dP steps");
 
-    // ---- dP'(t) = V'(t) . dO' : CVS steps of 3 MFMAs; staging pieces ride in the gaps ------------------------
-    // STAGE_K: the K tile of `t` goes to LDS as well (not in the first iteration: K(0) is committed by the prologue)
-    auto phase_dp = [&](f32x16& dp0, int t, auto stage_k) {
-        constexpr bool STAGE_K = decltype(stage_k)::value;
+    // ---- dP'(t) = V'(t) . dO' : CVS steps of 3 MFMAs; the value-tile pieces of tile t+1 ride in the gaps.  The first
+    //      fragments (vf_h, vf_l) were requested at the end of the previous iteration: the loop does not start cold ------
+    f16x8 vf_h, vf_l;
+    auto prefetch_v = [&](int t) {
+        const _Float16* vb0 = vt + (t & 1) * 2 * VPLANE + c * VROW + h * 8;
+        vf_h = *reinterpret_cast<const f16x8*>(vb0);
+        vf_l = *reinterpret_cast<const f16x8*>(vb0 + VPLANE);
+    };
+    auto phase_dp = [&](f32x16& dp0, int t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp0[r] = 0.f;
         const _Float16* vb0 = vt + (t & 1) * 2 * VPLANE + c * VROW + h * 8;
         f16x8 ah[2], al[2];
-        ah[0] = *reinterpret_cast<const f16x8*>(vb0);
-        al[0] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE);
-        // (2*VPT + 8) pieces over CVS steps
-        constexpr int NP = 2 * VPT + (STAGE_K ? 8 : 0);
+        ah[0] = vf_h;
+        al[0] = vf_l;
+        constexpr int NP = 2 * VPT;
         constexpr int PER = (NP + CVS - 1) / CVS;
 #pragma unroll
         for (int u = 0; u < CVS; ++u) {
             const int cur = u & 1, nxt = cur ^ 1;
-            if (u + 1 < CVS) {
+            if (!(COCOS_ABLATE & 2) && u + 1 < CVS) {
                 ah[nxt] = *reinterpret_cast<const f16x8*>(vb0 + (u + 1) * 16);
                 al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
             }
@@ -334,10 +349,26 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
         }
     };
 
+    // dS'' (and P) go to HBM as 16-byte row pieces of a [key][query] matrix, but each lane holds one QUERY column (16
+    // keys, two per packed register): the wave transposes its 32x32 tile through its private LDS buffer.  Register j of
+    // a lane = keys (2j', 2j'+1) of its query; neighbouring lanes exchange halves (one DPP move + one byte permute per
+    // register, VALU work that hides under the MFMAs) so that every lane writes ONE 32-bit word = two neighbouring
+    // queries of one key: 16 conflict-free ds_write_b32 per tile instead of 32 ds_write_b16 (measured 8 cycles each
+    // beyond what the MFMAs hide — tools/probes/filler_cost.hip), then 4 b128 reads + 4 b128 global stores.
+    unsigned* const ds32 = reinterpret_cast<unsigned*>(dstile) + (4 * h + (c & 1)) * (DSROW / 2) + (c >> 1);
+    const unsigned pair_sel = (c & 1) ? 0x03020706u : 0x05040100u;
+    auto stage_transpose = [&](int j, unsigned hw, unsigned lw) {
+        const int row = acc_row_base(2 * j);                    // even lanes: key row(2j); odd lanes: the next one
+        const unsigned xh = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hw, 0xB1, 0xf, 0xf, false);   // lane ^ 1
+        const unsigned xl = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lw, 0xB1, 0xf, 0xf, false);
+        ds32[row * (DSROW / 2)] = __builtin_amdgcn_perm(xh, hw, pair_sel);
+        ds32[DSPLANE / 2 + row * (DSROW / 2)] = __builtin_amdgcn_perm(xl, lw, pair_sel);
+    };
+
     // ---- VALU slice r of tile t: dS''[r] from logit register r; pairs are split to f16 hi/lo at odd r ----------
     auto valu_slice = [&](int r, int t, const f32x4 (&s)[4], const f32x16& dp0, float (&dsv)[2], float (&pv)[2],
                           DsRegs& out, DsRegs& pout) {
-        float pc = fast_exp2(__builtin_fmaf(s[r >> 2][r & 3], scale_log2, nlse2c));
+        float pc = (COCOS_ABLATE & 4) ? s[r >> 2][r & 3] * 1e-9f : fast_exp2(__builtin_fmaf(s[r >> 2][r & 3], scale_log2, nlse2c));
         if (RAGGED && (t * 32 + acc_row_base(r) + 4 * h >= Nk)) pc = 0.f;
         dsv[r & 1] = pc * (dp0[r] - d_lane);
         if (STORE_P) pv[r & 1] = pc * p_from_pc;
@@ -345,20 +376,11 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             split_pair_rtz(dsv[0], dsv[1], out.hw[r >> 1], out.lw[r >> 1]);
             if (STORE_P) split_pair_rtz(pv[0], pv[1], pout.hw[r >> 1], pout.lw[r >> 1]);
         }
-        if (STORE_DS && (r & 1)) {
-            // dS'' goes to HBM as 16-byte row pieces: each lane holds one QUERY column (16 keys), the matrix is
-            // [key][query] — the wave transposes its 32x32 tile through its private LDS buffer (2-byte writes here,
-            // 4 b128 reads + 4 b128 global stores after the last slice)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int rr = r - 1 + e, key = acc_row_base(rr) + 4 * h;
-                dstile[key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(out.hw[r >> 1] >> (16 * e)));
-                dstile[DSPLANE + key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(out.lw[r >> 1] >> (16 * e)));
-            }
-        }
+        if (STORE_DS && (r & 1) && !(COCOS_ABLATE & 8)) stage_transpose(r >> 1, out.hw[r >> 1], out.lw[r >> 1]);
     };
     // the wave's transposed 32x32 tile: LDS -> 16-byte row pieces of the [Nk][Nq] planes
     auto store_planes = [&](int t, __amdgpu_buffer_rsrc_t h_rs, __amdgpu_buffer_rsrc_t l_rs) {
+        if (COCOS_ABLATE & 8) return;
         // (LDS instructions of one wave execute in order: the 2-byte writes above are visible here)
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -371,44 +393,55 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             const unsigned lin = planes_blocked
                 ? (unsigned)(((row >> 7) * (Nq >> 5) + (col >> 5)) * 4096 + (row & 127) * 32 + (col & 31))
                 : (unsigned)(row * Nq + col);
-            const unsigned off = (row < Nk && col < Nq) ? lin * 2u : kBufOob;
-            __builtin_amdgcn_raw_buffer_store_b128(xh, h_rs, (int)off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(xl, l_rs, (int)off, 0, 0);
+            unsigned off = (row < Nk && col < Nq) ? lin * 2u : kBufOob;
+            if (COCOS_ABLATE & 32) off = (unsigned)(lane * 16 + wave * 1024 + pass * 4096);
+            __builtin_amdgcn_raw_buffer_store_b128(xh, h_rs, (int)off, 0, COCOS_STREAM_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(xl, l_rs, (int)off, 0, COCOS_STREAM_AUX);
         }
     };
     auto store_p_tile = [&](int t, const DsRegs& pr) {
         // same transposition for the P planes, through the same per-wave buffer (after the dS'' pieces have been
         // read back; one wave's LDS instructions execute in order)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = acc_row_base(i) + 4 * h;
-            dstile[key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(pr.hw[i >> 1] >> (16 * (i & 1))));
-            dstile[DSPLANE + key * DSROW + c] = __builtin_bit_cast(_Float16, (unsigned short)(pr.lw[i >> 1] >> (16 * (i & 1))));
-        }
+        for (int j = 0; j < 8; ++j) stage_transpose(j, pr.hw[j], pr.lw[j]);
         store_planes(t, ph_rs, pl_rs);
     };
 
-    // ---- dqn += K(t-1) . dS''(t-1) : 16 steps of 3 MFMAs (2 k-steps x 8 channel blocks), operands one step ahead;
-    //      WITH_VALU: slice i of tile t's VALU work and, as its logit registers are consumed, the loads of tile
-    //      t + 2's logits into them ride in the gaps -------------------------------------------------------------------
-    auto phase_dqn = [&](int t, const DsRegs& prev, auto with_valu, f32x4 (&s)[4], const f32x16& dp0, DsRegs& cur,
-                         DsRegs& pcur) {
+    // ---- dqn += K(t-1) . dS''(t-1) : 16 steps of 3 MFMAs (2 k-steps x 8 channel blocks), operands one step ahead.
+    //      This phase starts right behind the tile's barrier (the key tile it reads was committed by all four waves
+    //      during the previous iteration's pass through here), so its first fragments cannot be requested earlier:
+    //      WITH_VALU runs the first LEAD slices of tile t's VALU work while they arrive, the other slices and, as the
+    //      logit registers are consumed, the loads of tile t + 2's logits ride in the MFMA gaps.  STAGE_K: the key-tile
+    //      pieces of tile t go to LDS (read from the next iteration on), one every other step ----------------------------
+    constexpr int LEAD = 3;
+    auto phase_dqn = [&](int t, const DsRegs& prev, auto with_valu, auto stage_k, f32x4 (&s)[4], const f32x16& dp0,
+                         DsRegs& cur, DsRegs& pcur) {
         constexpr bool WITH_VALU = decltype(with_valu)::value;
+        constexpr bool STAGE_K = decltype(stage_k)::value;
+        const _Float16* kb0 = kt + ((t - 1) & 1) * 2 * KPLANE + c * BQH_KROW + h * 8;
+        f16x8 a_h[2], a_l[2];
+        a_h[0] = *reinterpret_cast<const f16x8*>(kb0);
+        a_l[0] = *reinterpret_cast<const f16x8*>(kb0 + KPLANE);
+        float dsv[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
+        auto slice = [&](int r) {
+            valu_slice(r, t, s, dp0, dsv, pv, cur, pcur);
+            if ((r & 3) == 3) load_s(s[r >> 2], t + 2, r >> 2);          // registers 4k..4k+3 are free again
+        };
+        if (WITH_VALU) {
+#pragma unroll
+            for (int r = 0; r < LEAD; ++r) slice(r);
+        }
         f16x8 sh[2], sl[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             sh[tt] = __builtin_bit_cast(f16x8, u32x4{prev.hw[4 * tt], prev.hw[4 * tt + 1], prev.hw[4 * tt + 2], prev.hw[4 * tt + 3]});
             sl[tt] = __builtin_bit_cast(f16x8, u32x4{prev.lw[4 * tt], prev.lw[4 * tt + 1], prev.lw[4 * tt + 2], prev.lw[4 * tt + 3]});
         }
-        const _Float16* kb0 = kt + ((t - 1) & 1) * 2 * KPLANE + c * BQH_KROW + h * 8;
-        f16x8 a_h[2], a_l[2];
-        a_h[0] = *reinterpret_cast<const f16x8*>(kb0);
-        a_l[0] = *reinterpret_cast<const f16x8*>(kb0 + KPLANE);
-        float dsv[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 2 * KB; ++i) {                // i = tt * KB + kb
             const int tt = i / KB, kb = i % KB, cur_ = i & 1, nxt = cur_ ^ 1;
-            if (i + 1 < 2 * KB) {
+            if (!(COCOS_ABLATE & 2) && i + 1 < 2 * KB) {
                 const int t2 = (i + 1) / KB, k2 = (i + 1) % KB;
                 a_h[nxt] = *reinterpret_cast<const f16x8*>(kb0 + k2 * 32 * BQH_KROW + t2 * 16);
                 a_l[nxt] = *reinterpret_cast<const f16x8*>(kb0 + KPLANE + k2 * 32 * BQH_KROW + t2 * 16);
@@ -416,10 +449,9 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             dx[kb] = bq_mfma(a_h[cur_], sh[tt], dx[kb]);
             dx[kb] = bq_mfma(a_h[cur_], sl[tt], dx[kb]);
             dx[kb] = bq_mfma(a_l[cur_], sh[tt], dx[kb]);
-            if (WITH_VALU) {
-                valu_slice(i, t, s, dp0, dsv, pv, cur, pcur);
-                if ((i & 3) == 3) load_s(s[i >> 2], t + 2, i >> 2);      // registers 4k..4k+3 are free again
-            }
+            if (WITH_VALU && i + LEAD < 16) slice(i + LEAD);
+            if (STAGE_K && (i & 1) == 0) stage_piece(2 * VPT + (i >> 1), t + 1, t);
+            if (WITH_VALU && i == 2 * KB - 1) prefetch_v(t + 1);         // first fragments of the next iteration's dP'
             __builtin_amdgcn_sched_barrier(0);
         }
         // the dqn accumulators live in the accumulator file for the whole kernel (without the pins hipcc
@@ -441,39 +473,47 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) load_s(sB[k], 1, k);
     __syncthreads();
+    prefetch_v(0);
 
     DsRegs dA, dB, pA, pB;
     f32x16 dp0;
     using std::false_type;
     using std::true_type;
 
+    // ONE barrier per iteration, between the two MFMA loops.  Value tile t+1 is committed during dP'(t) into the buffer
+    // dP'(t-1) read (every wave finished that before it passed the barrier of iteration t-1) and is read from the end of
+    // iteration t on (prefetch_v), behind the barrier of iteration t.  Key tile t is committed during the dqn loop of
+    // iteration t into the buffer the dqn loop of iteration t-1 read (every wave finished that before it reached this
+    // iteration's barrier) and is read by the dqn loop of iteration t+1, behind that iteration's barrier.
+
     // iteration 0: dP'(0), then tile 0's VALU work on its own (there is no dqn product to hide it under yet)
     {
-        phase_dp(dp0, 0, false_type{});
+        phase_dp(dp0, 0);
+        __syncthreads();
         float dsv[2], pv[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             valu_slice(r, 0, sA, dp0, dsv, pv, dA, pA);
             if ((r & 3) == 3) load_s(sA[r >> 2], 2, r >> 2);
         }
+        prefetch_v(1);
         if (STORE_DS) store_planes(0, dh_rs, dl_rs);
         if (STORE_P) store_p_tile(0, pA);
-        __syncthreads();
     }
     // iterations 1 .. ntiles-1, two per trip so that every register set is named statically:
     //   odd t : logits sB -> dS'' dB, dqn of tile t-1 from dA;   even t: logits sA -> dA, dqn from dB
     auto iter = [&](int t, f32x4 (&s)[4], const DsRegs& prev, DsRegs& cur, DsRegs& pcur) {
         BPH_T(tp0);
-        phase_dp(dp0, t, true_type{});
+        phase_dp(dp0, t);
         BPH_T(tp1);
-        phase_dqn(t, prev, true_type{}, s, dp0, cur, pcur);
+        __syncthreads();
         BPH_T(tp2);
+        phase_dqn(t, prev, true_type{}, true_type{}, s, dp0, cur, pcur);
+        BPH_T(tp3);
         if (STORE_DS) store_planes(t, dh_rs, dl_rs);
         if (STORE_P) store_p_tile(t, pcur);
-        BPH_T(tp3);
-        __syncthreads();
         BPH_T(tp4);
-        BPH_ADD(0, tp0, tp1); BPH_ADD(1, tp1, tp2); BPH_ADD(2, tp2, tp3); BPH_ADD(3, tp3, tp4);
+        BPH_ADD(0, tp0, tp1); BPH_ADD(3, tp1, tp2); BPH_ADD(1, tp2, tp3); BPH_ADD(2, tp3, tp4);
     };
     int t = 1;
     for (; t + 1 < ntiles; t += 2) {
@@ -482,9 +522,11 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     }
     if (t < ntiles) {
         iter(t, sB, dA, dB, pB);
-        phase_dqn(ntiles, dB, false_type{}, sA, dp0, dA, pA);
+        __syncthreads();           // the last key tile was committed during that iteration
+        phase_dqn(ntiles, dB, false_type{}, false_type{}, sA, dp0, dA, pA);
     } else {
-        phase_dqn(ntiles, dA, false_type{}, sB, dp0, dB, pB);
+        __syncthreads();
+        phase_dqn(ntiles, dA, false_type{}, false_type{}, sB, dp0, dB, pB);
     }
 
     // ---- epilogue: undo the scales -----------------------------------------------------------------------

@@ -80,6 +80,14 @@ __device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& l
 
 // Optional phase timing (build with COCOS_EXTRA_HIPFLAGS=-DCOCOS_DEBUG_TIMING): shader-clock ticks spent by
 // wave 0 of workgroup 0 in each phase of the tile loop, read back with cocos_debug_read_timing_fwd_f16x3().
+// Ablation builds (debug only, results are WRONG): -DCOCOS_ABLATE=<bits>  1: no tile staging in the QK loop,
+// 2: no operand re-reads from LDS, 4: no softmax arithmetic, 8: no logits store — tools/ablate_fwd.sh times them.
+#ifndef COCOS_ABLATE
+#define COCOS_ABLATE 0
+#endif
+// cache policy of the HWxHW streams (saved logits, dS'' / P planes): written once, read once by another kernel — `nt`
+// (aux bit 1) keeps them from evicting the key/value tiles that the 32 workgroups of a sample share in their XCD's L2
+#define COCOS_STREAM_AUX ((COCOS_ABLATE & 256) ? 0 : 2)
 #ifdef COCOS_DEBUG_TIMING
 __device__ long long g_phase_fwd_h[8];
 #define FPH_T(var) const long long var = __builtin_readcyclecounter()
@@ -244,84 +252,110 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     }
     __syncthreads();
 
+    // Operand rings (A fragments from LDS): requested RA - 1 steps ahead; with four waves on the LDS pipe a
+    // ds_read_b128 takes several hundred cycles to come back, far more than the 96 cycles of one step's MFMAs.
+    // The rings live ACROSS the tile loop: the first fragments of tile t+1's key tile are requested at the end of
+    // tile t's P.V loop, so the QK loop never starts cold (round 1 / step 1 read them right after the barrier:
+    // ~450 cycles of every tile's QK phase were that bubble — tools/ablate_fwd.sh, profiles/r02_ablation_fwd.txt).
+    constexpr int RA = 4, NS = SP_KD / 16;
+    f16x8 ah[RA], al[RA];
+    auto prefetch_k = [&](int buf) {
+        const _Float16* kb = kt + buf * 2 * KPLANE + c * SP_KROW + h * 8;
+#pragma unroll
+        for (int s = 0; s < RA - 1; ++s) {
+            ah[s] = *reinterpret_cast<const f16x8*>(kb + s * 16);
+            al[s] = *reinterpret_cast<const f16x8*>(kb + KPLANE + s * 16);
+        }
+    };
+    prefetch_k(0);
+
+    // One barrier per tile, BETWEEN the two MFMA loops.  Key tile t+1 is committed during QK(t) and read from QK(t+1)
+    // on (and by the prefetch at the end of P.V(t)): every wave has passed this barrier in between.  Value tile t+1 is
+    // committed during P.V(t) into the buffer P.V(t-1) read: every wave finished P.V(t-1) before it reached this
+    // barrier in tile t; it is read in P.V(t+1), after the barrier of tile t+1.
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * SP_BK, buf = t & 1;
         const bool ragged = RAGGED && (j0 + SP_BK > Nk);
+        _Float16* const kw = kt + (buf ^ 1) * 2 * KPLANE;
+        _Float16* const vw = vt + (buf ^ 1) * 2 * VPLANE;
+        const int jn = j0 + 2 * SP_BK;
+        // One staged piece of tile t+1 to the other LDS buffer, and its register immediately takes the load for tile
+        // t+2 — memory instructions are never issued as a burst.  i < 8: key-tile pieces (plane i & 1, chunk i >> 1),
+        // issued in the QK loop; 8 <= i < 8 + 2*CVB: value-tile pieces, issued in the P.V loop.
+        auto piece = [&](int i) {
+            if (COCOS_ABLATE & 1) return;
+            if (!RAGGED) {
+                const int jc = (COCOS_ABLATE & 64) ? SP_BK : min(jn, Nk - SP_BK);       // look-ahead past the end re-reads the last tile
+                if (i < 8) {
+                    const int pl_ = i & 1, u = i >> 1;
+                    *reinterpret_cast<u32x4*>(kw + pl_ * KPLANE + k_lds[u]) = kst[pl_][u];
+                    kst[pl_][u] = buf_load_u4s(pl_ ? kl_rs : kh_rs, k_voff[u], (unsigned)jc * (unsigned)(SP_KD * 2));
+                } else if (i - 8 < 2 * CVB) {
+                    const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
+                    *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + v_lds[u]) =
+                        (pl_ == 0 && u == CVB - 1 && ones_thread) ? kOnes2 : vst[pl_][u];
+                    vst[pl_][u] = buf_load_u2s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jc * 2u);
+                }
+                return;
+            }
+            if (i < 8) {
+                const int pl_ = i & 1, u = i >> 1;
+                const int g = u * 256 + tid, key = g >> 5, cc = g & 31;
+                *reinterpret_cast<u32x4*>(kw + pl_ * KPLANE + key * SP_KROW + cc * 8) = kst[pl_][u];
+                kst[pl_][u] = buf_load_u4(pl_ ? kl_rs : kh_rs, (unsigned)((jn + key) * SP_KD + cc * 8) * 2u);
+            } else if (i - 8 < 2 * CVB) {
+                const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
+                const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
+                const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);
+                *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + row * SP_VROW + slot) =
+                    (pl_ == 0 && u == CVB - 1 && ones_thread) ? kOnes2 : vst[pl_][u];
+                unsigned off = (unsigned)(row * Nk + jn + 4 * kq) * 2u;
+                if (row >= Cv || jn + 4 * kq >= Nk) off = kBufOob;
+                vst[pl_][u] = buf_load_u2(pl_ ? vl_rs : vh_rs, off);
+            }
+        };
 
         FPH_T(tp0);
-        // ---- S^T = K_tile . Q : 16 k-steps x 3 terms, operands read one step ahead.  Riding in the gaps:
-        //      the staged registers of tile t+1 go to the other LDS buffer (last read in iteration t-1, released
-        //      by the barrier that ended it) one 16-/8-byte piece per step, and each freed register immediately
-        //      takes its load for tile t+2 — memory instructions are never issued as a burst ------------------
-        f32x16 s0;     // all three terms of a product go into ONE accumulator (fp32 adds either way): no 16 adds per tile
+        // ---- S^T = K_tile . Q : 16 k-steps x 3 terms; three accumulators (one per product term) used round-robin, so
+        //      that consecutive MFMAs never depend on each other and every gap can carry a filler; the key-tile pieces of
+        //      tile t+1 ride in the gaps ------------------------------------------------------------------------------
+        f32x16 sa, sb, sc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s0[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; sc[r] = 0.f; }
         {
             const _Float16* kb = kt + buf * 2 * KPLANE + c * SP_KROW + h * 8;
-            _Float16* const kw = kt + (buf ^ 1) * 2 * KPLANE;
-            _Float16* const vw = vt + (buf ^ 1) * 2 * VPLANE;
-            const int jn = j0 + 2 * SP_BK;
-            auto piece = [&](int i) {
-                if (!RAGGED) {
-                    const int jc = min(jn, Nk - SP_BK);       // look-ahead past the end re-reads the last tile
-                    if (i < 8) {
-                        const int pl_ = i & 1, u = i >> 1;
-                        *reinterpret_cast<u32x4*>(kw + pl_ * KPLANE + k_lds[u]) = kst[pl_][u];
-                        kst[pl_][u] = buf_load_u4s(pl_ ? kl_rs : kh_rs, k_voff[u], (unsigned)jc * (unsigned)(SP_KD * 2));
-                    } else if (i - 8 < 2 * CVB) {
-                        const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
-                        *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + v_lds[u]) =
-                            (pl_ == 0 && u == CVB - 1 && ones_thread) ? kOnes2 : vst[pl_][u];
-                        vst[pl_][u] = buf_load_u2s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jc * 2u);
-                    }
-                    return;
-                }
-                if (i < 8) {                                  // K pieces: plane i&1, chunk i>>1
-                    const int pl_ = i & 1, u = i >> 1;
-                    const int g = u * 256 + tid, key = g >> 5, cc = g & 31;
-                    *reinterpret_cast<u32x4*>(kw + pl_ * KPLANE + key * SP_KROW + cc * 8) = kst[pl_][u];
-                    kst[pl_][u] = buf_load_u4(pl_ ? kl_rs : kh_rs, (unsigned)((jn + key) * SP_KD + cc * 8) * 2u);
-                } else if (i - 8 < 2 * CVB) {                 // V pieces
-                    const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
-                    const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
-                    const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);
-                    *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + row * SP_VROW + slot) =
-                        (pl_ == 0 && u == CVB - 1 && ones_thread) ? kOnes2 : vst[pl_][u];
-                    unsigned off = (unsigned)(row * Nk + jn + 4 * kq) * 2u;
-                    if (row >= Cv || jn + 4 * kq >= Nk) off = kBufOob;
-                    vst[pl_][u] = buf_load_u2(pl_ ? vl_rs : vh_rs, off);
-                }
-            };
-            // operands are requested RA steps ahead: with four waves on the LDS pipe a ds_read_b128 takes several
-            // hundred cycles to come back, far more than the 96 cycles of one step's MFMAs
-            constexpr int RA = 4, NS = SP_KD / 16;
-            f16x8 ah[RA], al[RA];
-#pragma unroll
-            for (int s = 0; s < RA - 1; ++s) {
-                ah[s] = *reinterpret_cast<const f16x8*>(kb + s * 16);
-                al[s] = *reinterpret_cast<const f16x8*>(kb + KPLANE + s * 16);
-            }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int cur = s % RA;
-                if (s + RA - 1 < NS) {
-                    ah[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + (s + RA - 1) * 16);
-                    al[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + KPLANE + (s + RA - 1) * 16);
-                }
-                s0 = mfma16h(ah[cur], qhr[s], s0);
-                s0 = mfma16h(ah[cur], qlr[s], s0);
-                s0 = mfma16h(al[cur], qhr[s], s0);
-                // 8 + 2*CVB <= 18 pieces over 16 steps
-                piece(s);
-                if (s < 2) piece(16 + s);
+                sa = mfma16h(ah[cur], qhr[s], sa);
+                if (!(COCOS_ABLATE & 2) && s + RA - 1 < NS) ah[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + (s + RA - 1) * 16);
+                __builtin_amdgcn_sched_barrier(0);
+                sb = mfma16h(ah[cur], qlr[s], sb);
+                if (!(COCOS_ABLATE & 2) && s + RA - 1 < NS) al[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + KPLANE + (s + RA - 1) * 16);
+                __builtin_amdgcn_sched_barrier(0);
+                sc = mfma16h(al[cur], qhr[s], sc);
+                if ((s & 1) == 0) piece(s >> 1);            // the 8 key-tile pieces, every other step
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         FPH_T(tp1);
+        __syncthreads();   // key tile t+1 visible to everyone; value buffer of tile t-1 free (see the loop header)
         FPH_T(tp2);
+        // ---- the P.V loop's first value fragments: their latency hides under the softmax arithmetic ------------------
+        constexpr int NSV = 2 * CVB;                          // P.V step i = tt * CVB + cb
+        f16x8 a_h[RA], a_l[RA];
+        const _Float16* vbase = vt + buf * 2 * VPLANE + c * SP_VROW + h * 8;
+#pragma unroll
+        for (int i = 0; i < RA - 1 && i < NSV; ++i) {
+            a_h[i] = *reinterpret_cast<const f16x8*>(vbase + (i % CVB) * 32 * SP_VROW + (i / CVB) * 16);
+            a_l[i] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + (i % CVB) * 32 * SP_VROW + (i / CVB) * 16);
+        }
         // ---- online softmax (log2 domain), lazy rescale as in the fp32 kernel -------------------------
         // The row maximum is taken on the raw accumulator (scale_log2 > 0) and scaled once; the exponent is one
         // fma per element: p = 2^(s * scale_log2 - (m - kPBias)).
+        f32x16 s0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = (sa[r] + sb[r]) + sc[r];
         if (ragged) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -347,19 +381,19 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
 #pragma unroll
             for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
         }
-        if (STORE_S) {
+        if (STORE_S && !(COCOS_ABLATE & 8)) {
             // the wave's 32x32 tile of raw logits: four contiguous 1 KB stores (registers 4k..4k+3 of every lane)
-            const unsigned soff = (unsigned)(t * nqblk) * 4096u;
+            const unsigned soff = (COCOS_ABLATE & 32) ? 0u : (unsigned)(t * nqblk) * 4096u;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 __builtin_amdgcn_raw_buffer_store_b128(
                     __builtin_bit_cast(u32x4, f32x4{s0[4 * k], s0[4 * k + 1], s0[4 * k + 2], s0[4 * k + 3]}), lg_rs,
-                    (int)lg_lane_off, (int)(soff + (unsigned)k * 1024u), 0);
+                    (int)lg_lane_off, (int)(soff + (unsigned)k * 1024u), COCOS_STREAM_AUX);
         }
         float p[16];
         const float nmb = kPBias - m_run;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[r] = fast_exp2(__builtin_fmaf(s0[r], scale_log2, nmb));
+        for (int r = 0; r < 16; ++r) p[r] = (COCOS_ABLATE & 4) ? s0[r] * 1e-3f + 1.0f : fast_exp2(__builtin_fmaf(s0[r], scale_log2, nmb));
 
         FPH_T(tp3);
         // P -> f16 hi/lo: registers 8t..8t+7 are the k-slots of P.V step t
@@ -375,26 +409,21 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
             }
 
         FPH_T(tp4);
-        // ---- O^T += V . P : A = V tile rows (channels) with permuted keys, B = P ---------------------
+        // ---- O^T += V . P : A = V tile rows (channels) with permuted keys, B = P.  Riding in the gaps: the value-tile
+        //      pieces of tile t+1 (one per step) and, in the last steps, the first key fragments of tile t+1 ----------------
         {
-            const _Float16* vbase = vt + buf * 2 * VPLANE + c * SP_VROW + h * 8;
-            constexpr int RA = 4, NS = 2 * CVB;               // step i = tt * CVB + cb
-            f16x8 a_h[RA], a_l[RA];
 #pragma unroll
-            for (int i = 0; i < RA - 1 && i < NS; ++i) {
-                a_h[i] = *reinterpret_cast<const f16x8*>(vbase + (i % CVB) * 32 * SP_VROW + (i / CVB) * 16);
-                a_l[i] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + (i % CVB) * 32 * SP_VROW + (i / CVB) * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
+            for (int i = 0; i < NSV; ++i) {
                 const int tt = i / CVB, cb = i % CVB, cur = i % RA, n = i + RA - 1;
-                if (n < NS) {
+                if (!(COCOS_ABLATE & 2) && n < NSV) {
                     a_h[n % RA] = *reinterpret_cast<const f16x8*>(vbase + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
                     a_l[n % RA] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
                 }
                 o[cb] = mfma16h(a_h[cur], ph[tt], o[cb]);
                 o[cb] = mfma16h(a_h[cur], pl[tt], o[cb]);
                 o[cb] = mfma16h(a_l[cur], ph[tt], o[cb]);
+                piece(8 + i);
+                if (i == NSV - 1) prefetch_k(buf ^ 1);      // (NSV = 2: both in the same step)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -403,10 +432,8 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
 #pragma unroll
         for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
         FPH_T(tp5);
-        __syncthreads();   // tile t+1 visible; buffer `buf` free for the commit of tile t+2
-        FPH_T(tp6);
         FPH_ADD(0, tp0, tp1); FPH_ADD(1, tp1, tp2); FPH_ADD(2, tp2, tp3); FPH_ADD(3, tp3, tp4);
-        FPH_ADD(4, tp4, tp5); FPH_ADD(5, tp5, tp6);
+        FPH_ADD(4, tp4, tp5);
     }
 
     // ---- epilogue: normalise, store channel-major [B,Cv,Nq], store row LSE --------------------------

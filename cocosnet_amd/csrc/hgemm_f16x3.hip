@@ -27,7 +27,9 @@ constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row
 
 // EXACT: M % 256 == 0, N % 128 == 0, K % 32 == 0 — no bounds tests at all.  With them hipcc wraps every staged load in
 // an exec-mask region (s_and_saveexec / s_or per load: ~120 scalar instructions per k-step of 96 MFMAs).
-template <bool EXACT>
+// BSTREAM: the B operand is a stream that nothing re-reads (the dS'' / P planes of the K2 backward: 0.5 GB per launch):
+// loaded `nt` so that it does not evict the A planes (4 MB per sample, re-read by every N tile) from the XCD's L2.
+template <bool EXACT, bool BSTREAM>
 __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __restrict__ ah,
                                                              const _Float16* __restrict__ al,
                                                              const _Float16* __restrict__ bh,
@@ -89,8 +91,8 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
             unsigned off = b_blocked ? (unsigned)(((n0 >> 7) * (K >> 5) + (k0 >> 5)) * 4096 + row * 32 + kc * 8) * 2u
                                      : (unsigned)((n0 + row) * K + k0 + kc * 8) * 2u;
             if (!EXACT && (n0 + row >= N || k0 + kc * 8 >= K)) off = kBufOob;
-            st.b[0][u] = __builtin_amdgcn_raw_buffer_load_b128(bh_rs, (int)off, 0, 0);
-            st.b[1][u] = __builtin_amdgcn_raw_buffer_load_b128(bl_rs, (int)off, 0, 0);
+            st.b[0][u] = __builtin_amdgcn_raw_buffer_load_b128(bh_rs, (int)off, 0, BSTREAM ? 2 : 0);
+            st.b[1][u] = __builtin_amdgcn_raw_buffer_load_b128(bl_rs, (int)off, 0, BSTREAM ? 2 : 0);
         }
     };
     auto commit = [&](const Stage& st, int buf) {
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
             unsigned off = b_blocked ? (unsigned)(((n0 >> 7) * (K >> 5) + (k0 >> 5)) * 4096 + row * 32 + kc * 8) * 2u
                                      : (unsigned)((n0 + row) * K + k0 + kc * 8) * 2u;
             if (!EXACT && (n0 + row >= N || k0 + kc * 8 >= K)) off = kBufOob;
-            st.b[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(pl ? bl_rs : bh_rs, (int)off, 0, 0);
+            st.b[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(pl ? bl_rs : bh_rs, (int)off, 0, BSTREAM ? 2 : 0);
         }
     };
     auto step = [&](int t, Stage& st) {
@@ -215,7 +217,8 @@ extern "C" int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void*
     COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "hgemm_f16x3: grid too large");
     const size_t smem = (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16);
     const bool exact = M % HG_BM == 0 && N % HG_BN == 0 && K % HG_BK == 0;
-    auto kern = exact ? hgemm_f16x3_kernel<true> : hgemm_f16x3_kernel<false>;
+    auto kern = exact ? (b_blocked ? hgemm_f16x3_kernel<true, true> : hgemm_f16x3_kernel<true, false>)
+                      : (b_blocked ? hgemm_f16x3_kernel<false, true> : hgemm_f16x3_kernel<false, false>);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),
