@@ -46,6 +46,7 @@ HIP_SOURCES = [
     "instnorm_prelu.hip",
     "upsample_nearest.hip",
     "warp_values.hip",
+    "contextual_rows.hip",
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              "-Wall", "-Wno-unused-function"]

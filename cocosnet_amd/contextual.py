@@ -1,0 +1,62 @@
+"""`ContextualLoss_forward` of the reference (models/networks/ContextualLoss.py:83-137) on the HIP kernels.
+
+SURVEY.md §8(f) rank 3: the contextual loss is the other QK^T -> normalise -> reduce op on the training step's critical
+path (pix2pix_model.py get_ctx_loss: VGG relu features of the generated image against the exemplar's).  Same class name,
+constructor and `forward(X_features, Y_features, h=0.1, feature_centering=True)` signature; returns the per-sample loss.
+
+    centring + x / (||x||_2 + eps)       K1 (`ops.center_l2norm`, mode 2 after the reference's own centring)   :108-116
+    cos = X^T Y                          K3 (`ops.corr_materialize`, split-precision GEMM)                     :121
+    d, d_norm, w, A, max_j A             K15 (`ops.contextual_rows`: one pass over the [N, N] matrix)          :121-132
+    CX = mean_i, loss = -log CX          host (B numbers)                                                      :132-133
+CPU tensors take the reference's formulation in torch (used by the CPU parity test only).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_EPS = __import__("sys").float_info.epsilon      # util.feature_normalize (util/util.py:31-34)
+
+
+def _feature_normalize(x):
+    if x.is_cuda and x.dtype == torch.float32:
+        return ops.feature_normalize(x, _EPS)
+    return x / (torch.norm(x, 2, 1, keepdim=True) + _EPS)
+
+
+class ContextualLoss_forward(nn.Module):
+    """Drop-in for the reference class; input feature maps [B, C, h, w] (or [B, C, N])."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+
+    def forward(self, X_features, Y_features, h=0.1, feature_centering=True):
+        B, C = X_features.shape[:2]
+        if feature_centering:                                                                  # :108-114
+            if getattr(self.opt, "PONO", False):
+                mu = Y_features.mean(dim=1).unsqueeze(dim=1)
+            else:
+                mu = Y_features.reshape(B, C, -1).mean(dim=-1).reshape(B, C, *([1] * (Y_features.dim() - 2)))
+            X_features, Y_features = X_features - mu, Y_features - mu
+        Xn = _feature_normalize(X_features).reshape(B, C, -1)                                  # :115-116
+        Yn = _feature_normalize(Y_features).reshape(B, C, -1)
+        if Xn.is_cuda and Xn.dtype == torch.float32 and Yn.shape[2] <= 4096:
+            cos = ops.corr_materialize(Xn.contiguous(), Yn.contiguous(), 1.0)                  # :121 (K3)
+            cx = ops.contextual_rows(cos, h, 1e-3)                                             # :121-132 (K15)
+            return -torch.log(cx.mean(dim=1))                                                  # :132-133
+        d = 1 - torch.matmul(Xn.permute(0, 2, 1), Yn)
+        d_norm = d / (torch.min(d, dim=-1, keepdim=True)[0] + 1e-3)
+        w = torch.exp((1 - d_norm) / h)
+        A = w / torch.sum(w, dim=-1, keepdim=True)
+        return -torch.log(torch.mean(torch.max(A, dim=-1)[0], dim=1))
+
+
+def install_contextual_loss_into_reference(models_module):
+    """`models.networks.ContextualLoss.ContextualLoss_forward` -> this class (pix2pix_model.py builds it by name)."""
+    import importlib
+    mod = importlib.import_module(models_module.__name__ + ".ContextualLoss")
+    mod.ContextualLoss_forward = ContextualLoss_forward
+    return ContextualLoss_forward

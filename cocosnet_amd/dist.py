@@ -115,6 +115,11 @@ class GradBuckets:
     @torch.no_grad()
     def zero_grad(self) -> None:
         """One fill per bucket; re-attaches any p.grad that something replaced (e.g. `p.grad = None`)."""
+        # a collective launched by a hook and never finish()ed (e.g. the discriminator's parameters receive gradients
+        # during the GENERATOR step of a GAN; its optimiser only zeroes them) must be over before its buffer is reused
+        for w in self._works:
+            if w is not None:
+                w.wait()
         for i, bucket in enumerate(self.buckets):
             flat = self._flat[i]
             flat.zero_()

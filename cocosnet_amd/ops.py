@@ -1005,6 +1005,50 @@ def instnorm_prelu(x, residual, weight, eps: float = INSTNORM_EPS):
     return _InstNormPReLU.apply(x, residual, weight, eps)
 
 
+def softmax_attention(q, k, v, scale: float = 1.0):
+    """out[b,c,i] = sum_j softmax_j(scale * <q[b,:,i], k[b,:,j]>) v[b,c,j] for any channel count K — the QK^T ->
+    softmax -> PV op class of the path (`Attention.forward`, architecture.py:114-127, has K =
+    ch/8 = 32..64, HW/4 keys and ch/2 value channels).  K == 256 takes the fused kernels (K2); every other K the
+    materialised family on the same MFMA GEMMs (K3 -> K4 -> K5), autograd included."""
+    if q.shape[1] == FUSED_K:
+        return corr_softmax_warp(q, k, v, scale)
+    return warp_materialized(row_softmax(corr_materialize(q, k, scale)), v)
+
+
+# ------------------------------------------------------------------------------------------
+# K15 row reductions of the contextual loss   (ContextualLoss.py:121-133)
+# ------------------------------------------------------------------------------------------
+class _ContextualRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cosm, h: float, eps: float):
+        cosm = _chk(cosm, "contextual_rows: cos")
+        cols = cosm.shape[-1]
+        rows = cosm.numel() // cols
+        cx = torch.empty(cosm.shape[:-1], device=cosm.device, dtype=torch.float32)
+        _call("contextual_rows_fwd", "cocos_contextual_rows_fwd", cosm.data_ptr(), cx.data_ptr(), rows, cols, float(h),
+              float(eps), _stream())
+        ctx.save_for_backward(cosm)
+        ctx.cfg = (float(h), float(eps))
+        return cx
+
+    @staticmethod
+    def backward(ctx, dcx):
+        (cosm,) = ctx.saved_tensors
+        h, eps = ctx.cfg
+        dcx = _chk(dcx, "contextual_rows: dcx")
+        cols = cosm.shape[-1]
+        dcos = torch.empty_like(cosm)
+        _call("contextual_rows_bwd", "cocos_contextual_rows_bwd", cosm.data_ptr(), dcx.data_ptr(), dcos.data_ptr(),
+              cosm.numel() // cols, cols, h, eps, _stream())
+        return dcos, None, None
+
+
+def contextual_rows(cosm, h: float = 0.1, eps: float = 1e-3):
+    """cx[..., i] = max_j A[..., i, j] of the contextual affinity A built from the cosine matrix cosm [..., N, M <= 4096]
+    (d = 1 - cos, d / (min_j d + eps), exp((1 - .) / h), row-normalised): ContextualLoss.py:121-132 in one pass."""
+    return _ContextualRows.apply(cosm, h, eps)
+
+
 def mfma_probe() -> torch.Tensor:
     """Debug: the 64x16 accumulator image of one v_mfma_f32_32x32x2_f32 (see api_common.hip)."""
     out = torch.empty((64, 16), device="cuda", dtype=torch.float32)

@@ -99,8 +99,13 @@ class Attention(nn.Module):
         theta = self.theta(x).view(B, self.ch // 8, H * W)
         phi = F.max_pool2d(self.phi(x), [2, 2]).view(B, self.ch // 8, H * W // 4)
         g = F.max_pool2d(self.g(x), [2, 2]).view(B, self.ch // 2, H * W // 4)
-        beta = F.softmax(torch.bmm(theta.transpose(1, 2), phi), -1)
-        o = self.o(torch.bmm(g, beta.transpose(1, 2)).view(B, self.ch // 2, H, W))
+        if x.is_cuda and x.dtype == torch.float32:
+            from . import ops            # QK^T -> softmax -> PV on the HIP kernels of the path (§8f rank 3)
+            att = ops.softmax_attention(theta.contiguous(), phi.contiguous(), g.contiguous(), 1.0)
+        else:
+            beta = F.softmax(torch.bmm(theta.transpose(1, 2), phi), -1)
+            att = torch.bmm(g, beta.transpose(1, 2))
+        o = self.o(att.view(B, self.ch // 2, H, W))
         return self.gamma * o + x
 
 

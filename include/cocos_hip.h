@@ -389,6 +389,20 @@ int cocos_logits_softmax_warp_bwd_f16x3(const float* logits_t, const void* vph, 
                                         int Nq, int Nk, int Cv, int CvPad, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * K15 row reductions of the contextual loss (ContextualLoss_forward.forward,
+ *     models/networks/ContextualLoss.py:121-133, after its cosine-similarity matmul = cocos_corr_materialize):
+ *       d = 1 - cos;  d_norm = d / (min_j d + eps);  w = exp((1 - d_norm) / h);  A = w / sum_j w;  cx[i] = max_j A[i,j]
+ *     = 1 / sum_j exp((cos[i,j] - m_i) s_i),  m_i = max_j cos[i,j],  s_i = 1 / (h (1 - m_i + eps)).
+ *   cosm [rows, cols] fp32 (rows = B * positions of X), 1 <= cols <= 4096; one read of the matrix forward, one read +
+ *   one write backward (row statistics recomputed).  bwd: dcos[i,j] = dcx[i] * d cx[i] / d cos[i,j], including the
+ *   path through the row maximum (first index on ties, like torch.min's gradient).
+ * ------------------------------------------------------------------------------------- */
+int cocos_contextual_rows_fwd(const float* cosm, float* cx, long long rows, int cols, float h, float eps,
+                              cocos_stream_t stream);
+int cocos_contextual_rows_bwd(const float* cosm, const float* dcx, float* dcos, long long rows, int cols, float h,
+                              float eps, cocos_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * K12 statistics of the zero-padded 3x3-unfolded, centred feature vectors without unfolding (match_kernel 3 with
  *     PONO_C: correspondence.py:276-280 / :286-289), feeding K6:
  *   fwd: x [B,C,h,w] -> mu[b,p] = mean of the 9*C unfolded entries at p, nrm[b,p] = ||U_p - mu||_2,

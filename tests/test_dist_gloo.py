@@ -164,3 +164,70 @@ def test_sync_batchnorm_single_process_and_state_dict_names():
     x = torch.randn(4, 3, 2, 2)
     assert torch.allclose(bn(x), ref(x), atol=1e-5)
     assert torch.allclose(bn.running_var, ref.running_var, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------- trainer-level driver
+class _ToyTrainer:
+    """The shape of the reference's Pix2PixTrainer (trainers/pix2pix_trainer.py:20-74): a model, two optimisers, a
+    generator step and a discriminator step that keeps the generator's output across the D step."""
+
+    def __init__(self, opt):
+        torch.manual_seed(opt.seed)
+        self.G = torch.nn.Sequential(torch.nn.Conv2d(3, 6, 3, padding=1), torch.nn.PReLU(), torch.nn.Conv2d(6, 3, 1))
+        self.D = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.LeakyReLU(0.2), torch.nn.Conv2d(4, 1, 1))
+        self.pix2pix_model_on_one_gpu = torch.nn.ModuleDict({"G": self.G, "D": self.D})
+        self.optimizer_G = torch.optim.Adam(self.G.parameters(), lr=1e-2, betas=(0.0, 0.9), eps=1e-3)
+        self.optimizer_D = torch.optim.Adam(self.D.parameters(), lr=2e-2, betas=(0.0, 0.9), eps=1e-3)
+
+    def run_generator_one_step(self, x, y):
+        self.optimizer_G.zero_grad()
+        self.out = self.G(x)
+        g_loss = (self.out - y).abs().mean() - self.D(self.out).mean()
+        g_loss.backward()
+        self.optimizer_G.step()
+
+    def run_discriminator_one_step(self, x, y):
+        self.optimizer_D.zero_grad()
+        d_loss = torch.relu(1 + self.D(self.out.detach())).mean() + torch.relu(1 - self.D(y)).mean()
+        d_loss.backward()
+        self.optimizer_D.step()
+
+
+def _trainer_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from types import SimpleNamespace
+    from cocosnet_amd import trainer as ctr
+    Dist = ctr.make_distributed_trainer(_ToyTrainer)
+    tr_ = Dist(SimpleNamespace(seed=100 + rank, gpu_ids=[]), backend="gloo", bucket_bytes=64)   # different seeds per rank:
+    g = torch.Generator().manual_seed(7)                                                         # the broadcast must fix it
+    X, Y = torch.randn(3, 4, 3, 5, 5, generator=g), torch.randn(3, 4, 3, 5, 5, generator=g)
+    for it in range(3):
+        lo, hi = tr_.shard(4)
+        tr_.run_generator_one_step(X[it, lo:hi], Y[it, lo:hi])
+        tr_.run_discriminator_one_step(X[it, lo:hi], Y[it, lo:hi])
+    ret[rank] = [p.detach().clone() for p in tr_.pix2pix_model_on_one_gpu.parameters()]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_trainer_equals_single_process_on_the_global_batch():
+    """Two ranks x batch 2 through the wrapped trainer == one process x batch 4 through the plain one (three G + D
+    steps with Adam): identical replicas after the start-up broadcast, gradient means == global-batch gradients, the
+    step functions themselves unchanged."""
+    from types import SimpleNamespace
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_trainer_worker, args=(world, port, ret), nprocs=world, join=True)
+    ref = _ToyTrainer(SimpleNamespace(seed=100))          # rank 0's initialisation
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(3, 4, 3, 5, 5, generator=g), torch.randn(3, 4, 3, 5, 5, generator=g)
+    for it in range(3):
+        ref.run_generator_one_step(X[it], Y[it])
+        ref.run_discriminator_one_step(X[it], Y[it])
+    want = [p.detach() for p in ref.pix2pix_model_on_one_gpu.parameters()]
+    for rank in range(world):
+        for a, b in zip(ret[rank], want):
+            assert torch.allclose(a, b, atol=2e-5, rtol=1e-4)

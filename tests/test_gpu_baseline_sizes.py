@@ -414,3 +414,103 @@ def test_drop_in_behaves_for_the_reference_callers():
         opt.CBN_intype = intype
         with torch.no_grad():
             assert caller.inference(seg, seg.flip(0), img)["fake_image"].shape == (2, 1, 64, 64)
+
+
+# ------------------------------------------------------------------ §8(f) rank 3: the same op class elsewhere in the model
+@pytest.mark.parametrize("B,ch,H,W", [(2, 512, 32, 32), (1, 256, 64, 64), (2, 64, 16, 24)])
+def test_attention_block_on_hip_matches_torch_fp64(B, ch, H, W):
+    """`Attention.forward` (architecture.py:114-127: theta ch/8, max-pooled phi ch/8 and g ch/2, softmax over HW/4
+    keys, gamma * o + x) through ops.softmax_attention — outputs and every gradient vs the torch formulation in fp64."""
+    from cocosnet_amd.producers import Attention
+    torch.manual_seed(0)
+    att = Attention(ch, use_sn=False).to(DEV)
+    with torch.no_grad():
+        att.gamma.fill_(0.7)
+        for m in (att.theta, att.phi):
+            m.weight.mul_(3.0)                   # sharper rows than the default initialisation gives
+    ref = Attention(ch, use_sn=False).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in att.state_dict().items()})
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(B, ch, H, W, device=DEV, generator=g)
+    gy = torch.randn(B, ch, H, W, device=DEV, generator=g)
+    xa = x.clone().requires_grad_(True)
+    y = att(xa)
+    y.backward(gy)
+    xr = x.double().cpu().requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(gy.double().cpu())
+    assert rel(y, yr.detach().numpy()) < TOL
+    assert rel(xa.grad, xr.grad.numpy()) < TOL
+    for (n, p), (_, q) in zip(att.named_parameters(), ref.named_parameters()):
+        assert rel(p.grad, q.grad.numpy()) < TOL, n
+
+
+@pytest.mark.parametrize("B,C,h,w,pono", [(2, 512, 32, 32, True), (2, 256, 16, 16, False), (1, 64, 64, 64, True), (1, 48, 9, 7, False)])
+def test_contextual_loss_forward_matches_the_reference_formula(B, C, h, w, pono):
+    """`ContextualLoss_forward.forward` (ContextualLoss.py:93-137) on K1 + K3 + K15 against the reference's formulation
+    in torch fp64: per-sample loss and the gradient w.r.t. the generated features X (the exemplar side Y is detached in
+    the caller, pix2pix_model.py get_ctx_loss; checked here too)."""
+    from types import SimpleNamespace
+    from cocosnet_amd.contextual import ContextualLoss_forward
+    g = torch.Generator(device=DEV).manual_seed(C + h)
+    Y = torch.randn(B, C, h, w, device=DEV, generator=g) + 0.3
+    perm = torch.randperm(h * w, device=DEV, generator=g)
+    X = (0.6 * Y.reshape(B, C, -1)[:, :, perm].reshape(B, C, h, w) + torch.randn(B, C, h, w, device=DEV, generator=g))
+    mod = ContextualLoss_forward(SimpleNamespace(PONO=pono))
+    xa, ya = X.clone().requires_grad_(True), Y.clone().requires_grad_(True)
+    loss = mod(xa, ya, h=0.1)
+    assert loss.shape == (B,)
+    loss.sum().backward()
+    xr, yr = X.double().cpu().requires_grad_(True), Y.double().cpu().requires_grad_(True)
+    lr = mod(xr, yr, h=0.1)               # CPU tensors: the reference's formulation (torch), here in fp64
+    lr.sum().backward()
+    assert rel(loss, lr.detach().numpy()) < 1e-3
+    assert rel(xa.grad, xr.grad.numpy()) < 2e-3
+    assert rel(ya.grad, yr.grad.numpy()) < 2e-3
+
+
+# ------------------------------------------------------------------ RCCL is at least initialised on the box
+def test_rccl_world_size_one_smoke():
+    """backend "nccl" IS RCCL on ROCm.  The driver owns the multi-GPU runs; here the same code path (process-group init
+    from the environment, an all-reduce on a CUDA tensor, the bucketed gradient exchange with its hooks, Sync-BN
+    statistics) runs once on a world of one, so that RCCL initialisation and the stream hand-over are exercised."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from cocosnet_amd import dist as cdist
+    from cocosnet_amd import trainer as ctr
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        if not dist.is_initialized():
+            dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        t = torch.arange(8, device=DEV, dtype=torch.float32)
+        dist.all_reduce(t)                                         # RCCL kernel on one rank: identity
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32))
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), cdist.SyncBatchNorm2d(4)).to(DEV)
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        buckets = ctr.attach_gradient_exchange(opt, bucket_bytes=64)
+        ctr.broadcast_parameters(net)
+        x = torch.randn(4, 3, 5, 5, device=DEV)
+        ref = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4)).to(DEV)
+        ref.load_state_dict(net.state_dict())
+        opt.zero_grad()
+        net(x).pow(2).mean().backward()
+        ref(x).pow(2).mean().backward()
+        opt.step()
+        assert sum(buckets._launched) == len(buckets.buckets)      # every bucket left from a hook
+        for a, b in zip(net.parameters(), ref.parameters()):
+            assert torch.allclose(a.grad, b.grad, atol=1e-5)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -168,3 +168,27 @@ def test_install_spade_into_reference(pono, monkeypatch):
     assert not hasattr(arch.SPADEResnetBlock, "_cocos_reference_forward")
     y3 = blk(x, seg)
     assert torch.allclose(y3.detach(), ref[0], atol=1e-6)
+
+
+@needs_ref
+def test_contextual_loss_module_equals_the_reference_class_on_cpu():
+    """cocosnet_amd.contextual.ContextualLoss_forward restates ContextualLoss.py:93-137: on CPU tensors (where it runs
+    the same formulation in torch) it must agree with the reference class itself, PONO and non-PONO centring."""
+    import importlib
+    from types import SimpleNamespace
+    from cocosnet_amd.contextual import ContextualLoss_forward, install_contextual_loss_into_reference
+    rh.load_reference()
+    ref_mod = importlib.import_module("models.networks.ContextualLoss")
+    g = torch.Generator().manual_seed(0)
+    X, Y = torch.randn(2, 16, 6, 5, generator=g), torch.randn(2, 16, 6, 5, generator=g) + 0.2
+    for pono in (True, False):
+        opt = SimpleNamespace(PONO=pono)
+        a = ContextualLoss_forward(opt)(X, Y, h=0.1)
+        b = ref_mod.ContextualLoss_forward(opt)(X, Y, h=0.1)
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    original = ref_mod.ContextualLoss_forward
+    try:
+        assert install_contextual_loss_into_reference(importlib.import_module("models.networks")) is ContextualLoss_forward
+        assert ref_mod.ContextualLoss_forward is ContextualLoss_forward
+    finally:
+        ref_mod.ContextualLoss_forward = original
