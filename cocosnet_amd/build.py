@@ -47,6 +47,7 @@ HIP_SOURCES = [
     "upsample_nearest.hip",
     "warp_values.hip",
     "contextual_rows.hip",
+    "conv_f16x3.hip",
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              "-Wall", "-Wno-unused-function"]

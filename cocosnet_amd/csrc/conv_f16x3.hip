@@ -1,0 +1,705 @@
+// K16: 2-D convolution as an implicit GEMM on v_mfma_f32_32x32x16_f16, fp32 in / fp32 out, every product carried as
+// f16 hi + lo with three MFMA terms and fp32 accumulation (the arithmetic of corr_fused_fwd_f16x3.hip) — gfx950.
+//
+// the 3x3 convolutions in front of the path — `ResidualBlock` x4 (correspondence.py:13-36,
+// :175-179: reflect-pad -> 3x3, 407 -> 407 channels on the 64x64 grid) and the adaptors (correspondence.py:150-173) — and,
+// riding along, the k4 s2 convolutions of the PatchGAN (discriminator.py:92-115).  The features they produce are
+// L2-normalised and multiplied by 1/T = 100 inside the softmax: plain f16/bf16 convolutions would break the 1e-3 parity
+// of the path they feed, the fp32 MFMA runs at 1/16 of the f16 rate, hence the split.
+//
+// The contraction index is ordered TAP-MAJOR:  k = tap * Cp + ci,  tap = ky*KW + kx,  Cp = Cin rounded up to 32.  A
+// k-block of 32 is then 32 consecutive channels at ONE tap: its addresses are a per-thread constant plus a per-step
+// scalar, its border masks are those of the tap — no per-element index arithmetic in the steady state.  (Measured on
+// the first version, ordered (ci,ky,kx): the integer work of the gather, not the loads, set the speed — a wave
+// that owns a SIMD issues ~1 instruction / 4-5 cycles, i.e. ~7 per 32-cycle MFMA, and everything else must fit there.)
+//
+//   forward / input gradient (conv_fwd_kernel):   Y[b,co,oy,ox] = bias[co] + sum_k Wt[co,k] X[b,ci,oy*s+ky-p,ox*s+kx-p]
+//       GEMM  C[M = Cout][N = B*OH*OW] over K = T*Cp;  A = weight planes (pre-split f16 hi/lo, k-block major
+//       [K/32][Cout][32], zero for ci >= Cin), B = the im2col matrix, never materialised: each k-block of 32 channels x 128
+//       positions is GATHERED from the fp32 input (zero padding = masked loads), split to hi/lo on the fly and written
+//       to LDS position-contiguous; the MFMA B fragments (8 consecutive k for one position) come out of that image
+//       through ds_read_b64_tr_b16, the LDS transpose read of gfx950 (lane i of a 16-lane group supplies the address of
+//       piece (row i>>2, columns 4(i&3)..+3) of a 4 x 16 block and receives column i — probed in
+//       tools/probes/tr16_probe.hip).  The input gradient of a stride-1 convolution is the same kernel on dY with the
+//       flipped, transposed weights and padding K-1-p.
+//   weight gradient (conv_wgrad_kernel):   dW[co,k] = sum_{b,oy,ox} dY[b,co,oy,ox] X[b,ci,oy*s+ky-p,ox*s+kx-p]
+//       GEMM  C[M = Cout][N = T*Cp] over the B*OH*OW positions, split over position chunks (few output tiles, long
+//       contraction); both operands are position-contiguous in memory, so both LDS images are k-contiguous and the
+//       fragments are plain 16-byte reads.  A thread's rows (co, k) are fixed for the whole kernel; only the position
+//       advances.
+// Tile BM (128 | 256) x 128 x 32, 4 waves as 2 x 2, double-buffered LDS, two register stages, staging pieces placed by
+// hand between the MFMA groups; ~2*M*N*K useful FLOPs, x3 issued.
+#include "common.h"
+
+#ifndef COCOS_CONV_ABLATE
+#define COCOS_CONV_ABLATE 0     // timing experiments only (tools/build_conv_ablations.sh): 1 no gather loads, 2 no weight
+#endif                          // loads, 4 no LDS commit, 8 no MFMA
+
+namespace cocos {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CV_BN = 128, CV_BK = 32;
+constexpr int CV_AROW = CV_BK + 8;      // halfs per row of a k-contiguous image (80 B: conflict-free b128 reads)
+constexpr int CV_GROW = CV_BN + 32;     // halfs per k row of the position-contiguous image: 320 B = 256 + 64, so the four
+                                        // rows of a transpose read fall into four different quarters of the 64 banks
+
+// n / d for 0 <= n < 2^31, branch-free:  (umulhi(n, mul) + (add ? n : 0)) >> sh.
+//   d not a power of two: sh = floor(log2 d), mul = ceil(2^(32+sh) / d), add = 0 — exact because the rounding excess of
+//   the multiplier is < d < 2^(sh+1), so n * excess < 2^(32+sh);   d = 2^sh: mul = 0, add = 1.
+struct Magic { unsigned mul, sh, add; };
+__device__ __forceinline__ int cv_div(int n, Magic m) {
+    return (int)((__umulhi((unsigned)n, m.mul) + (unsigned)n * m.add) >> m.sh);
+}
+
+struct ConvGeom {
+    int Cin, H, W, OH, OW, KH, KW, stride, pad;
+    int Cp;                  // Cin rounded up to 32
+    int Ktot;                // KH * KW * Cp
+    int Ntot;                // B * OH * OW
+    int xelems;              // B * Cin * H * W
+    Magic mNCB, mKW, mOHW, mOW, mCp;     // / (Cp/32), / KW, / (OH*OW), / OW, / Cp
+};
+
+__device__ __forceinline__ float cv_scale_from_amax(const float* amax) {
+    if (!amax) return 1.0f;
+    const float a = *amax;
+    if (!(a > 0.f) || !(a < INFINITY)) return 1.0f;
+    int e;
+    frexpf(a, &e);
+    return ldexpf(1.0f, 10 - e);
+}
+
+// x*s -> f16 hi (round toward zero) + f16 lo, four values
+__device__ __forceinline__ void cv_split4(const float (&x)[4], float s, u32x2& hi, u32x2& lo) {
+    unsigned h0, l0, h1, l1;
+    split_pair_rtz(x[0] * s, x[1] * s, h0, l0);
+    split_pair_rtz(x[2] * s, x[3] * s, h1, l1);
+    hi = u32x2{h0, h1};
+    lo = u32x2{l0, l1};
+}
+
+// GEMM column n -> (image b, output pixel): element offset of X[b, 0, oy*s - p, ox*s - p] (may be negative) and the
+// input coordinates of the window's corner.
+struct Corner { int base, iy0, ix0; };
+__device__ __forceinline__ Corner cv_corner(int n, const ConvGeom& g) {
+    const int b = cv_div(n, g.mOHW);
+    const int pos = n - b * g.OH * g.OW;
+    const int oy = cv_div(pos, g.mOW);
+    const int ox = pos - oy * g.OW;
+    Corner c;
+    c.iy0 = oy * g.stride - g.pad;
+    c.ix0 = ox * g.stride - g.pad;
+    c.base = (b * g.Cin * g.H + c.iy0) * g.W + c.ix0;
+    return c;
+}
+
+__device__ __forceinline__ f32x4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned byte_off, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, (int)soff, 0));
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// forward / input gradient
+// --------------------------------------------------------------------------------------------------------------------
+// Staging: two register stages; step t commits tile t+1 (fetched during step t-1) to the other LDS buffer under the
+// first half of its MFMAs and fetches tile t+3 into the same registers under the second half, so every load has more
+// than a full step to land.  The pieces are placed BETWEEN the MFMA groups by hand (sched_barrier): VALU, LDS writes
+// and load issue then run in the shadow of the matrix pipe instead of after it.
+// FAST4 (stride 1, OW % 4 == 0): a thread's 4 positions are consecutive pixels of one row: ONE 16-byte load per piece
+// (4-byte aligned) whose out-of-row neighbours are zeroed at commit by the tap's column masks.  Otherwise 4 element
+// loads with the mask folded into the offset.
+// The X descriptor starts `shift` = pad*W + pad elements BEFORE the tensor so that every per-thread offset constant is
+// >= 0 (the step offset travels in the scalar offset, which the hardware does not range-check): nothing below X is ever
+// dereferenced — a lane whose window corner lies outside the image is masked to the out-of-range offset.
+template <int BM, bool FAST4>
+__global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restrict__ X, const _Float16* __restrict__ wh,
+                                                          const _Float16* __restrict__ wl,
+                                                          const float* __restrict__ w_scale, const float* __restrict__ x_amax,
+                                                          const float* __restrict__ bias, float* __restrict__ Y, int M,
+                                                          ConvGeom g) {
+    constexpr int MI = BM / 64;                        // 32-row blocks per wave = staging slots per half step
+    constexpr int GPS = 4 / MI;                        // gathered pieces per slot
+    constexpr int APLANE = BM * CV_AROW, GPLANE = CV_BK * CV_GROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][BM][AROW]
+    _Float16* const gt = at + 2 * 2 * APLANE;                      // [2 buf][hi|lo][32 k][GROW]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (g.Ntot + CV_BN - 1) / CV_BN;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (vb / ntn) * BM, n0 = (vb % ntn) * CV_BN;       // consecutive ids: the position tiles of one row tile
+    const int HW = g.H * g.W, ncb = g.Cp >> 5, nkb = g.KH * g.KW * ncb;
+    const int shift = g.pad * g.W + g.pad;
+
+    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(X - shift, ((size_t)g.xelems + shift) * 4);
+    const size_t wbytes = (size_t)M * g.Ktot * 2;
+    const __amdgpu_buffer_rsrc_t wh_rs = make_rsrc(wh, wbytes), wl_rs = make_rsrc(wl, wbytes);
+    const float sx = cv_scale_from_amax(x_amax);
+
+    // the thread's columns: 4 consecutive GEMM columns n .. n+3
+    constexpr int NC = FAST4 ? 1 : 4;
+    Corner cr[NC];
+    bool live[NC];
+#pragma unroll
+    for (int e = 0; e < NC; ++e) {
+        const int n = n0 + 4 * c + e;
+        cr[e] = cv_corner(min(n, g.Ntot - 1), g);
+        live[e] = n < g.Ntot;
+    }
+    // only windows at the very beginning / end of the tensor can see a 16-byte piece cross its ends (wave-uniform flag)
+    const int maxoff = ((g.Cin - 1) * g.H + g.KH - 1) * g.W + g.KW - 1;
+    const bool edge_tile = FAST4 && __builtin_amdgcn_ballot_w64(cr[0].base < 0 || cr[0].base + maxoff + 4 > g.xelems) != 0;
+    // piece u = channels u*8 + 2*wave + h of the k-block (lane half h), the thread's columns
+    int rowlane[4];
+    unsigned vconst[4][NC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        rowlane[u] = u * 8 + 2 * wave + h;
+#pragma unroll
+        for (int e = 0; e < NC; ++e) vconst[u][e] = (unsigned)(cr[e].base + shift + rowlane[u] * HW) * 4u;
+    }
+    unsigned voffa[MI];                                // weight tile: 16-byte chunk idx of the BM x 32 tile
+#pragma unroll
+    for (int u = 0; u < MI; ++u) voffa[u] = (m0 + ((u * 256 + tid) >> 2) < M) ? (unsigned)(u * 256 + tid) * 16u : kBufOob;
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    struct Stage {
+        u32x4 a[2][MI];
+        float gv[4][4];
+        bool mk[4];        // FAST4: column e of the piece lies inside the image row (same for the 4 pieces of a step)
+    };
+    Stage st[2];
+    // per-step scalars of a fetch (set by fetch_begin)
+    int f_cb = 0, f_ky = 0, f_kx = 0;
+    unsigned f_soff = 0, f_soffa = 0;
+    bool f_rowok[NC];
+    auto fetch_begin = [&](Stage& S, int tt) {
+        tt = min(tt, nkb - 1);                         // prefetches beyond the end re-read the last tile (never used)
+        const int tap = cv_div(tt, g.mNCB);
+        f_cb = tt - tap * ncb;
+        f_ky = cv_div(tap, g.mKW);
+        f_kx = tap - f_ky * g.KW;
+        f_soff = (unsigned)(f_cb * 32 * HW + f_ky * g.W + f_kx) * 4u;
+        f_soffa = (unsigned)(tt * M + m0) * 64u;
+#pragma unroll
+        for (int e = 0; e < NC; ++e) {
+            f_rowok[e] = live[e] && (unsigned)(cr[e].iy0 + f_ky) < (unsigned)g.H;
+            if (!FAST4) f_rowok[e] = f_rowok[e] && (unsigned)(cr[e].ix0 + f_kx) < (unsigned)g.W;
+        }
+        if (FAST4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S.mk[e] = (unsigned)(cr[0].ix0 + f_kx + e) < (unsigned)g.W;
+        }
+    };
+    auto fetch_a = [&](Stage& S, int u) {
+        if (COCOS_CONV_ABLATE & 2) { S.a[0][u] = S.a[1][u] = u32x4{f_soffa, 0u, 0u, 0u}; return; }
+        S.a[0][u] = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, (int)voffa[u], (int)f_soffa, 0);
+        S.a[1][u] = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, (int)voffa[u], (int)f_soffa, 0);
+    };
+    auto fetch_g = [&](Stage& S, int u) {
+        if (COCOS_CONV_ABLATE & 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S.gv[u][e] = (float)(f_soff + u + e) * 1e-9f;
+            return;
+        }
+        const bool chanok = rowlane[u] + f_cb * 32 < g.Cin;
+        if (FAST4) {
+            const bool ok = chanok && f_rowok[0];
+            bool done = false;
+            if (edge_tile) {
+                const int e0 = cr[0].base + (rowlane[u] + f_cb * 32) * HW + f_ky * g.W + f_kx;
+                if (ok && (e0 < 0 || e0 + 4 > g.xelems)) {      // a handful of lanes of the first / last tile
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        S.gv[u][e] = buf_load1s(x_rs, S.mk[e] ? vconst[u][0] + 4u * e : kBufOob, f_soff);
+                    done = true;
+                }
+            }
+            if (!done) {
+                const f32x4 w = buf_load4s(x_rs, ok ? vconst[u][0] : kBufOob, f_soff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S.gv[u][e] = w[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                S.gv[u][e] = buf_load1s(x_rs, (chanok && f_rowok[e]) ? vconst[u][e] : kBufOob, f_soff);
+        }
+    };
+    auto commit_a = [&](const Stage& S, int buf, int u) {
+        if (COCOS_CONV_ABLATE & 4) return;
+        _Float16* ab = at + buf * 2 * APLANE;
+        const int idx = u * 256 + tid, row = idx >> 2, kc = idx & 3;
+        *reinterpret_cast<u32x4*>(ab + row * CV_AROW + kc * 8) = S.a[0][u];
+        *reinterpret_cast<u32x4*>(ab + APLANE + row * CV_AROW + kc * 8) = S.a[1][u];
+    };
+    auto commit_g = [&](Stage& S, int buf, int u) {
+        if (COCOS_CONV_ABLATE & 4) return;
+        _Float16* gb = gt + buf * 2 * GPLANE;
+        if (FAST4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S.gv[u][e] = S.mk[e] ? S.gv[u][e] : 0.f;
+        }
+        u32x2 hi, lo;
+        cv_split4(S.gv[u], sx, hi, lo);
+        const int kk = u * 8 + 2 * wave + h, col = 4 * c;
+        *reinterpret_cast<u32x2*>(gb + kk * CV_GROW + col) = hi;
+        *reinterpret_cast<u32x2*>(gb + GPLANE + kk * CV_GROW + col) = lo;
+    };
+    auto fetch_all = [&](Stage& S, int tt) {
+        fetch_begin(S, tt);
+#pragma unroll
+        for (int u = 0; u < MI; ++u) fetch_a(S, u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fetch_g(S, u);
+    };
+    auto commit_all = [&](Stage& S, int buf) {
+#pragma unroll
+        for (int u = 0; u < MI; ++u) commit_a(S, buf, u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) commit_g(S, buf, u);
+    };
+
+    fetch_all(st[0], 0);
+    commit_all(st[0], 0);
+    fetch_all(st[0], 1);
+    fetch_all(st[1], 2);
+    __syncthreads();
+
+    // transpose-read addressing of the gathered image (see header): 16-lane group (lane >> 4) = (column half nb, k
+    // half kg); lane i of the group supplies row (i >> 2), columns 4 (i & 3) .. +3 of its 4 x 16 block
+    const int li = lane & 15, nb = (lane >> 4) & 1, kg = lane >> 5;
+    const int tr_off = (8 * kg + (li >> 2)) * CV_GROW + 16 * nb + 4 * (li & 3);
+
+    auto step = [&](int t, Stage& S) {
+        const int buf = t & 1;
+        const _Float16* ab = at + buf * 2 * APLANE + (wm * (BM / 2) + c) * CV_AROW + h * 8;
+        const _Float16* gb = gt + buf * 2 * GPLANE + wn * 64 + tr_off;
+#pragma unroll
+        for (int s = 0; s < ((COCOS_CONV_ABLATE & 8) ? 0 : CV_BK / 16); ++s) {
+            f16x8 bvh[2], bvl[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const _Float16* p = gb + s * 16 * CV_GROW + j * 32;
+                const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+                const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * CV_GROW));
+                const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE));
+                const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE + 4 * CV_GROW));
+                bvh[j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                bvl[j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            f16x8 avh[MI], avl[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                avh[i] = *reinterpret_cast<const f16x8*>(ab + i * 32 * CV_AROW + s * 16);
+                avl[i] = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * CV_AROW + s * 16);
+            }
+            if (s == 1) fetch_begin(S, t + 3);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[i], bvh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[i], bvl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[i], bvh[j], acc[i][j], 0, 0, 0);
+                }
+                // slot i of this half step: s == 0 commits tile t+1, s == 1 fetches tile t+3
+                __builtin_amdgcn_sched_barrier(0);
+                if (s == 0) {
+                    commit_a(S, buf ^ 1, i);
+#pragma unroll
+                    for (int q = 0; q < GPS; ++q) commit_g(S, buf ^ 1, i * GPS + q);
+                } else {
+                    fetch_a(S, i);
+#pragma unroll
+                    for (int q = 0; q < GPS; ++q) fetch_g(S, i * GPS + q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (COCOS_CONV_ABLATE & 8) {
+            commit_all(S, buf ^ 1);
+            fetch_all(S, t + 3);
+        }
+        __syncthreads();
+    };
+    int t = 0;
+    for (; t + 1 < nkb; t += 2) {
+        step(t, st[0]);
+        step(t + 1, st[1]);
+    }
+    if (t < nkb) step(t, st[0]);
+
+    const float oscale = 1.0f / ((w_scale ? *w_scale : 1.0f) * sx);
+    const int ohw = g.OH * g.OW;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + c;
+        if (n >= g.Ntot) continue;
+        const int b = cv_div(n, g.mOHW);
+        const int pos = n - b * ohw;
+        float* yb = Y + ((size_t)b * M) * ohw + pos;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + acc_row_base(r) + 4 * h;
+                if (m < M) yb[(size_t)m * ohw] = acc[i][j][r] * oscale + (bias ? bias[m] : 0.f);
+            }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// weight gradient: partial[slice][co][k] over the slice's positions, k = tap * Cp + ci
+// --------------------------------------------------------------------------------------------------------------------
+template <int BM, bool FAST4>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                            const float* __restrict__ x_amax,
+                                                            const float* __restrict__ g_amax, float* __restrict__ part,
+                                                            int M, ConvGeom g, int nchunk /* positions per slice, % 32 == 0 */,
+                                                            int ybytes) {
+    constexpr int MI = BM / 64;
+    constexpr int APT = BM / 32;                       // dY pieces per thread (2 per slot)
+    constexpr int GPS = 4 / MI;
+    constexpr int APLANE = BM * CV_AROW, BPLANE = CV_BN * CV_AROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // dY image [2 buf][hi|lo][BM co][32 n + pad]
+    _Float16* const bt = at + 2 * 2 * APLANE;                      // gathered image [2 buf][hi|lo][128 k][32 n + pad]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntk = (g.Ktot + CV_BN - 1) / CV_BN, ntm = (M + BM - 1) / BM;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int slice = vb / (ntk * ntm), rem = vb % (ntk * ntm);
+    const int m0 = (rem / ntk) * BM, k0 = (rem % ntk) * CV_BN;
+    const int nbeg = slice * nchunk, nend = min(g.Ntot, nbeg + nchunk);
+    const int shift = g.pad * g.W + g.pad;
+
+    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(X - shift, ((size_t)g.xelems + shift) * 4);
+    const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(dY, (size_t)ybytes);
+    const float sx = cv_scale_from_amax(x_amax), sg = cv_scale_from_amax(g_amax);
+    const int ohw = g.OH * g.OW;
+    const int maxoff = ((g.Cin - 1) * g.H + g.KH - 1) * g.W + g.KW - 1;
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // A (dY): BM rows (co) x 32 positions = BM*8 float4: piece u -> row u*32 + tid/8, 4 positions (tid & 7)*4
+    // B (gather): 128 rows (k) x 32 positions = 1024 float4, 4 per thread: row u*32 + tid/8, the same 4 positions
+    const int q4 = 4 * (tid & 7);
+    // the thread's four k rows: tap and channel fixed for the whole kernel
+    int r_ky[4], r_kx[4], r_off[4];
+    bool r_ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * 32 + (tid >> 3);
+        const int tap = cv_div(k, g.mCp), ci = k - tap * g.Cp;
+        r_ky[u] = cv_div(tap, g.mKW);
+        r_kx[u] = tap - r_ky[u] * g.KW;
+        r_ok[u] = k < g.Ktot && ci < g.Cin;
+        r_off[u] = (ci * g.H + r_ky[u]) * g.W + r_kx[u] + shift;
+    }
+    unsigned y_row[APT];                                // co * OH*OW * 4 or out of range
+#pragma unroll
+    for (int u = 0; u < APT; ++u) {
+        const int co = m0 + u * 32 + (tid >> 3);
+        y_row[u] = co < M ? (unsigned)(co * ohw) * 4u : kBufOob;
+    }
+
+    struct Stage { float a[APT][4]; float gv[4][4]; int xs[4]; };
+    Stage st[2];
+    constexpr int NC = FAST4 ? 1 : 4;
+    Corner f_cr[NC];
+    bool f_live[NC];
+    unsigned f_y[NC];                                   // byte offset of dY[b, 0, pos]
+    bool f_edge = false;     // wave-uniform: some window of this step may see a 16-byte piece cross the tensor's ends
+    auto fetch_begin = [&](int np0) {
+#pragma unroll
+        for (int e = 0; e < NC; ++e) {
+            const int n = min(np0 + q4 + e, g.Ntot - 1);
+            f_cr[e] = cv_corner(n, g);
+            f_live[e] = np0 + q4 + e < nend;
+            const int b = cv_div(n, g.mOHW);
+            f_y[e] = (unsigned)(b * M * ohw + (n - b * ohw)) * 4u;
+        }
+        if (FAST4) f_edge = __builtin_amdgcn_ballot_w64(f_cr[0].base < 0 || f_cr[0].base + maxoff + 4 > g.xelems) != 0;
+    };
+    auto fetch_g = [&](Stage& S, int u) {
+        if (FAST4) {
+            const bool ok = r_ok[u] && f_live[0] && (unsigned)(f_cr[0].iy0 + r_ky[u]) < (unsigned)g.H;
+            const int e0s = f_cr[0].base + r_off[u];                    // element offset in the shifted descriptor
+            S.xs[u] = f_cr[0].ix0 + r_kx[u];
+            bool done = false;
+            if (f_edge) {
+                if (ok && (e0s - shift < 0 || e0s - shift + 4 > g.xelems)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        S.gv[u][e] = buf_load1(x_rs, (unsigned)(S.xs[u] + e) < (unsigned)g.W ? (unsigned)(e0s + e) * 4u : kBufOob);
+                    done = true;
+                }
+            }
+            if (!done) {
+                const f32x4 w = buf_load4(x_rs, ok ? (unsigned)e0s * 4u : kBufOob);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S.gv[u][e] = w[e];
+            }
+        } else {
+            S.xs[u] = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = r_ok[u] && f_live[e] && (unsigned)(f_cr[e].iy0 + r_ky[u]) < (unsigned)g.H &&
+                                (unsigned)(f_cr[e].ix0 + r_kx[u]) < (unsigned)g.W;
+                S.gv[u][e] = buf_load1(x_rs, ok ? (unsigned)(f_cr[e].base + r_off[u]) * 4u : kBufOob);
+            }
+        }
+    };
+    auto fetch_a = [&](Stage& S, int u) {
+        if (FAST4) {      // OH*OW % 4 == 0: the four positions are 16 contiguous, aligned bytes of one image
+            const f32x4 w = buf_load4(y_rs, (f_live[0] && y_row[u] != kBufOob) ? f_y[0] + y_row[u] : kBufOob);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S.a[u][e] = w[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                S.a[u][e] = buf_load1(y_rs, (f_live[e] && y_row[u] != kBufOob) ? f_y[e] + y_row[u] : kBufOob);
+        }
+    };
+    auto commit_a = [&](Stage& S, int buf, int u) {
+        _Float16* ab = at + buf * 2 * APLANE;
+        u32x2 hi, lo;
+        cv_split4(S.a[u], sg, hi, lo);
+        const int row = u * 32 + (tid >> 3);
+        *reinterpret_cast<u32x2*>(ab + row * CV_AROW + q4) = hi;
+        *reinterpret_cast<u32x2*>(ab + APLANE + row * CV_AROW + q4) = lo;
+    };
+    auto commit_g = [&](Stage& S, int buf, int u) {
+        _Float16* bb = bt + buf * 2 * BPLANE;
+        if (FAST4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S.gv[u][e] = (unsigned)(S.xs[u] + e) < (unsigned)g.W ? S.gv[u][e] : 0.f;
+        }
+        u32x2 hi, lo;
+        cv_split4(S.gv[u], sx, hi, lo);
+        const int row = u * 32 + (tid >> 3);
+        *reinterpret_cast<u32x2*>(bb + row * CV_AROW + q4) = hi;
+        *reinterpret_cast<u32x2*>(bb + BPLANE + row * CV_AROW + q4) = lo;
+    };
+    auto fetch_all = [&](Stage& S, int np0) {
+        fetch_begin(np0);
+#pragma unroll
+        for (int u = 0; u < APT; ++u) fetch_a(S, u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fetch_g(S, u);
+    };
+    auto commit_all = [&](Stage& S, int buf) {
+#pragma unroll
+        for (int u = 0; u < APT; ++u) commit_a(S, buf, u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) commit_g(S, buf, u);
+    };
+
+    const int nsteps = (max(nend - nbeg, 0) + CV_BK - 1) / CV_BK;
+    // positions at or beyond nend are masked (f_live), so prefetches past the last step are harmless
+    fetch_all(st[0], nbeg);
+    commit_all(st[0], 0);
+    fetch_all(st[0], nbeg + CV_BK);
+    fetch_all(st[1], nbeg + 2 * CV_BK);
+    __syncthreads();
+
+    auto step = [&](int t, Stage& S) {
+        const int buf = t & 1;
+        const _Float16* ab = at + buf * 2 * APLANE + (wm * (BM / 2) + c) * CV_AROW + h * 8;
+        const _Float16* bb = bt + buf * 2 * BPLANE + (wn * 64 + c) * CV_AROW + h * 8;
+#pragma unroll
+        for (int s = 0; s < CV_BK / 16; ++s) {
+            f16x8 bvh[2], bvl[2], avh[MI], avl[MI];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bvh[j] = *reinterpret_cast<const f16x8*>(bb + j * 32 * CV_AROW + s * 16);
+                bvl[j] = *reinterpret_cast<const f16x8*>(bb + BPLANE + j * 32 * CV_AROW + s * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                avh[i] = *reinterpret_cast<const f16x8*>(ab + i * 32 * CV_AROW + s * 16);
+                avl[i] = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * CV_AROW + s * 16);
+            }
+            if (s == 1) fetch_begin(nbeg + (t + 3) * CV_BK);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[i], bvh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[i], bvl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[i], bvh[j], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s == 0) {
+                    commit_a(S, buf ^ 1, 2 * i);
+                    commit_a(S, buf ^ 1, 2 * i + 1);
+#pragma unroll
+                    for (int q = 0; q < GPS; ++q) commit_g(S, buf ^ 1, i * GPS + q);
+                } else {
+                    fetch_a(S, 2 * i);
+                    fetch_a(S, 2 * i + 1);
+#pragma unroll
+                    for (int q = 0; q < GPS; ++q) fetch_g(S, i * GPS + q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    };
+    int t = 0;
+    for (; t + 1 < nsteps; t += 2) {
+        step(t, st[0]);
+        step(t + 1, st[1]);
+    }
+    if (t < nsteps) step(t, st[0]);
+
+    const float oscale = 1.0f / (sx * sg);
+    float* pb = part + (size_t)slice * M * g.Ktot;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wn * 64 + j * 32 + c;
+        if (k >= g.Ktot) continue;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + acc_row_base(r) + 4 * h;
+                if (m < M) pb[(size_t)m * g.Ktot + k] = acc[i][j][r] * oscale;
+            }
+    }
+}
+
+static Magic cv_magic(int d) {
+    unsigned sh = 0;
+    while ((2u << sh) <= (unsigned)d) ++sh;                 // floor(log2 d)
+    if ((1u << sh) == (unsigned)d) return Magic{0u, sh, 1u};
+    const unsigned long long two = 1ull << (32 + sh);
+    return Magic{(unsigned)((two + (unsigned)d - 1) / (unsigned)d), sh, 0u};
+}
+
+static int cv_geom(ConvGeom& g, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, const char* who) {
+    COCOS_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0,
+                  COCOS_ERR_INVALID, "%s: bad geometry B=%d Cin=%d Cout=%d H=%d W=%d k=%dx%d stride=%d pad=%d", who, B, Cin,
+                  Cout, H, W, KH, KW, stride, pad);
+    COCOS_REQUIRE(H + 2 * pad >= KH && W + 2 * pad >= KW, COCOS_ERR_INVALID, "%s: kernel larger than the padded input", who);
+    g.Cin = Cin; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    g.OH = (H + 2 * pad - KH) / stride + 1;
+    g.OW = (W + 2 * pad - KW) / stride + 1;
+    g.Cp = (Cin + 31) / 32 * 32;
+    const long long ktot = (long long)KH * KW * g.Cp, ntot = (long long)B * g.OH * g.OW;
+    // 32-bit byte offsets everywhere (buffer descriptors): both tensors and the weight planes below 2 GiB
+    COCOS_REQUIRE(ntot + 256 < (1ll << 30) && ktot + 256 < (1ll << 30), COCOS_ERR_UNSUPPORTED,
+                  "%s: problem too large for the 32-bit index arithmetic (positions %lld, K %lld)", who, ntot, ktot);
+    COCOS_REQUIRE(((long long)B * Cin * H * W + (long long)(g.Cp + 32) * H * W + (long long)pad * (W + 1)) * 4 < 0x7fffffffll &&
+                      (long long)B * Cout * g.OH * g.OW * 4 < 0x7fffffffll && (long long)Cout * ktot * 4 < 0x7fffffffll,
+                  COCOS_ERR_UNSUPPORTED, "%s: a tensor exceeds 2 GiB", who);
+    g.Ktot = (int)ktot;
+    g.Ntot = (int)ntot;
+    g.xelems = B * Cin * H * W;
+    g.mNCB = cv_magic(g.Cp / 32); g.mKW = cv_magic(KW); g.mOHW = cv_magic(g.OH * g.OW); g.mOW = cv_magic(g.OW);
+    g.mCp = cv_magic(g.Cp);
+    return COCOS_OK;
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_conv2d_out_size(int in, int k, int stride, int pad) {
+    return (stride >= 1 && in + 2 * pad >= k) ? (in + 2 * pad - k) / stride + 1 : 0;
+}
+extern "C" int cocos_conv2d_kdim(int Cin, int KH, int KW) { return KH * KW * ((Cin + 31) / 32 * 32); }
+
+extern "C" int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const void* w_lo, const float* w_scale_dev,
+                                      const float* x_amax_dev, const float* bias, float* y, int B, int Cin, int H, int W,
+                                      int Cout, int KH, int KW, int stride, int pad, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && w_hi && w_lo && y, COCOS_ERR_INVALID, "conv2d_fwd_f16x3: null pointer");
+    ConvGeom g;
+    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, "conv2d_fwd_f16x3")) return rc;
+    COCOS_REQUIRE(aligned16(w_hi) && aligned16(w_lo), COCOS_ERR_INVALID,
+                  "conv2d_fwd_f16x3: weight planes must be 16-byte aligned");
+    const bool fast4 = stride == 1 && g.OW % 4 == 0;
+    const int bm = Cout > 128 ? 256 : 128;
+    const long long blocks = (long long)((Cout + bm - 1) / bm) * ((g.Ntot + CV_BN - 1) / CV_BN);
+    COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "conv2d_fwd_f16x3: grid too large");
+    hipStream_t s = as_stream(stream);
+#define COCOS_GO(BMv, F4)                                                                                          \
+    do {                                                                                                           \
+        auto kern = conv_fwd_kernel<BMv, F4>;                                                                      \
+        const size_t smem = (size_t)2 * 2 * (BMv * CV_AROW + CV_BK * CV_GROW) * sizeof(_Float16);                  \
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));              \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, x, static_cast<const _Float16*>(w_hi), \
+                           static_cast<const _Float16*>(w_lo), w_scale_dev, x_amax_dev, bias, y, Cout, g);         \
+    } while (0)
+    if (bm == 256) { if (fast4) COCOS_GO(256, true); else COCOS_GO(256, false); }
+    else           { if (fast4) COCOS_GO(128, true); else COCOS_GO(128, false); }
+#undef COCOS_GO
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_conv2d_wgrad_slices(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
+    if (B < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || pad < 0 || H + 2 * pad < KH || W + 2 * pad < KW) return 0;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+    const long long ntot = (long long)B * OH * OW;
+    const int bm = Cout > 128 ? 256 : 128;
+    const long long tiles = (long long)((Cout + bm - 1) / bm) * ((cocos_conv2d_kdim(Cin, KH, KW) + 127) / 128);
+    long long s = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU over the launch
+    const long long maxs = (ntot + 255) / 256;            // at least 8 k-blocks of 32 positions per slice
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const float* x_amax_dev, const float* g_amax_dev,
+                                        float* partials, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
+                                        int pad, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && dy && partials, COCOS_ERR_INVALID, "conv2d_wgrad_f16x3: null pointer");
+    ConvGeom g;
+    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, "conv2d_wgrad_f16x3")) return rc;
+    const int nslices = cocos_conv2d_wgrad_slices(B, Cin, H, W, Cout, KH, KW, stride, pad);
+    const int nchunk = ((g.Ntot + nslices - 1) / nslices + CV_BK - 1) / CV_BK * CV_BK;
+    const bool fast4 = stride == 1 && g.OW % 4 == 0 && aligned16(dy);
+    const int bm = Cout > 128 ? 256 : 128;
+    const long long blocks = (long long)nslices * ((Cout + bm - 1) / bm) * ((g.Ktot + CV_BN - 1) / CV_BN);
+    COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "conv2d_wgrad_f16x3: grid too large");
+    const int ybytes = (int)((long long)B * Cout * g.OH * g.OW * 4);
+    hipStream_t s = as_stream(stream);
+#define COCOS_GO(BMv, F4)                                                                                          \
+    do {                                                                                                           \
+        auto kern = conv_wgrad_kernel<BMv, F4>;                                                                    \
+        const size_t smem = (size_t)2 * 2 * (BMv + CV_BN) * CV_AROW * sizeof(_Float16);                            \
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));              \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, x, dy, x_amax_dev, g_amax_dev, partials, \
+                           Cout, g, nchunk, ybytes);                                                               \
+    } while (0)
+    if (bm == 256) { if (fast4) COCOS_GO(256, true); else COCOS_GO(256, false); }
+    else           { if (fast4) COCOS_GO(128, true); else COCOS_GO(128, false); }
+#undef COCOS_GO
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}

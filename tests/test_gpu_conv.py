@@ -1,0 +1,84 @@
+"""K16 (conv_f16x3.hip) against torch's fp64 conv2d: forward, input gradient, weight gradient, bias gradient.
+Shapes: the ResidualBlock convolution (correspondence.py:13-36: 3x3 after ReflectionPad2d(1)), the adaptor layers
+(correspondence.py:150-173: k3 s1 p1, k4 s2 p1), the PatchGAN layers (discriminator.py:92-115: k4 s2 p2, odd outputs),
+and ragged sizes that exercise every mask.  Tolerance 1e-5 of the output range (the split carries ~22 bits)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad
+    (2, 407, 66, 66, 407, 3, 1, 0),      # ResidualBlock, B reduced
+    (1, 64, 64, 64, 128, 3, 1, 1),       # zero padding, fast gather
+    (2, 3, 33, 37, 16, 4, 2, 2),         # PatchGAN first layer shape class: odd outputs, element gather
+    (1, 16, 18, 22, 40, 4, 2, 1),        # adaptor down-sampling
+    (3, 5, 9, 7, 7, 3, 1, 1),            # everything ragged
+    (1, 8, 12, 12, 130, 1, 1, 0),        # 1x1, Cout > 128 tile class
+    (2, 20, 10, 16, 24, 3, 1, 2),        # pad > (k-1)/2: output larger than input
+    (1, 4, 8, 8, 4, 5, 1, 2),            # 5x5
+    (1, 2, 6, 6, 3, 3, 2, 0),            # stride 2, tiny
+]
+
+
+def _ref(x, w, b, stride, pad, go):
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    bd = None if b is None else b.double().requires_grad_(True)
+    y = F.conv2d(xd, wd, bd, stride=stride, padding=pad)
+    y.backward(go.double())
+    return y.detach(), xd.grad, wd.grad, None if b is None else bd.grad
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_conv2d_matches_fp64(case, with_bias):
+    from cocosnet_amd import ops
+    B, Cin, H, W, Cout, k, stride, pad = case
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(B, Cin, H, W, device="cuda", generator=g).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, device="cuda", generator=g).requires_grad_(True) if with_bias else None
+    y = ops.conv2d(x, w, b, stride, pad)
+    go = torch.randn(y.shape, device="cuda", generator=g)
+    y.backward(go)
+    yr, dxr, dwr, dbr = _ref(x.detach(), w.detach(), None if b is None else b.detach(), stride, pad, go)
+    assert y.shape == yr.shape
+
+    def close(a, r, what):
+        err = (a.double() - r).abs().max().item()
+        tol = 1e-5 * max(r.abs().max().item(), 1e-30)
+        assert err <= tol, f"{what}: max err {err:.3e} > {tol:.3e}"
+
+    close(y, yr, "y")
+    close(x.grad, dxr, "dx")
+    close(w.grad, dwr, "dw")
+    if with_bias:
+        close(b.grad, dbr, "db")
+
+
+def test_conv2d_operand_ranges():
+    """Operands far from O(1): the device-side power-of-two scales keep the f16 planes in range."""
+    from cocosnet_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for sx, sw in ((1e4, 1e-5), (1e-6, 1e3)):
+        x = (torch.randn(2, 12, 16, 16, device="cuda", generator=g) * sx).requires_grad_(True)
+        w = (torch.randn(9, 12, 3, 3, device="cuda", generator=g) * sw).requires_grad_(True)
+        y = ops.conv2d(x, w, None, 1, 1)
+        go = torch.randn(y.shape, device="cuda", generator=g)
+        y.backward(go)
+        yr, dxr, dwr, _ = _ref(x.detach(), w.detach(), None, 1, 1, go)
+        for a, r in ((y, yr), (x.grad, dxr), (w.grad, dwr)):
+            assert (a.double() - r).abs().max().item() <= 1e-5 * r.abs().max().item()
+
+
+def test_conv2d_rejects_bad_arguments():
+    from cocosnet_amd import ops
+    x = torch.randn(1, 4, 8, 8, device="cuda")
+    with pytest.raises(ValueError):
+        ops.conv2d(x, torch.randn(4, 5, 3, 3, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.conv2d(torch.randn(1, 4, 2, 2, device="cuda"), torch.randn(4, 4, 3, 3, device="cuda"))
+    with pytest.raises(Exception, match="no CPU fallback"):
+        ops.conv2d(x.cpu(), torch.randn(4, 4, 3, 3))
