@@ -58,9 +58,11 @@ struct ConvGeom {
     int Cin, H, W, OH, OW, KH, KW, stride, pad;
     int Cp;                  // Cin rounded up to 32
     int Ktot;                // KH * KW * Cp
-    int Ntot;                // B * OH * OW
+    int OWv;                 // forward kernel, stride 1: OW rounded up to 4 (virtual columns, computed and dropped) so
+                             // that 4 consecutive GEMM columns are always 4 consecutive pixels of ONE row; else OW
+    int Ntot;                // B * OH * OWv  (GEMM columns)
     int xelems;              // B * Cin * H * W
-    Magic mNCB, mKW, mOHW, mOW, mCp;     // / (Cp/32), / KW, / (OH*OW), / OW, / Cp
+    Magic mNCB, mKW, mOHW, mOW, mCp;     // / (Cp/32), / KW, / (OH*OWv), / OWv, / Cp
 };
 
 __device__ __forceinline__ float cv_scale_from_amax(const float* amax) {
@@ -86,9 +88,9 @@ __device__ __forceinline__ void cv_split4(const float (&x)[4], float s, u32x2& h
 struct Corner { int base, iy0, ix0; };
 __device__ __forceinline__ Corner cv_corner(int n, const ConvGeom& g) {
     const int b = cv_div(n, g.mOHW);
-    const int pos = n - b * g.OH * g.OW;
+    const int pos = n - b * g.OH * g.OWv;
     const int oy = cv_div(pos, g.mOW);
-    const int ox = pos - oy * g.OW;
+    const int ox = pos - oy * g.OWv;
     Corner c;
     c.iy0 = oy * g.stride - g.pad;
     c.ix0 = ox * g.stride - g.pad;
@@ -107,7 +109,7 @@ __device__ __forceinline__ f32x4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned b
 // first half of its MFMAs and fetches tile t+3 into the same registers under the second half, so every load has more
 // than a full step to land.  The pieces are placed BETWEEN the MFMA groups by hand (sched_barrier): VALU, LDS writes
 // and load issue then run in the shadow of the matrix pipe instead of after it.
-// FAST4 (stride 1, OW % 4 == 0): a thread's 4 positions are consecutive pixels of one row: ONE 16-byte load per piece
+// FAST4 (stride 1; rows padded to OWv): a thread's 4 positions are consecutive pixels of one row: ONE 16-byte load per piece
 // (4-byte aligned) whose out-of-row neighbours are zeroed at commit by the tap's column masks.  Otherwise 4 element
 // loads with the mask folded into the offset.
 // The X descriptor starts `shift` = pad*W + pad elements BEFORE the tensor so that every per-thread offset constant is
@@ -349,8 +351,11 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
         const int n = n0 + wn * 64 + j * 32 + c;
         if (n >= g.Ntot) continue;
         const int b = cv_div(n, g.mOHW);
-        const int pos = n - b * ohw;
-        float* yb = Y + ((size_t)b * M) * ohw + pos;
+        const int pos = n - b * g.OH * g.OWv;
+        const int oy = cv_div(pos, g.mOW);
+        const int ox = pos - oy * g.OWv;
+        if (ox >= g.OW) continue;                      // virtual column
+        float* yb = Y + ((size_t)b * M) * ohw + oy * g.OW + ox;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -599,7 +604,8 @@ static Magic cv_magic(int d) {
     return Magic{(unsigned)((two + (unsigned)d - 1) / (unsigned)d), sh, 0u};
 }
 
-static int cv_geom(ConvGeom& g, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, const char* who) {
+static int cv_geom(ConvGeom& g, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, bool virt,
+                   const char* who) {
     COCOS_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0,
                   COCOS_ERR_INVALID, "%s: bad geometry B=%d Cin=%d Cout=%d H=%d W=%d k=%dx%d stride=%d pad=%d", who, B, Cin,
                   Cout, H, W, KH, KW, stride, pad);
@@ -608,7 +614,8 @@ static int cv_geom(ConvGeom& g, int B, int Cin, int H, int W, int Cout, int KH, 
     g.OH = (H + 2 * pad - KH) / stride + 1;
     g.OW = (W + 2 * pad - KW) / stride + 1;
     g.Cp = (Cin + 31) / 32 * 32;
-    const long long ktot = (long long)KH * KW * g.Cp, ntot = (long long)B * g.OH * g.OW;
+    g.OWv = virt ? (g.OW + 3) / 4 * 4 : g.OW;
+    const long long ktot = (long long)KH * KW * g.Cp, ntot = (long long)B * g.OH * g.OWv;
     // 32-bit byte offsets everywhere (buffer descriptors): both tensors and the weight planes below 2 GiB
     COCOS_REQUIRE(ntot + 256 < (1ll << 30) && ktot + 256 < (1ll << 30), COCOS_ERR_UNSUPPORTED,
                   "%s: problem too large for the 32-bit index arithmetic (positions %lld, K %lld)", who, ntot, ktot);
@@ -618,7 +625,7 @@ static int cv_geom(ConvGeom& g, int B, int Cin, int H, int W, int Cout, int KH, 
     g.Ktot = (int)ktot;
     g.Ntot = (int)ntot;
     g.xelems = B * Cin * H * W;
-    g.mNCB = cv_magic(g.Cp / 32); g.mKW = cv_magic(KW); g.mOHW = cv_magic(g.OH * g.OW); g.mOW = cv_magic(g.OW);
+    g.mNCB = cv_magic(g.Cp / 32); g.mKW = cv_magic(KW); g.mOHW = cv_magic(g.OH * g.OWv); g.mOW = cv_magic(g.OWv);
     g.mCp = cv_magic(g.Cp);
     return COCOS_OK;
 }
@@ -636,10 +643,10 @@ extern "C" int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const vo
     using namespace cocos;
     COCOS_REQUIRE(x && w_hi && w_lo && y, COCOS_ERR_INVALID, "conv2d_fwd_f16x3: null pointer");
     ConvGeom g;
-    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, "conv2d_fwd_f16x3")) return rc;
+    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, stride == 1, "conv2d_fwd_f16x3")) return rc;
     COCOS_REQUIRE(aligned16(w_hi) && aligned16(w_lo), COCOS_ERR_INVALID,
                   "conv2d_fwd_f16x3: weight planes must be 16-byte aligned");
-    const bool fast4 = stride == 1 && g.OW % 4 == 0;
+    const bool fast4 = stride == 1;
     const int bm = Cout > 128 ? 256 : 128;
     const long long blocks = (long long)((Cout + bm - 1) / bm) * ((g.Ntot + CV_BN - 1) / CV_BN);
     COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "conv2d_fwd_f16x3: grid too large");
@@ -679,7 +686,7 @@ extern "C" int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const f
     using namespace cocos;
     COCOS_REQUIRE(x && dy && partials, COCOS_ERR_INVALID, "conv2d_wgrad_f16x3: null pointer");
     ConvGeom g;
-    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, "conv2d_wgrad_f16x3")) return rc;
+    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, false, "conv2d_wgrad_f16x3")) return rc;
     const int nslices = cocos_conv2d_wgrad_slices(B, Cin, H, W, Cout, KH, KW, stride, pad);
     const int nchunk = ((g.Ntot + nslices - 1) / nslices + CV_BK - 1) / CV_BK * CV_BK;
     const bool fast4 = stride == 1 && g.OW % 4 == 0 && aligned16(dy);

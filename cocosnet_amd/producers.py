@@ -1,23 +1,46 @@
-"""Feature producers that feed the correspondence hot path — plain PyTorch (stock MIOpen convs).
+"""Feature producers that feed the correspondence hot path.
 
 These are the layers immediately BEFORE the path: the two domain adaptors
 (`AdaptiveFeatureGenerator`, reference models/networks/generator.py:91-160, built from
 `SPADEResnetBlock` architecture.py:19-95 and `SPADE` normalization.py:83-151) and the four
 `ResidualBlock`s (correspondence.py:13-36).  They are re-implemented here only so that the drop-in
 `NoVGGCorrespondence` is a standalone module whose `state_dict()` keys and shapes equal the
-reference's (`*_net_Corr.pth` checkpoints load unchanged); none of this is on the HIP path yet.
+reference's (`*_net_Corr.pth` checkpoints load unchanged).  On a GPU in fp32 their convolutions run on K16
+(conv_f16x3.hip: split-precision implicit GEMM) / K0 (1x1), the InstanceNorm+PReLU and PONO-SPADE arithmetic on K13 / K11.
 
 Supported flag space = what the README commands use: spectral-norm convs (not --eqlr_sn), no apex,
 PONO or instance/batch/sync-batch parameter-free norms.  Unsupported flags raise immediately.
 """
 from __future__ import annotations
 
+import os
 import re
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
+
+
+CONV_BACKEND = os.environ.get("COCOS_CONV", "f16x3")     # "torch": the framework's convolution (A/B measurements)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d whose fp32 GPU forward/backward run on the HIP kernels: K16 (ops.conv2d) for kxk, K0 (ops.proj1x1) for
+    1x1.  Same parameters, same state_dict keys, works under torch.nn.utils.spectral_norm (which only rewrites
+    `.weight`).  Anything the kernels do not cover (dilation, groups, non-zero padding modes, rectangular
+    stride/padding, other dtypes, CPU) takes the framework path."""
+
+    def _conv_forward(self, input, weight, bias):
+        s, p, k = self.stride, self.padding, self.kernel_size
+        if (CONV_BACKEND == "f16x3" and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32
+                and input.dim() == 4 and self.groups == 1 and self.dilation == (1, 1) and self.padding_mode == "zeros"
+                and not isinstance(p, str) and s[0] == s[1] and p[0] == p[1]):
+            from . import ops
+            if k == (1, 1) and s[0] == 1 and p[0] == 0:
+                return ops.proj1x1(input, weight, bias)
+            return ops.conv2d(input, weight, bias, s[0], p[0])
+        return super()._conv_forward(input, weight, bias)
 
 
 def positional_norm(x, eps=1e-5):
@@ -55,10 +78,10 @@ class SPADE(nn.Module):
             self.param_free_norm = _param_free_norm(m.group(1), norm_nc)
         hidden = 128
         self.mlp_shared = nn.Sequential(nn.ReflectionPad2d(ks // 2),
-                                        nn.Conv2d(label_nc, hidden, ks), nn.ReLU())
+                                        Conv2d(label_nc, hidden, ks), nn.ReLU())
         self.pad = nn.ReflectionPad2d(ks // 2)
-        self.mlp_gamma = nn.Conv2d(hidden, norm_nc, ks)
-        self.mlp_beta = nn.Conv2d(hidden, norm_nc, ks)
+        self.mlp_gamma = Conv2d(hidden, norm_nc, ks)
+        self.mlp_beta = Conv2d(hidden, norm_nc, ks)
 
     def forward(self, x, segmap, similarity_map=None, slope: float = 1.0):
         """`slope` != 1 folds the LeakyReLU that SPADEResnetBlock applies right after (architecture.py:88-95).
@@ -88,10 +111,10 @@ class Attention(nn.Module):
         super().__init__()
         self.ch = ch
         wrap = spectral_norm if use_sn else (lambda m: m)
-        self.theta = wrap(nn.Conv2d(ch, ch // 8, 1, bias=False))
-        self.phi = wrap(nn.Conv2d(ch, ch // 8, 1, bias=False))
-        self.g = wrap(nn.Conv2d(ch, ch // 2, 1, bias=False))
-        self.o = wrap(nn.Conv2d(ch // 2, ch, 1, bias=False))
+        self.theta = wrap(Conv2d(ch, ch // 8, 1, bias=False))
+        self.phi = wrap(Conv2d(ch, ch // 8, 1, bias=False))
+        self.g = wrap(Conv2d(ch, ch // 2, 1, bias=False))
+        self.o = wrap(Conv2d(ch // 2, ch, 1, bias=False))
         self.gamma = nn.Parameter(torch.tensor(0.0), requires_grad=True)
 
     def forward(self, x, y=None):
@@ -126,10 +149,10 @@ class SPADEResnetBlock(nn.Module):
         fmid = min(fin, fout)
         self.use_se = use_se
         self.pad = nn.ReflectionPad2d(dilation)
-        self.conv_0 = nn.Conv2d(fin, fmid, 3, padding=0, dilation=dilation)
-        self.conv_1 = nn.Conv2d(fmid, fout, 3, padding=0, dilation=dilation)
+        self.conv_0 = Conv2d(fin, fmid, 3, padding=0, dilation=dilation)
+        self.conv_1 = Conv2d(fmid, fout, 3, padding=0, dilation=dilation)
         if self.learned_shortcut:
-            self.conv_s = nn.Conv2d(fin, fout, 1, bias=False)
+            self.conv_s = Conv2d(fin, fout, 1, bias=False)
         if "spectral" in opt.norm_G:
             self.conv_0 = spectral_norm(self.conv_0)
             self.conv_1 = spectral_norm(self.conv_1)
@@ -195,14 +218,14 @@ class AdaptiveFeatureGenerator(nn.Module):
         nf = opt.ngf
         wrap = nonspade_norm_layer(opt, opt.norm_E)
         ak = opt.adaptor_kernel
-        self.layer1 = wrap(nn.Conv2d(opt.spade_ic, nf, 3, stride=1, padding=1))
-        self.layer2 = wrap(nn.Conv2d(nf, nf * 2, ak, stride=2, padding=1))
-        self.layer3 = wrap(nn.Conv2d(nf * 2, nf * 4, 3, stride=1, padding=1))
+        self.layer1 = wrap(Conv2d(opt.spade_ic, nf, 3, stride=1, padding=1))
+        self.layer2 = wrap(Conv2d(nf, nf * 2, ak, stride=2, padding=1))
+        self.layer3 = wrap(Conv2d(nf * 2, nf * 4, 3, stride=1, padding=1))
         if opt.warp_stride == 2:
-            self.layer4 = wrap(nn.Conv2d(nf * 4, nf * 8, 3, stride=1, padding=1))
+            self.layer4 = wrap(Conv2d(nf * 4, nf * 8, 3, stride=1, padding=1))
         else:
-            self.layer4 = wrap(nn.Conv2d(nf * 4, nf * 8, ak, stride=2, padding=1))
-        self.layer5 = wrap(nn.Conv2d(nf * 8, nf * 8, 3, stride=1, padding=1))
+            self.layer4 = wrap(Conv2d(nf * 4, nf * 8, ak, stride=2, padding=1))
+        self.layer5 = wrap(Conv2d(nf * 8, nf * 8, 3, stride=1, padding=1))
         self.actvn = nn.LeakyReLU(0.2, False)
         self.head_0 = SPADEResnetBlock(8 * nf, 8 * nf, opt, use_se=opt.adaptor_se)
         if opt.adaptor_nonlocal:
@@ -214,8 +237,8 @@ class AdaptiveFeatureGenerator(nn.Module):
             if opt.dilation_conv:
                 self.deeper1 = SPADEResnetBlock(4 * nf, 4 * nf, opt, dilation=2)
                 self.deeper2 = SPADEResnetBlock(4 * nf, 4 * nf, opt, dilation=4)
-                self.degridding0 = wrap(nn.Conv2d(nf * 4, nf * 4, 3, stride=1, padding=2, dilation=2))
-                self.degridding1 = wrap(nn.Conv2d(nf * 4, nf * 4, 3, stride=1, padding=1))
+                self.degridding0 = wrap(Conv2d(nf * 4, nf * 4, 3, stride=1, padding=2, dilation=2))
+                self.degridding1 = wrap(Conv2d(nf * 4, nf * 4, 3, stride=1, padding=1))
             else:
                 self.deeper1 = SPADEResnetBlock(4 * nf, 4 * nf, opt)
                 self.deeper2 = SPADEResnetBlock(4 * nf, 4 * nf, opt)
@@ -242,11 +265,11 @@ class ResidualBlock(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, stride=1):
         super().__init__()
         self.padding1 = nn.ReflectionPad2d(padding)
-        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size, padding=0, stride=stride)
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size, padding=0, stride=stride)
         self.bn1 = nn.InstanceNorm2d(out_channels)
         self.prelu = nn.PReLU()
         self.padding2 = nn.ReflectionPad2d(padding)
-        self.conv2 = nn.Conv2d(in_channels, out_channels, kernel_size, padding=0, stride=stride)
+        self.conv2 = Conv2d(in_channels, out_channels, kernel_size, padding=0, stride=stride)
         self.bn2 = nn.InstanceNorm2d(out_channels)
 
     def forward(self, x):
