@@ -30,12 +30,31 @@
 // Tile BM (128 | 256) x 128 x 32, 4 waves as 2 x 2, double-buffered LDS, two register stages, staging pieces placed by
 // hand between the MFMA groups; ~2*M*N*K useful FLOPs, x3 issued.
 #include "common.h"
+#include <type_traits>
 
+#ifndef COCOS_CONV_SCHED
+#define COCOS_CONV_SCHED 1      // 0: staging pieces pinned after each group of 6 MFMAs; 1: sched_group_barrier pipeline
+                                // (measured 0.491 -> 0.470 ms on the 407-channel ResidualBlock convolution)
+#endif
+#ifndef COCOS_CONV_SCHED_N
+#define COCOS_CONV_SCHED_N 6
+#endif
 #ifndef COCOS_CONV_ABLATE
 #define COCOS_CONV_ABLATE 0     // timing experiments only (tools/build_conv_ablations.sh): 1 no gather loads, 2 no weight
 #endif                          // loads, 4 no LDS commit, 8 no MFMA
 
 namespace cocos {
+
+// Optional phase timing (build with COCOS_EXTRA_HIPFLAGS=-DCOCOS_DEBUG_TIMING): shader-clock cycles spent by thread 0 of
+// workgroup 0 in the two halves of a forward step and at its barrier — cocos_debug_read_timing_conv().
+#ifdef COCOS_DEBUG_TIMING
+__device__ long long g_phase_conv[8];
+#define CPH_T(var) const long long var = __builtin_readcyclecounter()
+#define CPH_ADD(i, a, b) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_phase_conv[i] += (b) - (a); } while (0)
+#else
+#define CPH_T(var) do {} while (0)
+#define CPH_ADD(i, a, b) do {} while (0)
+#endif
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
         S.a[0][u] = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, (int)voffa[u], (int)f_soffa, 0);
         S.a[1][u] = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, (int)voffa[u], (int)f_soffa, 0);
     };
-    auto fetch_g = [&](Stage& S, int u) {
+    auto fetch_g = [&](Stage& S, int u, auto edge_tag) __attribute__((always_inline)) {
         if (COCOS_CONV_ABLATE & 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) S.gv[u][e] = (float)(f_soff + u + e) * 1e-9f;
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
         if (FAST4) {
             const bool ok = chanok && f_rowok[0];
             bool done = false;
-            if (edge_tile) {
+            if constexpr (decltype(edge_tag)::value) {
                 const int e0 = cr[0].base + (rowlane[u] + f_cb * 32) * HW + f_ky * g.W + f_kx;
                 if (ok && (e0 < 0 || e0 + 4 > g.xelems)) {      // a handful of lanes of the first / last tile
 #pragma unroll
@@ -265,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < MI; ++u) fetch_a(S, u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fetch_g(S, u);
+        for (int u = 0; u < 4; ++u) fetch_g(S, u, std::true_type{});
     };
     auto commit_all = [&](Stage& S, int buf) {
 #pragma unroll
@@ -285,12 +304,14 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
     const int li = lane & 15, nb = (lane >> 4) & 1, kg = lane >> 5;
     const int tr_off = (8 * kg + (li >> 2)) * CV_GROW + 16 * nb + 4 * (li & 3);
 
-    auto step = [&](int t, Stage& S) {
+    auto step = [&](int t, Stage& S, auto edge_tag) __attribute__((always_inline)) {
         const int buf = t & 1;
         const _Float16* ab = at + buf * 2 * APLANE + (wm * (BM / 2) + c) * CV_AROW + h * 8;
         const _Float16* gb = gt + buf * 2 * GPLANE + wn * 64 + tr_off;
+        CPH_T(ts0);
 #pragma unroll
         for (int s = 0; s < ((COCOS_CONV_ABLATE & 8) ? 0 : CV_BK / 16); ++s) {
+            CPH_T(tsa);
             f16x8 bvh[2], bvl[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[i], bvh[j], acc[i][j], 0, 0, 0);
                 }
                 // slot i of this half step: s == 0 commits tile t+1, s == 1 fetches tile t+3
-                __builtin_amdgcn_sched_barrier(0);
+                if (COCOS_CONV_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
                 if (s == 0) {
                     commit_a(S, buf ^ 1, i);
 #pragma unroll
@@ -326,23 +347,43 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
                 } else {
                     fetch_a(S, i);
 #pragma unroll
-                    for (int q = 0; q < GPS; ++q) fetch_g(S, i * GPS + q);
+                    for (int q = 0; q < GPS; ++q) fetch_g(S, i * GPS + q, edge_tag);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (COCOS_CONV_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
             }
+            if (COCOS_CONV_SCHED == 1) {
+                // one MFMA, then up to COCOS_CONV_SCHED_N instructions of any other kind, 6 * MI times: spreads the slot
+                // work of this half step evenly through the gaps of the matrix pipe
+#pragma unroll
+                for (int q = 0; q < 6 * MI; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x010 | 0x080, COCOS_CONV_SCHED_N, 0);
+                }
+            }
+            CPH_T(tsb);
+            CPH_ADD(s, tsa, tsb);
         }
         if (COCOS_CONV_ABLATE & 8) {
             commit_all(S, buf ^ 1);
             fetch_all(S, t + 3);
         }
+        CPH_T(ts1);
         __syncthreads();
+        CPH_T(ts2);
+        CPH_ADD(2, ts1, ts2);
+        CPH_ADD(3, ts0, ts2);
+        CPH_ADD(4, 0, 1);
     };
-    int t = 0;
-    for (; t + 1 < nkb; t += 2) {
-        step(t, st[0]);
-        step(t + 1, st[1]);
-    }
-    if (t < nkb) step(t, st[0]);
+    auto run = [&](auto edge_tag) __attribute__((always_inline)) {
+        int t = 0;
+        for (; t + 1 < nkb; t += 2) {
+            step(t, st[0], edge_tag);
+            step(t + 1, st[1], edge_tag);
+        }
+        if (t < nkb) step(t, st[0], edge_tag);
+    };
+    // two copies of the loop: the common one has no branch in its body (one scheduling region per step)
+    if (edge_tile) run(std::true_type{}); else run(std::false_type{});
 
     const float oscale = 1.0f / ((w_scale ? *w_scale : 1.0f) * sx);
     const int ohw = g.OH * g.OW;
@@ -398,7 +439,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
     const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(dY, (size_t)ybytes);
     const float sx = cv_scale_from_amax(x_amax), sg = cv_scale_from_amax(g_amax);
     const int ohw = g.OH * g.OW;
-    const int maxoff = ((g.Cin - 1) * g.H + g.KH - 1) * g.W + g.KW - 1;
+    // a 16-byte piece can cross the ends of the whole tensor only for windows in the first rows of the first image /
+    // the last rows of the last one (conservative, workgroup-uniform): those slices run the loop copy with the check
+    const bool edge_slice = FAST4 && (nbeg < (g.pad + 2) * g.OW || nend > g.Ntot - (g.pad + 2) * g.OW);
 
     f32x16 acc[MI][2];
 #pragma unroll
@@ -436,7 +479,6 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
     Corner f_cr[NC];
     bool f_live[NC];
     unsigned f_y[NC];                                   // byte offset of dY[b, 0, pos]
-    bool f_edge = false;     // wave-uniform: some window of this step may see a 16-byte piece cross the tensor's ends
     auto fetch_begin = [&](int np0) {
 #pragma unroll
         for (int e = 0; e < NC; ++e) {
@@ -446,15 +488,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
             const int b = cv_div(n, g.mOHW);
             f_y[e] = (unsigned)(b * M * ohw + (n - b * ohw)) * 4u;
         }
-        if (FAST4) f_edge = __builtin_amdgcn_ballot_w64(f_cr[0].base < 0 || f_cr[0].base + maxoff + 4 > g.xelems) != 0;
     };
-    auto fetch_g = [&](Stage& S, int u) {
+    auto fetch_g = [&](Stage& S, int u, auto edge_tag) __attribute__((always_inline)) {
         if (FAST4) {
             const bool ok = r_ok[u] && f_live[0] && (unsigned)(f_cr[0].iy0 + r_ky[u]) < (unsigned)g.H;
             const int e0s = f_cr[0].base + r_off[u];                    // element offset in the shifted descriptor
             S.xs[u] = f_cr[0].ix0 + r_kx[u];
             bool done = false;
-            if (f_edge) {
+            if constexpr (decltype(edge_tag)::value) {
                 if (ok && (e0s - shift < 0 || e0s - shift + 4 > g.xelems)) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -513,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
 #pragma unroll
         for (int u = 0; u < APT; ++u) fetch_a(S, u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fetch_g(S, u);
+        for (int u = 0; u < 4; ++u) fetch_g(S, u, std::true_type{});
     };
     auto commit_all = [&](Stage& S, int buf) {
 #pragma unroll
@@ -530,7 +571,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
     fetch_all(st[1], nbeg + 2 * CV_BK);
     __syncthreads();
 
-    auto step = [&](int t, Stage& S) {
+    auto step = [&](int t, Stage& S, auto edge_tag) __attribute__((always_inline)) {
         const int buf = t & 1;
         const _Float16* ab = at + buf * 2 * APLANE + (wm * (BM / 2) + c) * CV_AROW + h * 8;
         const _Float16* bb = bt + buf * 2 * BPLANE + (wn * 64 + c) * CV_AROW + h * 8;
@@ -556,7 +597,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[i], bvl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[i], bvh[j], acc[i][j], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (COCOS_CONV_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
                 if (s == 0) {
                     commit_a(S, buf ^ 1, 2 * i);
                     commit_a(S, buf ^ 1, 2 * i + 1);
@@ -566,19 +607,29 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
                     fetch_a(S, 2 * i);
                     fetch_a(S, 2 * i + 1);
 #pragma unroll
-                    for (int q = 0; q < GPS; ++q) fetch_g(S, i * GPS + q);
+                    for (int q = 0; q < GPS; ++q) fetch_g(S, i * GPS + q, edge_tag);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (COCOS_CONV_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (COCOS_CONV_SCHED == 1) {
+#pragma unroll
+                for (int q = 0; q < 6 * MI; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x010 | 0x080, COCOS_CONV_SCHED_N, 0);
+                }
             }
         }
         __syncthreads();
     };
-    int t = 0;
-    for (; t + 1 < nsteps; t += 2) {
-        step(t, st[0]);
-        step(t + 1, st[1]);
-    }
-    if (t < nsteps) step(t, st[0]);
+    auto run = [&](auto edge_tag) __attribute__((always_inline)) {
+        int t = 0;
+        for (; t + 1 < nsteps; t += 2) {
+            step(t, st[0], edge_tag);
+            step(t + 1, st[1], edge_tag);
+        }
+        if (t < nsteps) step(t, st[0], edge_tag);
+    };
+    if (edge_slice) run(std::true_type{}); else run(std::false_type{});
 
     const float oscale = 1.0f / (sx * sg);
     float* pb = part + (size_t)slice * M * g.Ktot;
@@ -710,3 +761,16 @@ extern "C" int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const f
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
+
+#ifdef COCOS_DEBUG_TIMING
+extern "C" int cocos_debug_read_timing_conv(long long* host8, int reset) {
+    using namespace cocos;
+    COCOS_HIP_CHECK(hipDeviceSynchronize());
+    COCOS_HIP_CHECK(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_phase_conv), 8 * sizeof(long long)));
+    if (reset) {
+        long long z[8] = {0};
+        COCOS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_conv), z, sizeof(z)));
+    }
+    return COCOS_OK;
+}
+#endif
