@@ -126,12 +126,12 @@ _SIGNATURES = {
                                                  ctypes.c_float, _stream_t]),
     "cocos_contextual_rows_bwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_float,
                                                                    ctypes.c_float, _stream_t]),
-    "cocos_conv2d_out_size": (ctypes.c_int, [ctypes.c_int] * 4),
+    "cocos_conv2d_out_size": (ctypes.c_int, [ctypes.c_int] * 5),
     "cocos_conv2d_kdim": (ctypes.c_int, [ctypes.c_int] * 3),
     "cocos_conv2d_fwd_f16x3": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p,
-                                              _c_float_p, _c_float_p] + [ctypes.c_int] * 9 + [_stream_t]),
-    "cocos_conv2d_wgrad_slices": (ctypes.c_int, [ctypes.c_int] * 9),
-    "cocos_conv2d_wgrad_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 9 + [_stream_t]),
+                                              _c_float_p, _c_float_p] + [ctypes.c_int] * 10 + [_stream_t]),
+    "cocos_conv2d_wgrad_slices": (ctypes.c_int, [ctypes.c_int] * 10),
+    "cocos_conv2d_wgrad_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 10 + [_stream_t]),
     "cocos_debug_mfma_probe": (ctypes.c_int, [_c_float_p, _stream_t]),
 }
 

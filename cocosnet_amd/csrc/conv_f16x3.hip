@@ -74,7 +74,7 @@ __device__ __forceinline__ int cv_div(int n, Magic m) {
 }
 
 struct ConvGeom {
-    int Cin, H, W, OH, OW, KH, KW, stride, pad;
+    int Cin, H, W, OH, OW, KH, KW, stride, pad, dil;
     int Cp;                  // Cin rounded up to 32
     int Ktot;                // KH * KW * Cp
     int OWv;                 // forward kernel, stride 1: OW rounded up to 4 (virtual columns, computed and dropped) so
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
         live[e] = n < g.Ntot;
     }
     // only windows at the very beginning / end of the tensor can see a 16-byte piece cross its ends (wave-uniform flag)
-    const int maxoff = ((g.Cin - 1) * g.H + g.KH - 1) * g.W + g.KW - 1;
+    const int maxoff = ((g.Cin - 1) * g.H + (g.KH - 1) * g.dil) * g.W + (g.KW - 1) * g.dil;
     const bool edge_tile = FAST4 && __builtin_amdgcn_ballot_w64(cr[0].base < 0 || cr[0].base + maxoff + 4 > g.xelems) != 0;
     // piece u = channels u*8 + 2*wave + h of the k-block (lane half h), the thread's columns
     int rowlane[4];
@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
         const int tap = cv_div(tt, g.mNCB);
         f_cb = tt - tap * ncb;
         f_ky = cv_div(tap, g.mKW);
-        f_kx = tap - f_ky * g.KW;
+        f_kx = (tap - f_ky * g.KW) * g.dil;            // from here on: the tap's offset in input pixels
+        f_ky *= g.dil;
         f_soff = (unsigned)(f_cb * 32 * HW + f_ky * g.W + f_kx) * 4u;
         f_soffa = (unsigned)(tt * M + m0) * 64u;
 #pragma unroll
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
     const int ohw = g.OH * g.OW;
     // a 16-byte piece can cross the ends of the whole tensor only for windows in the first rows of the first image /
     // the last rows of the last one (conservative, workgroup-uniform): those slices run the loop copy with the check
-    const bool edge_slice = FAST4 && (nbeg < (g.pad + 2) * g.OW || nend > g.Ntot - (g.pad + 2) * g.OW);
+    const bool edge_slice = FAST4 && (nbeg < (g.pad + 2) * g.OW || nend > g.Ntot - (g.pad + g.KH * g.dil + 2) * g.OW);
 
     f32x16 acc[MI][2];
 #pragma unroll
@@ -462,7 +463,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
         const int k = k0 + u * 32 + (tid >> 3);
         const int tap = cv_div(k, g.mCp), ci = k - tap * g.Cp;
         r_ky[u] = cv_div(tap, g.mKW);
-        r_kx[u] = tap - r_ky[u] * g.KW;
+        r_kx[u] = (tap - r_ky[u] * g.KW) * g.dil;     // the tap's offset in input pixels
+        r_ky[u] *= g.dil;
         r_ok[u] = k < g.Ktot && ci < g.Cin;
         r_off[u] = (ci * g.H + r_ky[u]) * g.W + r_kx[u] + shift;
     }
@@ -655,15 +657,16 @@ static Magic cv_magic(int d) {
     return Magic{(unsigned)((two + (unsigned)d - 1) / (unsigned)d), sh, 0u};
 }
 
-static int cv_geom(ConvGeom& g, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, bool virt,
+static int cv_geom(ConvGeom& g, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int dil, bool virt,
                    const char* who) {
-    COCOS_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0,
-                  COCOS_ERR_INVALID, "%s: bad geometry B=%d Cin=%d Cout=%d H=%d W=%d k=%dx%d stride=%d pad=%d", who, B, Cin,
-                  Cout, H, W, KH, KW, stride, pad);
-    COCOS_REQUIRE(H + 2 * pad >= KH && W + 2 * pad >= KW, COCOS_ERR_INVALID, "%s: kernel larger than the padded input", who);
-    g.Cin = Cin; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
-    g.OH = (H + 2 * pad - KH) / stride + 1;
-    g.OW = (W + 2 * pad - KW) / stride + 1;
+    COCOS_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1 && H >= 1 && W >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0 && dil >= 1,
+                  COCOS_ERR_INVALID, "%s: bad geometry B=%d Cin=%d Cout=%d H=%d W=%d k=%dx%d stride=%d pad=%d dilation=%d", who, B,
+                  Cin, Cout, H, W, KH, KW, stride, pad, dil);
+    COCOS_REQUIRE(H + 2 * pad >= dil * (KH - 1) + 1 && W + 2 * pad >= dil * (KW - 1) + 1, COCOS_ERR_INVALID,
+                  "%s: kernel larger than the padded input", who);
+    g.Cin = Cin; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.dil = dil;
+    g.OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+    g.OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
     g.Cp = (Cin + 31) / 32 * 32;
     g.OWv = virt ? (g.OW + 3) / 4 * 4 : g.OW;
     const long long ktot = (long long)KH * KW * g.Cp, ntot = (long long)B * g.OH * g.OWv;
@@ -683,18 +686,18 @@ static int cv_geom(ConvGeom& g, int B, int Cin, int H, int W, int Cout, int KH, 
 
 }  // namespace cocos
 
-extern "C" int cocos_conv2d_out_size(int in, int k, int stride, int pad) {
-    return (stride >= 1 && in + 2 * pad >= k) ? (in + 2 * pad - k) / stride + 1 : 0;
+extern "C" int cocos_conv2d_out_size(int in, int k, int stride, int pad, int dil) {
+    return (stride >= 1 && dil >= 1 && in + 2 * pad >= dil * (k - 1) + 1) ? (in + 2 * pad - dil * (k - 1) - 1) / stride + 1 : 0;
 }
 extern "C" int cocos_conv2d_kdim(int Cin, int KH, int KW) { return KH * KW * ((Cin + 31) / 32 * 32); }
 
 extern "C" int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const void* w_lo, const float* w_scale_dev,
                                       const float* x_amax_dev, const float* bias, float* y, int B, int Cin, int H, int W,
-                                      int Cout, int KH, int KW, int stride, int pad, cocos_stream_t stream) {
+                                      int Cout, int KH, int KW, int stride, int pad, int dil, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(x && w_hi && w_lo && y, COCOS_ERR_INVALID, "conv2d_fwd_f16x3: null pointer");
     ConvGeom g;
-    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, stride == 1, "conv2d_fwd_f16x3")) return rc;
+    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, dil, stride == 1, "conv2d_fwd_f16x3")) return rc;
     COCOS_REQUIRE(aligned16(w_hi) && aligned16(w_lo), COCOS_ERR_INVALID,
                   "conv2d_fwd_f16x3: weight planes must be 16-byte aligned");
     const bool fast4 = stride == 1;
@@ -718,9 +721,10 @@ extern "C" int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const vo
     return COCOS_OK;
 }
 
-extern "C" int cocos_conv2d_wgrad_slices(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad) {
-    if (B < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 || stride < 1 || pad < 0 || H + 2 * pad < KH || W + 2 * pad < KW) return 0;
-    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+extern "C" int cocos_conv2d_wgrad_slices(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                                         int dil) {
+    const int OH = cocos_conv2d_out_size(H, KH, stride, pad, dil), OW = cocos_conv2d_out_size(W, KW, stride, pad, dil);
+    if (B < 1 || Cin < 1 || Cout < 1 || KH < 1 || KW < 1 || pad < 0 || OH < 1 || OW < 1) return 0;
     const long long ntot = (long long)B * OH * OW;
     const int bm = Cout > 128 ? 256 : 128;
     const long long tiles = (long long)((Cout + bm - 1) / bm) * ((cocos_conv2d_kdim(Cin, KH, KW) + 127) / 128);
@@ -733,12 +737,12 @@ extern "C" int cocos_conv2d_wgrad_slices(int B, int Cin, int H, int W, int Cout,
 
 extern "C" int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const float* x_amax_dev, const float* g_amax_dev,
                                         float* partials, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
-                                        int pad, cocos_stream_t stream) {
+                                        int pad, int dil, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(x && dy && partials, COCOS_ERR_INVALID, "conv2d_wgrad_f16x3: null pointer");
     ConvGeom g;
-    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, false, "conv2d_wgrad_f16x3")) return rc;
-    const int nslices = cocos_conv2d_wgrad_slices(B, Cin, H, W, Cout, KH, KW, stride, pad);
+    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, dil, false, "conv2d_wgrad_f16x3")) return rc;
+    const int nslices = cocos_conv2d_wgrad_slices(B, Cin, H, W, Cout, KH, KW, stride, pad, dil);
     const int nchunk = ((g.Ntot + nslices - 1) / nslices + CV_BK - 1) / CV_BK * CV_BK;
     const bool fast4 = stride == 1 && g.OW % 4 == 0 && aligned16(dy);
     const int bm = Cout > 128 ? 256 : 128;

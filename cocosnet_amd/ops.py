@@ -696,27 +696,27 @@ def _weight_planes(wt, amax):
     return wh, wl, ws
 
 
-def _conv_fwd_call(x, wh, wl, ws, xa, bias, Cout, KH, KW, stride, pad):
+def _conv_fwd_call(x, wh, wl, ws, xa, bias, Cout, KH, KW, stride, pad, dil):
     B, Cin, H, W = x.shape
     lib = _lib.load()
-    OH, OW = lib.cocos_conv2d_out_size(H, KH, stride, pad), lib.cocos_conv2d_out_size(W, KW, stride, pad)
+    OH, OW = lib.cocos_conv2d_out_size(H, KH, stride, pad, dil), lib.cocos_conv2d_out_size(W, KW, stride, pad, dil)
     if OH < 1 or OW < 1:
-        raise ValueError(f"conv2d: kernel {KH}x{KW} does not fit input {tuple(x.shape)} with padding {pad}")
+        raise ValueError(f"conv2d: kernel {KH}x{KW} (dilation {dil}) does not fit input {tuple(x.shape)} with padding {pad}")
     y = torch.empty((B, Cout, OH, OW), device=x.device, dtype=torch.float32)
     _call("conv2d_fwd", "cocos_conv2d_fwd_f16x3", x.data_ptr(), wh.data_ptr(), wl.data_ptr(), ws.data_ptr(),
-          xa.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, pad, _stream())
+          xa.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, pad, dil, _stream())
     return y
 
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride: int, pad: int):
+    def forward(ctx, x, weight, bias, stride: int, pad: int, dil: int):
         x = _chk(x, "conv2d: x")
         weight = _chk(weight, "conv2d: weight")
         if x.dim() != 4 or weight.dim() != 4 or weight.shape[1] != x.shape[1]:
             raise ValueError(f"conv2d: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}")
-        if stride < 1 or pad < 0:
-            raise ValueError(f"conv2d: stride {stride} / padding {pad}")
+        if stride < 1 or pad < 0 or dil < 1:
+            raise ValueError(f"conv2d: stride {stride} / padding {pad} / dilation {dil}")
         Cout, Cin, KH, KW = weight.shape
         bb = None if bias is None else _chk(bias, "conv2d: bias")
         xa = _recall_amax(x)
@@ -724,16 +724,16 @@ class _Conv2d(torch.autograd.Function):
             xa = absmax(x)
         wa = absmax(weight)
         wh, wl, ws = _weight_planes(weight.permute(0, 2, 3, 1).reshape(Cout, KH * KW, Cin), wa)
-        y = _conv_fwd_call(x, wh, wl, ws, xa, bb, Cout, KH, KW, stride, pad)
+        y = _conv_fwd_call(x, wh, wl, ws, xa, bb, Cout, KH, KW, stride, pad, dil)
         ctx.save_for_backward(x, weight)
-        ctx.cfg = (int(stride), int(pad), bias is not None)
+        ctx.cfg = (int(stride), int(pad), int(dil), bias is not None)
         ctx.amax = (xa, wa)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        stride, pad, has_bias = ctx.cfg
+        stride, pad, dil, has_bias = ctx.cfg
         xa, wa = ctx.amax
         dy = _chk(dy, "conv2d: dy")
         B, Cin, H, W = x.shape
@@ -744,31 +744,32 @@ class _Conv2d(torch.autograd.Function):
         if ga is None:
             ga = absmax(dy)
         if need_x:
-            if stride == 1 and KH - 1 - pad >= 0 and KW == KH:
-                # dx = conv(dy, flipped weights with the channel roles swapped, padding K-1-p): the same kernel
+            if stride == 1 and dil * (KH - 1) - pad >= 0 and KW == KH:
+                # dx = conv(dy, flipped weights with the channel roles swapped, padding d(K-1)-p): the same kernel
                 wt = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, KH * KW, Cout)
                 th, tl, ts = _weight_planes(wt, wa)
-                dx = _conv_fwd_call(dy, th, tl, ts, ga, None, Cin, KH, KW, 1, KH - 1 - pad)
+                dx = _conv_fwd_call(dy, th, tl, ts, ga, None, Cin, KH, KW, 1, dil * (KH - 1) - pad, dil)
             else:       # strided layers (PatchGAN): the framework's transposed convolution
-                dx = torch.nn.grad.conv2d_input(x.shape, weight, dy, stride=stride, padding=pad)
+                dx = torch.nn.grad.conv2d_input(x.shape, weight, dy, stride=stride, padding=pad, dilation=dil)
         if need_w:
             lib = _lib.load()
-            S = lib.cocos_conv2d_wgrad_slices(B, Cin, H, W, Cout, KH, KW, stride, pad)
+            S = lib.cocos_conv2d_wgrad_slices(B, Cin, H, W, Cout, KH, KW, stride, pad, dil)
             kdim = lib.cocos_conv2d_kdim(Cin, KH, KW)
             part = torch.empty((S, Cout, kdim), device=x.device, dtype=torch.float32)
             _call("conv2d_wgrad", "cocos_conv2d_wgrad_f16x3", x.data_ptr(), dy.data_ptr(), xa.data_ptr(), ga.data_ptr(),
-                  part.data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, pad, _stream())
+                  part.data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, pad, dil, _stream())
             dwk = part.sum(0) if S > 1 else part[0]                  # [Cout, T * Cp], k = tap * Cp + ci
             dw = dwk.reshape(Cout, KH, KW, kdim // (KH * KW))[..., :Cin].permute(0, 3, 1, 2).contiguous()
         if need_b and has_bias:
             db = dy.sum((0, 2, 3))
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride: int = 1, padding: int = 0):
-    """torch.nn.functional.conv2d(x, weight, bias, stride, padding) for groups = 1, dilation = 1, square stride/padding:
-    fp32 in and out, products on the f16 MFMA with split operands (3 terms, fp32 accumulate) — conv_f16x3.hip."""
-    return _Conv2d.apply(x, weight, bias, int(stride), int(padding))
+def conv2d(x, weight, bias=None, stride: int = 1, padding: int = 0, dilation: int = 1):
+    """torch.nn.functional.conv2d(x, weight, bias, stride, padding, dilation) for groups = 1 and one stride / padding /
+    dilation for both axes: fp32 in and out, products on the f16 MFMA with split operands (3 terms, fp32 accumulate) —
+    conv_f16x3.hip.  (The input gradient of a strided layer still takes the framework's transposed convolution.)"""
+    return _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation))
 
 
 # ------------------------------------------------------------------------------------------

@@ -28,19 +28,41 @@ CONV_BACKEND = os.environ.get("COCOS_CONV", "f16x3")     # "torch": the framewor
 class Conv2d(nn.Conv2d):
     """nn.Conv2d whose fp32 GPU forward/backward run on the HIP kernels: K16 (ops.conv2d) for kxk, K0 (ops.proj1x1) for
     1x1.  Same parameters, same state_dict keys, works under torch.nn.utils.spectral_norm (which only rewrites
-    `.weight`).  Anything the kernels do not cover (dilation, groups, non-zero padding modes, rectangular
-    stride/padding, other dtypes, CPU) takes the framework path."""
+    `.weight`).  Anything the kernels do not cover (groups, non-zero padding modes, rectangular stride / padding /
+    dilation, other dtypes, CPU) takes the framework path."""
 
     def _conv_forward(self, input, weight, bias):
-        s, p, k = self.stride, self.padding, self.kernel_size
+        s, p, k, d = self.stride, self.padding, self.kernel_size, self.dilation
         if (CONV_BACKEND == "f16x3" and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32
-                and input.dim() == 4 and self.groups == 1 and self.dilation == (1, 1) and self.padding_mode == "zeros"
-                and not isinstance(p, str) and s[0] == s[1] and p[0] == p[1]):
+                and input.dim() == 4 and self.groups == 1 and self.padding_mode == "zeros"
+                and not isinstance(p, str) and s[0] == s[1] and p[0] == p[1] and d[0] == d[1]):
             from . import ops
             if k == (1, 1) and s[0] == 1 and p[0] == 0:
                 return ops.proj1x1(input, weight, bias)
-            return ops.conv2d(input, weight, bias, s[0], p[0])
+            return ops.conv2d(input, weight, bias, s[0], p[0], d[0])
         return super()._conv_forward(input, weight, bias)
+
+
+def use_hip_convs(module: nn.Module) -> int:
+    """Re-class every plain `nn.Conv2d` inside `module` (e.g. the reference's `NLayerDiscriminator`
+    discriminator.py:92-115, its `SPADEGenerator`, `VGG19`) to `Conv2d` above, in place: parameters, buffers, hooks
+    (spectral norm) and state_dict keys are untouched, only `_conv_forward` changes.  Returns the number of layers
+    switched.  The inverse is `use_framework_convs`."""
+    n = 0
+    for m in module.modules():
+        if type(m) is nn.Conv2d:
+            m.__class__ = Conv2d
+            n += 1
+    return n
+
+
+def use_framework_convs(module: nn.Module) -> int:
+    n = 0
+    for m in module.modules():
+        if type(m) is Conv2d:
+            m.__class__ = nn.Conv2d
+            n += 1
+    return n
 
 
 def positional_norm(x, eps=1e-5):

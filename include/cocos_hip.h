@@ -403,7 +403,8 @@ int cocos_contextual_rows_bwd(const float* cosm, const float* dcx, float* dcos, 
                               float eps, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
- * K16 2-D convolution (cross-correlation, zero padding, like torch.nn.functional.conv2d with groups = 1, dilation = 1)
+ * K16 2-D convolution (cross-correlation, zero padding, like torch.nn.functional.conv2d with groups = 1, one stride /
+ *     padding / dilation for both axes)
  *     as an implicit GEMM on the f16 MFMA with split operands (conv_f16x3.hip).  Replaces the nn.Conv2d calls of the
  *     networks in front of and behind the path: ResidualBlock (correspondence.py:13-36: ReflectionPad2d(1) stays a
  *     host-side pad, the 3x3 convolution is this kernel with pad = 0), the adaptor layers (correspondence.py:150-173)
@@ -413,24 +414,25 @@ int cocos_contextual_rows_bwd(const float* cosm, const float* dcx, float* dcos, 
  *   fwd:   x [B,Cin,H,W] fp32, weight planes w_hi/w_lo [K/32][Cout][32] f16 (k-block major so that a tile's rows are
  *          contiguous; zero for ci >= Cin): cocos_split_f16_rows of the re-laid-out weight matrix, whose *scale_out
  *          goes to w_scale_dev (NULL = 1), x_amax_dev = max|x| (NULL: x is O(1)), bias [Cout] or NULL
- *          ->  y [B,Cout,OH,OW] fp32, OH = cocos_conv2d_out_size(H,KH,stride,pad) (0 when the kernel does not fit).
+ *          ->  y [B,Cout,OH,OW] fp32, OH = cocos_conv2d_out_size(H,KH,stride,pad,dilation) (0 when the kernel does not fit).
  *          The input gradient of a stride-1 convolution is the same call on dy with the planes of the flipped,
- *          transposed weight (roles of Cin and Cout swapped) and pad' = K-1-pad.
+ *          transposed weight (roles of Cin and Cout swapped) and pad' = dilation*(K-1)-pad.
  *   wgrad: x, dy [B,Cout,OH,OW] (+ their max|.|, NULL = O(1))  ->  partials [S][Cout][K] fp32 (k as above; entries
  *          with ci >= Cin are written as zeros), S = cocos_conv2d_wgrad_slices(...) slices over the B*OH*OW
  *          positions; the caller sums them (and sums dy over (b,oy,ox) for the bias gradient).
  *   Every tensor (and Cout*K*4) must stay below 2 GiB (32-bit offsets).
  * ------------------------------------------------------------------------------------- */
-int cocos_conv2d_out_size(int in, int k, int stride, int pad);
+int cocos_conv2d_out_size(int in, int k, int stride, int pad, int dilation);
 int cocos_conv2d_kdim(int Cin, int KH, int KW);
 int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const void* w_lo, const float* w_scale_dev /* nullable */,
                            const float* x_amax_dev /* nullable */, const float* bias /* nullable */, float* y,
-                           int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                           int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int dilation,
                            cocos_stream_t stream);
-int cocos_conv2d_wgrad_slices(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad);   /* 0 on bad dims */
+int cocos_conv2d_wgrad_slices(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                              int dilation);   /* 0 on bad dims */
 int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const float* x_amax_dev /* nullable */,
                              const float* dy_amax_dev /* nullable */, float* partials, int B, int Cin, int H, int W,
-                             int Cout, int KH, int KW, int stride, int pad, cocos_stream_t stream);
+                             int Cout, int KH, int KW, int stride, int pad, int dilation, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K12 statistics of the zero-padded 3x3-unfolded, centred feature vectors without unfolding (match_kernel 3 with

@@ -19,14 +19,16 @@ CASES = [
     (2, 20, 10, 16, 24, 3, 1, 2),        # pad > (k-1)/2: output larger than input
     (1, 4, 8, 8, 4, 5, 1, 2),            # 5x5
     (1, 2, 6, 6, 3, 3, 2, 0),            # stride 2, tiny
+    (2, 12, 20, 24, 10, 3, 1, 2, 2),     # dilation 2 (the adaptors' de-gridding convolution: k3 p2 d2)
+    (1, 6, 17, 13, 5, 3, 2, 3, 3),       # dilation 3, stride 2, ragged
 ]
 
 
-def _ref(x, w, b, stride, pad, go):
+def _ref(x, w, b, stride, pad, go, dil=1):
     xd = x.double().requires_grad_(True)
     wd = w.double().requires_grad_(True)
     bd = None if b is None else b.double().requires_grad_(True)
-    y = F.conv2d(xd, wd, bd, stride=stride, padding=pad)
+    y = F.conv2d(xd, wd, bd, stride=stride, padding=pad, dilation=dil)
     y.backward(go.double())
     return y.detach(), xd.grad, wd.grad, None if b is None else bd.grad
 
@@ -35,15 +37,16 @@ def _ref(x, w, b, stride, pad, go):
 @pytest.mark.parametrize("with_bias", [True, False])
 def test_conv2d_matches_fp64(case, with_bias):
     from cocosnet_amd import ops
-    B, Cin, H, W, Cout, k, stride, pad = case
+    B, Cin, H, W, Cout, k, stride, pad = case[:8]
+    dil = case[8] if len(case) > 8 else 1
     g = torch.Generator(device="cuda").manual_seed(11)
     x = torch.randn(B, Cin, H, W, device="cuda", generator=g).requires_grad_(True)
     w = (torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5).requires_grad_(True)
     b = torch.randn(Cout, device="cuda", generator=g).requires_grad_(True) if with_bias else None
-    y = ops.conv2d(x, w, b, stride, pad)
+    y = ops.conv2d(x, w, b, stride, pad, dil)
     go = torch.randn(y.shape, device="cuda", generator=g)
     y.backward(go)
-    yr, dxr, dwr, dbr = _ref(x.detach(), w.detach(), None if b is None else b.detach(), stride, pad, go)
+    yr, dxr, dwr, dbr = _ref(x.detach(), w.detach(), None if b is None else b.detach(), stride, pad, go, dil)
     assert y.shape == yr.shape
 
     def close(a, r, what):

@@ -192,3 +192,44 @@ def test_contextual_loss_module_equals_the_reference_class_on_cpu():
         assert ref_mod.ContextualLoss_forward is ContextualLoss_forward
     finally:
         ref_mod.ContextualLoss_forward = original
+
+
+def test_use_hip_convs_reclasses_in_place_and_keeps_the_cpu_result():
+    """producers.use_hip_convs: same parameters / keys / spectral-norm hooks, CPU forward unchanged (no GPU: the
+    framework path), and reversible."""
+    from cocosnet_amd import producers
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.utils.spectral_norm(torch.nn.Conv2d(3, 8, 4, stride=2, padding=2)),
+                              torch.nn.LeakyReLU(0.2), torch.nn.Conv2d(8, 1, 4, stride=1, padding=2))
+    net.eval()
+    x = torch.randn(2, 3, 16, 16)
+    keys, y0 = list(net.state_dict().keys()), net(x)
+    assert producers.use_hip_convs(net) == 2
+    assert all(isinstance(m, producers.Conv2d) for m in net if isinstance(m, torch.nn.Conv2d))
+    assert list(net.state_dict().keys()) == keys
+    assert torch.equal(net(x), y0)
+    assert producers.use_framework_convs(net) == 2 and type(net[0]) is torch.nn.Conv2d
+
+
+@needs_ref
+def test_use_hip_convs_on_the_reference_discriminator():
+    """The reference's PatchGAN (discriminator.py:92-115) takes the re-classing: every k4 convolution becomes a
+    producers.Conv2d and the multiscale forward still runs (CPU here; the GPU parity of the kernel itself is
+    tests/test_gpu_conv.py)."""
+    from cocosnet_amd import producers
+    rh.load_reference()
+    disc = __import__("importlib").import_module("models.networks.discriminator")
+    opt = rh.make_opt(semantic_nc=5)
+    for k, v in dict(ndf=8, n_layers_D=3, norm_D="spectralinstance", netD_subarch="n_layer", num_D=2, label_nc=4,
+                     contain_dontcare_label=True, no_instance=True, no_ganFeat_loss=False, D_cam=0.0, output_nc=3,
+                     use_attention=False, use_attention_st1=False, eqlr_sn=False).items():
+        setattr(opt, k, v)
+    try:
+        net = disc.MultiscaleDiscriminator(opt)
+    except Exception as e:     # option surface of the reference differs: not this test's business
+        pytest.skip(f"reference discriminator not constructible with the stand-in options: {e}")
+    n = producers.use_hip_convs(net)
+    assert n >= 2 * 4
+    x = torch.randn(1, opt.label_nc + 1 + 3, 32, 32)
+    out = net(x)
+    assert len(out) >= 1
