@@ -7,11 +7,14 @@
 // L2-normalised and multiplied by 1/T = 100 inside the softmax: plain f16/bf16 convolutions would break the 1e-3 parity
 // of the path they feed, the fp32 MFMA runs at 1/16 of the f16 rate, hence the split.
 //
-// The contraction index is ordered TAP-MAJOR:  k = tap * Cp + ci,  tap = ky*KW + kx,  Cp = Cin rounded up to 32.  A
-// k-block of 32 is then 32 consecutive channels at ONE tap: its addresses are a per-thread constant plus a per-step
-// scalar, its border masks are those of the tap — no per-element index arithmetic in the steady state.  (Measured on
-// the first version, ordered (ci,ky,kx): the integer work of the gather, not the loads, set the speed — a wave
-// that owns a SIMD issues ~1 instruction / 4-5 cycles, i.e. ~7 per 32-cycle MFMA, and everything else must fit there.)
+// The contraction index is ordered by BLOCKS OF 32 CHANNELS, taps inside:  k = ((ci/32) * T + tap) * 32 + ci%32,
+// tap = ky*KW + kx, T = KH*KW, channels zero-padded to Cp = 32*ceil(Cin/32).  A k-block of 32 is then 32 consecutive
+// channels at ONE tap: its addresses are a per-thread constant plus a per-step scalar, its border masks are those of
+// the tap — no per-element index arithmetic in the steady state — and the T k-blocks that follow each other read the
+// SAME 32 channels shifted by a pixel or a row, so the window comes from L1/L2 after its first touch.  (Measured on the
+// earlier orderings: with (ci,ky,kx) the integer work of the gather set the speed — a wave that owns a SIMD issues ~1
+// instruction / 4-5 cycles, ~7 per 32-cycle MFMA; with taps outermost every tap pass streamed all channels of the
+// XCD's images through its 4 MB L2 again.)
 //
 //   forward / input gradient (conv_fwd_kernel):   Y[b,co,oy,ox] = bias[co] + sum_k Wt[co,k] X[b,ci,oy*s+ky-p,ox*s+kx-p]
 //       GEMM  C[M = Cout][N = B*OH*OW] over K = T*Cp;  A = weight planes (pre-split f16 hi/lo, k-block major
@@ -30,6 +33,7 @@
 // Tile BM (128 | 256) x 128 x 32, 4 waves as 2 x 2, double-buffered LDS, two register stages, staging pieces placed by
 // hand between the MFMA groups; ~2*M*N*K useful FLOPs, x3 issued.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef COCOS_CONV_SCHED
@@ -38,6 +42,9 @@
 #endif
 #ifndef COCOS_CONV_SCHED_N
 #define COCOS_CONV_SCHED_N 6
+#endif
+#ifndef COCOS_CONV_STAGES
+#define COCOS_CONV_STAGES 0     // 0: per tile shape (see conv_fwd_kernel); 1 | 2: forced (timing experiments)
 #endif
 #ifndef COCOS_CONV_ABLATE
 #define COCOS_CONV_ABLATE 0     // timing experiments only (tools/build_conv_ablations.sh): 1 no gather loads, 2 no weight
@@ -62,8 +69,6 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CV_BN = 128, CV_BK = 32;
 constexpr int CV_AROW = CV_BK + 8;      // halfs per row of a k-contiguous image (80 B: conflict-free b128 reads)
-constexpr int CV_GROW = CV_BN + 32;     // halfs per k row of the position-contiguous image: 320 B = 256 + 64, so the four
-                                        // rows of a transpose read fall into four different quarters of the 64 banks
 
 // n / d for 0 <= n < 2^31, branch-free:  (umulhi(n, mul) + (add ? n : 0)) >> sh.
 //   d not a power of two: sh = floor(log2 d), mul = ceil(2^(32+sh) / d), add = 0 — exact because the rounding excess of
@@ -81,7 +86,7 @@ struct ConvGeom {
                              // that 4 consecutive GEMM columns are always 4 consecutive pixels of ONE row; else OW
     int Ntot;                // B * OH * OWv  (GEMM columns)
     int xelems;              // B * Cin * H * W
-    Magic mNCB, mKW, mOHW, mOW, mCp;     // / (Cp/32), / KW, / (OH*OWv), / OWv, / Cp
+    Magic mT, mKW, mOHW, mOW;            // / (KH*KW), / KW, / (OH*OWv), / OWv
 };
 
 __device__ __forceinline__ float cv_scale_from_amax(const float* amax) {
@@ -134,15 +139,23 @@ __device__ __forceinline__ f32x4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned b
 // The X descriptor starts `shift` = pad*W + pad elements BEFORE the tensor so that every per-thread offset constant is
 // >= 0 (the step offset travels in the scalar offset, which the hardware does not range-check): nothing below X is ever
 // dereferenced — a lane whose window corner lies outside the image is masked to the out-of-range offset.
-template <int BM, bool FAST4>
+template <int BM, int BN, bool FAST4>
 __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restrict__ X, const _Float16* __restrict__ wh,
                                                           const _Float16* __restrict__ wl,
                                                           const float* __restrict__ w_scale, const float* __restrict__ x_amax,
                                                           const float* __restrict__ bias, float* __restrict__ Y, int M,
                                                           ConvGeom g) {
-    constexpr int MI = BM / 64;                        // 32-row blocks per wave = staging slots per half step
-    constexpr int GPS = 4 / MI;                        // gathered pieces per slot
-    constexpr int APLANE = BM * CV_AROW, GPLANE = CV_BK * CV_GROW;
+    constexpr int MI = BM / 64, NJ = BN / 64;          // 32 x 32 blocks of a wave's tile (waves as 2 x 2)
+    // register stages: 2 (see above) while they fit; the 256 x 256 tile keeps all 256 accumulator registers and
+    // has ONE: step t fetches tile t+1 under its first half and commits it under the second (a step is twice as long)
+    constexpr int STAGES = COCOS_CONV_STAGES ? COCOS_CONV_STAGES : ((MI * NJ == 16) ? 1 : 2);
+    constexpr int LPR = BN / 4;                        // lanes per k row of the gathered tile (4 positions each)
+    constexpr int RPP = 256 / LPR;                     // k rows per pass of the 256 threads
+    constexpr int NP = CV_BK / RPP;                    // gathered pieces per thread (4 | 8)
+    constexpr int GPS = NP / MI;                       // gathered pieces per staging slot
+    constexpr int GROW = BN + 32;                      // halfs per k row: 64 B more than a multiple of 256 B, so the four
+                                                       // rows of a transpose read fall into different quarters of the banks
+    constexpr int APLANE = BM * CV_AROW, GPLANE = CV_BK * GROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][BM][AROW]
     _Float16* const gt = at + 2 * 2 * APLANE;                      // [2 buf][hi|lo][32 k][GROW]
@@ -151,9 +164,10 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (g.Ntot + CV_BN - 1) / CV_BN;
+    const int cg = tid % LPR, rowsub = tid / LPR;      // gather: column group (4 positions) and k row within a pass
+    const int ntn = (g.Ntot + BN - 1) / BN;
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (vb / ntn) * BM, n0 = (vb % ntn) * CV_BN;       // consecutive ids: the position tiles of one row tile
+    const int m0 = (vb / ntn) * BM, n0 = (vb % ntn) * BN;          // consecutive ids: the position tiles of one row tile
     const int HW = g.H * g.W, ncb = g.Cp >> 5, nkb = g.KH * g.KW * ncb;
     const int shift = g.pad * g.W + g.pad;
 
@@ -168,19 +182,19 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
     bool live[NC];
 #pragma unroll
     for (int e = 0; e < NC; ++e) {
-        const int n = n0 + 4 * c + e;
+        const int n = n0 + 4 * cg + e;
         cr[e] = cv_corner(min(n, g.Ntot - 1), g);
         live[e] = n < g.Ntot;
     }
     // only windows at the very beginning / end of the tensor can see a 16-byte piece cross its ends (wave-uniform flag)
     const int maxoff = ((g.Cin - 1) * g.H + (g.KH - 1) * g.dil) * g.W + (g.KW - 1) * g.dil;
     const bool edge_tile = FAST4 && __builtin_amdgcn_ballot_w64(cr[0].base < 0 || cr[0].base + maxoff + 4 > g.xelems) != 0;
-    // piece u = channels u*8 + 2*wave + h of the k-block (lane half h), the thread's columns
-    int rowlane[4];
-    unsigned vconst[4][NC];
+    // piece u = channel u*RPP + rowsub of the k-block, the thread's columns
+    int rowlane[NP];
+    unsigned vconst[NP][NC];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        rowlane[u] = u * 8 + 2 * wave + h;
+    for (int u = 0; u < NP; ++u) {
+        rowlane[u] = u * RPP + rowsub;
 #pragma unroll
         for (int e = 0; e < NC; ++e) vconst[u][e] = (unsigned)(cr[e].base + shift + rowlane[u] * HW) * 4u;
     }
@@ -188,28 +202,28 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
 #pragma unroll
     for (int u = 0; u < MI; ++u) voffa[u] = (m0 + ((u * 256 + tid) >> 2) < M) ? (unsigned)(u * 256 + tid) * 16u : kBufOob;
 
-    f32x16 acc[MI][2];
+    f32x16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     struct Stage {
         u32x4 a[2][MI];
-        float gv[4][4];
+        float gv[NP][4];
         bool mk[4];        // FAST4: column e of the piece lies inside the image row (same for the 4 pieces of a step)
     };
-    Stage st[2];
+    Stage st[STAGES];
     // per-step scalars of a fetch (set by fetch_begin)
     int f_cb = 0, f_ky = 0, f_kx = 0;
     unsigned f_soff = 0, f_soffa = 0;
     bool f_rowok[NC];
     auto fetch_begin = [&](Stage& S, int tt) {
         tt = min(tt, nkb - 1);                         // prefetches beyond the end re-read the last tile (never used)
-        const int tap = cv_div(tt, g.mNCB);
-        f_cb = tt - tap * ncb;
+        f_cb = cv_div(tt, g.mT);                       // k-block tt = 32 channels f_cb*32.. at tap tt % T
+        const int tap = tt - f_cb * (g.KH * g.KW);
         f_ky = cv_div(tap, g.mKW);
         f_kx = (tap - f_ky * g.KW) * g.dil;            // from here on: the tap's offset in input pixels
         f_ky *= g.dil;
@@ -276,51 +290,53 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
         }
         u32x2 hi, lo;
         cv_split4(S.gv[u], sx, hi, lo);
-        const int kk = u * 8 + 2 * wave + h, col = 4 * c;
-        *reinterpret_cast<u32x2*>(gb + kk * CV_GROW + col) = hi;
-        *reinterpret_cast<u32x2*>(gb + GPLANE + kk * CV_GROW + col) = lo;
+        const int kk = u * RPP + rowsub, col = 4 * cg;
+        *reinterpret_cast<u32x2*>(gb + kk * GROW + col) = hi;
+        *reinterpret_cast<u32x2*>(gb + GPLANE + kk * GROW + col) = lo;
     };
     auto fetch_all = [&](Stage& S, int tt) {
         fetch_begin(S, tt);
 #pragma unroll
         for (int u = 0; u < MI; ++u) fetch_a(S, u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fetch_g(S, u, std::true_type{});
+        for (int u = 0; u < NP; ++u) fetch_g(S, u, std::true_type{});
     };
     auto commit_all = [&](Stage& S, int buf) {
 #pragma unroll
         for (int u = 0; u < MI; ++u) commit_a(S, buf, u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) commit_g(S, buf, u);
+        for (int u = 0; u < NP; ++u) commit_g(S, buf, u);
     };
 
     fetch_all(st[0], 0);
     commit_all(st[0], 0);
-    fetch_all(st[0], 1);
-    fetch_all(st[1], 2);
+    if (STAGES == 2) {
+        fetch_all(st[0], 1);
+        fetch_all(st[1], 2);
+    }
     __syncthreads();
 
     // transpose-read addressing of the gathered image (see header): 16-lane group (lane >> 4) = (column half nb, k
     // half kg); lane i of the group supplies row (i >> 2), columns 4 (i & 3) .. +3 of its 4 x 16 block
     const int li = lane & 15, nb = (lane >> 4) & 1, kg = lane >> 5;
-    const int tr_off = (8 * kg + (li >> 2)) * CV_GROW + 16 * nb + 4 * (li & 3);
+    const int tr_off = (8 * kg + (li >> 2)) * GROW + 16 * nb + 4 * (li & 3);
 
     auto step = [&](int t, Stage& S, auto edge_tag) __attribute__((always_inline)) {
         const int buf = t & 1;
         const _Float16* ab = at + buf * 2 * APLANE + (wm * (BM / 2) + c) * CV_AROW + h * 8;
-        const _Float16* gb = gt + buf * 2 * GPLANE + wn * 64 + tr_off;
+        const _Float16* gb = gt + buf * 2 * GPLANE + wn * (32 * NJ) + tr_off;
         CPH_T(ts0);
 #pragma unroll
         for (int s = 0; s < ((COCOS_CONV_ABLATE & 8) ? 0 : CV_BK / 16); ++s) {
             CPH_T(tsa);
-            f16x8 bvh[2], bvl[2];
+            f16x8 bvh[NJ], bvl[NJ];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const _Float16* p = gb + s * 16 * CV_GROW + j * 32;
+            for (int j = 0; j < NJ; ++j) {
+                const _Float16* p = gb + s * 16 * GROW + j * 32;
                 const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
-                const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * CV_GROW));
+                const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * GROW));
                 const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE));
-                const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE + 4 * CV_GROW));
+                const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE + 4 * GROW));
                 bvh[j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
                 bvl[j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
             }
@@ -330,18 +346,19 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
                 avh[i] = *reinterpret_cast<const f16x8*>(ab + i * 32 * CV_AROW + s * 16);
                 avl[i] = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * CV_AROW + s * 16);
             }
-            if (s == 1) fetch_begin(S, t + 3);
+            if (s == STAGES - 1) fetch_begin(S, t + (STAGES == 2 ? 3 : 1));
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[i], bvh[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[i], bvl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[i], bvh[j], acc[i][j], 0, 0, 0);
                 }
-                // slot i of this half step: s == 0 commits tile t+1, s == 1 fetches tile t+3
+                // slot i of this half step.  Two stages: s == 0 commits tile t+1, s == 1 fetches tile t+3;  one stage:
+                // s == 0 fetches tile t+1, s == 1 commits it
                 if (COCOS_CONV_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
-                if (s == 0) {
+                if (s == 2 - STAGES) {
                     commit_a(S, buf ^ 1, i);
 #pragma unroll
                     for (int q = 0; q < GPS; ++q) commit_g(S, buf ^ 1, i * GPS + q);
@@ -356,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
                 // one MFMA, then up to COCOS_CONV_SCHED_N instructions of any other kind, 6 * MI times: spreads the slot
                 // work of this half step evenly through the gaps of the matrix pipe
 #pragma unroll
-                for (int q = 0; q < 6 * MI; ++q) {
+                for (int q = 0; q < 3 * MI * NJ; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x010 | 0x080, COCOS_CONV_SCHED_N, 0);
                 }
@@ -365,8 +382,9 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
             CPH_ADD(s, tsa, tsb);
         }
         if (COCOS_CONV_ABLATE & 8) {
+            if (STAGES == 1) fetch_all(S, t + 1);
             commit_all(S, buf ^ 1);
-            fetch_all(S, t + 3);
+            if (STAGES == 2) fetch_all(S, t + 3);
         }
         CPH_T(ts1);
         __syncthreads();
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
         int t = 0;
         for (; t + 1 < nkb; t += 2) {
             step(t, st[0], edge_tag);
-            step(t + 1, st[1], edge_tag);
+            step(t + 1, st[STAGES - 1], edge_tag);
         }
         if (t < nkb) step(t, st[0], edge_tag);
     };
@@ -389,8 +407,8 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
     const float oscale = 1.0f / ((w_scale ? *w_scale : 1.0f) * sx);
     const int ohw = g.OH * g.OW;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + c;
+    for (int j = 0; j < NJ; ++j) {
+        const int n = n0 + wn * (32 * NJ) + j * 32 + c;
         if (n >= g.Ntot) continue;
         const int b = cv_div(n, g.mOHW);
         const int pos = n - b * g.OH * g.OWv;
@@ -409,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
 }
 
 // --------------------------------------------------------------------------------------------------------------------
-// weight gradient: partial[slice][co][k] over the slice's positions, k = tap * Cp + ci
+// weight gradient: partial[slice][co][k] over the slice's positions, k = ((ci/32) * T + tap) * 32 + ci%32
 // --------------------------------------------------------------------------------------------------------------------
 template <int BM, bool FAST4>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int k = k0 + u * 32 + (tid >> 3);
-        const int tap = cv_div(k, g.mCp), ci = k - tap * g.Cp;
+        const int cb = cv_div(k >> 5, g.mT), tap = (k >> 5) - cb * (g.KH * g.KW), ci = cb * 32 + (k & 31);
         r_ky[u] = cv_div(tap, g.mKW);
         r_kx[u] = (tap - r_ky[u] * g.KW) * g.dil;     // the tap's offset in input pixels
         r_ky[u] *= g.dil;
@@ -679,8 +697,7 @@ static int cv_geom(ConvGeom& g, int B, int Cin, int H, int W, int Cout, int KH, 
     g.Ktot = (int)ktot;
     g.Ntot = (int)ntot;
     g.xelems = B * Cin * H * W;
-    g.mNCB = cv_magic(g.Cp / 32); g.mKW = cv_magic(KW); g.mOHW = cv_magic(g.OH * g.OWv); g.mOW = cv_magic(g.OWv);
-    g.mCp = cv_magic(g.Cp);
+    g.mT = cv_magic(KH * KW); g.mKW = cv_magic(KW); g.mOHW = cv_magic(g.OH * g.OWv); g.mOW = cv_magic(g.OWv);
     return COCOS_OK;
 }
 
@@ -701,21 +718,29 @@ extern "C" int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const vo
     COCOS_REQUIRE(aligned16(w_hi) && aligned16(w_lo), COCOS_ERR_INVALID,
                   "conv2d_fwd_f16x3: weight planes must be 16-byte aligned");
     const bool fast4 = stride == 1;
+    // tile: BM = 256 rows for wide layers, BN = 128 positions.  The 256 x 256 tile (wave tile 128 x 128: each LDS operand
+    // is re-read half as often per MFMA, all 256 accumulator registers in use, one register stage) exists and is
+    // tested, but measured no faster on the 407-channel block (0.466 vs 0.470 ms) and slower on its input gradient
+    // (fewer, longer workgroups): COCOS_CONV_BN=256 selects it for experiments.
     const int bm = Cout > 128 ? 256 : 128;
-    const long long blocks = (long long)((Cout + bm - 1) / bm) * ((g.Ntot + CV_BN - 1) / CV_BN);
+    const long long mt = (Cout + bm - 1) / bm;
+    const char* force = getenv("COCOS_CONV_BN");
+    const int bn = (force && atoi(force) == 256 && bm == 256) ? 256 : 128;
+    const long long blocks = mt * ((g.Ntot + bn - 1) / bn);
     COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "conv2d_fwd_f16x3: grid too large");
     hipStream_t s = as_stream(stream);
-#define COCOS_GO(BMv, F4)                                                                                          \
+#define COCOS_GO(BMv, BNv, F4)                                                                                     \
     do {                                                                                                           \
-        auto kern = conv_fwd_kernel<BMv, F4>;                                                                      \
-        const size_t smem = (size_t)2 * 2 * (BMv * CV_AROW + CV_BK * CV_GROW) * sizeof(_Float16);                  \
+        auto kern = conv_fwd_kernel<BMv, BNv, F4>;                                                                 \
+        const size_t smem = (size_t)2 * 2 * (BMv * CV_AROW + CV_BK * (BNv + 32)) * sizeof(_Float16);               \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));              \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, x, static_cast<const _Float16*>(w_hi), \
                            static_cast<const _Float16*>(w_lo), w_scale_dev, x_amax_dev, bias, y, Cout, g);         \
     } while (0)
-    if (bm == 256) { if (fast4) COCOS_GO(256, true); else COCOS_GO(256, false); }
-    else           { if (fast4) COCOS_GO(128, true); else COCOS_GO(128, false); }
+    if (bm == 256 && bn == 256) { if (fast4) COCOS_GO(256, 256, true); else COCOS_GO(256, 256, false); }
+    else if (bm == 256)         { if (fast4) COCOS_GO(256, 128, true); else COCOS_GO(256, 128, false); }
+    else                        { if (fast4) COCOS_GO(128, 128, true); else COCOS_GO(128, 128, false); }
 #undef COCOS_GO
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;

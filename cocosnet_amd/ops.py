@@ -679,15 +679,15 @@ def proj1x1(x, weight, bias=None):
 #      ResidualBlock (correspondence.py:13-36), adaptor convolutions (:150-173), PatchGAN (discriminator.py:92-115)
 # ------------------------------------------------------------------------------------------
 def _weight_planes(wt, amax):
-    """wt [M, T, C] fp32 (rows, taps, channels) -> f16 hi/lo planes in K16's layout: k = tap * Cp + c with the
-    channels zero-padded to Cp = 32 * ceil(C / 32), k-block major [K/32][M][32] (the M x 32 tile of a k-block is one
-    contiguous piece), + their device-side power-of-two scale."""
+    """wt [M, T, C] fp32 (rows, taps, channels) -> f16 hi/lo planes in K16's layout: channels zero-padded to
+    Cp = 32 * ceil(C / 32), k-blocks of 32 channels at one tap ordered (channel block, tap), k-block major
+    [K/32][M][32] (the M x 32 tile of a k-block is one contiguous piece), + their device-side power-of-two scale."""
     M, T, C = wt.shape
     cp = (C + 31) // 32 * 32
     if cp != C:
         wt = torch.nn.functional.pad(wt, (0, cp - C))
     nkb = T * cp // 32
-    wb = wt.reshape(M, nkb, 32).permute(1, 0, 2).contiguous()
+    wb = wt.reshape(M, T, cp // 32, 32).permute(2, 1, 0, 3).reshape(nkb, M, 32).contiguous()
     wh = torch.empty((nkb, M, 32), device=wt.device, dtype=torch.float16)
     wl = torch.empty_like(wh)
     ws = torch.empty(1, device=wt.device, dtype=torch.float32)
@@ -758,8 +758,10 @@ class _Conv2d(torch.autograd.Function):
             part = torch.empty((S, Cout, kdim), device=x.device, dtype=torch.float32)
             _call("conv2d_wgrad", "cocos_conv2d_wgrad_f16x3", x.data_ptr(), dy.data_ptr(), xa.data_ptr(), ga.data_ptr(),
                   part.data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, pad, dil, _stream())
-            dwk = part.sum(0) if S > 1 else part[0]                  # [Cout, T * Cp], k = tap * Cp + ci
-            dw = dwk.reshape(Cout, KH, KW, kdim // (KH * KW))[..., :Cin].permute(0, 3, 1, 2).contiguous()
+            dwk = part.sum(0) if S > 1 else part[0]                  # [Cout, K], k = ((ci/32) * T + tap) * 32 + ci%32
+            T = KH * KW
+            dw = (dwk.reshape(Cout, kdim // (32 * T), T, 32).permute(0, 1, 3, 2).reshape(Cout, kdim // T, KH, KW)[:, :Cin]
+                  .contiguous())
         if need_b and has_bias:
             db = dy.sum((0, 2, 3))
         return dx, dw, db, None, None, None

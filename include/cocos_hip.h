@@ -409,8 +409,9 @@ int cocos_contextual_rows_bwd(const float* cosm, const float* dcx, float* dcos, 
  *     networks in front of and behind the path: ResidualBlock (correspondence.py:13-36: ReflectionPad2d(1) stays a
  *     host-side pad, the 3x3 convolution is this kernel with pad = 0), the adaptor layers (correspondence.py:150-173)
  *     and the k4 s2 layers of the PatchGAN (discriminator.py:92-115).
- *   The contraction index is tap-major:  k = (ky*KW + kx) * Cp + ci,  Cp = Cin rounded up to 32,
- *   K = cocos_conv2d_kdim(Cin,KH,KW) = KH*KW*Cp (a k-block of 32 is 32 channels at one tap).
+ *   The contraction index runs over blocks of 32 channels, taps inside:  k = ((ci/32) * T + ky*KW + kx) * 32 + ci%32,
+ *   T = KH*KW, channels zero-padded to Cp = 32*ceil(Cin/32), K = cocos_conv2d_kdim(Cin,KH,KW) = T*Cp (a k-block of 32
+ *   is 32 channels at one tap; consecutive k-blocks re-read the same channels).
  *   fwd:   x [B,Cin,H,W] fp32, weight planes w_hi/w_lo [K/32][Cout][32] f16 (k-block major so that a tile's rows are
  *          contiguous; zero for ci >= Cin): cocos_split_f16_rows of the re-laid-out weight matrix, whose *scale_out
  *          goes to w_scale_dev (NULL = 1), x_amax_dev = max|x| (NULL: x is O(1)), bias [Cout] or NULL

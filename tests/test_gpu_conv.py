@@ -61,6 +61,27 @@ def test_conv2d_matches_fp64(case, with_bias):
         close(b.grad, dbr, "db")
 
 
+@pytest.mark.parametrize("case", [(2, 407, 66, 66, 407, 3, 1, 0), (1, 130, 20, 24, 140, 3, 1, 1), (2, 40, 9, 11, 200, 3, 2, 1)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_wide_tile_matches_fp64(case, monkeypatch):
+    """The 256 x 256 tile of the forward / input-gradient kernel (picked for wide layers on large grids), forced here
+    through COCOS_CONV_BN on shapes that finish quickly — including ragged ones that leave most of a tile empty."""
+    from cocosnet_amd import ops
+    monkeypatch.setenv("COCOS_CONV_BN", "256")
+    B, Cin, H, W, Cout, k, stride, pad = case
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, Cin, H, W, device="cuda", generator=g).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, device="cuda", generator=g).requires_grad_(True)
+    y = ops.conv2d(x, w, b, stride, pad)
+    go = torch.randn(y.shape, device="cuda", generator=g)
+    y.backward(go)
+    yr, dxr, dwr, dbr = _ref(x.detach(), w.detach(), b.detach(), stride, pad, go)
+    for a, r, what in ((y, yr, "y"), (x.grad, dxr, "dx"), (w.grad, dwr, "dw"), (b.grad, dbr, "db")):
+        err = (a.double() - r).abs().max().item()
+        assert err <= 1e-5 * r.abs().max().item(), f"{what}: {err:.3e}"
+
+
 def test_conv2d_operand_ranges():
     """Operands far from O(1): the device-side power-of-two scales keep the f16 planes in range."""
     from cocosnet_amd import ops
