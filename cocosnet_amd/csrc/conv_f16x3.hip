@@ -146,9 +146,9 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
                                                           const float* __restrict__ bias, float* __restrict__ Y, int M,
                                                           ConvGeom g) {
     constexpr int MI = BM / 64, NJ = BN / 64;          // 32 x 32 blocks of a wave's tile (waves as 2 x 2)
-    // register stages: 2 (see above) while they fit; the 256 x 256 tile keeps all 256 accumulator registers and
-    // has ONE: step t fetches tile t+1 under its first half and commits it under the second (a step is twice as long)
-    constexpr int STAGES = COCOS_CONV_STAGES ? COCOS_CONV_STAGES : ((MI * NJ == 16) ? 1 : 2);
+    // register stages: ONE (a tile fetched under the second half of step t is committed under the first half of step
+    // t+1); two measured slower once the fragments were double-buffered (0.455 vs 0.442 ms: register spills)
+    constexpr int STAGES = COCOS_CONV_STAGES ? COCOS_CONV_STAGES : 1;
     constexpr int LPR = BN / 4;                        // lanes per k row of the gathered tile (4 positions each)
     constexpr int RPP = 256 / LPR;                     // k rows per pass of the 256 threads
     constexpr int NP = CV_BK / RPP;                    // gathered pieces per thread (4 | 8)
@@ -310,10 +310,8 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
 
     fetch_all(st[0], 0);
     commit_all(st[0], 0);
-    if (STAGES == 2) {
-        fetch_all(st[0], 1);
-        fetch_all(st[1], 2);
-    }
+    fetch_all(st[0], 1);
+    if (STAGES == 2) fetch_all(st[1], 2);
     __syncthreads();
 
     // transpose-read addressing of the gathered image (see header): 16-lane group (lane >> 4) = (column half nb, k
@@ -321,44 +319,59 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
     const int li = lane & 15, nb = (lane >> 4) & 1, kg = lane >> 5;
     const int tr_off = (8 * kg + (li >> 2)) * GROW + 16 * nb + 4 * (li & 3);
 
-    auto step = [&](int t, Stage& S, auto edge_tag) __attribute__((always_inline)) {
-        const int buf = t & 1;
+    // MFMA operand fragments of one 16-wide k half-step: F[0] = k 0..15, F[1] = k 16..31 of the tile
+    f16x8 fah[2][MI], fal[2][MI], fbh[2][NJ], fbl[2][NJ];
+    auto read_frags = [&](int buf, int s) __attribute__((always_inline)) {
         const _Float16* ab = at + buf * 2 * APLANE + (wm * (BM / 2) + c) * CV_AROW + h * 8;
         const _Float16* gb = gt + buf * 2 * GPLANE + wn * (32 * NJ) + tr_off;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const _Float16* p = gb + s * 16 * GROW + j * 32;
+            const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+            const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * GROW));
+            const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE));
+            const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE + 4 * GROW));
+            fbh[s][j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+            fbl[s][j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            fah[s][i] = *reinterpret_cast<const f16x8*>(ab + i * 32 * CV_AROW + s * 16);
+            fal[s][i] = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * CV_AROW + s * 16);
+        }
+    };
+    // One step = one k-block of 32, ONE barrier, in its middle.  The operand fragments run half a step ahead of the MFMAs:
+    //   first half : MFMAs of k 0..15 (fragments read during the previous step) | reads the k 16..31 fragments of this
+    //                tile | commits the staged tile t+1 to the other LDS buffer (its last readers passed the previous
+    //                barrier with their fragments already in registers)
+    //   barrier    : tile t+1 is visible; nobody reads tile t from LDS any more
+    //   second half: MFMAs of k 16..31 | reads the k 0..15 fragments of tile t+1 | fetches tile t+1+STAGES from memory
+    // so neither the LDS reads nor the barrier leave the matrix pipe idle (the earlier shape — barrier, read, multiply —
+    // paid the LDS latency of all four waves at once after every barrier).
+    auto step = [&](int t, Stage& S, auto edge_tag) __attribute__((always_inline)) {
+        const int buf = t & 1;
         CPH_T(ts0);
 #pragma unroll
-        for (int s = 0; s < ((COCOS_CONV_ABLATE & 8) ? 0 : CV_BK / 16); ++s) {
+        for (int s = 0; s < 2; ++s) {
             CPH_T(tsa);
-            f16x8 bvh[NJ], bvl[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const _Float16* p = gb + s * 16 * GROW + j * 32;
-                const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
-                const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * GROW));
-                const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE));
-                const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE + 4 * GROW));
-                bvh[j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-                bvl[j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+            if (!(COCOS_CONV_ABLATE & 8)) {
+                if (s == 0) read_frags(buf, 1); else read_frags(buf ^ 1, 0);
             }
-            f16x8 avh[MI], avl[MI];
+            if (s == 1) fetch_begin(S, t + 1 + STAGES);
+            // program order: the fragment reads, then per row block its MFMAs followed by a slice of the staging work
+            // (first half: commits, second half: fetches); the pipeline below then hands the non-MFMA instructions out in
+            // that order, a few per MFMA.  (Measured: all loads first, then reads, then MFMAs: 0.499 instead of 0.442 ms.)
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                avh[i] = *reinterpret_cast<const f16x8*>(ab + i * 32 * CV_AROW + s * 16);
-                avl[i] = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * CV_AROW + s * 16);
-            }
-            if (s == STAGES - 1) fetch_begin(S, t + (STAGES == 2 ? 3 : 1));
+                if (!(COCOS_CONV_ABLATE & 8)) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[i], bvh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[i], bvl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[i], bvh[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
+                    }
                 }
-                // slot i of this half step.  Two stages: s == 0 commits tile t+1, s == 1 fetches tile t+3;  one stage:
-                // s == 0 fetches tile t+1, s == 1 commits it
-                if (COCOS_CONV_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
-                if (s == 2 - STAGES) {
+                if (s == 0) {
                     commit_a(S, buf ^ 1, i);
 #pragma unroll
                     for (int q = 0; q < GPS; ++q) commit_g(S, buf ^ 1, i * GPS + q);
@@ -367,11 +380,10 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
 #pragma unroll
                     for (int q = 0; q < GPS; ++q) fetch_g(S, i * GPS + q, edge_tag);
                 }
-                if (COCOS_CONV_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
             }
-            if (COCOS_CONV_SCHED == 1) {
-                // one MFMA, then up to COCOS_CONV_SCHED_N instructions of any other kind, 6 * MI times: spreads the slot
-                // work of this half step evenly through the gaps of the matrix pipe
+            if (!(COCOS_CONV_ABLATE & 8)) {
+                // one MFMA, then up to COCOS_CONV_SCHED_N instructions of any other kind (a wave that owns its SIMD issues
+                // about one instruction per 4-5 cycles: ~7 fit beside a 32-cycle MFMA)
 #pragma unroll
                 for (int q = 0; q < 3 * MI * NJ; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -380,20 +392,19 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
             }
             CPH_T(tsb);
             CPH_ADD(s, tsa, tsb);
+            if (s == 0) {
+                CPH_T(ts1);
+                __syncthreads();
+                CPH_T(ts2);
+                CPH_ADD(2, ts1, ts2);
+            }
         }
-        if (COCOS_CONV_ABLATE & 8) {
-            if (STAGES == 1) fetch_all(S, t + 1);
-            commit_all(S, buf ^ 1);
-            if (STAGES == 2) fetch_all(S, t + 3);
-        }
-        CPH_T(ts1);
-        __syncthreads();
-        CPH_T(ts2);
-        CPH_ADD(2, ts1, ts2);
-        CPH_ADD(3, ts0, ts2);
+        CPH_T(ts3);
+        CPH_ADD(3, ts0, ts3);
         CPH_ADD(4, 0, 1);
     };
     auto run = [&](auto edge_tag) __attribute__((always_inline)) {
+        read_frags(0, 0);
         int t = 0;
         for (; t + 1 < nkb; t += 2) {
             step(t, st[0], edge_tag);
