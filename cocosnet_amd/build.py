@@ -113,13 +113,15 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     return LIB_PATH
 
 
-def build_oracle(verbose: bool = True) -> str | None:
-    """Compile oracle/'s C restatement (test infrastructure, never loaded by the product)."""
-    mk = os.path.join(REPO_DIR, "oracle", "Makefile")
-    if not os.path.exists(mk):
-        return None
-    subprocess.run(["make", "-s", "-C", os.path.dirname(mk)], check=True)
-    return os.path.join(REPO_DIR, "oracle", "libcocos_oracle.so")
+def build_oracle(verbose: bool = True) -> None:
+    """Nothing to compile: the oracle (oracle/corr_oracle.py, oracle/torch_ref.py) is numpy / torch, and the reference
+    it is pinned against is pure Python (no oracle/_ref build).  Kept because __graft_entry__.build() calls it as the
+    "build the checker" step; it only checks that the files are there (the package never imports the oracle)."""
+    missing = [f for f in ("corr_oracle.py", "torch_ref.py") if not os.path.exists(os.path.join(REPO_DIR, "oracle", f))]
+    if missing:
+        raise FileNotFoundError(f"oracle/: missing {missing}")
+    if verbose:
+        print("[build] oracle: numpy/torch restatements present (nothing to compile)", flush=True)
 
 
 if __name__ == "__main__":
