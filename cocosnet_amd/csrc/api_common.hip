@@ -36,7 +36,7 @@ __global__ void mfma_probe_kernel(float* out) {
 
 }  // namespace cocos
 
-extern "C" int cocos_version(void) { return 300; /* 0.3.0: split-precision (f16x3) flavour of K2, K3, K7, K0; operand planes; K8-K12 */ }
+extern "C" int cocos_version(void) { return 400; /* 0.4.0 (round 2): K2 split kernels take a device-side V scale and a private saved-logits layout (signatures changed); K15 contextual rows; K16 convolution */ }
 
 extern "C" const char* cocos_last_error_string(void) { return cocos::last_error().c_str(); }
 

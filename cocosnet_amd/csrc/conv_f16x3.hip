@@ -43,6 +43,12 @@
 #ifndef COCOS_CONV_SCHED_N
 #define COCOS_CONV_SCHED_N 6
 #endif
+#ifndef COCOS_CONV_MFMA_ORDER
+#define COCOS_CONV_MFMA_ORDER 1
+#endif
+#ifndef COCOS_CONV_OCC2
+#define COCOS_CONV_OCC2 1       // 128-row tiles: two workgroups per CU (2 waves per SIMD, 80 KB of LDS each)
+#endif
 #ifndef COCOS_CONV_STAGES
 #define COCOS_CONV_STAGES 0     // 0: per tile shape (see conv_fwd_kernel); 1 | 2: forced (timing experiments)
 #endif
@@ -140,7 +146,7 @@ __device__ __forceinline__ f32x4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned b
 // >= 0 (the step offset travels in the scalar offset, which the hardware does not range-check): nothing below X is ever
 // dereferenced — a lane whose window corner lies outside the image is masked to the out-of-range offset.
 template <int BM, int BN, bool FAST4>
-__global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restrict__ X, const _Float16* __restrict__ wh,
+__global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void conv_fwd_kernel(const float* __restrict__ X, const _Float16* __restrict__ wh,
                                                           const _Float16* __restrict__ wl,
                                                           const float* __restrict__ w_scale, const float* __restrict__ x_amax,
                                                           const float* __restrict__ bias, float* __restrict__ Y, int M,
@@ -364,12 +370,23 @@ __global__ __launch_bounds__(256, 1) void conv_fwd_kernel(const float* __restric
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 if (!(COCOS_CONV_ABLATE & 8)) {
+#if COCOS_CONV_MFMA_ORDER == 0
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s][j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
                     }
+#else
+                    // term-major: two MFMAs on the same accumulator are never neighbours (an instruction issued between
+                    // two dependent MFMAs costs a ~43-cycle bubble on gfx950; between independent ones ~6)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
+#endif
                 }
                 if (s == 0) {
                     commit_a(S, buf ^ 1, i);
@@ -733,7 +750,8 @@ extern "C" int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const vo
     // is re-read half as often per MFMA, all 256 accumulator registers in use, one register stage) exists and is
     // tested, but measured no faster on the 407-channel block (0.466 vs 0.470 ms) and slower on its input gradient
     // (fewer, longer workgroups): COCOS_CONV_BN=256 selects it for experiments.
-    const int bm = Cout > 128 ? 256 : 128;
+    const char* force_bm = getenv("COCOS_CONV_BM");
+    const int bm = (force_bm && atoi(force_bm) == 128) ? 128 : (Cout > 128 ? 256 : 128);
     const long long mt = (Cout + bm - 1) / bm;
     const char* force = getenv("COCOS_CONV_BN");
     const int bn = (force && atoi(force) == 256 && bm == 256) ? 256 : 128;

@@ -5,8 +5,10 @@ threads, synthetic inputs of BASELINE config 1 (ADE20k flags, 256x256, batchSize
   (ii)  netCorr = NoVGGCorrespondence: forward (inference) and forward + backward;
   (iii) the hot path alone, through the reference's own lines (correspondence.py:272-336 restated in
         oracle/torch_ref.py, which tests/test_oracle_golden.py pins to the reference's outputs).
-The facade (i) Pix2PixModel(mode='inference') additionally needs netG; it is attempted and skipped with the reason
-if the option surface cannot be satisfied without torchvision.
+  (i)   the facade Pix2PixModel(data, mode='inference') (netCorr + netG) with the README's ADE20k test flags; the
+        literal `test.py --gpu_ids -1` is not runnable (torchvision absent, label_ref dtype defect
+        pix2pix_model.py:172-187), so the options come from the reference's own parser defaults and the inputs are
+        built here with an int64 label_ref.
 Output: one JSON document (committed as profiles/r02_reference_cpu_baseline.json).
     python -m oracle.time_reference_cpu [--runs 10] [--warmup 3] [--batch 2]
 """
@@ -85,16 +87,38 @@ def main():
     import bench
     cb = bench.cpu_baseline(runs=args.runs, batch=B)
     out["results"]["hot_path_forward_backward_mk1"] = cb
-    # (i) facade
+    # (i) the facade: Pix2PixModel(data, mode='inference') with the README's ADE20k test flags, B images, int64 label_ref
     try:
-        networks = rh.load_reference()
+        import contextlib
         import importlib
-        p2p = importlib.import_module("models.pix2pix_model")
-        out["results"]["pix2pix_inference"] = {"skipped": "needs the full option parser + netG; see netCorr rows "
-                                               "(BASELINE.md section 2 has the survey-time facade figure)"} \
-            if not hasattr(p2p, "Pix2PixModel") else {"skipped": "facade construction not attempted in this script: "
-                                                      "Pix2PixModel.__init__ loads VGG weights via torchvision "
-                                                      "(absent); netCorr + hot path are timed instead"}
+        networks = rh.load_reference()
+        with rh._cwd(rh.REFERENCE_ROOT):
+            to = importlib.import_module("options.test_options")
+            parser = to.TestOptions().initialize(argparse.ArgumentParser())
+            parser = networks.modify_commandline_options(parser, False)
+            opt, _ = parser.parse_known_args([])
+            for k, v in dict(name="ade20k", dataset_mode="ade20k", gpu_ids=[], use_attention=True, maskmix=True,
+                             warp_mask_losstype="direct", PONO=True, PONO_C=True, batchSize=B, isTrain=False,
+                             semantic_nc=151, label_nc=150, contain_dontcare_label=True, no_instance=True, crop_size=256,
+                             load_size=256, aspect_ratio=1.0, adaptor_nonlocal=True).items():
+                setattr(opt, k, v)
+            p2p = importlib.import_module("models.pix2pix_model")
+            g = torch.Generator().manual_seed(0)
+            blk = lambda: torch.randint(0, 151, (B, 1, 16, 16), generator=g).repeat_interleave(16, 2).repeat_interleave(16, 3)
+            data = {"label": blk().long(), "label_ref": blk().long(), "image": torch.rand(B, 3, 256, 256, generator=g) * 2 - 1,
+                    "ref": torch.rand(B, 3, 256, 256, generator=g) * 2 - 1, "self_ref": torch.zeros(B), "path": ["x"] * B}
+            for mk in (1, 3):
+                opt.match_kernel = mk
+                torch.manual_seed(0)
+                with contextlib.redirect_stdout(None):
+                    model = p2p.Pix2PixModel(opt).eval()
+
+                def run():
+                    with torch.no_grad():
+                        return model(data, mode="inference")
+                r = timed(run, max(3, args.runs // 2), 1)
+                r["images_per_s"] = B / r["median_s"]
+                out["results"][f"pix2pix_inference_mk{mk}"] = r
     except Exception as e:       # noqa: BLE001
         out["results"]["pix2pix_inference"] = {"skipped": repr(e)}
     print(json.dumps(out, indent=1))
