@@ -126,6 +126,8 @@ _SIGNATURES = {
                                                  ctypes.c_float, _stream_t]),
     "cocos_contextual_rows_bwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_float,
                                                                    ctypes.c_float, _stream_t]),
+    "cocos_spade_modulate_fwd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_longlong, ctypes.c_float, _stream_t]),
+    "cocos_spade_modulate_bwd": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_longlong, ctypes.c_float, _stream_t]),
     "cocos_conv2d_out_size": (ctypes.c_int, [ctypes.c_int] * 5),
     "cocos_conv2d_kdim": (ctypes.c_int, [ctypes.c_int] * 3),
     "cocos_conv2d_fwd_f16x3": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p,

@@ -48,6 +48,7 @@ HIP_SOURCES = [
     "warp_values.hip",
     "contextual_rows.hip",
     "conv_f16x3.hip",
+    "spade_modulate.hip",
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              "-Wall", "-Wno-unused-function"]
@@ -114,14 +115,15 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
 
 
 def build_oracle(verbose: bool = True) -> None:
-    """Nothing to compile: the oracle (oracle/corr_oracle.py, oracle/torch_ref.py) is numpy / torch, and the reference
-    it is pinned against is pure Python (no oracle/_ref build).  Kept because __graft_entry__.build() calls it as the
-    "build the checker" step; it only checks that the files are there (the package never imports the oracle)."""
-    missing = [f for f in ("corr_oracle.py", "torch_ref.py") if not os.path.exists(os.path.join(REPO_DIR, "oracle", f))]
-    if missing:
-        raise FileNotFoundError(f"oracle/: missing {missing}")
+    """Nothing to compile: the oracle under oracle/ is numpy / torch, and the reference it is pinned against is pure
+    Python (no oracle/_ref build).  Kept because __graft_entry__.build() calls it as the "build the checker" step; it
+    only checks that the directory has its Python files (the package never imports it)."""
+    odir = os.path.join(REPO_DIR, "oracle")
+    have = [f for f in os.listdir(odir) if f.endswith(".py")] if os.path.isdir(odir) else []
+    if len(have) < 2:
+        raise FileNotFoundError(f"{odir}: the CPU restatements are missing")
     if verbose:
-        print("[build] oracle: numpy/torch restatements present (nothing to compile)", flush=True)
+        print(f"[build] oracle: {len(have)} Python files present (nothing to compile)", flush=True)
 
 
 if __name__ == "__main__":

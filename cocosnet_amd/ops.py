@@ -1009,6 +1009,36 @@ def pono_spade(x, gamma, beta, slope: float = 1.0, eps: float = PONO_EPS):
     return _PonoSpade.apply(x, gamma, beta, slope, eps)
 
 
+class _SpadeModulate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xh, gamma, beta, slope: float):
+        xh, gamma, beta = (_chk(t, f"spade_modulate: {n}") for t, n in ((xh, "xh"), (gamma, "gamma"), (beta, "beta")))
+        if gamma.shape != xh.shape or beta.shape != xh.shape:
+            raise ValueError(f"spade_modulate: xh{tuple(xh.shape)} gamma{tuple(gamma.shape)} beta{tuple(beta.shape)}")
+        y = torch.empty_like(xh)
+        _call("spade_modulate_fwd", "cocos_spade_modulate_fwd", xh.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+              y.data_ptr(), xh.numel(), float(slope), _stream())
+        ctx.save_for_backward(xh, gamma, beta)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, gamma, beta = ctx.saved_tensors
+        dy = _chk(dy, "spade_modulate: dy")
+        need = ctx.needs_input_grad[:3]
+        outs = [torch.empty_like(xh) if w else None for w in need]
+        _call("spade_modulate_bwd", "cocos_spade_modulate_bwd", xh.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+              dy.data_ptr(), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), xh.numel(), ctx.slope, _stream())
+        return outs[0], outs[1], outs[2], None
+
+
+def spade_modulate(xh, gamma, beta, slope: float = 1.0):
+    """leaky_relu(xh * (1 + gamma) + beta, slope) where xh is ALREADY normalised (instance / batch / sync-batch norm):
+    the non-PONO tail of SPADE.forward (normalization.py:148) + the block's activation, one pass each way (K17)."""
+    return _SpadeModulate.apply(xh, gamma, beta, slope)
+
+
 # ------------------------------------------------------------------------------------------
 # K11 nearest-neighbour up-sampling of the warped image   (correspondence.py:188, :327)
 # ------------------------------------------------------------------------------------------

@@ -28,14 +28,17 @@ def _hip_ok(*ts) -> bool:
 
 def modulate(x, gamma, beta, pono: bool, param_free_norm=None, slope: float = 1.0):
     """leaky_relu(norm(x) * (1 + gamma) + beta, slope): the tail of SPADE.forward (+ the block's activation).
-    pono: PositionalNorm2d — fused with the modulation and the activation in K9 when x is CUDA fp32."""
+    pono: PositionalNorm2d — fused with the modulation and the activation in K9 when x is CUDA fp32; otherwise the
+    norm stays the module's own and the modulation + activation are K17."""
     if pono and _hip_ok(x, gamma, beta) and gamma.shape == x.shape and beta.shape == x.shape:
         return ops.pono_spade(x, gamma, beta, slope)
     if pono:
         mu = x.mean(dim=1, keepdim=True)                              # normalization.py:63-68
         normalized = (x - mu) / x.var(dim=1, keepdim=True).add(1e-5).sqrt()
     else:
-        normalized = param_free_norm(x)
+        normalized = param_free_norm(x)                               # instance | batch | sync-batch (normalization.py:93-101)
+        if _hip_ok(normalized, gamma, beta) and gamma.shape == normalized.shape and beta.shape == normalized.shape:
+            return ops.spade_modulate(normalized, gamma, beta, slope)  # K17: modulation + activation in one pass
     y = normalized * (1 + gamma) + beta                               # normalization.py:148
     return y if slope == 1.0 else F.leaky_relu(y, slope)
 

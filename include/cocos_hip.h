@@ -403,6 +403,17 @@ int cocos_contextual_rows_bwd(const float* cosm, const float* dcx, float* dcos, 
                               float eps, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * K17 SPADE modulation + LeakyReLU behind any parameter-free norm (the non-PONO branch of SPADE, normalization.py
+ *     :93-101 instance | syncbatch | batch, then :148 and architecture.py:88-95): xh = the normalised activations,
+ *     gamma, beta, y and the gradients all hold n fp32 elements (same shape).
+ *   fwd: y = leaky_relu(xh*(1+gamma) + beta, slope)       bwd: dxh, dgamma, dbeta (any may be NULL), z recomputed
+ * ------------------------------------------------------------------------------------- */
+int cocos_spade_modulate_fwd(const float* xh, const float* gamma, const float* beta, float* y, long long n, float slope,
+                             cocos_stream_t stream);
+int cocos_spade_modulate_bwd(const float* xh, const float* gamma, const float* beta, const float* dy, float* dxh,
+                             float* dgamma, float* dbeta, long long n, float slope, cocos_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * K16 2-D convolution (cross-correlation, zero padding, like torch.nn.functional.conv2d with groups = 1, one stride /
  *     padding / dilation for both axes)
  *     as an implicit GEMM on the f16 MFMA with split operands (conv_f16x3.hip).  Replaces the nn.Conv2d calls of the

@@ -106,3 +106,30 @@ def test_conv2d_rejects_bad_arguments():
         ops.conv2d(torch.randn(1, 4, 2, 2, device="cuda"), torch.randn(4, 4, 3, 3, device="cuda"))
     with pytest.raises(Exception, match="no CPU fallback"):
         ops.conv2d(x.cpu(), torch.randn(4, 4, 3, 3))
+
+
+@pytest.mark.parametrize("shape,slope", [((2, 16, 12, 12), 0.2), ((1, 5, 7, 9), 1.0), ((3, 64, 32, 32), 0.2)])
+def test_spade_modulate_matches_torch_fp64(shape, slope):
+    """K17: leaky_relu(xh*(1+gamma)+beta) and its three gradients (normalization.py:148 + architecture.py:88-95)."""
+    from cocosnet_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    xh, ga, be = (torch.randn(shape, device="cuda", generator=g).requires_grad_(True) for _ in range(3))
+    y = ops.spade_modulate(xh, ga, be, slope)
+    go = torch.randn(shape, device="cuda", generator=g)
+    y.backward(go)
+    xd, gd, bd = (t.detach().double().requires_grad_(True) for t in (xh, ga, be))
+    yr = F.leaky_relu(xd * (1 + gd) + bd, slope)
+    yr.backward(go.double())
+    for a, r in ((y, yr), (xh.grad, xd.grad), (ga.grad, gd.grad), (be.grad, bd.grad)):
+        assert (a.double() - r.detach()).abs().max().item() <= 1e-5 * max(r.abs().max().item(), 1.0)
+
+
+def test_spade_forward_instance_norm_branch_uses_the_kernels():
+    """spade.modulate with a parameter-free InstanceNorm (non-PONO SPADE): same result as the torch formulation."""
+    from cocosnet_amd import spade
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x, ga, be = (torch.randn(2, 8, 16, 16, device="cuda", generator=g) for _ in range(3))
+    norm = torch.nn.InstanceNorm2d(8, affine=False)
+    y = spade.modulate(x, ga, be, False, norm, 0.2)
+    ref = F.leaky_relu(norm(x.double()) * (1 + ga.double()) + be.double(), 0.2)
+    assert (y.double() - ref).abs().max().item() < 1e-5
