@@ -46,6 +46,10 @@
 #ifndef COCOS_CONV_MFMA_ORDER
 #define COCOS_CONV_MFMA_ORDER 1
 #endif
+#ifndef COCOS_CONV_WGRAD_PIPE
+#define COCOS_CONV_WGRAD_PIPE 0  // weight gradient: 1 = the forward kernel's step shape (mid barrier, fragments half a step ahead, one stage):
+                                // measured neutral (1.591 vs 1.582 ms fwd+bwd) and it spills, so 0 = barrier at the end, two stages
+#endif
 #ifndef COCOS_CONV_OCC2
 #define COCOS_CONV_OCC2 1       // 128-row tiles: two workgroups per CU (2 waves per SIMD, 80 KB of LDS each)
 #endif
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
     }
 
     struct Stage { float a[APT][4]; float gv[4][4]; int xs[4]; };
-    Stage st[2];
+    Stage st[COCOS_CONV_WGRAD_PIPE ? 1 : 2];
     constexpr int NC = FAST4 ? 1 : 4;
     Corner f_cr[NC];
     bool f_live[NC];
@@ -612,40 +616,49 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
     };
 
     const int nsteps = (max(nend - nbeg, 0) + CV_BK - 1) / CV_BK;
+    constexpr int WSTAGES = COCOS_CONV_WGRAD_PIPE ? 1 : 2;
     // positions at or beyond nend are masked (f_live), so prefetches past the last step are harmless
     fetch_all(st[0], nbeg);
     commit_all(st[0], 0);
     fetch_all(st[0], nbeg + CV_BK);
-    fetch_all(st[1], nbeg + 2 * CV_BK);
+    if (WSTAGES == 2) fetch_all(st[1], nbeg + 2 * CV_BK);
     __syncthreads();
 
-    auto step = [&](int t, Stage& S, auto edge_tag) __attribute__((always_inline)) {
-        const int buf = t & 1;
+    f16x8 fah[2][MI], fal[2][MI], fbh[2][2], fbl[2][2];
+    auto read_frags = [&](int buf, int s) __attribute__((always_inline)) {
         const _Float16* ab = at + buf * 2 * APLANE + (wm * (BM / 2) + c) * CV_AROW + h * 8;
         const _Float16* bb = bt + buf * 2 * BPLANE + (wn * 64 + c) * CV_AROW + h * 8;
 #pragma unroll
-        for (int s = 0; s < CV_BK / 16; ++s) {
-            f16x8 bvh[2], bvl[2], avh[MI], avl[MI];
+        for (int j = 0; j < 2; ++j) {
+            fbh[s][j] = *reinterpret_cast<const f16x8*>(bb + j * 32 * CV_AROW + s * 16);
+            fbl[s][j] = *reinterpret_cast<const f16x8*>(bb + BPLANE + j * 32 * CV_AROW + s * 16);
+        }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bvh[j] = *reinterpret_cast<const f16x8*>(bb + j * 32 * CV_AROW + s * 16);
-                bvl[j] = *reinterpret_cast<const f16x8*>(bb + BPLANE + j * 32 * CV_AROW + s * 16);
+        for (int i = 0; i < MI; ++i) {
+            fah[s][i] = *reinterpret_cast<const f16x8*>(ab + i * 32 * CV_AROW + s * 16);
+            fal[s][i] = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * CV_AROW + s * 16);
+        }
+    };
+    // same step shape as the forward kernel: one barrier in the middle, fragments read half a step ahead, the staged
+    // tile committed under the first half and the next one fetched under the second
+    auto step = [&](int t, Stage& S, auto edge_tag) __attribute__((always_inline)) {
+        const int buf = t & 1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (COCOS_CONV_WGRAD_PIPE) {
+                if (s == 0) read_frags(buf, 1); else read_frags(buf ^ 1, 0);
+            } else {
+                read_frags(buf, s);
             }
+            if (s == 1) fetch_begin(nbeg + (t + 1 + WSTAGES) * CV_BK);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                avh[i] = *reinterpret_cast<const f16x8*>(ab + i * 32 * CV_AROW + s * 16);
-                avl[i] = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * CV_AROW + s * 16);
-            }
-            if (s == 1) fetch_begin(nbeg + (t + 3) * CV_BK);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[i], bvh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh[i], bvl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl[i], bvh[j], acc[i][j], 0, 0, 0);
-                }
-                if (COCOS_CONV_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
                 if (s == 0) {
                     commit_a(S, buf ^ 1, 2 * i);
                     commit_a(S, buf ^ 1, 2 * i + 1);
@@ -657,23 +670,21 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
 #pragma unroll
                     for (int q = 0; q < GPS; ++q) fetch_g(S, i * GPS + q, edge_tag);
                 }
-                if (COCOS_CONV_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
             }
-            if (COCOS_CONV_SCHED == 1) {
 #pragma unroll
-                for (int q = 0; q < 6 * MI; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x010 | 0x080, COCOS_CONV_SCHED_N, 0);
-                }
+            for (int q = 0; q < 6 * MI; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x010 | 0x080, COCOS_CONV_SCHED_N, 0);
             }
+            if (COCOS_CONV_WGRAD_PIPE ? s == 0 : s == 1) __syncthreads();
         }
-        __syncthreads();
     };
     auto run = [&](auto edge_tag) __attribute__((always_inline)) {
+        if (COCOS_CONV_WGRAD_PIPE) read_frags(0, 0);
         int t = 0;
         for (; t + 1 < nsteps; t += 2) {
             step(t, st[0], edge_tag);
-            step(t + 1, st[1], edge_tag);
+            step(t + 1, st[WSTAGES - 1], edge_tag);
         }
         if (t < nsteps) step(t, st[0], edge_tag);
     };
