@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
     bool f_rowok[NC];
     auto fetch_begin = [&](Stage& S, int tt) {
         tt = min(tt, nkb - 1);                         // prefetches beyond the end re-read the last tile (never used)
+        if (COCOS_CONV_ABLATE & 16) tt = 0;            // timing experiment: every step re-reads tile 0 (cache-hot loads)
         f_cb = cv_div(tt, g.mT);                       // k-block tt = 32 channels f_cb*32.. at tap tt % T
         const int tap = tt - f_cb * (g.KH * g.KW);
         f_ky = cv_div(tap, g.mKW);
