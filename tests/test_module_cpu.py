@@ -154,15 +154,23 @@ def test_install_spade_into_reference(pono, monkeypatch):
             y = (xx - mu) / xx.var(1, keepdim=True).add(eps).sqrt() * (1 + gamma) + beta
             return torch.nn.functional.leaky_relu(y, slope) if slope != 1.0 else y
 
+        mod_calls = []
+
+        def fake_spade_modulate(xh, gamma, beta, slope=1.0):      # K17's arithmetic
+            mod_calls.append(slope)
+            y = xh * (1 + gamma) + beta
+            return torch.nn.functional.leaky_relu(y, slope) if slope != 1.0 else y
+
         monkeypatch.setattr(spade, "_hip_ok", lambda *ts: True)
         monkeypatch.setattr(ops, "pono_spade", fake_pono_spade)
+        monkeypatch.setattr(ops, "spade_modulate", fake_spade_modulate)
         with torch.no_grad():
             y2 = blk(x, seg)
+        assert torch.allclose(y2, ref[0], atol=1e-5, rtol=1e-5)
         if pono:
-            assert sorted(calls) == [0.2, 0.2, 1.0]
-            assert torch.allclose(y2, ref[0], atol=1e-5, rtol=1e-5)
-        else:
-            assert calls == []                    # instance-norm SPADE: statistics stay with nn.InstanceNorm2d
+            assert sorted(calls) == [0.2, 0.2, 1.0] and mod_calls == []
+        else:       # instance-norm SPADE: statistics stay with nn.InstanceNorm2d, modulation + activation go to K17
+            assert calls == [] and sorted(mod_calls) == [0.2, 0.2, 1.0]
     finally:
         spade.uninstall_spade_from_reference(networks)
     assert not hasattr(arch.SPADEResnetBlock, "_cocos_reference_forward")
