@@ -403,6 +403,29 @@ def main():
                            "kernels": ok, "roofline": roofline_of(ok, other)}
         ops.PRECISION = ops.PROJ_PRECISION = headline_precision
 
+    # N > 1: what BASELINE config 4's exchanges cost on this node — timed AFTER the contract window, never part of `value`:
+    # one in-place all-reduce (RCCL) of a flat fp32 buffer of netCorr's 59 M and of netG+netCorr's 156 M gradients
+    exchange_probe = None
+    if world > 1 and not args.no_extras:
+        try:
+            exchange_probe = {}
+            for name in ("netcorr", "full"):
+                buf = torch.zeros(PAYLOAD_PARAMS[name], device=device)
+                for _ in range(2):
+                    torch.distributed.all_reduce(buf)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    torch.distributed.all_reduce(buf)
+                sync()
+                ms = (time.perf_counter() - t0) / 5 * 1e3
+                nbytes = buf.numel() * 4
+                exchange_probe[name] = {"bytes": nbytes, "ms": round(ms, 3),
+                                        "bus_GBps": round(nbytes * 2 * (world - 1) / world / (ms * 1e-3) / 1e9, 1)}
+                del buf
+        except Exception as e:       # noqa: BLE001 — a probe must never cost the bench line
+            exchange_probe = {"error": repr(e)}
+
     if rank == 0:
         split = headline_precision == "f16x3"
         kernels = kernel_table(kern, headline_precision)
@@ -426,14 +449,14 @@ def main():
                                    f"precision={headline_precision}; scope={args.scope}: "
                                    + ("theta/phi 1x1 conv + centre/L2norm + fused corr-softmax-warp fwd+bwd"
                                       if args.scope == "hotpath" else
-                                      "whole NoVGGCorrespondence module fwd+bwd (producers on PyTorch-ROCm)"),
+                                      "whole NoVGGCorrespondence module fwd+bwd (convolutions K16, norms K9/K13/K17, theta/phi K0)"),
                        "global_batch": BATCH_PER_GPU * world, "parallelism": f"dp{world}",
                        "grad_payload": args.grad_payload,
                        "grad_allreduce_bytes": buckets.nbytes() if buckets is not None else 0,
                        "grad_allreduce": "bucketed (64 MiB), launched from post-accumulate-grad hooks during backward, "
                                          "in place on flat fp32 gradient buffers" if world > 1 else None},
             "roofline": roofline, "kernels": kernels, "abi_calls_ms_per_step": per_step,
-            "flavours": flavours, "stability": stability, "cpu_baseline": cpu,
+            "flavours": flavours, "stability": stability, "cpu_baseline": cpu, "exchange_probe": exchange_probe,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
