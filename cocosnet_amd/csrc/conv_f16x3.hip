@@ -89,7 +89,10 @@ __device__ __forceinline__ int cv_div(int n, Magic m) {
 }
 
 struct ConvGeom {
-    int Cin, H, W, OH, OW, KH, KW, stride, pad, dil;
+    int Cin, H, W, OH, OW, KH, KW, stride, pad, padx, dil;   // pad = rows, padx = columns (equal except for the strided dgrad)
+    // where output pixel (oy, ox) of plane (b, m) goes: Y[(b*M + m)*o_plane + o_off + oy*o_pitch + ox*o_cs]
+    // (dense: o_plane = OH*OW, o_pitch = OW, o_cs = 1, o_off = 0; the parity classes of a strided input gradient scatter)
+    int o_plane, o_pitch, o_cs, o_off;
     int Cp;                  // Cin rounded up to 32
     int Ktot;                // KH * KW * Cp
     int OWv;                 // forward kernel, stride 1: OW rounded up to 4 (virtual columns, computed and dropped) so
@@ -127,7 +130,7 @@ __device__ __forceinline__ Corner cv_corner(int n, const ConvGeom& g) {
     const int ox = pos - oy * g.OWv;
     Corner c;
     c.iy0 = oy * g.stride - g.pad;
-    c.ix0 = ox * g.stride - g.pad;
+    c.ix0 = ox * g.stride - g.padx;
     c.base = (b * g.Cin * g.H + c.iy0) * g.W + c.ix0;
     return c;
 }
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (vb / ntn) * BM, n0 = (vb % ntn) * BN;          // consecutive ids: the position tiles of one row tile
     const int HW = g.H * g.W, ncb = g.Cp >> 5, nkb = g.KH * g.KW * ncb;
-    const int shift = g.pad * g.W + g.pad;
+    const int shift = g.pad * g.W + g.padx;
 
     const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(X - shift, ((size_t)g.xelems + shift) * 4);
     const size_t wbytes = (size_t)M * g.Ktot * 2;
@@ -438,7 +441,6 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
     if (edge_tile) run(std::true_type{}); else run(std::false_type{});
 
     const float oscale = 1.0f / ((w_scale ? *w_scale : 1.0f) * sx);
-    const int ohw = g.OH * g.OW;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + wn * (32 * NJ) + j * 32 + c;
@@ -448,13 +450,13 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
         const int oy = cv_div(pos, g.mOW);
         const int ox = pos - oy * g.OWv;
         if (ox >= g.OW) continue;                      // virtual column
-        float* yb = Y + ((size_t)b * M) * ohw + oy * g.OW + ox;
+        float* yb = Y + ((size_t)b * M) * g.o_plane + g.o_off + oy * g.o_pitch + ox * g.o_cs;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (BM / 2) + i * 32 + acc_row_base(r) + 4 * h;
-                if (m < M) yb[(size_t)m * ohw] = acc[i][j][r] * oscale + (bias ? bias[m] : 0.f);
+                if (m < M) yb[(size_t)m * g.o_plane] = acc[i][j][r] * oscale + (bias ? bias[m] : 0.f);
             }
     }
 }
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
     const int slice = vb / (ntk * ntm), rem = vb % (ntk * ntm);
     const int m0 = (rem / ntk) * BM, k0 = (rem % ntk) * CV_BN;
     const int nbeg = slice * nchunk, nend = min(g.Ntot, nbeg + nchunk);
-    const int shift = g.pad * g.W + g.pad;
+    const int shift = g.pad * g.W + g.padx;
 
     const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(X - shift, ((size_t)g.xelems + shift) * 4);
     const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(dY, (size_t)ybytes);
@@ -722,9 +724,10 @@ static int cv_geom(ConvGeom& g, int B, int Cin, int H, int W, int Cout, int KH, 
                   Cin, Cout, H, W, KH, KW, stride, pad, dil);
     COCOS_REQUIRE(H + 2 * pad >= dil * (KH - 1) + 1 && W + 2 * pad >= dil * (KW - 1) + 1, COCOS_ERR_INVALID,
                   "%s: kernel larger than the padded input", who);
-    g.Cin = Cin; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.dil = dil;
+    g.Cin = Cin; g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad; g.padx = pad; g.dil = dil;
     g.OH = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
     g.OW = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    g.o_plane = g.OH * g.OW; g.o_pitch = g.OW; g.o_cs = 1; g.o_off = 0;
     g.Cp = (Cin + 31) / 32 * 32;
     g.OWv = virt ? (g.OW + 3) / 4 * 4 : g.OW;
     const long long ktot = (long long)KH * KW * g.Cp, ntot = (long long)B * g.OH * g.OWv;
@@ -748,16 +751,13 @@ extern "C" int cocos_conv2d_out_size(int in, int k, int stride, int pad, int dil
 }
 extern "C" int cocos_conv2d_kdim(int Cin, int KH, int KW) { return KH * KW * ((Cin + 31) / 32 * 32); }
 
-extern "C" int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const void* w_lo, const float* w_scale_dev,
-                                      const float* x_amax_dev, const float* bias, float* y, int B, int Cin, int H, int W,
-                                      int Cout, int KH, int KW, int stride, int pad, int dil, cocos_stream_t stream) {
+static int conv_fwd_launch(const cocos::ConvGeom& g, const float* x, const void* w_hi, const void* w_lo,
+                           const float* w_scale_dev, const float* x_amax_dev, const float* bias, float* y, int Cout,
+                           cocos_stream_t stream) {
     using namespace cocos;
-    COCOS_REQUIRE(x && w_hi && w_lo && y, COCOS_ERR_INVALID, "conv2d_fwd_f16x3: null pointer");
-    ConvGeom g;
-    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, dil, stride == 1, "conv2d_fwd_f16x3")) return rc;
     COCOS_REQUIRE(aligned16(w_hi) && aligned16(w_lo), COCOS_ERR_INVALID,
                   "conv2d_fwd_f16x3: weight planes must be 16-byte aligned");
-    const bool fast4 = stride == 1;
+    const bool fast4 = g.stride == 1;
     // tile: BM = 256 rows for wide layers, BN = 128 positions.  The 256 x 256 tile (wave tile 128 x 128: each LDS operand
     // is re-read half as often per MFMA, all 256 accumulator registers in use, one register stage) exists and is
     // tested, but measured no faster on the 407-channel block (0.466 vs 0.470 ms) and slower on its input gradient
@@ -785,6 +785,43 @@ extern "C" int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const vo
 #undef COCOS_GO
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+extern "C" int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const void* w_lo, const float* w_scale_dev,
+                                      const float* x_amax_dev, const float* bias, float* y, int B, int Cin, int H, int W,
+                                      int Cout, int KH, int KW, int stride, int pad, int dil, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && w_hi && w_lo && y, COCOS_ERR_INVALID, "conv2d_fwd_f16x3: null pointer");
+    ConvGeom g;
+    if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, dil, stride == 1, "conv2d_fwd_f16x3")) return rc;
+    return conv_fwd_launch(g, x, w_hi, w_lo, w_scale_dev, x_amax_dev, bias, y, Cout, stream);
+}
+
+// One parity class of the input gradient of a STRIDED convolution (see cocos_hip.h): a stride-1 convolution of x
+// ( = dy of the strided layer) with a JH x JW sub-kernel, separate row / column padding, an explicit output grid
+// OHo x OWo (reads beyond x are zero) and a strided placement of the result inside y ( = dx of the strided layer).
+extern "C" int cocos_conv2d_fwd_scatter_f16x3(const float* x, const void* w_hi, const void* w_lo, const float* w_scale_dev,
+                                              const float* x_amax_dev, float* y, int B, int Cin, int H, int W, int Cout,
+                                              int JH, int JW, int pad_y, int pad_x, int OHo, int OWo, long long y_plane,
+                                              int y_pitch, int y_col_stride, long long y_offset, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && w_hi && w_lo && y, COCOS_ERR_INVALID, "conv2d_fwd_scatter_f16x3: null pointer");
+    COCOS_REQUIRE(pad_y >= 0 && pad_x >= 0 && OHo >= 1 && OWo >= 1 && y_plane >= 1 && y_pitch >= 1 && y_col_stride >= 1 &&
+                      y_offset >= 0, COCOS_ERR_INVALID, "conv2d_fwd_scatter_f16x3: bad placement");
+    ConvGeom g;
+    // geometry of a stride-1 layer with the larger padding (bounds / 32-bit checks), then the explicit grid and placement
+    const int pmax = pad_y > pad_x ? pad_y : pad_x;
+    if (int rc = cv_geom(g, B, Cin, H + 0, W + 0, Cout, JH, JW, 1, pmax + (JH > JW ? JH : JW), 1, true, "conv2d_fwd_scatter_f16x3"))
+        return rc;
+    g.pad = pad_y; g.padx = pad_x; g.OH = OHo; g.OW = OWo; g.OWv = (OWo + 3) / 4 * 4;
+    const long long ntot = (long long)B * OHo * g.OWv;
+    COCOS_REQUIRE(ntot + 256 < (1ll << 30) && y_plane * (long long)B * Cout * 4 < 0x7fffffffll && y_plane < (1ll << 30) &&
+                      y_offset + (long long)(OHo - 1) * y_pitch + (long long)(OWo - 1) * y_col_stride < y_plane,
+                  COCOS_ERR_UNSUPPORTED, "conv2d_fwd_scatter_f16x3: output placement out of range");
+    g.Ntot = (int)ntot;
+    g.mOHW = cv_magic(OHo * g.OWv); g.mOW = cv_magic(g.OWv);
+    g.o_plane = (int)y_plane; g.o_pitch = y_pitch; g.o_cs = y_col_stride; g.o_off = (int)y_offset;
+    return conv_fwd_launch(g, x, w_hi, w_lo, w_scale_dev, x_amax_dev, nullptr, y, Cout, stream);
 }
 
 extern "C" int cocos_conv2d_wgrad_slices(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,

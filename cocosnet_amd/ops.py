@@ -708,6 +708,46 @@ def _conv_fwd_call(x, wh, wl, ws, xa, bias, Cout, KH, KW, stride, pad, dil):
     return y
 
 
+def _conv_dgrad_strided(xshape, weight, dy, ga, wa, s: int, p: int):
+    """Input gradient of a stride-s convolution (dilation 1) as s*s stride-1 convolutions of dy.
+    dx[y, x] only sees the taps with ky = (y + p) mod s (mod s): with y + p = s*u + ry and ky = ry + s*jy,
+        dx[s*u + ry - p, s*v + rx - p] = sum_{co, jy, jx} w[co, ci, ry + s*jy, rx + s*jx] * dy[co, u - jy, v - jx],
+    a correlation of dy with the flipped sub-kernel, evaluated for the u, v whose pixel lies inside the input and written
+    straight into dx with stride s (cocos_conv2d_fwd_scatter_f16x3).  Returns None when a class needs negative padding."""
+    B, Cin, H, W = xshape
+    Cout, _, KH, KW = weight.shape
+    OH, OW = dy.shape[2:]
+    classes = []
+    for ry in range(s):
+        JH = len(range(ry, KH, s))
+        u0 = max(0, -((ry - p) // s))                      # ceil((p - ry) / s), first u with s*u + ry - p >= 0
+        U = (H - 1 + p - ry) // s + 1 - u0 if H - 1 + p - ry >= 0 else 0
+        for rx in range(s):
+            JW = len(range(rx, KW, s))
+            v0 = max(0, -((rx - p) // s))
+            V = (W - 1 + p - rx) // s + 1 - v0 if W - 1 + p - rx >= 0 else 0
+            if U <= 0 or V <= 0:
+                continue
+            if JH == 0 or JW == 0:
+                classes.append(None)                         # pixels no tap reaches: zeros
+                continue
+            py, px = JH - 1 - u0, JW - 1 - v0
+            if py < 0 or px < 0:
+                return None
+            classes.append((ry, rx, JH, JW, u0, v0, U, V, py, px))
+    dx = (torch.zeros if any(c is None for c in classes) else torch.empty)(xshape, device=dy.device, dtype=torch.float32)
+    for c in classes:
+        if c is None:
+            continue
+        ry, rx, JH, JW, u0, v0, U, V, py, px = c
+        wt = weight[:, :, ry::s, rx::s].flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, JH * JW, Cout)
+        th, tl, ts = _weight_planes(wt, wa)
+        off = (s * u0 + ry - p) * W + (s * v0 + rx - p)
+        _call("conv2d_fwd", "cocos_conv2d_fwd_scatter_f16x3", dy.data_ptr(), th.data_ptr(), tl.data_ptr(), ts.data_ptr(),
+              ga.data_ptr(), dx.data_ptr(), B, Cout, OH, OW, Cin, JH, JW, py, px, U, V, H * W, s * W, s, off, _stream())
+    return dx
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride: int, pad: int, dil: int):
@@ -749,7 +789,9 @@ class _Conv2d(torch.autograd.Function):
                 wt = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, KH * KW, Cout)
                 th, tl, ts = _weight_planes(wt, wa)
                 dx = _conv_fwd_call(dy, th, tl, ts, ga, None, Cin, KH, KW, 1, dil * (KH - 1) - pad, dil)
-            else:       # strided layers (PatchGAN): the framework's transposed convolution
+            elif stride > 1 and dil == 1 and (dx := _conv_dgrad_strided(x.shape, weight, dy, ga, wa, stride, pad)) is not None:
+                pass    # stride^2 parity classes, each a stride-1 convolution of dy scattered into dx (K16)
+            else:       # whatever is left (dilated + strided, rectangular kernels with odd paddings): the framework
                 dx = torch.nn.grad.conv2d_input(x.shape, weight, dy, stride=stride, padding=pad, dilation=dil)
         if need_w:
             lib = _lib.load()

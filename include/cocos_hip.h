@@ -428,7 +428,8 @@ int cocos_spade_modulate_bwd(const float* xh, const float* gamma, const float* b
  *          goes to w_scale_dev (NULL = 1), x_amax_dev = max|x| (NULL: x is O(1)), bias [Cout] or NULL
  *          ->  y [B,Cout,OH,OW] fp32, OH = cocos_conv2d_out_size(H,KH,stride,pad,dilation) (0 when the kernel does not fit).
  *          The input gradient of a stride-1 convolution is the same call on dy with the planes of the flipped,
- *          transposed weight (roles of Cin and Cout swapped) and pad' = dilation*(K-1)-pad.
+ *          transposed weight (roles of Cin and Cout swapped) and pad' = dilation*(K-1)-pad; of a strided one
+ *          (dilation 1) stride^2 calls of cocos_conv2d_fwd_scatter_f16x3, one per parity class.
  *   wgrad: x, dy [B,Cout,OH,OW] (+ their max|.|, NULL = O(1))  ->  partials [S][Cout][K] fp32 (k as above; entries
  *          with ci >= Cin are written as zeros), S = cocos_conv2d_wgrad_slices(...) slices over the B*OH*OW
  *          positions; the caller sums them (and sums dy over (b,oy,ox) for the bias gradient).
@@ -440,6 +441,16 @@ int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const void* w_lo, c
                            const float* x_amax_dev /* nullable */, const float* bias /* nullable */, float* y,
                            int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int dilation,
                            cocos_stream_t stream);
+/* One parity class of the input gradient of a STRIDED convolution.  For stride s, dx[y,x] only receives the taps with
+ * ky = (y+p) mod s (mod s), kx likewise: the pixels of one class (ry,rx) form a grid on which the gradient is a
+ * stride-1 convolution of dy with the JH x JW sub-kernel w[:, :, ry::s, rx::s] (flipped, channel roles swapped; planes
+ * as for cocos_conv2d_fwd_f16x3).  This entry runs that convolution on x = dy [B,Cin,H,W] with separate row / column
+ * padding, an explicit output grid OHo x OWo (reads beyond x are zero) and writes output pixel (oy,ox) of plane (b,m)
+ * to y[(b*Cout + m)*y_plane + y_offset + oy*y_pitch + ox*y_col_stride]  (elements). */
+int cocos_conv2d_fwd_scatter_f16x3(const float* x, const void* w_hi, const void* w_lo, const float* w_scale_dev,
+                                   const float* x_amax_dev, float* y, int B, int Cin, int H, int W, int Cout, int JH, int JW,
+                                   int pad_y, int pad_x, int OHo, int OWo, long long y_plane, int y_pitch, int y_col_stride,
+                                   long long y_offset, cocos_stream_t stream);
 int cocos_conv2d_wgrad_slices(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                               int dilation);   /* 0 on bad dims */
 int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const float* x_amax_dev /* nullable */,

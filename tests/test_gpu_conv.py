@@ -19,6 +19,10 @@ CASES = [
     (2, 20, 10, 16, 24, 3, 1, 2),        # pad > (k-1)/2: output larger than input
     (1, 4, 8, 8, 4, 5, 1, 2),            # 5x5
     (1, 2, 6, 6, 3, 3, 2, 0),            # stride 2, tiny
+    (1, 3, 10, 11, 4, 1, 2, 0),          # 1x1 stride 2: three of the four parity classes of dx see no tap
+    (1, 3, 13, 12, 4, 5, 3, 2),          # stride 3, 5x5
+    (1, 3, 8, 8, 2, 2, 3, 0),            # kernel smaller than the stride
+    (2, 64, 32, 32, 130, 3, 2, 1),       # adaptor down-sampling layer class (k3 s2 p1), wide
     (2, 12, 20, 24, 10, 3, 1, 2, 2),     # dilation 2 (the adaptors' de-gridding convolution: k3 p2 d2)
     (1, 6, 17, 13, 5, 3, 2, 3, 3),       # dilation 3, stride 2, ragged
 ]
