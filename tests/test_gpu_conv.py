@@ -137,3 +137,31 @@ def test_spade_forward_instance_norm_branch_uses_the_kernels():
     y = spade.modulate(x, ga, be, False, norm, 0.2)
     ref = F.leaky_relu(norm(x.double()) * (1 + ga.double()) + be.double(), 0.2)
     assert (y.double() - ref).abs().max().item() < 1e-5
+
+
+def test_patchgan_stack_on_hip_convs_matches_the_framework():
+    """A PatchGAN-shaped stack (discriminator.py:92-115: k4 s2 convolutions, spectral norm, InstanceNorm, LeakyReLU, a final
+    k4 s1 convolution) re-classed with producers.use_hip_convs: forward and every gradient equal the framework's
+    convolutions to fp32 round-off (the same module, `use_framework_convs` in between)."""
+    from cocosnet_amd import producers
+    torch.manual_seed(0)
+    sn = torch.nn.utils.spectral_norm
+    net = torch.nn.Sequential(
+        torch.nn.Conv2d(7, 16, 4, stride=2, padding=1), torch.nn.LeakyReLU(0.2),
+        sn(torch.nn.Conv2d(16, 32, 4, stride=2, padding=1)), torch.nn.InstanceNorm2d(32), torch.nn.LeakyReLU(0.2),
+        sn(torch.nn.Conv2d(32, 64, 4, stride=1, padding=1)), torch.nn.InstanceNorm2d(64), torch.nn.LeakyReLU(0.2),
+        torch.nn.Conv2d(64, 1, 4, stride=1, padding=1)).cuda().eval()       # eval: spectral norm's u is not advanced
+    x = torch.randn(2, 7, 64, 48, device="cuda")
+
+    def run():
+        net.zero_grad()
+        xx = x.clone().requires_grad_(True)
+        y = net(xx)
+        y.square().mean().backward()
+        return [y.detach(), xx.grad] + [p.grad.clone() for p in net.parameters()]
+    ref = run()
+    assert producers.use_hip_convs(net) == 4
+    got = run()
+    producers.use_framework_convs(net)
+    for a, r in zip(got, ref):
+        assert (a - r).abs().max().item() <= 2e-4 * max(r.abs().max().item(), 1e-6), (a.shape, (a - r).abs().max().item())
