@@ -284,7 +284,9 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
                 const int jn = (COCOS_ABLATE & 64) ? 32 : min((tv + 1) * 32, Nk - 32);
                 if (u * 256 + 255 < VCH || u * 256 + tid < VCH)
                     *reinterpret_cast<u32x4*>(vw + pl_ * VPLANE + v_lds[u]) = vst[pl_][u];
-                vst[pl_][u] = bq_load16s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jn * (unsigned)(CVP * 2));
+                vst[pl_][u] = bq_load16s(pl_ ? vl_rs : vh_rs,
+                                         ((COCOS_ABLATE & 512) && pl_ == 1 && (u * 256 + tid) % (CVP / 8) >= 4) ? kBufOob : v_voff[u],
+                                         (unsigned)jn * (unsigned)(CVP * 2));
             } else {
                 const int jn = (tv + 1) * 32;
                 const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
@@ -337,11 +339,11 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             const int cur = u & 1, nxt = cur ^ 1;
             if (!(COCOS_ABLATE & 2) && u + 1 < CVS) {
                 ah[nxt] = *reinterpret_cast<const f16x8*>(vb0 + (u + 1) * 16);
-                al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
+                if (!(COCOS_ABLATE & 512) || u + 1 < 2) al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
             }
             dp0 = bq_mfma(ah[cur], goh[u], dp0);
             dp0 = bq_mfma(ah[cur], gol[u], dp0);
-            dp0 = bq_mfma(al[cur], goh[u], dp0);
+            if (!(COCOS_ABLATE & 512) || u < 2) dp0 = bq_mfma(al[cur], goh[u], dp0);
 #pragma unroll
             for (int q = 0; q < PER; ++q)
                 if (u * PER + q < NP) stage_piece(u * PER + q, t + 1, t);

@@ -81,7 +81,8 @@ __device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& l
 // Optional phase timing (build with COCOS_EXTRA_HIPFLAGS=-DCOCOS_DEBUG_TIMING): shader-clock ticks spent by
 // wave 0 of workgroup 0 in each phase of the tile loop, read back with cocos_debug_read_timing_fwd_f16x3().
 // Ablation builds (debug only, results are WRONG): -DCOCOS_ABLATE=<bits>  1: no tile staging in the QK loop,
-// 2: no operand re-reads from LDS, 4: no softmax arithmetic, 8: no logits store — tools/ablate_fwd.sh times them.
+// 2: no operand re-reads from LDS, 4: no softmax arithmetic, 8: no logits store, 512: V lo plane skipped for channel
+// blocks >= 1 (what exactly-representable label channels could save) — tools/ablate_ms.sh times them.
 #ifndef COCOS_ABLATE
 #define COCOS_ABLATE 0
 #endif
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                     kst[pl_][u] = buf_load_u4s(pl_ ? kl_rs : kh_rs, k_voff[u], (unsigned)jc * (unsigned)(SP_KD * 2));
                 } else if (i - 8 < 2 * CVB) {
                     const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
+                    if ((COCOS_ABLATE & 512) && pl_ == 1 && u >= 1) return;
                     *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + v_lds[u]) =
                         (pl_ == 0 && u == CVB - 1 && ones_thread) ? kOnes2 : vst[pl_][u];
                     vst[pl_][u] = buf_load_u2s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jc * 2u);
@@ -417,11 +419,12 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                 const int tt = i / CVB, cb = i % CVB, cur = i % RA, n = i + RA - 1;
                 if (!(COCOS_ABLATE & 2) && n < NSV) {
                     a_h[n % RA] = *reinterpret_cast<const f16x8*>(vbase + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
-                    a_l[n % RA] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
+                    if (!(COCOS_ABLATE & 512) || (n % CVB) == 0)
+                        a_l[n % RA] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
                 }
                 o[cb] = mfma16h(a_h[cur], ph[tt], o[cb]);
                 o[cb] = mfma16h(a_h[cur], pl[tt], o[cb]);
-                o[cb] = mfma16h(a_l[cur], ph[tt], o[cb]);
+                if (!(COCOS_ABLATE & 512) || cb == 0) o[cb] = mfma16h(a_l[cur], ph[tt], o[cb]);
                 piece(8 + i);
                 if (i == NSV - 1) prefetch_k(buf ^ 1);      // (NSV = 2: both in the same step)
                 __builtin_amdgcn_sched_barrier(0);
