@@ -213,6 +213,11 @@ PMC_KEY = {"f16x3": {"corr_softmax_warp_fwd": "corr_fwd_f16x3_kernel<5, 1, 0>",
                     "corr_softmax_warp_bwd_key_from_ds": "sgemm_mfma_kernel<true, true>"}}
 
 
+def ops_value_lo_skip():
+    from cocosnet_amd import ops
+    return bool(getattr(ops, "VALUE_LO_SKIP", False))
+
+
 def kernel_table(kern, precision):
     """Per-kernel algorithmic TFLOP/s from the live HIP-event times (forward 2*HW^2*(K+Cv), backward
     split as query side 2*HW^2*(K+Cv) [dP + dqn] and key side 2*HW^2*K [dkn]; no recompute counted)."""
@@ -239,9 +244,18 @@ def kernel_table(kern, precision):
             kernels[tag] = {"avg_ms": round(ms, 4), "calls": kern[tag]["calls"], "alg_tflops": round(tf, 2),
                             "frac_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
             if split and tag in SPLIT_TAGS:
-                kernels[tag].update({"mfma": "v_mfma_f32_32x32x16_f16 x3 (f16 hi/lo split, fp32 accumulate)",
-                                     "issued_tflops": round(3 * tf, 1),
-                                     "frac_f16_mfma_peak": round(3 * tf / F16_MFMA_PEAK_TFLOPS, 4)})
+                # MFMA terms per fp32-accurate product: 3 (hi*hi + hi*lo + lo*hi).  The 151 label channels of this
+                # workload are one-hot, i.e. exact in f16: their lo plane is all zero, the kernels find that out on the
+                # device (cocos_f16_plane_block_mask) and skip the V_lo term for 4 of the 5 value blocks — per 32-key tile
+                # and wave 70 MFMAs instead of 78 in the forward and in the query backward (same result).
+                terms = 3.0
+                if ops_value_lo_skip() and tag in ("corr_softmax_warp_fwd", "corr_softmax_warp_bwd_query"):
+                    vsteps, cvb = 2 * (cv // 32 + 1), cv // 32 + 1
+                    terms = (3 * 16 + 3 * vsteps - 2 * (cvb - 1)) / (16 + vsteps)
+                kernels[tag].update({"mfma": f"v_mfma_f32_32x32x16_f16 x{terms:.2f} per product on average "
+                                             "(f16 hi/lo split, fp32 accumulate)",
+                                     "issued_tflops": round(terms * tf, 1),
+                                     "frac_f16_mfma_peak": round(terms * tf / F16_MFMA_PEAK_TFLOPS, 4)})
             else:
                 kernels[tag]["mfma"] = "v_mfma_f32_32x32x2_f32"
     return kernels
@@ -268,11 +282,14 @@ def roofline_of(kernels, precision):
                 "unit": "TFLOP/s", "frac": round(kernels[dom]["alg_tflops"] / peak, 4), "traffic": traffic,
                 "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                 "avg_launch_ms": kernels[dom]["avg_ms"], "issued_tflops": kernels[dom]["issued_tflops"],
+                "frac_issued": kernels[dom]["frac_f16_mfma_peak"],
                 "vs_fp32_mfma_peak": kernels[dom]["frac_fp32_mfma_peak"],
                 "note": "achieved = ALGORITHMIC fp32 FLOPs per launch / HIP-event time on torch's current stream. Each "
                         "fp32-accurate product is 3 v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi of f16 hi/lo "
-                        f"operand planes, fp32 accumulate), so peak = dense f16 MFMA peak {F16_MFMA_PEAK_TFLOPS:.0f} / 3; "
-                        f"frac is identical to issued FLOPs / {F16_MFMA_PEAK_TFLOPS:.0f}. vs_fp32_mfma_peak = achieved / "
+                        f"operand planes, fp32 accumulate), so peak = dense f16 MFMA peak {F16_MFMA_PEAK_TFLOPS:.0f} / 3. "
+                        f"frac_issued = issued FLOPs / {F16_MFMA_PEAK_TFLOPS:.0f}: equal to frac when all three terms are "
+                        "issued; lower here because the V_lo term of the one-hot label blocks (exactly zero) is skipped "
+                        "(kernels[...].mfma). vs_fp32_mfma_peak = achieved / "
                         "157.3 (the exact-fp32 MFMA this kernel replaces; flavours.fp32 in this line is that flavour, "
                         "same process, same box)."}
     return {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["alg_tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,

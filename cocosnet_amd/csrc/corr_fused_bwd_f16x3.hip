@@ -74,7 +74,7 @@ struct DsRegs {
     unsigned hw[8], lw[8];     // f16 hi / lo, two values per register: register j>>1, half j&1
 };
 
-template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED>
+template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED, bool VLO0>
 __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     const _Float16* __restrict__ kch, const _Float16* __restrict__ kcl,   // [B,256,Nk] planes of k_scale*kn
     const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] planes of s_v*v
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     const float* __restrict__ v_amax,                                      // max|v| (device)
     const float* __restrict__ v_scale,                                     // s_v (device) or NULL
     float* __restrict__ ds_scale_out,                                      // out: s_o * s_v * ds_shift (device)
+    const unsigned* __restrict__ v_lo_mask,                                // bit cb: value block cb has a non-zero lo plane (or NULL)
     int B, int Nq, int Nk, int Cv, float inv_t, float k_scale, int planes_blocked) {
     constexpr int CVP = CVB * 32;
     constexpr int CVS = CVP / 16;                     // k-steps of the dP product
@@ -105,7 +106,13 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     constexpr int DSROW = 32, DSPLANE = 32 * DSROW;
     _Float16* const dstile = kt + 2 * 2 * KPLANE + (threadIdx.x >> 6) * 2 * DSPLANE;
 
+    using std::false_type;
+    using std::true_type;
     const int tid = threadIdx.x;
+    // VLO0 (template): only value block 0 has a non-zero lo plane (see the forward kernel).  The host launches both
+    // instantiations; the one the device-side mask does not select returns at once.
+    if ((CVB > 1 && v_lo_mask != nullptr && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u) != VLO0) return;
+    const std::integral_constant<bool, VLO0> vlo0_tag{};
     const int lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
 
@@ -274,7 +281,8 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
 
     // one staged piece of the V tile (i < 2*VPT) or of the K tile (2*VPT <= i < 2*VPT + 8) to LDS, and the reload of
     // its register with the tile after: V(tv) -> vt[bufv], then V(tv + 1) requested; K(tk) -> kt[bufk], then K(tk + 1)
-    auto stage_piece = [&](int i, int tv, int tk) {
+    auto stage_piece = [&](int i, int tv, int tk, auto piece_tag) __attribute__((always_inline)) {
+        constexpr bool PLO0 = decltype(piece_tag)::value || (COCOS_ABLATE & 512);   // lo plane of value channels >= 32 is zero: not fetched
         if (COCOS_ABLATE & 1) return;
         _Float16* const vw = vt + (tv & 1) * 2 * VPLANE;
         _Float16* const kw = kt + (tk & 1) * 2 * KPLANE;
@@ -285,14 +293,14 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
                 if (u * 256 + 255 < VCH || u * 256 + tid < VCH)
                     *reinterpret_cast<u32x4*>(vw + pl_ * VPLANE + v_lds[u]) = vst[pl_][u];
                 vst[pl_][u] = bq_load16s(pl_ ? vl_rs : vh_rs,
-                                         ((COCOS_ABLATE & 512) && pl_ == 1 && (u * 256 + tid) % (CVP / 8) >= 4) ? kBufOob : v_voff[u],
+                                         (PLO0 && pl_ == 1 && (u * 256 + tid) % (CVP / 8) >= 4) ? kBufOob : v_voff[u],
                                          (unsigned)jn * (unsigned)(CVP * 2));
             } else {
                 const int jn = (tv + 1) * 32;
                 const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
                 if (g < VCH) *reinterpret_cast<u32x4*>(vw + pl_ * VPLANE + key * VROW + cc * 8) = vst[pl_][u];
                 vst[pl_][u] = bq_load16(pl_ ? vl_rs : vh_rs,
-                                        g < VCH ? (unsigned)((jn + key) * CVP + cc * 8) * 2u : kBufOob);
+                                        (g < VCH && !(PLO0 && pl_ == 1 && cc >= 4)) ? (unsigned)((jn + key) * CVP + cc * 8) * 2u : kBufOob);
             }
         } else if (i - 2 * VPT < 8) {
             const int pl_ = (i - 2 * VPT) & 1, u = (i - 2 * VPT) >> 1;
@@ -325,7 +333,10 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
         vf_h = *reinterpret_cast<const f16x8*>(vb0);
         vf_l = *reinterpret_cast<const f16x8*>(vb0 + VPLANE);
     };
-    auto phase_dp = [&](f32x16& dp0, int t) {
+    // VLO0 (uniform, see the forward kernel): only value block 0 has a non-zero lo plane — the V_lo * dO_hi term, its
+    // fragment reads and the fetch of those lo channels are skipped for the other blocks (8 of 30 MFMAs, same result)
+    auto phase_dp = [&](f32x16& dp0, int t) __attribute__((always_inline)) {
+        constexpr bool SKIPLO = VLO0 || (COCOS_ABLATE & 512);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp0[r] = 0.f;
         const _Float16* vb0 = vt + (t & 1) * 2 * VPLANE + c * VROW + h * 8;
@@ -339,14 +350,14 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             const int cur = u & 1, nxt = cur ^ 1;
             if (!(COCOS_ABLATE & 2) && u + 1 < CVS) {
                 ah[nxt] = *reinterpret_cast<const f16x8*>(vb0 + (u + 1) * 16);
-                if (!(COCOS_ABLATE & 512) || u + 1 < 2) al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
+                if (!SKIPLO || u + 1 < 2) al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
             }
             dp0 = bq_mfma(ah[cur], goh[u], dp0);
             dp0 = bq_mfma(ah[cur], gol[u], dp0);
-            if (!(COCOS_ABLATE & 512) || u < 2) dp0 = bq_mfma(al[cur], goh[u], dp0);
+            if (!SKIPLO || u < 2) dp0 = bq_mfma(al[cur], goh[u], dp0);
 #pragma unroll
             for (int q = 0; q < PER; ++q)
-                if (u * PER + q < NP) stage_piece(u * PER + q, t + 1, t);
+                if (u * PER + q < NP) stage_piece(u * PER + q, t + 1, t, vlo0_tag);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             dx[kb] = bq_mfma(a_h[cur_], sl[tt], dx[kb]);
             dx[kb] = bq_mfma(a_l[cur_], sh[tt], dx[kb]);
             if (WITH_VALU && i + LEAD < 16) slice(i + LEAD);
-            if (STAGE_K && (i & 1) == 0) stage_piece(2 * VPT + (i >> 1), t + 1, t);
+            if (STAGE_K && (i & 1) == 0) stage_piece(2 * VPT + (i >> 1), t + 1, t, false_type{});
             if (WITH_VALU && i == 2 * KB - 1) prefetch_v(t + 1);         // first fragments of the next iteration's dP'
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -479,8 +490,6 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
 
     DsRegs dA, dB, pA, pB;
     f32x16 dp0;
-    using std::false_type;
-    using std::true_type;
 
     // ONE barrier per iteration, between the two MFMA loops.  Value tile t+1 is committed during dP'(t) into the buffer
     // dP'(t-1) read (every wave finished that before it passed the barrier of iteration t-1) and is read from the end of
@@ -550,7 +559,8 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                            const _Float16* gph, const _Float16* gpl, const float* g_scale, const float* outp,
                            const float* dout, const float* lse, const float* lg, float* dqn, _Float16* dsh,
                            _Float16* dsl, _Float16* psh, _Float16* psl, const float* v_amax, const float* v_scale,
-                           float* ds_scale_out, int B, int Nq, int Nk, int Cv, float inv_t, float k_scale, int blocked,
+                           float* ds_scale_out, const unsigned* v_lo_mask, int B, int Nq, int Nk, int Cv, float inv_t,
+                           float k_scale, int blocked,
                            hipStream_t s) {
     const bool ragged = (Nk % 32) != 0, store = dsh != nullptr, storep = psh != nullptr;
     const size_t smem = ((size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) + 4 * 2 * 32 * 32) * sizeof(_Float16);
@@ -559,19 +569,27 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
     do {                                                                                                     \
         if (storep) COCOS_GO2(DS, true, RG); else COCOS_GO2(DS, false, RG);                                  \
     } while (0)
-#define COCOS_GO2(DS, SP, RG)                                                                                \
+#define COCOS_GO3(DS, SP, RG, VL, MASK)                                                                      \
     do {                                                                                                     \
-        auto kern = corr_bwd_query_f16x3_kernel<CVB, DS, SP, RG>;                                            \
+        auto kern = corr_bwd_query_f16x3_kernel<CVB, DS, SP, RG, VL>;                                        \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
         hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, s, kch, kcl, vph, vpl, gph, gpl, g_scale,   \
-                           outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, B, Nq, \
+                           outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, MASK, B, Nq, \
                            Nk, Cv, inv_t, k_scale, blocked);                                                 \
+    } while (0)
+    /* with a mask and more than one value block both instantiations are launched: the one the mask does not select
+       returns at once (the choice is data on the device; no host round trip) */
+#define COCOS_GO2(DS, SP, RG)                                                                                \
+    do {                                                                                                     \
+        if (CVB > 1 && v_lo_mask) COCOS_GO3(DS, SP, RG, (CVB > 1), v_lo_mask);                               \
+        COCOS_GO3(DS, SP, RG, false, (CVB > 1 ? v_lo_mask : nullptr));                                       \
     } while (0)
     if (store) { if (ragged) COCOS_GO(true, true); else COCOS_GO(true, false); }
     else       { if (ragged) COCOS_GO(false, true); else COCOS_GO(false, false); }
 #undef COCOS_GO
 #undef COCOS_GO2
+#undef COCOS_GO3
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -595,8 +613,8 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
     const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
     const float* g_scale_dev, const float* out, const float* dout, const float* lse, const void* saved_logits,
     float* dqn, void* dsh, void* dsl, void* psh, void* psl, const float* v_amax_dev, const float* v_scale_dev,
-    float* ds_scale_out_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale,
-    int planes_blocked, cocos_stream_t stream) {
+    float* ds_scale_out_dev, const unsigned* v_lo_mask_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad,
+    float inv_temperature, float k_scale, int planes_blocked, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(kch && kcl && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse && saved_logits && dqn &&
                       v_amax_dev && ds_scale_out_dev,
@@ -627,7 +645,7 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
         static_cast<const _Float16*>(vpl), static_cast<const _Float16*>(gph), static_cast<const _Float16*>(gpl), \
         g_scale_dev, out, dout, lse, static_cast<const float*>(saved_logits), dqn, static_cast<_Float16*>(dsh),  \
         static_cast<_Float16*>(dsl), static_cast<_Float16*>(psh), static_cast<_Float16*>(psl), v_amax_dev,      \
-        v_scale_dev, ds_scale_out_dev, B, Nq, Nk, Cv, inv_temperature, k_scale, planes_blocked, s
+        v_scale_dev, ds_scale_out_dev, v_lo_mask_dev, B, Nq, Nk, Cv, inv_temperature, k_scale, planes_blocked, s
     switch (cvb) {
         case 1: return launch_bq_f16x3<1>(COCOS_ARGS);
         case 2: return launch_bq_f16x3<2>(COCOS_ARGS);

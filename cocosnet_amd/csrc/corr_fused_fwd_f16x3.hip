@@ -31,6 +31,7 @@
 //     stores (and the backward loads) its 32x32 tile as four fully contiguous 1 KB instructions instead of
 //     sixteen 4-byte-per-lane ones (the store tail of round 1 was instruction-bound, not bandwidth-bound).
 #include "common.h"
+#include <type_traits>
 
 namespace cocos {
 
@@ -98,12 +99,12 @@ __device__ long long g_phase_fwd_h[8];
 #define FPH_ADD(i, a, b) do {} while (0)
 #endif
 
-template <int CVB, bool STORE_S, bool RAGGED>
+template <int CVB, bool STORE_S, bool RAGGED, bool VLO0>
 __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     const _Float16* __restrict__ qh, const _Float16* __restrict__ ql, const _Float16* __restrict__ kh,
     const _Float16* __restrict__ kl, const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
     float* __restrict__ out, float* __restrict__ lse, float* __restrict__ lg, const float* __restrict__ v_scale,
-    int B, int Nq, int Nk, int Cv, float scale_log2 /* inv_temperature * log2(e) / (q_scale * k_scale) */) {
+    const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2 /* inv_temperature * log2(e) / (q_scale * k_scale) */) {
     constexpr int CVP = CVB * 32;
     constexpr int KPLANE = SP_BK * SP_KROW;          // halfs per K plane per buffer
     constexpr int VPLANE = CVP * SP_VROW;
@@ -259,6 +260,9 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     // tile t's P.V loop, so the QK loop never starts cold (round 1 / step 1 read them right after the barrier:
     // ~450 cycles of every tile's QK phase were that bubble — tools/ablate_fwd.sh, profiles/r02_ablation_fwd.txt).
     constexpr int RA = 4, NS = SP_KD / 16;
+    // uniform: the lo plane of every value block but the first is all zero (nullptr / single block: general path);
+    // the instantiation that does not match leaves
+    if ((CVB > 1 && v_lo_mask != nullptr && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u) != VLO0) return;
     f16x8 ah[RA], al[RA];
     auto prefetch_k = [&](int buf) {
         const _Float16* kb = kt + buf * 2 * KPLANE + c * SP_KROW + h * 8;
@@ -274,6 +278,11 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     // on (and by the prefetch at the end of P.V(t)): every wave has passed this barrier in between.  Value tile t+1 is
     // committed during P.V(t) into the buffer P.V(t-1) read: every wave finished P.V(t-1) before it reached this
     // barrier in tile t; it is read in P.V(t+1), after the barrier of tile t+1.
+    // VLO0 (template): only value block 0 has a non-zero lo plane (one-hot label channels are exact in f16: `v_lo_mask`,
+    // cocos_f16_plane_block_mask) — the V_lo * P_hi term, its fragment reads and its staging are skipped for the other
+    // blocks: same result, 8 of 30 P.V MFMAs fewer.  The host launches both instantiations; the one the mask does not
+    // select returns at once (a choice inside ONE kernel — per tile or per loop copy — cost registers: measured slower).
+    const std::integral_constant<bool, VLO0> vlo0_tag{};
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * SP_BK, buf = t & 1;
         const bool ragged = RAGGED && (j0 + SP_BK > Nk);
@@ -283,7 +292,8 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
         // One staged piece of tile t+1 to the other LDS buffer, and its register immediately takes the load for tile
         // t+2 — memory instructions are never issued as a burst.  i < 8: key-tile pieces (plane i & 1, chunk i >> 1),
         // issued in the QK loop; 8 <= i < 8 + 2*CVB: value-tile pieces, issued in the P.V loop.
-        auto piece = [&](int i) {
+        auto piece = [&](int i, auto vlo0_piece_tag) __attribute__((always_inline)) {
+            constexpr bool PLO0 = decltype(vlo0_piece_tag)::value;     // value blocks >= 1 have an all-zero lo plane: not staged
             if (COCOS_ABLATE & 1) return;
             if (!RAGGED) {
                 const int jc = (COCOS_ABLATE & 64) ? SP_BK : min(jn, Nk - SP_BK);       // look-ahead past the end re-reads the last tile
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                     kst[pl_][u] = buf_load_u4s(pl_ ? kl_rs : kh_rs, k_voff[u], (unsigned)jc * (unsigned)(SP_KD * 2));
                 } else if (i - 8 < 2 * CVB) {
                     const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
-                    if ((COCOS_ABLATE & 512) && pl_ == 1 && u >= 1) return;
+                    if ((PLO0 || (COCOS_ABLATE & 512)) && pl_ == 1 && u >= 1) return;
                     *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + v_lds[u]) =
                         (pl_ == 0 && u == CVB - 1 && ones_thread) ? kOnes2 : vst[pl_][u];
                     vst[pl_][u] = buf_load_u2s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jc * 2u);
@@ -307,6 +317,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                 kst[pl_][u] = buf_load_u4(pl_ ? kl_rs : kh_rs, (unsigned)((jn + key) * SP_KD + cc * 8) * 2u);
             } else if (i - 8 < 2 * CVB) {
                 const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
+                if (PLO0 && pl_ == 1 && u >= 1) return;
                 const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
                 const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);
                 *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + row * SP_VROW + slot) =
@@ -336,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
                 if (!(COCOS_ABLATE & 2) && s + RA - 1 < NS) al[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + KPLANE + (s + RA - 1) * 16);
                 __builtin_amdgcn_sched_barrier(0);
                 sc = mfma16h(al[cur], qhr[s], sc);
-                if ((s & 1) == 0) piece(s >> 1);            // the 8 key-tile pieces, every other step
+                if ((s & 1) == 0) piece(s >> 1, std::false_type{});   // the 8 key-tile pieces, every other step
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -414,18 +425,19 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
         // ---- O^T += V . P : A = V tile rows (channels) with permuted keys, B = P.  Riding in the gaps: the value-tile
         //      pieces of tile t+1 (one per step) and, in the last steps, the first key fragments of tile t+1 ----------------
         {
+            constexpr bool SKIPLO = VLO0 || (COCOS_ABLATE & 512);
 #pragma unroll
             for (int i = 0; i < NSV; ++i) {
                 const int tt = i / CVB, cb = i % CVB, cur = i % RA, n = i + RA - 1;
                 if (!(COCOS_ABLATE & 2) && n < NSV) {
                     a_h[n % RA] = *reinterpret_cast<const f16x8*>(vbase + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
-                    if (!(COCOS_ABLATE & 512) || (n % CVB) == 0)
+                    if (!SKIPLO || (n % CVB) == 0)
                         a_l[n % RA] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
                 }
                 o[cb] = mfma16h(a_h[cur], ph[tt], o[cb]);
                 o[cb] = mfma16h(a_h[cur], pl[tt], o[cb]);
-                if (!(COCOS_ABLATE & 512) || cb == 0) o[cb] = mfma16h(a_l[cur], ph[tt], o[cb]);
-                piece(8 + i);
+                if (!SKIPLO || cb == 0) o[cb] = mfma16h(a_l[cur], ph[tt], o[cb]);
+                piece(8 + i, vlo0_tag);
                 if (i == NSV - 1) prefetch_k(buf ^ 1);      // (NSV = 2: both in the same step)
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -460,17 +472,18 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     }
 }
 
-template <int CVB, bool STORE_S, bool RAGGED>
+template <int CVB, bool STORE_S, bool RAGGED, bool VLO0>
 static int launch_f16x3_k(const _Float16* qh, const _Float16* ql, const _Float16* kh, const _Float16* kl,
                           const _Float16* vh, const _Float16* vl, float* out, float* lse, float* lg,
-                          const float* v_scale, int B, int Nq, int Nk, int Cv, float scale_log2, hipStream_t stream) {
-    auto kern = corr_fwd_f16x3_kernel<CVB, STORE_S, RAGGED>;
+                          const float* v_scale, const unsigned* v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2,
+                          hipStream_t stream) {
+    auto kern = corr_fwd_f16x3_kernel<CVB, STORE_S, RAGGED, VLO0>;
     const size_t smem = (size_t)2 * 2 * (SP_BK * SP_KROW + CVB * 32 * SP_VROW) * sizeof(_Float16);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int nqb = (Nq + SP_BQ - 1) / SP_BQ;
     hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, stream, qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale,
-                       B, Nq, Nk, Cv, scale_log2);
+                       v_lo_mask, B, Nq, Nk, Cv, scale_log2);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -490,6 +503,19 @@ extern "C" int cocos_debug_read_timing_fwd_f16x3(long long* host8, int reset) {
 }
 #endif
 
+template <int CVB, bool ST, bool RG, typename... A>
+static int cocos_go_both(const _Float16* a, const _Float16* b2, const _Float16* c2, const _Float16* d, const _Float16* e,
+                         const _Float16* f, float* out, float* lse, float* lgp, const float* v_scale_dev,
+                         const unsigned* v_lo_mask_dev, A... rest) {
+    using namespace cocos;
+    if (CVB > 1 && v_lo_mask_dev) {
+        if (int rc = launch_f16x3_k<CVB, ST, RG, (CVB > 1)>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, v_lo_mask_dev, rest...))
+            return rc;
+    }
+    return launch_f16x3_k<CVB, ST, RG, false>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, CVB > 1 ? v_lo_mask_dev : nullptr,
+                                              rest...);
+}
+
 extern "C" size_t cocos_corr_softmax_warp_saved_logits_bytes(int B, int Nq, int Nk) {
     if (B < 1 || Nq < 1 || Nk < 1) return 0;
     return (size_t)B * ((Nk + 31) / 32) * ((Nq + 31) / 32) * 4096;
@@ -497,7 +523,8 @@ extern "C" size_t cocos_corr_softmax_warp_saved_logits_bytes(int B, int Nq, int 
 
 extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void* kh,
                                                  const void* kl, const void* vh, const void* vl, float* out,
-                                                 float* lse, void* saved_logits, const float* v_scale_dev, int B,
+                                                 float* lse, void* saved_logits, const float* v_scale_dev,
+                                                 const unsigned* v_lo_mask_dev, int B,
                                                  int K, int Nq, int Nk, int Cv, float inv_temperature,
                                                  float operand_scale, cocos_stream_t stream) {
     using namespace cocos;
@@ -529,8 +556,10 @@ extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql,
     const _Float16 *a = static_cast<const _Float16*>(qh), *b2 = static_cast<const _Float16*>(ql),
                    *c2 = static_cast<const _Float16*>(kh), *d = static_cast<const _Float16*>(kl),
                    *e = static_cast<const _Float16*>(vh), *f = static_cast<const _Float16*>(vl);
+    // with a mask and more than one value block: both instantiations are launched, the kernel the mask does not select
+    // returns at once (the choice is data on the device; no host round trip)
 #define COCOS_GO(CVB, ST, RG) \
-    launch_f16x3_k<CVB, ST, RG>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, B, Nq, Nk, Cv, scale_log2, s)
+    cocos_go_both<CVB, ST, RG>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, v_lo_mask_dev, B, Nq, Nk, Cv, scale_log2, s)
 #define COCOS_CVB(CVB)                                                           \
     case CVB:                                                                    \
         if (lgp) return ragged ? COCOS_GO(CVB, true, true) : COCOS_GO(CVB, true, false); \

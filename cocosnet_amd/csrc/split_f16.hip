@@ -129,6 +129,26 @@ __global__ __launch_bounds__(256) void split_f16_rows_kernel(const float* __rest
     lo[i] = b;
 }
 
+// bit (c >> 5) of *mask |= (some element of channel c of a channel-major f16 plane [B,C,N] is non-zero): one workgroup per
+// (b, c) row.  Used on the LO plane of the values: label / mask channels are exact in f16, their lo plane is all zero and
+// the K2 split kernels then skip it for whole 32-channel blocks (corr_fused_fwd_f16x3.hip, corr_fused_bwd_f16x3.hip).
+__global__ __launch_bounds__(256) void f16_plane_block_mask_kernel(const _Float16* __restrict__ plane, int C, int N,
+                                                                   unsigned* __restrict__ mask) {
+    const int row = blockIdx.x, c = row % C;
+    const unsigned short* p = reinterpret_cast<const unsigned short*>(plane) + (size_t)row * N;
+    unsigned any = 0;
+    const bool vec = (N % 8 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15u) == 0);
+    if (vec) {
+        for (int i = threadIdx.x; i < N / 8; i += 256) {
+            const u32x4 v = reinterpret_cast<const u32x4*>(p)[i];
+            any |= (v.x | v.y | v.z | v.w) & 0x7fff7fffu;           // -0 counts as zero
+        }
+    } else {
+        for (int i = threadIdx.x; i < N; i += 256) any |= p[i] & 0x7fffu;
+    }
+    if (__builtin_amdgcn_ballot_w64(any != 0) != 0 && (threadIdx.x & 63) == 0) atomicOr(mask, 1u << (c >> 5));
+}
+
 }  // namespace cocos
 
 static int split_f16_launch(const float* x, void* hi, void* lo, int B, int C, int N, int Cpad, int transpose,
@@ -188,6 +208,18 @@ extern "C" int cocos_split_f16_rows(const float* x, void* hi, void* lo, int rows
     hipLaunchKernelGGL(split_f16_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x,
                        static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), rows, cols, cols_pad, scale, amax_dev,
                        scale_out_dev);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_f16_plane_block_mask(const void* plane, int B, int C, int N, unsigned* mask_inout_dev,
+                                          cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(plane && mask_inout_dev, COCOS_ERR_INVALID, "f16_plane_block_mask: null pointer");
+    COCOS_REQUIRE(B >= 1 && C >= 1 && C <= 1024 && N >= 1 && (long long)B * C <= 0x7fffffffll, COCOS_ERR_INVALID,
+                  "f16_plane_block_mask: bad dims B=%d C=%d N=%d (C <= 1024)", B, C, N);
+    hipLaunchKernelGGL(f16_plane_block_mask_kernel, dim3((unsigned)(B * C)), dim3(256), 0, as_stream(stream),
+                       static_cast<const _Float16*>(plane), C, N, mask_inout_dev);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

@@ -34,6 +34,8 @@ PRECISION = os.environ.get("COCOS_PRECISION", "f16x3")
 #: the f16 MFMA — the streaming kernels below at the reference's shapes, else the split GEMM of sgemm_f16x3.hip
 #: (operands split on the fly, staged pieces converted/committed between MFMAs).
 PROJ_PRECISION = os.environ.get("COCOS_PROJ_PRECISION", "f16x3")
+#: K2 split kernels: test V's f16 lo plane per 32-channel block and skip all-zero blocks (exact label / mask channels)
+VALUE_LO_SKIP = os.environ.get("COCOS_VALUE_LO_SKIP", "1") != "0"
 #: K0 at the reference's own shapes (<= 416 input channels, HW % 64 == 0): y = W x and dx = W^T dy on the streaming
 #: kernel (proj_stream_f16x3.hip: weight planes resident in the accumulator file, x / y touched once), dw + db as one
 #: streaming reduction (proj_dw_f16x3.hip).  "0" = the general split GEMM everywhere (A/B, tests).
@@ -207,6 +209,15 @@ def split_f16(x: torch.Tensor, transpose: bool, scale: float = 1.0, cpad=None, a
     return hi, lo
 
 
+def f16_plane_block_mask(plane: torch.Tensor) -> torch.Tensor:
+    """plane [B,C,N] f16 (channel-major) -> 1-element int32 CUDA tensor whose bit (c >> 5) says "channel block c//32 has
+    a non-zero element" (cocos_f16_plane_block_mask; no host sync)."""
+    B, C, N = plane.shape
+    cell = _zero_cell(plane.device)                      # fp32 zero = integer zero
+    _call("f16_plane_block_mask", "cocos_f16_plane_block_mask", plane.data_ptr(), B, C, N, cell.data_ptr(), _stream())
+    return cell
+
+
 def _split_bwd_ok(B, Nq, Nk, Cv):
     """Shapes the split-precision K2 backward takes (cocos_corr_softmax_warp_bwd_query_f16x3 + the planes GEMM)."""
     return (Nk % 8 == 0 and Nq % 8 == 0 and Cv <= MAX_FUSED_CV and B * Nq * Nk * 4 <= MAX_DS_WORKSPACE_BYTES
@@ -230,16 +241,18 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         logits_t = None
         ctx.split = planes is not None
         ctx.v_amax = None
+        ctx.v_lomask = None
         if planes is not None:       # split-precision flavour: same outputs, f16x3 matrix products
-            qh, ql, kh, kl, vh, vl, v_scale, v_amax = planes[:8]
+            qh, ql, kh, kl, vh, vl, v_scale, v_amax, v_lomask = planes[:9]
             if keep_logits:          # the forward's private tile-blocked layout (cocos_hip.h), opaque here
                 nbytes = _lib.load().cocos_corr_softmax_warp_saved_logits_bytes(B, Nq, Nk)
                 logits_t = torch.empty(nbytes // 4, device=qn.device, dtype=torch.float32)
             _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd_f16x3", qh.data_ptr(), ql.data_ptr(),
                   kh.data_ptr(), kl.data_ptr(), vh.data_ptr(), vl.data_ptr(), out.data_ptr(), lse.data_ptr(),
-                  _ptr(logits_t), v_scale.data_ptr(), B, K, Nq, Nk, Cv, float(inv_temperature),
+                  _ptr(logits_t), v_scale.data_ptr(), _ptr(v_lomask), B, K, Nq, Nk, Cv, float(inv_temperature),
                   SPLIT_OPERAND_SCALE, _stream())
             ctx.v_amax = v_amax
+            ctx.v_lomask = v_lomask
         else:
             keep = (keep_logits and B * Nq * Nk * 4 <= MAX_DS_WORKSPACE_BYTES and Nq * Nk * 4 < 2 ** 31 - 1)
             logits_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if keep else None
@@ -250,7 +263,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         ctx.logits_t = logits_t
         ctx.inv_t = float(inv_temperature)
         # channel-major planes of k_scale*qn, k_scale*kn for the split-precision backward (when given)
-        ctx.cplanes = planes[8:] if (planes is not None and len(planes) > 8 and logits_t is not None) else None
+        ctx.cplanes = planes[9:] if (planes is not None and len(planes) > 9 and logits_t is not None) else None
         return out
 
     @staticmethod
@@ -290,8 +303,8 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                   kcl.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(),
                   g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), logits_t.data_ptr(),
                   dqn_buf.data_ptr(), _ptr(dsh), _ptr(dsl), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
-                  v_scale.data_ptr(), ds_scale.data_ptr(), B, K, Nq, Nk, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE,
-                  blocked, st)
+                  v_scale.data_ptr(), ds_scale.data_ptr(), _ptr(ctx.v_lomask), B, K, Nq, Nk, Cv, cvp, ctx.inv_t,
+                  SPLIT_OPERAND_SCALE, blocked, st)
             if want_k:
                 _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
                       dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 / SPLIT_OPERAND_SCALE,
@@ -363,8 +376,11 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes |
                 if v_amax is None:
                     v_amax = absmax(vv)
                 vh, vl, v_scale = split_f16(vv, False, amax=v_amax)
+                # which 32-channel blocks of V have a non-zero lo plane (one-hot labels / masks are exact in f16:
+                # theirs is all zero and the kernels skip it) — one pass over the lo plane, only when it can pay
+                v_lomask = f16_plane_block_mask(vl) if (VALUE_LO_SKIP and vv.shape[1] > 32) else None
                 pl = (*planes.get(qn, True, SPLIT_OPERAND_SCALE), *planes.get(kn, True, SPLIT_OPERAND_SCALE),
-                      vh, vl, v_scale, v_amax)
+                      vh, vl, v_scale, v_amax, v_lomask)
                 if keep:   # the backward wants the channel-major planes as well
                     pl += (*planes.get(qn, False, SPLIT_OPERAND_SCALE), *planes.get(kn, False, SPLIT_OPERAND_SCALE))
         return _CorrSoftmaxWarp.apply(qn, kn, vv, inv_temperature, keep, pl)

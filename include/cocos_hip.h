@@ -118,8 +118,15 @@ int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void
                                       const void* vh, const void* vl,
                                       float* out, float* lse, void* saved_logits /* nullable */,
                                       const float* v_scale_dev /* nullable */,
+                                      const unsigned* v_lo_mask_dev /* nullable */,
                                       int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
                                       float operand_scale, cocos_stream_t stream);
+/* bit (c >> 5) of *mask_inout_dev |= (channel c of the channel-major f16 plane [B,C,N] has a non-zero element); the
+ * cell must hold 0 (or an earlier partial mask) on entry; C <= 1024.  Run on the LO plane of V: value channels that
+ * are exact in f16 (one-hot labels, masks) have an all-zero lo plane, and when every 32-channel block but the first
+ * reports zero the K2 split kernels skip that plane's staging, fragment reads and MFMA term for those blocks
+ * (v_lo_mask_dev of the two calls; NULL = no information, the general path). */
+int cocos_f16_plane_block_mask(const void* plane, int B, int C, int N, unsigned* mask_inout_dev, cocos_stream_t stream);
 
 /* Split-precision backward of K2 (same reference lines as cocos_corr_softmax_warp_bwd_query / _bwd_key_from_ds):
  *   cocos_split_f16_ex: as cocos_split_f16, plus (a) transposed rows padded with zero channels to Cpad halfs,
@@ -155,7 +162,7 @@ int cocos_corr_softmax_warp_bwd_query_f16x3(
     const float* g_scale_dev, const float* out, const float* dout, const float* lse, const void* saved_logits,
     float* dqn, void* dsh /* nullable */, void* dsl /* nullable */, void* psh /* nullable */,
     void* psl /* nullable */, const float* v_amax_dev, const float* v_scale_dev /* nullable */,
-    float* ds_scale_out_dev,
+    float* ds_scale_out_dev, const unsigned* v_lo_mask_dev /* nullable: as in the forward call */,
     int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale,
     int planes_blocked, cocos_stream_t stream);
 int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* c,

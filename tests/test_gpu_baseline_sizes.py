@@ -514,3 +514,42 @@ def test_rccl_world_size_one_smoke():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+@pytest.mark.parametrize("labels_exact", [True, False])
+def test_value_lo_plane_skipping_is_exact(labels_exact):
+    """V = [3 image channels | one-hot labels]: the label blocks' f16 lo plane is all zero and the split kernels skip it
+    (cocos_f16_plane_block_mask -> v_lo_mask); with soft labels the general path runs.  Both must match the fp64 oracle,
+    forward and theta/phi gradients, and the mask must say what the data is."""
+    from cocosnet_amd import ops
+    from oracle import torch_ref as tr
+    B, N, Cv = 2, 1024, 3 + 70
+    g = torch.Generator(device="cuda").manual_seed(21)
+    nrm = lambda x: (x - x.mean(1, keepdim=True)) / (x - x.mean(1, keepdim=True)).norm(dim=1, keepdim=True)
+    q = nrm(torch.randn(B, 256, N, device="cuda", generator=g)).requires_grad_(True)
+    k = nrm(0.3 * q.detach() + torch.randn(B, 256, N, device="cuda", generator=g)).requires_grad_(True)
+    img = torch.rand(B, 3, N, device="cuda", generator=g) * 2 - 1
+    lab = torch.randint(0, 70, (B, 1, N), device="cuda", generator=g)
+    onehot = torch.zeros(B, 70, N, device="cuda").scatter_(1, lab, 1.0)
+    if not labels_exact:
+        onehot = onehot * 0.9 + 0.1 * torch.rand(B, 70, N, device="cuda", generator=g)
+    v = torch.cat([img, onehot], 1).contiguous()
+    # the mask itself
+    vh, vl, _ = ops.split_f16(v, False, amax=ops.absmax(v))
+    mask = int(ops.f16_plane_block_mask(vl).view(torch.int32).item())
+    assert (mask & 1) == 1 and ((mask & ~1) == 0) == labels_exact
+    prev = ops.PRECISION
+    ops.PRECISION = "f16x3"
+    try:
+        out = ops.corr_softmax_warp(q, k, v, 100.0)
+        go = torch.randn(out.shape, device="cuda", generator=g)
+        out.backward(go)
+    finally:
+        ops.PRECISION = prev
+    qd, kd = q.detach().double().requires_grad_(True), k.detach().double().requires_grad_(True)
+    p = torch.softmax(torch.einsum("bkq,bkj->bqj", qd, kd) * 100.0, dim=2)
+    ref = torch.einsum("bqj,bcj->bcq", p, v.double())
+    ref.backward(go.double())
+    for a, r, what in ((out, ref, "out"), (q.grad, qd.grad, "dq"), (k.grad, kd.grad, "dk")):
+        err = (a.double() - r.detach()).abs().max().item()
+        assert err <= 2e-4 * r.abs().max().item(), f"{what}: {err:.3e}"
