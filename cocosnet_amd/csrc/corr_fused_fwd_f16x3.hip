@@ -105,6 +105,9 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     const _Float16* __restrict__ kl, const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
     float* __restrict__ out, float* __restrict__ lse, float* __restrict__ lg, const float* __restrict__ v_scale,
     const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2 /* inv_temperature * log2(e) / (q_scale * k_scale) */) {
+    // FIRST thing (before the resident query slice is fetched): the instantiation the device-side mask does not select
+    // leaves.  Uniform: lo plane of every value block but the first all zero (nullptr / single block: general path).
+    if ((CVB > 1 && v_lo_mask != nullptr && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u) != VLO0) return;
     constexpr int CVP = CVB * 32;
     constexpr int KPLANE = SP_BK * SP_KROW;          // halfs per K plane per buffer
     constexpr int VPLANE = CVP * SP_VROW;
@@ -260,9 +263,6 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     // tile t's P.V loop, so the QK loop never starts cold (round 1 / step 1 read them right after the barrier:
     // ~450 cycles of every tile's QK phase were that bubble — tools/ablate_fwd.sh, profiles/r02_ablation_fwd.txt).
     constexpr int RA = 4, NS = SP_KD / 16;
-    // uniform: the lo plane of every value block but the first is all zero (nullptr / single block: general path);
-    // the instantiation that does not match leaves
-    if ((CVB > 1 && v_lo_mask != nullptr && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u) != VLO0) return;
     f16x8 ah[RA], al[RA];
     auto prefetch_k = [&](int buf) {
         const _Float16* kb = kt + buf * 2 * KPLANE + c * SP_KROW + h * 8;
