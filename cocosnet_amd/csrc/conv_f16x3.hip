@@ -30,22 +30,16 @@
 //       contraction); both operands are position-contiguous in memory, so both LDS images are k-contiguous and the
 //       fragments are plain 16-byte reads.  A thread's rows (co, k) are fixed for the whole kernel; only the position
 //       advances.
-// Tile BM (128 | 256) x 128 x 32, 4 waves as 2 x 2, double-buffered LDS, two register stages, staging pieces placed by
-// hand between the MFMA groups; ~2*M*N*K useful FLOPs, x3 issued.
+// Tile BM (128 | 256) x 128 x 32, 4 waves as 2 x 2, double-buffered LDS, staging work handed out between the MFMAs by a
+// sched_group_barrier pipeline; ~2*M*N*K useful FLOPs, x3 issued.  Compile-time knobs below = measured experiments
+// (DESIGN.md section 3.3), the defaults are what shipped.
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef COCOS_CONV_SCHED
-#define COCOS_CONV_SCHED 1      // 0: staging pieces pinned after each group of 6 MFMAs; 1: sched_group_barrier pipeline
-                                // (measured 0.491 -> 0.470 ms on the 407-channel ResidualBlock convolution)
-#endif
 #ifndef COCOS_CONV_SCHED_N
-#define COCOS_CONV_SCHED_N 6
-#endif
-#ifndef COCOS_CONV_MFMA_ORDER
-#define COCOS_CONV_MFMA_ORDER 1
-#endif
+#define COCOS_CONV_SCHED_N 6    // non-MFMA instructions handed out per MFMA gap (4..8 measured equal; pinning the staging
+#endif                          // pieces after each group of 6 MFMAs instead: 0.491 vs 0.470 ms on the 407-channel block)
 #ifndef COCOS_CONV_WGRAD_PIPE
 #define COCOS_CONV_WGRAD_PIPE 0  // weight gradient: 1 = the forward kernel's step shape (mid barrier, fragments half a step ahead, one stage):
                                 // measured neutral (1.591 vs 1.582 ms fwd+bwd) and it spills, so 0 = barrier at the end, two stages
@@ -378,14 +372,6 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 if (!(COCOS_CONV_ABLATE & 8)) {
-#if COCOS_CONV_MFMA_ORDER == 0
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s][j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
-                    }
-#else
                     // term-major: two MFMAs on the same accumulator are never neighbours (an instruction issued between
                     // two dependent MFMAs costs a ~43-cycle bubble on gfx950; between independent ones ~6)
 #pragma unroll
@@ -394,7 +380,6 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
                     for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s][j], acc[i][j], 0, 0, 0);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
-#endif
                 }
                 if (s == 0) {
                     commit_a(S, buf ^ 1, i);
