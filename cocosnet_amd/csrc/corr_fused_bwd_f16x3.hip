@@ -74,7 +74,7 @@ struct DsRegs {
     unsigned hw[8], lw[8];     // f16 hi / lo, two values per register: register j>>1, half j&1
 };
 
-template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED, bool VLO0>
+template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED, bool VLO0, bool BLK>
 __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     const _Float16* __restrict__ kch, const _Float16* __restrict__ kcl,   // [B,256,Nk] planes of k_scale*kn
     const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] planes of s_v*v
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     const float* __restrict__ v_scale,                                     // s_v (device) or NULL
     float* __restrict__ ds_scale_out,                                      // out: s_o * s_v * ds_shift (device)
     const unsigned* __restrict__ v_lo_mask,                                // bit cb: value block cb has a non-zero lo plane (or NULL)
-    int B, int Nq, int Nk, int Cv, float inv_t, float k_scale, int planes_blocked) {
+    int B, int Nq, int Nk, int Cv, float inv_t, float k_scale) {
     constexpr int CVP = CVB * 32;
     constexpr int CVS = CVP / 16;                     // k-steps of the dP product
     constexpr int KB = BQH_KD / 32;                   // channel blocks of dqn
@@ -389,10 +389,38 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             split_pair_rtz(dsv[0], dsv[1], out.hw[r >> 1], out.lw[r >> 1]);
             if (STORE_P) split_pair_rtz(pv[0], pv[1], pout.hw[r >> 1], pout.lw[r >> 1]);
         }
-        if (STORE_DS && (r & 1) && !(COCOS_ABLATE & 8)) stage_transpose(r >> 1, out.hw[r >> 1], out.lw[r >> 1]);
+        if (!BLK && STORE_DS && (r & 1) && !(COCOS_ABLATE & 8)) stage_transpose(r >> 1, out.hw[r >> 1], out.lw[r >> 1]);
     };
-    // the wave's transposed 32x32 tile: LDS -> 16-byte row pieces of the [Nk][Nq] planes
-    auto store_planes = [&](int t, __amdgpu_buffer_rsrc_t h_rs, __amdgpu_buffer_rsrc_t l_rs) {
+    // BLK: the planes are stored in the accumulator's own orientation, [query][key], as [Nq/32][Nk/32] blocks of
+    // 2 x [32 queries][16 keys] halfs (2 KB; halves = keys 0..15 | 16..31 of the tile): lane (c, h) holds keys 8m + 4h .. +3 of query c in regs (2m, 2m+1); ONE
+    // v_permlane32_swap per register pair of groups (m0, m1) = (0,1), (2,3) leaves lane h = 0 with the 8 consecutive keys of
+    // group m0 and lane h = 1 with those of m1 (probed: tools/probes/permlane_probe.hip) — 16 bytes per lane, the wave's
+    // tile is 2 KB contiguous and leaves as two stores per plane.  No LDS round trip; the key-side GEMM reads its B
+    // fragments from this layout with ds_read_b64_tr_b16 (hgemm_f16x3.hip, b_blocked = 2).
+    auto store_regs_blk = [&](int t, const DsRegs& d, __amdgpu_buffer_rsrc_t h_rs, __amdgpu_buffer_rsrc_t l_rs) {
+        if (COCOS_ABLATE & 8) return;
+        const unsigned blk = (unsigned)((((q0 >> 5) + wave) * (Nk >> 5) + t) * 2048);     // bytes: block (q-block, key tile t)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {                 // group pairs (0,1) and (2,3)
+            const int m0 = 2 * pp, m1 = 2 * pp + 1;         // lane h = 0 ends up with group m0, h = 1 with m1
+            u32x4 xh, xl;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const auto sh = __builtin_amdgcn_permlane32_swap(d.hw[2 * m0 + i], d.hw[2 * m1 + i], false, false);
+                const auto sl = __builtin_amdgcn_permlane32_swap(d.lw[2 * m0 + i], d.lw[2 * m1 + i], false, false);
+                xh[i] = sh[0]; xh[2 + i] = sh[1];
+                xl[i] = sl[0]; xl[2 + i] = sl[1];
+            }
+            // block = two 1 KB halves [pp][32 queries][16 keys]: each store instruction writes one half, contiguous
+            unsigned off = blk + (unsigned)(pp * 1024 + c * 32 + h * 16);
+            if (COCOS_ABLATE & 32) off = (unsigned)(lane * 16 + wave * 1024 + pp * 4096);
+            __builtin_amdgcn_raw_buffer_store_b128(xh, h_rs, (int)off, 0, COCOS_STREAM_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(xl, l_rs, (int)off, 0, COCOS_STREAM_AUX);
+        }
+    };
+    // !BLK: the wave's transposed 32x32 tile: LDS -> 16-byte row pieces of the row-major [Nk][Nq] planes
+    auto store_planes = [&](int t, const DsRegs& d, __amdgpu_buffer_rsrc_t h_rs, __amdgpu_buffer_rsrc_t l_rs) {
+        if (BLK) { store_regs_blk(t, d, h_rs, l_rs); return; }
         if (COCOS_ABLATE & 8) return;
         // (LDS instructions of one wave execute in order: the 2-byte writes above are visible here)
 #pragma unroll
@@ -401,12 +429,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             const u32x4 xh = *reinterpret_cast<const u32x4*>(dstile + key * DSROW + qc);
             const u32x4 xl = *reinterpret_cast<const u32x4*>(dstile + DSPLANE + key * DSROW + qc);
             const int row = t * 32 + key, col = q0 + wave * 32 + qc;        // Nq % 8 == 0: whole pieces
-            // blocked layout ([128 keys][32 queries] blocks of 8 KB, see cocos_hip.h): the wave's whole
-            // 32x32 tile is 2 KB contiguous, and a k-block of the key-side GEMM is one contiguous block
-            const unsigned lin = planes_blocked
-                ? (unsigned)(((row >> 7) * (Nq >> 5) + (col >> 5)) * 4096 + (row & 127) * 32 + (col & 31))
-                : (unsigned)(row * Nq + col);
-            unsigned off = (row < Nk && col < Nq) ? lin * 2u : kBufOob;
+            unsigned off = (row < Nk && col < Nq) ? (unsigned)(row * Nq + col) * 2u : kBufOob;
             if (COCOS_ABLATE & 32) off = (unsigned)(lane * 16 + wave * 1024 + pass * 4096);
             __builtin_amdgcn_raw_buffer_store_b128(xh, h_rs, (int)off, 0, COCOS_STREAM_AUX);
             __builtin_amdgcn_raw_buffer_store_b128(xl, l_rs, (int)off, 0, COCOS_STREAM_AUX);
@@ -415,9 +438,11 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     auto store_p_tile = [&](int t, const DsRegs& pr) {
         // same transposition for the P planes, through the same per-wave buffer (after the dS'' pieces have been
         // read back; one wave's LDS instructions execute in order)
+        if (!BLK) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) stage_transpose(j, pr.hw[j], pr.lw[j]);
-        store_planes(t, ph_rs, pl_rs);
+            for (int j = 0; j < 8; ++j) stage_transpose(j, pr.hw[j], pr.lw[j]);
+        }
+        store_planes(t, pr, ph_rs, pl_rs);
     };
 
     // ---- dqn += K(t-1) . dS''(t-1) : 16 steps of 3 MFMAs (2 k-steps x 8 channel blocks), operands one step ahead.
@@ -508,7 +533,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
             if ((r & 3) == 3) load_s(sA[r >> 2], 2, r >> 2);
         }
         prefetch_v(1);
-        if (STORE_DS) store_planes(0, dh_rs, dl_rs);
+        if (STORE_DS) store_planes(0, dA, dh_rs, dl_rs);
         if (STORE_P) store_p_tile(0, pA);
     }
     // iterations 1 .. ntiles-1, two per trip so that every register set is named statically:
@@ -521,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
         BPH_T(tp2);
         phase_dqn(t, prev, true_type{}, true_type{}, s, dp0, cur, pcur);
         BPH_T(tp3);
-        if (STORE_DS) store_planes(t, dh_rs, dl_rs);
+        if (STORE_DS) store_planes(t, cur, dh_rs, dl_rs);
         if (STORE_P) store_p_tile(t, pcur);
         BPH_T(tp4);
         BPH_ADD(0, tp0, tp1); BPH_ADD(3, tp1, tp2); BPH_ADD(1, tp2, tp3); BPH_ADD(2, tp3, tp4);
@@ -569,14 +594,19 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
     do {                                                                                                     \
         if (storep) COCOS_GO2(DS, true, RG); else COCOS_GO2(DS, false, RG);                                  \
     } while (0)
-#define COCOS_GO3(DS, SP, RG, VL, MASK)                                                                      \
+#define COCOS_GO4(DS, SP, RG, VL, MASK, BL)                                                                  \
     do {                                                                                                     \
-        auto kern = corr_bwd_query_f16x3_kernel<CVB, DS, SP, RG, VL>;                                        \
+        auto kern = corr_bwd_query_f16x3_kernel<CVB, DS, SP, RG, VL, BL>;                                        \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                             \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
         hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, s, kch, kcl, vph, vpl, gph, gpl, g_scale,   \
                            outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, MASK, B, Nq, \
-                           Nk, Cv, inv_t, k_scale, blocked);                                                 \
+                           Nk, Cv, inv_t, k_scale);                                                          \
+    } while (0)
+    /* blocked planes ([query][key] blocks, see the kernel) only exist for whole tiles */
+#define COCOS_GO3(DS, SP, RG, VL, MASK)                                                                      \
+    do {                                                                                                     \
+        if (!RG && blocked) COCOS_GO4(DS, SP, RG, VL, MASK, (!RG)); else COCOS_GO4(DS, SP, RG, VL, MASK, false); \
     } while (0)
     /* with a mask and more than one value block both instantiations are launched: the one the mask does not select
        returns at once (the choice is data on the device; no host round trip) */
@@ -590,6 +620,7 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
 #undef COCOS_GO
 #undef COCOS_GO2
 #undef COCOS_GO3
+#undef COCOS_GO4
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

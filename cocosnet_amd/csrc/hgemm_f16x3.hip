@@ -29,7 +29,7 @@ constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row
 // an exec-mask region (s_and_saveexec / s_or per load: ~120 scalar instructions per k-step of 96 MFMAs).
 // BSTREAM: the B operand is a stream that nothing re-reads (the dS'' / P planes of the K2 backward: 0.5 GB per launch):
 // loaded `nt` so that it does not evict the A planes (4 MB per sample, re-read by every N tile) from the XCD's L2.
-template <bool EXACT, bool BSTREAM>
+template <bool EXACT, int BMODE>
 __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __restrict__ ah,
                                                              const _Float16* __restrict__ al,
                                                              const _Float16* __restrict__ bh,
@@ -37,8 +37,15 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                                                              float* __restrict__ C, int M, int N, int K,
                                                              float host_scale,
                                                              const float* __restrict__ dev_scale,
-                                                             const float* __restrict__ dev_scale2, int b_blocked) {
-    constexpr int APLANE = HG_BM * HG_ROW, BPLANE = HG_BN * HG_ROW;
+                                                             const float* __restrict__ dev_scale2) {
+    // BMODE 0: B planes row-major [N][K]; 1: [N/128][K/32] blocks of [128 n][32 k] (k contiguous); 2: the orientation the
+    // K2 query backward leaves its dS'' / P planes in — [K/32][N/32] blocks of 2 x [32 k][16 n] (n contiguous, 2 KB): staged
+    // as they are into an LDS image [32 k][128 n + 32 pad] and read as MFMA fragments with ds_read_b64_tr_b16 (the
+    // scheme of conv_f16x3.hip).  Modes 1 and 2 are streams nothing re-reads: loaded `nt`.
+    constexpr bool BSTREAM = BMODE != 0;
+    constexpr int HG_GROW = HG_BN + 32;             // halfs per k row of the mode-2 image (320 B = 64 B mod 256 B)
+    constexpr int APLANE = HG_BM * HG_ROW, BPLANE = HG_BN * HG_ROW;     // (= 32 * HG_GROW: both images are 5120 halfs)
+    static_assert(32 * HG_GROW == HG_BN * HG_ROW, "B plane size");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][256][ROW]
     _Float16* const bt = at + 2 * 2 * APLANE;                      // [2 buf][hi|lo][128][ROW]
@@ -71,6 +78,18 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
     // TWO register stages: LDS holds k-blocks t and t+1, the stages hold t+1 / t+2 resp. t+2 / t+3 in flight — the
     // B planes stream from HBM and one step (~1.7 us) of look-ahead does not cover the latency.  No branch around
     // the loads, so the compiler's vmcnt waits are exact.
+    // chunk g (0..511) of the B tile of a step: global offset in halfs and LDS position
+    auto b_goff = [&](int g, int k0) -> unsigned {
+        const int row = g >> 2, kc = g & 3;
+        if (BMODE == 2)      // block = 2 x [32 k][16 n]: 8-n chunk kc of k row q sits in half kc >> 1
+            return (unsigned)((((k0 >> 5) * (N >> 5) + (n0 >> 5) + (g >> 7)) * 1024) + (kc >> 1) * 512 + ((g & 127) >> 2) * 16 + (kc & 1) * 8);
+        if (BMODE == 1) return (unsigned)(((n0 >> 7) * (K >> 5) + (k0 >> 5)) * 4096 + row * 32 + kc * 8);
+        return (unsigned)((n0 + row) * K + k0 + kc * 8);
+    };
+    auto b_lds = [&](int g) -> int {
+        if (BMODE == 2) return ((g & 127) >> 2) * HG_GROW + (g >> 7) * 32 + (g & 3) * 8;
+        return (g >> 2) * HG_ROW + (g & 3) * 8;
+    };
     struct Stage { u32x4 a[2][4], b[2][2]; };
     Stage st0, st1;
     // (loads are issued in the order in which the step loop consumes them: A h0 l0 h1 l1 ..., then B)
@@ -86,11 +105,9 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
-            // b_blocked: B is stored as [N/128][K/32] blocks of [128][32] halfs (8 KB, contiguous) — exactly one
-            // (N tile, k-block) of this kernel; linear otherwise
-            unsigned off = b_blocked ? (unsigned)(((n0 >> 7) * (K >> 5) + (k0 >> 5)) * 4096 + row * 32 + kc * 8) * 2u
-                                     : (unsigned)((n0 + row) * K + k0 + kc * 8) * 2u;
-            if (!EXACT && (n0 + row >= N || k0 + kc * 8 >= K)) off = kBufOob;
+            unsigned off = b_goff(g, k0) * 2u;
+            if (!EXACT && BMODE != 2 && (n0 + row >= N || k0 + kc * 8 >= K)) off = kBufOob;
+            if (BMODE == 2 && k0 >= K) off = kBufOob;                       // look-ahead past the last k-block
             st.b[0][u] = __builtin_amdgcn_raw_buffer_load_b128(bh_rs, (int)off, 0, BSTREAM ? 2 : 0);
             st.b[1][u] = __builtin_amdgcn_raw_buffer_load_b128(bl_rs, (int)off, 0, BSTREAM ? 2 : 0);
         }
@@ -106,9 +123,9 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
-            *reinterpret_cast<u32x4*>(bb + row * HG_ROW + kc * 8) = st.b[0][u];
-            *reinterpret_cast<u32x4*>(bb + BPLANE + row * HG_ROW + kc * 8) = st.b[1][u];
+            const int g = u * 256 + tid;
+            *reinterpret_cast<u32x4*>(bb + b_lds(g)) = st.b[0][u];
+            *reinterpret_cast<u32x4*>(bb + BPLANE + b_lds(g)) = st.b[1][u];
         }
     };
 
@@ -136,24 +153,37 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
         } else {                                         // B: plane (idx - 8) & 1, chunk (idx - 8) >> 1
             const int pl = (idx - 8) & 1, u = (idx - 8) >> 1;
             const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
-            *reinterpret_cast<u32x4*>(bb + pl * BPLANE + row * HG_ROW + kc * 8) = st.b[pl][u];
-            unsigned off = b_blocked ? (unsigned)(((n0 >> 7) * (K >> 5) + (k0 >> 5)) * 4096 + row * 32 + kc * 8) * 2u
-                                     : (unsigned)((n0 + row) * K + k0 + kc * 8) * 2u;
-            if (!EXACT && (n0 + row >= N || k0 + kc * 8 >= K)) off = kBufOob;
+            *reinterpret_cast<u32x4*>(bb + pl * BPLANE + b_lds(g)) = st.b[pl][u];
+            unsigned off = b_goff(g, k0) * 2u;
+            if (!EXACT && BMODE != 2 && (n0 + row >= N || k0 + kc * 8 >= K)) off = kBufOob;
+            if (BMODE == 2 && k0 >= K) off = kBufOob;
             st.b[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(pl ? bl_rs : bh_rs, (int)off, 0, BSTREAM ? 2 : 0);
         }
     };
+    // mode 2: transpose-read addressing (lane i of a 16-lane group supplies row i>>2, columns 4(i&3)..+3 of its 4 x 16 block)
+    const int tr_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * HG_GROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     auto step = [&](int t, Stage& st) {
         const int buf = t & 1;
         const _Float16* ab = at + buf * 2 * APLANE + (wm * 128 + c) * HG_ROW + h * 8;
-        const _Float16* bb = bt + buf * 2 * BPLANE + (wn * 64 + c) * HG_ROW + h * 8;
+        const _Float16* bb = bt + buf * 2 * BPLANE + (BMODE == 2 ? wn * 64 + tr_off : (wn * 64 + c) * HG_ROW + h * 8);
 #pragma unroll
         for (int s = 0; s < HG_BK / 16; ++s) {
             f16x8 bvh[2], bvl[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                bvh[j] = *reinterpret_cast<const f16x8*>(bb + j * 32 * HG_ROW + s * 16);
-                bvl[j] = *reinterpret_cast<const f16x8*>(bb + BPLANE + j * 32 * HG_ROW + s * 16);
+                if (BMODE == 2) {
+                    typedef short s16x4 __attribute__((ext_vector_type(4)));
+                    const _Float16* p = bb + s * 16 * HG_GROW + j * 32;
+                    const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+                    const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * HG_GROW));
+                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + BPLANE));
+                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + BPLANE + 4 * HG_GROW));
+                    bvh[j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    bvl[j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                } else {
+                    bvh[j] = *reinterpret_cast<const f16x8*>(bb + j * 32 * HG_ROW + s * 16);
+                    bvl[j] = *reinterpret_cast<const f16x8*>(bb + BPLANE + j * 32 * HG_ROW + s * 16);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -217,14 +247,18 @@ extern "C" int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void*
     COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "hgemm_f16x3: grid too large");
     const size_t smem = (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16);
     const bool exact = M % HG_BM == 0 && N % HG_BN == 0 && K % HG_BK == 0;
-    auto kern = exact ? (b_blocked ? hgemm_f16x3_kernel<true, true> : hgemm_f16x3_kernel<true, false>)
-                      : (b_blocked ? hgemm_f16x3_kernel<false, true> : hgemm_f16x3_kernel<false, false>);
+    COCOS_REQUIRE(b_blocked >= 0 && b_blocked <= 2 && (b_blocked != 2 || exact || (N % 128 == 0 && K % 32 == 0)),
+                  COCOS_ERR_INVALID, "hgemm_f16x3: b_blocked=%d", b_blocked);
+    auto kern = exact ? (b_blocked == 2 ? hgemm_f16x3_kernel<true, 2> : b_blocked ? hgemm_f16x3_kernel<true, 1>
+                                                                                  : hgemm_f16x3_kernel<true, 0>)
+                      : (b_blocked == 2 ? hgemm_f16x3_kernel<false, 2> : b_blocked ? hgemm_f16x3_kernel<false, 1>
+                                                                                   : hgemm_f16x3_kernel<false, 0>);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),
                        static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
                        static_cast<const _Float16*>(b_hi), static_cast<const _Float16*>(b_lo), c, M, N, K,
-                       host_scale, dev_scale, dev_scale2, b_blocked);
+                       host_scale, dev_scale, dev_scale2);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

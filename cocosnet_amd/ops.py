@@ -294,7 +294,8 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             if dv is not None:      # cycle terms: V itself is differentiated, the key side needs P as well
                 psh, psl = torch.empty((B, Nk, Nq), **half), torch.empty((B, Nk, Nq), **half)
             ds_scale = torch.empty(1, device=qn.device, dtype=torch.float32)
-            blocked = int(Nk % 128 == 0 and Nq % 32 == 0)     # tile-blocked [Nk][Nq] planes (see cocos_hip.h)
+            blocked = int(Nk % 128 == 0 and Nq % 32 == 0)     # [query][key]-blocked dS'' / P planes (see cocos_hip.h)
+            gemm_b = 2 * blocked                               # ... which the GEMM reads as b_blocked = 2
             if dqn is None:          # the query kernel always accumulates dqn; scratch when nobody wants it
                 dqn_buf = torch.empty_like(qn)
             else:
@@ -308,11 +309,11 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             if want_k:
                 _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
                       dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 / SPLIT_OPERAND_SCALE,
-                      ds_scale.data_ptr(), 0, blocked, st)
+                      ds_scale.data_ptr(), 0, gemm_b, st)
             if dv is not None:      # dv[c,j] = sum_i dout[c,i] P[i,j]
                 gch, gcl, _ = split_f16(dout, False, amax=g_amax)
                 _call("corr_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(),
-                      psl.data_ptr(), dv.data_ptr(), B, Cv, Nk, Nq, 1.0 / 16384.0, g_scale.data_ptr(), 0, blocked, st)
+                      psl.data_ptr(), dv.data_ptr(), B, Cv, Nk, Nq, 1.0 / 16384.0, g_scale.data_ptr(), 0, gemm_b, st)
             return dqn, (dkn if need_k else None), dv, None, None, None
         # key side: GEMM over a materialised dS^T when it pays and fits (see cocos_hip.h), else the
         # flash-style kernel that recomputes the logits (always when dv is wanted: it needs P)

@@ -143,10 +143,12 @@ int cocos_f16_plane_block_mask(const void* plane, int B, int C, int N, unsigned*
  *          dv = hgemm(A = channel-major planes of s_o*dout [Cv][Nq], B = P planes, host_scale = 2^-14,
  *          dev_scale = g_scale_dev)
  *       Supported: K == 256, Cv <= 160, CvPad = Cv rounded up to 32, Nk % 8 == 0.
- *   planes_blocked / b_blocked != 0: the [Nk][Nq] planes (dS'', P) are stored as [Nk/128][Nq/32] blocks of
- *       [128 keys][32 queries] halfs (8 KB each, contiguous) instead of row-major — the query kernel then writes
- *       each wave's 32x32 tile as 2 KB contiguous and the GEMM reads one contiguous block per k-step (needs
- *       Nk % 128 == 0, Nq % 32 == 0; both sides must agree).
+ *   planes_blocked != 0 (query kernel) <-> b_blocked = 2 (GEMM): the dS'' / P planes are stored in the orientation
+ *       the accumulators of the query kernel have — [query][key] — as [Nq/32][Nk/32] blocks of 2 x [32 queries][16 keys]
+ *       halfs (2 KB each, contiguous; the two halves are keys 0..15 and 16..31 of the tile): a wave's tile leaves its registers as two 16-byte stores per plane (no transposition),
+ *       the GEMM stages four consecutive blocks per k-step and reads its B fragments with the transposing LDS read
+ *       (needs Nk % 128 == 0, Nq % 32 == 0; both sides must agree).  planes_blocked = 0 <-> b_blocked = 0: row-major
+ *       [Nk][Nq].  b_blocked = 1 (GEMM only): [N/128][K/32] blocks of [128 n][32 k] halfs, k contiguous.
  *   cocos_hgemm_f16x3: C[b][m][n] = host_scale / (*dev_scale * *dev_scale2) * sum_k A[b][m][k] B[b][n][k] on hi/lo planes
  *       (k contiguous, K % 8 == 0); the key side is  dkn = hgemm(A = planes of k_scale*qn [256][Nq],
  *       B = dS'' planes [Nk][Nq], host_scale = 1/k_scale, dev_scale = ds_scale_out_dev). */

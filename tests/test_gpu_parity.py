@@ -177,6 +177,14 @@ def test_hgemm_f16x3_matches_fp64(batch, M, N, K):
         _lib.call("cocos_hgemm_f16x3", ah.data_ptr(), al.data_ptr(), bhb.data_ptr(), blb.data_ptr(), c2.data_ptr(), batch,
                   M, N, K, 0.25, sc.data_ptr(), 0, 1, torch.cuda.current_stream().cuda_stream)
         assert torch.equal(c, c2)
+        # the [k][n]-oriented layout of the K2 query backward ([K/32][N/32] blocks of 2 x [32 k][16 n]), read with the
+        # transposing LDS read: same products, same order of accumulation
+        nat = lambda t: t.view(batch, N // 32, 2, 16, K // 32, 32).permute(0, 4, 1, 2, 5, 3).contiguous()
+        bhn, bln = nat(bh), nat(bl)
+        c3 = torch.empty_like(c)
+        _lib.call("cocos_hgemm_f16x3", ah.data_ptr(), al.data_ptr(), bhn.data_ptr(), bln.data_ptr(), c3.data_ptr(), batch,
+                  M, N, K, 0.25, sc.data_ptr(), 0, 2, torch.cuda.current_stream().cuda_stream)
+        assert torch.equal(c, c3)
 
 
 def test_key_side_strategies_agree(monkeypatch):
