@@ -400,6 +400,12 @@ def main():
         return dt, kt.summary()
 
     headline_precision = ops.PRECISION
+    # set-up, outside the W + K contract: the first calls load every kernel's code object (the K2 kernels exist in two
+    # instantiations each), size the caching allocator's pools and the max|x| cell pool — not steady-state work
+    SETUP_STEPS = 3
+    for _ in range(SETUP_STEPS):
+        step()
+    sync()
     dt, kern = window(args.steps, args.warmup)
     with ops.KernelTimer() as kt_all:
         step()
@@ -458,7 +464,7 @@ def main():
         line = {
             "metric": "images/sec fwd+bwd ADE20k 256x256 batch-8/GPU (correspondence hot path)",
             "value": round(images / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "warmup": args.warmup, "setup_steps": SETUP_STEPS, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (K2 products as 3-term f16 hi/lo split on the f16 MFMA, fp32 accumulate)" if split else "f32",
             "data": "synthetic",
