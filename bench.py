@@ -206,8 +206,8 @@ SPLIT_TAGS = ("corr_softmax_warp_fwd", "corr_softmax_warp_bwd_query", "corr_soft
 PAYLOAD_PARAMS = {"path": 0, "netcorr": 59_000_000, "full": 156_000_000}
 PMC_FILE = {"f16x3": "r02_pmc_f16x3.json", "fp32": "r01_pmc_final.json"}
 # (the counters were taken on the general instantiations <..., 0>; the one that skips exact value blocks moves 8 MB less)
-PMC_KEY = {"f16x3": {"corr_softmax_warp_fwd": "corr_fwd_f16x3_kernel<5, 1, 0, 0>",
-                     "corr_softmax_warp_bwd_query": "corr_bwd_query_f16x3_kernel<5, 1, 0, 0, 0>",
+PMC_KEY = {"f16x3": {"corr_softmax_warp_fwd": "corr_fwd_f16x3_kernel<5, 1, 0, 0",
+                     "corr_softmax_warp_bwd_query": "corr_bwd_query_f16x3_kernel<5, 1, 0, 0, 0",
                      "corr_softmax_warp_bwd_key_from_ds": "hgemm_f16x3_kernel"},
            "fp32": {"corr_softmax_warp_fwd": "corr_softmax_warp_fwd_kernel<256, 5, true",
                     "corr_softmax_warp_bwd_query": "corr_bwd_query_saved_kernel<256, 5, true",
