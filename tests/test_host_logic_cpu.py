@@ -106,3 +106,33 @@ def test_operand_planes_are_per_call_objects(monkeypatch):
     assert len(calls) == 3                                        # modified in place: planes rebuilt
     assert len(ops.OperandPlanes()) == 0                          # a new call starts empty
     assert not hasattr(ops, "_split_cache")
+
+
+def test_bench_roofline_and_kernel_table_contract():
+    """bench.py's JSON pieces (no GPU): per-kernel table from fake HIP-event times, the roofline object of the dominant
+    kernel with `frac`, `frac_issued`, `traffic` from the committed PMC file, and the bounded CPU baseline's fields."""
+    import bench
+    kern = {"corr_softmax_warp_fwd": {"avg_ms": 0.29, "calls": 20, "total_ms": 5.8},
+            "corr_softmax_warp_bwd_query": {"avg_ms": 0.35, "calls": 20, "total_ms": 7.0},
+            "corr_softmax_warp_bwd_key_from_ds": {"avg_ms": 0.17, "calls": 20, "total_ms": 3.4}}
+    tab = bench.kernel_table(kern, "f16x3")
+    assert set(tab) == set(kern)
+    alg = 2.0 * 4096 * 4096 * (256 + 154) * 8 / 0.35 / 1e9
+    assert abs(tab["corr_softmax_warp_bwd_query"]["alg_tflops"] - alg) < 0.5
+    # the key GEMM always issues three terms; forward / query backward 70 of 78 MFMAs when the label blocks' lo plane is skipped
+    assert abs(tab["corr_softmax_warp_bwd_key_from_ds"]["issued_tflops"] / tab["corr_softmax_warp_bwd_key_from_ds"]["alg_tflops"] - 3.0) < 0.01
+    ratio = tab["corr_softmax_warp_fwd"]["issued_tflops"] / tab["corr_softmax_warp_fwd"]["alg_tflops"]
+    assert abs(ratio - (70 / 26 if bench.ops_value_lo_skip() else 3.0)) < 0.01
+    roof = bench.roofline_of(tab, "f16x3")
+    assert roof["kernel"] == "corr_softmax_warp_bwd_query" and roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s"
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["frac_issued"] <= roof["frac"] + 1e-6
+    assert roof["traffic"] is None or roof["traffic"] > 1e8          # bytes per launch from profiles/r02_pmc_f16x3.json
+    fp = bench.roofline_of(bench.kernel_table(kern, "fp32"), "fp32")
+    assert fp["peak"] == bench.FP32_MFMA_PEAK_TFLOPS
+
+
+def test_bench_cpu_baseline_is_bounded_and_labelled():
+    import bench
+    cb = bench.cpu_baseline(runs=1, batch=1, budget_s=5.0)
+    assert cb["unit"] == "images/s" and cb["kind"] == "port" and cb["value"] > 0 and 1 <= cb["cores"] <= 32
+    assert "all_cores" in cb and cb["all_cores"]["cores"] >= cb["cores"] and "sample" in cb
