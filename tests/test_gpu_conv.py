@@ -165,3 +165,35 @@ def test_patchgan_stack_on_hip_convs_matches_the_framework():
     producers.use_framework_convs(net)
     for a, r in zip(got, ref):
         assert (a - r).abs().max().item() <= 2e-4 * max(r.abs().max().item(), 1e-6), (a.shape, (a - r).abs().max().item())
+
+
+def test_feature_producers_on_k16_agree_with_the_framework_convolutions(monkeypatch):
+    """The whole drop-in module up to theta/phi (adaptors with SPADE blocks, the four ResidualBlocks, the 1x1 projections):
+    the same weights and inputs through K16 / K0 and through the framework's fp32 convolutions (COCOS_CONV=torch: MIOpen
+    Winograd / implicit GEMM, themselves ~1e-4 from fp64 — K16's own error is measured against fp64 per layer above).
+    End-to-end wiring check: features to 1e-3, parameter gradients (instance norms and PONO in the chain amplify
+    round-off) to 1e-2 of their range."""
+    from cocosnet_amd import correspondence as cc
+    from cocosnet_amd import producers
+    opt = cc.base_options(semantic_nc=6, match_kernel=1, maskmix=True, PONO=True, PONO_C=True, use_attention=False)
+    torch.manual_seed(0)
+    net = cc.NoVGGCorrespondence(opt).cuda()
+    net.init_weights(opt.init_type, opt.init_variance)
+    net.eval()                     # freezes the spectral-norm power iteration
+    g = torch.Generator(device="cuda").manual_seed(2)
+    img = torch.rand(2, 3, 64, 64, device="cuda", generator=g) * 2 - 1
+    real = torch.rand(2, 3, 64, 64, device="cuda", generator=g) * 2 - 1
+    lab = torch.randint(0, 6, (2, 1, 8, 8), device="cuda", generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    seg = torch.zeros(2, 6, 64, 64, device="cuda").scatter_(1, lab, 1.0)
+    probes = (net.theta.weight, net.layer[0].conv1.weight, net.adaptive_model_img.layer1[0].weight_orig)
+
+    def run(backend):
+        monkeypatch.setattr(producers, "CONV_BACKEND", backend)
+        net.zero_grad()
+        th, ph = net.project(img, real, seg, seg.flip(0))
+        (th.square().mean() + ph.square().mean()).backward()
+        return [th.detach(), ph.detach()] + [p.grad.clone() for p in probes]
+    ref, got = run("torch"), run("f16x3")
+    for i, (a, r) in enumerate(zip(got, ref)):
+        err = (a - r).abs().max().item() / r.abs().max().item()
+        assert err <= (1e-3 if i < 2 else 1e-2), (i, tuple(a.shape), err)
