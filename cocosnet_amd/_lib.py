@@ -128,6 +128,8 @@ _SIGNATURES = {
                                                  ctypes.c_float, _stream_t]),
     "cocos_contextual_rows_bwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_float,
                                                                    ctypes.c_float, _stream_t]),
+    "cocos_reflect_pad2d_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong] + [ctypes.c_int] * 3 + [_stream_t]),
+    "cocos_reflect_pad2d_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong] + [ctypes.c_int] * 3 + [_stream_t]),
     "cocos_spade_modulate_fwd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_longlong, ctypes.c_float, _stream_t]),
     "cocos_spade_modulate_bwd": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_longlong, ctypes.c_float, _stream_t]),
     "cocos_conv2d_out_size": (ctypes.c_int, [ctypes.c_int] * 5),

@@ -49,6 +49,7 @@ HIP_SOURCES = [
     "contextual_rows.hip",
     "conv_f16x3.hip",
     "spade_modulate.hip",
+    "reflect_pad.hip",
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              "-Wall", "-Wno-unused-function"]

@@ -1068,6 +1068,32 @@ def pono_spade(x, gamma, beta, slope: float = 1.0, eps: float = PONO_EPS):
     return _PonoSpade.apply(x, gamma, beta, slope, eps)
 
 
+class _ReflectPad2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pad: int):
+        x = _chk(x, "reflect_pad2d: x")
+        if x.dim() != 4 or not (0 <= pad < min(x.shape[2:])):
+            raise ValueError(f"reflect_pad2d: x{tuple(x.shape)} pad={pad} (pad must be smaller than H and W)")
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H + 2 * pad, W + 2 * pad), device=x.device, dtype=torch.float32)
+        _call("reflect_pad2d_fwd", "cocos_reflect_pad2d_fwd", x.data_ptr(), y.data_ptr(), B * C, H, W, int(pad), _stream())
+        ctx.cfg = (B, C, H, W, int(pad))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, pad = ctx.cfg
+        dy = _chk(dy, "reflect_pad2d: dy")
+        dx = torch.empty((B, C, H, W), device=dy.device, dtype=torch.float32)
+        _call("reflect_pad2d_bwd", "cocos_reflect_pad2d_bwd", dy.data_ptr(), dx.data_ptr(), B * C, H, W, pad, _stream())
+        return dx, None
+
+
+def reflect_pad2d(x, pad: int):
+    """nn.ReflectionPad2d(pad)(x) for x [B,C,H,W] (one padding for the four sides, pad < H, W): K18, backward as a gather."""
+    return _ReflectPad2d.apply(x, int(pad))
+
+
 class _SpadeModulate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xh, gamma, beta, slope: float):

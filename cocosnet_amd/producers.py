@@ -43,6 +43,19 @@ class Conv2d(nn.Conv2d):
         return super()._conv_forward(input, weight, bias)
 
 
+class ReflectionPad2d(nn.ReflectionPad2d):
+    """nn.ReflectionPad2d whose fp32 GPU forward / backward are K18 (one padding for all four sides); anything else takes
+    the framework path.  No parameters: state_dict keys are untouched."""
+
+    def forward(self, input):
+        p = self.padding
+        if (CONV_BACKEND == "f16x3" and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+                and len(set(p)) == 1 and 0 <= p[0] < min(input.shape[2:])):
+            from . import ops
+            return ops.reflect_pad2d(input, p[0])
+        return super().forward(input)
+
+
 def use_hip_convs(module: nn.Module) -> int:
     """Re-class every plain `nn.Conv2d` inside `module` (e.g. the reference's `NLayerDiscriminator`
     discriminator.py:92-115, its `SPADEGenerator`, `VGG19`) to `Conv2d` above, in place: parameters, buffers, hooks
@@ -53,6 +66,8 @@ def use_hip_convs(module: nn.Module) -> int:
         if type(m) is nn.Conv2d:
             m.__class__ = Conv2d
             n += 1
+        elif type(m) is nn.ReflectionPad2d:     # rides along (not counted): K18
+            m.__class__ = ReflectionPad2d
     return n
 
 
@@ -62,6 +77,8 @@ def use_framework_convs(module: nn.Module) -> int:
         if type(m) is Conv2d:
             m.__class__ = nn.Conv2d
             n += 1
+        elif type(m) is ReflectionPad2d:
+            m.__class__ = nn.ReflectionPad2d
     return n
 
 
@@ -99,9 +116,9 @@ class SPADE(nn.Module):
         if not self.pono:
             self.param_free_norm = _param_free_norm(m.group(1), norm_nc)
         hidden = 128
-        self.mlp_shared = nn.Sequential(nn.ReflectionPad2d(ks // 2),
+        self.mlp_shared = nn.Sequential(ReflectionPad2d(ks // 2),
                                         Conv2d(label_nc, hidden, ks), nn.ReLU())
-        self.pad = nn.ReflectionPad2d(ks // 2)
+        self.pad = ReflectionPad2d(ks // 2)
         self.mlp_gamma = Conv2d(hidden, norm_nc, ks)
         self.mlp_beta = Conv2d(hidden, norm_nc, ks)
 
@@ -170,7 +187,7 @@ class SPADEResnetBlock(nn.Module):
         self.learned_shortcut = fin != fout
         fmid = min(fin, fout)
         self.use_se = use_se
-        self.pad = nn.ReflectionPad2d(dilation)
+        self.pad = ReflectionPad2d(dilation)
         self.conv_0 = Conv2d(fin, fmid, 3, padding=0, dilation=dilation)
         self.conv_1 = Conv2d(fmid, fout, 3, padding=0, dilation=dilation)
         if self.learned_shortcut:
@@ -286,11 +303,11 @@ class ResidualBlock(nn.Module):
 
     def __init__(self, in_channels, out_channels, kernel_size=3, padding=1, stride=1):
         super().__init__()
-        self.padding1 = nn.ReflectionPad2d(padding)
+        self.padding1 = ReflectionPad2d(padding)
         self.conv1 = Conv2d(in_channels, out_channels, kernel_size, padding=0, stride=stride)
         self.bn1 = nn.InstanceNorm2d(out_channels)
         self.prelu = nn.PReLU()
-        self.padding2 = nn.ReflectionPad2d(padding)
+        self.padding2 = ReflectionPad2d(padding)
         self.conv2 = Conv2d(in_channels, out_channels, kernel_size, padding=0, stride=stride)
         self.bn2 = nn.InstanceNorm2d(out_channels)
 

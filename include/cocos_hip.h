@@ -412,6 +412,14 @@ int cocos_contextual_rows_bwd(const float* cosm, const float* dcx, float* dcos, 
                               float eps, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * K18 nn.ReflectionPad2d(pad) and its backward: the pad in front of the 3x3 convolutions of ResidualBlock
+ *     (correspondence.py:19,:23), SPADE (normalization.py:118,:146) and SPADEResnetBlock (architecture.py:30).
+ *   fwd: x [planes,H,W] -> y [planes,H+2pad,W+2pad];  bwd: dy -> dx as a gather (no atomics).  pad < H, W.
+ * ------------------------------------------------------------------------------------- */
+int cocos_reflect_pad2d_fwd(const float* x, float* y, long long planes, int H, int W, int pad, cocos_stream_t stream);
+int cocos_reflect_pad2d_bwd(const float* dy, float* dx, long long planes, int H, int W, int pad, cocos_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * K17 SPADE modulation + LeakyReLU behind any parameter-free norm (the non-PONO branch of SPADE, normalization.py
  *     :93-101 instance | syncbatch | batch, then :148 and architecture.py:88-95): xh = the normalised activations,
  *     gamma, beta, y and the gradients all hold n fp32 elements (same shape).

@@ -197,3 +197,21 @@ def test_feature_producers_on_k16_agree_with_the_framework_convolutions(monkeypa
     for i, (a, r) in enumerate(zip(got, ref)):
         err = (a - r).abs().max().item() / r.abs().max().item()
         assert err <= (1e-3 if i < 2 else 1e-2), (i, tuple(a.shape), err)
+
+
+@pytest.mark.parametrize("shape,pad", [((2, 5, 8, 11), 1), ((1, 3, 4, 4), 3), ((2, 16, 64, 64), 1), ((1, 2, 7, 5), 2), ((1, 1, 3, 9), 0)])
+def test_reflect_pad2d_matches_torch(shape, pad):
+    """K18 vs nn.ReflectionPad2d: forward bit-exact (pure data movement), backward equal to autograd's (a gather here)."""
+    from cocosnet_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(6)
+    x = torch.randn(shape, device="cuda", generator=g).requires_grad_(True)
+    y = ops.reflect_pad2d(x, pad)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = F.pad(xr, (pad,) * 4, mode="reflect") if pad else xr * 1.0
+    assert torch.equal(y, yr)
+    go = torch.randn(y.shape, device="cuda", generator=g)
+    y.backward(go)
+    yr.backward(go)
+    assert (x.grad - xr.grad).abs().max().item() <= 1e-6 * max(xr.grad.abs().max().item(), 1.0)
+    with pytest.raises(ValueError):
+        ops.reflect_pad2d(x.detach(), min(shape[2:]))
