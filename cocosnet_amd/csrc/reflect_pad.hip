@@ -10,15 +10,16 @@ namespace cocos {
 
 __device__ __forceinline__ int rp_reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
+// grid (planes, row chunks of 32), block (64 columns, 4 rows): no divisions in the index arithmetic
 __global__ __launch_bounds__(256) void reflect_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
-                                                              int p, size_t total) {
+                                                              int p) {
     const int Ho = H + 2 * p, Wo = W + 2 * p;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int X = (int)(i % Wo);
-        const size_t r = i / Wo;
-        const int Y = (int)(r % Ho);
-        const size_t plane = r / Ho;
-        y[i] = x[(plane * H + rp_reflect(Y - p, H)) * W + rp_reflect(X - p, W)];
+    const float* xp = x + (size_t)blockIdx.x * H * W;
+    float* yp = y + (size_t)blockIdx.x * Ho * Wo;
+    const int y1 = min(Ho, (int)(blockIdx.y + 1) * 32);
+    for (int Y = blockIdx.y * 32 + threadIdx.y; Y < y1; Y += 4) {
+        const float* row = xp + (size_t)rp_reflect(Y - p, H) * W;
+        for (int X = threadIdx.x; X < Wo; X += 64) yp[(size_t)Y * Wo + X] = row[rp_reflect(X - p, W)];
     }
 }
 
@@ -33,26 +34,23 @@ __device__ __forceinline__ int rp_sources(int i, int n, int p, int (&src)[3]) {
 }
 
 __global__ __launch_bounds__(256) void reflect_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W,
-                                                              int p, size_t total) {
+                                                              int p) {
     const int Ho = H + 2 * p, Wo = W + 2 * p;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int xx = (int)(i % W);
-        const size_t r = i / W;
-        const int yy = (int)(r % H);
-        const size_t plane = r / H;
-        int sy[3], sx[3];
-        const int ny = rp_sources(yy, H, p, sy), nx = rp_sources(xx, W, p, sx);
-        const float* d = dy + plane * (size_t)Ho * Wo;
-        float acc = 0.f;
-        for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) acc += d[(size_t)sy[a] * Wo + sx[b]];
-        dx[i] = acc;
+    const float* d = dy + (size_t)blockIdx.x * Ho * Wo;
+    float* o = dx + (size_t)blockIdx.x * H * W;
+    const int y1 = min(H, (int)(blockIdx.y + 1) * 32);
+    for (int yy = blockIdx.y * 32 + threadIdx.y; yy < y1; yy += 4) {
+        int sy[3];
+        const int ny = rp_sources(yy, H, p, sy);
+        for (int xx = threadIdx.x; xx < W; xx += 64) {
+            int sx[3];
+            const int nx = rp_sources(xx, W, p, sx);
+            float acc = 0.f;
+            for (int a = 0; a < ny; ++a)
+                for (int b = 0; b < nx; ++b) acc += d[(size_t)sy[a] * Wo + sx[b]];
+            o[(size_t)yy * W + xx] = acc;
+        }
     }
-}
-
-static unsigned rp_blocks(size_t n) {
-    const size_t want = (n + 255) / 256;
-    return (unsigned)(want < 1 ? 1 : (want > 16384 ? 16384 : want));
 }
 
 }  // namespace cocos
@@ -62,8 +60,9 @@ extern "C" int cocos_reflect_pad2d_fwd(const float* x, float* y, long long plane
     COCOS_REQUIRE(x && y, COCOS_ERR_INVALID, "reflect_pad2d_fwd: null pointer");
     COCOS_REQUIRE(planes >= 1 && H >= 1 && W >= 1 && pad >= 0 && pad < H && pad < W, COCOS_ERR_INVALID,
                   "reflect_pad2d_fwd: bad dims planes=%lld H=%d W=%d pad=%d (pad must be smaller than H and W)", planes, H, W, pad);
-    const size_t total = (size_t)planes * (H + 2 * pad) * (W + 2 * pad);
-    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(rp_blocks(total)), dim3(256), 0, as_stream(stream), x, y, H, W, pad, total);
+    COCOS_REQUIRE(planes <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "reflect_pad2d_fwd: too many planes");
+    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3((unsigned)planes, (unsigned)((H + 2 * pad + 31) / 32)), dim3(64, 4), 0,
+                       as_stream(stream), x, y, H, W, pad);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -73,8 +72,9 @@ extern "C" int cocos_reflect_pad2d_bwd(const float* dy, float* dx, long long pla
     COCOS_REQUIRE(dy && dx, COCOS_ERR_INVALID, "reflect_pad2d_bwd: null pointer");
     COCOS_REQUIRE(planes >= 1 && H >= 1 && W >= 1 && pad >= 0 && pad < H && pad < W, COCOS_ERR_INVALID,
                   "reflect_pad2d_bwd: bad dims planes=%lld H=%d W=%d pad=%d", planes, H, W, pad);
-    const size_t total = (size_t)planes * H * W;
-    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(rp_blocks(total)), dim3(256), 0, as_stream(stream), dy, dx, H, W, pad, total);
+    COCOS_REQUIRE(planes <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "reflect_pad2d_bwd: too many planes");
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3((unsigned)planes, (unsigned)((H + 31) / 32)), dim3(64, 4), 0,
+                       as_stream(stream), dy, dx, H, W, pad);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
