@@ -139,6 +139,9 @@ _SIGNATURES = {
     "cocos_conv2d_fwd_scatter_f16x3": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p,
                                                       _c_float_p] + [ctypes.c_int] * 11 + [ctypes.c_longlong, ctypes.c_int,
                                                       ctypes.c_int, ctypes.c_longlong, _stream_t]),
+    "cocos_conv2d_weight_planes": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 10
+                                   + [_c_float_p, _c_float_p, _stream_t]),
+    "cocos_conv2d_wgrad_reduce": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 5 + [_stream_t]),
     "cocos_conv2d_wgrad_slices": (ctypes.c_int, [ctypes.c_int] * 10),
     "cocos_conv2d_wgrad_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 10 + [_stream_t]),
     "cocos_debug_mfma_probe": (ctypes.c_int, [_c_float_p, _stream_t]),

@@ -866,3 +866,96 @@ extern "C" int cocos_debug_read_timing_conv(long long* host8, int reset) {
     return COCOS_OK;
 }
 #endif
+
+// --------------------------------------------------------------------------------------------------------------------
+// host-side glue as two kernels (instead of ~8 framework launches per convolution and step)
+// --------------------------------------------------------------------------------------------------------------------
+namespace cocos {
+
+// weight [Cout][Cin][KH][KW] fp32 -> the f16 hi/lo planes K16 reads ([K/32][M][32], k = ((c/32)*T + tap)*32 + c%32):
+//   mode 0 (forward):         M = Cout rows, c = ci,  tap = (ky, kx) of the JH x JW = KH x KW kernel
+//   mode 1 (input gradient):  M = Cin rows,  c = co,  tap (ky', kx') of the flipped sub-kernel:
+//                             source tap (ry + s*(JH-1-ky'), rx + s*(JW-1-kx'))   (stride 1: ry = rx = 0, s = 1, J = K)
+// scaled by the power of two from *amax_dev (written to *scale_out), zero for c beyond the channel count.
+__global__ __launch_bounds__(256) void conv_weight_planes_kernel(const float* __restrict__ w, _Float16* __restrict__ hi,
+                                                                 _Float16* __restrict__ lo, int Cout, int Cin, int KH, int KW,
+                                                                 int mode, int JH, int JW, int ry, int rx, int s,
+                                                                 const float* __restrict__ amax_dev, float* __restrict__ scale_out,
+                                                                 int M, int C, int nkb) {
+    const float scale = cv_scale_from_amax(amax_dev);
+    const unsigned total2 = (unsigned)nkb * (unsigned)M * 16u;            // pairs of consecutive c: one 32-bit store per plane
+    const int T = JH * JW;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total2; i += gridDim.x * 256u) {
+        if (i == 0 && scale_out) *scale_out = scale;
+        const int j = (int)(i & 15u) * 2;
+        const unsigned r = i >> 4;
+        const int m = (int)(r % (unsigned)M), kb = (int)(r / (unsigned)M);
+        const int cb = kb / T, tap = kb - cb * T;
+        const int kyp = tap / JW, kxp = tap - kyp * JW;
+        const int ky = mode == 0 ? kyp : ry + s * (JH - 1 - kyp), kx = mode == 0 ? kxp : rx + s * (JW - 1 - kxp);
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = cb * 32 + j + e;
+            const int co = mode == 0 ? m : c, ci = mode == 0 ? c : m;
+            v[e] = c < C ? w[(((size_t)co * Cin + ci) * KH + ky) * KW + kx] * scale : 0.f;
+        }
+        unsigned h2, l2;
+        split_pair_rtz(v[0], v[1], h2, l2);
+        reinterpret_cast<unsigned*>(hi)[i] = h2;
+        reinterpret_cast<unsigned*>(lo)[i] = l2;
+    }
+}
+
+// partial [S][Cout][K] (k as above) -> dw [Cout][Cin][KH][KW]: the sum over the S position slices and the re-ordering of
+// k; threads run over the partials' own order (coalesced reads of S x 4 bytes each), the 4-byte writes scatter into dw
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S,
+                                                                int Cout, int Cin, int T, int K) {
+    const unsigned total = (unsigned)Cout * (unsigned)K;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int co = (int)(i / (unsigned)K), k = (int)(i - (unsigned)co * (unsigned)K);
+        const int kb = k >> 5, cb = kb / T, tap = kb - cb * T, ci = cb * 32 + (k & 31);
+        if (ci >= Cin) continue;
+        float acc = 0.f;
+        for (int sl = 0; sl < S; ++sl) acc += part[(size_t)sl * total + i];
+        dw[((size_t)co * Cin + ci) * T + tap] = acc;
+    }
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_conv2d_weight_planes(const float* w, void* hi, void* lo, int Cout, int Cin, int KH, int KW, int mode,
+                                          int JH, int JW, int ry, int rx, int s, const float* amax_dev, float* scale_out_dev,
+                                          cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(w && hi && lo, COCOS_ERR_INVALID, "conv2d_weight_planes: null pointer");
+    COCOS_REQUIRE(Cout >= 1 && Cin >= 1 && KH >= 1 && KW >= 1 && (mode == 0 || mode == 1) && JH >= 1 && JW >= 1 && s >= 1 &&
+                      ry >= 0 && rx >= 0 && ry + s * (JH - 1) < KH && rx + s * (JW - 1) < KW &&
+                      (mode == 1 || (JH == KH && JW == KW && s == 1 && ry == 0 && rx == 0)),
+                  COCOS_ERR_INVALID, "conv2d_weight_planes: bad arguments (k=%dx%d mode=%d J=%dx%d r=(%d,%d) s=%d)", KH, KW, mode,
+                  JH, JW, ry, rx, s);
+    const int M = mode == 0 ? Cout : Cin, C = mode == 0 ? Cin : Cout;
+    const int nkb = JH * JW * ((C + 31) / 32);
+    const size_t total = (size_t)nkb * M * 16;
+    COCOS_REQUIRE(total < 0x7fffffffull, COCOS_ERR_UNSUPPORTED, "conv2d_weight_planes: weight too large");
+    const size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(conv_weight_planes_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, as_stream(stream),
+                       w, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Cout, Cin, KH, KW, mode, JH, JW, ry, rx, s,
+                       amax_dev, scale_out_dev, M, C, nkb);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_conv2d_wgrad_reduce(const float* partials, float* dw, int S, int Cout, int Cin, int KH, int KW,
+                                         cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(partials && dw, COCOS_ERR_INVALID, "conv2d_wgrad_reduce: null pointer");
+    COCOS_REQUIRE(S >= 1 && Cout >= 1 && Cin >= 1 && KH >= 1 && KW >= 1, COCOS_ERR_INVALID, "conv2d_wgrad_reduce: bad dims");
+    const size_t total = (size_t)Cout * cocos_conv2d_kdim(Cin, KH, KW);
+    COCOS_REQUIRE(total < 0x7fffffffull, COCOS_ERR_UNSUPPORTED, "conv2d_wgrad_reduce: weight too large");
+    const size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, as_stream(stream),
+                       partials, dw, S, Cout, Cin, KH * KW, cocos_conv2d_kdim(Cin, KH, KW));
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}

@@ -695,21 +695,18 @@ def proj1x1(x, weight, bias=None):
 # K16  nn.Conv2d (groups 1, dilation 1, zero padding) as a split-precision implicit GEMM   (conv_f16x3.hip)
 #      ResidualBlock (correspondence.py:13-36), adaptor convolutions (:150-173), PatchGAN (discriminator.py:92-115)
 # ------------------------------------------------------------------------------------------
-def _weight_planes(wt, amax):
-    """wt [M, T, C] fp32 (rows, taps, channels) -> f16 hi/lo planes in K16's layout: channels zero-padded to
-    Cp = 32 * ceil(C / 32), k-blocks of 32 channels at one tap ordered (channel block, tap), k-block major
-    [K/32][M][32] (the M x 32 tile of a k-block is one contiguous piece), + their device-side power-of-two scale."""
-    M, T, C = wt.shape
-    cp = (C + 31) // 32 * 32
-    if cp != C:
-        wt = torch.nn.functional.pad(wt, (0, cp - C))
-    nkb = T * cp // 32
-    wb = wt.reshape(M, T, cp // 32, 32).permute(2, 1, 0, 3).reshape(nkb, M, 32).contiguous()
-    wh = torch.empty((nkb, M, 32), device=wt.device, dtype=torch.float16)
+def _conv_weight_planes(weight, amax, mode: int, JH=None, JW=None, ry=0, rx=0, s=1):
+    """weight [Cout,Cin,KH,KW] -> K16's f16 hi/lo planes in ONE launch (cocos_conv2d_weight_planes): mode 0 = forward,
+    mode 1 = input gradient (flipped (sub-)kernel w[:, :, ry::s, rx::s], channel roles swapped)."""
+    Cout, Cin, KH, KW = weight.shape
+    JH, JW = (KH if JH is None else JH), (KW if JW is None else JW)
+    M, C = (Cout, Cin) if mode == 0 else (Cin, Cout)
+    nkb = JH * JW * ((C + 31) // 32)
+    wh = torch.empty((nkb, M, 32), device=weight.device, dtype=torch.float16)
     wl = torch.empty_like(wh)
-    ws = torch.empty(1, device=wt.device, dtype=torch.float32)
-    _call("split_f16", "cocos_split_f16_rows", wb.data_ptr(), wh.data_ptr(), wl.data_ptr(), M * nkb, 32, 32, 1.0,
-          amax.data_ptr(), ws.data_ptr(), _stream())
+    ws = torch.empty(1, device=weight.device, dtype=torch.float32)
+    _call("split_f16", "cocos_conv2d_weight_planes", weight.data_ptr(), wh.data_ptr(), wl.data_ptr(), Cout, Cin, KH, KW, mode,
+          JH, JW, ry, rx, s, amax.data_ptr(), ws.data_ptr(), _stream())
     return wh, wl, ws
 
 
@@ -757,8 +754,7 @@ def _conv_dgrad_strided(xshape, weight, dy, ga, wa, s: int, p: int):
         if c is None:
             continue
         ry, rx, JH, JW, u0, v0, U, V, py, px = c
-        wt = weight[:, :, ry::s, rx::s].flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, JH * JW, Cout)
-        th, tl, ts = _weight_planes(wt, wa)
+        th, tl, ts = _conv_weight_planes(weight, wa, 1, JH, JW, ry, rx, s)
         off = (s * u0 + ry - p) * W + (s * v0 + rx - p)
         _call("conv2d_fwd", "cocos_conv2d_fwd_scatter_f16x3", dy.data_ptr(), th.data_ptr(), tl.data_ptr(), ts.data_ptr(),
               ga.data_ptr(), dx.data_ptr(), B, Cout, OH, OW, Cin, JH, JW, py, px, U, V, H * W, s * W, s, off, _stream())
@@ -780,7 +776,7 @@ class _Conv2d(torch.autograd.Function):
         if xa is None:
             xa = absmax(x)
         wa = absmax(weight)
-        wh, wl, ws = _weight_planes(weight.permute(0, 2, 3, 1).reshape(Cout, KH * KW, Cin), wa)
+        wh, wl, ws = _conv_weight_planes(weight, wa, 0)
         y = _conv_fwd_call(x, wh, wl, ws, xa, bb, Cout, KH, KW, stride, pad, dil)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (int(stride), int(pad), int(dil), bias is not None)
@@ -803,8 +799,7 @@ class _Conv2d(torch.autograd.Function):
         if need_x:
             if stride == 1 and dil * (KH - 1) - pad >= 0 and KW == KH:
                 # dx = conv(dy, flipped weights with the channel roles swapped, padding d(K-1)-p): the same kernel
-                wt = weight.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, KH * KW, Cout)
-                th, tl, ts = _weight_planes(wt, wa)
+                th, tl, ts = _conv_weight_planes(weight, wa, 1)
                 dx = _conv_fwd_call(dy, th, tl, ts, ga, None, Cin, KH, KW, 1, dil * (KH - 1) - pad, dil)
             elif stride > 1 and dil == 1 and (dx := _conv_dgrad_strided(x.shape, weight, dy, ga, wa, stride, pad)) is not None:
                 pass    # stride^2 parity classes, each a stride-1 convolution of dy scattered into dx (K16)
@@ -817,10 +812,8 @@ class _Conv2d(torch.autograd.Function):
             part = torch.empty((S, Cout, kdim), device=x.device, dtype=torch.float32)
             _call("conv2d_wgrad", "cocos_conv2d_wgrad_f16x3", x.data_ptr(), dy.data_ptr(), xa.data_ptr(), ga.data_ptr(),
                   part.data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, pad, dil, _stream())
-            dwk = part.sum(0) if S > 1 else part[0]                  # [Cout, K], k = ((ci/32) * T + tap) * 32 + ci%32
-            T = KH * KW
-            dw = (dwk.reshape(Cout, kdim // (32 * T), T, 32).permute(0, 1, 3, 2).reshape(Cout, kdim // T, KH, KW)[:, :Cin]
-                  .contiguous())
+            dw = torch.empty_like(weight)          # sum over the S slices + back to [Cout, Cin, KH, KW] in one pass
+            _call("conv2d_wgrad", "cocos_conv2d_wgrad_reduce", part.data_ptr(), dw.data_ptr(), S, Cout, Cin, KH, KW, _stream())
         if need_b and has_bias:
             db = dy.sum((0, 2, 3))
         return dx, dw, db, None, None, None

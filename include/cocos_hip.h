@@ -468,6 +468,16 @@ int cocos_conv2d_fwd_scatter_f16x3(const float* x, const void* w_hi, const void*
                                    const float* x_amax_dev, float* y, int B, int Cin, int H, int W, int Cout, int JH, int JW,
                                    int pad_y, int pad_x, int OHo, int OWo, long long y_plane, int y_pitch, int y_col_stride,
                                    long long y_offset, cocos_stream_t stream);
+/* The two pieces of host-side glue around the calls above as one launch each:
+ *   cocos_conv2d_weight_planes: weight [Cout,Cin,KH,KW] fp32 -> the planes of cocos_conv2d_fwd_f16x3 (mode 0) or of the
+ *       input-gradient calls (mode 1: channel roles swapped, sub-kernel w[:, :, ry::s, rx::s] of JH x JW taps, flipped;
+ *       stride-1 layers: ry = rx = 0, s = 1, J = K), scaled by the power of two from *amax_dev (-> *scale_out_dev).
+ *   cocos_conv2d_wgrad_reduce: partials [S][Cout][K] of cocos_conv2d_wgrad_f16x3 -> dw [Cout,Cin,KH,KW]. */
+int cocos_conv2d_weight_planes(const float* w, void* hi, void* lo, int Cout, int Cin, int KH, int KW, int mode, int JH, int JW,
+                               int ry, int rx, int s, const float* amax_dev /* nullable */,
+                               float* scale_out_dev /* nullable */, cocos_stream_t stream);
+int cocos_conv2d_wgrad_reduce(const float* partials, float* dw, int S, int Cout, int Cin, int KH, int KW,
+                              cocos_stream_t stream);
 int cocos_conv2d_wgrad_slices(int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                               int dilation);   /* 0 on bad dims */
 int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const float* x_amax_dev /* nullable */,
