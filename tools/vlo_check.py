@@ -1,3 +1,4 @@
+"""K2 split kernels with exactly-representable label channels (v_lo_mask = 1: lo plane of value blocks >= 1 skipped) vs a dense V."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
@@ -13,7 +14,6 @@ lab = torch.randint(0, 151, (B, 1, N), device="cuda", generator=g)
 v_exact = torch.cat([img, torch.zeros(B, 151, N, device="cuda").scatter_(1, lab, 1.0)], 1).contiguous()
 v_soft = torch.rand(B, 154, N, device="cuda", generator=g) * 2 - 1
 go = torch.randn(B, 154, N, device="cuda", generator=g)
-"""K2 split kernels with exactly-representable label channels (v_lo_mask = 1: lo plane of value blocks >= 1 skipped) vs a dense V."""
 for name, v in (("exact labels", v_exact), ("dense V", v_soft), ("exact labels", v_exact), ("dense V", v_soft)):
     vh, vl, _ = ops.split_f16(v, False, amax=ops.absmax(v))
     print(name, "mask", bin(int(ops.f16_plane_block_mask(vl).view(torch.int32).item())))
