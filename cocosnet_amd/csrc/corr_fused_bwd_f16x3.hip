@@ -74,8 +74,20 @@ struct DsRegs {
     unsigned hw[8], lw[8];     // f16 hi / lo, two values per register: register j>>1, half j&1
 };
 
+#define COCOS_BQ_PARAMS \
+    const _Float16* __restrict__ kch, const _Float16* __restrict__ kcl, const _Float16* __restrict__ vph,          \
+    const _Float16* __restrict__ vpl, const _Float16* __restrict__ gph, const _Float16* __restrict__ gpl,          \
+    const float* __restrict__ g_scale, const float* __restrict__ outp, const float* __restrict__ dout,             \
+    const float* __restrict__ lse, const float* __restrict__ lg, float* __restrict__ dqn, _Float16* __restrict__ dsh, \
+    _Float16* __restrict__ dsl, _Float16* __restrict__ psh, _Float16* __restrict__ psl, const float* __restrict__ v_amax, \
+    const float* __restrict__ v_scale, float* __restrict__ ds_scale_out, const unsigned* __restrict__ v_lo_mask, int B, \
+    int Nq, int Nk, int Cv, float inv_t, float k_scale
+#define COCOS_BQ_ARGS \
+    kch, kcl, vph, vpl, gph, gpl, g_scale, outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, \
+    v_lo_mask, B, Nq, Nk, Cv, inv_t, k_scale
+
 template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED, bool VLO0, bool BLK>
-__global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
+__device__ __forceinline__ void corr_bwd_query_f16x3_body(
     const _Float16* __restrict__ kch, const _Float16* __restrict__ kcl,   // [B,256,Nk] planes of k_scale*kn
     const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] planes of s_v*v
     const _Float16* __restrict__ gph, const _Float16* __restrict__ gpl,   // [B,Nq,CVP] planes of s_o*dout
@@ -109,9 +121,8 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     using std::false_type;
     using std::true_type;
     const int tid = threadIdx.x;
-    // VLO0 (template): only value block 0 has a non-zero lo plane (see the forward kernel).  The host launches both
-    // instantiations; the one the device-side mask does not select returns at once.
-    if ((CVB > 1 && v_lo_mask != nullptr && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u) != VLO0) return;
+    // VLO0 (template): only value block 0 has a non-zero lo plane (see the forward kernel); the kernel below holds both
+    // flavours of this body and picks one from the device-side mask.
     const std::integral_constant<bool, VLO0> vlo0_tag{};
     const int lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
@@ -579,6 +590,17 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(
     }
 }
 
+// The kernel: one launch holds both flavours of the body (V_lo terms of the value blocks >= 1 issued / skipped) and picks
+// one, workgroup-uniformly, from the device-side mask as its first action (see corr_fused_fwd_f16x3.hip).  DUAL = false:
+// no mask / a single value block — only the general flavour is compiled in.
+template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED, bool DUAL, bool BLK>
+__global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(COCOS_BQ_PARAMS) {
+    if (DUAL && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
+        corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, DUAL, BLK>(COCOS_BQ_ARGS);
+    else
+        corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK>(COCOS_BQ_ARGS);
+}
+
 template <int CVB>
 static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Float16* vph, const _Float16* vpl,
                            const _Float16* gph, const _Float16* gpl, const float* g_scale, const float* outp,
@@ -608,12 +630,12 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
     do {                                                                                                     \
         if (!RG && blocked) COCOS_GO4(DS, SP, RG, VL, MASK, (!RG)); else COCOS_GO4(DS, SP, RG, VL, MASK, false); \
     } while (0)
-    /* with a mask and more than one value block both instantiations are launched: the one the mask does not select
-       returns at once (the choice is data on the device; no host round trip) */
+    /* with a mask and more than one value block the kernel holds both flavours and picks one from the device-side mask
+       (whole tiles only: the ragged two-flavour instantiations need a few dwords of scratch and are not built) */
 #define COCOS_GO2(DS, SP, RG)                                                                                \
     do {                                                                                                     \
-        if (CVB > 1 && v_lo_mask) COCOS_GO3(DS, SP, RG, (CVB > 1), v_lo_mask);                               \
-        COCOS_GO3(DS, SP, RG, false, (CVB > 1 ? v_lo_mask : nullptr));                                       \
+        if (CVB > 1 && !RG && v_lo_mask) COCOS_GO3(DS, SP, RG, (CVB > 1 && !RG), v_lo_mask);                 \
+        else COCOS_GO3(DS, SP, RG, false, nullptr);                                                          \
     } while (0)
     if (store) { if (ragged) COCOS_GO(true, true); else COCOS_GO(true, false); }
     else       { if (ragged) COCOS_GO(false, true); else COCOS_GO(false, false); }

@@ -100,14 +100,11 @@ __device__ long long g_phase_fwd_h[8];
 #endif
 
 template <int CVB, bool STORE_S, bool RAGGED, bool VLO0>
-__global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
+__device__ __forceinline__ void corr_fwd_f16x3_body(
     const _Float16* __restrict__ qh, const _Float16* __restrict__ ql, const _Float16* __restrict__ kh,
     const _Float16* __restrict__ kl, const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
     float* __restrict__ out, float* __restrict__ lse, float* __restrict__ lg, const float* __restrict__ v_scale,
     const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2 /* inv_temperature * log2(e) / (q_scale * k_scale) */) {
-    // FIRST thing (before the resident query slice is fetched): the instantiation the device-side mask does not select
-    // leaves.  Uniform: lo plane of every value block but the first all zero (nullptr / single block: general path).
-    if ((CVB > 1 && v_lo_mask != nullptr && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u) != VLO0) return;
     constexpr int CVP = CVB * 32;
     constexpr int KPLANE = SP_BK * SP_KROW;          // halfs per K plane per buffer
     constexpr int VPLANE = CVP * SP_VROW;
@@ -280,8 +277,8 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     // barrier in tile t; it is read in P.V(t+1), after the barrier of tile t+1.
     // VLO0 (template): only value block 0 has a non-zero lo plane (one-hot label channels are exact in f16: `v_lo_mask`,
     // cocos_f16_plane_block_mask) — the V_lo * P_hi term, its fragment reads and its staging are skipped for the other
-    // blocks: same result, 8 of 30 P.V MFMAs fewer.  The host launches both instantiations; the one the mask does not
-    // select returns at once (a choice inside ONE kernel — per tile or per loop copy — cost registers: measured slower).
+    // blocks: same result, 8 of 30 P.V MFMAs fewer.  The kernel (below) holds both flavours of this body and picks one
+    // from the mask before anything else (a choice further inside — per tile or per loop copy — cost registers: measured slower).
     const std::integral_constant<bool, VLO0> vlo0_tag{};
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * SP_BK, buf = t & 1;
@@ -472,6 +469,22 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     }
 }
 
+// The kernel: one launch holds BOTH flavours of the body (V_lo terms of the value blocks >= 1 issued / skipped); the
+// workgroup-uniform choice is the first thing it does — data on the device (cocos_f16_plane_block_mask), no host round
+// trip, and no second launch whose workgroups only look at the mask and leave (that cost 5-8 us per call).
+// DUAL = false: no mask / a single value block — only the general flavour is compiled in.
+template <int CVB, bool STORE_S, bool RAGGED, bool DUAL>
+__global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
+    const _Float16* __restrict__ qh, const _Float16* __restrict__ ql, const _Float16* __restrict__ kh,
+    const _Float16* __restrict__ kl, const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
+    float* __restrict__ out, float* __restrict__ lse, float* __restrict__ lg, const float* __restrict__ v_scale,
+    const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2) {
+    if (DUAL && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
+        corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, DUAL>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk, Cv, scale_log2);
+    else
+        corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, false>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk, Cv, scale_log2);
+}
+
 template <int CVB, bool STORE_S, bool RAGGED, bool VLO0>
 static int launch_f16x3_k(const _Float16* qh, const _Float16* ql, const _Float16* kh, const _Float16* kl,
                           const _Float16* vh, const _Float16* vl, float* out, float* lse, float* lg,
@@ -508,12 +521,9 @@ static int cocos_go_both(const _Float16* a, const _Float16* b2, const _Float16* 
                          const _Float16* f, float* out, float* lse, float* lgp, const float* v_scale_dev,
                          const unsigned* v_lo_mask_dev, A... rest) {
     using namespace cocos;
-    if (CVB > 1 && v_lo_mask_dev) {
-        if (int rc = launch_f16x3_k<CVB, ST, RG, (CVB > 1)>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, v_lo_mask_dev, rest...))
-            return rc;
-    }
-    return launch_f16x3_k<CVB, ST, RG, false>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, CVB > 1 ? v_lo_mask_dev : nullptr,
-                                              rest...);
+    if (CVB > 1 && v_lo_mask_dev)
+        return launch_f16x3_k<CVB, ST, RG, (CVB > 1)>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, v_lo_mask_dev, rest...);
+    return launch_f16x3_k<CVB, ST, RG, false>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, nullptr, rest...);
 }
 
 extern "C" size_t cocos_corr_softmax_warp_saved_logits_bytes(int B, int Nq, int Nk) {
@@ -556,8 +566,7 @@ extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql,
     const _Float16 *a = static_cast<const _Float16*>(qh), *b2 = static_cast<const _Float16*>(ql),
                    *c2 = static_cast<const _Float16*>(kh), *d = static_cast<const _Float16*>(kl),
                    *e = static_cast<const _Float16*>(vh), *f = static_cast<const _Float16*>(vl);
-    // with a mask and more than one value block: both instantiations are launched, the kernel the mask does not select
-    // returns at once (the choice is data on the device; no host round trip)
+    // with a mask and more than one value block the kernel holds both flavours and picks one from the device-side mask
 #define COCOS_GO(CVB, ST, RG) \
     cocos_go_both<CVB, ST, RG>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, v_lo_mask_dev, B, Nq, Nk, Cv, scale_log2, s)
 #define COCOS_CVB(CVB)                                                           \
