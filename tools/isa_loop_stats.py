@@ -1,5 +1,8 @@
 """Opcode statistics of the MFMA-heavy basic blocks of one kernel in a hipcc -save-temps .s file.
-Usage: python tools/isa_loop_stats.py file.s <substring of the mangled kernel name>"""
+Usage: python tools/isa_loop_stats.py file.s <substring of the mangled kernel name>
+CAUTION: a "block" here is the text between two .LBB labels — it says nothing about loop membership.  A block that ends in
+a backward branch may be the loop's EXIT path (hipcc puts the accumulator shuffles of the epilogue there): check with
+tools/isa_mfma_gaps.sh / the branch targets before reading a block's v_accvgpr_* count as per-iteration work."""
 import collections
 import re
 import sys
