@@ -38,6 +38,7 @@ if REPO not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16: 32 cycles), no sparsity
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 BATCH_PER_GPU = 8
 IMG = 256
 DOWN = 4
@@ -277,9 +278,18 @@ def roofline_of(kernels, precision):
             if PMC_KEY[precision][dom] in name:
                 traffic = rec["hbm_bytes"]
                 traffic_src = f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes)"
+    # the same kernel's HBM coordinate (the second roofline north_star names): PMC bytes per launch / measured time
+    hbm = None
+    if traffic:
+        gbs = traffic / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+        hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+               "note": "HBM bytes per launch (PMC, profiles/) / the launch time measured in this run; the kernel moves the "
+                       "saved logits and the dS'' planes (2 x HW^2 x 4 B per sample) next to its MFMA work, so this "
+                       "fraction, not only the MFMA one, says how close it is to a roof (a linear read reaches "
+                       "4.7-4.9 TB/s on this chip: tools/probes/strided_rows.hip)"}
     if split and dom in SPLIT_TAGS:
         peak = F16_MFMA_PEAK_TFLOPS / 3.0
-        return {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["alg_tflops"], "peak": round(peak, 1),
+        return {"bound": "mfma", "kernel": dom, "hbm": hbm, "achieved": kernels[dom]["alg_tflops"], "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(kernels[dom]["alg_tflops"] / peak, 4), "traffic": traffic,
                 "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                 "avg_launch_ms": kernels[dom]["avg_ms"], "issued_tflops": kernels[dom]["issued_tflops"],
@@ -293,7 +303,7 @@ def roofline_of(kernels, precision):
                         "(kernels[...].mfma). vs_fp32_mfma_peak = achieved / "
                         "157.3 (the exact-fp32 MFMA this kernel replaces; flavours.fp32 in this line is that flavour, "
                         "same process, same box)."}
-    return {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["alg_tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
+    return {"bound": "mfma", "kernel": dom, "hbm": hbm, "achieved": kernels[dom]["alg_tflops"], "peak": FP32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": kernels[dom]["frac_fp32_mfma_peak"], "traffic": traffic,
             "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "avg_launch_ms": kernels[dom]["avg_ms"],
             "note": "algorithmic FLOPs per launch / HIP-event time on torch's current stream; peak = dense fp32 MFMA "

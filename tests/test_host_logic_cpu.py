@@ -127,6 +127,10 @@ def test_bench_roofline_and_kernel_table_contract():
     assert roof["kernel"] == "corr_softmax_warp_bwd_query" and roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s"
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["frac_issued"] <= roof["frac"] + 1e-6
     assert roof["traffic"] is None or roof["traffic"] > 1e8          # bytes per launch from profiles/r02_pmc_f16x3.json
+    if roof["traffic"]:                                              # the HBM coordinate of the same kernel
+        assert roof["hbm"]["unit"] == "GB/s" and roof["hbm"]["peak"] == bench.HBM_PEAK_GBS
+        assert abs(roof["hbm"]["achieved"] - roof["traffic"] / 0.35e-3 / 1e9) < 1.0
+        assert abs(roof["hbm"]["frac"] - roof["hbm"]["achieved"] / 8000.0) < 1e-3
     fp = bench.roofline_of(bench.kernel_table(kern, "fp32"), "fp32")
     assert fp["peak"] == bench.FP32_MFMA_PEAK_TFLOPS
 
