@@ -66,6 +66,25 @@ class GradBuckets:
             loss(model(batch)).backward()              # full buckets leave from the hooks, during backward
             buckets.finish()                           # launch what is left, wait, average
             optimizer.step()
+
+    Contract: ONE backward between zero_grad() and finish().  A second backward (gradient accumulation, two losses
+    with retain_graph) would add into a buffer whose all-reduce has already left: its contribution would never be
+    reduced and the ranks would silently diverge — the hook RAISES instead.  Accumulate explicitly:
+
+            with buckets.accumulate():                 # hooks count nothing, nothing is launched
+                loss_a.backward()
+            loss_b.backward()                          # the last backward launches the buckets as usual
+
+    A backward AFTER finish() and before the next zero_grad() (a GAN's generator step also writes the discriminator's
+    gradients; its optimiser only ever zeroes them) is harmless and launches nothing.
+
+    Stream ordering (backend "nccl" = RCCL).  A hook runs on the autograd thread with the stream of the forward op
+    current; `dist.all_reduce(async_op=True)` makes RCCL's own stream wait for that stream at the launch point, so
+    the collective sees the finished gradient.  `work.wait()` in finish() / zero_grad() does not block the host: it
+    makes the CALLER's current stream wait for the collective, and the in-place division is enqueued behind it on
+    that same stream — so finish() and the optimiser step that follows must run on the stream (or a stream ordered
+    after the stream) backward ran on, which is the case for the reference's single-stream step functions.  After
+    finish() returns no collective of this object is in flight (`in_flight() == 0`, tested on gloo).
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = DEFAULT_BUCKET_BYTES,
@@ -103,6 +122,8 @@ class GradBuckets:
         self._pending = [len(b) for b in self.buckets]
         self._works: List = [None] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._finished = False        # finish() has run since the last zero_grad(): later gradients are nobody's
+        self._accumulating = False    # inside accumulate(): hooks neither count nor launch
         self._hooks = []
         if self.overlap:
             for p in self.params:
@@ -132,6 +153,26 @@ class GradBuckets:
         self._pending = [len(b) for b in self.buckets]
         self._works = [None] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._finished = False
+
+    def in_flight(self) -> int:
+        """Collectives launched by this object that have not completed yet (0 after finish())."""
+        return sum(1 for w in self._works if w is not None and not w.is_completed())
+
+    def accumulate(self):
+        """Context manager for every backward but the LAST of a step: gradients add up in the buckets, nothing is
+        counted or launched (DistributedDataParallel's no_sync())."""
+        outer = self
+
+        class _Accumulate:
+            def __enter__(self_inner):
+                outer._accumulating = True
+                return outer
+
+            def __exit__(self_inner, *exc):
+                outer._accumulating = False
+                return False
+        return _Accumulate()
 
     def _launch(self, i: int) -> None:
         if self._launched[i]:
@@ -153,6 +194,13 @@ class GradBuckets:
     def _on_grad_ready(self, p: torch.nn.Parameter) -> None:
         i = self._bucket_of[p]
         self._adopt(p)
+        if self._accumulating or self._finished:
+            return            # accumulate(): a later backward launches; after finish(): a gradient nobody steps with
+        if self._launched[i]:
+            raise RuntimeError(
+                "GradBuckets: a second backward reached a gradient bucket whose all-reduce has already been launched "
+                "(one backward per zero_grad()/finish() pair; wrap all but the last backward of a step in "
+                "`with buckets.accumulate():`) - the new contribution would never be reduced")
         self._pending[i] -= 1
         if self._pending[i] == 0:
             self._launch(i)
@@ -162,6 +210,9 @@ class GradBuckets:
         """Launch the buckets the hooks have not (parameters without a gradient this step, or overlap=False), wait
         for all of them and turn the sums into means.  grad <- mean over ranks."""
         world = world_size or _live_world(self.group)
+        if self._finished:
+            return                           # idempotent: the means are already in place
+        self._finished = True
         if world <= 1:
             return
         for i in range(len(self.buckets)):
@@ -171,8 +222,8 @@ class GradBuckets:
             self._launch(i)
         for i, w in enumerate(self._works):
             if w is not None:
-                w.wait()
-            self._flat[i].div_(world)
+                w.wait()                     # nccl: the current stream waits for RCCL's; gloo: the host does
+            self._flat[i].div_(world)        # ... and the division is ordered behind it on that stream
 
     # round-1 name: post-backward exchange in one call
     def all_reduce_(self, world_size: int | None = None, async_op: bool = True) -> None:

@@ -12,6 +12,12 @@ backend "nccl"), attached to the two optimisers so that the step functions need 
     optimizer.step()       ->  first waits for the buckets and turns sums into means, then the reference's Adam step
 
 Sync-BN layers (the reference without --PONO) exchange their statistics through `cocosnet_amd.dist.SyncBatchNorm2d`.
+
+Checkpoints: the replicas are identical, so `save()` writes on RANK 0 ONLY and every rank waits at a barrier — the
+inherited `Pix2PixTrainer.save()` (:84-97 -> util.save_network, util/util.py:226-231: `net.cpu()`, `torch.save` to ONE
+shared path, `net.cuda()`) run by every rank would race on the same files.  Data: `sampler(dataset)` returns the
+`DistributedSampler` that gives each rank its own shard of every epoch (the reference's DataLoader has no notion of
+ranks: data/__init__.py builds a plain shuffled loader, every process would draw the SAME samples).
 """
 from __future__ import annotations
 
@@ -72,6 +78,7 @@ def make_distributed_trainer(trainer_cls):
             if isinstance(model, torch.nn.Module):
                 broadcast_parameters(model)
             self.grad_buckets = {}
+            self._bucket_bytes = bucket_bytes
             for name in ("optimizer_G", "optimizer_D"):
                 optim = getattr(self, name, None)
                 if optim is not None:
@@ -80,6 +87,37 @@ def make_distributed_trainer(trainer_cls):
         def shard(self, global_batch: int):
             """[start, stop) of this rank's samples of a global batch (for data loaders that index by sample)."""
             return shard_batch(global_batch, self.rank, self.world_size)
+
+        def sampler(self, dataset, shuffle: bool = True, seed: int = 0, drop_last: bool = True):
+            """The sampler to hand to `torch.utils.data.DataLoader(dataset, batch_size=opt.batchSize, sampler=...)`
+            in place of the reference's `shuffle=` (data/__init__.py): disjoint shards of one common permutation per
+            epoch (call `.set_epoch(epoch)` at the top of every epoch, as with DistributedDataParallel)."""
+            from torch.utils.data.distributed import DistributedSampler
+            return DistributedSampler(dataset, num_replicas=self.world_size, rank=self.rank, shuffle=shuffle,
+                                      seed=seed, drop_last=drop_last)
+
+        def save(self, epoch):
+            """pix2pix_trainer.py:84-97 on rank 0 only (identical replicas; one writer per file), then a barrier so
+            that no rank races ahead into a `continue_train` load or the next save.  The other ranks skip the
+            `.cpu()` / `.cuda()` round trip of util.save_network altogether."""
+            try:
+                if self.rank == 0:
+                    super().save(epoch)
+            finally:
+                if self.world_size > 1 and dist.is_initialized():
+                    dist.barrier()
+            # util.save_network moved rank 0's parameters (and their .grad) to the host and back: the gradient views
+            # into the flat buckets are re-attached by the next zero_grad() (GradBuckets.zero_grad checks every view)
+
+        def update_fixed_params(self):
+            """pix2pix_trainer.py:125-139 REPLACES optimizer_G (netCorr unfrozen): move the gradient exchange to the
+            new optimiser, or it would step on unreduced gradients."""
+            old = self.grad_buckets.pop("optimizer_G", None)
+            if old is not None:
+                old.finish()
+                old.close()
+            super().update_fixed_params()
+            self.grad_buckets["optimizer_G"] = attach_gradient_exchange(self.optimizer_G, bucket_bytes=self._bucket_bytes)
 
     DistributedTrainer.__name__ = "Distributed" + trainer_cls.__name__
     return DistributedTrainer

@@ -178,6 +178,7 @@ class _ToyTrainer:
         self.pix2pix_model_on_one_gpu = torch.nn.ModuleDict({"G": self.G, "D": self.D})
         self.optimizer_G = torch.optim.Adam(self.G.parameters(), lr=1e-2, betas=(0.0, 0.9), eps=1e-3)
         self.optimizer_D = torch.optim.Adam(self.D.parameters(), lr=2e-2, betas=(0.0, 0.9), eps=1e-3)
+        self.opt_dir = getattr(opt, "checkpoints_dir", None)
 
     def run_generator_one_step(self, x, y):
         self.optimizer_G.zero_grad()
@@ -192,21 +193,45 @@ class _ToyTrainer:
         d_loss.backward()
         self.optimizer_D.step()
 
+    def save(self, epoch):
+        """The reference's save path in miniature (pix2pix_trainer.py:84-97 -> util/util.py:226-231): every caller
+        writes the SAME file names."""
+        os.makedirs(self.opt_dir, exist_ok=True)
+        with open(os.path.join(self.opt_dir, "writers.log"), "a") as f:
+            f.write("save\n")
+        torch.save(self.pix2pix_model_on_one_gpu.state_dict(), os.path.join(self.opt_dir, f"{epoch}_net.pth"))
+        torch.save({"G": self.optimizer_G.state_dict(), "D": self.optimizer_D.state_dict()},
+                   os.path.join(self.opt_dir, "optimizer.pth"))
 
-def _trainer_worker(rank, world, port, ret):
+    def update_fixed_params(self):
+        """pix2pix_trainer.py:125-139: a NEW optimizer_G object over the same parameters."""
+        self.optimizer_G = torch.optim.Adam(self.G.parameters(), lr=1e-2, betas=(0.0, 0.9), eps=1e-3)
+
+
+def _trainer_worker(rank, world, port, ret, ckpt_dir=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from types import SimpleNamespace
     from cocosnet_amd import trainer as ctr
     Dist = ctr.make_distributed_trainer(_ToyTrainer)
-    tr_ = Dist(SimpleNamespace(seed=100 + rank, gpu_ids=[]), backend="gloo", bucket_bytes=64)   # different seeds per rank:
-    g = torch.Generator().manual_seed(7)                                                         # the broadcast must fix it
+    tr_ = Dist(SimpleNamespace(seed=100 + rank, gpu_ids=[], checkpoints_dir=ckpt_dir), backend="gloo",
+               bucket_bytes=64)                          # different seeds per rank: the broadcast must fix it
+    g = torch.Generator().manual_seed(7)
     X, Y = torch.randn(3, 4, 3, 5, 5, generator=g), torch.randn(3, 4, 3, 5, 5, generator=g)
+    in_flight = []
     for it in range(3):
         lo, hi = tr_.shard(4)
         tr_.run_generator_one_step(X[it, lo:hi], Y[it, lo:hi])
+        # after optimizer_G.step(): G's collectives are over.  (D's parameters also received gradients during this
+        # backward; from the second iteration on their buckets are finished and launch nothing.)
+        in_flight.append(tr_.grad_buckets["optimizer_G"].in_flight())
         tr_.run_discriminator_one_step(X[it, lo:hi], Y[it, lo:hi])
-    ret[rank] = [p.detach().clone() for p in tr_.pix2pix_model_on_one_gpu.parameters()]
+        in_flight.append(tr_.grad_buckets["optimizer_D"].in_flight() + tr_.grad_buckets["optimizer_G"].in_flight())
+        if it == 1 and ckpt_dir is not None:
+            tr_.save("latest")                           # EVERY rank calls it, as the reference's train.py would
+            tr_.update_fixed_params()                    # optimizer_G is replaced: the exchange must follow it
+    ret[rank] = ([p.detach().clone() for p in tr_.pix2pix_model_on_one_gpu.parameters()], in_flight,
+                 hasattr(tr_.optimizer_G, "grad_buckets"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -229,5 +254,91 @@ def test_distributed_trainer_equals_single_process_on_the_global_batch():
         ref.run_discriminator_one_step(X[it], Y[it])
     want = [p.detach() for p in ref.pix2pix_model_on_one_gpu.parameters()]
     for rank in range(world):
-        for a, b in zip(ret[rank], want):
+        params, in_flight, _ = ret[rank]
+        for a, b in zip(params, want):
             assert torch.allclose(a, b, atol=2e-5, rtol=1e-4)
+        assert in_flight == [0] * 6                     # no collective left in flight across a G / D step boundary
+
+
+def test_distributed_trainer_save_writes_once_and_follows_a_replaced_optimizer(tmp_path):
+    """ADVICE r2 (medium): the inherited save() run by every rank races on ONE set of files.  Both ranks call save();
+    exactly one writer ran, the checkpoint is rank 0's state after two iterations, and after update_fixed_params()
+    (a NEW optimizer_G, pix2pix_trainer.py:125-139) the third iteration still exchanges gradients: the replicas end
+    identical and equal to the single-process run that replaces its optimiser at the same point."""
+    from types import SimpleNamespace
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ckpt = str(tmp_path / "ckpt")
+    mp.spawn(_trainer_worker, args=(world, port, ret, ckpt), nprocs=world, join=True)
+    assert open(os.path.join(ckpt, "writers.log")).read().count("save") == 1
+    ref = _ToyTrainer(SimpleNamespace(seed=100))
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(3, 4, 3, 5, 5, generator=g), torch.randn(3, 4, 3, 5, 5, generator=g)
+    for it in range(3):
+        ref.run_generator_one_step(X[it], Y[it])
+        ref.run_discriminator_one_step(X[it], Y[it])
+        if it == 1:
+            saved = {k: v.clone() for k, v in ref.pix2pix_model_on_one_gpu.state_dict().items()}
+            ref.update_fixed_params()
+    on_disk = torch.load(os.path.join(ckpt, "latest_net.pth"))
+    for k, v in saved.items():
+        assert torch.allclose(on_disk[k], v, atol=2e-5, rtol=1e-4), k
+    want = [p.detach() for p in ref.pix2pix_model_on_one_gpu.parameters()]
+    for rank in range(world):
+        params, in_flight, attached = ret[rank]
+        assert attached and in_flight == [0] * 6
+        for a, b in zip(params, want):
+            assert torch.allclose(a, b, atol=2e-5, rtol=1e-4)
+
+
+def _accumulate_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from cocosnet_amd import dist as cdist
+    cdist.init_from_env("gloo")
+    model = _model()
+    x, y = _data(8)
+    lo, hi = cdist.shard_batch(8, rank, world)
+    mid = (lo + hi) // 2
+    buckets = cdist.GradBuckets(model.parameters(), bucket_bytes=64)
+    buckets.zero_grad()
+    with buckets.accumulate():                           # micro-batch 1: nothing may leave
+        (((model(x[lo:mid]) - y[lo:mid]) ** 2).mean() / 2).backward()
+        launched_inside = sum(buckets._launched)
+    (((model(x[mid:hi]) - y[mid:hi]) ** 2).mean() / 2).backward()
+    buckets.finish()
+    buckets.finish()                                     # idempotent: must not divide twice
+    grads = [p.grad.clone() for p in model.parameters()]
+    # the contract violation: a second backward WITHOUT accumulate() after the buckets have left
+    buckets.zero_grad()
+    ((model(x[lo:mid]) - y[lo:mid]) ** 2).mean().backward()
+    try:
+        ((model(x[mid:hi]) - y[mid:hi]) ** 2).mean().backward()
+        raised = False
+    except RuntimeError as e:
+        raised = "second backward" in str(e)
+    buckets.finish()
+    ret[rank] = (grads, launched_inside, raised, buckets.in_flight())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_accumulation_is_explicit_and_a_second_backward_raises():
+    """two backwards between zero_grad() and finish() used to add into a bucket whose all-reduce had
+    already left.  accumulate() defers the launch (two micro-batches per rank == the global-batch gradient); without it
+    the hook raises."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_accumulate_worker, args=(world, port, ret), nprocs=world, join=True)
+    model = _model()
+    x, y = _data(8)
+    ((model(x) - y) ** 2).mean().backward()
+    for rank in range(world):
+        grads, launched_inside, raised, in_flight = ret[rank]
+        assert launched_inside == 0 and raised and in_flight == 0
+        for a, p in zip(grads, model.parameters()):
+            assert torch.allclose(a, p.grad, atol=1e-6, rtol=1e-5)

@@ -1,5 +1,12 @@
 """Accuracy of the two K2-forward flavours against the fp64 oracle on the same inputs (GPU box).
-Prints max|out - ref| / max|ref| for diffuse and peaked logits."""
+
+Two views of the same error (round-2 VERDICT, weak 1: "every tolerance is max-normalised"):
+  * max|out - ref| / max|ref|  — the tolerance kind of the parity tests;
+  * an ELEMENTWISE relative histogram |out - ref| / |ref| of the soft label map (`warp_mask` = P @ one-hot, the tensor
+    whose log the loss takes, pix2pix_model.py:276), bucketed by the magnitude of the reference entry: north_star's
+    "1e-3 relative" read literally.
+"""
+import json
 import sys
 import numpy as np
 import torch
@@ -7,16 +14,30 @@ sys.path.insert(0, ".")
 from cocosnet_amd import ops
 from oracle import corr_oracle as co
 
+res = []
 for peaked in (False, True):
     rs = np.random.RandomState(1)
-    B, N, Cv = 1, 1024, 154
+    B, N, Cv, nc = 1, 1024, 154, 151
     q = rs.standard_normal((B, 256, N))
     k = q + 0.05 * rs.standard_normal((B, 256, N)) if peaked else rs.standard_normal((B, 256, N))
     v = rs.uniform(-1, 1, (B, Cv, N))
+    v[:, 3:] = np.eye(nc)[rs.randint(0, nc, N)].T[None]          # 151 one-hot label channels, like ADE20k's ref_seg
     qn, kn = co.center_l2norm(q, True), co.center_l2norm(k, True)
     ref = co.corr_softmax_warp(qn, kn, v, 100.0)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
     for prec in ("fp32", "f16x3"):
         ops.PRECISION = prec
         out = ops.corr_softmax_warp(t(qn), t(kn), t(v), 100.0).double().cpu().numpy()
-        print(f"peaked={peaked} {prec:6s} rel err {np.abs(out - ref).max() / np.abs(ref).max():.2e}")
+        rec = {"peaked": peaked, "flavour": prec, "max_normalised": float(np.abs(out - ref).max() / np.abs(ref).max())}
+        m_out, m_ref = out[:, 3:].ravel(), ref[:, 3:].ravel()
+        hist = {}
+        for lo, hi in ((1e-1, 2.0), (1e-3, 1e-1), (1e-6, 1e-3), (1e-9, 1e-6), (1e-12, 1e-9)):
+            sel = (m_ref >= lo) & (m_ref < hi)
+            if sel.any():
+                e = np.abs(m_out[sel] - m_ref[sel]) / m_ref[sel]
+                hist[f"[{lo:g},{hi:g})"] = {"n": int(sel.sum()), "max": float(e.max()), "p99": float(np.percentile(e, 99)),
+                                            "median": float(np.median(e))}
+        rec["mask_elementwise_relative"] = hist
+        rec["mask_log_abs_err_max"] = float(np.abs(np.log(m_out.clip(0) + 1e-10) - np.log(m_ref + 1e-10)).max())
+        res.append(rec)
+        print(json.dumps(rec), flush=True)
