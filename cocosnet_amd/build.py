@@ -37,6 +37,7 @@ HIP_SOURCES = [
     "proj_stream_f16x3.hip",
     "proj_dw_f16x3.hip",
     "box3_unfold.hip",
+    "box3_fused_f16x3.hip",
     "unfold3_stats.hip",
     "logits_softmax_warp.hip",
     "logits_softmax_warp_f16x3.hip",
@@ -87,7 +88,7 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP translation unit for gfx950 and link libcocos_hip.so. Returns its path."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = [os.path.join(CSRC_DIR, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC_DIR, "common.h"),
+    deps = srcs + [os.path.join(CSRC_DIR, "common.h"), os.path.join(CSRC_DIR, "box3_common.h"),
                    os.path.join(REPO_DIR, "include", "cocos_hip.h")]
     stamp = LIB_PATH + ".sha256"      # next to the library: it travels with it (obj/ does not have to)
     want = _digest(deps)
@@ -95,13 +96,20 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
             and open(stamp).read().strip() == want):
         return LIB_PATH
     hipcc = _hipcc()
+    headers = [d for d in deps if not d.endswith(".hip")]
 
     def compile_one(src: str) -> str:
+        # per-object stamp (source + every header + flags): editing one kernel file recompiles one translation unit
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        ostamp, owant = obj + ".sha256", _digest([src] + headers)
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == owant:
+            return obj
         cmd = [hipcc, *_flags(), *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        with open(ostamp, "w") as f:
+            f.write(owant)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:

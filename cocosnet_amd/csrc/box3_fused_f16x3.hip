@@ -1,0 +1,765 @@
+// match_kernel = 3 (the reference's default, options/base_options.py:70) without unfolding and without a materialised
+// logits matrix — K19 (box -> softmax -> warp, forward and backward) and K20 (box adjoint -> operand planes), gfx950.
+//
+// Replaces, for PONO_C on a 64-wide feature grid, the round-1/2 chain  K3 (C_raw) -> K6 (box filter, logits) -> K7
+// (softmax + warp)  and its backward  K7' -> K6' -> K3'  (correspondence.py:276-280, :286-291, :304, :307, :318 and their
+// autograd).  See box3_common.h for the decomposition; the data flow is
+//
+//   forward   T  = xbox(C_raw)                         cocos_box3_corr_xbox_f16x3 (hgemm_f16x3.hip, epilogue)
+//             z[p,q] = scale * a_p * b_q * (T[p-w,q-w] + T[p,q] + T[p+w,q+w] - kc * mu_p * nu_q)
+//             out = softmax_q(z) @ V                   K19 fwd: three 4 KB blocks of T per 32x32 tile, added in registers
+//   backward  P from T again (no saved logits), L = dloss/dz = P * (V.dO - D),
+//             G = L * scale * a_p * b_q  (= dloss / d(ybox T))  -> HBM, tile-blocked fp32              K19 bwd
+//             d mu, d a (row sums of L) directly; d nu, d b (column sums) as per-workgroup partials
+//             dC = xbox(ybox(G))  (the filter is self-adjoint) -> f16 hi/lo planes                     K20
+//             d theta = dC . phi^T, d phi = dC^T . theta^T                                             hgemm (modes 3, 2)
+//
+// HBM traffic per logit: forward 4 B written (T) + 4 B read; backward 4 (T) + 4 (G) + 4 (G) + 4 (planes) + 2 x 4
+// (planes) — against 16 B forward and 36 B backward for the materialised chain.
+//
+// mu / a (queries) and nu / b (keys) are the statistics of the unfolded, centred vectors (K12, unfold3_stats.hip):
+// mean over the 9*256 entries and 1 / (norm + eps).  kc = 2304.
+#include "box3_common.h"
+
+namespace cocos {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BX_VROW = 40;             // halfs per channel row of the forward V tile (32 permuted keys + pad)
+constexpr float kBxRescaleThr = 6.0f;   // lazy rescale of the running maximum (corr_fused_fwd_f16x3.hip)
+constexpr float kBxPBias = 9.0f;
+constexpr float kBxPPlaneScale = 16384.0f;
+
+__device__ __forceinline__ f32x16 bx_mfma(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// The three T blocks of one tile and the key statistics of its 32 keys, in flight one tile ahead.
+struct BxTile {
+    f32x4 s[3][4];      // [dy + 1][g]: accumulator registers 4g..4g+3
+    f32x4 bk[4], nu[4]; // b_k and nu_k of keys 8g + 4h + 0..3
+};
+
+// Geometry of a wave's query block, fixed for the kernel.
+struct BxGeom {
+    __amdgpu_buffer_rsrc_t t_rs, b_rs, nu_rs;
+    int qblk, py, tpr, himg, nqblk;
+    unsigned lane_off;      // lane * 16
+    unsigned stat_off;      // 4h floats
+};
+
+__device__ __forceinline__ void bx_fetch(BxTile& tl, const BxGeom& gm, int t, int ntiles) {
+    const int tc = min(t, ntiles - 1);                  // look-ahead past the end re-reads the last tile
+    const int ky = tc / gm.tpr;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int dy = d - 1;
+        const bool ok = (unsigned)(gm.py + dy) < (unsigned)gm.himg && (unsigned)(ky + dy) < (unsigned)gm.himg;
+        const int blk = ok ? (tc + dy * gm.tpr) * gm.nqblk + gm.qblk + dy * gm.tpr : 0;
+        const unsigned voff = ok ? gm.lane_off : kBufOob;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            tl.s[d][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                gm.t_rs, (int)voff, (int)((unsigned)blk * 4096u + (unsigned)g * 1024u), 0));
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const unsigned soff = (unsigned)(tc * 32 + 8 * g) * 4u;
+        tl.bk[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gm.b_rs, (int)gm.stat_off, (int)soff, 0));
+        tl.nu[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gm.nu_rs, (int)gm.stat_off, (int)soff, 0));
+    }
+}
+
+// tt[r] = b_q * (T_sum) - mu_p * kc * nu_q * b_q  (the logit without its per-query factor scale * a_p); also returns
+// b_q and kc * nu_q * b_q per register for the backward.
+__device__ __forceinline__ void bx_logits(const BxTile& tl, float mu_p, float kc, float (&tt)[16], float (&bq)[16],
+                                          float (&kn)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int g = r >> 2, e = r & 3;
+        const float ts = (tl.s[0][g][e] + tl.s[2][g][e]) + tl.s[1][g][e];
+        bq[r] = tl.bk[g][e];
+        kn[r] = kc * tl.nu[g][e] * bq[r];
+        tt[r] = __builtin_fmaf(bq[r], ts, -(mu_p * kn[r]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K19 forward
+// ---------------------------------------------------------------------------------------------------------
+template <int CVB>
+__global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
+    const float* __restrict__ T, const float* __restrict__ mu_q, const float* __restrict__ a_q,
+    const float* __restrict__ nu_k, const float* __restrict__ b_k, const _Float16* __restrict__ vh,
+    const _Float16* __restrict__ vl, float* __restrict__ out, float* __restrict__ lse,
+    const float* __restrict__ v_scale, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale) {
+    constexpr int CVP = CVB * 32, VPLANE = CVP * BX_VROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
+    _Float16* const vt = reinterpret_cast<_Float16*>(bx_smem);      // [2 buf][hi|lo|hi*2^-11][CVP][VROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int nqb = Nq / 128;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vb / nqb, q0 = (vb % nqb) * 128;
+    const int i_lane = q0 + wave * 32 + c;
+
+    const size_t vbytes = (size_t)Cv * Nk * 2;
+    const __amdgpu_buffer_rsrc_t vh_rs = make_rsrc(vh + (size_t)b * Cv * Nk, vbytes);
+    const __amdgpu_buffer_rsrc_t vl_rs = make_rsrc(vl + (size_t)b * Cv * Nk, vbytes);
+    BxGeom gm;
+    gm.t_rs = make_rsrc(T + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
+    gm.b_rs = make_rsrc(b_k + (size_t)b * Nk, (size_t)Nk * 4);
+    gm.nu_rs = make_rsrc(nu_k + (size_t)b * Nk, (size_t)Nk * 4);
+    gm.tpr = wimg / 32;
+    gm.qblk = (q0 >> 5) + wave;
+    gm.py = gm.qblk / gm.tpr;
+    gm.himg = himg;
+    gm.nqblk = Nq >> 5;
+    gm.lane_off = (unsigned)lane * 16u;
+    gm.stat_off = (unsigned)h * 16u;
+
+    const float mu_p = mu_q[(size_t)b * Nq + i_lane];
+    const float a2 = a_q[(size_t)b * Nq + i_lane] * scale * kLog2e;      // log2-domain factor of this query's logits (> 0)
+
+    f32x16 o[CVB];
+#pragma unroll
+    for (int cb = 0; cb < CVB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    u32x2 vst[2][CVB];
+    auto fetch_v_piece = [&](int i, int j0) {          // plane i & 1, chunk i >> 1
+        const int pl = i & 1, u = i >> 1;
+        const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
+        unsigned off = (unsigned)(row * Nk + j0 + 4 * kq) * 2u;
+        if (row >= Cv || j0 + 4 * kq >= Nk) off = kBufOob;
+        vst[pl][u] = __builtin_amdgcn_raw_buffer_load_b64(pl ? vl_rs : vh_rs, (int)off, 0, 0);
+    };
+    auto commit_v_piece = [&](int i, int buf) {
+        const int pl = i & 1, u = i >> 1;
+        const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
+        const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);   // see corr_fused_fwd_f16x3.hip
+        *reinterpret_cast<u32x2*>(vt + (buf * 3 + pl) * VPLANE + row * BX_VROW + slot) = vst[pl][u];
+        if (pl == 0)
+            *reinterpret_cast<u32x2*>(vt + (buf * 3 + 2) * VPLANE + row * BX_VROW + slot) =
+                u32x2{pk_unshift_f16(vst[0][u].x), pk_unshift_f16(vst[0][u].y)};
+    };
+
+    const int ntiles = Nk / 32;
+    BxTile tl;
+#pragma unroll
+    for (int i = 0; i < 2 * CVB; ++i) fetch_v_piece(i, 0);
+    bx_fetch(tl, gm, 0, ntiles);
+#pragma unroll
+    for (int i = 0; i < 2 * CVB; ++i) commit_v_piece(i, 0);
+#pragma unroll
+    for (int i = 0; i < 2 * CVB; ++i) fetch_v_piece(i, 32);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * 32, buf = t & 1;
+        float tt[16], bq[16], kn[16];
+        bx_logits(tl, mu_p, kc, tt, bq, kn);
+        bx_fetch(tl, gm, t + 1, ntiles);                  // the next tile's blocks have the whole MFMA loop to arrive
+        float tmax = tt[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, tt[r]);
+        tmax = fmaxf(tmax, swap_half(tmax)) * a2;
+        if (__any(tmax > m_run + kBxRescaleThr)) {
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = fast_exp2(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
+#pragma unroll
+            for (int cb = 0; cb < CVB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
+#pragma unroll
+            for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
+        }
+        float p[16];
+        float psum = 0.f;
+        const float nmb = kBxPBias - m_run;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = fast_exp2(__builtin_fmaf(tt[r], a2, nmb));
+            psum += p[r];
+        }
+        l_run += psum;
+        f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                unsigned hw, lw;
+                split_pair_rtz_lo_scaled(p[8 * s + j], p[8 * s + j + 1], hw, lw);
+                const f16x2 a = __builtin_bit_cast(f16x2, hw), bl = __builtin_bit_cast(f16x2, lw);
+                ph[s][j] = a[0]; ph[s][j + 1] = a[1];
+                pl[s][j] = bl[0]; pl[s][j + 1] = bl[1];
+            }
+        // ---- O^T += V . P, the staged V pieces of tile t+1 / t+2 riding between the MFMAs ---------------------------
+        {
+            const _Float16* vbase = vt + buf * 3 * VPLANE + c * BX_VROW + h * 8;
+            constexpr int NS = 2 * CVB;
+            f16x8 a_h[2], a_l[2], a_s[2];
+            a_h[0] = *reinterpret_cast<const f16x8*>(vbase);
+            a_l[0] = *reinterpret_cast<const f16x8*>(vbase + VPLANE);
+            a_s[0] = *reinterpret_cast<const f16x8*>(vbase + 2 * VPLANE);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int s = i / CVB, cb = i % CVB, cur = i & 1, nxt = cur ^ 1;
+                if (i + 1 < NS) {
+                    const int s2 = (i + 1) / CVB, c2 = (i + 1) % CVB;
+                    a_h[nxt] = *reinterpret_cast<const f16x8*>(vbase + c2 * 32 * BX_VROW + s2 * 16);
+                    a_l[nxt] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + c2 * 32 * BX_VROW + s2 * 16);
+                    a_s[nxt] = *reinterpret_cast<const f16x8*>(vbase + 2 * VPLANE + c2 * 32 * BX_VROW + s2 * 16);
+                }
+                o[cb] = bx_mfma(a_h[cur], ph[s], o[cb]);
+                o[cb] = bx_mfma(a_s[cur], pl[s], o[cb]);      // (2^-11 V_hi) . (2^11 P_lo)
+                o[cb] = bx_mfma(a_l[cur], ph[s], o[cb]);
+                commit_v_piece(i, buf ^ 1);
+                fetch_v_piece(i, j0 + 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + swap_half(l_run);
+    const float inv_l = (v_scale ? 1.0f / *v_scale : 1.0f) / l_tot;
+    float* out_b = out + (size_t)b * Cv * Nq;
+#pragma unroll
+    for (int cb = 0; cb < CVB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = cb * 32 + acc_row_base(r) + 4 * h;
+            if (ch < Cv) out_b[(size_t)ch * Nq + i_lane] = o[cb][r] * inv_l;
+        }
+    if (h == 0) lse[(size_t)b * Nq + i_lane] = (m_run + log2f(l_tot) - kBxPBias) * kLn2;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K19 backward
+// ---------------------------------------------------------------------------------------------------------
+// Column sums of a 32 x 32 accumulator image over its 32 query lanes, for two quantities at once: a reduce-scatter
+// butterfly over lane bits 0..3 (16 -> 8 -> 4 -> 2 -> 1 registers per lane), then one exchange across the two rows of
+// 16.  Afterwards lane c (both c and c ^ 16) holds the sum of register r(c) = 8 b0 + 4 b1 + 2 b2 + b3 (b_k = bit k of c).
+// Exchange with lane c ^ MASK inside a row of 16 lanes, on the DPP path (no LDS crossbar, no address register): 1, 2 are
+// quad permutations; 4 = row_half_mirror (c ^ 7) followed by the quad reversal (c ^ 3); 8 = a row rotation by 8.
+template <int MASK>
+__device__ __forceinline__ float bx_xchg(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    if (MASK == 1) r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);            // quad_perm [1,0,3,2]
+    else if (MASK == 2) r = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);       // quad_perm [2,3,0,1]
+    else if (MASK == 4)
+        r = __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false), 0x1B, 0xf, 0xf, false);
+    else r = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);                     // row_ror:8
+    return __builtin_bit_cast(float, r);
+}
+template <int N, int MASK>
+__device__ __forceinline__ void bx_fold(float (&x)[16], int c) {
+    const bool up = (c & MASK) != 0;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        const float keep = up ? x[i + N / 2] : x[i];
+        const float send = up ? x[i] : x[i + N / 2];
+        x[i] = keep + bx_xchg<MASK>(send);
+    }
+}
+__device__ __forceinline__ float bx_colsum(float (&x)[16], int c) {
+    bx_fold<16, 1>(x, c);
+    bx_fold<8, 2>(x, c);
+    bx_fold<4, 4>(x, c);
+    bx_fold<2, 8>(x, c);
+    return x[0] + __shfl_xor(x[0], 16, 64);
+}
+
+template <int CVB, bool STORE_P>
+__global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
+    const float* __restrict__ T, const float* __restrict__ mu_q, const float* __restrict__ a_q,
+    const float* __restrict__ nu_k, const float* __restrict__ b_k,
+    const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] position-major planes of s_v*v
+    const _Float16* __restrict__ gph, const _Float16* __restrict__ gpl,   // [B,Nq,CVP] planes of s_o*dout
+    const float* __restrict__ g_scale, const float* __restrict__ v_scale,
+    const float* __restrict__ outp, const float* __restrict__ dout,        // [B,Cv,Nq] fp32 (for D)
+    const float* __restrict__ lse,
+    float* __restrict__ G,                                                 // out, tile-blocked like T
+    float* __restrict__ dmu, float* __restrict__ da,                       // out [B,Nq]
+    float* __restrict__ colpart,                                           // out [B][Nq/128][2][Nk]
+    float* __restrict__ gmax,                                              // in/out: max|G| (atomic max on the bit pattern)
+    _Float16* __restrict__ psh, _Float16* __restrict__ psl,                // out (STORE_P): planes of 2^14 P, blocked
+    int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale) {
+    constexpr int CVP = CVB * 32, CVS = CVP / 16, VROW = CVP + 8, VPLANE = 32 * VROW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
+    _Float16* const vt = reinterpret_cast<_Float16*>(bx_smem);          // [2 buf][hi|lo][32 keys][VROW]
+    float* const colbuf = reinterpret_cast<float*>(vt + 2 * 2 * VPLANE);   // [2 buf][2 quantities][32 keys]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int nqb = Nq / 128;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = vb / nqb, wg = vb % nqb, q0 = wg * 128;
+    const int i_lane = q0 + wave * 32 + c;
+
+    const size_t vbytes = (size_t)Nk * CVP * 2, gbytes = (size_t)Nq * CVP * 2;
+    const __amdgpu_buffer_rsrc_t vh_rs = make_rsrc(vph + (size_t)b * Nk * CVP, vbytes);
+    const __amdgpu_buffer_rsrc_t vl_rs = make_rsrc(vpl + (size_t)b * Nk * CVP, vbytes);
+    const __amdgpu_buffer_rsrc_t gh_rs = make_rsrc(gph + (size_t)b * Nq * CVP, gbytes);
+    const __amdgpu_buffer_rsrc_t gl_rs = make_rsrc(gpl + (size_t)b * Nq * CVP, gbytes);
+    const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(outp + (size_t)b * Cv * Nq, (size_t)Cv * Nq * 4);
+    const __amdgpu_buffer_rsrc_t go_rs = make_rsrc(dout + (size_t)b * Cv * Nq, (size_t)Cv * Nq * 4);
+    const __amdgpu_buffer_rsrc_t G_rs = make_rsrc(G + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
+    const __amdgpu_buffer_rsrc_t ph_rs = make_rsrc(STORE_P ? psh + (size_t)b * Nk * Nq : nullptr, STORE_P ? (size_t)Nk * Nq * 2 : 0);
+    const __amdgpu_buffer_rsrc_t pl_rs = make_rsrc(STORE_P ? psl + (size_t)b * Nk * Nq : nullptr, STORE_P ? (size_t)Nk * Nq * 2 : 0);
+    BxGeom gm;
+    gm.t_rs = make_rsrc(T + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
+    gm.b_rs = make_rsrc(b_k + (size_t)b * Nk, (size_t)Nk * 4);
+    gm.nu_rs = make_rsrc(nu_k + (size_t)b * Nk, (size_t)Nk * 4);
+    gm.tpr = wimg / 32;
+    gm.qblk = (q0 >> 5) + wave;
+    gm.py = gm.qblk / gm.tpr;
+    gm.himg = himg;
+    gm.nqblk = Nq >> 5;
+    gm.lane_off = (unsigned)lane * 16u;
+    gm.stat_off = (unsigned)h * 16u;
+
+    const float mu_p = mu_q[(size_t)b * Nq + i_lane];
+    const float a_p = a_q[(size_t)b * Nq + i_lane];
+    const float a_n = a_p * scale;                     // natural-domain factor: z = tt * a_n
+    const float a2 = a_n * kLog2e;
+    const float am = a_n * mu_p;
+
+    const float s_o = *g_scale * (v_scale ? *v_scale : 1.0f);      // scale of dP' = V' . dO'
+    f16x8 goh[CVS], gol[CVS];
+    {
+        const unsigned off = (unsigned)(i_lane * CVP + h * 8) * 2u;
+#pragma unroll
+        for (int u = 0; u < CVS; ++u) {
+            goh[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(gh_rs, (int)(off + u * 32u), 0, 0));
+            gol[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(gl_rs, (int)(off + u * 32u), 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < CVS; ++u) {
+            asm volatile("" : "+a"(goh[u]));
+            asm volatile("" : "+a"(gol[u]));
+        }
+    }
+    float d_lane;
+    {
+        double dacc = 0.0;
+        for (int ch = h; ch < Cv; ch += 2) {
+            const unsigned off = (unsigned)(ch * Nq + i_lane) * 4u;
+            dacc += (double)buf_load1(go_rs, off) * (double)buf_load1(o_rs, off);
+        }
+        const int lo = __shfl_xor((int)__double2loint(dacc), 32, 64);
+        const int hi = __shfl_xor((int)__double2hiint(dacc), 32, 64);
+        d_lane = (float)((dacc + __hiloint2double(hi, lo)) * (double)s_o);
+    }
+    const float lse2 = lse[(size_t)b * Nq + i_lane] * kLog2e;
+    const float undo = 1.0f / s_o;
+
+    constexpr int VCH = 32 * CVP / 8, VPT = (VCH + 255) / 256;
+    u32x4 vst[2][VPT];
+    auto fetch_v_piece = [&](int i, int j0) {
+        const int pl = i & 1, u = i >> 1;
+        const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
+        vst[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(
+            pl ? vl_rs : vh_rs, (int)(g < VCH ? (unsigned)((j0 + key) * CVP + cc * 8) * 2u : kBufOob), 0, 0);
+    };
+    auto commit_v_piece = [&](int i, int buf) {
+        const int pl = i & 1, u = i >> 1;
+        const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
+        if (g < VCH) *reinterpret_cast<u32x4*>(vt + (buf * 2 + pl) * VPLANE + key * VROW + cc * 8) = vst[pl][u];
+    };
+    // flush of one tile's column sums: [quantity][32 keys] of this workgroup's 128 queries -> colpart, then re-zero
+    float* const cp_b = colpart + ((size_t)b * nqb + wg) * 2 * Nk;
+    auto flush_cols = [&](int t) {
+        if (tid < 64) {
+            float* cell = colbuf + (t & 1) * 64 + tid;
+            cp_b[(size_t)(tid >> 5) * Nk + t * 32 + (tid & 31)] = *cell;
+            *cell = 0.f;
+        }
+    };
+
+    const int ntiles = Nk / 32;
+    if (tid < 128) colbuf[tid] = 0.f;
+    BxTile tl;
+#pragma unroll
+    for (int i = 0; i < 2 * VPT; ++i) fetch_v_piece(i, 0);
+    bx_fetch(tl, gm, 0, ntiles);
+#pragma unroll
+    for (int i = 0; i < 2 * VPT; ++i) commit_v_piece(i, 0);
+#pragma unroll
+    for (int i = 0; i < 2 * VPT; ++i) fetch_v_piece(i, 32);
+    __syncthreads();
+
+    float r2 = 0.f, rm = 0.f, gabs = 0.f;
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * 32, buf = t & 1;
+        if (t > 0) flush_cols(t - 1);                     // (behind the barrier that ended tile t-1)
+        float tt[16], bq[16], kn[16];
+        bx_logits(tl, mu_p, kc, tt, bq, kn);
+        bx_fetch(tl, gm, t + 1, ntiles);
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = fast_exp2(__builtin_fmaf(tt[r], a2, -lse2));
+
+        // ---- dP' = V(t) . dO' ---------------------------------------------------------------------------------------
+        f32x16 dp0, dp1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dp0[r] = 0.f; dp1[r] = 0.f; }
+        {
+            const _Float16* vb0 = vt + buf * 2 * VPLANE + c * VROW + h * 8;
+            f16x8 ah[2], al[2];
+            ah[0] = *reinterpret_cast<const f16x8*>(vb0);
+            al[0] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE);
+#pragma unroll
+            for (int u = 0; u < CVS; ++u) {
+                const int cur = u & 1, nxt = cur ^ 1;
+                if (u + 1 < CVS) {
+                    ah[nxt] = *reinterpret_cast<const f16x8*>(vb0 + (u + 1) * 16);
+                    al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
+                }
+                dp0 = bx_mfma(ah[cur], goh[u], dp0);
+                dp1 = bx_mfma(ah[cur], gol[u], dp1);
+                dp1 = bx_mfma(al[cur], goh[u], dp1);
+                if (u < 2 * VPT) {
+                    commit_v_piece(u, buf ^ 1);
+                    fetch_v_piece(u, j0 + 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        static_assert(2 * VPT <= CVS, "staging pieces must fit the dP steps");
+
+        // ---- L = P (dP - D); G = L * a_n * b_q; row sums in registers, column sums through the butterfly -----------------
+        float x1[16], x2[16];
+        f32x4 gout[4];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float L = p[r] * ((dp0[r] + dp1[r]) - d_lane) * undo;
+            const float z = tt[r] * a_n;
+            const float gv = L * a_n * bq[r];
+            gout[r >> 2][r & 3] = gv;
+            gabs = fmaxf(gabs, fabsf(gv));
+            x1[r] = L * z;
+            x2[r] = L * am;
+            r2 += x1[r];
+            rm = __builtin_fmaf(L, kn[r], rm);
+        }
+        {
+            const unsigned blk = (unsigned)((t * gm.nqblk + gm.qblk) * 4096);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gout[g]), G_rs, (int)gm.lane_off,
+                                                       (int)(blk + (unsigned)g * 1024u), 0);
+        }
+        if (STORE_P) {
+            // planes of 2^14 P in the accumulator's own orientation: [Nq/32][Nk/32] blocks of 2 x [32 queries][16 keys]
+            // (corr_fused_bwd_f16x3.hip, store_regs_blk; read by hgemm_f16x3 with b_blocked = 2)
+            unsigned hw[8], lw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                split_pair_rtz(p[2 * j] * kBxPPlaneScale, p[2 * j + 1] * kBxPPlaneScale, hw[j], lw[j]);
+            const unsigned blk = (unsigned)((gm.qblk * (Nk >> 5) + t) * 2048);
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int m0 = 2 * pp, m1 = 2 * pp + 1;
+                u32x4 xh, xl;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const auto sh = __builtin_amdgcn_permlane32_swap(hw[2 * m0 + i], hw[2 * m1 + i], false, false);
+                    const auto sl = __builtin_amdgcn_permlane32_swap(lw[2 * m0 + i], lw[2 * m1 + i], false, false);
+                    xh[i] = sh[0]; xh[2 + i] = sh[1];
+                    xl[i] = sl[0]; xl[2 + i] = sl[1];
+                }
+                const unsigned off = blk + (unsigned)(pp * 1024 + c * 32 + h * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(xh, ph_rs, (int)off, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(xl, pl_rs, (int)off, 0, 2);
+            }
+        }
+        {
+            const float c2 = bx_colsum(x1, c);
+            const float cm = bx_colsum(x2, c);
+            if (c < 16) {
+                const int r = 8 * (c & 1) + 4 * ((c >> 1) & 1) + 2 * ((c >> 2) & 1) + ((c >> 3) & 1);
+                const int kk = acc_row_base(r) + 4 * h;
+                atomicAdd(colbuf + buf * 64 + kk, c2);
+                atomicAdd(colbuf + buf * 64 + 32 + kk, cm);
+            }
+        }
+        __syncthreads();
+    }
+    flush_cols(ntiles - 1);
+
+    r2 += swap_half(r2);
+    rm += swap_half(rm);
+    if (h == 0) {
+        da[(size_t)b * Nq + i_lane] = r2 / a_p;
+        dmu[(size_t)b * Nq + i_lane] = -a_n * rm;
+    }
+    gabs = wave_max_dpp(gabs);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(gmax), __builtin_bit_cast(unsigned, gabs));   // >= 0: ordered as integers
+}
+
+// d nu[b,q] = -kc * b_q * sum_wg colpart[b,wg,1,q];   d b[b,q] = sum_wg colpart[b,wg,0,q] / b_q
+__global__ void box3_col_reduce_kernel(const float* __restrict__ colpart, const float* __restrict__ b_k,
+                                       float* __restrict__ dnu, float* __restrict__ db, int B, int nwg, int Nk, float kc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Nk) return;
+    const int b = i / Nk, q = i % Nk;
+    float c2 = 0.f, cm = 0.f;
+    for (int w = 0; w < nwg; ++w) {
+        const float* p = colpart + ((size_t)b * nwg + w) * 2 * Nk;
+        c2 += p[q];
+        cm += p[Nk + q];
+    }
+    const float bq = b_k[i];
+    dnu[i] = -kc * bq * cm;
+    db[i] = c2 / bq;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K20: dC = xbox(ybox(G)) -> f16 hi/lo planes in the [Nq/32][Nk/32] blocks of 2 x [32 queries][16 keys] both
+// correlation-gradient GEMMs read (hgemm_f16x3.hip modes 2 and 3).  One wave per (key image row, query image row).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void box3_adjoint_planes_kernel(const float* __restrict__ G,
+                                                                     const float* __restrict__ gmax,
+                                                                     _Float16* __restrict__ dch, _Float16* __restrict__ dcl,
+                                                                     float* __restrict__ scale_out, int B, int Nq, int Nk,
+                                                                     int himg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    float* const img = reinterpret_cast<float*>(bx_smem) + wave * kXbFloats;
+    xbox_zero_border(img, lane);
+
+    const int grp = blockIdx.x * 4 + wave;                     // (b, ky, py)
+    const int per = himg * himg;
+    const int b = grp / per, ky = (grp % per) / himg, py = grp % himg;
+    if (b >= B) return;
+    const int nqblk = Nq >> 5;
+    const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(G + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
+    const __amdgpu_buffer_rsrc_t h_rs = make_rsrc(dch + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 2);
+    const __amdgpu_buffer_rsrc_t l_rs = make_rsrc(dcl + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 2);
+
+    // power-of-two scale: max|G| -> [2^6, 2^7), so |dC| <= 9 max|G| stays below 2^11
+    float s = 1.0f;
+    {
+        const float m = *gmax;
+        if (m > 0.f && m < INFINITY) {
+            int e;
+            frexpf(m, &e);
+            s = ldexpf(1.0f, min(max(7 - e, -100), 100));
+        }
+        if (blockIdx.x == 0 && tid == 0) *scale_out = s;
+    }
+
+    f32x16 t[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[kt][qt][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int dy = d - 1;
+        const bool ok = (unsigned)(py + dy) < (unsigned)himg && (unsigned)(ky + dy) < (unsigned)himg;
+        f32x4 ld[2][2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int blk = ok ? ((ky + dy) * 2 + kt) * nqblk + (py + dy) * 2 + qt : 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    ld[kt][qt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        g_rs, (int)(ok ? (unsigned)lane * 16u : kBufOob), (int)((unsigned)blk * 4096u + (unsigned)g * 1024u), 0));
+            }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[kt][qt][r] += ld[kt][qt][r >> 2][r & 3];
+    }
+    xbox_64x64(t, img, lane);
+
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            unsigned hw[8], lw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) split_pair_rtz(t[kt][qt][2 * j] * s, t[kt][qt][2 * j + 1] * s, hw[j], lw[j]);
+            const unsigned blk = (unsigned)(((py * 2 + qt) * (Nk >> 5) + ky * 2 + kt) * 2048);
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int m0 = 2 * pp, m1 = 2 * pp + 1;
+                u32x4 xh, xl;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const auto sh = __builtin_amdgcn_permlane32_swap(hw[2 * m0 + i], hw[2 * m1 + i], false, false);
+                    const auto sl = __builtin_amdgcn_permlane32_swap(lw[2 * m0 + i], lw[2 * m1 + i], false, false);
+                    xh[i] = sh[0]; xh[2 + i] = sh[1];
+                    xl[i] = sl[0]; xl[2 + i] = sl[1];
+                }
+                const unsigned off = blk + (unsigned)(pp * 1024 + c * 32 + h * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(xh, h_rs, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(xl, l_rs, (int)off, 0, 0);
+            }
+        }
+}
+
+template <int CVB>
+static int bx_fwd_launch(const float* T, const float* mu, const float* a, const float* nu, const float* bk,
+                         const _Float16* vh, const _Float16* vl, float* out, float* lse, const float* vs, int B, int Nq,
+                         int Nk, int Cv, int himg, int wimg, float kc, float scale, hipStream_t s) {
+    const size_t smem = (size_t)2 * 3 * CVB * 32 * BX_VROW * sizeof(_Float16);
+    auto kern = box3_sw_fwd_kernel<CVB>;
+    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(B * (Nq / 128)), dim3(256), smem, s, T, mu, a, nu, bk, vh, vl, out, lse, vs, B, Nq, Nk,
+                       Cv, himg, wimg, kc, scale);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+template <int CVB>
+static int bx_bwd_launch(const float* T, const float* mu, const float* a, const float* nu, const float* bk,
+                         const _Float16* vph, const _Float16* vpl, const _Float16* gph, const _Float16* gpl,
+                         const float* gs, const float* vs, const float* outp, const float* dout, const float* lse, float* G,
+                         float* dmu, float* da, float* colpart, float* gmax, _Float16* psh, _Float16* psl, int B, int Nq,
+                         int Nk, int Cv, int himg, int wimg, float kc, float scale, hipStream_t s) {
+    const size_t smem = (size_t)2 * 2 * 32 * (CVB * 32 + 8) * sizeof(_Float16) + 128 * sizeof(float);
+#define COCOS_BX_GO(SP)                                                                                                  \
+    do {                                                                                                                 \
+        auto kern = box3_sw_bwd_kernel<CVB, SP>;                                                                         \
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(kern, dim3(B * (Nq / 128)), dim3(256), smem, s, T, mu, a, nu, bk, vph, vpl, gph, gpl, gs, vs, outp, \
+                           dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, Nk, Cv, himg, wimg, kc, scale);        \
+    } while (0)
+    if (psh) COCOS_BX_GO(true); else COCOS_BX_GO(false);
+#undef COCOS_BX_GO
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+static bool bx_shape_ok(int Nq, int Nk, int Cv, int himg, int wimg) {
+    return himg >= 1 && wimg == 64 && Nq == himg * wimg && Nk == Nq && Nq % 256 == 0 && Cv >= 1 && Cv <= 160 &&
+           (size_t)Nq * Nk * 4 < 0x7fffffffull;
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_box3_fused_supported(int Nq, int Nk, int Cv, int grid_h, int grid_w) {
+    return cocos::bx_shape_ok(Nq, Nk, Cv, grid_h, grid_w) ? 1 : 0;
+}
+
+extern "C" int cocos_box3_softmax_warp_fwd_f16x3(const float* t_blocked, const float* mu_q, const float* a_q,
+                                                 const float* nu_k, const float* b_k, const void* vh, const void* vl,
+                                                 float* out, float* lse, const float* v_scale_dev, int B, int Nq, int Nk,
+                                                 int Cv, int grid_h, int grid_w, float k_unfolded, float scale,
+                                                 cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(t_blocked && mu_q && a_q && nu_k && b_k && vh && vl && out && lse, COCOS_ERR_INVALID,
+                  "box3_softmax_warp_fwd_f16x3: null pointer");
+    COCOS_REQUIRE(B >= 1 && scale > 0.f, COCOS_ERR_INVALID, "box3_softmax_warp_fwd_f16x3: bad B=%d / scale", B);
+    COCOS_REQUIRE(bx_shape_ok(Nq, Nk, Cv, grid_h, grid_w), COCOS_ERR_UNSUPPORTED,
+                  "box3_softmax_warp_fwd_f16x3: needs a 64-wide grid with Nq == Nk == h*w, Nq %% 256 == 0, Cv <= 160 "
+                  "(Nq=%d Nk=%d Cv=%d grid %dx%d)", Nq, Nk, Cv, grid_h, grid_w);
+    COCOS_REQUIRE(aligned16(t_blocked) && aligned16(nu_k) && aligned16(b_k), COCOS_ERR_INVALID,
+                  "box3_softmax_warp_fwd_f16x3: T / nu / b must be 16-byte aligned");
+    for (const void* p : {vh, vl})
+        COCOS_REQUIRE((reinterpret_cast<uintptr_t>(p) & 7u) == 0, COCOS_ERR_INVALID,
+                      "box3_softmax_warp_fwd_f16x3: v planes must be 8-byte aligned");
+    const _Float16 *a = static_cast<const _Float16*>(vh), *b2 = static_cast<const _Float16*>(vl);
+    hipStream_t s = as_stream(stream);
+#define COCOS_ARGS t_blocked, mu_q, a_q, nu_k, b_k, a, b2, out, lse, v_scale_dev, B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, s
+    switch ((Cv + 31) / 32) {
+        case 1: return bx_fwd_launch<1>(COCOS_ARGS);
+        case 2: return bx_fwd_launch<2>(COCOS_ARGS);
+        case 3: return bx_fwd_launch<3>(COCOS_ARGS);
+        case 4: return bx_fwd_launch<4>(COCOS_ARGS);
+        default: return bx_fwd_launch<5>(COCOS_ARGS);
+    }
+#undef COCOS_ARGS
+}
+
+extern "C" size_t cocos_box3_softmax_warp_bwd_colpart_bytes(int B, int Nq, int Nk) {
+    if (B < 1 || Nq < 128 || Nk < 1) return 0;
+    return (size_t)B * (Nq / 128) * 2 * Nk * sizeof(float);
+}
+
+extern "C" int cocos_box3_softmax_warp_bwd_f16x3(
+    const float* t_blocked, const float* mu_q, const float* a_q, const float* nu_k, const float* b_k, const void* vph,
+    const void* vpl, const void* gph, const void* gpl, const float* g_scale_dev, const float* v_scale_dev, const float* out,
+    const float* dout, const float* lse, float* g_blocked, float* dmu, float* da, float* dnu, float* db, void* colpart,
+    float* gmax_dev, void* psh, void* psl, int B, int Nq, int Nk, int Cv, int CvPad, int grid_h, int grid_w,
+    float k_unfolded, float scale, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(t_blocked && mu_q && a_q && nu_k && b_k && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse &&
+                      g_blocked && dmu && da && dnu && db && colpart && gmax_dev,
+                  COCOS_ERR_INVALID, "box3_softmax_warp_bwd_f16x3: null pointer");
+    COCOS_REQUIRE((psh == nullptr) == (psl == nullptr), COCOS_ERR_INVALID,
+                  "box3_softmax_warp_bwd_f16x3: P plane pointers come as a hi/lo pair");
+    COCOS_REQUIRE(B >= 1 && scale > 0.f, COCOS_ERR_INVALID, "box3_softmax_warp_bwd_f16x3: bad B=%d / scale", B);
+    COCOS_REQUIRE(bx_shape_ok(Nq, Nk, Cv, grid_h, grid_w), COCOS_ERR_UNSUPPORTED,
+                  "box3_softmax_warp_bwd_f16x3: needs a 64-wide grid with Nq == Nk == h*w, Nq %% 256 == 0, Cv <= 160 "
+                  "(Nq=%d Nk=%d Cv=%d grid %dx%d)", Nq, Nk, Cv, grid_h, grid_w);
+    const int cvb = (Cv + 31) / 32;
+    COCOS_REQUIRE(CvPad == cvb * 32, COCOS_ERR_INVALID, "box3_softmax_warp_bwd_f16x3: CvPad=%d, expected %d", CvPad, cvb * 32);
+    for (const void* p : {(const void*)t_blocked, (const void*)g_blocked, vph, vpl, gph, gpl, (const void*)nu_k, (const void*)b_k})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "box3_softmax_warp_bwd_f16x3: planes, T, G, nu, b must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+#define COCOS_ARGS                                                                                                       \
+    t_blocked, mu_q, a_q, nu_k, b_k, static_cast<const _Float16*>(vph), static_cast<const _Float16*>(vpl),               \
+        static_cast<const _Float16*>(gph), static_cast<const _Float16*>(gpl), g_scale_dev, v_scale_dev, out, dout, lse,   \
+        g_blocked, dmu, da, static_cast<float*>(colpart), gmax_dev, static_cast<_Float16*>(psh),                         \
+        static_cast<_Float16*>(psl), B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, s
+    int rc;
+    switch (cvb) {
+        case 1: rc = bx_bwd_launch<1>(COCOS_ARGS); break;
+        case 2: rc = bx_bwd_launch<2>(COCOS_ARGS); break;
+        case 3: rc = bx_bwd_launch<3>(COCOS_ARGS); break;
+        case 4: rc = bx_bwd_launch<4>(COCOS_ARGS); break;
+        default: rc = bx_bwd_launch<5>(COCOS_ARGS); break;
+    }
+#undef COCOS_ARGS
+    if (rc != COCOS_OK) return rc;
+    const int n = B * Nk;
+    hipLaunchKernelGGL(box3_col_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, static_cast<const float*>(colpart),
+                       b_k, dnu, db, B, Nq / 128, Nk, k_unfolded);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_box3_adjoint_planes_f16x3(const float* g_blocked, const float* gmax_dev, void* dc_hi, void* dc_lo,
+                                               float* scale_out_dev, int B, int Nq, int Nk, int grid_h, int grid_w,
+                                               cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(g_blocked && gmax_dev && dc_hi && dc_lo && scale_out_dev, COCOS_ERR_INVALID,
+                  "box3_adjoint_planes_f16x3: null pointer");
+    COCOS_REQUIRE(B >= 1 && bx_shape_ok(Nq, Nk, 1, grid_h, grid_w), COCOS_ERR_UNSUPPORTED,
+                  "box3_adjoint_planes_f16x3: needs a 64-wide grid with Nq == Nk == h*w, Nq %% 256 == 0 (Nq=%d Nk=%d grid %dx%d)",
+                  Nq, Nk, grid_h, grid_w);
+    for (const void* p : {(const void*)g_blocked, (const void*)dc_hi, (const void*)dc_lo})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "box3_adjoint_planes_f16x3: pointers must be 16-byte aligned");
+    const long long groups = (long long)B * grid_h * grid_h;
+    const size_t smem = (size_t)4 * kXbFloats * sizeof(float);
+    auto kern = box3_adjoint_planes_kernel;
+    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((groups + 3) / 4)), dim3(256), smem, as_stream(stream), g_blocked, gmax_dev,
+                       static_cast<_Float16*>(dc_hi), static_cast<_Float16*>(dc_lo), scale_out_dev, B, Nq, Nk, grid_h);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}

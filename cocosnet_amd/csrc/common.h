@@ -62,6 +62,29 @@ __device__ __forceinline__ void split_pair_rtz(float a, float b, unsigned& hi, u
     lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
 
+// The same split for softmax probabilities, with the lo plane carried at 2^11 times its value (kLoShift): p = hi +
+// lo' * 2^-11.  Plain `lo = p - hi` lives 11 binades below hi, i.e. in f16's SUBNORMAL range for every p below 2^-3 —
+// a probability 1e-7 of its row maximum kept ~8 bits (round-3 finding: warp_mask entries in [1e-9, 1e-6) were off by up
+// to 30 %, tools/precision_check.py).  Scaled, lo' is a normal f16 whenever hi is, and still carries 11 bits below hi's
+// own subnormal grid: >= 22 bits down to p = 2^-14, >= 11 bits down to 2^-24.  The consumer multiplies lo' with a copy
+// of the OTHER operand's hi plane scaled by 2^-11 (exact: a power of two), so nothing is undone afterwards.
+constexpr float kLoShift = 2048.0f;
+constexpr float kLoUnshift = 1.0f / 2048.0f;
+__device__ __forceinline__ void split_pair_rtz_lo_scaled(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(hi));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(hi));
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra * kLoShift, rb * kLoShift));
+}
+// four packed f16 values times 2^-11 (two v_pk_mul_f16): the scaled hi-plane copy described above
+__device__ __forceinline__ unsigned pk_unshift_f16(unsigned v) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 x = __builtin_bit_cast(h2, v);
+    x *= (_Float16)kLoUnshift;
+    return __builtin_bit_cast(unsigned, x);
+}
+
 // max over the 64 lanes of a wave, result in every lane: DPP inside the rows of 16, read-lane across the four rows
 // (no LDS traffic, ~12 instructions)
 __device__ __forceinline__ float wave_max_dpp(float v) {

@@ -71,10 +71,11 @@ __device__ __forceinline__ u32x2 buf_load_u2s(__amdgpu_buffer_rsrc_t r, unsigned
     return __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, (int)soff, 0);
 }
 
-// p (>= 0, <= 2^8) -> f16 hi (round toward zero, so lo >= 0) and f16 lo, two values per instruction
+// p (>= 0, <= 2^15) -> f16 hi (round toward zero, so lo >= 0) and f16 lo' = 2^11 * (p - hi), two values per
+// instruction (common.h: split_pair_rtz_lo_scaled; the V_hi * P_lo term reads the 2^-11-scaled copy of V's hi plane)
 __device__ __forceinline__ void split_pair(float a, float b, f16x2& hi, f16x2& lo) {
     unsigned h, l;
-    split_pair_rtz(a, b, h, l);
+    split_pair_rtz_lo_scaled(a, b, h, l);
     hi = __builtin_bit_cast(f16x2, h);
     lo = __builtin_bit_cast(f16x2, l);
 }
@@ -110,7 +111,7 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
     constexpr int VPLANE = CVP * SP_VROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* const kt = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][32 keys][KROW]
-    _Float16* const vt = kt + 2 * 2 * KPLANE;                      // [2 buf][hi|lo][CVP][VROW]
+    _Float16* const vt = kt + 2 * 2 * KPLANE;                      // [2 buf][hi|lo|hi*2^-11][CVP][VROW]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -162,6 +163,8 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
     // the thread that stages the last row of the padded V tile writes ones into its hi plane (see header)
     const bool ones_thread = tid >= 248;
     const u32x2 kOnes2 = u32x2{0x3C003C00u, 0x3C003C00u};
+    const u32x2 kOnesS2 = u32x2{0x10001000u, 0x10001000u};      // ... and 2^-11 into the scaled copy of the hi plane
+    auto unshift2 = [](u32x2 v) { return u32x2{pk_unshift_f16(v.x), pk_unshift_f16(v.y)}; };
 
     // ---- staging: global -> registers (in flight under the MFMAs of the previous tile) -> LDS -------
     // K: 32 keys x 512 B per plane = 1024 16-byte chunks, 4 per thread; a key row is contiguous in HBM.
@@ -198,14 +201,16 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
         }
     };
     auto commit_v = [&](int buf) {
-        _Float16* base = vt + buf * 2 * VPLANE;
+        _Float16* base = vt + buf * 3 * VPLANE;
 #pragma unroll
         for (int u = 0; u < CVB; ++u) {
             const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
             // keys 4kq..4kq+3 -> k-slots of the P.V MFMA (see header): step kq>>2, half kq&1, quad (kq>>1)&1
             const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);
-            *reinterpret_cast<u32x2*>(base + row * SP_VROW + slot) = (u == CVB - 1 && ones_thread) ? kOnes2 : vst[0][u];
+            const bool ones = u == CVB - 1 && ones_thread;
+            *reinterpret_cast<u32x2*>(base + row * SP_VROW + slot) = ones ? kOnes2 : vst[0][u];
             *reinterpret_cast<u32x2*>(base + VPLANE + row * SP_VROW + slot) = vst[1][u];
+            *reinterpret_cast<u32x2*>(base + 2 * VPLANE + row * SP_VROW + slot) = ones ? kOnesS2 : unshift2(vst[0][u]);
         }
     };
 
@@ -284,7 +289,7 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
         const int j0 = t * SP_BK, buf = t & 1;
         const bool ragged = RAGGED && (j0 + SP_BK > Nk);
         _Float16* const kw = kt + (buf ^ 1) * 2 * KPLANE;
-        _Float16* const vw = vt + (buf ^ 1) * 2 * VPLANE;
+        _Float16* const vw = vt + (buf ^ 1) * 3 * VPLANE;
         const int jn = j0 + 2 * SP_BK;
         // One staged piece of tile t+1 to the other LDS buffer, and its register immediately takes the load for tile
         // t+2 — memory instructions are never issued as a burst.  i < 8: key-tile pieces (plane i & 1, chunk i >> 1),
@@ -301,8 +306,9 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
                 } else if (i - 8 < 2 * CVB) {
                     const int pl_ = (i - 8) & 1, u = (i - 8) >> 1;
                     if ((PLO0 || (COCOS_ABLATE & 512)) && pl_ == 1 && u >= 1) return;
-                    *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + v_lds[u]) =
-                        (pl_ == 0 && u == CVB - 1 && ones_thread) ? kOnes2 : vst[pl_][u];
+                    const bool ones = pl_ == 0 && u == CVB - 1 && ones_thread;
+                    *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + v_lds[u]) = ones ? kOnes2 : vst[pl_][u];
+                    if (pl_ == 0) *reinterpret_cast<u32x2*>(vw + 2 * VPLANE + v_lds[u]) = ones ? kOnesS2 : unshift2(vst[0][u]);
                     vst[pl_][u] = buf_load_u2s(pl_ ? vl_rs : vh_rs, v_voff[u], (unsigned)jc * 2u);
                 }
                 return;
@@ -317,8 +323,9 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
                 if (PLO0 && pl_ == 1 && u >= 1) return;
                 const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
                 const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);
-                *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + row * SP_VROW + slot) =
-                    (pl_ == 0 && u == CVB - 1 && ones_thread) ? kOnes2 : vst[pl_][u];
+                const bool ones = pl_ == 0 && u == CVB - 1 && ones_thread;
+                *reinterpret_cast<u32x2*>(vw + pl_ * VPLANE + row * SP_VROW + slot) = ones ? kOnes2 : vst[pl_][u];
+                if (pl_ == 0) *reinterpret_cast<u32x2*>(vw + 2 * VPLANE + row * SP_VROW + slot) = ones ? kOnesS2 : unshift2(vst[0][u]);
                 unsigned off = (unsigned)(row * Nk + jn + 4 * kq) * 2u;
                 if (row >= Cv || jn + 4 * kq >= Nk) off = kBufOob;
                 vst[pl_][u] = buf_load_u2(pl_ ? vl_rs : vh_rs, off);
@@ -353,12 +360,13 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
         FPH_T(tp2);
         // ---- the P.V loop's first value fragments: their latency hides under the softmax arithmetic ------------------
         constexpr int NSV = 2 * CVB;                          // P.V step i = tt * CVB + cb
-        f16x8 a_h[RA], a_l[RA];
-        const _Float16* vbase = vt + buf * 2 * VPLANE + c * SP_VROW + h * 8;
+        f16x8 a_h[RA], a_l[RA], a_s[RA];                      // hi, lo and hi * 2^-11 fragments of the value tile
+        const _Float16* vbase = vt + buf * 3 * VPLANE + c * SP_VROW + h * 8;
 #pragma unroll
         for (int i = 0; i < RA - 1 && i < NSV; ++i) {
             a_h[i] = *reinterpret_cast<const f16x8*>(vbase + (i % CVB) * 32 * SP_VROW + (i / CVB) * 16);
             a_l[i] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + (i % CVB) * 32 * SP_VROW + (i / CVB) * 16);
+            a_s[i] = *reinterpret_cast<const f16x8*>(vbase + 2 * VPLANE + (i % CVB) * 32 * SP_VROW + (i / CVB) * 16);
         }
         // ---- online softmax (log2 domain), lazy rescale as in the fp32 kernel -------------------------
         // The row maximum is taken on the raw accumulator (scale_log2 > 0) and scaled once; the exponent is one
@@ -428,11 +436,12 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
                 const int tt = i / CVB, cb = i % CVB, cur = i % RA, n = i + RA - 1;
                 if (!(COCOS_ABLATE & 2) && n < NSV) {
                     a_h[n % RA] = *reinterpret_cast<const f16x8*>(vbase + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
+                    a_s[n % RA] = *reinterpret_cast<const f16x8*>(vbase + 2 * VPLANE + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
                     if (!SKIPLO || (n % CVB) == 0)
                         a_l[n % RA] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + (n % CVB) * 32 * SP_VROW + (n / CVB) * 16);
                 }
                 o[cb] = mfma16h(a_h[cur], ph[tt], o[cb]);
-                o[cb] = mfma16h(a_h[cur], pl[tt], o[cb]);
+                o[cb] = mfma16h(a_s[cur], pl[tt], o[cb]);      // (2^-11 V_hi) . (2^11 P_lo)
                 if (!SKIPLO || cb == 0) o[cb] = mfma16h(a_l[cur], ph[tt], o[cb]);
                 piece(8 + i, vlo0_tag);
                 if (i == NSV - 1) prefetch_k(buf ^ 1);      // (NSV = 2: both in the same step)
@@ -491,7 +500,7 @@ static int launch_f16x3_k(const _Float16* qh, const _Float16* ql, const _Float16
                           const float* v_scale, const unsigned* v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2,
                           hipStream_t stream) {
     auto kern = corr_fwd_f16x3_kernel<CVB, STORE_S, RAGGED, VLO0>;
-    const size_t smem = (size_t)2 * 2 * (SP_BK * SP_KROW + CVB * 32 * SP_VROW) * sizeof(_Float16);
+    const size_t smem = (size_t)2 * (2 * SP_BK * SP_KROW + 3 * CVB * 32 * SP_VROW) * sizeof(_Float16);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int nqb = (Nq + SP_BQ - 1) / SP_BQ;

@@ -16,7 +16,7 @@
 // (128 accumulator registers).  LDS rows are 32 k-halfs + 8 pad = 80 B: the 16-byte operand reads of 16
 // consecutive rows fall into 16 distinct 4-bank groups (conflict-free).  Double-buffered LDS plus two register
 // stages: the loads of k-blocks t+2 and t+3 are in flight while t multiplies.
-#include "common.h"
+#include "box3_common.h"
 
 namespace cocos {
 
@@ -29,7 +29,11 @@ constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row
 // an exec-mask region (s_and_saveexec / s_or per load: ~120 scalar instructions per k-step of 96 MFMAs).
 // BSTREAM: the B operand is a stream that nothing re-reads (the dS'' / P planes of the K2 backward: 0.5 GB per launch):
 // loaded `nt` so that it does not evict the A planes (4 MB per sample, re-read by every N tile) from the XCD's L2.
-template <bool EXACT, int BMODE>
+// EPI 1 (match_kernel 3, box3_common.h): C is the K = 256 correlation with KEYS in the rows (A = key planes) and queries
+// in the columns; the epilogue applies the x-direction diagonal box filter to the wave's 128 x 64 sub-tile (= two image
+// rows of keys x one image row of queries on a 64-wide grid) through a per-wave LDS image laid over the dead staging
+// buffers, and stores the result in the tile-blocked layout the fused box -> softmax -> warp kernels read.
+template <bool EXACT, int BMODE, int EPI = 0>
 __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __restrict__ ah,
                                                              const _Float16* __restrict__ al,
                                                              const _Float16* __restrict__ bh,
@@ -38,6 +42,9 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                                                              float host_scale,
                                                              const float* __restrict__ dev_scale,
                                                              const float* __restrict__ dev_scale2) {
+    // BMODE 3: the SAME blocks as mode 2 read the other way round — [N/32][K/32] blocks of 2 x [32 n][16 k] (k contiguous):
+    // the box-adjoint kernel writes dC once in that layout and both correlation-gradient GEMMs read it (d phi: mode 2 with
+    // n = keys, k = queries; d theta: mode 3 with n = queries, k = keys).
     // BMODE 0: B planes row-major [N][K]; 1: [N/128][K/32] blocks of [128 n][32 k] (k contiguous); 2: the orientation the
     // K2 query backward leaves its dS'' / P planes in — [K/32][N/32] blocks of 2 x [32 k][16 n] (n contiguous, 2 KB): staged
     // as they are into an LDS image [32 k][128 n + 32 pad] and read as MFMA fragments with ds_read_b64_tr_b16 (the
@@ -83,6 +90,8 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
         const int row = g >> 2, kc = g & 3;
         if (BMODE == 2)      // block = 2 x [32 k][16 n]: 8-n chunk kc of k row q sits in half kc >> 1
             return (unsigned)((((k0 >> 5) * (N >> 5) + (n0 >> 5) + (g >> 7)) * 1024) + (kc >> 1) * 512 + ((g & 127) >> 2) * 16 + (kc & 1) * 8);
+        if (BMODE == 3)
+            return (unsigned)((((n0 >> 5) + (row >> 5)) * (K >> 5) + (k0 >> 5)) * 1024 + (kc >> 1) * 512 + (row & 31) * 16 + (kc & 1) * 8);
         if (BMODE == 1) return (unsigned)(((n0 >> 7) * (K >> 5) + (k0 >> 5)) * 4096 + row * 32 + kc * 8);
         return (unsigned)((n0 + row) * K + k0 + kc * 8);
     };
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
             const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
             unsigned off = b_goff(g, k0) * 2u;
             if (!EXACT && BMODE != 2 && (n0 + row >= N || k0 + kc * 8 >= K)) off = kBufOob;
-            if (BMODE == 2 && k0 >= K) off = kBufOob;                       // look-ahead past the last k-block
+            if ((BMODE == 2 || BMODE == 3) && k0 >= K) off = kBufOob;       // look-ahead past the last k-block
             st.b[0][u] = __builtin_amdgcn_raw_buffer_load_b128(bh_rs, (int)off, 0, BSTREAM ? 2 : 0);
             st.b[1][u] = __builtin_amdgcn_raw_buffer_load_b128(bl_rs, (int)off, 0, BSTREAM ? 2 : 0);
         }
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
             *reinterpret_cast<u32x4*>(bb + pl * BPLANE + b_lds(g)) = st.b[pl][u];
             unsigned off = b_goff(g, k0) * 2u;
             if (!EXACT && BMODE != 2 && (n0 + row >= N || k0 + kc * 8 >= K)) off = kBufOob;
-            if (BMODE == 2 && k0 >= K) off = kBufOob;
+            if ((BMODE == 2 || BMODE == 3) && k0 >= K) off = kBufOob;
             st.b[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(pl ? bl_rs : bh_rs, (int)off, 0, BSTREAM ? 2 : 0);
         }
     };
@@ -212,6 +221,31 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
     if (t < nsteps) step(t, st1);
 
     const float scale = host_scale / ((dev_scale ? *dev_scale : 1.0f) * (dev_scale2 ? *dev_scale2 : 1.0f));
+    if (EPI == 1) {
+        // (the last step() ended with a barrier: the staging buffers are dead)
+        float* const img = reinterpret_cast<float*>(smem_raw) + wave * kXbFloats;
+        xbox_zero_border(img, lane);
+        const int nqblk = N >> 5;
+        const __amdgpu_buffer_rsrc_t t_rs = make_rsrc(C + (size_t)b * M * N, (size_t)M * N * 4);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x16 (&t)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * hh]);
+            xbox_64x64(t, img, lane);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    const unsigned blk = (unsigned)((((m0 + wm * 128 + (2 * hh + kt) * 32) >> 5) * nqblk + ((n0 + wn * 64 + qt * 32) >> 5)) * 4096);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            __builtin_bit_cast(u32x4, f32x4{t[kt][qt][4 * g] * scale, t[kt][qt][4 * g + 1] * scale,
+                                                            t[kt][qt][4 * g + 2] * scale, t[kt][qt][4 * g + 3] * scale}),
+                            t_rs, (int)(blk + (unsigned)(g * 1024 + lane * 16)), 0, 0);
+                }
+        }
+        return;
+    }
     float* Cb = C + (size_t)b * M * N;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -247,18 +281,49 @@ extern "C" int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void*
     COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "hgemm_f16x3: grid too large");
     const size_t smem = (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16);
     const bool exact = M % HG_BM == 0 && N % HG_BN == 0 && K % HG_BK == 0;
-    COCOS_REQUIRE(b_blocked >= 0 && b_blocked <= 2 && (b_blocked != 2 || exact || (N % 128 == 0 && K % 32 == 0)),
+    COCOS_REQUIRE(b_blocked >= 0 && b_blocked <= 3 && (b_blocked < 2 || exact || (N % 128 == 0 && K % 32 == 0)),
                   COCOS_ERR_INVALID, "hgemm_f16x3: b_blocked=%d", b_blocked);
-    auto kern = exact ? (b_blocked == 2 ? hgemm_f16x3_kernel<true, 2> : b_blocked ? hgemm_f16x3_kernel<true, 1>
-                                                                                  : hgemm_f16x3_kernel<true, 0>)
-                      : (b_blocked == 2 ? hgemm_f16x3_kernel<false, 2> : b_blocked ? hgemm_f16x3_kernel<false, 1>
-                                                                                   : hgemm_f16x3_kernel<false, 0>);
+    auto kern = exact ? (b_blocked == 3 ? hgemm_f16x3_kernel<true, 3> : b_blocked == 2 ? hgemm_f16x3_kernel<true, 2>
+                         : b_blocked ? hgemm_f16x3_kernel<true, 1> : hgemm_f16x3_kernel<true, 0>)
+                      : (b_blocked == 3 ? hgemm_f16x3_kernel<false, 3> : b_blocked == 2 ? hgemm_f16x3_kernel<false, 2>
+                         : b_blocked ? hgemm_f16x3_kernel<false, 1> : hgemm_f16x3_kernel<false, 0>);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),
                        static_cast<const _Float16*>(a_hi), static_cast<const _Float16*>(a_lo),
                        static_cast<const _Float16*>(b_hi), static_cast<const _Float16*>(b_lo), c, M, N, K,
                        host_scale, dev_scale, dev_scale2);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_box3_corr_xbox_f16x3(const void* k_hi, const void* k_lo, const void* q_hi, const void* q_lo,
+                                          float* t_blocked, int batch, int Nk, int Nq, int K, int grid_w,
+                                          const float* k_scale_dev, const float* q_scale_dev, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(k_hi && k_lo && q_hi && q_lo && t_blocked, COCOS_ERR_INVALID, "box3_corr_xbox_f16x3: null pointer");
+    COCOS_REQUIRE(batch >= 1 && Nk >= 1 && Nq >= 1 && K >= 1, COCOS_ERR_INVALID,
+                  "box3_corr_xbox_f16x3: bad dims batch=%d Nk=%d Nq=%d K=%d", batch, Nk, Nq, K);
+    COCOS_REQUIRE(grid_w == 64 && Nk % HG_BM == 0 && Nq % HG_BN == 0 && K % HG_BK == 0, COCOS_ERR_UNSUPPORTED,
+                  "box3_corr_xbox_f16x3: needs a 64-wide grid, Nk %% 256 == 0, Nq %% 128 == 0, K %% 32 == 0 "
+                  "(w=%d Nk=%d Nq=%d K=%d)", grid_w, Nk, Nq, K);
+    COCOS_REQUIRE((size_t)Nk * K * 2 < 0x7fffffffull && (size_t)Nq * K * 2 < 0x7fffffffull &&
+                      (size_t)Nk * Nq * 4 < 0x7fffffffull,
+                  COCOS_ERR_UNSUPPORTED, "box3_corr_xbox_f16x3: per-sample tensor exceeds 2 GiB");
+    for (const void* p : {k_hi, k_lo, q_hi, q_lo, (const void*)t_blocked})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "box3_corr_xbox_f16x3: pointers must be 16-byte aligned");
+    const long long blocks = (long long)batch * (Nq / HG_BN) * (Nk / HG_BM);
+    COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "box3_corr_xbox_f16x3: grid too large");
+    const size_t smem = (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16);
+    static_assert((size_t)4 * kXbFloats * sizeof(float) <= (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16),
+                  "the four x-box images must fit the staging buffers");
+    auto kern = hgemm_f16x3_kernel<true, 0, 1>;
+    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),
+                       static_cast<const _Float16*>(k_hi), static_cast<const _Float16*>(k_lo),
+                       static_cast<const _Float16*>(q_hi), static_cast<const _Float16*>(q_lo), t_blocked, Nk, Nq, K,
+                       1.0f, k_scale_dev, q_scale_dev);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

@@ -25,9 +25,11 @@ constexpr float kLwPBias = 9.0f;
 __device__ __forceinline__ f32x16 lw_mfma(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
+// P -> f16 hi and lo' = 2^11 * (p - hi) (common.h: split_pair_rtz_lo_scaled): forward only — the backward's dlogits are
+// fp32 and its P never becomes an MFMA operand
 __device__ __forceinline__ void lw_split_pair(float a, float b, f16x2& hi, f16x2& lo) {
     unsigned h, l;
-    split_pair_rtz(a, b, h, l);
+    split_pair_rtz_lo_scaled(a, b, h, l);
     hi = __builtin_bit_cast(f16x2, h);
     lo = __builtin_bit_cast(f16x2, l);
 }
@@ -43,7 +45,8 @@ __global__ __launch_bounds__(256, 1) void lsw_fwd_f16x3_kernel(const float* __re
                                                                const float* __restrict__ v_scale,     // s_v or NULL
                                                                int B, int Nq, int Nk, int Cv) {
     constexpr int CVP = CVB * 32, VPLANE = CVP * LW_VROW;
-    __shared__ __attribute__((aligned(16))) _Float16 vt[2 * 2 * VPLANE];   // [2 buf][hi|lo][CVP][VROW]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsw_smem[];   // 75 KB at CVB = 5: dynamic
+    _Float16* const vt = reinterpret_cast<_Float16*>(lsw_smem);                // [2 buf][hi|lo|hi*2^-11][CVP][VROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
@@ -79,7 +82,10 @@ __global__ __launch_bounds__(256, 1) void lsw_fwd_f16x3_kernel(const float* __re
         const int pl = i & 1, u = i >> 1;
         const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
         const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);   // see corr_fused_fwd_f16x3.hip
-        *reinterpret_cast<u32x2*>(vt + (buf * 2 + pl) * VPLANE + row * LW_VROW + slot) = vst[pl][u];
+        *reinterpret_cast<u32x2*>(vt + (buf * 3 + pl) * VPLANE + row * LW_VROW + slot) = vst[pl][u];
+        if (pl == 0)      // the 2^-11-scaled copy of the hi plane: A operand of the V_hi . P_lo' term
+            *reinterpret_cast<u32x2*>(vt + (buf * 3 + 2) * VPLANE + row * LW_VROW + slot) =
+                u32x2{pk_unshift_f16(vst[0][u].x), pk_unshift_f16(vst[0][u].y)};
     };
     auto fetch_s = [&](int j0) {
 #pragma unroll
@@ -151,11 +157,12 @@ __global__ __launch_bounds__(256, 1) void lsw_fwd_f16x3_kernel(const float* __re
 
         // ---- O^T += V . P, with the staged V pieces of tile t+1 / t+2 riding between the MFMAs ----------------------
         {
-            const _Float16* vbase = vt + buf * 2 * VPLANE + c * LW_VROW + h * 8;
+            const _Float16* vbase = vt + buf * 3 * VPLANE + c * LW_VROW + h * 8;
             constexpr int NS = 2 * CVB;
-            f16x8 a_h[2], a_l[2];
+            f16x8 a_h[2], a_l[2], a_s[2];
             a_h[0] = *reinterpret_cast<const f16x8*>(vbase);
             a_l[0] = *reinterpret_cast<const f16x8*>(vbase + VPLANE);
+            a_s[0] = *reinterpret_cast<const f16x8*>(vbase + 2 * VPLANE);
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const int tt = i / CVB, cb = i % CVB, cur = i & 1, nxt = cur ^ 1;
@@ -163,9 +170,10 @@ __global__ __launch_bounds__(256, 1) void lsw_fwd_f16x3_kernel(const float* __re
                     const int t2 = (i + 1) / CVB, c2 = (i + 1) % CVB;
                     a_h[nxt] = *reinterpret_cast<const f16x8*>(vbase + c2 * 32 * LW_VROW + t2 * 16);
                     a_l[nxt] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + c2 * 32 * LW_VROW + t2 * 16);
+                    a_s[nxt] = *reinterpret_cast<const f16x8*>(vbase + 2 * VPLANE + c2 * 32 * LW_VROW + t2 * 16);
                 }
                 o[cb] = lw_mfma(a_h[cur], ph[tt], o[cb]);
-                o[cb] = lw_mfma(a_h[cur], pl[tt], o[cb]);
+                o[cb] = lw_mfma(a_s[cur], pl[tt], o[cb]);
                 o[cb] = lw_mfma(a_l[cur], ph[tt], o[cb]);
                 commit_v_piece(i, buf ^ 1);
                 fetch_v_piece(i, j0 + 64);
@@ -344,8 +352,10 @@ template <int CVB>
 static int lsw_fwd_launch(const float* lg, const _Float16* vh, const _Float16* vl, float* out, float* lse,
                           const float* vs, int B, int Nq, int Nk, int Cv, hipStream_t s) {
     const int nqb = (Nq + 127) / 128;
-    if (Nk % 32) hipLaunchKernelGGL((lsw_fwd_f16x3_kernel<CVB, true>), dim3(B * nqb), dim3(256), 0, s, lg, vh, vl, out, lse, vs, B, Nq, Nk, Cv);
-    else         hipLaunchKernelGGL((lsw_fwd_f16x3_kernel<CVB, false>), dim3(B * nqb), dim3(256), 0, s, lg, vh, vl, out, lse, vs, B, Nq, Nk, Cv);
+    const size_t smem = (size_t)2 * 3 * CVB * 32 * LW_VROW * sizeof(_Float16);
+    auto kern = (Nk % 32) ? lsw_fwd_f16x3_kernel<CVB, true> : lsw_fwd_f16x3_kernel<CVB, false>;
+    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, s, lg, vh, vl, out, lse, vs, B, Nq, Nk, Cv);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

@@ -99,9 +99,10 @@ class _Attention:
        streamed   logits materialised once per orientation, softmax + warp fused (match_kernel 3);
        generic    materialised logits -> row softmax -> GEMM (return_corr / WTA / everything else)."""
 
-    def __init__(self, qn=None, kn=None, inv_t=1.0, f_scaled=None, logits_q=None, logits_k=None):
+    def __init__(self, qn=None, kn=None, inv_t=1.0, f_scaled=None, logits_q=None, logits_k=None, boxed=None):
         self.qn, self.kn, self.inv_t = qn, kn, inv_t
         self.fused = qn is not None
+        self._boxed = boxed                          # match_kernel 3 fused (K19 / K20): a _BoxedCorr
         self._f = f_scaled
         self._lq, self._lk = logits_q, logits_k      # providers: query-major f / key-major f^T
         self._cache = {}
@@ -122,6 +123,8 @@ class _Attention:
         """softmax over exemplar positions, then @ v   (f_div_C @ v, :307/:318)."""
         if self.fused:
             return ops.corr_softmax_warp(self.qn, self.kn, v, self.inv_t, self._planes)
+        if self._boxed is not None:
+            return self._boxed.rows(v)
         if self._lk is not None:
             return ops.logits_softmax_warp(self._get("lk", self._lk), v)
         return ops.warp_materialized(self._get("p_row", lambda: ops.row_softmax(self._f)), v)
@@ -130,10 +133,41 @@ class _Attention:
         """softmax over content positions of f^T, then @ v   (f_div_C_v @ v, :338/:351)."""
         if self.fused:
             return ops.corr_softmax_warp(self.kn, self.qn, v, self.inv_t, self._planes)
+        if self._boxed is not None:
+            return self._boxed.cols(v)
         if self._lq is not None:   # f itself is the key-major logit matrix of the swapped problem
             return ops.logits_softmax_warp(self._get("lq", self._lq), v)
         return ops.warp_materialized(
             self._get("p_col", lambda: ops.row_softmax(self._f.transpose(1, 2).contiguous())), v)
+
+
+class _BoxedCorr:
+    """match_kernel 3, PONO_C, 64-wide grid: the statistics of the unfolded vectors (K12) and, per orientation that is
+    actually used, T = xbox(C_raw) from the correlation GEMM's epilogue; every softmax + warp pass then reads T three
+    blocks at a time (K19).  Nothing box-filtered and no logits matrix reaches HBM."""
+
+    def __init__(self, theta_raw, phi_raw, inv_t):
+        self.th, self.ph, self.inv_t = theta_raw, phi_raw, inv_t
+        _, C, self.fh, self.fw = theta_raw.shape
+        self.kc = float(C * 9)
+        self._cache = {}
+
+    def _get(self, name, fn):
+        if name not in self._cache:
+            self._cache[name] = fn()
+        return self._cache[name]
+
+    def rows(self, v):
+        mu, a = self._get("q", lambda: _unfold3_stats(self.th, self.kc))
+        nu, b = self._get("k", lambda: _unfold3_stats(self.ph, self.kc))
+        t = self._get("t_rows", lambda: ops.box3_corr_xbox(self.th, self.ph))
+        return ops.box3_softmax_warp(t, mu, a, nu, b, v, self.fh, self.fw, self.kc, self.inv_t)
+
+    def cols(self, v):   # the same operator with the roles of theta and phi exchanged
+        mu, a = self._get("q", lambda: _unfold3_stats(self.th, self.kc))
+        nu, b = self._get("k", lambda: _unfold3_stats(self.ph, self.kc))
+        t = self._get("t_cols", lambda: ops.box3_corr_xbox(self.ph, self.th))
+        return ops.box3_softmax_warp(t, nu, b, mu, a, v, self.fh, self.fw, self.kc, self.inv_t)
 
 
 def _box_sum3(x):
@@ -213,8 +247,14 @@ def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_
         if detach_flag:   # :292-293 `f = f.detach()`: nothing upstream of f receives a gradient
             qn, kn = qn.detach(), kn.detach()
         attn = _Attention(qn=qn, kn=kn, inv_t=inv_t)
+    elif (mk == 3 and cfg.PONO_C and WTA_scale_weight == 1 and not return_corr and _hip_fp32(theta_raw)
+          and ops.box3_fused_ok(B, C, fh, fw)):
+        # the reference's default: 3x3 neighbourhoods, fused (round 3): x box in the correlation GEMM, y box + softmax + warp
+        # in one kernel — see _BoxedCorr
+        th, ph = (theta_raw.detach(), phi_raw.detach()) if detach_flag else (theta_raw, phi_raw)
+        attn = _Attention(inv_t=inv_t, boxed=_BoxedCorr(th, ph, inv_t))
     elif mk == 3 and cfg.PONO_C and WTA_scale_weight == 1:
-        # the reference's default: 3x3 neighbourhoods.  Logits = diagonal box filter of the K = 256
+        # every other shape / the exact-fp32 flavour: logits = diagonal box filter of the K = 256
         # correlation, materialised once per orientation that is actually used, then streamed.
         th, ph = (theta_raw.detach(), phi_raw.detach()) if detach_flag else (theta_raw, phi_raw)
         attn = _Attention(inv_t=inv_t,

@@ -878,6 +878,145 @@ def box3_logits(c_raw, mu, nu, a, b, h, w, k_unfolded, scale):
 
 
 # ------------------------------------------------------------------------------------------
+# K19 / K20  match_kernel = 3 fused: x-box in the correlation GEMM's epilogue, y-box + softmax + warp in one kernel,
+#            nothing box-filtered and no logits in HBM   (correspondence.py:276-291, :304, :307, :318; box3_fused_f16x3.hip)
+# ------------------------------------------------------------------------------------------
+#: "0": match_kernel 3 keeps the round-2 chain (K3 -> K6 -> K7) everywhere (A/B runs, tests of that chain)
+BOX3_FUSED = os.environ.get("COCOS_BOX3_FUSED", "1") != "0"
+
+
+def box3_fused_ok(B, C, h, w, Cv=1):
+    """Shapes the fused match_kernel-3 family takes (64-wide grid, whole 256-position tiles) on the split flavour."""
+    return (BOX3_FUSED and PRECISION == "f16x3" and C == FUSED_K
+            and bool(_lib.load().cocos_box3_fused_supported(h * w, h * w, min(Cv, MAX_FUSED_CV), h, w)))
+
+
+class _Box3CorrXbox(torch.autograd.Function):
+    """T = xbox(C_raw) with KEYS in the rows, tile-blocked (include/cocos_hip.h, K19).  Private contract with
+    _Box3SoftmaxWarp: the gradient this node RECEIVES is G = dloss / d ybox(T) (same blocked layout), not dloss / dT — the
+    y box of the adjoint is applied here, together with the x box, by K20."""
+
+    @staticmethod
+    def forward(ctx, q_raw, k_raw):
+        q_raw, k_raw = _chk(q_raw, "box3_corr_xbox: q"), _chk(k_raw, "box3_corr_xbox: k")
+        B, K, h, w = q_raw.shape
+        N = h * w
+        qf, kf = q_raw.reshape(B, K, N), k_raw.reshape(B, K, N)
+        qa, ka = absmax(qf), absmax(kf)
+        qh, ql, qs = split_f16(qf, True, amax=qa)            # position-major planes [B,N,K]
+        kh, kl, ks = split_f16(kf, True, amax=ka)
+        t = torch.empty(B * N * N, device=q_raw.device, dtype=torch.float32)
+        _call("box3_corr_xbox", "cocos_box3_corr_xbox_f16x3", kh.data_ptr(), kl.data_ptr(), qh.data_ptr(), ql.data_ptr(),
+              t.data_ptr(), B, N, N, K, w, ks.data_ptr(), qs.data_ptr(), _stream())
+        ctx.save_for_backward(q_raw, k_raw)
+        ctx.amax = (qa, ka)
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        q_raw, k_raw = ctx.saved_tensors
+        qa, ka = ctx.amax
+        g = _chk(g, "box3_corr_xbox: g")
+        B, K, h, w = q_raw.shape
+        N = h * w
+        gmax = _recall_amax(g)              # left by K19's backward; a sum of several passes' gradients: one pass over it
+        if gmax is None:
+            gmax = absmax(g)
+        half = dict(device=g.device, dtype=torch.float16)
+        dch, dcl = torch.empty(B * N * N, **half), torch.empty(B * N * N, **half)
+        sc = torch.empty(1, device=g.device, dtype=torch.float32)
+        _call("box3_adjoint_planes", "cocos_box3_adjoint_planes_f16x3", g.data_ptr(), gmax.data_ptr(), dch.data_ptr(),
+              dcl.data_ptr(), sc.data_ptr(), B, N, N, h, w, _stream())
+        dq = dk = None
+        if ctx.needs_input_grad[0]:         # d q_raw[c,P] = sum_Q dC[P,Q] k_raw[c,Q]
+            ch, cl, cs = split_f16(k_raw.reshape(B, K, N), False, amax=ka)
+            dq = torch.empty_like(q_raw)
+            _call("box3_corr_grad", "cocos_hgemm_f16x3", ch.data_ptr(), cl.data_ptr(), dch.data_ptr(), dcl.data_ptr(),
+                  dq.data_ptr(), B, K, N, N, 1.0, cs.data_ptr(), sc.data_ptr(), 3, _stream())
+        if ctx.needs_input_grad[1]:         # d k_raw[c,Q] = sum_P dC[P,Q] q_raw[c,P]
+            ch, cl, cs = split_f16(q_raw.reshape(B, K, N), False, amax=qa)
+            dk = torch.empty_like(k_raw)
+            _call("box3_corr_grad", "cocos_hgemm_f16x3", ch.data_ptr(), cl.data_ptr(), dch.data_ptr(), dcl.data_ptr(),
+                  dk.data_ptr(), B, K, N, N, 1.0, cs.data_ptr(), sc.data_ptr(), 2, _stream())
+        return dq, dk
+
+
+def box3_corr_xbox(q_raw, k_raw):
+    """x-direction diagonal box filter of the K = 256 correlation of two raw [B,256,h,w] feature maps (64-wide grid),
+    keys in the rows, in the tile-blocked layout of K19 (an opaque 1-D tensor of B*N*N floats)."""
+    return _Box3CorrXbox.apply(q_raw, k_raw)
+
+
+class _Box3SoftmaxWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, mu, a, nu, b, v, h: int, w: int, kc: float, scale: float):
+        t, v = _chk(t, "box3_softmax_warp: t"), _chk(v, "box3_softmax_warp: v")
+        mu, a, nu, b = (_chk(x, n) for x, n in ((mu, "mu"), (a, "a"), (nu, "nu"), (b, "b")))
+        B, N = mu.shape
+        Cv = v.shape[1]
+        if N != h * w or v.shape != (B, Cv, N) or t.numel() != B * N * N or any(x.shape != (B, N) for x in (a, nu, b)):
+            raise ValueError("box3_softmax_warp: shape mismatch")
+        v_amax = _recall_amax(v)
+        if v_amax is None:
+            v_amax = absmax(v)
+        vh, vl, v_scale = split_f16(v, False, amax=v_amax)
+        out = torch.empty((B, Cv, N), device=v.device, dtype=torch.float32)
+        lse = torch.empty((B, N), device=v.device, dtype=torch.float32)
+        _call("box3_softmax_warp_fwd", "cocos_box3_softmax_warp_fwd_f16x3", t.data_ptr(), mu.data_ptr(), a.data_ptr(),
+              nu.data_ptr(), b.data_ptr(), vh.data_ptr(), vl.data_ptr(), out.data_ptr(), lse.data_ptr(), v_scale.data_ptr(),
+              B, N, N, Cv, h, w, float(kc), float(scale), _stream())
+        ctx.save_for_backward(t, mu, a, nu, b, v, out, lse)
+        ctx.cfg = (int(h), int(w), float(kc), float(scale))
+        ctx.v_amax = v_amax
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        t, mu, a, nu, b, v, out, lse = ctx.saved_tensors
+        h, w, kc, scale = ctx.cfg
+        dout = _chk(dout, "box3_softmax_warp: dout")
+        B, N = mu.shape
+        Cv = v.shape[1]
+        cvp = (Cv + 31) // 32 * 32
+        g_amax = absmax(dout)
+        gph, gpl, gs = split_f16(dout, True, cpad=cvp, amax=g_amax)
+        vph, vpl, v_scale = split_f16(v, True, cpad=cvp, amax=ctx.v_amax)
+        f32 = dict(device=v.device, dtype=torch.float32)
+        g = torch.empty(B * N * N, **f32)
+        dmu, da, dnu, db = (torch.empty((B, N), **f32) for _ in range(4))
+        colpart = torch.empty(_lib.load().cocos_box3_softmax_warp_bwd_colpart_bytes(B, N, N) // 4, **f32)
+        gmax = _zero_cell(v.device)
+        need_v = ctx.needs_input_grad[5]
+        psh = psl = None
+        if need_v:        # cycle terms: V itself is differentiated -> the planes of 2^14 P for dv = dout . P
+            psh = torch.empty(B * N * N, device=v.device, dtype=torch.float16)
+            psl = torch.empty_like(psh)
+        _call("box3_softmax_warp_bwd", "cocos_box3_softmax_warp_bwd_f16x3", t.data_ptr(), mu.data_ptr(), a.data_ptr(),
+              nu.data_ptr(), b.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(), gs.data_ptr(),
+              v_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), g.data_ptr(), dmu.data_ptr(),
+              da.data_ptr(), dnu.data_ptr(), db.data_ptr(), colpart.data_ptr(), gmax.data_ptr(), _ptr(psh), _ptr(psl),
+              B, N, N, Cv, cvp, h, w, kc, scale, _stream())
+        _remember_amax(g, gmax)
+        dv = None
+        if need_v:
+            gch, gcl, _ = split_f16(dout, False, amax=g_amax)
+            dv = torch.empty_like(v)
+            _call("box3_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(),
+                  psl.data_ptr(), dv.data_ptr(), B, Cv, N, N, 1.0 / 16384.0, gs.data_ptr(), None, 2, _stream())
+        return g, dmu, da, dnu, db, dv, None, None, None, None
+
+
+def box3_softmax_warp(t, mu, a, nu, b, v, h, w, k_unfolded, scale):
+    """out[b,c,p] = sum_q softmax_q(scale * a_p b_q (ybox(T)[p,q] - k mu_p nu_q)) v[b,c,q] with T from box3_corr_xbox —
+    the whole match_kernel-3 attention of one orientation; v [B,Cv,N] in chunks of 160 channels."""
+    Cv = v.shape[1]
+    if Cv <= MAX_FUSED_CV:
+        return _Box3SoftmaxWarp.apply(t, mu, a, nu, b, v, h, w, k_unfolded, scale)
+    return torch.cat([_Box3SoftmaxWarp.apply(t, mu, a, nu, b, v[:, c0:c0 + MAX_FUSED_CV], h, w, k_unfolded, scale)
+                      for c0 in range(0, Cv, MAX_FUSED_CV)], dim=1)
+
+
+# ------------------------------------------------------------------------------------------
 # K12 statistics of the 3x3-unfolded vectors without unfolding   (correspondence.py:276-280, match_kernel 3)
 # ------------------------------------------------------------------------------------------
 class _Unfold3Stats(torch.autograd.Function):

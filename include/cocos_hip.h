@@ -484,6 +484,53 @@ int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const float* x_ama
                              const float* dy_amax_dev /* nullable */, float* partials, int B, int Cin, int H, int W,
                              int Cout, int KH, int KW, int stride, int pad, int dilation, cocos_stream_t stream);
 
+/* K19 / K20 — match_kernel = 3 (the reference's DEFAULT, options/base_options.py:70) fused, round 3: replaces
+ * F.unfold(k=3) + centre + normalise (correspondence.py:276-280, :286-289), the K = 2304 matmul (:291), /temperature (:304),
+ * softmax (:307) and the warp matmul (:318 / :334) — and their autograd — for --PONO_C on a 64-wide feature grid, without a
+ * [B,2304,HW] tensor, without the box-filtered logits matrix and without saved logits.  Decomposition (csrc/box3_common.h):
+ *     S[p,q] = sum over the 3x3 offsets d of C[p+d, q+d]   (C = the K = 256 correlation; zero outside the grid)
+ *            = ybox(xbox(C)),   xbox along a row (both indices +-1), ybox across rows (both indices +-w)
+ *     z[p,q] = scale * a_p * b_q * (S[p,q] - kc * mu_p * nu_q),  kc = 9*256,
+ *   mu / a (queries), nu / b (keys): mean and 1 / (norm + eps) of the unfolded, centred vectors (cocos_unfold3_stats_*).
+ *   cocos_box3_corr_xbox_f16x3: T = xbox(C) from POSITION-major f16 hi/lo planes of the raw theta / phi ([B][N][K],
+ *       scaled by *k_scale_dev / *q_scale_dev as written by cocos_split_f16_ex), keys in the rows.  T is TILE-BLOCKED:
+ *       [B][Nk/32][Nq/32] blocks of 4 KB = [g][lane][4] — the accumulator image of a 32x32 MFMA tile (registers 4g..4g+3 of a
+ *       lane = keys 8g + 4*(lane>>5) + 0..3, lane & 31 = query), B*Nk*Nq floats in all.
+ *   cocos_box3_softmax_warp_fwd_f16x3: out[b,c,p] = sum_q softmax_q(z[p,q]) v[b,c,q], lse [B,Nq]; reads three blocks of T per
+ *       tile (the y box) and nothing else of size HWxHW.  v planes channel-major [B,Cv,Nk] (cocos_split_f16_ex).
+ *   cocos_box3_softmax_warp_bwd_f16x3: with L = dloss/dz = P * (V.dout - sum_c dout*out) it writes
+ *       g_blocked = L * scale * a_p * b_q (= dloss / d ybox(T)[p,q], blocked like T), dmu, da [B,Nq], dnu, db [B,Nk] (column
+ *       sums: per-workgroup partials in `colpart`, cocos_box3_softmax_warp_bwd_colpart_bytes, folded by a second launch),
+ *       max|g| into *gmax_dev (a zeroed cell on entry; atomic max), and — when psh/psl are given (V is differentiated: the
+ *       cycle terms) — the planes of 2^14 P in the [Nq/32][Nk/32] blocked orientation of cocos_hgemm_f16x3 mode 2.
+ *       vph/vpl [B,Nk,CvPad], gph/gpl [B,Nq,CvPad]: position-major planes of s_v*v and s_o*dout as for K2 / K7.
+ *   cocos_box3_adjoint_planes_f16x3: dC = xbox(ybox(g)) (the filter is self-adjoint) as f16 hi/lo planes scaled by the power of
+ *       two written to *scale_out_dev (from *gmax_dev), in [Nq/32][Nk/32] blocks of 2 x [32 queries][16 keys]; then
+ *           d theta_raw [256][Nq] = hgemm(A = channel-major planes of phi_raw,  B = dC planes, b_blocked = 3)
+ *           d phi_raw   [256][Nk] = hgemm(A = channel-major planes of theta_raw, B = dC planes, b_blocked = 2)
+ *       (b_blocked = 3: the same blocks read with n = queries, k = keys).
+ *   cocos_box3_fused_supported: 1 when this family takes the shape (64-wide grid, Nq == Nk == h*w, Nq % 256 == 0, Cv <= 160);
+ *       every other match_kernel-3 shape keeps the K3 -> K6 -> K7 chain. */
+int cocos_box3_fused_supported(int Nq, int Nk, int Cv, int grid_h, int grid_w);
+int cocos_box3_corr_xbox_f16x3(const void* k_hi, const void* k_lo, const void* q_hi, const void* q_lo, float* t_blocked,
+                               int batch, int Nk, int Nq, int K, int grid_w, const float* k_scale_dev /* nullable */,
+                               const float* q_scale_dev /* nullable */, cocos_stream_t stream);
+int cocos_box3_softmax_warp_fwd_f16x3(const float* t_blocked, const float* mu_q, const float* a_q, const float* nu_k,
+                                      const float* b_k, const void* vh, const void* vl, float* out, float* lse,
+                                      const float* v_scale_dev /* nullable */, int B, int Nq, int Nk, int Cv, int grid_h,
+                                      int grid_w, float k_unfolded, float scale, cocos_stream_t stream);
+size_t cocos_box3_softmax_warp_bwd_colpart_bytes(int B, int Nq, int Nk);
+int cocos_box3_softmax_warp_bwd_f16x3(const float* t_blocked, const float* mu_q, const float* a_q, const float* nu_k,
+                                      const float* b_k, const void* vph, const void* vpl, const void* gph, const void* gpl,
+                                      const float* g_scale_dev, const float* v_scale_dev /* nullable */, const float* out,
+                                      const float* dout, const float* lse, float* g_blocked, float* dmu, float* da, float* dnu,
+                                      float* db, void* colpart, float* gmax_dev, void* psh /* nullable */,
+                                      void* psl /* nullable */, int B, int Nq, int Nk, int Cv, int CvPad, int grid_h,
+                                      int grid_w, float k_unfolded, float scale, cocos_stream_t stream);
+int cocos_box3_adjoint_planes_f16x3(const float* g_blocked, const float* gmax_dev, void* dc_hi, void* dc_lo,
+                                    float* scale_out_dev, int B, int Nq, int Nk, int grid_h, int grid_w,
+                                    cocos_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * K12 statistics of the zero-padded 3x3-unfolded, centred feature vectors without unfolding (match_kernel 3 with
  *     PONO_C: correspondence.py:276-280 / :286-289), feeding K6:

@@ -179,6 +179,58 @@ def test_warp_mask_is_elementwise_relative_1e3(mk, precision):
     mx, p999, n = _rel_hist(f64(out["warp_mask"][:1]), o64["warp_mask"].numpy(), 1e-6)
     assert n > 1000, n
     assert mx < 1e-3, (mx, p999, n)
-    # the log the loss takes: absolute error of log(mask + 1e-10) over ALL entries (also the ones below 1e-6)
-    lg = np.abs(np.log(f64(out["warp_mask"][:1]).clip(0) + 1e-10) - np.log(o64["warp_mask"].numpy() + 1e-10))
-    assert float(lg.max()) < 2e-3, float(lg.max())
+    # ... and every entry above 1e-9 within 1e-3 as well (the split flavour's P planes carry >= 11 bits down to 2^-39 of a
+    # row maximum since round 3: lo plane scaled by 2^11, common.h split_pair_rtz_lo_scaled; before: 30 % off at 1e-9)
+    mx9, _, _ = _rel_hist(f64(out["warp_mask"][:1]), o64["warp_mask"].numpy(), 1e-9)
+    assert mx9 < 1e-3, mx9
+    # the log the loss takes, over ALL entries (also the ones below 1e-9, where only the 1e-10 of the loss keeps the
+    # logarithm finite): per-pixel loss term log(mask + 1e-10) within 1e-3 of its own magnitude
+    lref = np.log(o64["warp_mask"].numpy() + 1e-10)
+    lg = np.abs(np.log(f64(out["warp_mask"][:1]).clip(0) + 1e-10) - lref) / np.maximum(np.abs(lref), 1.0)
+    assert float(lg.max()) < 1e-3, float(lg.max())
+
+
+# ------------------------------------------------------------------ the fused family (K19 / K20) on small 64-wide grids
+@pytest.mark.parametrize("fh,flags", [
+    (4, dict(warp_mask_losstype="direct")),
+    (8, dict(warp_mask_losstype="cycle", warp_cycle_w=1.0, two_cycle=True)),
+    (12, dict(warp_mask_losstype="none", warp_cycle_w=1.0, warp_bilinear=True)),
+])
+def test_box3_fused_family_on_small_grids_vs_fp64_and_vs_the_materialised_chain(fh, flags, monkeypatch):
+    """fh x 64 grids (N = 256 .. 768): edge rows everywhere (fh = 4: two of four rows are border rows), row AND column
+    softmax, V differentiated (cycle terms: P planes + GEMM), both against torch-fp64 autograd of the unfolded
+    formulation and against the round-2 chain (K3 -> K6 -> K7, COCOS_BOX3_FUSED=0) on the same inputs."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    B, d, fw, nc = 2, 4, 64, 11
+    g = torch.Generator(device=DEV).manual_seed(100 + fh)
+    th = torch.randn(B, 256, fh, fw, device=DEV, generator=g) + 0.15
+    ph = 0.4 * th.roll((1, 5), (2, 3)) + torch.randn(B, 256, fh, fw, device=DEV, generator=g) - 0.1
+    H, W = fh * d, fw * d
+    ref_img = torch.rand(B, 3, H, W, device=DEV, generator=g) * 2 - 1
+    real_img = torch.rand(B, 3, H, W, device=DEV, generator=g) * 2 - 1
+    seg = torch.rand(B, nc, H, W, device=DEV, generator=g)
+    ref_seg = torch.rand(B, nc, H, W, device=DEV, generator=g)
+    cfg = dict(match_kernel=3, PONO_C=True, down=d, isTrain=True, **flags)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "BOX3_FUSED", fused)
+        t, p = th.clone().requires_grad_(True), ph.clone().requires_grad_(True)
+        with ops.KernelTimer() as kt:
+            out = correspondence_hot_path(t, p, ref_img, real_img, seg, ref_seg, HotPathConfig(**cfg))
+            if fused:
+                G = {k: torch.randn(v.shape, device=DEV, generator=g) for k, v in sorted(out.items())}
+            torch.autograd.backward([out[k] for k in sorted(out)], [G[k] for k in sorted(out)])
+        res[fused] = (out, t.grad, p.grad, set(kt.summary()))
+    assert "box3_softmax_warp_fwd" in res[True][3] and "box3_adjoint_planes" in res[True][3]
+    assert "box3_logits_fwd" in res[False][3] and "box3_softmax_warp_fwd" not in res[False][3]
+    outs, dth, dph = tr.forward_backward(f64(th), f64(ph), f64(ref_img), f64(real_img), f64(seg), f64(ref_seg),
+                                         co.default_opt(**cfg), {k: f64(v) for k, v in G.items()})
+    for fused in (True, False):
+        out, gt, gp, _ = res[fused]
+        assert set(out) == set(outs)
+        for k in outs:
+            assert rel(out[k], outs[k]) < TOL, (fused, k)
+        assert rel(gt, dth) < TOL, fused
+        assert rel(gp, dph) < TOL, fused
