@@ -28,6 +28,10 @@ _SIGNATURES = {
                                                 ctypes.c_int, ctypes.c_float, _stream_t]),
     "cocos_center_l2norm_bwd_amax": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 4
                                      + [ctypes.c_float, _c_float_p, _stream_t]),
+    "cocos_center_l2norm_fwd_planes": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4
+                                       + [ctypes.c_float, ctypes.c_float, _stream_t]),
+    "cocos_center_l2norm_bwd_planes": (ctypes.c_int, [ctypes.c_void_p] * 2 + [_c_float_p] * 3 + [ctypes.c_int] * 4
+                                       + [ctypes.c_float, ctypes.c_float, _c_float_p, _stream_t]),
     "cocos_corr_softmax_warp_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, _c_float_p,
                                                     _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -108,6 +112,13 @@ _SIGNATURES = {
                                           + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, _stream_t]),
     "cocos_box3_adjoint_planes_f16x3": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p]
                                         + [ctypes.c_int] * 5 + [_stream_t]),
+    "cocos_warp_values_amax": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 6 + [_c_float_p, _stream_t]),
+    "cocos_concat2_amax": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong,
+                                                              _c_float_p, _stream_t]),
+    "cocos_split_f16_chan_mask": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3
+                                  + [_c_float_p, _c_float_p, ctypes.c_void_p, _stream_t]),
+    "cocos_proj_weight_planes": (ctypes.c_int, [_c_float_p] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4
+                                 + [_c_float_p, _c_float_p, _stream_t]),
     "cocos_hgemm_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 4 + [_c_float_p] + [ctypes.c_int] * 4
                           + [ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_int, _stream_t]),
     "cocos_absmax": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, _c_float_p, _stream_t]),

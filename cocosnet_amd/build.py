@@ -28,6 +28,7 @@ HIP_SOURCES = [
     "corr_fused_fwd.hip",
     "corr_fused_fwd_f16x3.hip",
     "split_f16.hip",
+    "plane_prep.hip",
     "corr_fused_bwd_f16x3.hip",
     "hgemm_f16x3.hip",
     "corr_fused_bwd.hip",

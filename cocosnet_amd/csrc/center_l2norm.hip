@@ -270,6 +270,140 @@ __global__ __launch_bounds__(256) void center_l2norm_bwd_reg_kernel(const float*
     }
 }
 
+// ---- K1 forward that emits the f16 hi/lo OPERAND PLANES of the split-precision correlation kernels itself (round 3).
+// The fp32 result qn / kn used to be written (4 B/element) only to be read again by two cocos_split_f16 launches per
+// tensor (position-major planes for the forward, channel-major ones for the backward): 24 B/element of traffic and six
+// launches per step for what is 12 B/element here.  Thread (pq, cg) owns 16 CONSECUTIVE channels 16cg..16cg+15 of
+// positions 4pq..4pq+3, so a position-major row piece (16 channels = 32 bytes per plane) leaves as two 16-byte stores
+// and a channel-major piece (4 positions of one channel) as one 8-byte store.  plane_scale * y = hi + lo, hi rounded to
+// nearest exactly like split_f16.hip (the planes are bit-identical to the ones the split kernels would have made).
+typedef _Float16 cn_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 cn_f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void center_l2norm_fwd_planes_kernel(
+    const float* __restrict__ x, float* __restrict__ norm_out, _Float16* __restrict__ ph, _Float16* __restrict__ pl,
+    _Float16* __restrict__ ch, _Float16* __restrict__ cl, int N, float eps, bool center, float plane_scale) {
+    constexpr int K = 256, NI = 16;
+    __shared__ __attribute__((aligned(16))) float red[16 * 64];
+    const int tid = threadIdx.x, pq = tid & 15, cg = tid >> 4;
+    const int b = blockIdx.y, n = blockIdx.x * 64 + pq * 4;
+    const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(x + (size_t)b * K * N, (size_t)K * N * 4);
+    const bool ok = n < N;   // N % 4 == 0
+    f32x4 v[NI];
+    f32x4 s[1] = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        v[i] = buf_load4(x_rs, ok ? (unsigned)((cg * 16 + i) * N + n) * 4u : kBufOob);
+        s[0] += v[i];
+    }
+    if (center) reduce_cg<1>(s, red, cg, pq);
+    const f32x4 mean = s[0] * (center ? 1.0f / (float)K : 0.0f);
+    f32x4 ss[1] = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        v[i] -= mean;
+        ss[0] += v[i] * v[i];
+    }
+    reduce_cg<1>(ss, red, cg, pq);
+    f32x4 nrm, u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { nrm[e] = sqrtf(ss[0][e]); u[e] = 1.0f / (nrm[e] + eps); }
+    if (!ok) return;
+    if (cg == 0) *reinterpret_cast<f32x4*>(norm_out + (size_t)b * N + n) = nrm;
+    // hi / lo of the 16 channels x 4 positions of this thread (y rounded exactly as the fp32 kernel rounds it, then times
+    // the power-of-two plane scale: the planes are bit-identical to cocos_split_f16 of that kernel's output)
+    _Float16 hh[NI][4], ll[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y = (v[i][e] * u[e]) * plane_scale;
+            hh[i][e] = (_Float16)y;
+            ll[i][e] = (_Float16)(y - (float)hh[i][e]);
+        }
+    if (ch) {      // channel-major planes [B,256,N]
+        _Float16* chb = ch + (size_t)b * K * N;
+        _Float16* clb = cl + (size_t)b * K * N;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const size_t off = (size_t)(cg * 16 + i) * N + n;
+            *reinterpret_cast<cn_f16x4*>(chb + off) = cn_f16x4{hh[i][0], hh[i][1], hh[i][2], hh[i][3]};
+            *reinterpret_cast<cn_f16x4*>(clb + off) = cn_f16x4{ll[i][0], ll[i][1], ll[i][2], ll[i][3]};
+        }
+    }
+    // position-major planes [B,N,256]: 32 bytes per plane and position
+    _Float16* phb = ph + ((size_t)b * N + n) * K + cg * 16;
+    _Float16* plb = pl + ((size_t)b * N + n) * K + cg * 16;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            cn_f16x8 a, c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[j] = hh[8 * g + j][e]; c[j] = ll[8 * g + j][e]; }
+            *reinterpret_cast<cn_f16x8*>(phb + (size_t)e * K + 8 * g) = a;
+            *reinterpret_cast<cn_f16x8*>(plb + (size_t)e * K + 8 * g) = c;
+        }
+}
+
+// Backward of the planes flavour: y is read back from the channel-major planes, y = (hi + lo) / plane_scale (22 mantissa
+// bits: the gradient's own rounding is coarser), everything else as center_l2norm_bwd_reg_kernel<16>.
+__global__ __launch_bounds__(256) void center_l2norm_bwd_planes_kernel(
+    const _Float16* __restrict__ ch, const _Float16* __restrict__ cl, const float* __restrict__ nrm_in,
+    const float* __restrict__ dy, float* __restrict__ dx, int N, float eps, bool center, float inv_plane_scale,
+    unsigned* __restrict__ dx_amax) {
+    constexpr int K = 256, NI = 16;
+    __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
+    const int tid = threadIdx.x, pq = tid & 15, cg = tid >> 4;
+    const int b = blockIdx.y, n = blockIdx.x * 64 + pq * 4;
+    const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(dy + (size_t)b * K * N, (size_t)K * N * 4);
+    const __amdgpu_buffer_rsrc_t h_rs = make_rsrc(ch + (size_t)b * K * N, (size_t)K * N * 2);
+    const __amdgpu_buffer_rsrc_t l_rs = make_rsrc(cl + (size_t)b * K * N, (size_t)K * N * 2);
+    const bool ok = n < N;
+    f32x4 yy[NI], gg[NI];
+    f32x4 s[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const unsigned e0 = (unsigned)((cg + 16 * i) * N + n);
+        gg[i] = buf_load4(g_rs, ok ? e0 * 4u : kBufOob);
+        typedef unsigned int cn_u32x2 __attribute__((ext_vector_type(2)));
+        const cn_u32x2 hw = __builtin_amdgcn_raw_buffer_load_b64(h_rs, (int)(ok ? e0 * 2u : kBufOob), 0, 0);
+        const cn_u32x2 lw = __builtin_amdgcn_raw_buffer_load_b64(l_rs, (int)(ok ? e0 * 2u : kBufOob), 0, 0);
+        const cn_f16x4 h4 = __builtin_bit_cast(cn_f16x4, hw), l4 = __builtin_bit_cast(cn_f16x4, lw);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) yy[i][e] = ((float)h4[e] + (float)l4[e]) * inv_plane_scale;
+        s[0] += gg[i] * yy[i];
+        s[1] += gg[i];
+        s[2] += yy[i];
+    }
+    reduce_cg<3>(s, red, cg, pq);
+    if (!ok && !dx_amax) return;
+    const f32x4 nrm = ok ? *reinterpret_cast<const f32x4*>(nrm_in + (size_t)b * N + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+    f32x4 u, g, m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        u[e] = 1.0f / (nrm[e] + eps);
+        g[e] = nrm[e] > 0.f ? s[0][e] / nrm[e] : 0.f;
+        m[e] = center ? (u[e] * s[1][e] - g[e] * s[2][e]) / (float)K : 0.f;
+    }
+    float* dxb = dx + (size_t)b * K * N;
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const f32x4 d = u * gg[i] - g * yy[i] - m;
+        if (ok) *reinterpret_cast<f32x4*>(dxb + (size_t)(cg + 16 * i) * N + n) = d;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
+    }
+    if (dx_amax) {
+        const float wmax = wave_max_dpp(ok ? amax : 0.f);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wmax;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(dx_amax, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    }
+}
+
 template <bool BWD>
 static bool launch_reg_variant(const float* a, const float* nrm_in, const float* dy, float* out,
                                float* norm_out, int B, int K, int N, float eps, bool center, hipStream_t s,
@@ -374,4 +508,50 @@ extern "C" int cocos_center_l2norm_bwd_amax(const float* y, const float* norm, c
     COCOS_REQUIRE(dx_amax_inout, COCOS_ERR_INVALID, "center_l2norm_bwd_amax: null amax cell");
     return center_l2norm_bwd_impl(y, norm, dy, dx, col_ws, row_ws, B, K, N, center_over_channels, eps,
                                   dx_amax_inout, stream);
+}
+
+// K1 forward for the split-precision correlation kernels (K == 256, N % 4 == 0; PONO_C centring or none): writes the row
+// norms and the operand planes of plane_scale * y directly — position-major [B,N,256] (pos_hi / pos_lo: always) and
+// channel-major [B,256,N] (chan_hi / chan_lo: nullable, wanted by the backward) — and NO fp32 y.
+extern "C" int cocos_center_l2norm_fwd_planes(const float* x, float* norm, void* pos_hi, void* pos_lo, void* chan_hi,
+                                              void* chan_lo, int B, int K, int N, int center_over_channels, float eps,
+                                              float plane_scale, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && norm && pos_hi && pos_lo, COCOS_ERR_INVALID, "center_l2norm_fwd_planes: null pointer");
+    COCOS_REQUIRE((chan_hi == nullptr) == (chan_lo == nullptr), COCOS_ERR_INVALID,
+                  "center_l2norm_fwd_planes: channel-major planes come as a hi/lo pair");
+    COCOS_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && plane_scale > 0.f, COCOS_ERR_INVALID,
+                  "center_l2norm_fwd_planes: bad dims B=%d N=%d", B, N);
+    COCOS_REQUIRE(K == 256 && N % 4 == 0 && (center_over_channels == 1 || center_over_channels == 2), COCOS_ERR_UNSUPPORTED,
+                  "center_l2norm_fwd_planes: needs K == 256, N %% 4 == 0, centring over channels or none (K=%d N=%d mode=%d)",
+                  K, N, center_over_channels);
+    for (const void* p : {(const void*)x, (const void*)norm, (const void*)pos_hi, (const void*)pos_lo})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "center_l2norm_fwd_planes: pointers must be 16-byte aligned");
+    COCOS_REQUIRE(!chan_hi || ((reinterpret_cast<uintptr_t>(chan_hi) | reinterpret_cast<uintptr_t>(chan_lo)) & 7u) == 0,
+                  COCOS_ERR_INVALID, "center_l2norm_fwd_planes: channel-major planes must be 8-byte aligned");
+    hipLaunchKernelGGL(center_l2norm_fwd_planes_kernel, dim3((N + 63) / 64, B), dim3(256), 0, as_stream(stream), x, norm,
+                       static_cast<_Float16*>(pos_hi), static_cast<_Float16*>(pos_lo), static_cast<_Float16*>(chan_hi),
+                       static_cast<_Float16*>(chan_lo), N, eps, center_over_channels == 1, plane_scale);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+// ... and its backward: y comes from the channel-major planes; *dx_amax_inout (nullable) as in cocos_center_l2norm_bwd_amax.
+extern "C" int cocos_center_l2norm_bwd_planes(const void* chan_hi, const void* chan_lo, const float* norm, const float* dy,
+                                              float* dx, int B, int K, int N, int center_over_channels, float eps,
+                                              float plane_scale, float* dx_amax_inout, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(chan_hi && chan_lo && norm && dy && dx, COCOS_ERR_INVALID, "center_l2norm_bwd_planes: null pointer");
+    COCOS_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && plane_scale > 0.f, COCOS_ERR_INVALID,
+                  "center_l2norm_bwd_planes: bad dims B=%d N=%d", B, N);
+    COCOS_REQUIRE(K == 256 && N % 4 == 0 && (center_over_channels == 1 || center_over_channels == 2), COCOS_ERR_UNSUPPORTED,
+                  "center_l2norm_bwd_planes: needs K == 256, N %% 4 == 0, centring over channels or none (K=%d N=%d mode=%d)",
+                  K, N, center_over_channels);
+    COCOS_REQUIRE(aligned16(dy) && aligned16(dx) && aligned16(norm), COCOS_ERR_INVALID,
+                  "center_l2norm_bwd_planes: dy, dx, norm must be 16-byte aligned");
+    hipLaunchKernelGGL(center_l2norm_bwd_planes_kernel, dim3((N + 63) / 64, B), dim3(256), 0, as_stream(stream),
+                       static_cast<const _Float16*>(chan_hi), static_cast<const _Float16*>(chan_lo), norm, dy, dx, N, eps,
+                       center_over_channels == 1, 1.0f / plane_scale, reinterpret_cast<unsigned*>(dx_amax_inout));
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
 }

@@ -9,15 +9,18 @@
 // byte crosses HBM once (64-byte bursts hold 4 of the wanted floats): 79 MB + 6 MB in, 20 MB out.
 // One thread per OUTPUT element: a wave reads 64 x 16-byte-strided floats = 1 KB of a label row / writes 256
 // contiguous bytes; the image channels (3 of 154) take their d x d window as d float4 loads when d == 4.
+#include <algorithm>
+
 #include "common.h"
 
 namespace cocos {
 
 __global__ __launch_bounds__(256) void warp_values_kernel(const float* __restrict__ img, const float* __restrict__ seg,
                                                           float* __restrict__ out, int Ci, int Cs, int h, int w, int d,
-                                                          size_t n, bool vec4) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+                                                          size_t n, bool vec4, unsigned* __restrict__ amax) {
+  float vmax = 0.f;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const int x = (int)(i % w);
     size_t r = i / w;
     const int y = (int)(r % h);
@@ -44,14 +47,25 @@ __global__ __launch_bounds__(256) void warp_values_kernel(const float* __restric
         v = acc / (float)(d * d);
     }
     out[i] = v;
+    vmax = fmaxf(vmax, fabsf(v));
+  }
+  // max|V| as a by-product (the K2 forward's f16 split of V wants it): one same-address atomic per workgroup, the
+  // grid of the _amax entry point is capped accordingly
+  if (amax) {
+      __shared__ float red[4];
+      vmax = wave_max_dpp(vmax);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+      __syncthreads();
+      if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+  }
 }
 
 }  // namespace cocos
 
 // out [B, Ci+Cs, H/down, W/down]: channels [0,Ci) = down x down mean of img [B,Ci,H,W]; channels [Ci,Ci+Cs) =
 // seg [B,Cs,H,W] sampled at (y*down, x*down).  Either part may be absent (Ci == 0 / Cs == 0 with a NULL pointer).
-extern "C" int cocos_warp_values(const float* img, const float* seg, float* out, int B, int Ci, int Cs, int H, int W,
-                                 int down, cocos_stream_t stream) {
+static int warp_values_impl(const float* img, const float* seg, float* out, int B, int Ci, int Cs, int H, int W, int down,
+                            float* amax_inout_dev, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(out && (img || Ci == 0) && (seg || Cs == 0), COCOS_ERR_INVALID, "warp_values: null pointer");
     COCOS_REQUIRE(B >= 1 && Ci >= 0 && Cs >= 0 && Ci + Cs >= 1 && H >= 1 && W >= 1 && down >= 1, COCOS_ERR_INVALID,
@@ -61,8 +75,21 @@ extern "C" int cocos_warp_values(const float* img, const float* seg, float* out,
     const size_t n = (size_t)B * (Ci + Cs) * (H / down) * (W / down);
     COCOS_REQUIRE((n + 255) / 256 <= 0x7fffffffull, COCOS_ERR_UNSUPPORTED, "warp_values: tensor too large");
     const bool vec4 = down == 4 && W % 4 == 0 && img && aligned16(img);
-    hipLaunchKernelGGL(warp_values_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), img, seg,
-                       out, Ci, Cs, H / down, W / down, down, n, vec4);
+    const size_t blocks = amax_inout_dev ? std::min<size_t>(1024, (n + 255) / 256) : (n + 255) / 256;
+    hipLaunchKernelGGL(warp_values_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), img, seg,
+                       out, Ci, Cs, H / down, W / down, down, n, vec4, reinterpret_cast<unsigned*>(amax_inout_dev));
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+extern "C" int cocos_warp_values(const float* img, const float* seg, float* out, int B, int Ci, int Cs, int H, int W,
+                                 int down, cocos_stream_t stream) {
+    return warp_values_impl(img, seg, out, B, Ci, Cs, H, W, down, nullptr, stream);
+}
+
+// Same, and *amax_inout_dev = max(*amax_inout_dev, max|out|) (a cell holding a finite value >= 0, e.g. zero).
+extern "C" int cocos_warp_values_amax(const float* img, const float* seg, float* out, int B, int Ci, int Cs, int H, int W,
+                                      int down, float* amax_inout_dev, cocos_stream_t stream) {
+    COCOS_REQUIRE(amax_inout_dev, COCOS_ERR_INVALID, "warp_values_amax: null amax cell");
+    return warp_values_impl(img, seg, out, B, Ci, Cs, H, W, down, amax_inout_dev, stream);
 }

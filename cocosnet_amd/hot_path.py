@@ -69,6 +69,8 @@ class _SplitChannels(torch.autograd.Function):
         for g, c in ((ga, n), (gb, shape[1] - n)):
             parts.append(g if g is not None else torch.zeros((shape[0], c) + tuple(shape[2:]), device=(ga if ga is not None else gb).device,
                                                              dtype=(ga if ga is not None else gb).dtype))
+        if ga is not None and gb is not None and ga.is_cuda and ga.dtype == torch.float32 and gb.dtype == torch.float32:
+            return ops.concat_channels_amax(ga, gb), None      # one kernel, and max|.| for the K2 backward's f16 split
         return torch.cat(parts, dim=1), None
 
 
@@ -99,7 +101,7 @@ class _Attention:
        streamed   logits materialised once per orientation, softmax + warp fused (match_kernel 3);
        generic    materialised logits -> row softmax -> GEMM (return_corr / WTA / everything else)."""
 
-    def __init__(self, qn=None, kn=None, inv_t=1.0, f_scaled=None, logits_q=None, logits_k=None, boxed=None):
+    def __init__(self, qn=None, kn=None, inv_t=1.0, f_scaled=None, logits_q=None, logits_k=None, boxed=None, planes=None):
         self.qn, self.kn, self.inv_t = qn, kn, inv_t
         self.fused = qn is not None
         self._boxed = boxed                          # match_kernel 3 fused (K19 / K20): a _BoxedCorr
@@ -108,7 +110,7 @@ class _Attention:
         self._cache = {}
         # f16 operand planes of theta/phi, shared by the row / column / second row pass of THIS forward call
         # (per-call object: nothing is cached across calls or threads)
-        self._planes = ops.OperandPlanes() if self.fused else None
+        self._planes = (planes if planes is not None else ops.OperandPlanes()) if self.fused else None
 
     def _get(self, name, fn):
         if name not in self._cache:
@@ -242,11 +244,20 @@ def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_
     fused = (mk == 1) and (C == ops.FUSED_K) and WTA_scale_weight == 1 and not return_corr
     if fused:
         # :272-289 — flatten, centre, L2-normalise; the rest happens inside the fused kernels
-        qn = ops.center_l2norm(_flat(theta_raw), cfg.PONO_C)
-        kn = ops.center_l2norm(_flat(phi_raw), cfg.PONO_C)
+        th_f, ph_f = _flat(theta_raw), _flat(phi_raw)
         if detach_flag:   # :292-293 `f = f.detach()`: nothing upstream of f receives a gradient
-            qn, kn = qn.detach(), kn.detach()
-        attn = _Attention(qn=qn, kn=kn, inv_t=inv_t)
+            th_f, ph_f = th_f.detach(), ph_f.detach()
+        keep = torch.is_grad_enabled() and (th_f.requires_grad or ph_f.requires_grad)
+        planes = ops.OperandPlanes()
+        if (ops.NORM_PLANES and cfg.PONO_C and _hip_fp32(theta_raw)
+                and ops.corr_split_ok(B, C, fh * fw, fh * fw, 1, keep)):
+            # K1 writes the operand planes of the split kernels itself: fp32 qn / kn never exist (ops.center_l2norm_planes)
+            qn = ops.center_l2norm_planes(th_f, 1, planes)
+            kn = ops.center_l2norm_planes(ph_f, 1, planes)
+        else:
+            qn = ops.center_l2norm(th_f, cfg.PONO_C)
+            kn = ops.center_l2norm(ph_f, cfg.PONO_C)
+        attn = _Attention(qn=qn, kn=kn, inv_t=inv_t, planes=planes)
     elif (mk == 3 and cfg.PONO_C and WTA_scale_weight == 1 and not return_corr and _hip_fp32(theta_raw)
           and ops.box3_fused_ok(B, C, fh, fw)):
         # the reference's default: 3x3 neighbourhoods, fused (round 3): x box in the correlation GEMM, y box + softmax + warp

@@ -161,6 +161,69 @@ def feature_normalize(x: torch.Tensor, eps: float = NORM_EPS):
     return _CenterL2Norm.apply(x.reshape(B, C, -1), 2, eps).reshape(x.shape)
 
 
+#: K1 writes the f16 operand planes of the split correlation kernels itself (no fp32 qn / kn, no split launches); "0":
+#: fp32 K1 + cocos_split_f16 as in rounds 1-2 (A/B runs)
+NORM_PLANES = os.environ.get("COCOS_NORM_PLANES", "1") != "0"
+
+
+class _CenterL2NormPlanes(torch.autograd.Function):
+    """K1 for the split flavour: x [B,256,N] -> operand planes (handed to the caller's OperandPlanes) + norms.  The autograd
+    OUTPUT is only a handle: a view of x (no new memory) whose VALUES are x's, not the normalised tensor's — the split
+    correlation kernels never read it, they read the planes; its gradient (d qn from K2's backward) comes back here."""
+
+    @staticmethod
+    def forward(ctx, x, center_over_channels: int, eps: float, planes, want_chan: bool):
+        x = _chk(x, "center_l2norm_planes: x")
+        B, K, N = x.shape
+        half = dict(device=x.device, dtype=torch.float16)
+        norm = torch.empty((B, N), device=x.device, dtype=torch.float32)
+        ph, pl = torch.empty((B, N, K), **half), torch.empty((B, N, K), **half)
+        ch = cl = None
+        if want_chan:
+            ch, cl = torch.empty((B, K, N), **half), torch.empty((B, K, N), **half)
+        _call("center_l2norm_fwd", "cocos_center_l2norm_fwd_planes", x.data_ptr(), norm.data_ptr(), ph.data_ptr(),
+              pl.data_ptr(), _ptr(ch), _ptr(cl), B, K, N, int(center_over_channels), float(eps), SPLIT_OPERAND_SCALE, _stream())
+        handle = x.view_as(x)
+        planes.put(handle, True, SPLIT_OPERAND_SCALE, ph, pl)
+        if want_chan:
+            planes.put(handle, False, SPLIT_OPERAND_SCALE, ch, cl)
+        ctx.save_for_backward(norm, ch, cl)
+        ctx.cfg = (int(center_over_channels), float(eps))
+        return handle
+
+    @staticmethod
+    def backward(ctx, dy):
+        norm, ch, cl = ctx.saved_tensors
+        mode, eps = ctx.cfg
+        dy = _chk(dy, "center_l2norm_planes: dy")
+        B, K, N = dy.shape
+        if ch is None:
+            raise _lib.CocosHipError("center_l2norm_planes: backward without the channel-major planes (forward ran without grad)")
+        dx = torch.empty_like(dy)
+        cell = _zero_cell(dx.device) if PROJ_PRECISION == "f16x3" else None
+        _call("center_l2norm_bwd", "cocos_center_l2norm_bwd_planes", ch.data_ptr(), cl.data_ptr(), norm.data_ptr(),
+              dy.data_ptr(), dx.data_ptr(), B, K, N, mode, eps, SPLIT_OPERAND_SCALE, _ptr(cell), _stream())
+        if cell is not None:
+            _remember_amax(dx, cell)
+        return dx, None, None, None, None
+
+
+def center_l2norm_planes(x: torch.Tensor, center_over_channels, planes: OperandPlanes, eps: float = NORM_EPS):
+    """K1 whose only products are the operand planes of the split correlation kernels (registered in `planes`) — see
+    _CenterL2NormPlanes.  Returns the autograd handle to pass to corr_softmax_warp(..., planes=planes) as qn / kn.  Only
+    for callers that take the split path (corr_split_ok)."""
+    want_chan = torch.is_grad_enabled() and x.requires_grad
+    return _CenterL2NormPlanes.apply(x, int(center_over_channels), eps, planes, want_chan)
+
+
+def corr_split_ok(B, K, Nq, Nk, Cv, keep: bool) -> bool:
+    """True when corr_softmax_warp takes the split-precision kernels for this shape (forward and, when `keep`, backward):
+    the condition under which qn / kn may exist as operand planes only."""
+    chunk = min(Cv, MAX_FUSED_SPLIT_CV)
+    return (PRECISION == "f16x3" and K == FUSED_K and Nk % 4 == 0 and Nq % 4 == 0
+            and (not keep or (_split_bwd_ok(B, Nq, Nk, chunk) and _split_bwd_ok(B, Nk, Nq, chunk))))
+
+
 # ------------------------------------------------------------------------------------------
 # K2  fused correlation -> softmax -> warp     (correspondence.py:291,:304,:307,:318)
 # ------------------------------------------------------------------------------------------
@@ -173,13 +236,25 @@ class OperandPlanes:
     def __init__(self):
         self._planes = {}
 
+    def put(self, x: torch.Tensor, transpose: bool, scale: float, hi: torch.Tensor, lo: torch.Tensor):
+        """Planes a producer kernel wrote itself (K1's planes flavour): later get() calls for `x` return them."""
+        self._planes[(id(x), bool(transpose), float(scale))] = (x, x._version, hi, lo, True)
+
     def get(self, x: torch.Tensor, transpose: bool, scale: float):
         key = (id(x), bool(transpose), float(scale))
         ent = self._planes.get(key)
+        if ent is not None and ent[0] is x and len(ent) > 4:
+            # producer-made planes: x is only a handle (its VALUES are not what the planes hold), they cannot be re-made
+            if ent[1] != x._version:
+                raise _lib.CocosHipError("OperandPlanes: the tensor behind producer-made operand planes was modified in place")
+            return ent[2], ent[3]
         if ent is None or ent[0] is not x or ent[1] != x._version:
             hi, lo = split_f16(x, transpose, scale)
             ent = self._planes[key] = (x, x._version, hi, lo)     # holds x: its id cannot be recycled meanwhile
         return ent[2], ent[3]
+
+    def has(self, x: torch.Tensor) -> bool:
+        return any(k[0] == id(x) and e[0] is x for k, e in self._planes.items())
 
     def __len__(self):
         return len(self._planes)
@@ -207,6 +282,23 @@ def split_f16(x: torch.Tensor, transpose: bool, scale: float = 1.0, cpad=None, a
     _call("split_f16", "cocos_split_f16", x.data_ptr(), hi.data_ptr(), lo.data_ptr(), B, C, N, int(bool(transpose)),
           float(scale), _stream())
     return hi, lo
+
+
+def split_f16_chan_mask(x: torch.Tensor, amax: torch.Tensor, want_mask: bool):
+    """x [B,C,N] -> (hi, lo, scale_tensor, mask_cell | None): the channel-major planes of split_f16(x, False, amax=amax) and,
+    when `want_mask`, f16_plane_block_mask(lo), in ONE launch (cocos_split_f16_chan_mask; N % 4 == 0, else two launches)."""
+    x = _chk(x, "split_f16_chan_mask: x")
+    B, C, N = x.shape
+    if N % 4 != 0 or C > 1024 or x.data_ptr() % 16 != 0:
+        hi, lo, sc = split_f16(x, False, amax=amax)
+        return hi, lo, sc, (f16_plane_block_mask(lo) if want_mask else None)
+    hi = torch.empty((B, C, N), device=x.device, dtype=torch.float16)
+    lo = torch.empty((B, C, N), device=x.device, dtype=torch.float16)
+    sc = torch.empty(1, device=x.device, dtype=torch.float32)
+    mask = _zero_cell(x.device) if want_mask else None          # fp32 zero = integer zero
+    _call("split_f16", "cocos_split_f16_chan_mask", x.data_ptr(), hi.data_ptr(), lo.data_ptr(), B, C, N, amax.data_ptr(),
+          sc.data_ptr(), _ptr(mask), _stream())
+    return hi, lo, sc, mask
 
 
 def f16_plane_block_mask(plane: torch.Tensor) -> torch.Tensor:
@@ -283,7 +375,9 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             # forward only takes this flavour (and saves its private logits layout) for shapes this branch takes.
             qch, qcl, kch, kcl = ctx.cplanes
             cvp = (Cv + 31) // 32 * 32
-            g_amax, v_amax = absmax(dout), ctx.v_amax         # max|v| was taken once, by the forward
+            g_amax, v_amax = _recall_amax(dout), ctx.v_amax   # max|v| was taken once, by the forward; max|dout| comes
+            if g_amax is None:                                # with dout when concat_channels_amax produced it
+                g_amax = absmax(dout)
             gph, gpl, g_scale = split_f16(dout, True, cpad=cvp, amax=g_amax)
             vph, vpl, v_scale = split_f16(v, True, cpad=cvp, amax=v_amax)
             half = dict(device=qn.device, dtype=torch.float16)
@@ -366,6 +460,9 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes |
              and (not keep or _split_bwd_ok(B, Nq, Nk, chunk)))
     if planes is None:
         planes = OperandPlanes()
+    if not split and (planes.has(qn) or planes.has(kn)):
+        raise _lib.CocosHipError("corr_softmax_warp: qn / kn exist as operand planes only (center_l2norm_planes) but this "
+                                 "shape does not take the split-precision kernels")
 
     def run(vv):
         pl = None
@@ -376,10 +473,9 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes |
                 v_amax = _recall_amax(vv)
                 if v_amax is None:
                     v_amax = absmax(vv)
-                vh, vl, v_scale = split_f16(vv, False, amax=v_amax)
-                # which 32-channel blocks of V have a non-zero lo plane (one-hot labels / masks are exact in f16:
-                # theirs is all zero and the kernels skip it) — one pass over the lo plane, only when it can pay
-                v_lomask = f16_plane_block_mask(vl) if (VALUE_LO_SKIP and vv.shape[1] > 32) else None
+                # V planes, and which 32-channel blocks of V have a non-zero lo plane (one-hot labels / masks are exact in
+                # f16: theirs is all zero and the kernels skip it) — the same launch, only when it can pay
+                vh, vl, v_scale, v_lomask = split_f16_chan_mask(vv, v_amax, VALUE_LO_SKIP and vv.shape[1] > 32)
                 pl = (*planes.get(qn, True, SPLIT_OPERAND_SCALE), *planes.get(kn, True, SPLIT_OPERAND_SCALE),
                       vh, vl, v_scale, v_amax, v_lomask)
                 if keep:   # the backward wants the channel-major planes as well
@@ -608,8 +704,16 @@ class _Proj1x1(torch.autograd.Function):
                 wh = torch.empty((Cout, kp), device=x.device, dtype=torch.float16)
                 wl = torch.empty((Cout, kp), device=x.device, dtype=torch.float16)
                 ws = torch.empty(1, device=x.device, dtype=torch.float32)
-                _call("split_f16", "cocos_split_f16_rows", w2.data_ptr(), wh.data_ptr(), wl.data_ptr(), Cout, Cin, kp,
-                      1.0, wa.data_ptr(), ws.data_ptr(), _stream())
+                # ... and, when the input gradient will be wanted, the transposed planes [Cin][Kpad(Cout)] of dx = W^T dy
+                # in the same launch (they used to be a second split in the backward)
+                th = tl = None
+                if ctx.needs_input_grad[0]:
+                    kpo = lib.cocos_proj1x1_stream_kpad(Cout)
+                    th = torch.empty((Cin, kpo), device=x.device, dtype=torch.float16)
+                    tl = torch.empty((Cin, kpo), device=x.device, dtype=torch.float16)
+                _call("split_f16", "cocos_proj_weight_planes", w2.data_ptr(), wh.data_ptr(), wl.data_ptr(), _ptr(th), _ptr(tl),
+                      Cout, Cin, kp, lib.cocos_proj1x1_stream_kpad(Cout), wa.data_ptr(), ws.data_ptr(), _stream())
+                ctx.t_planes = (th, tl, ws) if th is not None else None
                 _call("proj1x1_fwd", "cocos_proj1x1_stream_f16x3", x.data_ptr(), wh.data_ptr(), wl.data_ptr(),
                       ws.data_ptr(), _ptr(bb), y.data_ptr(), B, Cin, Cout, h * w, xa.data_ptr(), _stream())
             else:
@@ -645,8 +749,11 @@ class _Proj1x1(torch.autograd.Function):
                 ga = absmax(dy)
             dx_gemm, dw_gemm = need_x, need_w
             if ctx.stream and need_x:     # dx = W^T dy, same streaming kernel with the transposed weight planes
-                th, tl, ts = split_f16(w2.unsqueeze(0), transpose=True, cpad=lib.cocos_proj1x1_stream_kpad(Cout),
-                                       amax=wa)
+                if getattr(ctx, "t_planes", None) is not None:
+                    th, tl, ts = ctx.t_planes
+                else:
+                    th, tl, ts = split_f16(w2.unsqueeze(0), transpose=True, cpad=lib.cocos_proj1x1_stream_kpad(Cout),
+                                           amax=wa)
                 _call("proj1x1_bwd", "cocos_proj1x1_stream_f16x3", dy.data_ptr(), th.data_ptr(), tl.data_ptr(),
                       ts.data_ptr(), None, dx.data_ptr(), B, Cout, Cin, N, ga.data_ptr(), _stream())
                 dx_gemm = False
@@ -1300,8 +1407,30 @@ def warp_values(img, seg_map, down: int):
     if seg is not None and (seg.shape[0], seg.shape[2], seg.shape[3]) != (B, H, W):
         raise ValueError(f"warp_values: seg_map {tuple(seg.shape)} does not match img {tuple(img.shape)}")
     out = torch.empty((B, Ci + Cs, H // down, W // down), device=img.device, dtype=torch.float32)
+    if PRECISION == "f16x3":      # max|V| as a by-product: the consumer (the K2 forward's f16 split of V) picks it up
+        cell = _zero_cell(out.device)
+        _call("warp_values", "cocos_warp_values_amax", img.data_ptr(), _ptr(seg), out.data_ptr(), B, Ci, Cs, H, W, int(down),
+              cell.data_ptr(), _stream())
+        _remember_amax(out, cell)
+        return out
     _call("warp_values", "cocos_warp_values", img.data_ptr(), _ptr(seg), out.data_ptr(), B, Ci, Cs, H, W, int(down),
           _stream())
+    return out
+
+
+def concat_channels_amax(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat((a, b), dim=1) of two fp32 CUDA tensors whose per-sample sizes are multiples of 4, with max|result| left for
+    the consumer (the f16 split of the K2 backward's dout) — one kernel instead of a framework copy + a max pass."""
+    a, b = _chk(a, "concat_channels_amax: a"), _chk(b, "concat_channels_amax: b")
+    B = a.shape[0]
+    na, nb = a.numel() // B, b.numel() // B
+    if b.shape[0] != B or a.shape[2:] != b.shape[2:] or na % 4 or nb % 4 or a.data_ptr() % 16 or b.data_ptr() % 16:
+        return torch.cat((a, b), dim=1)
+    out = torch.empty((B, a.shape[1] + b.shape[1]) + tuple(a.shape[2:]), device=a.device, dtype=torch.float32)
+    cell = _zero_cell(out.device) if PRECISION == "f16x3" else None
+    _call("concat2_amax", "cocos_concat2_amax", a.data_ptr(), b.data_ptr(), out.data_ptr(), B, na, nb, _ptr(cell), _stream())
+    if cell is not None:
+        _remember_amax(out, cell)
     return out
 
 

@@ -72,6 +72,18 @@ int cocos_center_l2norm_bwd_amax(const float* y, const float* norm, const float*
                                  float* row_ws, int B, int K, int N, int center_over_channels, float eps,
                                  float* dx_amax_inout, cocos_stream_t stream);
 
+/* K1 for the split-precision correlation kernels (round 3): the forward writes the f16 hi/lo OPERAND PLANES of
+ * plane_scale * y itself — position-major [B,N,256] (always) and channel-major [B,256,N] (nullable pair; the backward wants
+ * them) — and no fp32 y: 12 B/element instead of 24 for K1 + two cocos_split_f16 launches per tensor.  K == 256,
+ * N % 4 == 0, center_over_channels 1 (PONO_C) or 2 (none).  The planes are bit-identical to cocos_split_f16(y, scale).
+ * The backward reads y back from the channel-major planes. */
+int cocos_center_l2norm_fwd_planes(const float* x, float* norm, void* pos_hi, void* pos_lo, void* chan_hi /* nullable */,
+                                   void* chan_lo /* nullable */, int B, int K, int N, int center_over_channels, float eps,
+                                   float plane_scale, cocos_stream_t stream);
+int cocos_center_l2norm_bwd_planes(const void* chan_hi, const void* chan_lo, const float* norm, const float* dy, float* dx,
+                                   int B, int K, int N, int center_over_channels, float eps, float plane_scale,
+                                   float* dx_amax_inout /* nullable */, cocos_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * K2  fused correlation -> /temperature -> softmax over key positions -> warp
  *     (correspondence.py:281,291,304,307,318 and the extra P@V products at :334,:343-344,
@@ -384,6 +396,27 @@ int cocos_upsample_nearest_bwd(const float* dy, float* dx, int planes, int h, in
  *   Forward only (the exemplar image and its label map are data).  H, W multiples of down. */
 int cocos_warp_values(const float* img, const float* seg, float* out, int B, int Ci, int Cs, int H, int W,
                       int down, cocos_stream_t stream);
+/* Same, and *amax_inout_dev = max(*amax_inout_dev, max|out|): the scale source of the K2 forward's f16 split of V comes out
+ * of the kernel that writes V. */
+int cocos_warp_values_amax(const float* img, const float* seg, float* out, int B, int Ci, int Cs, int H, int W,
+                           int down, float* amax_inout_dev, cocos_stream_t stream);
+
+/* Plane preparation folded into kernels that already touch the data (csrc/plane_prep.hip):
+ *   cocos_concat2_amax: out[b] = [a[b] | b[b]] (torch.cat of two [B, *] fp32 tensors along dim 1; na, nb = elements per
+ *       sample, multiples of 4) and *amax_inout_dev = max(., max|out|) — the backward of the row pass's output split, whose
+ *       result is the `dout` of the K2 backward.
+ *   cocos_split_f16_chan_mask: cocos_split_f16_ex(transpose = 0, amax_dev) + cocos_f16_plane_block_mask(lo) in one launch.
+ *   cocos_proj_weight_planes: the f16 hi/lo planes of a 1x1-projection weight w [Cout][Cin] in both orientations —
+ *       rows [Cout][KpadIn] (= cocos_split_f16_rows) and, when t_hi/t_lo are given, transposed [Cin][KpadOut]
+ *       (= cocos_split_f16_ex(transpose = 1, Cpad = KpadOut)) — scaled by the power of two from *amax_dev. */
+int cocos_concat2_amax(const float* a, const float* b, float* out, int B, long long na, long long nb,
+                       float* amax_inout_dev /* nullable */, cocos_stream_t stream);
+int cocos_split_f16_chan_mask(const float* x, void* hi, void* lo, int B, int C, int N, const float* amax_dev,
+                              float* scale_out_dev /* nullable */, unsigned* mask_inout_dev /* nullable */,
+                              cocos_stream_t stream);
+int cocos_proj_weight_planes(const float* w, void* rows_hi, void* rows_lo, void* t_hi /* nullable */,
+                             void* t_lo /* nullable */, int Cout, int Cin, int KpadIn, int KpadOut, const float* amax_dev,
+                             float* scale_out_dev /* nullable */, cocos_stream_t stream);
 
 /* K7 on the f16 MFMA (same contract as cocos_logits_softmax_warp_fwd / _bwd; operand planes as for K2's split flavour):
  *   fwd: vh,vl [B,Cv,Nk] channel-major planes of s_v*v, s_v = *v_scale_dev (NULL = 1; undone in the epilogue); Nk % 4 == 0
