@@ -21,6 +21,13 @@
 // mean over the 9*256 entries and 1 / (norm + eps).  kc = 2304.
 #include "box3_common.h"
 
+// Ablation builds (debug only, results are WRONG): -DBX_ABLATE=<bits>  1: no column sums (butterfly + LDS atomics),
+// 2: no G / P-plane stores, 4: only the centre T block is loaded (no y box), 8: no MFMAs, 16: key statistics not loaded,
+// 32: no exp — tools/box3_ablate.sh times them.
+#ifndef BX_ABLATE
+#define BX_ABLATE 0
+#endif
+
 namespace cocos {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -36,18 +43,18 @@ __device__ __forceinline__ f32x16 bx_mfma(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// The three T blocks of one tile and the key statistics of its 32 keys, in flight one tile ahead.
+// The three T blocks of one tile, in flight one tile ahead.
 struct BxTile {
     f32x4 s[3][4];      // [dy + 1][g]: accumulator registers 4g..4g+3
-    f32x4 bk[4], nu[4]; // b_k and nu_k of keys 8g + 4h + 0..3
 };
 
 // Geometry of a wave's query block, fixed for the kernel.
 struct BxGeom {
-    __amdgpu_buffer_rsrc_t t_rs, b_rs, nu_rs;
+    __amdgpu_buffer_rsrc_t t_rs;
     int qblk, py, tpr, himg, nqblk;
     unsigned lane_off;      // lane * 16
-    unsigned stat_off;      // 4h floats
+    const float* kstat;     // LDS: [b_q (Nk floats) | kc * nu_q * b_q (Nk floats)] of this sample's keys
+    int nk;
 };
 
 __device__ __forceinline__ void bx_fetch(BxTile& tl, const BxGeom& gm, int t, int ntiles) {
@@ -56,6 +63,7 @@ __device__ __forceinline__ void bx_fetch(BxTile& tl, const BxGeom& gm, int t, in
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int dy = d - 1;
+        if ((BX_ABLATE & 4) && d != 1) continue;
         const bool ok = (unsigned)(gm.py + dy) < (unsigned)gm.himg && (unsigned)(ky + dy) < (unsigned)gm.himg;
         const int blk = ok ? (tc + dy * gm.tpr) * gm.nqblk + gm.qblk + dy * gm.tpr : 0;
         const unsigned voff = ok ? gm.lane_off : kBufOob;
@@ -64,25 +72,36 @@ __device__ __forceinline__ void bx_fetch(BxTile& tl, const BxGeom& gm, int t, in
             tl.s[d][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 gm.t_rs, (int)voff, (int)((unsigned)blk * 4096u + (unsigned)g * 1024u), 0));
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const unsigned soff = (unsigned)(tc * 32 + 8 * g) * 4u;
-        tl.bk[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gm.b_rs, (int)gm.stat_off, (int)soff, 0));
-        tl.nu[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gm.nu_rs, (int)gm.stat_off, (int)soff, 0));
+}
+
+// The per-key statistics of the whole sample go to LDS once per workgroup (b_q and kn_q = kc * nu_q * b_q: 8 Nk bytes);
+// every tile then reads its 2 x 16 values per lane as broadcast 16-byte LDS reads.  (Round-3 ablation: fetching them from
+// global memory per tile — 8 buffer loads whose 32 lanes share an address — cost 0.06 ms of the 0.46 ms backward.)
+__device__ __forceinline__ void bx_stage_stats(float* kstat, const float* __restrict__ b_k, const float* __restrict__ nu_k,
+                                               int Nk, float kc, int tid) {
+    for (int i = tid; i < Nk; i += 256) {
+        const float bq = b_k[i];
+        kstat[i] = bq;
+        kstat[Nk + i] = kc * nu_k[i] * bq;
     }
 }
 
 // tt[r] = b_q * (T_sum) - mu_p * kc * nu_q * b_q  (the logit without its per-query factor scale * a_p); also returns
-// b_q and kc * nu_q * b_q per register for the backward.
-__device__ __forceinline__ void bx_logits(const BxTile& tl, float mu_p, float kc, float (&tt)[16], float (&bq)[16],
-                                          float (&kn)[16]) {
+// b_q and kn_q per register for the backward.
+__device__ __forceinline__ void bx_logits(const BxTile& tl, const BxGeom& gm, int t, int h, float mu_p, float (&tt)[16],
+                                          float (&bq)[16], float (&kn)[16]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int g = r >> 2, e = r & 3;
-        const float ts = (tl.s[0][g][e] + tl.s[2][g][e]) + tl.s[1][g][e];
-        bq[r] = tl.bk[g][e];
-        kn[r] = kc * tl.nu[g][e] * bq[r];
-        tt[r] = __builtin_fmaf(bq[r], ts, -(mu_p * kn[r]));
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(gm.kstat + t * 32 + 8 * g + 4 * h);
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(gm.kstat + gm.nk + t * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const float ts = (BX_ABLATE & 4) ? tl.s[1][g][e] : (tl.s[0][g][e] + tl.s[2][g][e]) + tl.s[1][g][e];
+            bq[r] = b4[e];
+            kn[r] = k4[e];
+            tt[r] = __builtin_fmaf(bq[r], ts, -(mu_p * kn[r]));
+        }
     }
 }
 
@@ -98,6 +117,7 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
     constexpr int CVP = CVB * 32, VPLANE = CVP * BX_VROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
     _Float16* const vt = reinterpret_cast<_Float16*>(bx_smem);      // [2 buf][hi|lo|hi*2^-11][CVP][VROW]
+    float* const kstat = reinterpret_cast<float*>(vt + 2 * 3 * VPLANE);   // [b | kn][Nk]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
@@ -105,21 +125,21 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
     const int b = vb / nqb, q0 = (vb % nqb) * 128;
     const int i_lane = q0 + wave * 32 + c;
+    bx_stage_stats(kstat, b_k + (size_t)b * Nk, nu_k + (size_t)b * Nk, Nk, kc, tid);
 
     const size_t vbytes = (size_t)Cv * Nk * 2;
     const __amdgpu_buffer_rsrc_t vh_rs = make_rsrc(vh + (size_t)b * Cv * Nk, vbytes);
     const __amdgpu_buffer_rsrc_t vl_rs = make_rsrc(vl + (size_t)b * Cv * Nk, vbytes);
     BxGeom gm;
     gm.t_rs = make_rsrc(T + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
-    gm.b_rs = make_rsrc(b_k + (size_t)b * Nk, (size_t)Nk * 4);
-    gm.nu_rs = make_rsrc(nu_k + (size_t)b * Nk, (size_t)Nk * 4);
+    gm.kstat = kstat;
+    gm.nk = Nk;
     gm.tpr = wimg / 32;
     gm.qblk = (q0 >> 5) + wave;
     gm.py = gm.qblk / gm.tpr;
     gm.himg = himg;
     gm.nqblk = Nq >> 5;
     gm.lane_off = (unsigned)lane * 16u;
-    gm.stat_off = (unsigned)h * 16u;
 
     const float mu_p = mu_q[(size_t)b * Nq + i_lane];
     const float a2 = a_q[(size_t)b * Nq + i_lane] * scale * kLog2e;      // log2-domain factor of this query's logits (> 0)
@@ -163,7 +183,7 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 32, buf = t & 1;
         float tt[16], bq[16], kn[16];
-        bx_logits(tl, mu_p, kc, tt, bq, kn);
+        bx_logits(tl, gm, t, h, mu_p, tt, bq, kn);
         bx_fetch(tl, gm, t + 1, ntiles);                  // the next tile's blocks have the whole MFMA loop to arrive
         float tmax = tt[0];
 #pragma unroll
@@ -188,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
         const float nmb = kBxPBias - m_run;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            p[r] = fast_exp2(__builtin_fmaf(tt[r], a2, nmb));
+            p[r] = (BX_ABLATE & 32) ? tt[r] * 1e-3f + 1.0f : fast_exp2(__builtin_fmaf(tt[r], a2, nmb));
             psum += p[r];
         }
         l_run += psum;
@@ -220,9 +240,11 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
                     a_l[nxt] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + c2 * 32 * BX_VROW + s2 * 16);
                     a_s[nxt] = *reinterpret_cast<const f16x8*>(vbase + 2 * VPLANE + c2 * 32 * BX_VROW + s2 * 16);
                 }
-                o[cb] = bx_mfma(a_h[cur], ph[s], o[cb]);
-                o[cb] = bx_mfma(a_s[cur], pl[s], o[cb]);      // (2^-11 V_hi) . (2^11 P_lo)
-                o[cb] = bx_mfma(a_l[cur], ph[s], o[cb]);
+                if (!(BX_ABLATE & 8)) {
+                    o[cb] = bx_mfma(a_h[cur], ph[s], o[cb]);
+                    o[cb] = bx_mfma(a_s[cur], pl[s], o[cb]);      // (2^-11 V_hi) . (2^11 P_lo)
+                    o[cb] = bx_mfma(a_l[cur], ph[s], o[cb]);
+                }
                 commit_v_piece(i, buf ^ 1);
                 fetch_v_piece(i, j0 + 64);
                 __builtin_amdgcn_sched_barrier(0);
@@ -249,9 +271,13 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
 // ---------------------------------------------------------------------------------------------------------
 // K19 backward
 // ---------------------------------------------------------------------------------------------------------
-// Column sums of a 32 x 32 accumulator image over its 32 query lanes, for two quantities at once: a reduce-scatter
-// butterfly over lane bits 0..3 (16 -> 8 -> 4 -> 2 -> 1 registers per lane), then one exchange across the two rows of
-// 16.  Afterwards lane c (both c and c ^ 16) holds the sum of register r(c) = 8 b0 + 4 b1 + 2 b2 + b3 (b_k = bit k of c).
+// Column sums (over queries) of two 32 x 32 accumulator images per tile — d b and d nu are sums over ALL queries of a key.
+// The four waves of a workgroup hold the same keys for four different query blocks: every wave parks its two images in
+// its own LDS slot (8 ds_write_b128), and behind the tile's barrier every wave adds up ONE register group (4 of the 16
+// registers) of the four slots (8 ds_read_b128) and reduces it over its 32 lanes: two reduce-scatter folds over lane bits
+// 0 and 1 and an all-reduce over bits 2..4, all but the last on the DPP path.  (Round-3 history: every wave running the full
+// 16-register butterfly for both quantities cost 0.083 ms of the 0.46 ms kernel; ds_add_f32 into one shared image — 32 LDS
+// float atomics per wave and tile — cost 1.3 ms.)
 // Exchange with lane c ^ MASK inside a row of 16 lanes, on the DPP path (no LDS crossbar, no address register): 1, 2 are
 // quad permutations; 4 = row_half_mirror (c ^ 7) followed by the quad reversal (c ^ 3); 8 = a row rotation by 8.
 template <int MASK>
@@ -265,22 +291,15 @@ __device__ __forceinline__ float bx_xchg(float v) {
     else r = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);                     // row_ror:8
     return __builtin_bit_cast(float, r);
 }
-template <int N, int MASK>
-__device__ __forceinline__ void bx_fold(float (&x)[16], int c) {
-    const bool up = (c & MASK) != 0;
-#pragma unroll
-    for (int i = 0; i < N / 2; ++i) {
-        const float keep = up ? x[i + N / 2] : x[i];
-        const float send = up ? x[i] : x[i + N / 2];
-        x[i] = keep + bx_xchg<MASK>(send);
-    }
-}
-__device__ __forceinline__ float bx_colsum(float (&x)[16], int c) {
-    bx_fold<16, 1>(x, c);
-    bx_fold<8, 2>(x, c);
-    bx_fold<4, 4>(x, c);
-    bx_fold<2, 8>(x, c);
-    return x[0] + __shfl_xor(x[0], 16, 64);
+// x[0..3] = registers 4w..4w+3 of the summed image -> the column sum of register 4w + 2*b0 + b1 (b_k = bit k of the lane)
+__device__ __forceinline__ float bx_colsum4(const float (&x)[4], int c) {
+    const bool up0 = (c & 1) != 0, up1 = (c & 2) != 0;
+    const float y0 = (up0 ? x[2] : x[0]) + bx_xchg<1>(up0 ? x[0] : x[2]);
+    const float y1 = (up0 ? x[3] : x[1]) + bx_xchg<1>(up0 ? x[1] : x[3]);
+    float z = (up1 ? y1 : y0) + bx_xchg<2>(up1 ? y0 : y1);
+    z += bx_xchg<4>(z);
+    z += bx_xchg<8>(z);
+    return z + __shfl_xor(z, 16, 64);
 }
 
 template <int CVB, bool STORE_P>
@@ -301,7 +320,8 @@ __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
     constexpr int CVP = CVB * 32, CVS = CVP / 16, VROW = CVP + 8, VPLANE = 32 * VROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
     _Float16* const vt = reinterpret_cast<_Float16*>(bx_smem);          // [2 buf][hi|lo][32 keys][VROW]
-    float* const colbuf = reinterpret_cast<float*>(vt + 2 * 2 * VPLANE);   // [2 buf][2 quantities][32 keys]
+    float* const colacc = reinterpret_cast<float*>(vt + 2 * 2 * VPLANE);   // [2 buf][4 waves][2 quantities][4 groups][64 lanes][4]
+    float* const kstat = colacc + 2 * 4 * 2048;                            // [b | kn][Nk]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
@@ -309,6 +329,7 @@ __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
     const int b = vb / nqb, wg = vb % nqb, q0 = wg * 128;
     const int i_lane = q0 + wave * 32 + c;
+    bx_stage_stats(kstat, b_k + (size_t)b * Nk, nu_k + (size_t)b * Nk, Nk, kc, tid);
 
     const size_t vbytes = (size_t)Nk * CVP * 2, gbytes = (size_t)Nq * CVP * 2;
     const __amdgpu_buffer_rsrc_t vh_rs = make_rsrc(vph + (size_t)b * Nk * CVP, vbytes);
@@ -322,15 +343,14 @@ __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
     const __amdgpu_buffer_rsrc_t pl_rs = make_rsrc(STORE_P ? psl + (size_t)b * Nk * Nq : nullptr, STORE_P ? (size_t)Nk * Nq * 2 : 0);
     BxGeom gm;
     gm.t_rs = make_rsrc(T + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
-    gm.b_rs = make_rsrc(b_k + (size_t)b * Nk, (size_t)Nk * 4);
-    gm.nu_rs = make_rsrc(nu_k + (size_t)b * Nk, (size_t)Nk * 4);
+    gm.kstat = kstat;
+    gm.nk = Nk;
     gm.tpr = wimg / 32;
     gm.qblk = (q0 >> 5) + wave;
     gm.py = gm.qblk / gm.tpr;
     gm.himg = himg;
     gm.nqblk = Nq >> 5;
     gm.lane_off = (unsigned)lane * 16u;
-    gm.stat_off = (unsigned)h * 16u;
 
     const float mu_p = mu_q[(size_t)b * Nq + i_lane];
     const float a_p = a_q[(size_t)b * Nq + i_lane];
@@ -380,18 +400,23 @@ __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
         const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
         if (g < VCH) *reinterpret_cast<u32x4*>(vt + (buf * 2 + pl) * VPLANE + key * VROW + cc * 8) = vst[pl][u];
     };
-    // flush of one tile's column sums: [quantity][32 keys] of this workgroup's 128 queries -> colpart, then re-zero
+    // behind the barrier that ended tile t: register group `wave` of the four waves' images, summed -> column sums -> colpart
     float* const cp_b = colpart + ((size_t)b * nqb + wg) * 2 * Nk;
-    auto flush_cols = [&](int t) {
-        if (tid < 64) {
-            float* cell = colbuf + (t & 1) * 64 + tid;
-            cp_b[(size_t)(tid >> 5) * Nk + t * 32 + (tid & 31)] = *cell;
-            *cell = 0.f;
+    auto reduce_cols = [&](int t) {
+        if (BX_ABLATE & 1) return;
+        const float* a = colacc + (t & 1) * 4 * 2048 + wave * 256 + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(a + q * 1024);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) acc += *reinterpret_cast<const f32x4*>(a + w * 2048 + q * 1024);
+            const float x[4] = {acc[0], acc[1], acc[2], acc[3]};
+            const float z = bx_colsum4(x, c);
+            if (c < 4) cp_b[(size_t)q * Nk + t * 32 + 8 * wave + 4 * h + 2 * (c & 1) + ((c >> 1) & 1)] = z;
         }
     };
 
     const int ntiles = Nk / 32;
-    if (tid < 128) colbuf[tid] = 0.f;
     BxTile tl;
 #pragma unroll
     for (int i = 0; i < 2 * VPT; ++i) fetch_v_piece(i, 0);
@@ -405,13 +430,13 @@ __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
     float r2 = 0.f, rm = 0.f, gabs = 0.f;
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 32, buf = t & 1;
-        if (t > 0) flush_cols(t - 1);                     // (behind the barrier that ended tile t-1)
+        if (t > 0) reduce_cols(t - 1);
         float tt[16], bq[16], kn[16];
-        bx_logits(tl, mu_p, kc, tt, bq, kn);
+        bx_logits(tl, gm, t, h, mu_p, tt, bq, kn);
         bx_fetch(tl, gm, t + 1, ntiles);
         float p[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[r] = fast_exp2(__builtin_fmaf(tt[r], a2, -lse2));
+        for (int r = 0; r < 16; ++r) p[r] = (BX_ABLATE & 32) ? tt[r] * 1e-3f : fast_exp2(__builtin_fmaf(tt[r], a2, -lse2));
 
         // ---- dP' = V(t) . dO' ---------------------------------------------------------------------------------------
         f32x16 dp0, dp1;
@@ -429,9 +454,11 @@ __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
                     ah[nxt] = *reinterpret_cast<const f16x8*>(vb0 + (u + 1) * 16);
                     al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
                 }
-                dp0 = bx_mfma(ah[cur], goh[u], dp0);
-                dp1 = bx_mfma(ah[cur], gol[u], dp1);
-                dp1 = bx_mfma(al[cur], goh[u], dp1);
+                if (!(BX_ABLATE & 8)) {
+                    dp0 = bx_mfma(ah[cur], goh[u], dp0);
+                    dp1 = bx_mfma(ah[cur], gol[u], dp1);
+                    dp1 = bx_mfma(al[cur], goh[u], dp1);
+                }
                 if (u < 2 * VPT) {
                     commit_v_piece(u, buf ^ 1);
                     fetch_v_piece(u, j0 + 64);
@@ -456,14 +483,14 @@ __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
             r2 += x1[r];
             rm = __builtin_fmaf(L, kn[r], rm);
         }
-        {
+        if (!(BX_ABLATE & 2)) {
             const unsigned blk = (unsigned)((t * gm.nqblk + gm.qblk) * 4096);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gout[g]), G_rs, (int)gm.lane_off,
                                                        (int)(blk + (unsigned)g * 1024u), 0);
         }
-        if (STORE_P) {
+        if (STORE_P && !(BX_ABLATE & 2)) {
             // planes of 2^14 P in the accumulator's own orientation: [Nq/32][Nk/32] blocks of 2 x [32 queries][16 keys]
             // (corr_fused_bwd_f16x3.hip, store_regs_blk; read by hgemm_f16x3 with b_blocked = 2)
             unsigned hw[8], lw[8];
@@ -487,19 +514,18 @@ __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
                 __builtin_amdgcn_raw_buffer_store_b128(xl, pl_rs, (int)off, 0, 2);
             }
         }
-        {
-            const float c2 = bx_colsum(x1, c);
-            const float cm = bx_colsum(x2, c);
-            if (c < 16) {
-                const int r = 8 * (c & 1) + 4 * ((c >> 1) & 1) + 2 * ((c >> 2) & 1) + ((c >> 3) & 1);
-                const int kk = acc_row_base(r) + 4 * h;
-                atomicAdd(colbuf + buf * 64 + kk, c2);
-                atomicAdd(colbuf + buf * 64 + 32 + kk, cm);
+        if (!(BX_ABLATE & 1)) {
+            // (slot of tile t - 2 was read by every wave before it passed the barrier of tile t - 1)
+            float* a = colacc + buf * 4 * 2048 + wave * 2048 + lane * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<f32x4*>(a + g * 256) = f32x4{x1[4 * g], x1[4 * g + 1], x1[4 * g + 2], x1[4 * g + 3]};
+                *reinterpret_cast<f32x4*>(a + 1024 + g * 256) = f32x4{x2[4 * g], x2[4 * g + 1], x2[4 * g + 2], x2[4 * g + 3]};
             }
         }
         __syncthreads();
     }
-    flush_cols(ntiles - 1);
+    reduce_cols(ntiles - 1);
 
     r2 += swap_half(r2);
     rm += swap_half(rm);
@@ -625,7 +651,7 @@ template <int CVB>
 static int bx_fwd_launch(const float* T, const float* mu, const float* a, const float* nu, const float* bk,
                          const _Float16* vh, const _Float16* vl, float* out, float* lse, const float* vs, int B, int Nq,
                          int Nk, int Cv, int himg, int wimg, float kc, float scale, hipStream_t s) {
-    const size_t smem = (size_t)2 * 3 * CVB * 32 * BX_VROW * sizeof(_Float16);
+    const size_t smem = (size_t)2 * 3 * CVB * 32 * BX_VROW * sizeof(_Float16) + (size_t)2 * Nk * sizeof(float);
     auto kern = box3_sw_fwd_kernel<CVB>;
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3(B * (Nq / 128)), dim3(256), smem, s, T, mu, a, nu, bk, vh, vl, out, lse, vs, B, Nq, Nk,
@@ -640,7 +666,7 @@ static int bx_bwd_launch(const float* T, const float* mu, const float* a, const 
                          const float* gs, const float* vs, const float* outp, const float* dout, const float* lse, float* G,
                          float* dmu, float* da, float* colpart, float* gmax, _Float16* psh, _Float16* psl, int B, int Nq,
                          int Nk, int Cv, int himg, int wimg, float kc, float scale, hipStream_t s) {
-    const size_t smem = (size_t)2 * 2 * 32 * (CVB * 32 + 8) * sizeof(_Float16) + 128 * sizeof(float);
+    const size_t smem = (size_t)2 * 2 * 32 * (CVB * 32 + 8) * sizeof(_Float16) + (size_t)(2 * 4 * 2048 + 2 * Nk) * sizeof(float);
 #define COCOS_BX_GO(SP)                                                                                                  \
     do {                                                                                                                 \
         auto kern = box3_sw_bwd_kernel<CVB, SP>;                                                                         \
@@ -655,8 +681,8 @@ static int bx_bwd_launch(const float* T, const float* mu, const float* a, const 
 }
 
 static bool bx_shape_ok(int Nq, int Nk, int Cv, int himg, int wimg) {
-    return himg >= 1 && wimg == 64 && Nq == himg * wimg && Nk == Nq && Nq % 256 == 0 && Cv >= 1 && Cv <= 160 &&
-           (size_t)Nq * Nk * 4 < 0x7fffffffull;
+    return himg >= 1 && wimg == 64 && Nq == himg * wimg && Nk == Nq && Nq % 256 == 0 && Nk <= 8192 && Cv >= 1 && Cv <= 160 &&
+           (size_t)Nq * Nk * 4 < 0x7fffffffull;       // (Nk <= 8192: the per-key statistics of a sample live in LDS)
 }
 
 }  // namespace cocos
