@@ -108,8 +108,10 @@ __device__ __forceinline__ void bx_logits(const BxTile& tl, const BxGeom& gm, in
 // ---------------------------------------------------------------------------------------------------------
 // K19 forward
 // ---------------------------------------------------------------------------------------------------------
-template <int CVB>
-__global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
+// VLO0 (as in the K2 split kernels, corr_fused_fwd_f16x3.hip): only value block 0 has a non-zero f16 lo plane (one-hot label
+// channels are exact in f16) — the V_lo . P_hi term, its fragment reads and its staging are skipped for the other blocks.
+template <int CVB, bool VLO0>
+__device__ __forceinline__ void box3_sw_fwd_body(
     const float* __restrict__ T, const float* __restrict__ mu_q, const float* __restrict__ a_q,
     const float* __restrict__ nu_k, const float* __restrict__ b_k, const _Float16* __restrict__ vh,
     const _Float16* __restrict__ vl, float* __restrict__ out, float* __restrict__ lse,
@@ -152,8 +154,9 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
     float m_run = -INFINITY, l_run = 0.f;
 
     u32x2 vst[2][CVB];
-    auto fetch_v_piece = [&](int i, int j0) {          // plane i & 1, chunk i >> 1
+    auto fetch_v_piece = [&](int i, int j0) {          // plane i & 1, chunk i >> 1 (= value block)
         const int pl = i & 1, u = i >> 1;
+        if (VLO0 && pl == 1 && u >= 1) return;
         const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
         unsigned off = (unsigned)(row * Nk + j0 + 4 * kq) * 2u;
         if (row >= Cv || j0 + 4 * kq >= Nk) off = kBufOob;
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
     };
     auto commit_v_piece = [&](int i, int buf) {
         const int pl = i & 1, u = i >> 1;
+        if (VLO0 && pl == 1 && u >= 1) return;
         const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
         const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);   // see corr_fused_fwd_f16x3.hip
         *reinterpret_cast<u32x2*>(vt + (buf * 3 + pl) * VPLANE + row * BX_VROW + slot) = vst[pl][u];
@@ -237,13 +241,14 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
                 if (i + 1 < NS) {
                     const int s2 = (i + 1) / CVB, c2 = (i + 1) % CVB;
                     a_h[nxt] = *reinterpret_cast<const f16x8*>(vbase + c2 * 32 * BX_VROW + s2 * 16);
-                    a_l[nxt] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + c2 * 32 * BX_VROW + s2 * 16);
+                    if (!VLO0 || c2 == 0)
+                        a_l[nxt] = *reinterpret_cast<const f16x8*>(vbase + VPLANE + c2 * 32 * BX_VROW + s2 * 16);
                     a_s[nxt] = *reinterpret_cast<const f16x8*>(vbase + 2 * VPLANE + c2 * 32 * BX_VROW + s2 * 16);
                 }
                 if (!(BX_ABLATE & 8)) {
                     o[cb] = bx_mfma(a_h[cur], ph[s], o[cb]);
                     o[cb] = bx_mfma(a_s[cur], pl[s], o[cb]);      // (2^-11 V_hi) . (2^11 P_lo)
-                    o[cb] = bx_mfma(a_l[cur], ph[s], o[cb]);
+                    if (!VLO0 || cb == 0) o[cb] = bx_mfma(a_l[cur], ph[s], o[cb]);
                 }
                 commit_v_piece(i, buf ^ 1);
                 fetch_v_piece(i, j0 + 64);
@@ -266,6 +271,21 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
             if (ch < Cv) out_b[(size_t)ch * Nq + i_lane] = o[cb][r] * inv_l;
         }
     if (h == 0) lse[(size_t)b * Nq + i_lane] = (m_run + log2f(l_tot) - kBxPBias) * kLn2;
+}
+
+// One launch holds both flavours of the body and picks one, workgroup-uniformly, from the device-side mask of V's lo plane
+// (cocos_split_f16_chan_mask) as its first action.  DUAL = false: no mask / a single value block.
+template <int CVB, bool DUAL>
+__global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
+    const float* __restrict__ T, const float* __restrict__ mu_q, const float* __restrict__ a_q,
+    const float* __restrict__ nu_k, const float* __restrict__ b_k, const _Float16* __restrict__ vh,
+    const _Float16* __restrict__ vl, float* __restrict__ out, float* __restrict__ lse,
+    const float* __restrict__ v_scale, const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, int himg,
+    int wimg, float kc, float scale) {
+    if (DUAL && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
+        box3_sw_fwd_body<CVB, DUAL>(T, mu_q, a_q, nu_k, b_k, vh, vl, out, lse, v_scale, B, Nq, Nk, Cv, himg, wimg, kc, scale);
+    else
+        box3_sw_fwd_body<CVB, false>(T, mu_q, a_q, nu_k, b_k, vh, vl, out, lse, v_scale, B, Nq, Nk, Cv, himg, wimg, kc, scale);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -302,21 +322,20 @@ __device__ __forceinline__ float bx_colsum4(const float (&x)[4], int c) {
     return z + __shfl_xor(z, 16, 64);
 }
 
-template <int CVB, bool STORE_P>
-__global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
-    const float* __restrict__ T, const float* __restrict__ mu_q, const float* __restrict__ a_q,
-    const float* __restrict__ nu_k, const float* __restrict__ b_k,
-    const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] position-major planes of s_v*v
-    const _Float16* __restrict__ gph, const _Float16* __restrict__ gpl,   // [B,Nq,CVP] planes of s_o*dout
-    const float* __restrict__ g_scale, const float* __restrict__ v_scale,
-    const float* __restrict__ outp, const float* __restrict__ dout,        // [B,Cv,Nq] fp32 (for D)
-    const float* __restrict__ lse,
-    float* __restrict__ G,                                                 // out, tile-blocked like T
-    float* __restrict__ dmu, float* __restrict__ da,                       // out [B,Nq]
-    float* __restrict__ colpart,                                           // out [B][Nq/128][2][Nk]
-    float* __restrict__ gmax,                                              // in/out: max|G| (atomic max on the bit pattern)
-    _Float16* __restrict__ psh, _Float16* __restrict__ psl,                // out (STORE_P): planes of 2^14 P, blocked
-    int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale) {
+#define COCOS_BXB_PARAMS \
+    const float* __restrict__ T, const float* __restrict__ mu_q, const float* __restrict__ a_q,                        \
+    const float* __restrict__ nu_k, const float* __restrict__ b_k, const _Float16* __restrict__ vph,                   \
+    const _Float16* __restrict__ vpl, const _Float16* __restrict__ gph, const _Float16* __restrict__ gpl,              \
+    const float* __restrict__ g_scale, const float* __restrict__ v_scale, const float* __restrict__ outp,              \
+    const float* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ G, float* __restrict__ dmu,     \
+    float* __restrict__ da, float* __restrict__ colpart, float* __restrict__ gmax, _Float16* __restrict__ psh,         \
+    _Float16* __restrict__ psl, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale
+#define COCOS_BXB_ARGS \
+    T, mu_q, a_q, nu_k, b_k, vph, vpl, gph, gpl, g_scale, v_scale, outp, dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, \
+    Nk, Cv, himg, wimg, kc, scale
+
+template <int CVB, bool STORE_P, bool VLO0>
+__device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     constexpr int CVP = CVB * 32, CVS = CVP / 16, VROW = CVP + 8, VPLANE = 32 * VROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
     _Float16* const vt = reinterpret_cast<_Float16*>(bx_smem);          // [2 buf][hi|lo][32 keys][VROW]
@@ -392,8 +411,9 @@ __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
     auto fetch_v_piece = [&](int i, int j0) {
         const int pl = i & 1, u = i >> 1;
         const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
+        // (VLO0: the lo plane of channels >= 32 is all zero and never read: not fetched — its LDS image stays whatever it was)
         vst[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(
-            pl ? vl_rs : vh_rs, (int)(g < VCH ? (unsigned)((j0 + key) * CVP + cc * 8) * 2u : kBufOob), 0, 0);
+            pl ? vl_rs : vh_rs, (int)((g < VCH && !(VLO0 && pl == 1 && cc >= 4)) ? (unsigned)((j0 + key) * CVP + cc * 8) * 2u : kBufOob), 0, 0);
     };
     auto commit_v_piece = [&](int i, int buf) {
         const int pl = i & 1, u = i >> 1;
@@ -452,12 +472,12 @@ __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
                 const int cur = u & 1, nxt = cur ^ 1;
                 if (u + 1 < CVS) {
                     ah[nxt] = *reinterpret_cast<const f16x8*>(vb0 + (u + 1) * 16);
-                    al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
+                    if (!VLO0 || u + 1 < 2) al[nxt] = *reinterpret_cast<const f16x8*>(vb0 + VPLANE + (u + 1) * 16);
                 }
                 if (!(BX_ABLATE & 8)) {
                     dp0 = bx_mfma(ah[cur], goh[u], dp0);
                     dp1 = bx_mfma(ah[cur], gol[u], dp1);
-                    dp1 = bx_mfma(al[cur], goh[u], dp1);
+                    if (!VLO0 || u < 2) dp1 = bx_mfma(al[cur], goh[u], dp1);
                 }
                 if (u < 2 * VPT) {
                     commit_v_piece(u, buf ^ 1);
@@ -535,6 +555,14 @@ __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(
     }
     gabs = wave_max_dpp(gabs);
     if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(gmax), __builtin_bit_cast(unsigned, gabs));   // >= 0: ordered as integers
+}
+
+template <int CVB, bool STORE_P, bool DUAL>
+__global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(COCOS_BXB_PARAMS, const unsigned* __restrict__ v_lo_mask) {
+    if (DUAL && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
+        box3_sw_bwd_body<CVB, STORE_P, DUAL>(COCOS_BXB_ARGS);
+    else
+        box3_sw_bwd_body<CVB, STORE_P, false>(COCOS_BXB_ARGS);
 }
 
 // d nu[b,q] = -kc * b_q * sum_wg colpart[b,wg,1,q];   d b[b,q] = sum_wg colpart[b,wg,0,q] / b_q
@@ -649,12 +677,13 @@ __global__ __launch_bounds__(256, 1) void box3_adjoint_planes_kernel(const float
 
 template <int CVB>
 static int bx_fwd_launch(const float* T, const float* mu, const float* a, const float* nu, const float* bk,
-                         const _Float16* vh, const _Float16* vl, float* out, float* lse, const float* vs, int B, int Nq,
-                         int Nk, int Cv, int himg, int wimg, float kc, float scale, hipStream_t s) {
+                         const _Float16* vh, const _Float16* vl, float* out, float* lse, const float* vs,
+                         const unsigned* mask, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale,
+                         hipStream_t s) {
     const size_t smem = (size_t)2 * 3 * CVB * 32 * BX_VROW * sizeof(_Float16) + (size_t)2 * Nk * sizeof(float);
-    auto kern = box3_sw_fwd_kernel<CVB>;
+    auto kern = (CVB > 1 && mask) ? box3_sw_fwd_kernel<CVB, (CVB > 1)> : box3_sw_fwd_kernel<CVB, false>;
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3(B * (Nq / 128)), dim3(256), smem, s, T, mu, a, nu, bk, vh, vl, out, lse, vs, B, Nq, Nk,
+    hipLaunchKernelGGL(kern, dim3(B * (Nq / 128)), dim3(256), smem, s, T, mu, a, nu, bk, vh, vl, out, lse, vs, mask, B, Nq, Nk,
                        Cv, himg, wimg, kc, scale);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
@@ -664,15 +693,16 @@ template <int CVB>
 static int bx_bwd_launch(const float* T, const float* mu, const float* a, const float* nu, const float* bk,
                          const _Float16* vph, const _Float16* vpl, const _Float16* gph, const _Float16* gpl,
                          const float* gs, const float* vs, const float* outp, const float* dout, const float* lse, float* G,
-                         float* dmu, float* da, float* colpart, float* gmax, _Float16* psh, _Float16* psl, int B, int Nq,
-                         int Nk, int Cv, int himg, int wimg, float kc, float scale, hipStream_t s) {
+                         float* dmu, float* da, float* colpart, float* gmax, _Float16* psh, _Float16* psl,
+                         const unsigned* mask, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale,
+                         hipStream_t s) {
     const size_t smem = (size_t)2 * 2 * 32 * (CVB * 32 + 8) * sizeof(_Float16) + (size_t)(2 * 4 * 2048 + 2 * Nk) * sizeof(float);
 #define COCOS_BX_GO(SP)                                                                                                  \
     do {                                                                                                                 \
-        auto kern = box3_sw_bwd_kernel<CVB, SP>;                                                                         \
+        auto kern = (CVB > 1 && mask) ? box3_sw_bwd_kernel<CVB, SP, (CVB > 1)> : box3_sw_bwd_kernel<CVB, SP, false>;     \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         hipLaunchKernelGGL(kern, dim3(B * (Nq / 128)), dim3(256), smem, s, T, mu, a, nu, bk, vph, vpl, gph, gpl, gs, vs, outp, \
-                           dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, Nk, Cv, himg, wimg, kc, scale);        \
+                           dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, Nk, Cv, himg, wimg, kc, scale, mask);  \
     } while (0)
     if (psh) COCOS_BX_GO(true); else COCOS_BX_GO(false);
 #undef COCOS_BX_GO
@@ -693,7 +723,8 @@ extern "C" int cocos_box3_fused_supported(int Nq, int Nk, int Cv, int grid_h, in
 
 extern "C" int cocos_box3_softmax_warp_fwd_f16x3(const float* t_blocked, const float* mu_q, const float* a_q,
                                                  const float* nu_k, const float* b_k, const void* vh, const void* vl,
-                                                 float* out, float* lse, const float* v_scale_dev, int B, int Nq, int Nk,
+                                                 float* out, float* lse, const float* v_scale_dev,
+                                                 const unsigned* v_lo_mask_dev, int B, int Nq, int Nk,
                                                  int Cv, int grid_h, int grid_w, float k_unfolded, float scale,
                                                  cocos_stream_t stream) {
     using namespace cocos;
@@ -710,7 +741,7 @@ extern "C" int cocos_box3_softmax_warp_fwd_f16x3(const float* t_blocked, const f
                       "box3_softmax_warp_fwd_f16x3: v planes must be 8-byte aligned");
     const _Float16 *a = static_cast<const _Float16*>(vh), *b2 = static_cast<const _Float16*>(vl);
     hipStream_t s = as_stream(stream);
-#define COCOS_ARGS t_blocked, mu_q, a_q, nu_k, b_k, a, b2, out, lse, v_scale_dev, B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, s
+#define COCOS_ARGS t_blocked, mu_q, a_q, nu_k, b_k, a, b2, out, lse, v_scale_dev, v_lo_mask_dev, B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, s
     switch ((Cv + 31) / 32) {
         case 1: return bx_fwd_launch<1>(COCOS_ARGS);
         case 2: return bx_fwd_launch<2>(COCOS_ARGS);
@@ -730,8 +761,8 @@ extern "C" int cocos_box3_softmax_warp_bwd_f16x3(
     const float* t_blocked, const float* mu_q, const float* a_q, const float* nu_k, const float* b_k, const void* vph,
     const void* vpl, const void* gph, const void* gpl, const float* g_scale_dev, const float* v_scale_dev, const float* out,
     const float* dout, const float* lse, float* g_blocked, float* dmu, float* da, float* dnu, float* db, void* colpart,
-    float* gmax_dev, void* psh, void* psl, int B, int Nq, int Nk, int Cv, int CvPad, int grid_h, int grid_w,
-    float k_unfolded, float scale, cocos_stream_t stream) {
+    float* gmax_dev, void* psh, void* psl, const unsigned* v_lo_mask_dev, int B, int Nq, int Nk, int Cv, int CvPad, int grid_h,
+    int grid_w, float k_unfolded, float scale, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(t_blocked && mu_q && a_q && nu_k && b_k && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse &&
                       g_blocked && dmu && da && dnu && db && colpart && gmax_dev,
@@ -751,7 +782,7 @@ extern "C" int cocos_box3_softmax_warp_bwd_f16x3(
     t_blocked, mu_q, a_q, nu_k, b_k, static_cast<const _Float16*>(vph), static_cast<const _Float16*>(vpl),               \
         static_cast<const _Float16*>(gph), static_cast<const _Float16*>(gpl), g_scale_dev, v_scale_dev, out, dout, lse,   \
         g_blocked, dmu, da, static_cast<float*>(colpart), gmax_dev, static_cast<_Float16*>(psh),                         \
-        static_cast<_Float16*>(psl), B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, s
+        static_cast<_Float16*>(psl), v_lo_mask_dev, B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, s
     int rc;
     switch (cvb) {
         case 1: rc = bx_bwd_launch<1>(COCOS_ARGS); break;

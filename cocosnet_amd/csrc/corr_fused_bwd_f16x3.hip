@@ -81,10 +81,10 @@ struct DsRegs {
     const float* __restrict__ lse, const float* __restrict__ lg, float* __restrict__ dqn, _Float16* __restrict__ dsh, \
     _Float16* __restrict__ dsl, _Float16* __restrict__ psh, _Float16* __restrict__ psl, const float* __restrict__ v_amax, \
     const float* __restrict__ v_scale, float* __restrict__ ds_scale_out, const unsigned* __restrict__ v_lo_mask, int B, \
-    int Nq, int Nk, int Cv, float inv_t, float k_scale
+    int Nq, int Nk, int Cv, float inv_t, float k_scale, float q_scale
 #define COCOS_BQ_ARGS \
     kch, kcl, vph, vpl, gph, gpl, g_scale, outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, \
-    v_lo_mask, B, Nq, Nk, Cv, inv_t, k_scale
+    v_lo_mask, B, Nq, Nk, Cv, inv_t, k_scale, q_scale
 
 template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED, bool VLO0, bool BLK>
 __device__ __forceinline__ void corr_bwd_query_f16x3_body(
@@ -101,7 +101,8 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     const float* __restrict__ v_scale,                                     // s_v (device) or NULL
     float* __restrict__ ds_scale_out,                                      // out: s_o * s_v * ds_shift (device)
     const unsigned* __restrict__ v_lo_mask,                                // bit cb: value block cb has a non-zero lo plane (or NULL)
-    int B, int Nq, int Nk, int Cv, float inv_t, float k_scale) {
+    int B, int Nq, int Nk, int Cv, float inv_t, float k_scale /* of the K planes */, float q_scale /* of the query planes the
+    forward multiplied them with: raw logits = q_scale * k_scale * <q, k> */) {
     constexpr int CVP = CVB * 32;
     constexpr int CVS = CVP / 16;                     // k-steps of the dP product
     constexpr int KB = BQH_KD / 32;                   // channel blocks of dqn
@@ -201,7 +202,7 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     //   p_c = 2^(raw * scale_log2 - (lse * log2 e - log2 cs)),   dS'' = p_c * (dP' - D')
     // (raw = the forward's accumulator, k_scale^2 * cos; padded lanes: lse2c = +inf -> p_c = 0)
     const float cs = inv_t * ds_shift;
-    const float scale_log2 = inv_t * kLog2e / (k_scale * k_scale);
+    const float scale_log2 = inv_t * kLog2e / (k_scale * q_scale);
     const float nlse2c = live ? log2f(cs) - lse[(size_t)b * Nq + i_lane] * kLog2e : -INFINITY;
     const float p_from_pc = kPPlaneScale / cs;        // STORE_P: 2^14 * P = p_c * (2^14 / cs)
 
@@ -594,7 +595,12 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
 // one, workgroup-uniformly, from the device-side mask as its first action (see corr_fused_fwd_f16x3.hip).  DUAL = false:
 // no mask / a single value block — only the general flavour is compiled in.
 template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED, bool DUAL, bool BLK>
-__global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(COCOS_BQ_PARAMS) {
+__global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(COCOS_BQ_PARAMS, const float* __restrict__ q_scale_dev,
+                                                                      const float* __restrict__ k_scale_dev) {
+    if (q_scale_dev) {           // operands with device-side scales (see the forward kernel)
+        q_scale = *q_scale_dev;
+        k_scale = *k_scale_dev;
+    }
     if (DUAL && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
         corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, DUAL, BLK>(COCOS_BQ_ARGS);
     else
@@ -607,7 +613,7 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                            const float* dout, const float* lse, const float* lg, float* dqn, _Float16* dsh,
                            _Float16* dsl, _Float16* psh, _Float16* psl, const float* v_amax, const float* v_scale,
                            float* ds_scale_out, const unsigned* v_lo_mask, int B, int Nq, int Nk, int Cv, float inv_t,
-                           float k_scale, int blocked,
+                           float k_scale, int blocked, const float* qsd, const float* ksd,
                            hipStream_t s) {
     const bool ragged = (Nk % 32) != 0, store = dsh != nullptr, storep = psh != nullptr;
     const size_t smem = ((size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) + 4 * 2 * 32 * 32) * sizeof(_Float16);
@@ -623,7 +629,7 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
         hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, s, kch, kcl, vph, vpl, gph, gpl, g_scale,   \
                            outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, MASK, B, Nq, \
-                           Nk, Cv, inv_t, k_scale);                                                          \
+                           Nk, Cv, inv_t, k_scale, k_scale, qsd, ksd);                                       \
     } while (0)
     /* blocked planes ([query][key] blocks, see the kernel) only exist for whole tiles */
 #define COCOS_GO3(DS, SP, RG, VL, MASK)                                                                      \
@@ -667,11 +673,14 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
     const float* g_scale_dev, const float* out, const float* dout, const float* lse, const void* saved_logits,
     float* dqn, void* dsh, void* dsl, void* psh, void* psl, const float* v_amax_dev, const float* v_scale_dev,
     float* ds_scale_out_dev, const unsigned* v_lo_mask_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad,
-    float inv_temperature, float k_scale, int planes_blocked, cocos_stream_t stream) {
+    float inv_temperature, float k_scale, const float* q_scale_dev, const float* k_scale_dev, int planes_blocked,
+    cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(kch && kcl && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse && saved_logits && dqn &&
                       v_amax_dev && ds_scale_out_dev,
                   COCOS_ERR_INVALID, "corr_softmax_warp_bwd_query_f16x3: null pointer");
+    COCOS_REQUIRE((q_scale_dev == nullptr) == (k_scale_dev == nullptr), COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_query_f16x3: the device-side operand scales come as a pair");
     COCOS_REQUIRE((dsh == nullptr) == (dsl == nullptr) && (psh == nullptr) == (psl == nullptr), COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd_query_f16x3: plane pointers come in hi/lo pairs");
     COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && k_scale > 0.f && inv_temperature > 0.f, COCOS_ERR_INVALID,
@@ -698,7 +707,8 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
         static_cast<const _Float16*>(vpl), static_cast<const _Float16*>(gph), static_cast<const _Float16*>(gpl), \
         g_scale_dev, out, dout, lse, static_cast<const float*>(saved_logits), dqn, static_cast<_Float16*>(dsh),  \
         static_cast<_Float16*>(dsl), static_cast<_Float16*>(psh), static_cast<_Float16*>(psl), v_amax_dev,      \
-        v_scale_dev, ds_scale_out_dev, v_lo_mask_dev, B, Nq, Nk, Cv, inv_temperature, k_scale, planes_blocked, s
+        v_scale_dev, ds_scale_out_dev, v_lo_mask_dev, B, Nq, Nk, Cv, inv_temperature, k_scale, planes_blocked, q_scale_dev, \
+        k_scale_dev, s
     switch (cvb) {
         case 1: return launch_bq_f16x3<1>(COCOS_ARGS);
         case 2: return launch_bq_f16x3<2>(COCOS_ARGS);

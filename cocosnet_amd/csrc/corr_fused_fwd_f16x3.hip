@@ -487,7 +487,11 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     const _Float16* __restrict__ qh, const _Float16* __restrict__ ql, const _Float16* __restrict__ kh,
     const _Float16* __restrict__ kl, const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
     float* __restrict__ out, float* __restrict__ lse, float* __restrict__ lg, const float* __restrict__ v_scale,
-    const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2) {
+    const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2,
+    const float* __restrict__ q_scale_dev, const float* __restrict__ k_scale_dev) {
+    // operands without an a-priori magnitude (ops.softmax_attention: the reference's Attention block feeds raw 1x1-conv
+    // outputs): their planes carry device-side power-of-two scales; scale_log2 then arrives WITHOUT the 1 / (q_scale k_scale)
+    if (q_scale_dev) scale_log2 = scale_log2 / (*q_scale_dev * *k_scale_dev);
     if (DUAL && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
         corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, DUAL>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk, Cv, scale_log2);
     else
@@ -498,14 +502,14 @@ template <int CVB, bool STORE_S, bool RAGGED, bool VLO0>
 static int launch_f16x3_k(const _Float16* qh, const _Float16* ql, const _Float16* kh, const _Float16* kl,
                           const _Float16* vh, const _Float16* vl, float* out, float* lse, float* lg,
                           const float* v_scale, const unsigned* v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2,
-                          hipStream_t stream) {
+                          const float* qsd, const float* ksd, hipStream_t stream) {
     auto kern = corr_fwd_f16x3_kernel<CVB, STORE_S, RAGGED, VLO0>;
     const size_t smem = (size_t)2 * (2 * SP_BK * SP_KROW + 3 * CVB * 32 * SP_VROW) * sizeof(_Float16);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int nqb = (Nq + SP_BQ - 1) / SP_BQ;
     hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, stream, qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale,
-                       v_lo_mask, B, Nq, Nk, Cv, scale_log2);
+                       v_lo_mask, B, Nq, Nk, Cv, scale_log2, qsd, ksd);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -545,7 +549,8 @@ extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql,
                                                  float* lse, void* saved_logits, const float* v_scale_dev,
                                                  const unsigned* v_lo_mask_dev, int B,
                                                  int K, int Nq, int Nk, int Cv, float inv_temperature,
-                                                 float operand_scale, cocos_stream_t stream) {
+                                                 float operand_scale, const float* q_scale_dev, const float* k_scale_dev,
+                                                 cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(qh && ql && kh && kl && vh && vl && out && lse, COCOS_ERR_INVALID,
                   "corr_softmax_warp_fwd_f16x3: null pointer");
@@ -569,7 +574,9 @@ extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql,
     COCOS_REQUIRE(!saved_logits || aligned16(saved_logits), COCOS_ERR_INVALID,
                   "corr_softmax_warp_fwd_f16x3: saved_logits must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
-    const float scale_log2 = inv_temperature * kLog2e / (operand_scale * operand_scale);
+    COCOS_REQUIRE((q_scale_dev == nullptr) == (k_scale_dev == nullptr), COCOS_ERR_INVALID,
+                  "corr_softmax_warp_fwd_f16x3: the device-side operand scales come as a pair");
+    const float scale_log2 = q_scale_dev ? inv_temperature * kLog2e : inv_temperature * kLog2e / (operand_scale * operand_scale);
     const bool ragged = (Nk % SP_BK) != 0;
     float* lgp = static_cast<float*>(saved_logits);
     const _Float16 *a = static_cast<const _Float16*>(qh), *b2 = static_cast<const _Float16*>(ql),
@@ -577,7 +584,8 @@ extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql,
                    *e = static_cast<const _Float16*>(vh), *f = static_cast<const _Float16*>(vl);
     // with a mask and more than one value block the kernel holds both flavours and picks one from the device-side mask
 #define COCOS_GO(CVB, ST, RG) \
-    cocos_go_both<CVB, ST, RG>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, v_lo_mask_dev, B, Nq, Nk, Cv, scale_log2, s)
+    cocos_go_both<CVB, ST, RG>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, v_lo_mask_dev, B, Nq, Nk, Cv, scale_log2, \
+                               q_scale_dev, k_scale_dev, s)
 #define COCOS_CVB(CVB)                                                           \
     case CVB:                                                                    \
         if (lgp) return ragged ? COCOS_GO(CVB, true, true) : COCOS_GO(CVB, true, false); \

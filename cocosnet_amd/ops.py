@@ -253,6 +253,19 @@ class OperandPlanes:
             ent = self._planes[key] = (x, x._version, hi, lo)     # holds x: its id cannot be recycled meanwhile
         return ent[2], ent[3]
 
+    def get_scaled(self, x: torch.Tensor, transpose: bool):
+        """Planes with a DEVICE-side power-of-two scale from max|x| (operands without an a-priori magnitude):
+        (hi, lo, scale_tensor).  The scale depends on x only, so both orientations of x share it."""
+        key = (id(x), bool(transpose), "amax")
+        ent = self._planes.get(key)
+        if ent is None or ent[0] is not x or ent[1] != x._version:
+            am = self._planes.get((id(x), "amax_cell"))
+            if am is None or am[0] is not x or am[1] != x._version:
+                am = self._planes[(id(x), "amax_cell")] = (x, x._version, absmax(x))
+            hi, lo, sc = split_f16(x, transpose, amax=am[2])
+            ent = self._planes[key] = (x, x._version, hi, lo, sc)
+        return ent[2], ent[3], ent[4]
+
     def has(self, x: torch.Tensor) -> bool:
         return any(k[0] == id(x) and e[0] is x for k, e in self._planes.items())
 
@@ -336,15 +349,18 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         ctx.v_lomask = None
         if planes is not None:       # split-precision flavour: same outputs, f16x3 matrix products
             qh, ql, kh, kl, vh, vl, v_scale, v_amax, v_lomask = planes[:9]
+            qk_scales = planes[13] if len(planes) > 13 else None      # (q_scale, k_scale) device scalars, or None
             if keep_logits:          # the forward's private tile-blocked layout (cocos_hip.h), opaque here
                 nbytes = _lib.load().cocos_corr_softmax_warp_saved_logits_bytes(B, Nq, Nk)
                 logits_t = torch.empty(nbytes // 4, device=qn.device, dtype=torch.float32)
             _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd_f16x3", qh.data_ptr(), ql.data_ptr(),
                   kh.data_ptr(), kl.data_ptr(), vh.data_ptr(), vl.data_ptr(), out.data_ptr(), lse.data_ptr(),
                   _ptr(logits_t), v_scale.data_ptr(), _ptr(v_lomask), B, K, Nq, Nk, Cv, float(inv_temperature),
-                  SPLIT_OPERAND_SCALE, _stream())
+                  SPLIT_OPERAND_SCALE, _ptr(qk_scales[0] if qk_scales else None), _ptr(qk_scales[1] if qk_scales else None),
+                  _stream())
             ctx.v_amax = v_amax
             ctx.v_lomask = v_lomask
+            ctx.qk_scales = qk_scales
         else:
             keep = (keep_logits and B * Nq * Nk * 4 <= MAX_DS_WORKSPACE_BYTES and Nq * Nk * 4 < 2 ** 31 - 1)
             logits_t = torch.empty((B, Nk, Nq), device=qn.device, dtype=torch.float32) if keep else None
@@ -355,7 +371,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         ctx.logits_t = logits_t
         ctx.inv_t = float(inv_temperature)
         # channel-major planes of k_scale*qn, k_scale*kn for the split-precision backward (when given)
-        ctx.cplanes = planes[9:] if (planes is not None and len(planes) > 9 and logits_t is not None) else None
+        ctx.cplanes = planes[9:13] if (planes is not None and len(planes) > 9 and logits_t is not None) else None
         return out
 
     @staticmethod
@@ -374,6 +390,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             # split-precision backward: everything on the f16 MFMA, fp32-class accuracy (see cocos_hip.h).  The
             # forward only takes this flavour (and saves its private logits layout) for shapes this branch takes.
             qch, qcl, kch, kcl = ctx.cplanes
+            qks = ctx.qk_scales
             cvp = (Cv + 31) // 32 * 32
             g_amax, v_amax = _recall_amax(dout), ctx.v_amax   # max|v| was taken once, by the forward; max|dout| comes
             if g_amax is None:                                # with dout when concat_channels_amax produced it
@@ -399,11 +416,11 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                   g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), logits_t.data_ptr(),
                   dqn_buf.data_ptr(), _ptr(dsh), _ptr(dsl), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
                   v_scale.data_ptr(), ds_scale.data_ptr(), _ptr(ctx.v_lomask), B, K, Nq, Nk, Cv, cvp, ctx.inv_t,
-                  SPLIT_OPERAND_SCALE, blocked, st)
-            if want_k:
+                  SPLIT_OPERAND_SCALE, _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked, st)
+            if want_k:    # A = the channel-major planes of q_scale * qn
                 _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
-                      dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 / SPLIT_OPERAND_SCALE,
-                      ds_scale.data_ptr(), 0, gemm_b, st)
+                      dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 if qks else 1.0 / SPLIT_OPERAND_SCALE,
+                      ds_scale.data_ptr(), _ptr(qks[0] if qks else None), gemm_b, st)
             if dv is not None:      # dv[c,j] = sum_i dout[c,i] P[i,j]
                 gch, gcl, _ = split_f16(dout, False, amax=g_amax)
                 _call("corr_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(),
@@ -442,12 +459,14 @@ def _wants_logits(qn, kn):
     return torch.is_grad_enabled() and (qn.requires_grad or kn.requires_grad)
 
 
-def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes | None = None):
+def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes | None = None, operand_amax: bool = False):
     """out[b,c,i] = sum_j softmax_j(<qn[b,:,i], kn[b,:,j]> * inv_temperature) * v[b,c,j].
 
     qn [B,256,Nq], kn [B,256,Nk], v [B,Cv,Nk] -> [B,Cv,Nq].  Wider V is processed in chunks of
     159 channels (each chunk recomputes the logits; no materialisation).  `planes`: the caller's per-forward
-    OperandPlanes (theta/phi planes shared by several launches); None = made for this call only."""
+    OperandPlanes (theta/phi planes shared by several launches); None = made for this call only.  `operand_amax`: qn / kn
+    are NOT unit-norm columns (softmax_attention): their planes get device-side power-of-two scales from max|.| instead of
+    the fixed SPLIT_OPERAND_SCALE (split flavour only; raises if this shape cannot take it)."""
     B, K, Nq = qn.shape
     Nk, Cv = kn.shape[2], v.shape[1]
     keep = _wants_logits(qn, kn)
@@ -460,6 +479,8 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes |
              and (not keep or _split_bwd_ok(B, Nq, Nk, chunk)))
     if planes is None:
         planes = OperandPlanes()
+    if operand_amax and not split:
+        raise _lib.CocosHipError("corr_softmax_warp: operand_amax needs the split-precision kernels for this shape")
     if not split and (planes.has(qn) or planes.has(kn)):
         raise _lib.CocosHipError("corr_softmax_warp: qn / kn exist as operand planes only (center_l2norm_planes) but this "
                                  "shape does not take the split-precision kernels")
@@ -476,10 +497,17 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes |
                 # V planes, and which 32-channel blocks of V have a non-zero lo plane (one-hot labels / masks are exact in
                 # f16: theirs is all zero and the kernels skip it) — the same launch, only when it can pay
                 vh, vl, v_scale, v_lomask = split_f16_chan_mask(vv, v_amax, VALUE_LO_SKIP and vv.shape[1] > 32)
-                pl = (*planes.get(qn, True, SPLIT_OPERAND_SCALE), *planes.get(kn, True, SPLIT_OPERAND_SCALE),
-                      vh, vl, v_scale, v_amax, v_lomask)
-                if keep:   # the backward wants the channel-major planes as well
-                    pl += (*planes.get(qn, False, SPLIT_OPERAND_SCALE), *planes.get(kn, False, SPLIT_OPERAND_SCALE))
+                if operand_amax:
+                    qh, ql, qs = planes.get_scaled(qn, True)
+                    kh, kl, ks = planes.get_scaled(kn, True)
+                    pl = (qh, ql, kh, kl, vh, vl, v_scale, v_amax, v_lomask)
+                    cpl = (*planes.get_scaled(qn, False)[:2], *planes.get_scaled(kn, False)[:2]) if keep else (None,) * 4
+                    pl += cpl + ((qs, ks),)
+                else:
+                    pl = (*planes.get(qn, True, SPLIT_OPERAND_SCALE), *planes.get(kn, True, SPLIT_OPERAND_SCALE),
+                          vh, vl, v_scale, v_amax, v_lomask)
+                    if keep:   # the backward wants the channel-major planes as well
+                        pl += (*planes.get(qn, False, SPLIT_OPERAND_SCALE), *planes.get(kn, False, SPLIT_OPERAND_SCALE))
         return _CorrSoftmaxWarp.apply(qn, kn, vv, inv_temperature, keep, pl)
 
     limit = MAX_FUSED_SPLIT_CV if split else MAX_FUSED_CV
@@ -1066,12 +1094,13 @@ class _Box3SoftmaxWarp(torch.autograd.Function):
         v_amax = _recall_amax(v)
         if v_amax is None:
             v_amax = absmax(v)
-        vh, vl, v_scale = split_f16(v, False, amax=v_amax)
+        vh, vl, v_scale, v_lomask = split_f16_chan_mask(v, v_amax, VALUE_LO_SKIP and Cv > 32)
         out = torch.empty((B, Cv, N), device=v.device, dtype=torch.float32)
         lse = torch.empty((B, N), device=v.device, dtype=torch.float32)
         _call("box3_softmax_warp_fwd", "cocos_box3_softmax_warp_fwd_f16x3", t.data_ptr(), mu.data_ptr(), a.data_ptr(),
               nu.data_ptr(), b.data_ptr(), vh.data_ptr(), vl.data_ptr(), out.data_ptr(), lse.data_ptr(), v_scale.data_ptr(),
-              B, N, N, Cv, h, w, float(kc), float(scale), _stream())
+              _ptr(v_lomask), B, N, N, Cv, h, w, float(kc), float(scale), _stream())
+        ctx.v_lomask = v_lomask
         ctx.save_for_backward(t, mu, a, nu, b, v, out, lse)
         ctx.cfg = (int(h), int(w), float(kc), float(scale))
         ctx.v_amax = v_amax
@@ -1102,7 +1131,7 @@ class _Box3SoftmaxWarp(torch.autograd.Function):
               nu.data_ptr(), b.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(), gs.data_ptr(),
               v_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), g.data_ptr(), dmu.data_ptr(),
               da.data_ptr(), dnu.data_ptr(), db.data_ptr(), colpart.data_ptr(), gmax.data_ptr(), _ptr(psh), _ptr(psl),
-              B, N, N, Cv, cvp, h, w, kc, scale, _stream())
+              _ptr(ctx.v_lomask), B, N, N, Cv, cvp, h, w, kc, scale, _stream())
         _remember_amax(g, gmax)
         dv = None
         if need_v:
@@ -1481,13 +1510,30 @@ def instnorm_prelu(x, residual, weight, eps: float = INSTNORM_EPS):
     return _InstNormPReLU.apply(x, residual, weight, eps)
 
 
+#: softmax_attention on the fused kernels for K < 256 as well (channels zero-padded to 256); "0": the materialised family
+ATTENTION_FUSED = os.environ.get("COCOS_ATTENTION_FUSED", "1") != "0"
+
+
 def softmax_attention(q, k, v, scale: float = 1.0):
     """out[b,c,i] = sum_j softmax_j(scale * <q[b,:,i], k[b,:,j]>) v[b,c,j] for any channel count K — the QK^T ->
     softmax -> PV op class of the path (`Attention.forward`, architecture.py:114-127, has K =
-    ch/8 = 32..64, HW/4 keys and ch/2 value channels).  K == 256 takes the fused kernels (K2); every other K the
-    materialised family on the same MFMA GEMMs (K3 -> K4 -> K5), autograd included."""
-    if q.shape[1] == FUSED_K:
-        return corr_softmax_warp(q, k, v, scale)
+    ch/8 = 32..64, HW/4 keys and ch/2 value channels).
+
+    K <= 256 on the split flavour: the FUSED kernels (K2) — nothing HWxHW is materialised in inference, training keeps the
+    saved logits like the correspondence itself.  q / k are raw 1x1-conv outputs here, not unit-norm columns: their operand
+    planes get device-side power-of-two scales from max|q|, max|k| (no fixed 2^4: ADVICE r2), and K < 256 is zero-padded to
+    the 256 channels the kernels are specialised for (the padded products are zeros: exact; 256 / K of the QK^T matrix work
+    is spent on them — still ~1.5x faster than the materialised route at the reference's shape and 4x less memory, see
+    tools/attention_bench.py).  Everything else: the materialised family on the same MFMA GEMMs (K3 -> K4 -> K5)."""
+    B, K, Nq = q.shape
+    Nk = k.shape[2]
+    keep = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)
+    if (ATTENTION_FUSED and K <= FUSED_K and q.is_cuda and q.dtype == torch.float32
+            and corr_split_ok(B, FUSED_K, Nq, Nk, v.shape[1], keep)):
+        if K < FUSED_K:      # zero channels: autograd slices the gradient back
+            q = torch.nn.functional.pad(q, (0, 0, 0, FUSED_K - K))
+            k = torch.nn.functional.pad(k, (0, 0, 0, FUSED_K - K))
+        return corr_softmax_warp(q, k, v, scale, operand_amax=True)
     return warp_materialized(row_softmax(corr_materialize(q, k, scale)), v)
 
 

@@ -132,7 +132,11 @@ int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void
                                       const float* v_scale_dev /* nullable */,
                                       const unsigned* v_lo_mask_dev /* nullable */,
                                       int B, int K, int Nq, int Nk, int Cv, float inv_temperature,
-                                      float operand_scale, cocos_stream_t stream);
+                                      float operand_scale,
+                                      const float* q_scale_dev /* nullable */, const float* k_scale_dev /* nullable: operands
+                                      without an a-priori magnitude (ops.softmax_attention) — planes scaled by device-side
+                                      powers of two (cocos_split_f16_ex); given as a pair they replace operand_scale */,
+                                      cocos_stream_t stream);
 /* bit (c >> 5) of *mask_inout_dev |= (channel c of the channel-major f16 plane [B,C,N] has a non-zero element); the
  * cell must hold 0 (or an earlier partial mask) on entry; C <= 1024.  Run on the LO plane of V: value channels that
  * are exact in f16 (one-hot labels, masks) have an all-zero lo plane, and when every 32-channel block but the first
@@ -178,6 +182,7 @@ int cocos_corr_softmax_warp_bwd_query_f16x3(
     void* psl /* nullable */, const float* v_amax_dev, const float* v_scale_dev /* nullable */,
     float* ds_scale_out_dev, const unsigned* v_lo_mask_dev /* nullable: as in the forward call */,
     int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale,
+    const float* q_scale_dev /* nullable */, const float* k_scale_dev /* nullable: as in the forward call */,
     int planes_blocked, cocos_stream_t stream);
 int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* c,
                       int batch, int M, int N, int K, float host_scale, const float* dev_scale /* nullable */,
@@ -550,16 +555,19 @@ int cocos_box3_corr_xbox_f16x3(const void* k_hi, const void* k_lo, const void* q
                                const float* q_scale_dev /* nullable */, cocos_stream_t stream);
 int cocos_box3_softmax_warp_fwd_f16x3(const float* t_blocked, const float* mu_q, const float* a_q, const float* nu_k,
                                       const float* b_k, const void* vh, const void* vl, float* out, float* lse,
-                                      const float* v_scale_dev /* nullable */, int B, int Nq, int Nk, int Cv, int grid_h,
-                                      int grid_w, float k_unfolded, float scale, cocos_stream_t stream);
+                                      const float* v_scale_dev /* nullable */,
+                                      const unsigned* v_lo_mask_dev /* nullable: as for cocos_corr_softmax_warp_fwd_f16x3 */,
+                                      int B, int Nq, int Nk, int Cv, int grid_h, int grid_w, float k_unfolded, float scale,
+                                      cocos_stream_t stream);
 size_t cocos_box3_softmax_warp_bwd_colpart_bytes(int B, int Nq, int Nk);
 int cocos_box3_softmax_warp_bwd_f16x3(const float* t_blocked, const float* mu_q, const float* a_q, const float* nu_k,
                                       const float* b_k, const void* vph, const void* vpl, const void* gph, const void* gpl,
                                       const float* g_scale_dev, const float* v_scale_dev /* nullable */, const float* out,
                                       const float* dout, const float* lse, float* g_blocked, float* dmu, float* da, float* dnu,
                                       float* db, void* colpart, float* gmax_dev, void* psh /* nullable */,
-                                      void* psl /* nullable */, int B, int Nq, int Nk, int Cv, int CvPad, int grid_h,
-                                      int grid_w, float k_unfolded, float scale, cocos_stream_t stream);
+                                      void* psl /* nullable */, const unsigned* v_lo_mask_dev /* nullable */, int B, int Nq,
+                                      int Nk, int Cv, int CvPad, int grid_h, int grid_w, float k_unfolded, float scale,
+                                      cocos_stream_t stream);
 int cocos_box3_adjoint_planes_f16x3(const float* g_blocked, const float* gmax_dev, void* dc_hi, void* dc_lo,
                                     float* scale_out_dev, int B, int Nq, int Nk, int grid_h, int grid_w,
                                     cocos_stream_t stream);
