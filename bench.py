@@ -108,9 +108,13 @@ def cpu_baseline_numpy(n_images, seed=0):
     from theta/phi on, batch 1 per call."""
     import numpy as np
     from oracle import corr_oracle as co
+    # ONE thread policy for both CPU figures (VERDICT r2): min(host cores, 32) BLAS threads, like the torch baseline below
+    used = min(os.cpu_count() or 1, 32)
+    limiter = None
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=used)
+        cores = used
     except Exception:
         cores = os.cpu_count() or 1
     rs = np.random.RandomState(seed)
@@ -131,6 +135,8 @@ def cpu_baseline_numpy(n_images, seed=0):
     for _ in range(n_images):
         one()
     dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits()
     return {"value": n_images / dt, "unit": "images/s", "cores": int(cores), "kind": "port",
             "sample": f"{n_images} images (batch 1 each) through oracle/corr_oracle.py in fp32 numpy: centre+L2norm, "
                       f"correlation, softmax, warp (Cv=154), and their backward; {dt:.1f} s wall"}
@@ -205,7 +211,8 @@ SPLIT_TAGS = ("corr_softmax_warp_fwd", "corr_softmax_warp_bwd_query", "corr_soft
 #: parameter counts of BASELINE config 4's exchange: theta/phi only (what the hot path owns),
 #: netCorr (59 M), netG + netCorr (156 M)
 PAYLOAD_PARAMS = {"path": 0, "netcorr": 59_000_000, "full": 156_000_000}
-PMC_FILE = {"f16x3": "r02_pmc_f16x3.json", "fp32": "r01_pmc_final.json"}
+PMC_FILE = {"f16x3": "r03_pmc_f16x3.json" if os.path.exists(os.path.join(REPO, "profiles", "r03_pmc_f16x3.json"))
+            else "r02_pmc_f16x3.json", "fp32": "r01_pmc_final.json"}
 # (the counters were taken on the general instantiations <..., 0>; the one that skips exact value blocks moves 8 MB less)
 PMC_KEY = {"f16x3": {"corr_softmax_warp_fwd": "corr_fwd_f16x3_kernel<5, 1, 0, 0",
                      "corr_softmax_warp_bwd_query": "corr_bwd_query_f16x3_kernel<5, 1, 0, 0, 0",
@@ -290,7 +297,9 @@ def roofline_of(kernels, precision):
     if split and dom in SPLIT_TAGS:
         peak = F16_MFMA_PEAK_TFLOPS / 3.0
         return {"bound": "mfma", "kernel": dom, "hbm": hbm, "achieved": kernels[dom]["alg_tflops"], "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(kernels[dom]["alg_tflops"] / peak, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(kernels[dom]["alg_tflops"] / peak, 4),
+                "frac_kind": "algorithmic FLOPs / (f16 MFMA peak / 3): the utilisation of the matrix pipe by ISSUED "
+                             "instructions is frac_issued", "traffic": traffic,
                 "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                 "avg_launch_ms": kernels[dom]["avg_ms"], "issued_tflops": kernels[dom]["issued_tflops"],
                 "frac_issued": kernels[dom]["frac_f16_mfma_peak"],
@@ -368,6 +377,7 @@ def main():
     buckets = cdist.GradBuckets(params) if world > 1 else None
     d = build_inputs(device, args.scope)
     ones = [torch.ones((), device=device) for _ in extra]
+    fwd_box = [fwd]          # the forward the step runs (the match_kernel-3 context window swaps it)
 
     def step():
         if buckets is not None:
@@ -378,7 +388,7 @@ def main():
         for k in ("cont_features", "ref_features"):
             if k in d:
                 d[k].grad = None
-        out = fwd(d)
+        out = fwd_box[0](d)
         # backward of the synthetic loss <warp_out, G_out> + <warp_mask, G_mask>: its gradients w.r.t. the two
         # outputs ARE the fixed tensors G, so they are fed to autograd directly (no loss kernels in the timing).
         # Gradient buckets leave for the all-reduce from autograd's hooks, while backward is still running.
@@ -422,7 +432,7 @@ def main():
     kern_all = kt_all.summary()
 
     # ---- extras, same process / same box, after the headline window (N = 1 only) --------------------------------
-    flavours, stability = {}, None
+    flavours, stability, context = {}, None, None
     if world == 1 and not args.no_extras and args.scope == "hotpath":
         sdt, _ = window(args.stability_steps, 0, tags=())
         stability = {"steps": args.stability_steps, "ms_per_step": round(sdt / args.stability_steps * 1e3, 4),
@@ -436,6 +446,37 @@ def main():
                            "images_per_s": round(BATCH_PER_GPU * args.steps / odt, 1), "steps": args.steps,
                            "kernels": ok, "roofline": roofline_of(ok, other)}
         ops.PRECISION = ops.PROJ_PRECISION = headline_precision
+        # the same step with the value-lo skipping switched off: what a workload WITHOUT exactly-representable label
+        # channels gets (BASELINE configs 3 and 5 carry float label maps) — the headline benefits from ADE20k's one-hot map
+        if headline_precision == "f16x3" and ops.VALUE_LO_SKIP:
+            ops.VALUE_LO_SKIP = False
+            gdt, gkern = window(args.steps, 3)
+            gk = kernel_table(gkern, headline_precision)
+            flavours["general_v"] = {"ms_per_step": round(gdt / args.steps * 1e3, 4),
+                                     "images_per_s": round(BATCH_PER_GPU * args.steps / gdt, 1), "steps": args.steps,
+                                     "kernels": gk, "note": "COCOS_VALUE_LO_SKIP=0: every V_lo term issued (78 MFMAs per "
+                                                            "32-key wave tile instead of 70)"}
+            ops.VALUE_LO_SKIP = True
+        # context: the reference's SHIPPED default match_kernel 3 on the same inputs (fused family K19 / K20)
+        if args.match_kernel == 1:
+            model3, fwd3 = make_step(args.scope, device, 3)
+            n_own = len(params)
+            params.extend(model3.parameters())            # their gradients are reset by the step like the headline model's
+            try:
+                fwd_box[0] = fwd3
+                mdt, mkern = window(args.steps, 3, tags=())
+                with ops.KernelTimer() as kt3:
+                    step()
+                context = {"match_kernel_3": {"ms_per_step": round(mdt / args.steps * 1e3, 4),
+                                              "images_per_s": round(BATCH_PER_GPU * args.steps / mdt, 1),
+                                              "abi_calls_ms_per_step": {t: round(r["total_ms"], 4)
+                                                                        for t, r in sorted(kt3.summary().items())},
+                                              "note": "same step with match_kernel 3 (options/base_options.py:70): x box in "
+                                                      "the correlation GEMM's epilogue, y box + softmax + warp in one kernel"}}
+            finally:
+                fwd_box[0] = fwd
+                del params[n_own:]
+            del model3
 
     # N > 1: what BASELINE config 4's exchanges cost on this node — timed AFTER the contract window, never part of `value`:
     # one in-place all-reduce (RCCL) of a flat fp32 buffer of netCorr's 59 M and of netG+netCorr's 156 M gradients
@@ -484,6 +525,8 @@ def main():
                                    + ("theta/phi 1x1 conv + centre/L2norm + fused corr-softmax-warp fwd+bwd"
                                       if args.scope == "hotpath" else
                                       "whole NoVGGCorrespondence module fwd+bwd (convolutions K16, norms K9/K13/K17, theta/phi K0)"),
+                       "untimed_steps_before_window": SETUP_STEPS + args.warmup,
+                       "context": context,
                        "global_batch": BATCH_PER_GPU * world, "parallelism": f"dp{world}",
                        "grad_payload": args.grad_payload,
                        "grad_allreduce_bytes": buckets.nbytes() if buckets is not None else 0,

@@ -146,6 +146,8 @@ _SIGNATURES = {
     "cocos_logits_softmax_warp_bwd_f16x3": (ctypes.c_int, [_c_float_p] + [ctypes.c_void_p] * 4 + [_c_float_p] * 6
                                             + [ctypes.c_int] * 5 + [_stream_t]),
     "cocos_unfold3_stats_fwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_float] * 2 + [_stream_t]),
+    "cocos_unfold3_stats_fwd_amax": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4
+                                     + [ctypes.c_float, ctypes.c_float, _c_float_p, _stream_t]),
     "cocos_unfold3_stats_bwd": (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float, _stream_t]),
     "cocos_instnorm_prelu_fwd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float, _stream_t]),
     "cocos_instnorm_prelu_bwd": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 2 + [ctypes.c_float, _stream_t]),

@@ -16,12 +16,14 @@ namespace cocos {
 
 // per-position channel sums: WG = 64 positions (16 quads) x 16 channel groups
 __global__ __launch_bounds__(256) void unfold3_sums_kernel(const float* __restrict__ x, float* __restrict__ s1,
-                                                           float* __restrict__ s2, int C, int N) {
+                                                           float* __restrict__ s2, int C, int N,
+                                                           unsigned* __restrict__ amax) {
     __shared__ __attribute__((aligned(16))) float red[2 * 16 * 64];
     const int tid = threadIdx.x, pq = tid & 15, cg = tid >> 4;
     const int b = blockIdx.y, n = blockIdx.x * 64 + pq * 4;
     const float* xb = x + (size_t)b * C * N;
     f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+    float vmax = 0.f;
     const bool vec = (N % 4 == 0) && n < N;
     for (int c = cg; c < C; c += 16) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -31,6 +33,7 @@ __global__ __launch_bounds__(256) void unfold3_sums_kernel(const float* __restri
             for (int e = 0; e < 4; ++e) if (n + e < N) v[e] = xb[(size_t)c * N + n + e];
         a1 += v;
         a2 += v * v;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
     *reinterpret_cast<f32x4*>(red + cg * 64 + pq * 4) = a1;
     *reinterpret_cast<f32x4*>(red + 1024 + cg * 64 + pq * 4) = a2;
@@ -42,6 +45,15 @@ __global__ __launch_bounds__(256) void unfold3_sums_kernel(const float* __restri
         for (int g = 0; g < 16; ++g) acc += red[which * 1024 + g * 64 + p];
         const int nn = blockIdx.x * 64 + p;
         if (nn < N) (which ? s2 : s1)[(size_t)b * N + nn] = acc;
+    }
+    // max|x| as a by-product (the scale source of the f16 split of x for the correlation GEMM that follows): one
+    // same-address atomic per workgroup
+    if (amax) {
+        __shared__ float wred[4];
+        vmax = wave_max_dpp(vmax);
+        if ((tid & 63) == 0) wred[tid >> 6] = vmax;
+        __syncthreads();
+        if (tid == 0) atomicMax(amax, __float_as_uint(fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]))));
     }
 }
 
@@ -121,8 +133,8 @@ __global__ __launch_bounds__(256) void unfold3_bwd_apply_kernel(const float* __r
 
 }  // namespace cocos
 
-extern "C" int cocos_unfold3_stats_fwd(const float* x, float* mu, float* a, float* nrm, float* ws /* 2*B*h*w */,
-                                       int B, int C, int h, int w, float k_unfolded, float eps, cocos_stream_t stream) {
+static int unfold3_stats_fwd_impl(const float* x, float* mu, float* a, float* nrm, float* ws, int B, int C, int h, int w,
+                                  float k_unfolded, float eps, float* amax_inout, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(x && mu && a && nrm && ws, COCOS_ERR_INVALID, "unfold3_stats_fwd: null pointer");
     COCOS_REQUIRE(B >= 1 && B <= 65535 && C >= 1 && h >= 1 && w >= 1 && k_unfolded > 0.f, COCOS_ERR_INVALID,
@@ -131,11 +143,25 @@ extern "C" int cocos_unfold3_stats_fwd(const float* x, float* mu, float* a, floa
     hipStream_t s = as_stream(stream);
     float* s1 = ws;
     float* s2 = ws + (size_t)B * N;
-    hipLaunchKernelGGL(unfold3_sums_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, x, s1, s2, C, N);
+    hipLaunchKernelGGL(unfold3_sums_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, x, s1, s2, C, N,
+                       reinterpret_cast<unsigned*>(amax_inout));
     hipLaunchKernelGGL(unfold3_finish_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, s1, s2, mu, a, nrm, h, w,
                        k_unfolded, eps);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+extern "C" int cocos_unfold3_stats_fwd(const float* x, float* mu, float* a, float* nrm, float* ws /* 2*B*h*w */,
+                                       int B, int C, int h, int w, float k_unfolded, float eps, cocos_stream_t stream) {
+    return unfold3_stats_fwd_impl(x, mu, a, nrm, ws, B, C, h, w, k_unfolded, eps, nullptr, stream);
+}
+
+// Same, and *amax_inout_dev = max(*amax_inout_dev, max|x|) (a cell holding a finite value >= 0): x is read once for both.
+extern "C" int cocos_unfold3_stats_fwd_amax(const float* x, float* mu, float* a, float* nrm, float* ws, int B, int C, int h,
+                                            int w, float k_unfolded, float eps, float* amax_inout_dev,
+                                            cocos_stream_t stream) {
+    COCOS_REQUIRE(amax_inout_dev, COCOS_ERR_INVALID, "unfold3_stats_fwd_amax: null amax cell");
+    return unfold3_stats_fwd_impl(x, mu, a, nrm, ws, B, C, h, w, k_unfolded, eps, amax_inout_dev, stream);
 }
 
 extern "C" int cocos_unfold3_stats_bwd(const float* x, const float* mu, const float* a, const float* nrm,

@@ -658,7 +658,7 @@ class _ThreadState(threading.local):
 
 
 _tls = _ThreadState()
-_KNOWN_AMAX_MAX = 2      # entries per thread
+_KNOWN_AMAX_MAX = 4      # entries per thread
 
 
 def _remember_amax(t: torch.Tensor, cell: torch.Tensor):
@@ -1037,7 +1037,9 @@ class _Box3CorrXbox(torch.autograd.Function):
         B, K, h, w = q_raw.shape
         N = h * w
         qf, kf = q_raw.reshape(B, K, N), k_raw.reshape(B, K, N)
-        qa, ka = absmax(qf), absmax(kf)
+        qa, ka = _recall_amax(qf, consume=False), _recall_amax(kf, consume=False)   # left by K12 (both orientations read them)
+        qa = absmax(qf) if qa is None else qa
+        ka = absmax(kf) if ka is None else ka
         qh, ql, qs = split_f16(qf, True, amax=qa)            # position-major planes [B,N,K]
         kh, kl, ks = split_f16(kf, True, amax=ka)
         t = torch.empty(B * N * N, device=q_raw.device, dtype=torch.float32)
@@ -1163,8 +1165,14 @@ class _Unfold3Stats(torch.autograd.Function):
         mk = lambda: torch.empty((B, h * w), device=x.device, dtype=torch.float32)
         mu, a, nrm = mk(), mk(), mk()
         ws = torch.empty(2 * B * h * w, device=x.device, dtype=torch.float32)
-        _call("unfold3_stats_fwd", "cocos_unfold3_stats_fwd", x.data_ptr(), mu.data_ptr(), a.data_ptr(), nrm.data_ptr(),
-              ws.data_ptr(), B, C, h, w, float(k_unfolded), float(eps), _stream())
+        if PRECISION == "f16x3":      # max|x| as a by-product: the correlation GEMM of the fused family splits x next
+            cell = _zero_cell(x.device)
+            _call("unfold3_stats_fwd", "cocos_unfold3_stats_fwd_amax", x.data_ptr(), mu.data_ptr(), a.data_ptr(),
+                  nrm.data_ptr(), ws.data_ptr(), B, C, h, w, float(k_unfolded), float(eps), cell.data_ptr(), _stream())
+            _remember_amax(x, cell)
+        else:
+            _call("unfold3_stats_fwd", "cocos_unfold3_stats_fwd", x.data_ptr(), mu.data_ptr(), a.data_ptr(), nrm.data_ptr(),
+                  ws.data_ptr(), B, C, h, w, float(k_unfolded), float(eps), _stream())
         ctx.save_for_backward(x, mu, a, nrm)
         ctx.kc = float(k_unfolded)
         ctx.mark_non_differentiable(nrm)

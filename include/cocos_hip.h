@@ -581,6 +581,9 @@ int cocos_box3_adjoint_planes_f16x3(const float* g_blocked, const float* gmax_de
  * ------------------------------------------------------------------------------------- */
 int cocos_unfold3_stats_fwd(const float* x, float* mu, float* a, float* nrm, float* ws,
                             int B, int C, int h, int w, float k_unfolded, float eps, cocos_stream_t stream);
+/* Same, and *amax_inout_dev = max(*amax_inout_dev, max|x|): the scale source of the f16 split of x (K19's correlation GEMM). */
+int cocos_unfold3_stats_fwd_amax(const float* x, float* mu, float* a, float* nrm, float* ws, int B, int C, int h, int w,
+                                 float k_unfolded, float eps, float* amax_inout_dev, cocos_stream_t stream);
 int cocos_unfold3_stats_bwd(const float* x, const float* mu, const float* a, const float* nrm,
                             const float* dmu, const float* da, float* dx, float* ws,
                             int B, int C, int h, int w, float k_unfolded, cocos_stream_t stream);
