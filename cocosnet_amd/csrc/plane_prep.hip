@@ -136,7 +136,94 @@ __global__ __launch_bounds__(256) void proj_weight_planes_kernel(const float* __
     }
 }
 
+// out[i] = sum_s x[s][i]: the sum over the leading dimension of [S][n] partial tiles (weight-gradient partials of the
+// general split GEMMs) — one thread per float4 column group, S small
+__global__ __launch_bounds__(256) void sum_leading_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ out, int S,
+                                                          size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 acc = x[i];
+    for (int s = 1; s < S; ++s) acc += x[(size_t)s * n4 + i];
+    out[i] = acc;
+}
+__global__ __launch_bounds__(256) void sum_leading_tail_kernel(const float* __restrict__ x, float* __restrict__ out, int S,
+                                                               size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = x[i];
+    for (int s = 1; s < S; ++s) acc += x[(size_t)s * n + i];
+    out[i] = acc;
+}
+
+// db[c] = sum over b, n of dy[b][c][n]  (the bias gradient of a convolution: dy.sum((0, 2, 3))): one workgroup per channel
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dy, float* __restrict__ db, int B, int C,
+                                                          int N) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* p = dy + ((size_t)b * C + c) * N;
+        for (int i = threadIdx.x; i < N; i += 256) acc += p[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) db[c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// the four statistic gradients of K6's backward from its row / column sums (box3_unfold.hip; ops._Box3Logits.backward)
+__global__ __launch_bounds__(256) void box3_stat_grads_kernel(const float* __restrict__ r1, const float* __restrict__ r2,
+                                                              const float* __restrict__ c1, const float* __restrict__ c2,
+                                                              const float* __restrict__ a, const float* __restrict__ b,
+                                                              float* __restrict__ dmu, float* __restrict__ dnu,
+                                                              float* __restrict__ da, float* __restrict__ db, size_t n,
+                                                              float kcs) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float av = a[i], bv = b[i];
+    dmu[i] = -kcs * av * r1[i];
+    dnu[i] = -kcs * bv * c1[i];
+    da[i] = r2[i] / av;
+    db[i] = c2[i] / bv;
+}
+
 }  // namespace cocos
+
+extern "C" int cocos_sum_leading(const float* x, float* out, int S, long long n, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && out && S >= 1 && n >= 1, COCOS_ERR_INVALID, "sum_leading: bad arguments");
+    if (n % 4 == 0 && aligned16(x) && aligned16(out)) {
+        const size_t n4 = (size_t)n / 4;
+        hipLaunchKernelGGL(sum_leading_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream),
+                           reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(out), S, n4);
+    } else {
+        hipLaunchKernelGGL(sum_leading_tail_kernel, dim3((unsigned)(((size_t)n + 255) / 256)), dim3(256), 0,
+                           as_stream(stream), x, out, S, (size_t)n);
+    }
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_channel_sum(const float* dy, float* db, int B, int C, long long N, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(dy && db && B >= 1 && C >= 1 && N >= 1 && N <= 0x7fffffffLL, COCOS_ERR_INVALID, "channel_sum: bad arguments");
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)C), dim3(256), 0, as_stream(stream), dy, db, B, C, (int)N);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_box3_stat_grads(const float* r1, const float* r2, const float* c1, const float* c2, const float* a,
+                                     const float* b, float* dmu, float* dnu, float* da, float* db, long long n,
+                                     float k_unfolded, float scale, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(r1 && r2 && c1 && c2 && a && b && dmu && dnu && da && db && n >= 1, COCOS_ERR_INVALID,
+                  "box3_stat_grads: bad arguments");
+    hipLaunchKernelGGL(box3_stat_grads_kernel, dim3((unsigned)(((size_t)n + 255) / 256)), dim3(256), 0, as_stream(stream), r1,
+                       r2, c1, c2, a, b, dmu, dnu, da, db, (size_t)n, k_unfolded * scale);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
 
 extern "C" int cocos_concat2_amax(const float* a, const float* b, float* out, int B, long long na, long long nb,
                                   float* amax_inout_dev, cocos_stream_t stream) {

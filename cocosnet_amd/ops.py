@@ -707,6 +707,23 @@ def absmax(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def sum_leading(x: torch.Tensor) -> torch.Tensor:
+    """x.sum(0) for contiguous fp32 partial tiles [S, ...] (cocos_sum_leading)."""
+    x = _chk(x, "sum_leading: x")
+    out = torch.empty(x.shape[1:], device=x.device, dtype=torch.float32)
+    _call("sum_leading", "cocos_sum_leading", x.data_ptr(), out.data_ptr(), x.shape[0], out.numel(), _stream())
+    return out
+
+
+def channel_sum(dy: torch.Tensor) -> torch.Tensor:
+    """dy.sum((0, 2, 3)) of a contiguous fp32 [B,C,...] tensor: the bias gradient of a convolution (cocos_channel_sum)."""
+    dy = _chk(dy, "channel_sum: dy")
+    B, C = dy.shape[:2]
+    db = torch.empty(C, device=dy.device, dtype=torch.float32)
+    _call("channel_sum", "cocos_channel_sum", dy.data_ptr(), db.data_ptr(), B, C, dy.numel() // (B * C), _stream())
+    return db
+
+
 class _Proj1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -803,7 +820,7 @@ class _Proj1x1(torch.autograd.Function):
                       dx.data_ptr() if dx_gemm else None, _ptr(dwb), B, Cin, Cout, N, xa.data_ptr(), wa.data_ptr(),
                       ga.data_ptr(), _stream())
                 if dw_gemm:
-                    dw = dwb.sum(0)                                         # [P,256,Cl] partials, small
+                    dw = sum_leading(dwb)                                   # [P,256,Cl] partials, small
         else:
             dwb = None
             if need_w:
@@ -812,11 +829,11 @@ class _Proj1x1(torch.autograd.Function):
             _call("proj1x1_bwd", "cocos_proj1x1_bwd", x.data_ptr(), w2.data_ptr(), dy.data_ptr(), _ptr(dx),
                   _ptr(dwb), B, Cin, Cout, N, _stream())
             if need_w:
-                dw = dwb.sum(0)
+                dw = sum_leading(dwb)
         if need_w:
             dw = dw.reshape(ctx.wshape)
         if need_b and db is None:
-            db = dy.sum(dim=(0, 2, 3))
+            db = channel_sum(dy)
         return dx, dw, db
 
 
@@ -950,7 +967,7 @@ class _Conv2d(torch.autograd.Function):
             dw = torch.empty_like(weight)          # sum over the S slices + back to [Cout, Cin, KH, KW] in one pass
             _call("conv2d_wgrad", "cocos_conv2d_wgrad_reduce", part.data_ptr(), dw.data_ptr(), S, Cout, Cin, KH, KW, _stream())
         if need_b and has_bias:
-            db = dy.sum((0, 2, 3))
+            db = channel_sum(dy)
         return dx, dw, db, None, None, None
 
 
@@ -1000,10 +1017,10 @@ class _Box3Logits(torch.autograd.Function):
             _call("box3_logits_bwd", "cocos_box3_logits_bwd", g.data_ptr(), f.data_ptr(), mu.data_ptr(),
                   nu.data_ptr(), a.data_ptr(), b.data_ptr(), dc.data_ptr(), r1.data_ptr(), r2.data_ptr(),
                   c1.data_ptr(), c2.data_ptr(), ws.data_ptr(), ws.numel() * 4, B, h, w, scale, _stream())
-        dmu = -kc * scale * a * r1
-        dnu = -kc * scale * b * c1
-        da = r2 / a
-        db = c2 / b
+        dmu, dnu, da, db = (torch.empty_like(r1) for _ in range(4))
+        _call("box3_logits_bwd", "cocos_box3_stat_grads", r1.data_ptr(), r2.data_ptr(), c1.data_ptr(), c2.data_ptr(),
+              a.data_ptr(), b.data_ptr(), dmu.data_ptr(), dnu.data_ptr(), da.data_ptr(), db.data_ptr(), r1.numel(), kc, scale,
+              _stream())
         return dc, dmu, dnu, da, db, None, None, None, None
 
 
@@ -1508,7 +1525,7 @@ class _InstNormPReLU(torch.autograd.Function):
         dap = torch.empty(B * C, device=x.device, dtype=torch.float32) if need_w else None
         _call("instnorm_prelu_bwd", "cocos_instnorm_prelu_bwd", x.data_ptr(), _ptr(res), w.data_ptr(), dy.data_ptr(),
               _ptr(dx), _ptr(dr), _ptr(dap), B * C, N, ctx.eps, _stream())
-        dw = dap.sum().reshape(w.shape) if need_w else None
+        dw = channel_sum(dap.reshape(1, 1, -1)).reshape(w.shape) if need_w else None   # one workgroup sums the B*C partials
         return dx, dr, dw, None
 
 

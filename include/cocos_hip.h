@@ -423,6 +423,16 @@ int cocos_proj_weight_planes(const float* w, void* rows_hi, void* rows_lo, void*
                              void* t_lo /* nullable */, int Cout, int Cin, int KpadIn, int KpadOut, const float* amax_dev,
                              float* scale_out_dev /* nullable */, cocos_stream_t stream);
 
+/* Small reductions that used to be framework calls inside the autograd Functions:
+ *   cocos_sum_leading: out[i] = sum_s x[s][i] over [S][n] partial tiles (weight-gradient partials of the general GEMMs);
+ *   cocos_channel_sum: db[c] = sum_{b,n} dy[b][c][n] (the bias gradient of a convolution, dy.sum((0,2,3)));
+ *   cocos_box3_stat_grads: dmu = -k s a r1, dnu = -k s b c1, da = r2 / a, db = c2 / b from K6's row / column sums. */
+int cocos_sum_leading(const float* x, float* out, int S, long long n, cocos_stream_t stream);
+int cocos_channel_sum(const float* dy, float* db, int B, int C, long long N, cocos_stream_t stream);
+int cocos_box3_stat_grads(const float* r1, const float* r2, const float* c1, const float* c2, const float* a, const float* b,
+                          float* dmu, float* dnu, float* da, float* db, long long n, float k_unfolded, float scale,
+                          cocos_stream_t stream);
+
 /* K7 on the f16 MFMA (same contract as cocos_logits_softmax_warp_fwd / _bwd; operand planes as for K2's split flavour):
  *   fwd: vh,vl [B,Cv,Nk] channel-major planes of s_v*v, s_v = *v_scale_dev (NULL = 1; undone in the epilogue); Nk % 4 == 0
  *   bwd: vph,vpl [B,Nk,CvPad] and gph,gpl [B,Nq,CvPad] position-major planes of s_v*v and of (*g_scale_dev)*dout
