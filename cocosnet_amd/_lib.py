@@ -175,6 +175,7 @@ _SIGNATURES = {
     "cocos_conv2d_wgrad_reduce": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 5 + [_stream_t]),
     "cocos_conv2d_wgrad_slices": (ctypes.c_int, [ctypes.c_int] * 10),
     "cocos_conv2d_wgrad_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 10 + [_stream_t]),
+    "cocos_conv2d_wgrad_bf16": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 10 + [_stream_t]),
     "cocos_debug_mfma_probe": (ctypes.c_int, [_c_float_p, _stream_t]),
 }
 
@@ -218,5 +219,7 @@ def call(name: str, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.cocos_last_error_string()
-        raise CocosHipError(f"{name} failed with code {rc}: {msg.decode() if msg else ''}")
+        err = CocosHipError(f"{name} failed with code {rc}: {msg.decode() if msg else ''}")
+        err.code = rc                # COCOS_ERR_* of include/cocos_hip.h
+        raise err
     return rc

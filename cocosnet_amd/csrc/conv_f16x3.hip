@@ -105,6 +105,20 @@ __device__ __forceinline__ float cv_scale_from_amax(const float* amax) {
     return ldexpf(1.0f, 10 - e);
 }
 
+// ONE-term flavour (BASELINE config 3's precision for the SPADE / PatchGAN convolutions: "bf16 MFMA"): operands are single
+// bf16 planes (fp32 range: no amax pass, no power-of-two scales), one v_mfma_f32_32x32x16_bf16 per product instead of three
+// f16 ones, fp32 accumulate.  8 mantissa bits per operand: NOT for anything upstream of the correlation (its features end
+// up times 100 inside a softmax) — for the generator / discriminator stacks behind InstanceNorm / SPADE.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cv_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float cv_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cv_pack_bf16(float a, float b) {     // round to nearest even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(cv_f32x2{a, b}, cv_bf16x2));
+}
+__device__ __forceinline__ f32x16 cv_mfma_bf16(f16x8 a, f16x8 b, f32x16 c) {     // the planes are typed f16x8 in this file
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // x*s -> f16 hi (round toward zero) + f16 lo, four values
 __device__ __forceinline__ void cv_split4(const float (&x)[4], float s, u32x2& hi, u32x2& lo) {
     unsigned h0, l0, h1, l1;
@@ -146,7 +160,7 @@ __device__ __forceinline__ f32x4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned b
 // The X descriptor starts `shift` = pad*W + pad elements BEFORE the tensor so that every per-thread offset constant is
 // >= 0 (the step offset travels in the scalar offset, which the hardware does not range-check): nothing below X is ever
 // dereferenced — a lane whose window corner lies outside the image is masked to the out-of-range offset.
-template <int BM, int BN, bool FAST4>
+template <int BM, int BN, bool FAST4, bool ONE = false>
 __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void conv_fwd_kernel(const float* __restrict__ X, const _Float16* __restrict__ wh,
                                                           const _Float16* __restrict__ wl,
                                                           const float* __restrict__ w_scale, const float* __restrict__ x_amax,
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
     const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(X - shift, ((size_t)g.xelems + shift) * 4);
     const size_t wbytes = (size_t)M * g.Ktot * 2;
     const __amdgpu_buffer_rsrc_t wh_rs = make_rsrc(wh, wbytes), wl_rs = make_rsrc(wl, wbytes);
-    const float sx = cv_scale_from_amax(x_amax);
+    const float sx = ONE ? 1.0f : cv_scale_from_amax(x_amax);
 
     // the thread's columns: 4 consecutive GEMM columns n .. n+3
     constexpr int NC = FAST4 ? 1 : 4;
@@ -250,7 +264,7 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
     auto fetch_a = [&](Stage& S, int u) {
         if (COCOS_CONV_ABLATE & 2) { S.a[0][u] = S.a[1][u] = u32x4{f_soffa, 0u, 0u, 0u}; return; }
         S.a[0][u] = __builtin_amdgcn_raw_buffer_load_b128(wh_rs, (int)voffa[u], (int)f_soffa, 0);
-        S.a[1][u] = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, (int)voffa[u], (int)f_soffa, 0);
+        if (!ONE) S.a[1][u] = __builtin_amdgcn_raw_buffer_load_b128(wl_rs, (int)voffa[u], (int)f_soffa, 0);
     };
     auto fetch_g = [&](Stage& S, int u, auto edge_tag) __attribute__((always_inline)) {
         if (COCOS_CONV_ABLATE & 1) {
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
         _Float16* ab = at + buf * 2 * APLANE;
         const int idx = u * 256 + tid, row = idx >> 2, kc = idx & 3;
         *reinterpret_cast<u32x4*>(ab + row * CV_AROW + kc * 8) = S.a[0][u];
-        *reinterpret_cast<u32x4*>(ab + APLANE + row * CV_AROW + kc * 8) = S.a[1][u];
+        if (!ONE) *reinterpret_cast<u32x4*>(ab + APLANE + row * CV_AROW + kc * 8) = S.a[1][u];
     };
     auto commit_g = [&](Stage& S, int buf, int u) {
         if (COCOS_CONV_ABLATE & 4) return;
@@ -296,9 +310,14 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
 #pragma unroll
             for (int e = 0; e < 4; ++e) S.gv[u][e] = S.mk[e] ? S.gv[u][e] : 0.f;
         }
+        const int kk = u * RPP + rowsub, col = 4 * cg;
+        if (ONE) {
+            *reinterpret_cast<u32x2*>(gb + kk * GROW + col) =
+                u32x2{cv_pack_bf16(S.gv[u][0], S.gv[u][1]), cv_pack_bf16(S.gv[u][2], S.gv[u][3])};
+            return;
+        }
         u32x2 hi, lo;
         cv_split4(S.gv[u], sx, hi, lo);
-        const int kk = u * RPP + rowsub, col = 4 * cg;
         *reinterpret_cast<u32x2*>(gb + kk * GROW + col) = hi;
         *reinterpret_cast<u32x2*>(gb + GPLANE + kk * GROW + col) = lo;
     };
@@ -337,15 +356,17 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
             const _Float16* p = gb + s * 16 * GROW + j * 32;
             const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
             const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + 4 * GROW));
-            const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE));
-            const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE + 4 * GROW));
             fbh[s][j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
-            fbl[s][j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+            if (!ONE) {
+                const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE));
+                const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p + GPLANE + 4 * GROW));
+                fbl[s][j] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             fah[s][i] = *reinterpret_cast<const f16x8*>(ab + i * 32 * CV_AROW + s * 16);
-            fal[s][i] = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * CV_AROW + s * 16);
+            if (!ONE) fal[s][i] = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * CV_AROW + s * 16);
         }
     };
     // One step = one k-block of 32, ONE barrier, in its middle.  The operand fragments run half a step ahead of the MFMAs:
@@ -374,12 +395,17 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
                 if (!(COCOS_CONV_ABLATE & 8)) {
                     // term-major: two MFMAs on the same accumulator are never neighbours (an instruction issued between
                     // two dependent MFMAs costs a ~43-cycle bubble on gfx950; between independent ones ~6)
+                    if (ONE) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = cv_mfma_bf16(fah[s][i], fbh[s][j], acc[i][j]);
+                    } else {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s][j], acc[i][j], 0, 0, 0);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
+                    }
                 }
                 if (s == 0) {
                     commit_a(S, buf ^ 1, i);
@@ -395,9 +421,9 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
                 // one MFMA, then up to COCOS_CONV_SCHED_N instructions of any other kind (a wave that owns its SIMD issues
                 // about one instruction per 4-5 cycles: ~7 fit beside a 32-cycle MFMA)
 #pragma unroll
-                for (int q = 0; q < 3 * MI * NJ; ++q) {
+                for (int q = 0; q < (ONE ? 1 : 3) * MI * NJ; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x010 | 0x080, COCOS_CONV_SCHED_N, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x010 | 0x080, ONE ? 3 * COCOS_CONV_SCHED_N : COCOS_CONV_SCHED_N, 0);
                 }
             }
             CPH_T(tsb);
@@ -425,7 +451,7 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
     // two copies of the loop: the common one has no branch in its body (one scheduling region per step)
     if (edge_tile) run(std::true_type{}); else run(std::false_type{});
 
-    const float oscale = 1.0f / ((w_scale ? *w_scale : 1.0f) * sx);
+    const float oscale = ONE ? 1.0f : 1.0f / ((w_scale ? *w_scale : 1.0f) * sx);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + wn * (32 * NJ) + j * 32 + c;
@@ -449,7 +475,7 @@ __global__ __launch_bounds__(256, (BM == 128 && COCOS_CONV_OCC2) ? 2 : 1) void c
 // --------------------------------------------------------------------------------------------------------------------
 // weight gradient: partial[slice][co][k] over the slice's positions, k = ((ci/32) * T + tap) * 32 + ci%32
 // --------------------------------------------------------------------------------------------------------------------
-template <int BM, bool FAST4>
+template <int BM, bool FAST4, bool ONE = false>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
                                                             const float* __restrict__ x_amax,
                                                             const float* __restrict__ g_amax, float* __restrict__ part,
@@ -476,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
 
     const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(X - shift, ((size_t)g.xelems + shift) * 4);
     const __amdgpu_buffer_rsrc_t y_rs = make_rsrc(dY, (size_t)ybytes);
-    const float sx = cv_scale_from_amax(x_amax), sg = cv_scale_from_amax(g_amax);
+    const float sx = ONE ? 1.0f : cv_scale_from_amax(x_amax), sg = ONE ? 1.0f : cv_scale_from_amax(g_amax);
     const int ohw = g.OH * g.OW;
     // a 16-byte piece can cross the ends of the whole tensor only for windows in the first rows of the first image /
     // the last rows of the last one (conservative, workgroup-uniform): those slices run the loop copy with the check
@@ -571,9 +597,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
     };
     auto commit_a = [&](Stage& S, int buf, int u) {
         _Float16* ab = at + buf * 2 * APLANE;
+        const int row = u * 32 + (tid >> 3);
+        if (ONE) {
+            *reinterpret_cast<u32x2*>(ab + row * CV_AROW + q4) =
+                u32x2{cv_pack_bf16(S.a[u][0], S.a[u][1]), cv_pack_bf16(S.a[u][2], S.a[u][3])};
+            return;
+        }
         u32x2 hi, lo;
         cv_split4(S.a[u], sg, hi, lo);
-        const int row = u * 32 + (tid >> 3);
         *reinterpret_cast<u32x2*>(ab + row * CV_AROW + q4) = hi;
         *reinterpret_cast<u32x2*>(ab + APLANE + row * CV_AROW + q4) = lo;
     };
@@ -583,9 +614,14 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
 #pragma unroll
             for (int e = 0; e < 4; ++e) S.gv[u][e] = (unsigned)(S.xs[u] + e) < (unsigned)g.W ? S.gv[u][e] : 0.f;
         }
+        const int row = u * 32 + (tid >> 3);
+        if (ONE) {
+            *reinterpret_cast<u32x2*>(bb + row * CV_AROW + q4) =
+                u32x2{cv_pack_bf16(S.gv[u][0], S.gv[u][1]), cv_pack_bf16(S.gv[u][2], S.gv[u][3])};
+            return;
+        }
         u32x2 hi, lo;
         cv_split4(S.gv[u], sx, hi, lo);
-        const int row = u * 32 + (tid >> 3);
         *reinterpret_cast<u32x2*>(bb + row * CV_AROW + q4) = hi;
         *reinterpret_cast<u32x2*>(bb + BPLANE + row * CV_AROW + q4) = lo;
     };
@@ -619,12 +655,12 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             fbh[s][j] = *reinterpret_cast<const f16x8*>(bb + j * 32 * CV_AROW + s * 16);
-            fbl[s][j] = *reinterpret_cast<const f16x8*>(bb + BPLANE + j * 32 * CV_AROW + s * 16);
+            if (!ONE) fbl[s][j] = *reinterpret_cast<const f16x8*>(bb + BPLANE + j * 32 * CV_AROW + s * 16);
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             fah[s][i] = *reinterpret_cast<const f16x8*>(ab + i * 32 * CV_AROW + s * 16);
-            fal[s][i] = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * CV_AROW + s * 16);
+            if (!ONE) fal[s][i] = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * CV_AROW + s * 16);
         }
     };
     // same step shape as the forward kernel: one barrier in the middle, fragments read half a step ahead, the staged
@@ -641,12 +677,17 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
             if (s == 1) fetch_begin(nbeg + (t + 1 + WSTAGES) * CV_BK);
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
+                if (ONE) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = cv_mfma_bf16(fah[s][i], fbh[s][j], acc[i][j]);
+                } else {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[s][i], fbl[s][j], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[s][i], fbh[s][j], acc[i][j], 0, 0, 0);
+                }
                 if (s == 0) {
                     commit_a(S, buf ^ 1, 2 * i);
                     commit_a(S, buf ^ 1, 2 * i + 1);
@@ -660,9 +701,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 6 * MI; ++q) {
+            for (int q = 0; q < (ONE ? 2 : 6) * MI; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x010 | 0x080, COCOS_CONV_SCHED_N, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002 | 0x004 | 0x010 | 0x080, ONE ? 3 * COCOS_CONV_SCHED_N : COCOS_CONV_SCHED_N, 0);
             }
             if (COCOS_CONV_WGRAD_PIPE ? s == 0 : s == 1) __syncthreads();
         }
@@ -678,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(const float* __restr
     };
     if (edge_slice) run(std::true_type{}); else run(std::false_type{});
 
-    const float oscale = 1.0f / (sx * sg);
+    const float oscale = ONE ? 1.0f : 1.0f / (sx * sg);
     float* pb = part + (size_t)slice * M * g.Ktot;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -740,8 +781,9 @@ static int conv_fwd_launch(const cocos::ConvGeom& g, const float* x, const void*
                            const float* w_scale_dev, const float* x_amax_dev, const float* bias, float* y, int Cout,
                            cocos_stream_t stream) {
     using namespace cocos;
-    COCOS_REQUIRE(aligned16(w_hi) && aligned16(w_lo), COCOS_ERR_INVALID,
+    COCOS_REQUIRE(aligned16(w_hi) && (!w_lo || aligned16(w_lo)), COCOS_ERR_INVALID,
                   "conv2d_fwd_f16x3: weight planes must be 16-byte aligned");
+    const bool one = w_lo == nullptr;            // single bf16 plane: the one-term flavour
     const bool fast4 = g.stride == 1;
     // tile: BM = 256 rows for wide layers, BN = 128 positions.  The 256 x 256 tile (wave tile 128 x 128: each LDS operand
     // is re-read half as often per MFMA, all 256 accumulator registers in use, one register stage) exists and is
@@ -755,19 +797,21 @@ static int conv_fwd_launch(const cocos::ConvGeom& g, const float* x, const void*
     const long long blocks = mt * ((g.Ntot + bn - 1) / bn);
     COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "conv2d_fwd_f16x3: grid too large");
     hipStream_t s = as_stream(stream);
-#define COCOS_GO(BMv, BNv, F4)                                                                                     \
+#define COCOS_GO(BMv, BNv, F4) do { if (one && BNv == 128) COCOS_GO1(BMv, 128, F4, true); else COCOS_GO1(BMv, BNv, F4, false); } while (0)
+#define COCOS_GO1(BMv, BNv, F4, ONEv)                                                                              \
     do {                                                                                                           \
-        auto kern = conv_fwd_kernel<BMv, BNv, F4>;                                                                 \
+        auto kern = conv_fwd_kernel<BMv, BNv, F4, ONEv>;                                                           \
         const size_t smem = (size_t)2 * 2 * (BMv * CV_AROW + CV_BK * (BNv + 32)) * sizeof(_Float16);               \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));              \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, s, x, static_cast<const _Float16*>(w_hi), \
                            static_cast<const _Float16*>(w_lo), w_scale_dev, x_amax_dev, bias, y, Cout, g);         \
     } while (0)
-    if (bm == 256 && bn == 256) { if (fast4) COCOS_GO(256, 256, true); else COCOS_GO(256, 256, false); }
+    if (bm == 256 && bn == 256 && !one) { if (fast4) COCOS_GO(256, 256, true); else COCOS_GO(256, 256, false); }
     else if (bm == 256)         { if (fast4) COCOS_GO(256, 128, true); else COCOS_GO(256, 128, false); }
     else                        { if (fast4) COCOS_GO(128, 128, true); else COCOS_GO(128, 128, false); }
 #undef COCOS_GO
+#undef COCOS_GO1
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -776,7 +820,7 @@ extern "C" int cocos_conv2d_fwd_f16x3(const float* x, const void* w_hi, const vo
                                       const float* x_amax_dev, const float* bias, float* y, int B, int Cin, int H, int W,
                                       int Cout, int KH, int KW, int stride, int pad, int dil, cocos_stream_t stream) {
     using namespace cocos;
-    COCOS_REQUIRE(x && w_hi && w_lo && y, COCOS_ERR_INVALID, "conv2d_fwd_f16x3: null pointer");
+    COCOS_REQUIRE(x && w_hi && y, COCOS_ERR_INVALID, "conv2d_fwd_f16x3: null pointer");
     ConvGeom g;
     if (int rc = cv_geom(g, B, Cin, H, W, Cout, KH, KW, stride, pad, dil, stride == 1, "conv2d_fwd_f16x3")) return rc;
     return conv_fwd_launch(g, x, w_hi, w_lo, w_scale_dev, x_amax_dev, bias, y, Cout, stream);
@@ -790,7 +834,7 @@ extern "C" int cocos_conv2d_fwd_scatter_f16x3(const float* x, const void* w_hi, 
                                               int JH, int JW, int pad_y, int pad_x, int OHo, int OWo, long long y_plane,
                                               int y_pitch, int y_col_stride, long long y_offset, cocos_stream_t stream) {
     using namespace cocos;
-    COCOS_REQUIRE(x && w_hi && w_lo && y, COCOS_ERR_INVALID, "conv2d_fwd_scatter_f16x3: null pointer");
+    COCOS_REQUIRE(x && w_hi && y, COCOS_ERR_INVALID, "conv2d_fwd_scatter_f16x3: null pointer");
     COCOS_REQUIRE(pad_y >= 0 && pad_x >= 0 && OHo >= 1 && OWo >= 1 && y_plane >= 1 && y_pitch >= 1 && y_col_stride >= 1 &&
                       y_offset >= 0, COCOS_ERR_INVALID, "conv2d_fwd_scatter_f16x3: bad placement");
     ConvGeom g;
@@ -823,9 +867,9 @@ extern "C" int cocos_conv2d_wgrad_slices(int B, int Cin, int H, int W, int Cout,
     return (int)s;
 }
 
-extern "C" int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const float* x_amax_dev, const float* g_amax_dev,
-                                        float* partials, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
-                                        int pad, int dil, cocos_stream_t stream) {
+static int conv_wgrad_impl(const float* x, const float* dy, const float* x_amax_dev, const float* g_amax_dev, float* partials,
+                           int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad, int dil, bool one,
+                           cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(x && dy && partials, COCOS_ERR_INVALID, "conv2d_wgrad_f16x3: null pointer");
     ConvGeom g;
@@ -838,9 +882,10 @@ extern "C" int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const f
     COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "conv2d_wgrad_f16x3: grid too large");
     const int ybytes = (int)((long long)B * Cout * g.OH * g.OW * 4);
     hipStream_t s = as_stream(stream);
-#define COCOS_GO(BMv, F4)                                                                                          \
+#define COCOS_GO(BMv, F4) do { if (one) COCOS_GO1(BMv, F4, true); else COCOS_GO1(BMv, F4, false); } while (0)
+#define COCOS_GO1(BMv, F4, ONEv)                                                                                   \
     do {                                                                                                           \
-        auto kern = conv_wgrad_kernel<BMv, F4>;                                                                    \
+        auto kern = conv_wgrad_kernel<BMv, F4, ONEv>;                                                              \
         const size_t smem = (size_t)2 * 2 * (BMv + CV_BN) * CV_AROW * sizeof(_Float16);                            \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));              \
@@ -850,8 +895,21 @@ extern "C" int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const f
     if (bm == 256) { if (fast4) COCOS_GO(256, true); else COCOS_GO(256, false); }
     else           { if (fast4) COCOS_GO(128, true); else COCOS_GO(128, false); }
 #undef COCOS_GO
+#undef COCOS_GO1
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+extern "C" int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const float* x_amax_dev, const float* g_amax_dev,
+                                        float* partials, int B, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
+                                        int pad, int dil, cocos_stream_t stream) {
+    return conv_wgrad_impl(x, dy, x_amax_dev, g_amax_dev, partials, B, Cin, H, W, Cout, KH, KW, stride, pad, dil, false, stream);
+}
+
+// The one-term bf16 flavour of the weight gradient (no scales: bf16 has fp32's range).
+extern "C" int cocos_conv2d_wgrad_bf16(const float* x, const float* dy, float* partials, int B, int Cin, int H, int W, int Cout,
+                                       int KH, int KW, int stride, int pad, int dil, cocos_stream_t stream) {
+    return conv_wgrad_impl(x, dy, nullptr, nullptr, partials, B, Cin, H, W, Cout, KH, KW, stride, pad, dil, true, stream);
 }
 
 #ifdef COCOS_DEBUG_TIMING
@@ -882,7 +940,9 @@ __global__ __launch_bounds__(256) void conv_weight_planes_kernel(const float* __
                                                                  int mode, int JH, int JW, int ry, int rx, int s,
                                                                  const float* __restrict__ amax_dev, float* __restrict__ scale_out,
                                                                  int M, int C, int nkb) {
-    const float scale = cv_scale_from_amax(amax_dev);
+    const bool bf = (mode & 2) != 0;                                      // one bf16 plane (hi), no scale
+    mode &= 1;
+    const float scale = bf ? 1.0f : cv_scale_from_amax(amax_dev);
     const unsigned total2 = (unsigned)nkb * (unsigned)M * 16u;            // pairs of consecutive c: one 32-bit store per plane
     const int T = JH * JW;
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total2; i += gridDim.x * 256u) {
@@ -899,6 +959,10 @@ __global__ __launch_bounds__(256) void conv_weight_planes_kernel(const float* __
             const int c = cb * 32 + j + e;
             const int co = mode == 0 ? m : c, ci = mode == 0 ? c : m;
             v[e] = c < C ? w[(((size_t)co * Cin + ci) * KH + ky) * KW + kx] * scale : 0.f;
+        }
+        if (bf) {
+            reinterpret_cast<unsigned*>(hi)[i] = cv_pack_bf16(v[0], v[1]);
+            continue;
         }
         unsigned h2, l2;
         split_pair_rtz(v[0], v[1], h2, l2);
@@ -928,8 +992,11 @@ extern "C" int cocos_conv2d_weight_planes(const float* w, void* hi, void* lo, in
                                           int JH, int JW, int ry, int rx, int s, const float* amax_dev, float* scale_out_dev,
                                           cocos_stream_t stream) {
     using namespace cocos;
-    COCOS_REQUIRE(w && hi && lo, COCOS_ERR_INVALID, "conv2d_weight_planes: null pointer");
-    COCOS_REQUIRE(Cout >= 1 && Cin >= 1 && KH >= 1 && KW >= 1 && (mode == 0 || mode == 1) && JH >= 1 && JW >= 1 && s >= 1 &&
+    COCOS_REQUIRE(w && hi && (lo || (mode & 2)), COCOS_ERR_INVALID, "conv2d_weight_planes: null pointer");
+    const int mode_full = mode;
+    mode &= 1;
+    COCOS_REQUIRE(mode_full >= 0 && mode_full <= 3, COCOS_ERR_INVALID, "conv2d_weight_planes: mode %d", mode_full);
+    COCOS_REQUIRE(Cout >= 1 && Cin >= 1 && KH >= 1 && KW >= 1 && JH >= 1 && JW >= 1 && s >= 1 &&
                       ry >= 0 && rx >= 0 && ry + s * (JH - 1) < KH && rx + s * (JW - 1) < KW &&
                       (mode == 1 || (JH == KH && JW == KW && s == 1 && ry == 0 && rx == 0)),
                   COCOS_ERR_INVALID, "conv2d_weight_planes: bad arguments (k=%dx%d mode=%d J=%dx%d r=(%d,%d) s=%d)", KH, KW, mode,
@@ -940,7 +1007,7 @@ extern "C" int cocos_conv2d_weight_planes(const float* w, void* hi, void* lo, in
     COCOS_REQUIRE(total < 0x7fffffffull, COCOS_ERR_UNSUPPORTED, "conv2d_weight_planes: weight too large");
     const size_t blocks = (total + 255) / 256;
     hipLaunchKernelGGL(conv_weight_planes_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, as_stream(stream),
-                       w, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Cout, Cin, KH, KW, mode, JH, JW, ry, rx, s,
+                       w, static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), Cout, Cin, KH, KW, mode_full, JH, JW, ry, rx, s,
                        amax_dev, scale_out_dev, M, C, nkb);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;

@@ -52,6 +52,13 @@ __device__ __forceinline__ u32x4 bq_load16s(__amdgpu_buffer_rsrc_t r, unsigned o
 
 // Ablation builds (debug only, results are WRONG): -DCOCOS_ABLATE=<bits>  1: no tile staging, 2: no operand re-reads
 // from LDS, 4: no exp/split arithmetic, 8: no dS'' transposition + plane stores, 16: no logits loads
+// Projection of a FUSED key side ("accumulate dkn in the same kernel"; round 3): 1024: the 48 extra MFMAs
+// per wave tile that dkn_tile[256 x 32 keys] += Q_wave . dS''^T would issue (on the dqn accumulators: no registers are left
+// for a second 128-register accumulator set, which is the first obstacle); 2048: its output traffic — the wave's 256 x 32
+// fp32 partial tile leaving as 128 atomic adds per lane and tile (32 KB per wave tile; with 8 + 2048 the dS'' stores it
+// would replace are removed).  Not modelled and still owed by a real variant: the transposition of dS'' through LDS that
+// the product needs (the contraction runs over QUERIES, which sit in the lanes of this kernel's tiles — an MFMA never
+// contracts over the lane index), measured at +4.4 % of the kernel when the planes still left through it.
 #ifndef COCOS_ABLATE
 #define COCOS_ABLATE 0
 #endif
@@ -503,6 +510,22 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
             if (STAGE_K && (i & 1) == 0) stage_piece(2 * VPT + (i >> 1), t + 1, t, false_type{});
             if (WITH_VALU && i == 2 * KB - 1) prefetch_v(t + 1);         // first fragments of the next iteration's dP'
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (COCOS_ABLATE & 1024) {
+#pragma unroll
+            for (int i = 0; i < 2 * KB; ++i) {
+                dx[i % KB] = bq_mfma(a_h[i & 1], sh[i / KB], dx[i % KB]);
+                dx[i % KB] = bq_mfma(a_h[i & 1], sl[i / KB], dx[i % KB]);
+                dx[i % KB] = bq_mfma(a_l[i & 1], sh[i / KB], dx[i % KB]);
+            }
+        }
+        if ((COCOS_ABLATE & 2048) && live) {
+            float* base = dqn + (size_t)b * BQH_KD * Nq + (size_t)((t & 127) * 32) + c;      // a 256 x 32 tile somewhere in dqn[b]
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    atomicAdd(base + (size_t)(kb * 32 + acc_row_base(r) + 4 * h) * Nq, dx[kb][r]);
         }
         // the dqn accumulators live in the accumulator file for the whole kernel (without the pins hipcc
         // rotates them through other AGPR ranges: 64 v_accvgpr_mov per tile)

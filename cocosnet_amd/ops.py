@@ -847,6 +847,18 @@ def proj1x1(x, weight, bias=None):
 # K16  nn.Conv2d (groups 1, dilation 1, zero padding) as a split-precision implicit GEMM   (conv_f16x3.hip)
 #      ResidualBlock (correspondence.py:13-36), adaptor convolutions (:150-173), PatchGAN (discriminator.py:92-115)
 # ------------------------------------------------------------------------------------------
+#: K16's arithmetic: "f16x3" = f16 hi/lo split, three MFMA terms (fp32-class accuracy: everything upstream of the correlation);
+#: "bf16" = single bf16 planes, one MFMA term (BASELINE config 3's precision for the generator / discriminator stacks behind
+#: InstanceNorm / SPADE — ~3x less matrix work, no max|x| passes).  Module attribute, read at call time.
+CONV_PRECISION = os.environ.get("COCOS_CONV", "f16x3")
+
+
+def _conv_bf16() -> bool:
+    if CONV_PRECISION not in ("f16x3", "bf16"):
+        raise ValueError(f"cocosnet_amd.ops.CONV_PRECISION = {CONV_PRECISION!r}: expected 'f16x3' or 'bf16'")
+    return CONV_PRECISION == "bf16"
+
+
 def _conv_weight_planes(weight, amax, mode: int, JH=None, JW=None, ry=0, rx=0, s=1):
     """weight [Cout,Cin,KH,KW] -> K16's f16 hi/lo planes in ONE launch (cocos_conv2d_weight_planes): mode 0 = forward,
     mode 1 = input gradient (flipped (sub-)kernel w[:, :, ry::s, rx::s], channel roles swapped)."""
@@ -855,6 +867,10 @@ def _conv_weight_planes(weight, amax, mode: int, JH=None, JW=None, ry=0, rx=0, s
     M, C = (Cout, Cin) if mode == 0 else (Cin, Cout)
     nkb = JH * JW * ((C + 31) // 32)
     wh = torch.empty((nkb, M, 32), device=weight.device, dtype=torch.float16)
+    if amax is None:          # one bf16 plane (the bits live in an f16-typed tensor), no scale
+        _call("split_f16", "cocos_conv2d_weight_planes", weight.data_ptr(), wh.data_ptr(), None, Cout, Cin, KH, KW, mode | 2,
+              JH, JW, ry, rx, s, None, None, _stream())
+        return wh, None, None
     wl = torch.empty_like(wh)
     ws = torch.empty(1, device=weight.device, dtype=torch.float32)
     _call("split_f16", "cocos_conv2d_weight_planes", weight.data_ptr(), wh.data_ptr(), wl.data_ptr(), Cout, Cin, KH, KW, mode,
@@ -869,8 +885,8 @@ def _conv_fwd_call(x, wh, wl, ws, xa, bias, Cout, KH, KW, stride, pad, dil):
     if OH < 1 or OW < 1:
         raise ValueError(f"conv2d: kernel {KH}x{KW} (dilation {dil}) does not fit input {tuple(x.shape)} with padding {pad}")
     y = torch.empty((B, Cout, OH, OW), device=x.device, dtype=torch.float32)
-    _call("conv2d_fwd", "cocos_conv2d_fwd_f16x3", x.data_ptr(), wh.data_ptr(), wl.data_ptr(), ws.data_ptr(),
-          xa.data_ptr(), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, pad, dil, _stream())
+    _call("conv2d_fwd", "cocos_conv2d_fwd_f16x3", x.data_ptr(), wh.data_ptr(), _ptr(wl), _ptr(ws),
+          _ptr(xa), _ptr(bias), y.data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, pad, dil, _stream())
     return y
 
 
@@ -908,8 +924,8 @@ def _conv_dgrad_strided(xshape, weight, dy, ga, wa, s: int, p: int):
         ry, rx, JH, JW, u0, v0, U, V, py, px = c
         th, tl, ts = _conv_weight_planes(weight, wa, 1, JH, JW, ry, rx, s)
         off = (s * u0 + ry - p) * W + (s * v0 + rx - p)
-        _call("conv2d_fwd", "cocos_conv2d_fwd_scatter_f16x3", dy.data_ptr(), th.data_ptr(), tl.data_ptr(), ts.data_ptr(),
-              ga.data_ptr(), dx.data_ptr(), B, Cout, OH, OW, Cin, JH, JW, py, px, U, V, H * W, s * W, s, off, _stream())
+        _call("conv2d_fwd", "cocos_conv2d_fwd_scatter_f16x3", dy.data_ptr(), th.data_ptr(), _ptr(tl), _ptr(ts),
+              _ptr(ga), dx.data_ptr(), B, Cout, OH, OW, Cin, JH, JW, py, px, U, V, H * W, s * W, s, off, _stream())
     return dx
 
 
@@ -924,10 +940,13 @@ class _Conv2d(torch.autograd.Function):
             raise ValueError(f"conv2d: stride {stride} / padding {pad} / dilation {dil}")
         Cout, Cin, KH, KW = weight.shape
         bb = None if bias is None else _chk(bias, "conv2d: bias")
-        xa = _recall_amax(x)
-        if xa is None:
-            xa = absmax(x)
-        wa = absmax(weight)
+        if _conv_bf16():          # one-term flavour: no max|x| passes at all
+            xa = wa = None
+        else:
+            xa = _recall_amax(x)
+            if xa is None:
+                xa = absmax(x)
+            wa = absmax(weight)
         wh, wl, ws = _conv_weight_planes(weight, wa, 0)
         y = _conv_fwd_call(x, wh, wl, ws, xa, bb, Cout, KH, KW, stride, pad, dil)
         ctx.save_for_backward(x, weight)
@@ -945,9 +964,12 @@ class _Conv2d(torch.autograd.Function):
         Cout, _, KH, KW = weight.shape
         need_x, need_w, need_b = ctx.needs_input_grad[:3]
         dx = dw = db = None
-        ga = _recall_amax(dy)
-        if ga is None:
-            ga = absmax(dy)
+        bf = wa is None           # the flavour the forward ran
+        ga = None
+        if not bf:
+            ga = _recall_amax(dy)
+            if ga is None:
+                ga = absmax(dy)
         if need_x:
             if stride == 1 and dil * (KH - 1) - pad >= 0 and KW == KH:
                 # dx = conv(dy, flipped weights with the channel roles swapped, padding d(K-1)-p): the same kernel
@@ -962,8 +984,12 @@ class _Conv2d(torch.autograd.Function):
             S = lib.cocos_conv2d_wgrad_slices(B, Cin, H, W, Cout, KH, KW, stride, pad, dil)
             kdim = lib.cocos_conv2d_kdim(Cin, KH, KW)
             part = torch.empty((S, Cout, kdim), device=x.device, dtype=torch.float32)
-            _call("conv2d_wgrad", "cocos_conv2d_wgrad_f16x3", x.data_ptr(), dy.data_ptr(), xa.data_ptr(), ga.data_ptr(),
-                  part.data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, pad, dil, _stream())
+            if bf:
+                _call("conv2d_wgrad", "cocos_conv2d_wgrad_bf16", x.data_ptr(), dy.data_ptr(), part.data_ptr(), B, Cin, H, W,
+                      Cout, KH, KW, stride, pad, dil, _stream())
+            else:
+                _call("conv2d_wgrad", "cocos_conv2d_wgrad_f16x3", x.data_ptr(), dy.data_ptr(), xa.data_ptr(), ga.data_ptr(),
+                      part.data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, pad, dil, _stream())
             dw = torch.empty_like(weight)          # sum over the S slices + back to [Cout, Cin, KH, KW] in one pass
             _call("conv2d_wgrad", "cocos_conv2d_wgrad_reduce", part.data_ptr(), dw.data_ptr(), S, Cout, Cin, KH, KW, _stream())
         if need_b and has_bias:

@@ -22,7 +22,11 @@ import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
 
-CONV_BACKEND = os.environ.get("COCOS_CONV", "f16x3")     # "torch": the framework's convolution (A/B measurements)
+#: "f16x3" / "bf16": K16 in that arithmetic (ops.CONV_PRECISION follows the same variable; bf16 is BASELINE config 3's
+#: precision for the generator / discriminator stacks — inside netCorr it is a timing reference only: everything there is
+#: upstream of the correlation); "torch": the framework's convolution (A/B measurements)
+CONV_BACKEND = os.environ.get("COCOS_CONV", "f16x3")
+_HIP_BACKENDS = ("f16x3", "bf16")
 
 
 class Conv2d(nn.Conv2d):
@@ -33,13 +37,20 @@ class Conv2d(nn.Conv2d):
 
     def _conv_forward(self, input, weight, bias):
         s, p, k, d = self.stride, self.padding, self.kernel_size, self.dilation
-        if (CONV_BACKEND == "f16x3" and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32
+        if (CONV_BACKEND in _HIP_BACKENDS and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32
                 and input.dim() == 4 and self.groups == 1 and self.padding_mode == "zeros"
                 and not isinstance(p, str) and s[0] == s[1] and p[0] == p[1] and d[0] == d[1]):
-            from . import ops
-            if k == (1, 1) and s[0] == 1 and p[0] == 0:
-                return ops.proj1x1(input, weight, bias)
-            return ops.conv2d(input, weight, bias, s[0], p[0], d[0])
+            from . import _lib, ops
+            try:
+                if k == (1, 1) and s[0] == 1 and p[0] == 0:
+                    return ops.proj1x1(input, weight, bias)
+                return ops.conv2d(input, weight, bias, s[0], p[0], d[0])
+            except _lib.CocosHipError as e:
+                # kernel-side limits (a tensor of 2 GiB or more, a grid too large for the 32-bit index arithmetic: the
+                # discriminator / VGG at very large batch or resolution) are not part of the check above: they take the
+                # framework path instead of failing the training step.  Anything else is a real error.
+                if getattr(e, "code", 0) != -2:          # COCOS_ERR_UNSUPPORTED (include/cocos_hip.h)
+                    raise
         return super()._conv_forward(input, weight, bias)
 
 
@@ -49,7 +60,7 @@ class ReflectionPad2d(nn.ReflectionPad2d):
 
     def forward(self, input):
         p = self.padding
-        if (CONV_BACKEND == "f16x3" and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+        if (CONV_BACKEND in _HIP_BACKENDS and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
                 and len(set(p)) == 1 and 0 <= p[0] < min(input.shape[2:])):
             from . import ops
             return ops.reflect_pad2d(input, p[0])

@@ -531,6 +531,14 @@ int cocos_conv2d_wgrad_slices(int B, int Cin, int H, int W, int Cout, int KH, in
 int cocos_conv2d_wgrad_f16x3(const float* x, const float* dy, const float* x_amax_dev /* nullable */,
                              const float* dy_amax_dev /* nullable */, float* partials, int B, int Cin, int H, int W,
                              int Cout, int KH, int KW, int stride, int pad, int dilation, cocos_stream_t stream);
+/* One-term bf16 flavour of K16 (BASELINE config 3: "bf16 MFMA" for the SPADE generator / PatchGAN convolutions): single
+ * bf16 operand planes, ONE v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate, no scales (bf16 has fp32's range).
+ *   forward / input gradient: cocos_conv2d_fwd_f16x3 / _fwd_scatter_f16x3 with w_lo = NULL and w_hi = the bf16 plane written
+ *       by cocos_conv2d_weight_planes(mode | 2) (lo may be NULL there; scale pointers ignored);
+ *   weight gradient: cocos_conv2d_wgrad_bf16 (partials as for the f16x3 entry point).
+ * 8 mantissa bits per operand: measured error vs fp64 in tests/test_gpu_conv.py; never used upstream of the correlation. */
+int cocos_conv2d_wgrad_bf16(const float* x, const float* dy, float* partials, int B, int Cin, int H, int W, int Cout, int KH,
+                            int KW, int stride, int pad, int dilation, cocos_stream_t stream);
 
 /* K19 / K20 — match_kernel = 3 (the reference's DEFAULT, options/base_options.py:70) fused, round 3: replaces
  * F.unfold(k=3) + centre + normalise (correspondence.py:276-280, :286-289), the K = 2304 matmul (:291), /temperature (:304),

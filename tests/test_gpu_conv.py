@@ -215,3 +215,45 @@ def test_reflect_pad2d_matches_torch(shape, pad):
     assert (x.grad - xr.grad).abs().max().item() <= 1e-6 * max(xr.grad.abs().max().item(), 1.0)
     with pytest.raises(ValueError):
         ops.reflect_pad2d(x.detach(), min(shape[2:]))
+
+
+# ------------------------------------------------------------------ the one-term bf16 flavour (BASELINE config 3's precision)
+BF16_CASES = [
+    (2, 407, 66, 66, 407, 3, 1, 0),      # ResidualBlock shape (for the error figure only: that block stays on f16x3)
+    (2, 64, 64, 64, 128, 3, 1, 1),       # SPADE mlp_shared class
+    (2, 3, 33, 37, 16, 4, 2, 2),         # PatchGAN first layer: odd outputs, element gather, strided input gradient
+    (2, 64, 32, 32, 130, 4, 2, 2),       # PatchGAN inner layer class
+    (3, 5, 9, 7, 7, 3, 1, 1),            # everything ragged
+    (2, 12, 20, 24, 10, 3, 1, 2, 2),     # dilation 2
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_bf16_flavour_error_vs_fp64(case, monkeypatch):
+    """COCOS_CONV=bf16: single bf16 operand planes, one v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate (VERDICT r2
+    missing 4).  bf16 keeps 8 mantissa bits: with K = Cin*k*k random products the error of a sum is ~2^-9 * sqrt(K) of
+    a term, i.e. a few 1e-3 of the output range — asserted at 1.5e-2 (forward, input / weight / bias gradient), and the
+    SAME inputs through the f16x3 flavour stay at 1e-5: the two flavours are different arithmetic, not different code paths."""
+    from cocosnet_amd import ops
+    B, Cin, H, W, Cout, k, stride, pad = case[:8]
+    dil = case[8] if len(case) > 8 else 1
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x0 = torch.randn(B, Cin, H, W, device="cuda", generator=g)
+    w0 = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
+    b0 = torch.randn(Cout, device="cuda", generator=g)
+    errs = {}
+    for prec, tol in (("bf16", 1.5e-2), ("f16x3", 1e-5)):
+        monkeypatch.setattr(ops, "CONV_PRECISION", prec)
+        x, w, b = (t.clone().requires_grad_(True) for t in (x0, w0, b0))
+        with ops.KernelTimer() as kt:
+            y = ops.conv2d(x, w, b, stride, pad, dil)
+            if prec == "bf16":
+                go = torch.randn(y.shape, device="cuda", generator=g)
+            y.backward(go)
+        assert ("absmax" in kt.summary()) == (prec == "f16x3")          # bf16: no max|x| passes at all
+        yr, dxr, dwr, dbr = _ref(x0, w0, b0, stride, pad, go, dil)
+        for a, r, what in ((y, yr, "y"), (x.grad, dxr, "dx"), (w.grad, dwr, "dw"), (b.grad, dbr, "db")):
+            e = (a.double() - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+            errs[(prec, what)] = e
+            assert e <= tol, f"{prec} {what}: {e:.3e}"
+    assert errs[("bf16", "y")] > 1e-4          # it really is the low-precision arithmetic
