@@ -48,11 +48,11 @@ def test_amax_table_is_keyed_by_storage_version_and_consumed_once(monkeypatch):
     ops._remember_amax(t, cell)
     t.add_(1.0)                                                # modified in place after the producer ran
     assert ops._recall_amax(t) is None
-    # bounded: two younger entries evict the oldest (and release the tensor it held)
-    a, b, c = (torch.randn(4) for _ in range(3))
-    for x in (a, b, c):
+    # bounded: a younger entry beyond the table's size evicts the oldest (and releases the tensor it held)
+    xs = [torch.randn(4) for _ in range(ops._KNOWN_AMAX_MAX + 1)]
+    for x in xs:
         ops._remember_amax(x, cell)
-    assert ops._recall_amax(a) is None and ops._recall_amax(b) is cell and ops._recall_amax(c) is cell
+    assert ops._recall_amax(xs[0]) is None and all(ops._recall_amax(x) is cell for x in xs[1:])
     assert len(ops._tls.known_amax) == 0
 
 
