@@ -508,7 +508,7 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gout[g]), G_rs, (int)gm.lane_off,
-                                                       (int)(blk + (unsigned)g * 1024u), 0);
+                                                       (int)(blk + (unsigned)g * 1024u), 2);      // nt: a stream for K20
         }
         if (STORE_P && !(BX_ABLATE & 2)) {
             // planes of 2^14 P in the accumulator's own orientation: [Nq/32][Nk/32] blocks of 2 x [32 queries][16 keys]
@@ -669,8 +669,8 @@ __global__ __launch_bounds__(256, 1) void box3_adjoint_planes_kernel(const float
                     xl[i] = sl[0]; xl[2 + i] = sl[1];
                 }
                 const unsigned off = blk + (unsigned)(pp * 1024 + c * 32 + h * 16);
-                __builtin_amdgcn_raw_buffer_store_b128(xh, h_rs, (int)off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(xl, l_rs, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(xh, h_rs, (int)off, 0, 2);      // nt: streams for the two GEMMs
+                __builtin_amdgcn_raw_buffer_store_b128(xl, l_rs, (int)off, 0, 2);
             }
         }
 }

@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                         __builtin_amdgcn_raw_buffer_store_b128(
                             __builtin_bit_cast(u32x4, f32x4{t[kt][qt][4 * g] * scale, t[kt][qt][4 * g + 1] * scale,
                                                             t[kt][qt][4 * g + 2] * scale, t[kt][qt][4 * g + 3] * scale}),
-                            t_rs, (int)(blk + (unsigned)(g * 1024 + lane * 16)), 0, 0);
+                            t_rs, (int)(blk + (unsigned)(g * 1024 + lane * 16)), 0, 2);     // nt: 537 MB written once, read by another
+                                                                                             // kernel — keep the operand planes in L2
                 }
         }
         return;
