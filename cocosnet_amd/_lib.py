@@ -123,7 +123,8 @@ _SIGNATURES = {
     "cocos_proj_weight_planes": (ctypes.c_int, [_c_float_p] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4
                                  + [_c_float_p, _c_float_p, _stream_t]),
     "cocos_sum_leading": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_longlong, _stream_t]),
-    "cocos_channel_sum": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, _stream_t]),
+    "cocos_channel_sum_slices": (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong]),
+    "cocos_channel_sum": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, _stream_t]),
     "cocos_box3_stat_grads": (ctypes.c_int, [_c_float_p] * 10 + [ctypes.c_longlong, ctypes.c_float, ctypes.c_float,
                                                                   _stream_t]),
     "cocos_hgemm_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 4 + [_c_float_p] + [ctypes.c_int] * 4

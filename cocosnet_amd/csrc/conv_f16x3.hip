@@ -972,17 +972,36 @@ __global__ __launch_bounds__(256) void conv_weight_planes_kernel(const float* __
 }
 
 // partial [S][Cout][K] (k as above) -> dw [Cout][Cin][KH][KW]: the sum over the S position slices and the re-ordering of
-// k; threads run over the partials' own order (coalesced reads of S x 4 bytes each), the 4-byte writes scatter into dw
+// k.  A workgroup owns 64 consecutive elements of the partials' own order (256-byte coalesced pieces) and splits the S
+// slices over its four waves (a small layer has ~200 slices of 37 K elements: one thread per element walking all of them
+// was 36 us of dependent loads on 144 workgroups); the four wave sums meet in LDS, the 4-byte writes scatter into dw.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S,
                                                                 int Cout, int Cin, int T, int K) {
+    __shared__ float red[4][64];
     const unsigned total = (unsigned)Cout * (unsigned)K;
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
-        const int co = (int)(i / (unsigned)K), k = (int)(i - (unsigned)co * (unsigned)K);
-        const int kb = k >> 5, cb = kb / T, tap = kb - cb * T, ci = cb * 32 + (k & 31);
-        if (ci >= Cin) continue;
-        float acc = 0.f;
-        for (int sl = 0; sl < S; ++sl) acc += part[(size_t)sl * total + i];
-        dw[((size_t)co * Cin + ci) * T + tap] = acc;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (unsigned base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
+        const unsigned i = base + lane;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (i < total) {
+            const float* p = part + i;
+            int sl = grp;
+            for (; sl + 12 < S; sl += 16) {
+                a0 += p[(size_t)sl * total];
+                a1 += p[(size_t)(sl + 4) * total];
+                a2 += p[(size_t)(sl + 8) * total];
+                a3 += p[(size_t)(sl + 12) * total];
+            }
+            for (; sl < S; sl += 4) a0 += p[(size_t)sl * total];
+        }
+        red[grp][lane] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (grp == 0 && i < total) {
+            const int co = (int)(i / (unsigned)K), k = (int)(i - (unsigned)co * (unsigned)K);
+            const int kb = k >> 5, cb = kb / T, tap = kb - cb * T, ci = cb * 32 + (k & 31);
+            if (ci < Cin) dw[((size_t)co * Cin + ci) * T + tap] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        }
+        __syncthreads();
     }
 }
 
@@ -1020,7 +1039,7 @@ extern "C" int cocos_conv2d_wgrad_reduce(const float* partials, float* dw, int S
     COCOS_REQUIRE(S >= 1 && Cout >= 1 && Cin >= 1 && KH >= 1 && KW >= 1, COCOS_ERR_INVALID, "conv2d_wgrad_reduce: bad dims");
     const size_t total = (size_t)Cout * cocos_conv2d_kdim(Cin, KH, KW);
     COCOS_REQUIRE(total < 0x7fffffffull, COCOS_ERR_UNSUPPORTED, "conv2d_wgrad_reduce: weight too large");
-    const size_t blocks = (total + 255) / 256;
+    const size_t blocks = (total + 63) / 64;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, as_stream(stream),
                        partials, dw, S, Cout, Cin, KH * KW, cocos_conv2d_kdim(Cin, KH, KW));
     COCOS_HIP_CHECK(hipGetLastError());

@@ -719,8 +719,11 @@ def channel_sum(dy: torch.Tensor) -> torch.Tensor:
     """dy.sum((0, 2, 3)) of a contiguous fp32 [B,C,...] tensor: the bias gradient of a convolution (cocos_channel_sum)."""
     dy = _chk(dy, "channel_sum: dy")
     B, C = dy.shape[:2]
+    N = dy.numel() // (B * C)
+    S = _lib.load().cocos_channel_sum_slices(C, N)
     db = torch.empty(C, device=dy.device, dtype=torch.float32)
-    _call("channel_sum", "cocos_channel_sum", dy.data_ptr(), db.data_ptr(), B, C, dy.numel() // (B * C), _stream())
+    part = torch.empty(S * C, device=dy.device, dtype=torch.float32) if S > 1 else None
+    _call("channel_sum", "cocos_channel_sum", dy.data_ptr(), db.data_ptr(), part.data_ptr() if S > 1 else None, B, C, N, _stream())
     return db
 
 

@@ -428,7 +428,8 @@ int cocos_proj_weight_planes(const float* w, void* rows_hi, void* rows_lo, void*
  *   cocos_channel_sum: db[c] = sum_{b,n} dy[b][c][n] (the bias gradient of a convolution, dy.sum((0,2,3)));
  *   cocos_box3_stat_grads: dmu = -k s a r1, dnu = -k s b c1, da = r2 / a, db = c2 / b from K6's row / column sums. */
 int cocos_sum_leading(const float* x, float* out, int S, long long n, cocos_stream_t stream);
-int cocos_channel_sum(const float* dy, float* db, int B, int C, long long N, cocos_stream_t stream);
+int cocos_channel_sum_slices(int C, long long N);   /* S: `partials` of cocos_channel_sum holds S * C floats */
+int cocos_channel_sum(const float* dy, float* db, float* partials, int B, int C, long long N, cocos_stream_t stream);
 int cocos_box3_stat_grads(const float* r1, const float* r2, const float* c1, const float* c2, const float* a, const float* b,
                           float* dmu, float* dnu, float* da, float* db, long long n, float k_unfolded, float scale,
                           cocos_stream_t stream);

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from cocosnet_amd import ops
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
@@ -118,3 +120,24 @@ def test_warp_values_amax_matches_and_is_picked_up(monkeypatch):
     assert torch.equal(out, ref)
     cell = ops._recall_amax(out.reshape(4, 154, -1))
     assert cell is not None and float(cell) == float(ref.abs().max())
+
+
+@pytest.mark.parametrize("B,C,shape", [(8, 64, (64, 64)), (2, 3, (37, 5)), (1, 256, (1, 1)), (4, 16, (128, 130)), (3, 1, (100003,))])
+def test_channel_sum_is_the_bias_gradient_sum(B, C, shape):
+    """cocos_channel_sum (sliced, two launches when the tensor is large) against an fp64 sum; an unaligned view takes the 4-byte path."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    dy = torch.randn(B, C, *shape, device=DEV, generator=g) + 0.25
+    ref = dy.double().sum(dim=[0] + list(range(2, dy.dim())))
+    n = dy[0, 0].numel() * B
+    tol = 4e-7 * (n ** 0.5) * 4 + 1e-6
+    assert (ops.channel_sum(dy).double() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+    flat = torch.empty(dy.numel() + 1, device=DEV)
+    odd = flat[1:].view_as(dy).copy_(dy)                       # data pointer 4 bytes past a 16-byte boundary
+    assert (ops.channel_sum(odd).double() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+
+
+def test_sum_leading_sums_partial_slices():
+    g = torch.Generator(device=DEV).manual_seed(6)
+    for S, n in ((7, 4096), (3, 1001), (1, 8)):
+        x = torch.randn(S, n, device=DEV, generator=g)
+        assert torch.allclose(ops.sum_leading(x), x.sum(0), rtol=1e-6, atol=1e-5)

@@ -20,10 +20,10 @@ def timed(tag, key, fn, *a):
     return out
 
 
-def fwd(ctx, x, weight, bias, stride, pad):
+def fwd(ctx, x, weight, bias, stride, pad, *rest):
     key = (tuple(x.shape), tuple(weight.shape), stride, pad)
     ctx._key = key
-    return timed("fwd", key, orig_fwd, ctx, x, weight, bias, stride, pad)
+    return timed("fwd", key, orig_fwd, ctx, x, weight, bias, stride, pad, *rest)
 
 
 def bwd(ctx, dy):
