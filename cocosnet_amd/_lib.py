@@ -123,6 +123,11 @@ _SIGNATURES = {
     "cocos_proj_weight_planes": (ctypes.c_int, [_c_float_p] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4
                                  + [_c_float_p, _c_float_p, _stream_t]),
     "cocos_sum_leading": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_int, ctypes.c_longlong, _stream_t]),
+    "cocos_conv2d_nhwc_bf16_supported": (ctypes.c_int, [ctypes.c_int] * 5),
+    "cocos_conv2d_nhwc_prep_bf16": (ctypes.c_int, [_c_float_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [_stream_t]),
+    "cocos_conv2d_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p] + [ctypes.c_int] * 8 + [_stream_t]),
+    "cocos_conv2d_nhwc_wgrad_bf16_slices": (ctypes.c_int, [ctypes.c_int] * 7),
+    "cocos_conv2d_nhwc_wgrad_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 9 + [_stream_t]),
     "cocos_channel_sum_slices": (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong]),
     "cocos_channel_sum": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, _stream_t]),
     "cocos_box3_stat_grads": (ctypes.c_int, [_c_float_p] * 10 + [ctypes.c_longlong, ctypes.c_float, ctypes.c_float,

@@ -50,6 +50,7 @@ HIP_SOURCES = [
     "warp_values.hip",
     "contextual_rows.hip",
     "conv_f16x3.hip",
+    "conv_nhwc_bf16.hip",
     "spade_modulate.hip",
     "reflect_pad.hip",
 ]

@@ -1,0 +1,491 @@
+// K16b: stride-1 convolution in ONE bf16 MFMA term on operands that are bf16 IN MEMORY — gfx950.
+//
+// The one-term flavour of conv_f16x3.hip (`COCOS_CONV=bf16`) halved the matrix work of K16 and then sat on the CU's vector
+// memory path: its activations are fp32 NCHW in HBM, every k-block of 32 channels x 128 positions is gathered once PER TAP
+// (9 x for a 3x3 kernel), converted in registers and committed to LDS by the wave that also issues the MFMAs
+// (conv shapes of the feature producers, B = 8: 370-560 TFLOP/s, 15-22 % of the dense bf16 peak).  Here the producer-side
+// work is done ONCE per tensor by a small streaming kernel and the GEMM's inner loop touches no VALU at all:
+//
+//   prep   x fp32 [B][C][H][W]  ->  xp bf16 [B][H+2p][W+2p][Cp]   (NHWC, channels zero-padded to Cp = 32 ceil(C/32), the
+//          border written as zeros or mirrored: the GEMM never masks, never converts, a reflect-padded layer needs no
+//          separate padding pass)                                     [conv_nhwc_prep_kernel]
+//   GEMM   Y[co][n] = bias[co] + sum_k Wt[co][k] Xp[n][k],  k = ((ci/32) T + tap) 32 + ci%32 (the k order of K16: one k-block =
+//          32 consecutive channels at one tap = 64 contiguous bytes of xp per position, 64 contiguous bytes of the weight
+//          planes [K/32][Cout][32] per row).  Both tiles go HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`,
+//          16 bytes per lane, no registers, no LDS write instructions), three stages deep, ONE raw s_barrier per k-step
+//          and counted vmcnt waits (the CDNA guide's "3-buffer span" recipe).  An LDS-DMA writes lane-linear (wave base +
+//          lane x 16), so the bank swizzle of the 64-byte rows is applied to the SOURCE chunk each lane fetches:
+//          physical chunk = logical chunk ^ ((row >> 2) & 3), conflict-free `ds_read_b128` fragments.
+//          Tile 256 (Cout) x 256 | 128 (positions) x 32, 4 waves as 2 x 2, wave tile 128 x 128 | 64: all 256 accumulator
+//          registers, 0.5 KB of LDS operand reads per MFMA.                     [conv_nhwc_bf16_kernel]
+//   The input gradient of a stride-1 layer is the same GEMM on prep(dy, pad = d(K-1)-p, zeros) with the flipped,
+//   transposed weight planes (cocos_conv2d_weight_planes mode 1|2).
+//   The weight gradient contracts over positions, which are the STRIDED index of both NHWC operands: its fragments come out
+//   of the same lane-linear LDS images through ds_read_b64_tr_b16.                [conv_nhwc_wgrad_bf16_kernel]
+//
+// Reference lines served: every stride-1 nn.Conv2d of the feature producers — ResidualBlock correspondence.py:13-36,
+// adaptor layers :150-173, SPADE mlp convolutions normalization.py:118-127 — under `COCOS_CONV=bf16` (the precision of the
+// reference's --amp run).  Strided layers and layers with fewer than 192 output channels stay on conv_f16x3.hip's kernels.
+#include "common.h"
+
+namespace cocos {
+
+typedef __bf16 nb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 nb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float nb_f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* nb_lds_ptr;
+typedef short s16x4_nb __attribute__((ext_vector_type(4)));
+
+constexpr int NB_BM = 256, NB_BK = 32, NB_STAGES = 3;
+constexpr int NB_ROW = NB_BK * 2;                       // bytes per LDS row (one position / one weight row, 32 k)
+
+struct NhwcGeom {
+    int B, Cp, Hp, Wp;        // padded NHWC input
+    int OH, OW, OHW, Ntot;    // output grid, positions in all
+    int Cout, T, KW, dil;     // rows of the weight planes, taps, kernel width, dilation
+    int ncb, nsteps;          // channel blocks of 32, k-steps = ncb * T
+    unsigned xp_bytes, w_bytes;
+};
+
+__device__ __forceinline__ unsigned nb_pack_bf16(float a, float b) {      // round to nearest even (v_cvt_pk_bf16_f32)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(nb_f32x2{a, b}, nb_bf16x2));
+}
+
+__device__ __forceinline__ int nb_reflect(int i, int n) {                  // torch's ReflectionPad2d index (pad < n)
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// prep: fp32 NCHW -> bf16 NHWC with a border.  A workgroup owns 64 consecutive positions of one padded image (rows
+// flattened: a 66-wide row does not strand 62 lanes) and walks the channels 64 at a time: wave g loads channels 16 g .. +15
+// of the chunk for its lane's position (each load 256 bytes coalesced across the wave), the packed pairs cross through LDS
+// ([position][64 channels], 144-byte rows: conflict-free 16-byte writes), and go out as 128 contiguous bytes per position.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_nhwc_prep_kernel(const float* __restrict__ x, unsigned char* __restrict__ xp, int B, int C,
+                                                             int H, int W, int Hp, int Wp, int Cp, int pad, int reflect) {
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * 144];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int npos = Hp * Wp, chunks = (npos + 63) >> 6;
+    const int b = blockIdx.x / chunks, q0 = (blockIdx.x - b * chunks) * 64;
+    const int q = q0 + lane;
+    const int yp = q / Wp, xq = q - yp * Wp;
+    int ys = yp - pad, xs = xq - pad;
+    bool inside = q < npos;
+    if (reflect) {
+        ys = nb_reflect(ys, H);
+        xs = nb_reflect(xs, W);
+    } else {
+        inside = inside && ys >= 0 && ys < H && xs >= 0 && xs < W;
+    }
+    const size_t plane = (size_t)H * W;
+    const float* src = x + (size_t)b * C * plane + (inside ? (size_t)ys * W + xs : 0);
+    // store side: position (tid >> 3) + 32 pass, 16-byte piece tid & 7 of the chunk's 128 bytes
+    const int sp = threadIdx.x >> 3, so = threadIdx.x & 7;
+    for (int c0 = 0; c0 < Cp; c0 += 64) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = c0 + wave * 16 + i;
+            v[i] = (inside && c < C) ? src[(size_t)c * plane] : 0.f;
+        }
+        u32x4 o0 = {nb_pack_bf16(v[0], v[1]), nb_pack_bf16(v[2], v[3]), nb_pack_bf16(v[4], v[5]), nb_pack_bf16(v[6], v[7])};
+        u32x4 o1 = {nb_pack_bf16(v[8], v[9]), nb_pack_bf16(v[10], v[11]), nb_pack_bf16(v[12], v[13]), nb_pack_bf16(v[14], v[15])};
+        if (c0) __syncthreads();                           // the previous chunk has been read out
+        *reinterpret_cast<u32x4*>(tile + lane * 144 + wave * 32) = o0;
+        *reinterpret_cast<u32x4*>(tile + lane * 144 + wave * 32 + 16) = o1;
+        __syncthreads();
+        if (c0 + so * 8 < Cp) {
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                const int pl = sp + 32 * pass;
+                if (q0 + pl < npos)
+                    *reinterpret_cast<u32x4*>(xp + (((size_t)b * npos + q0 + pl) * Cp + c0 + so * 8) * 2) =
+                        *reinterpret_cast<const u32x4*>(tile + pl * 144 + so * 16);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GEMM (forward / input gradient)
+// ---------------------------------------------------------------------------------------------------------------------
+// k-step t = cb * T + tap reads weight rows at byte t * Cout * 64 and activations at ((ky*dil*Wp + kx*dil) * Cp + cb*32) * 2
+// beyond the position's corner: both travel in the scalar offset of the buffer instruction, the per-lane offsets are loop
+// constants.  Rows beyond Cout / positions beyond Ntot are clamped to the last valid one (computed, never stored).
+//
+// step t:   fragments k 16..31 of stage t  |  16 | 8 MFMAs (k 0..15)  |  vmcnt: stage t+1 landed; barrier: every wave is done
+//           reading stage t  |  LDS-DMA of stage t+3 into stage t's buffer  |  fragments k 0..15 of stage t+1  |  MFMAs (k 16..31)
+template <int BN>
+__global__ __launch_bounds__(256, 1) void conv_nhwc_bf16_kernel(const void* __restrict__ xp, const void* __restrict__ wpl,
+                                                                const float* __restrict__ bias, float* __restrict__ y,
+                                                                const NhwcGeom g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char nb_smem[];
+    constexpr int A_BYTES = NB_BM * NB_ROW, B_BYTES = BN * NB_ROW, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int NI = 4, NJ = BN / 64;                 // 32x32 MFMA tiles of a wave: 128 rows x BN/2 columns
+    constexpr int NBI = BN / 64;                        // activation DMA instructions per wave and stage (16 positions each)
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    const int ntm = (g.Cout + NB_BM - 1) / NB_BM;
+    const int mt = blockIdx.x % ntm, nt = blockIdx.x / ntm;
+    const int m0 = mt * NB_BM, n0 = nt * BN;
+
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(wpl, g.w_bytes), rB = make_rsrc(xp, g.xp_bytes);
+    const int chunk = (lane & 3) ^ ((lane >> 4) & 3);   // the 16-byte piece of its row this lane fetches (source-side swizzle)
+    unsigned voffA[4], voffB[NBI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = min(m0 + w * 64 + i * 16 + (lane >> 2), g.Cout - 1);
+        voffA[i] = (unsigned)row * NB_ROW + chunk * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        const int n = min(n0 + w * (BN / 4) + i * 16 + (lane >> 2), g.Ntot - 1);
+        const int b = n / g.OHW, rem = n - b * g.OHW, oy = rem / g.OW, ox = rem - oy * g.OW;
+        voffB[i] = (unsigned)(((b * g.Hp + oy) * g.Wp + ox) * g.Cp) * 2u + chunk * 16;
+    }
+    const unsigned stepA = (unsigned)g.Cout * NB_ROW;
+
+    auto issue = [&](int cb, int tap, int t, int buf) {
+        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+        const unsigned sA = (unsigned)t * stepA;
+        const unsigned sB = (unsigned)(((ky * g.Wp + kx) * g.dil) * g.Cp + cb * 32) * 2u;
+        unsigned char* st = nb_smem + buf * ST_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (nb_lds_ptr)(st + w * 4096 + i * 1024), 16, (int)voffA[i], (int)sA, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NBI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (nb_lds_ptr)(st + A_BYTES + w * (BN * 16) + i * 1024), 16, (int)voffB[i],
+                                                     (int)sB, 0, 0);
+    };
+
+    f32x16 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: row (lane & 31) of a 32-row MFMA tile, logical chunk kk*2 + (lane >> 5), swizzled by the row
+    const int frow = lane & 31, fsw = (lane >> 2) & 3, fh = lane >> 5;
+    const int fo0 = frow * NB_ROW + ((0 + fh) ^ fsw) * 16, fo1 = frow * NB_ROW + ((2 + fh) ^ fsw) * 16;
+    const int fbaseA = wm * (128 * NB_ROW), fbaseB = A_BYTES + wn * ((BN / 2) * NB_ROW);
+
+    nb_bf16x8 fa[2][NI], fb[2][NJ];
+    auto frags = [&](int buf, int kk) {
+        const unsigned char* st = nb_smem + buf * ST_BYTES + (kk ? fo1 : fo0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fa[kk][i] = *reinterpret_cast<const nb_bf16x8*>(st + fbaseA + i * (32 * NB_ROW));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[kk][j] = *reinterpret_cast<const nb_bf16x8*>(st + fbaseB + j * (32 * NB_ROW));
+    };
+    auto mfmas = [&](int kk) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+    };
+
+    const int nsteps = g.nsteps, T = g.T;
+    // prologue: stages 0, 1, 2 in flight; stage 0 landed and visible
+    int icb = 0, itap = 0, it = 0;                       // the next k-step to issue
+#pragma unroll 1
+    for (; it < NB_STAGES && it < nsteps; ++it) {
+        issue(icb, itap, it, it);
+        if (++itap == T) { itap = 0; ++icb; }
+    }
+    if (nsteps >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (4 + NBI)) : "memory");
+    else if (nsteps == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 + NBI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    frags(0, 0);
+
+    int buf = 0;
+#pragma unroll 1
+    for (int t = 0; t < nsteps; ++t) {
+        frags(buf, 1);
+        mfmas(0);
+        const int nbuf = buf == NB_STAGES - 1 ? 0 : buf + 1;
+        if (t + 1 < nsteps) {
+            if (t + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 + NBI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (it < nsteps) {
+                issue(icb, itap, it, buf);
+                ++it;
+                if (++itap == T) { itap = 0; ++icb; }
+            }
+            frags(nbuf, 0);
+        }
+        mfmas(1);
+        buf = nbuf;
+    }
+
+    // epilogue: accumulator (i, j, r) is row m0 + wm*128 + 32 i + (r&3) + 8 (r>>2) + 4 (lane>>5), position n0 + wn*BN/2 + 32 j + (lane&31)
+    const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (size_t)g.Cout * 4 : 0);      // no bias: every read returns 0
+    const int corow = m0 + wm * 128 + 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = buf_load1(rbias, (unsigned)(corow + i * 32 + (r & 3) + 8 * (r >> 2)) * 4u);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+            if (n >= g.Ntot) continue;
+            const int b = n / g.OHW, rem = n - b * g.OHW;
+            float* yp = y + (size_t)b * g.Cout * g.OHW + rem;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = corow + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (co < g.Cout) yp[(size_t)co * g.OHW] = acc[i][j][r] + bv[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient:  partial[s][co][k'] = sum over the slice's positions n of dY[n][co] Xp[n + tap][ci],  k' = ((ci/32) T + tap) 32 + ci%32
+// ---------------------------------------------------------------------------------------------------------------------
+// Both operands are NHWC: the contraction index (positions) is the strided one, so the MFMA fragments (8 consecutive
+// positions of one channel) are transposing reads, ds_read_b64_tr_b16, of images the DMA lays out as
+//     [n >> 2][column / 16][n & 3][16 columns]      (n = position inside the 32-position k-step, 128-byte 4 x 16 blocks)
+// — a 16-lane group's four 32-byte row pieces are one contiguous 128 bytes, two groups 256: conflict-free.  One DMA
+// instruction fills 8 such blocks (4 positions x 128 channels): per position its 16 lanes fetch 256 contiguous bytes.
+// Requires OW % 32 == 0 (a k-step of 32 positions lies in one output row: its address is a scalar base + lane constants).
+// dyp = dy as bf16 NHWC [B][OH + 2q][OW + 2q][Cop] (the input-gradient GEMM's operand, border q, or q = 0).
+struct NhwcWgradGeom {
+    int B, Cp, Hp, Wp;          // xp (the forward's operand)
+    int Cop, Hq, Wq, q;         // dyp
+    int OH, OW, Ntot;
+    int Cout, T, KW, dil, nkb;  // nkb = T * Cp / 32 blocks of k'
+    int steps_total, steps_per_slice;
+    unsigned xp_bytes, dy_bytes;
+};
+
+__global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void* __restrict__ xp, const void* __restrict__ dyp,
+                                                                      float* __restrict__ partial, const NhwcWgradGeom g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char nb_smem[];
+    constexpr int A_BYTES = 256 * NB_ROW, ST_BYTES = 2 * A_BYTES;       // 32 positions x 256 columns, both operands
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    const int ntm = (g.Cout + 255) / 256, ntn = (g.nkb * 32 + 255) / 256;
+    const int mt = blockIdx.x % ntm, ntile = (blockIdx.x / ntm) % ntn, slice = blockIdx.x / (ntm * ntn);
+    const int m0 = mt * 256, k0 = ntile * 256;
+    const int t_begin = slice * g.steps_per_slice, nsteps = min(g.steps_per_slice, g.steps_total - t_begin);
+
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(dyp, g.dy_bytes), rB = make_rsrc(xp, g.xp_bytes);
+    // DMA instruction id = w*4 + i: positions 4 (id >> 1) + ((lane >> 1) & 3), columns ((id & 1) * 8 + (lane >> 3)) * 16 + (lane & 1) * 8 .. +7
+    unsigned voffA[4], voffB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = w * 4 + i, nl = 4 * (id >> 1) + ((lane >> 1) & 3), col = (((id & 1) * 8 + (lane >> 3)) * 2 + (lane & 1)) * 8;
+        const int co = min(m0 + col, g.Cop - 8);
+        voffA[i] = (unsigned)(nl * g.Cop + co) * 2u;
+        const int kb = min((k0 + col) >> 5, g.nkb - 1), cb = kb / g.T, tap = kb - cb * g.T, ky = tap / g.KW, kx = tap - ky * g.KW;
+        voffB[i] = (unsigned)(((ky * g.Wp + kx) * g.dil + nl) * g.Cp + cb * 32 + (col & 31)) * 2u;
+    }
+    // scalar position of the next k-step to issue: image b, output row oy, first column ox
+    int it = 0, ib, ioy, iox;
+    {
+        const int n = t_begin * 32, ohw = g.OH * g.OW;
+        ib = n / ohw;
+        const int rem = n - ib * ohw;
+        ioy = rem / g.OW;
+        iox = rem - ioy * g.OW;
+    }
+    auto issue = [&](int buf) {
+        const unsigned sA = (unsigned)(((ib * g.Hq + ioy + g.q) * g.Wq + iox + g.q) * g.Cop) * 2u;
+        const unsigned sB = (unsigned)(((ib * g.Hp + ioy) * g.Wp + iox) * g.Cp) * 2u;
+        unsigned char* st = nb_smem + buf * ST_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (nb_lds_ptr)(st + (w * 4 + i) * 1024), 16, (int)voffA[i], (int)sA, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (nb_lds_ptr)(st + A_BYTES + (w * 4 + i) * 1024), 16, (int)voffB[i], (int)sB, 0, 0);
+        ++it;
+        iox += 32;
+        if (iox >= g.OW) { iox = 0; if (++ioy == g.OH) { ioy = 0; ++ib; } }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing fragment reads: 16-lane group (nb = column half, kg = position half), lane li -> row li >> 2, columns 4 (li & 3)..+3
+    const int li = lane & 15, nb = (lane >> 4) & 1, kg = lane >> 5;
+    const int tr_off = (kg * 32 + nb) * 128 + (li >> 2) * 32 + (li & 3) * 8;
+    const int fbaseA = wm * (8 * 128) + tr_off, fbaseB = A_BYTES + wn * (8 * 128) + tr_off;     // 128 columns = 8 blocks of 16
+
+    nb_bf16x8 fa[2][4], fb[2][4];
+    auto frags = [&](int buf, int kk) {
+        const unsigned char* st = nb_smem + buf * ST_BYTES + kk * 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned char* p = st + fbaseA + i * 256;
+            const s16x4_nb v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_nb __attribute__((address_space(3)))*)(p));
+            const s16x4_nb v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_nb __attribute__((address_space(3)))*)(p + 2048));
+            fa[kk][i] = __builtin_bit_cast(nb_bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned char* p = st + fbaseB + j * 256;
+            const s16x4_nb v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_nb __attribute__((address_space(3)))*)(p));
+            const s16x4_nb v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_nb __attribute__((address_space(3)))*)(p + 2048));
+            fb[kk][j] = __builtin_bit_cast(nb_bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+    auto mfmas = [&](int kk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+    };
+
+#pragma unroll 1
+    for (int u = 0; u < NB_STAGES && u < nsteps; ++u) issue(u);
+    if (nsteps >= 3) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    else if (nsteps == 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (nsteps > 0) frags(0, 0);
+
+    int buf = 0;
+#pragma unroll 1
+    for (int t = 0; t < nsteps; ++t) {
+        frags(buf, 1);
+        mfmas(0);
+        const int nbuf = buf == NB_STAGES - 1 ? 0 : buf + 1;
+        if (t + 1 < nsteps) {
+            if (t + 2 < nsteps) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (it < nsteps) issue(buf);
+            frags(nbuf, 0);
+        }
+        mfmas(1);
+        buf = nbuf;
+    }
+
+    const int Ktot = g.nkb * 32;
+    float* out = partial + (size_t)slice * g.Cout * Ktot;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + wn * 128 + j * 32 + (lane & 31);
+        if (k >= Ktot) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < g.Cout) out[(size_t)co * Ktot + k] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+}  // namespace cocos
+
+extern "C" int cocos_conv2d_nhwc_prep_bf16(const float* x, void* xp, int B, int C, int H, int W, int pad, int reflect,
+                                           cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && xp, COCOS_ERR_INVALID, "conv2d_nhwc_prep_bf16: null pointer");
+    COCOS_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1 && pad >= 0 && (!reflect || (pad < H && pad < W)), COCOS_ERR_INVALID,
+                  "conv2d_nhwc_prep_bf16: bad arguments (B=%d C=%d H=%d W=%d pad=%d reflect=%d)", B, C, H, W, pad, reflect);
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad, Cp = (C + 31) / 32 * 32;
+    const long long total = (long long)B * Hp * Wp * Cp * 2;
+    COCOS_REQUIRE(total < 0x7fffffffLL && aligned16(xp), COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_prep_bf16: tensor too large / xp unaligned");
+    const long long blocks = (long long)B * (((long long)Hp * Wp + 63) / 64);
+    COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_prep_bf16: grid too large");
+    hipLaunchKernelGGL(conv_nhwc_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, static_cast<unsigned char*>(xp),
+                       B, C, H, W, Hp, Wp, Cp, pad, reflect ? 1 : 0);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_conv2d_nhwc_bf16_supported(int Cin, int Cout, int KH, int KW, int stride) {
+    return (stride == 1 && Cout >= 128 && Cin >= 32 && KH >= 1 && KW >= 1 && KH * KW <= 49) ? 1 : 0;
+}
+
+// y fp32 [B][Cout][OH][OW] = bias + conv(xp), xp bf16 [B][Hp][Wp][Cp] already padded (cocos_conv2d_nhwc_prep_bf16), stride 1,
+// OH = Hp - dil (KH-1), OW = Wp - dil (KW-1); w_planes = cocos_conv2d_weight_planes(mode | 2): bf16 [KH*KW*Cp/32][Cout][32].
+extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias, float* y, int B, int Cp, int Hp,
+                                      int Wp, int Cout, int KH, int KW, int dil, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(xp && w_planes && y, COCOS_ERR_INVALID, "conv2d_nhwc_bf16: null pointer");
+    COCOS_REQUIRE(B >= 1 && Cp >= 32 && Cp % 32 == 0 && Cout >= 1 && KH >= 1 && KW >= 1 && dil >= 1, COCOS_ERR_INVALID,
+                  "conv2d_nhwc_bf16: bad arguments (B=%d Cp=%d Cout=%d k=%dx%d dil=%d)", B, Cp, Cout, KH, KW, dil);
+    NhwcGeom g;
+    g.B = B; g.Cp = Cp; g.Hp = Hp; g.Wp = Wp;
+    g.OH = Hp - dil * (KH - 1); g.OW = Wp - dil * (KW - 1);
+    COCOS_REQUIRE(g.OH >= 1 && g.OW >= 1, COCOS_ERR_INVALID, "conv2d_nhwc_bf16: kernel larger than the padded input");
+    g.OHW = g.OH * g.OW;
+    const long long ntot = (long long)B * g.OHW, xbytes = (long long)B * Hp * Wp * Cp * 2;
+    g.Cout = Cout; g.T = KH * KW; g.KW = KW; g.dil = dil; g.ncb = Cp / 32; g.nsteps = g.ncb * g.T;
+    const long long wbytes = (long long)g.nsteps * Cout * NB_ROW;
+    COCOS_REQUIRE(ntot < 0x7fffffffLL && xbytes < 0x7fffffffLL && wbytes < 0x7fffffffLL && (long long)B * Cout * g.OHW < (1LL << 40),
+                  COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_bf16: tensor too large");
+    COCOS_REQUIRE(aligned16(xp) && aligned16(w_planes), COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_bf16: operands must be 16-byte aligned");
+    g.Ntot = (int)ntot; g.xp_bytes = (unsigned)xbytes; g.w_bytes = (unsigned)wbytes;
+    const int ntm = (Cout + NB_BM - 1) / NB_BM;
+    const bool wide = (long long)ntm * ((ntot + 255) / 256) >= 200;       // enough 256-column tiles for the 256 CUs
+    hipStream_t s = as_stream(stream);
+    if (wide) {
+        auto kern = conv_nhwc_bf16_kernel<256>;
+        const size_t smem = (size_t)NB_STAGES * (NB_BM + 256) * NB_ROW;
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ((ntot + 255) / 256))), dim3(256), smem, s, xp, w_planes, bias, y, g);
+    } else {
+        auto kern = conv_nhwc_bf16_kernel<128>;
+        const size_t smem = (size_t)NB_STAGES * (NB_BM + 128) * NB_ROW;
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ((ntot + 127) / 128))), dim3(256), smem, s, xp, w_planes, bias, y, g);
+    }
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_conv2d_nhwc_wgrad_bf16_slices(int B, int OH, int OW, int Cp, int Cout, int KH, int KW) {
+    if (B < 1 || OH < 1 || OW < 1 || Cp < 32 || Cout < 1 || OW % 32 != 0) return 0;
+    const long long steps = (long long)B * OH * OW / 32;
+    const long long tiles = (long long)((Cout + 255) / 256) * (((long long)KH * KW * Cp + 255) / 256);
+    long long s = 256 / tiles;                               // ONE round of workgroups on the 256 CUs (a 257th doubles the time)
+    if (s > steps / 8) s = steps / 8;                        // at least 8 k-steps per slice
+    return (int)(s < 1 ? 1 : s);
+}
+
+// partial fp32 [S][Cout][KH*KW*Cp] (k' order of K16; summed and re-ordered by cocos_conv2d_wgrad_reduce), S = ..._slices(...);
+// xp as in cocos_conv2d_nhwc_bf16; dyp = bf16 NHWC [B][OH+2q][OW+2q][Cop] (cocos_conv2d_nhwc_prep_bf16 of dy with pad q, zeros).
+extern "C" int cocos_conv2d_nhwc_wgrad_bf16(const void* xp, const void* dyp, float* partial, int B, int Cp, int Hp, int Wp, int Cout,
+                                            int q, int KH, int KW, int dil, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(xp && dyp && partial, COCOS_ERR_INVALID, "conv2d_nhwc_wgrad_bf16: null pointer");
+    COCOS_REQUIRE(B >= 1 && Cp >= 32 && Cp % 32 == 0 && Cout >= 1 && KH >= 1 && KW >= 1 && dil >= 1 && q >= 0, COCOS_ERR_INVALID,
+                  "conv2d_nhwc_wgrad_bf16: bad arguments");
+    NhwcWgradGeom g;
+    g.B = B; g.Cp = Cp; g.Hp = Hp; g.Wp = Wp;
+    g.OH = Hp - dil * (KH - 1); g.OW = Wp - dil * (KW - 1);
+    COCOS_REQUIRE(g.OH >= 1 && g.OW >= 32 && g.OW % 32 == 0, COCOS_ERR_UNSUPPORTED,
+                  "conv2d_nhwc_wgrad_bf16: output rows must be whole k-steps of 32 positions (OW=%d)", g.OW);
+    g.Cop = (Cout + 31) / 32 * 32; g.q = q; g.Hq = g.OH + 2 * q; g.Wq = g.OW + 2 * q;
+    g.Cout = Cout; g.T = KH * KW; g.KW = KW; g.dil = dil; g.nkb = g.T * (Cp / 32);
+    const long long ntot = (long long)B * g.OH * g.OW, xbytes = (long long)B * Hp * Wp * Cp * 2,
+                    ybytes = (long long)B * g.Hq * g.Wq * g.Cop * 2;
+    COCOS_REQUIRE(ntot < 0x7fffffffLL && xbytes < 0x7fffffffLL && ybytes < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED,
+                  "conv2d_nhwc_wgrad_bf16: tensor too large");
+    COCOS_REQUIRE(aligned16(xp) && aligned16(dyp), COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_wgrad_bf16: operands must be 16-byte aligned");
+    g.Ntot = (int)ntot; g.xp_bytes = (unsigned)xbytes; g.dy_bytes = (unsigned)ybytes;
+    const int S = cocos_conv2d_nhwc_wgrad_bf16_slices(B, g.OH, g.OW, Cp, Cout, KH, KW);
+    g.steps_total = (int)(ntot / 32);
+    g.steps_per_slice = (g.steps_total + S - 1) / S;
+    const int ntm = (Cout + 255) / 256, ntn = (g.nkb * 32 + 255) / 256;
+    auto kern = conv_nhwc_wgrad_bf16_kernel;
+    const size_t smem = (size_t)NB_STAGES * 2 * 256 * NB_ROW;
+    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn * S)), dim3(256), smem, as_stream(stream), xp, dyp, partial, g);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}

@@ -893,6 +893,36 @@ def _conv_fwd_call(x, wh, wl, ws, xa, bias, Cout, KH, KW, stride, pad, dil):
     return y
 
 
+#: "0": COCOS_CONV=bf16 keeps every layer on conv_f16x3.hip's one-term kernels (fp32 NCHW operands gathered per tap) — A/B runs
+CONV_NHWC = os.environ.get("COCOS_CONV_NHWC", "1") != "0"
+
+
+def _conv_nhwc_ok(Cin, Cout, KH, KW, stride):
+    return CONV_NHWC and bool(_lib.load().cocos_conv2d_nhwc_bf16_supported(Cin, Cout, KH, KW, stride))
+
+
+def conv_nhwc_prep(x: torch.Tensor, pad: int, reflect: bool = False) -> torch.Tensor:
+    """fp32 [B,C,H,W] -> bf16 [B,H+2p,W+2p,Cp] (channels padded to 32, border zero or mirrored): the operand layout of K16b
+    (cocos_conv2d_nhwc_prep_bf16)."""
+    x = _chk(x, "conv_nhwc_prep: x")
+    B, C, H, W = x.shape
+    xp = torch.empty((B, H + 2 * pad, W + 2 * pad, (C + 31) // 32 * 32), device=x.device, dtype=torch.bfloat16)
+    _call("conv2d_nhwc_prep", "cocos_conv2d_nhwc_prep_bf16", x.data_ptr(), xp.data_ptr(), B, C, H, W, int(pad), int(bool(reflect)),
+          _stream())
+    return xp
+
+
+def _conv_nhwc_call(xp, planes, bias, Cout, KH, KW, dil):
+    B, Hp, Wp, Cp = xp.shape
+    OH, OW = Hp - dil * (KH - 1), Wp - dil * (KW - 1)
+    if OH < 1 or OW < 1:
+        raise ValueError(f"conv2d: kernel {KH}x{KW} (dilation {dil}) does not fit the padded input {tuple(xp.shape)}")
+    y = torch.empty((B, Cout, OH, OW), device=xp.device, dtype=torch.float32)
+    _call("conv2d_fwd", "cocos_conv2d_nhwc_bf16", xp.data_ptr(), planes.data_ptr(), _ptr(bias), y.data_ptr(), B, Cp, Hp, Wp, Cout,
+          KH, KW, dil, _stream())
+    return y
+
+
 def _conv_dgrad_strided(xshape, weight, dy, ga, wa, s: int, p: int):
     """Input gradient of a stride-s convolution (dilation 1) as s*s stride-1 convolutions of dy.
     dx[y, x] only sees the taps with ky = (y + p) mod s (mod s): with y + p = s*u + ry and ky = ry + s*jy,
@@ -934,7 +964,7 @@ def _conv_dgrad_strided(xshape, weight, dy, ga, wa, s: int, p: int):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride: int, pad: int, dil: int):
+    def forward(ctx, x, weight, bias, stride: int, pad: int, dil: int, reflect: int = 0):
         x = _chk(x, "conv2d: x")
         weight = _chk(weight, "conv2d: weight")
         if x.dim() != 4 or weight.dim() != 4 or weight.shape[1] != x.shape[1]:
@@ -951,19 +981,35 @@ class _Conv2d(torch.autograd.Function):
                 xa = absmax(x)
             wa = absmax(weight)
         wh, wl, ws = _conv_weight_planes(weight, wa, 0)
-        y = _conv_fwd_call(x, wh, wl, ws, xa, bb, Cout, KH, KW, stride, pad, dil)
-        ctx.save_for_backward(x, weight)
+        xp = None
+        if wa is None and _conv_nhwc_ok(Cin, Cout, KH, KW, stride):
+            # K16b: operands bf16 in memory (NHWC, border included), LDS-DMA GEMM — conv_nhwc_bf16.hip
+            xp = conv_nhwc_prep(x, reflect if reflect else pad, bool(reflect))    # the border: zeros, or the layer's ReflectionPad2d
+            y = _conv_nhwc_call(xp, wh, bb, Cout, KH, KW, dil)
+            if y.shape[3] % 32 != 0:
+                xp = None               # its weight gradient takes whole rows of 32 positions: this layer's stays on K16
+        else:
+            y = _conv_fwd_call(x, wh, wl, ws, xa, bb, Cout, KH, KW, stride, pad, dil)
+        if reflect and xp is None:
+            raise _lib.CocosHipError("conv2d: reflect padding is only fused on the K16b path (ops.conv2d checks the shape first)")
+        keep_xp = xp is not None and (ctx.needs_input_grad[1] or reflect)
+        ctx.save_for_backward(weight, *((xp,) if keep_xp else (x,)))
+        ctx.x_shape, ctx.has_xp, ctx.reflect = tuple(x.shape), keep_xp, int(reflect)
         ctx.cfg = (int(stride), int(pad), int(dil), bias is not None)
         ctx.amax = (xa, wa)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        weight, saved = ctx.saved_tensors
+        x, xp = (None, saved) if ctx.has_xp else (saved, None)
         stride, pad, dil, has_bias = ctx.cfg
         xa, wa = ctx.amax
         dy = _chk(dy, "conv2d: dy")
-        B, Cin, H, W = x.shape
+        B, Cin, H, W = ctx.x_shape
+        reflect = ctx.reflect
+        if reflect:                 # the layer the kernels see: pad 0 on the mirrored (H + 2r) x (W + 2r) input
+            H, W = H + 2 * reflect, W + 2 * reflect
         Cout, _, KH, KW = weight.shape
         need_x, need_w, need_b = ctx.needs_input_grad[:3]
         dx = dw = db = None
@@ -973,16 +1019,33 @@ class _Conv2d(torch.autograd.Function):
             ga = _recall_amax(dy)
             if ga is None:
                 ga = absmax(dy)
+        q = dil * (KH - 1) - pad
+        dx_nhwc = need_x and bf and stride == 1 and q >= 0 and KW == KH and _conv_nhwc_ok(Cout, Cin, KH, KW, 1)
+        dyp = None
+        if dx_nhwc or (need_w and xp is not None):
+            dyp = conv_nhwc_prep(dy, q if dx_nhwc else 0)        # bf16 NHWC, the border the input gradient needs
         if need_x:
-            if stride == 1 and dil * (KH - 1) - pad >= 0 and KW == KH:
+            if dx_nhwc:
+                th, _, _ = _conv_weight_planes(weight, None, 1)
+                dx = _conv_nhwc_call(dyp, th, None, Cin, KH, KW, dil)
+            elif stride == 1 and q >= 0 and KW == KH:
                 # dx = conv(dy, flipped weights with the channel roles swapped, padding d(K-1)-p): the same kernel
                 th, tl, ts = _conv_weight_planes(weight, wa, 1)
                 dx = _conv_fwd_call(dy, th, tl, ts, ga, None, Cin, KH, KW, 1, dil * (KH - 1) - pad, dil)
-            elif stride > 1 and dil == 1 and (dx := _conv_dgrad_strided(x.shape, weight, dy, ga, wa, stride, pad)) is not None:
+            elif stride > 1 and dil == 1 and (dx := _conv_dgrad_strided((B, Cin, H, W), weight, dy, ga, wa, stride, pad)) is not None:
                 pass    # stride^2 parity classes, each a stride-1 convolution of dy scattered into dx (K16)
             else:       # whatever is left (dilated + strided, rectangular kernels with odd paddings): the framework
-                dx = torch.nn.grad.conv2d_input(x.shape, weight, dy, stride=stride, padding=pad, dilation=dil)
-        if need_w:
+                dx = torch.nn.grad.conv2d_input((B, Cin, H, W), weight, dy, stride=stride, padding=pad, dilation=dil)
+        if need_w and xp is not None:
+            lib = _lib.load()
+            _, Hp, Wp, Cp = xp.shape
+            S = lib.cocos_conv2d_nhwc_wgrad_bf16_slices(B, dy.shape[2], dy.shape[3], Cp, Cout, KH, KW)
+            part = torch.empty((S, Cout, lib.cocos_conv2d_kdim(Cin, KH, KW)), device=dy.device, dtype=torch.float32)
+            _call("conv2d_wgrad", "cocos_conv2d_nhwc_wgrad_bf16", xp.data_ptr(), dyp.data_ptr(), part.data_ptr(), B, Cp, Hp, Wp, Cout,
+                  q if dx_nhwc else 0, KH, KW, dil, _stream())
+            dw = torch.empty_like(weight)
+            _call("conv2d_wgrad", "cocos_conv2d_wgrad_reduce", part.data_ptr(), dw.data_ptr(), S, Cout, Cin, KH, KW, _stream())
+        elif need_w:
             lib = _lib.load()
             S = lib.cocos_conv2d_wgrad_slices(B, Cin, H, W, Cout, KH, KW, stride, pad, dil)
             kdim = lib.cocos_conv2d_kdim(Cin, KH, KW)
@@ -997,14 +1060,28 @@ class _Conv2d(torch.autograd.Function):
             _call("conv2d_wgrad", "cocos_conv2d_wgrad_reduce", part.data_ptr(), dw.data_ptr(), S, Cout, Cin, KH, KW, _stream())
         if need_b and has_bias:
             db = channel_sum(dy)
-        return dx, dw, db, None, None, None
+        if reflect and dx is not None:          # fold the mirrored border back (K18's backward gather)
+            dxp, dx = dx, torch.empty(ctx.x_shape, device=dy.device, dtype=torch.float32)
+            _call("reflect_pad2d_bwd", "cocos_reflect_pad2d_bwd", dxp.data_ptr(), dx.data_ptr(), B * Cin, ctx.x_shape[2], ctx.x_shape[3],
+                  reflect, _stream())
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride: int = 1, padding: int = 0, dilation: int = 1):
+def conv2d(x, weight, bias=None, stride: int = 1, padding: int = 0, dilation: int = 1, reflect: int = 0):
     """torch.nn.functional.conv2d(x, weight, bias, stride, padding, dilation) for groups = 1 and one stride / padding /
     dilation for both axes: fp32 in and out, products on the f16 MFMA with split operands (3 terms, fp32 accumulate) —
-    conv_f16x3.hip.  (The input gradient of a strided layer still takes the framework's transposed convolution.)"""
-    return _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+    conv_f16x3.hip — or, under COCOS_CONV=bf16, in one bf16 term (stride-1 layers with >= 128 output channels: conv_nhwc_bf16.hip).
+    `reflect` = r > 0: the convolution of nn.ReflectionPad2d(r)(x) — on the K16b path the mirrored border is written by the
+    operand preparation (no padded fp32 tensor), everywhere else it is ops.reflect_pad2d followed by the plain layer."""
+    reflect = int(reflect)
+    if reflect:
+        Cout, Cin, KH, KW = weight.shape
+        ow = x.shape[3] + 2 * reflect + 2 * int(padding) - int(dilation) * (KW - 1)
+        fused = (_conv_bf16() and int(stride) == 1 and int(padding) == 0 and x.dim() == 4 and reflect < min(x.shape[2:])
+                 and ow >= 32 and ow % 32 == 0 and _conv_nhwc_ok(Cin, Cout, KH, KW, 1))
+        if not fused:
+            x, reflect = reflect_pad2d(x, reflect), 0
+    return _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation), reflect)
 
 
 # ------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ PONO or instance/batch/sync-batch parameter-free norms.  Unsupported flags raise
 from __future__ import annotations
 
 import os
+import threading
 import re
 
 import torch
@@ -37,21 +38,45 @@ class Conv2d(nn.Conv2d):
 
     def _conv_forward(self, input, weight, bias):
         s, p, k, d = self.stride, self.padding, self.kernel_size, self.dilation
+        reflect = getattr(_pending, "reflect", 0)          # set by reflect_conv(): this call is conv(ReflectionPad2d(r)(input))
+        _pending.reflect = 0
+        if reflect and not (CONV_BACKEND in _HIP_BACKENDS and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4):
+            input, reflect = nn.functional.pad(input, (reflect,) * 4, mode="reflect"), 0
         if (CONV_BACKEND in _HIP_BACKENDS and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32
                 and input.dim() == 4 and self.groups == 1 and self.padding_mode == "zeros"
                 and not isinstance(p, str) and s[0] == s[1] and p[0] == p[1] and d[0] == d[1]):
             from . import _lib, ops
             try:
-                if k == (1, 1) and s[0] == 1 and p[0] == 0:
+                if k == (1, 1) and s[0] == 1 and p[0] == 0 and not reflect:
                     return ops.proj1x1(input, weight, bias)
-                return ops.conv2d(input, weight, bias, s[0], p[0], d[0])
+                return ops.conv2d(input, weight, bias, s[0], p[0], d[0], reflect)
             except _lib.CocosHipError as e:
                 # kernel-side limits (a tensor of 2 GiB or more, a grid too large for the 32-bit index arithmetic: the
                 # discriminator / VGG at very large batch or resolution) are not part of the check above: they take the
                 # framework path instead of failing the training step.  Anything else is a real error.
                 if getattr(e, "code", 0) != -2:          # COCOS_ERR_UNSUPPORTED (include/cocos_hip.h)
                     raise
+        if reflect:
+            input = nn.functional.pad(input, (reflect,) * 4, mode="reflect")
         return super()._conv_forward(input, weight, bias)
+
+
+_pending = threading.local()
+
+
+def reflect_conv(pad: nn.Module, conv: nn.Module, x):
+    """conv(pad(x)) for a ReflectionPad2d directly in front of one of this module's Conv2d layers.  The convolution is still
+    CALLED as a module (spectral-norm and other forward hooks run); the padding travels to its `_conv_forward` as a
+    per-thread note, so that the bf16 / NHWC path can write the mirrored border while it prepares its operand
+    (ops.conv2d(reflect=r)) instead of materialising the padded fp32 tensor first."""
+    p = pad.padding
+    if isinstance(conv, Conv2d) and len(set(p)) == 1 and p[0] > 0 and torch.is_tensor(x) and x.dim() == 4 and p[0] < min(x.shape[2:]):
+        _pending.reflect = int(p[0])
+        try:
+            return conv(x)
+        finally:
+            _pending.reflect = 0
+    return conv(pad(x))
 
 
 class ReflectionPad2d(nn.ReflectionPad2d):
@@ -219,8 +244,8 @@ class SPADEResnetBlock(nn.Module):
 
     def forward(self, x, seg):
         x_s = self.conv_s(self.norm_s(x, seg)) if self.learned_shortcut else x
-        dx = self.conv_0(self.pad(self.norm_0(x, seg, slope=0.2)))       # norm -> LeakyReLU(0.2) -> pad -> conv
-        dx = self.conv_1(self.pad(self.norm_1(dx, seg, slope=0.2)))
+        dx = reflect_conv(self.pad, self.conv_0, self.norm_0(x, seg, slope=0.2))       # norm -> LeakyReLU(0.2) -> pad -> conv
+        dx = reflect_conv(self.pad, self.conv_1, self.norm_1(dx, seg, slope=0.2))
         if self.use_se:
             dx = self.se_layar(dx)
         return x_s + dx
@@ -325,8 +350,8 @@ class ResidualBlock(nn.Module):
     def forward(self, x):
         if x.is_cuda and x.dtype == torch.float32:
             from . import ops            # K13: InstanceNorm (+ skip) + PReLU in one HBM pass each
-            y = ops.instnorm_prelu(self.conv1(self.padding1(x)), None, self.prelu.weight, self.bn1.eps)
-            return ops.instnorm_prelu(self.conv2(self.padding2(y)), x, self.prelu.weight, self.bn2.eps)
+            y = ops.instnorm_prelu(reflect_conv(self.padding1, self.conv1, x), None, self.prelu.weight, self.bn1.eps)
+            return ops.instnorm_prelu(reflect_conv(self.padding2, self.conv2, y), x, self.prelu.weight, self.bn2.eps)
         y = self.prelu(self.bn1(self.conv1(self.padding1(x))))
         y = self.bn2(self.conv2(self.padding2(y)))
         return self.prelu(y + x)

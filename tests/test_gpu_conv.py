@@ -225,6 +225,14 @@ BF16_CASES = [
     (2, 64, 32, 32, 130, 4, 2, 2),       # PatchGAN inner layer class
     (3, 5, 9, 7, 7, 3, 1, 1),            # everything ragged
     (2, 12, 20, 24, 10, 3, 1, 2, 2),     # dilation 2
+    # K16b (conv_nhwc_bf16.hip: stride 1, >= 128 output channels, >= 32 input channels)
+    (1, 40, 20, 36, 200, 3, 1, 1),       # ragged rows (OW = 36: its weight gradient stays on K16), row / position tails
+    (2, 128, 34, 34, 512, 3, 1, 0),      # SPADE gamma/beta class, OW = 32: forward + both gradients on K16b, 128-column tiles
+    (2, 32, 44, 44, 256, 3, 1, 2, 2),    # dilation 2
+    (1, 96, 8, 64, 130, 1, 1, 0),        # 1x1 kernel, 3 k-steps
+    (2, 32, 16, 32, 128, 1, 1, 0),       # ONE k-step (the pipeline's prologue is everything)
+    (1, 64, 6, 64, 160, 5, 1, 2),        # 5x5, 50 k-steps
+    (9, 256, 64, 64, 256, 3, 1, 1),      # 36864 positions: 256-column tiles, two slices of the weight gradient per tile
 ]
 
 
@@ -257,3 +265,89 @@ def test_conv2d_bf16_flavour_error_vs_fp64(case, monkeypatch):
             errs[(prec, what)] = e
             assert e <= tol, f"{prec} {what}: {e:.3e}"
     assert errs[("bf16", "y")] > 1e-4          # it really is the low-precision arithmetic
+
+
+@pytest.mark.parametrize("B,C,H,W,pad,reflect", [(2, 37, 9, 70, 1, True), (1, 64, 5, 5, 2, False), (3, 3, 8, 8, 0, False),
+                                                 (1, 130, 4, 66, 3, True)])
+def test_conv_nhwc_prep_is_pad_plus_bf16_plus_permute(B, C, H, W, pad, reflect):
+    """cocos_conv2d_nhwc_prep_bf16 against the framework's pad -> bf16 (round to nearest even) -> NHWC, bit for bit."""
+    from cocosnet_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B, C, H, W, device="cuda", generator=g) * 3
+    xp = ops.conv_nhwc_prep(x, pad, reflect)
+    Cp = (C + 31) // 32 * 32
+    assert xp.shape == (B, H + 2 * pad, W + 2 * pad, Cp) and xp.dtype == torch.bfloat16
+    ref = torch.nn.functional.pad(x, (pad,) * 4, mode="reflect" if reflect else "constant") if pad else x
+    ref = torch.nn.functional.pad(ref.to(torch.bfloat16).permute(0, 2, 3, 1), (0, Cp - C))
+    assert torch.equal(xp, ref)
+
+
+def test_conv2d_bf16_nhwc_matches_the_gather_flavour(monkeypatch):
+    """Same arithmetic (one bf16 term, fp32 accumulate) through the two data paths: K16b (operands bf16 NHWC in memory,
+    LDS-DMA) against conv_f16x3.hip's one-term kernels (fp32 NCHW gathered per tap) — differences are summation order only."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "CONV_PRECISION", "bf16")
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x0 = torch.randn(2, 96, 34, 66, device="cuda", generator=g)
+    w0 = torch.randn(288, 96, 3, 3, device="cuda", generator=g) / 30
+    b0 = torch.randn(288, device="cuda", generator=g)
+    go = torch.randn(2, 288, 32, 64, device="cuda", generator=g)
+    res = {}
+    for nhwc in (True, False):
+        monkeypatch.setattr(ops, "CONV_NHWC", nhwc)
+        x, w, b = (t.clone().requires_grad_(True) for t in (x0, w0, b0))
+        with ops.KernelTimer() as kt:
+            y = ops.conv2d(x, w, b, 1, 0, 1)
+            y.backward(go)
+        assert ("conv2d_nhwc_prep" in kt.summary()) == nhwc
+        res[nhwc] = (y.detach(), x.grad, w.grad, b.grad)
+    for a, r, what in zip(res[True], res[False], ("y", "dx", "dw", "db")):
+        e = (a - r).abs().max().item() / r.abs().max().item()
+        assert e <= 2e-5, f"{what}: {e:.3e}"
+
+
+def test_conv2d_reflect_fused_equals_pad_then_conv(monkeypatch):
+    """ops.conv2d(reflect=r) on the K16b path (mirrored border written by the operand preparation, input gradient folded back by
+    K18's backward) against reflect_pad2d followed by the same layer; shapes the fused path does not take fall back to exactly that."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "CONV_PRECISION", "bf16")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for (B, Cin, H, W, Cout, r, fused) in ((2, 64, 32, 64, 192, 1, True), (1, 40, 12, 64, 128, 2, True), (2, 64, 20, 36, 192, 1, False)):
+        k = 2 * r + 1
+        x0 = torch.randn(B, Cin, H, W, device="cuda", generator=g)
+        w0 = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
+        b0 = torch.randn(Cout, device="cuda", generator=g)
+        go = torch.randn(B, Cout, H, W, device="cuda", generator=g)
+        res = []
+        for mode in ("fused", "separate"):
+            x, w, b = (t.clone().requires_grad_(True) for t in (x0, w0, b0))
+            with ops.KernelTimer() as kt:
+                y = ops.conv2d(x, w, b, 1, 0, 1, reflect=r) if mode == "fused" else ops.conv2d(ops.reflect_pad2d(x, r), w, b, 1, 0, 1)
+                y.backward(go)
+            if mode == "fused":
+                assert ("reflect_pad2d_fwd" not in kt.summary()) == fused
+            res.append((y.detach(), x.grad, w.grad, b.grad))
+        for a, ref, what in zip(res[0], res[1], ("y", "dx", "dw", "db")):
+            e = (a - ref).abs().max().item() / ref.abs().max().item()
+            assert e <= 2e-5, f"{(B, Cin, H, W, Cout, r)} {what}: {e:.3e}"
+
+
+def test_reflect_conv_helper_keeps_module_semantics(monkeypatch):
+    """producers.reflect_conv(pad, conv, x) == conv(pad(x)) — with spectral norm on the layer (its hook must still run), in both
+    convolution flavours, and for a layer the fused path does not take."""
+    from cocosnet_amd import ops, producers
+    g = torch.Generator(device="cuda").manual_seed(10)
+    x = torch.randn(2, 64, 32, 32, device="cuda", generator=g)
+    for prec in ("bf16", "f16x3"):
+        monkeypatch.setattr(ops, "CONV_PRECISION", prec)
+        monkeypatch.setattr(producers, "CONV_BACKEND", prec)
+        for cout in (160, 24):
+            torch.manual_seed(0)
+            conv = torch.nn.utils.spectral_norm(producers.Conv2d(64, cout, 3)).cuda()
+            pad = producers.ReflectionPad2d(1)
+            conv.eval()                                    # spectral norm: no power iteration, same weight for both calls
+            a = producers.reflect_conv(pad, conv, x)
+            b = conv(pad(x))
+            assert a.shape == b.shape == (2, cout, 32, 32)
+            assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+            assert getattr(producers._pending, "reflect", 0) == 0
