@@ -44,6 +44,7 @@ struct NhwcGeom {
     int OH, OW, OHW, Ntot;    // output grid, positions in all
     int Cout, T, KW, dil;     // rows of the weight planes, taps, kernel width, dilation
     int ncb, nsteps;          // channel blocks of 32, k-steps = ncb * T
+    int ntiles;               // row tiles x column tiles of the launch's tile shape
     unsigned xp_bytes, w_bytes;
 };
 
@@ -116,132 +117,193 @@ __global__ __launch_bounds__(256) void conv_nhwc_prep_kernel(const float* __rest
 //
 // step t:   fragments k 16..31 of stage t  |  16 | 8 MFMAs (k 0..15)  |  vmcnt: stage t+1 landed; barrier: every wave is done
 //           reading stage t  |  LDS-DMA of stage t+3 into stage t's buffer  |  fragments k 0..15 of stage t+1  |  MFMAs (k 16..31)
-template <int BN>
+//
+// SK ("stream-K"): a layer whose tile count is a little above a multiple of the CU count (the input gradient of the
+// reflect-padded 64x64 layers: 8 x 66 x 66 positions = 136.1 tiles of 256, x 2 row tiles = 274 workgroups on 256 CUs)
+// pays a whole second round for 18 tiles.  With SK the grid is ONE workgroup per CU and workgroup w takes the k-step
+// units [w U, (w+1) U) of the (tile, k-step) sequence: U >= one tile's steps, so a tile is cut at most once — its head
+// (k-steps 0..) is the LAST thing workgroup w does, its tail the FIRST thing workgroup w+1 does.  The early finisher
+// parks its partial tile in a workspace slot and raises a flag; the late one adds the parked tile to its own and stores.
+// No atomics on the output (same-address-class fp32 atomics ran at ~140 G/s in the K2 experiments: 0.1 ms for this tensor).
+template <int BM, int BN, bool SK>
 __global__ __launch_bounds__(256, 1) void conv_nhwc_bf16_kernel(const void* __restrict__ xp, const void* __restrict__ wpl,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
-                                                                const NhwcGeom g) {
+                                                                float* __restrict__ ws, int* __restrict__ flags, const NhwcGeom g,
+                                                                const int units_per_wg) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char nb_smem[];
-    constexpr int A_BYTES = NB_BM * NB_ROW, B_BYTES = BN * NB_ROW, ST_BYTES = A_BYTES + B_BYTES;
-    constexpr int NI = 4, NJ = BN / 64;                 // 32x32 MFMA tiles of a wave: 128 rows x BN/2 columns
+    constexpr int A_BYTES = BM * NB_ROW, B_BYTES = BN * NB_ROW, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int NI = BM / 64, NJ = BN / 64;           // 32x32 MFMA tiles of a wave: BM/2 rows x BN/2 columns
+    constexpr int NAI = BM / 64;                        // weight DMA instructions per wave and stage (16 rows each)
     constexpr int NBI = BN / 64;                        // activation DMA instructions per wave and stage (16 positions each)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
-    const int ntm = (g.Cout + NB_BM - 1) / NB_BM;
-    const int mt = blockIdx.x % ntm, nt = blockIdx.x / ntm;
-    const int m0 = mt * NB_BM, n0 = nt * BN;
+    const int ntm = (g.Cout + BM - 1) / BM;
+    const int nsteps = g.nsteps, T = g.T;
 
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(wpl, g.w_bytes), rB = make_rsrc(xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (size_t)g.Cout * 4 : 0);      // no bias: every read returns 0
     const int chunk = (lane & 3) ^ ((lane >> 4) & 3);   // the 16-byte piece of its row this lane fetches (source-side swizzle)
-    unsigned voffA[4], voffB[NBI];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = min(m0 + w * 64 + i * 16 + (lane >> 2), g.Cout - 1);
-        voffA[i] = (unsigned)row * NB_ROW + chunk * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < NBI; ++i) {
-        const int n = min(n0 + w * (BN / 4) + i * 16 + (lane >> 2), g.Ntot - 1);
-        const int b = n / g.OHW, rem = n - b * g.OHW, oy = rem / g.OW, ox = rem - oy * g.OW;
-        voffB[i] = (unsigned)(((b * g.Hp + oy) * g.Wp + ox) * g.Cp) * 2u + chunk * 16;
-    }
     const unsigned stepA = (unsigned)g.Cout * NB_ROW;
-
-    auto issue = [&](int cb, int tap, int t, int buf) {
-        const int ky = tap / g.KW, kx = tap - ky * g.KW;
-        const unsigned sA = (unsigned)t * stepA;
-        const unsigned sB = (unsigned)(((ky * g.Wp + kx) * g.dil) * g.Cp + cb * 32) * 2u;
-        unsigned char* st = nb_smem + buf * ST_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (nb_lds_ptr)(st + w * 4096 + i * 1024), 16, (int)voffA[i], (int)sA, 0, 0);
-#pragma unroll
-        for (int i = 0; i < NBI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (nb_lds_ptr)(st + A_BYTES + w * (BN * 16) + i * 1024), 16, (int)voffB[i],
-                                                     (int)sB, 0, 0);
-    };
-
-    f32x16 acc[NI][NJ];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     // fragment addresses: row (lane & 31) of a 32-row MFMA tile, logical chunk kk*2 + (lane >> 5), swizzled by the row
     const int frow = lane & 31, fsw = (lane >> 2) & 3, fh = lane >> 5;
     const int fo0 = frow * NB_ROW + ((0 + fh) ^ fsw) * 16, fo1 = frow * NB_ROW + ((2 + fh) ^ fsw) * 16;
-    const int fbaseA = wm * (128 * NB_ROW), fbaseB = A_BYTES + wn * ((BN / 2) * NB_ROW);
+    const int fbaseA = wm * ((BM / 2) * NB_ROW), fbaseB = A_BYTES + wn * ((BN / 2) * NB_ROW);
 
-    nb_bf16x8 fa[2][NI], fb[2][NJ];
-    auto frags = [&](int buf, int kk) {
-        const unsigned char* st = nb_smem + buf * ST_BYTES + (kk ? fo1 : fo0);
+    int u0 = SK ? (int)blockIdx.x * units_per_wg : (int)blockIdx.x * nsteps;
+    const int u1 = SK ? min(u0 + units_per_wg, g.ntiles * nsteps) : u0 + nsteps;
+    if (SK && u0 >= u1) return;
+#pragma unroll 1
+    do {
+        const int tile = u0 / nsteps, s0 = SK ? u0 - tile * nsteps : 0, s1 = SK ? min(nsteps, s0 + (u1 - u0)) : nsteps;
+        const int mt = tile % ntm, nt = tile / ntm;
+        const int m0 = mt * BM, n0 = nt * BN;
+        unsigned voffA[NAI], voffB[NBI];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) fa[kk][i] = *reinterpret_cast<const nb_bf16x8*>(st + fbaseA + i * (32 * NB_ROW));
+        for (int i = 0; i < NAI; ++i) {
+            const int row = min(m0 + w * (BM / 4) + i * 16 + (lane >> 2), g.Cout - 1);
+            voffA[i] = (unsigned)row * NB_ROW + chunk * 16;
+        }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) fb[kk][j] = *reinterpret_cast<const nb_bf16x8*>(st + fbaseB + j * (32 * NB_ROW));
-    };
-    auto mfmas = [&](int kk) {
+        for (int i = 0; i < NBI; ++i) {
+            const int n = min(n0 + w * (BN / 4) + i * 16 + (lane >> 2), g.Ntot - 1);
+            const int b = n / g.OHW, rem = n - b * g.OHW, oy = rem / g.OW, ox = rem - oy * g.OW;
+            voffB[i] = (unsigned)(((b * g.Hp + oy) * g.Wp + ox) * g.Cp) * 2u + chunk * 16;
+        }
+        auto issue = [&](int cb, int tap, int t, int buf) {
+            const int ky = tap / g.KW, kx = tap - ky * g.KW;
+            const unsigned sA = (unsigned)t * stepA;
+            const unsigned sB = (unsigned)(((ky * g.Wp + kx) * g.dil) * g.Cp + cb * 32) * 2u;
+            unsigned char* st = nb_smem + buf * ST_BYTES;
+#pragma unroll
+            for (int i = 0; i < NAI; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (nb_lds_ptr)(st + w * (BM * 16) + i * 1024), 16, (int)voffA[i], (int)sA, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NBI; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (nb_lds_ptr)(st + A_BYTES + w * (BN * 16) + i * 1024), 16, (int)voffB[i],
+                                                         (int)sB, 0, 0);
+        };
+
+        f32x16 acc[NI][NJ];
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-    };
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nsteps = g.nsteps, T = g.T;
-    // prologue: stages 0, 1, 2 in flight; stage 0 landed and visible
-    int icb = 0, itap = 0, it = 0;                       // the next k-step to issue
+        nb_bf16x8 fa[2][NI], fb[2][NJ];
+        auto frags = [&](int buf, int kk) {
+            const unsigned char* st = nb_smem + buf * ST_BYTES + (kk ? fo1 : fo0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fa[kk][i] = *reinterpret_cast<const nb_bf16x8*>(st + fbaseA + i * (32 * NB_ROW));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[kk][j] = *reinterpret_cast<const nb_bf16x8*>(st + fbaseB + j * (32 * NB_ROW));
+        };
+        auto mfmas = [&](int kk) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+        };
+
+        // prologue: the first three k-steps in flight; the first landed and visible
+        int it = s0, icb = s0 / T, itap = s0 - icb * T;      // the next k-step to issue
+        const int nseg = s1 - s0;
 #pragma unroll 1
-    for (; it < NB_STAGES && it < nsteps; ++it) {
-        issue(icb, itap, it, it);
-        if (++itap == T) { itap = 0; ++icb; }
-    }
-    if (nsteps >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (4 + NBI)) : "memory");
-    else if (nsteps == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 + NBI) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    frags(0, 0);
+        for (int u = 0; u < NB_STAGES && it < s1; ++u, ++it) {
+            issue(icb, itap, it, u);
+            if (++itap == T) { itap = 0; ++icb; }
+        }
+        if (nseg >= 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * (NAI + NBI)) : "memory");
+        else if (nseg == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NAI + NBI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        frags(0, 0);
 
-    int buf = 0;
+        int buf = 0;
 #pragma unroll 1
-    for (int t = 0; t < nsteps; ++t) {
-        frags(buf, 1);
-        mfmas(0);
-        const int nbuf = buf == NB_STAGES - 1 ? 0 : buf + 1;
-        if (t + 1 < nsteps) {
-            if (t + 2 < nsteps) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 + NBI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (it < nsteps) {
-                issue(icb, itap, it, buf);
-                ++it;
-                if (++itap == T) { itap = 0; ++icb; }
+        for (int t = s0; t < s1; ++t) {
+            frags(buf, 1);
+            mfmas(0);
+            const int nbuf = buf == NB_STAGES - 1 ? 0 : buf + 1;
+            if (t + 1 < s1) {
+                if (t + 2 < s1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NAI + NBI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (it < s1) {
+                    issue(icb, itap, it, buf);
+                    ++it;
+                    if (++itap == T) { itap = 0; ++icb; }
+                }
+                frags(nbuf, 0);
             }
-            frags(nbuf, 0);
+            mfmas(1);
+            buf = nbuf;
         }
-        mfmas(1);
-        buf = nbuf;
-    }
 
-    // epilogue: accumulator (i, j, r) is row m0 + wm*128 + 32 i + (r&3) + 8 (r>>2) + 4 (lane>>5), position n0 + wn*BN/2 + 32 j + (lane&31)
-    const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (size_t)g.Cout * 4 : 0);      // no bias: every read returns 0
-    const int corow = m0 + wm * 128 + 4 * (lane >> 5);
+        // epilogue: accumulator (i, j, r) is row m0 + wm*BM/2 + 32 i + (r&3) + 8 (r>>2) + 4 (lane>>5), position n0 + wn*BN/2 + 32 j + (lane&31)
+        if (SK && s0 > 0) {
+            // the tail of a cut tile (always this workgroup's first segment): park it, raise the flag
+            float* slot = ws + (size_t)blockIdx.x * (BM * BN) + tid;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        float bv[16];
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bv[r] = buf_load1(rbias, (unsigned)(corow + i * 32 + (r & 3) + 8 * (r >> 2)) * 4u);
+                for (int j = 0; j < NJ; ++j) {
+                    float* p = slot + (i * NJ + j) * (16 * 256);
+                    asm volatile("" : "+v"(p));          // addresses made here, not 256 loop-invariant pointers spilled to scratch
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-            if (n >= g.Ntot) continue;
-            const int b = n / g.OHW, rem = n - b * g.OHW;
-            float* yp = y + (size_t)b * g.Cout * g.OHW + rem;
+                    for (int r = 0; r < 16; ++r) p[r * 256] = acc[i][j][r];
+                }
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (SK && s1 < nsteps) {
+                // the head of a cut tile (always the last segment): the next workgroup parked the tail long ago
+                const int partner = (int)blockIdx.x + 1;
+                if (tid == 0) {
+                    while (__hip_atomic_load(flags + partner, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+                }
+                __syncthreads();
+                (void)__hip_atomic_load(flags + partner, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);    // every wave acquires
+                const float* slot = ws + (size_t)partner * (BM * BN) + tid;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = corow + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (co < g.Cout) yp[(size_t)co * g.OHW] = acc[i][j][r] + bv[r];
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        float pv[16];               // 16 loads in flight, then their adds: not 256 (the register file is full of accumulators)
+                        const float* p = slot + (i * NJ + j) * (16 * 256);
+                        asm volatile("" : "+v"(p));
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) pv[r] = __builtin_nontemporal_load(p + r * 256);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += pv[r];
+                        asm volatile("" ::: "memory");
+                    }
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(flags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            const int corow = m0 + wm * (BM / 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                float bv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = buf_load1(rbias, (unsigned)(corow + i * 32 + (r & 3) + 8 * (r >> 2)) * 4u);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+                    if (n >= g.Ntot) continue;
+                    const int b = n / g.OHW, rem = n - b * g.OHW;
+                    float* yp = y + (size_t)b * g.Cout * g.OHW + rem;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = corow + i * 32 + (r & 3) + 8 * (r >> 2);
+                        if (co < g.Cout) yp[(size_t)co * g.OHW] = acc[i][j][r] + bv[r];
+                    }
+                }
             }
         }
-    }
+        u0 += nseg;
+        if (SK && u0 < u1) __syncthreads();      // every wave is done with the LDS stages before the next segment refills them
+    } while (SK && u0 < u1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -410,10 +472,37 @@ extern "C" int cocos_conv2d_nhwc_bf16_supported(int Cin, int Cout, int KH, int K
     return (stride == 1 && Cout >= 128 && Cin >= 32 && KH >= 1 && KW >= 1 && KH * KW <= 49) ? 1 : 0;
 }
 
+namespace {
+constexpr long long kNhwcFlagBytes = 4096;                                  // 1024 flags (one per workgroup of an SK launch)
+constexpr long long kNhwcSlotBytes = 256LL * 256 * 4;                        // one parked tile
+int nhwc_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+}  // namespace
+
+// Bytes of the ZERO-INITIALISED scratch cocos_conv2d_nhwc_bf16 wants for its stream-K launches (flags + one parked tile per
+// CU); the flags are left zero by every launch, so the caller clears the buffer once, when it allocates it, and hands the same
+// buffer to every call ON ONE STREAM (calls on different streams need their own).
+extern "C" long long cocos_conv2d_nhwc_bf16_workspace_bytes(void) {
+    const int cus = nhwc_cu_count();
+    return kNhwcFlagBytes + (long long)(cus < 1024 ? cus : 1024) * kNhwcSlotBytes;
+}
+
 // y fp32 [B][Cout][OH][OW] = bias + conv(xp), xp bf16 [B][Hp][Wp][Cp] already padded (cocos_conv2d_nhwc_prep_bf16), stride 1,
 // OH = Hp - dil (KH-1), OW = Wp - dil (KW-1); w_planes = cocos_conv2d_weight_planes(mode | 2): bf16 [KH*KW*Cp/32][Cout][32].
-extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias, float* y, int B, int Cp, int Hp,
-                                      int Wp, int Cout, int KH, int KW, int dil, cocos_stream_t stream) {
+// workspace (nullable): see cocos_conv2d_nhwc_bf16_workspace_bytes — without it every launch is one tile per workgroup.
+extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias, float* y, void* workspace,
+                                      long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil,
+                                      cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(xp && w_planes && y, COCOS_ERR_INVALID, "conv2d_nhwc_bf16: null pointer");
     COCOS_REQUIRE(B >= 1 && Cp >= 32 && Cp % 32 == 0 && Cout >= 1 && KH >= 1 && KW >= 1 && dil >= 1, COCOS_ERR_INVALID,
@@ -430,20 +519,42 @@ extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, cons
                   COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_bf16: tensor too large");
     COCOS_REQUIRE(aligned16(xp) && aligned16(w_planes), COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_bf16: operands must be 16-byte aligned");
     g.Ntot = (int)ntot; g.xp_bytes = (unsigned)xbytes; g.w_bytes = (unsigned)wbytes;
-    const int ntm = (Cout + NB_BM - 1) / NB_BM;
-    const bool wide = (long long)ntm * ((ntot + 255) / 256) >= 200;       // enough 256-column tiles for the 256 CUs
+    // tile: 256 rows unless the layer has at most 128 (a half-empty 256-row tile costs what a full one does); 256 columns
+    // when that still gives the CUs something each
+    const int cus = nhwc_cu_count() < 1024 ? nhwc_cu_count() : 1024;
+    const int bm = Cout <= 128 ? 128 : 256;
+    const long long ntm = (Cout + bm - 1) / bm;
+    const int bn = (bm == 128 ? (ntot + 255) / 256 >= 100 : ntm * ((ntot + 255) / 256) >= 200) ? 256 : 128;
+    const long long tiles = ntm * ((ntot + bn - 1) / bn);
+    COCOS_REQUIRE(tiles * g.nsteps < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_bf16: too many tiles");
+    g.ntiles = (int)tiles;
+    // stream-K when the last round of one-tile workgroups would leave more than a fifth of the chip idle
+    const long long rounds = (tiles + cus - 1) / cus;
+    const bool sk = workspace && tiles > cus && tiles * 5 < rounds * cus * 4 &&
+                    workspace_bytes >= kNhwcFlagBytes + (long long)cus * kNhwcSlotBytes && bm == 256 && bn == 256;
+    // (measured, B = 8, 66 x 66 outputs: 407 -> 407 0.232 -> 0.204 ms, 512 -> 512 0.268 -> 0.250; nearly every tile is cut, so the
+    //  parked partials are 128 MB of extra traffic — with 256 x 128 tiles, 273 of them, stream-K LOST: 0.089 -> 0.101 ms)
     hipStream_t s = as_stream(stream);
-    if (wide) {
-        auto kern = conv_nhwc_bf16_kernel<256>;
-        const size_t smem = (size_t)NB_STAGES * (NB_BM + 256) * NB_ROW;
-        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ((ntot + 255) / 256))), dim3(256), smem, s, xp, w_planes, bias, y, g);
+    int* flags = static_cast<int*>(workspace);
+    float* slots = workspace ? reinterpret_cast<float*>(static_cast<char*>(workspace) + kNhwcFlagBytes) : nullptr;
+    const int units = sk ? (int)((tiles * g.nsteps + cus - 1) / cus) : g.nsteps;
+#define COCOS_NHWC_GO(BMv, BNv, SKv)                                                                                     \
+    do {                                                                                                                 \
+        auto kern = conv_nhwc_bf16_kernel<BMv, BNv, SKv>;                                                                \
+        const size_t smem = (size_t)NB_STAGES * (BMv + BNv) * NB_ROW;                                                    \
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                            (int)smem));                                                                \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(SKv ? cus : tiles)), dim3(256), smem, s, xp, w_planes, bias, y, slots, flags, g, \
+                           units);                                                                                      \
+    } while (0)
+    if (bm == 128) {
+        if (bn == 256) COCOS_NHWC_GO(128, 256, false); else COCOS_NHWC_GO(128, 128, false);
+    } else if (bn == 256) {
+        if (sk) COCOS_NHWC_GO(256, 256, true); else COCOS_NHWC_GO(256, 256, false);
     } else {
-        auto kern = conv_nhwc_bf16_kernel<128>;
-        const size_t smem = (size_t)NB_STAGES * (NB_BM + 128) * NB_ROW;
-        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ((ntot + 127) / 128))), dim3(256), smem, s, xp, w_planes, bias, y, g);
+        COCOS_NHWC_GO(256, 128, false);
     }
+#undef COCOS_NHWC_GO
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

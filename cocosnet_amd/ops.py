@@ -912,14 +912,34 @@ def conv_nhwc_prep(x: torch.Tensor, pad: int, reflect: bool = False) -> torch.Te
     return xp
 
 
+#: "0": no stream-K launches (every workgroup of K16b owns one tile) — A/B runs
+CONV_NHWC_STREAMK = os.environ.get("COCOS_CONV_STREAMK", "1") != "0"
+
+
+def _conv_nhwc_workspace(device):
+    """K16b's stream-K scratch: one zero-initialised buffer per (thread, device, stream), cleared when it is allocated (the kernel
+    leaves its flags zero)."""
+    if not CONV_NHWC_STREAMK:
+        return None
+    pool = getattr(_tls, "nhwc_ws", None)
+    if pool is None:
+        pool = _tls.nhwc_ws = {}
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    ws = pool.get(key)
+    if ws is None:
+        ws = pool[key] = torch.zeros(_lib.load().cocos_conv2d_nhwc_bf16_workspace_bytes() // 4, device=device, dtype=torch.int32)
+    return ws
+
+
 def _conv_nhwc_call(xp, planes, bias, Cout, KH, KW, dil):
     B, Hp, Wp, Cp = xp.shape
     OH, OW = Hp - dil * (KH - 1), Wp - dil * (KW - 1)
     if OH < 1 or OW < 1:
         raise ValueError(f"conv2d: kernel {KH}x{KW} (dilation {dil}) does not fit the padded input {tuple(xp.shape)}")
     y = torch.empty((B, Cout, OH, OW), device=xp.device, dtype=torch.float32)
-    _call("conv2d_fwd", "cocos_conv2d_nhwc_bf16", xp.data_ptr(), planes.data_ptr(), _ptr(bias), y.data_ptr(), B, Cp, Hp, Wp, Cout,
-          KH, KW, dil, _stream())
+    ws = _conv_nhwc_workspace(xp.device)
+    _call("conv2d_fwd", "cocos_conv2d_nhwc_bf16", xp.data_ptr(), planes.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(ws),
+          ws.numel() * 4 if ws is not None else 0, B, Cp, Hp, Wp, Cout, KH, KW, dil, _stream())
     return y
 
 

@@ -632,13 +632,19 @@ int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);
  *   cocos_conv2d_nhwc_bf16:  y fp32 [B][Cout][OH][OW] = bias + conv(xp) with stride 1 and NO further padding,
  *       OH = Hp - dil (KH-1), OW = Wp - dil (KW-1); w_planes = cocos_conv2d_weight_planes(mode | 2) ([KH*KW*Cp/32][Cout][32] bf16).
  *       The input gradient of a stride-1 layer is this call on prep(dy, dil (K-1) - pad, 0) with the mode-1 planes.
+ *       workspace: zero-initialised scratch of cocos_conv2d_nhwc_bf16_workspace_bytes() bytes, one per stream, cleared once by
+ *       the caller (every launch leaves its flags zero): with it, a layer whose tile count is just above a multiple of the CU
+ *       count runs as ONE workgroup per CU over contiguous ranges of (tile, k-step) units ("stream-K"; a cut tile's two parts
+ *       meet through the workspace) instead of paying a whole extra round; without it every workgroup owns one tile.
  *   cocos_conv2d_nhwc_wgrad_bf16:  partial fp32 [S][Cout][KH*KW*Cp] (summed / re-ordered by cocos_conv2d_wgrad_reduce),
  *       S = cocos_conv2d_nhwc_wgrad_bf16_slices(...) (0: shape not taken — OW must be a multiple of 32); dyp = prep(dy, q, 0).
  *   cocos_conv2d_nhwc_bf16_supported: 1 when the layer shape takes this path (stride 1, >= 128 output rows, >= 32 input channels). */
 int cocos_conv2d_nhwc_bf16_supported(int Cin, int Cout, int KH, int KW, int stride);
 int cocos_conv2d_nhwc_prep_bf16(const float* x, void* xp, int B, int C, int H, int W, int pad, int reflect, cocos_stream_t stream);
-int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias /* nullable */, float* y, int B, int Cp, int Hp,
-                           int Wp, int Cout, int KH, int KW, int dil, cocos_stream_t stream);
+long long cocos_conv2d_nhwc_bf16_workspace_bytes(void);
+int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias /* nullable */, float* y,
+                           void* workspace /* nullable */, long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH,
+                           int KW, int dil, cocos_stream_t stream);
 int cocos_conv2d_nhwc_wgrad_bf16_slices(int B, int OH, int OW, int Cp, int Cout, int KH, int KW);
 int cocos_conv2d_nhwc_wgrad_bf16(const void* xp, const void* dyp, float* partial, int B, int Cp, int Hp, int Wp, int Cout, int q,
                                  int KH, int KW, int dil, cocos_stream_t stream);
