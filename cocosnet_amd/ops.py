@@ -912,8 +912,10 @@ def conv_nhwc_prep(x: torch.Tensor, pad: int, reflect: bool = False) -> torch.Te
     return xp
 
 
-#: "0": no stream-K launches (every workgroup of K16b owns one tile) — A/B runs
-CONV_NHWC_STREAMK = os.environ.get("COCOS_CONV_STREAMK", "1") != "0"
+#: "1": stream-K launches for K16b layers whose tile count is just above a whole round of the CUs.  Off by default: once the
+#: DMA pieces were interleaved with the MFMAs a tile got 20 % faster and the parked partials (nearly every tile is cut: 128 MB)
+#: cost what the second round costs (407 -> 407 input gradient 0.191 vs 0.192 ms, 512 -> 512 0.224 vs 0.239).
+CONV_NHWC_STREAMK = os.environ.get("COCOS_CONV_STREAMK", "0") == "1"
 
 
 def _conv_nhwc_workspace(device):
