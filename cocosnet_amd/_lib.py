@@ -127,9 +127,9 @@ _SIGNATURES = {
     "cocos_conv2d_nhwc_prep_bf16": (ctypes.c_int, [_c_float_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [_stream_t]),
     "cocos_conv2d_nhwc_bf16_workspace_bytes": (ctypes.c_longlong, []),
     "cocos_conv2d_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_void_p,
-                                               ctypes.c_longlong] + [ctypes.c_int] * 8 + [_stream_t]),
+                                               ctypes.c_longlong] + [ctypes.c_int] * 9 + [_stream_t]),
     "cocos_conv2d_nhwc_wgrad_bf16_slices": (ctypes.c_int, [ctypes.c_int] * 7),
-    "cocos_conv2d_nhwc_wgrad_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 9 + [_stream_t]),
+    "cocos_conv2d_nhwc_wgrad_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 10 + [_stream_t]),
     "cocos_channel_sum_slices": (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong]),
     "cocos_channel_sum": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, _stream_t]),
     "cocos_box3_stat_grads": (ctypes.c_int, [_c_float_p] * 10 + [ctypes.c_longlong, ctypes.c_float, ctypes.c_float,

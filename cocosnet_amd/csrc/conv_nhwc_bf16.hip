@@ -1,4 +1,4 @@
-// K16b: stride-1 convolution in ONE bf16 MFMA term on operands that are bf16 IN MEMORY — gfx950.
+// K16b: convolution (any stride; input gradient for stride 1) in ONE bf16 MFMA term on operands that are bf16 IN MEMORY — gfx950.
 //
 // The one-term flavour of conv_f16x3.hip (`COCOS_CONV=bf16`) halved the matrix work of K16 and then sat on the CU's vector
 // memory path: its activations are fp32 NCHW in HBM, every k-block of 32 channels x 128 positions is gathered once PER TAP
@@ -52,6 +52,7 @@ struct NhwcGeom {
     int B, Cp, Hp, Wp;        // padded NHWC input
     int OH, OW, OHW, Ntot;    // output grid, positions in all
     int Cout, T, KW, dil;     // rows of the weight planes, taps, kernel width, dilation
+    int stride;
     int ncb, nsteps;          // channel blocks of 32, k-steps = ncb * T
     int ntiles;               // row tiles x column tiles of the launch's tile shape
     unsigned xp_bytes, w_bytes;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_bf16_kernel(const void* __re
         for (int i = 0; i < NBI; ++i) {
             const int n = min(n0 + w * (BN / 4) + i * 16 + (lane >> 2), g.Ntot - 1);
             const int b = n / g.OHW, rem = n - b * g.OHW, oy = rem / g.OW, ox = rem - oy * g.OW;
-            voffB[i] = (unsigned)(((b * g.Hp + oy) * g.Wp + ox) * g.Cp) * 2u + chunk * 16;
+            voffB[i] = (unsigned)(((b * g.Hp + oy * g.stride) * g.Wp + ox * g.stride) * g.Cp) * 2u + chunk * 16;
         }
         auto issue = [&](int cb, int tap, int t, int buf) {
             const int ky = tap / g.KW, kx = tap - ky * g.KW;
@@ -354,6 +355,7 @@ struct NhwcWgradGeom {
     int Cop, Hq, Wq, q;         // dyp
     int OH, OW, Ntot;
     int Cout, T, KW, dil, nkb;  // nkb = T * Cp / 32 blocks of k'
+    int stride;
     int steps_total, steps_per_slice;
     unsigned xp_bytes, dy_bytes;
 };
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void
         const int co = min(m0 + col, g.Cop - 8);
         voffA[i] = (unsigned)(nl * g.Cop + co) * 2u;
         const int kb = min((k0 + col) >> 5, g.nkb - 1), cb = kb / g.T, tap = kb - cb * g.T, ky = tap / g.KW, kx = tap - ky * g.KW;
-        voffB[i] = (unsigned)(((ky * g.Wp + kx) * g.dil + nl) * g.Cp + cb * 32 + (col & 31)) * 2u;
+        voffB[i] = (unsigned)(((ky * g.Wp + kx) * g.dil + nl * g.stride) * g.Cp + cb * 32 + (col & 31)) * 2u;
     }
     // scalar position of the next k-step to issue: image b, output row oy, first column ox
     int it = 0, ib, ioy, iox;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void
     }
     auto issue = [&](int buf) {
         const unsigned sA = (unsigned)(((ib * g.Hq + ioy + g.q) * g.Wq + iox + g.q) * g.Cop) * 2u;
-        const unsigned sB = (unsigned)(((ib * g.Hp + ioy) * g.Wp + iox) * g.Cp) * 2u;
+        const unsigned sB = (unsigned)(((ib * g.Hp + ioy * g.stride) * g.Wp + iox * g.stride) * g.Cp) * 2u;
         unsigned char* st = nb_smem + buf * ST_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -522,7 +524,7 @@ extern "C" int cocos_conv2d_nhwc_prep_bf16(const float* x, void* xp, int B, int 
 }
 
 extern "C" int cocos_conv2d_nhwc_bf16_supported(int Cin, int Cout, int KH, int KW, int stride) {
-    return (stride == 1 && Cout >= 128 && Cin >= 32 && KH >= 1 && KW >= 1 && KH * KW <= 49) ? 1 : 0;
+    return (stride >= 1 && stride <= 4 && Cout >= 128 && Cin >= 32 && KH >= 1 && KW >= 1 && KH * KW <= 49) ? 1 : 0;
 }
 
 namespace {
@@ -550,20 +552,20 @@ extern "C" long long cocos_conv2d_nhwc_bf16_workspace_bytes(void) {
     return kNhwcFlagBytes + (long long)(cus < 1024 ? cus : 1024) * kNhwcSlotBytes;
 }
 
-// y fp32 [B][Cout][OH][OW] = bias + conv(xp), xp bf16 [B][Hp][Wp][Cp] already padded (cocos_conv2d_nhwc_prep_bf16), stride 1,
-// OH = Hp - dil (KH-1), OW = Wp - dil (KW-1); w_planes = cocos_conv2d_weight_planes(mode | 2): bf16 [KH*KW*Cp/32][Cout][32].
+// y fp32 [B][Cout][OH][OW] = bias + conv(xp), xp bf16 [B][Hp][Wp][Cp] already padded (cocos_conv2d_nhwc_prep_bf16),
+// OH = (Hp - dil (KH-1) - 1) / stride + 1, OW likewise; w_planes = cocos_conv2d_weight_planes(mode | 2): bf16 [KH*KW*Cp/32][Cout][32].
 // workspace (nullable): see cocos_conv2d_nhwc_bf16_workspace_bytes — without it every launch is one tile per workgroup.
 extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias, float* y, void* workspace,
                                       long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil,
-                                      cocos_stream_t stream) {
+                                      int stride, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(xp && w_planes && y, COCOS_ERR_INVALID, "conv2d_nhwc_bf16: null pointer");
-    COCOS_REQUIRE(B >= 1 && Cp >= 32 && Cp % 32 == 0 && Cout >= 1 && KH >= 1 && KW >= 1 && dil >= 1, COCOS_ERR_INVALID,
-                  "conv2d_nhwc_bf16: bad arguments (B=%d Cp=%d Cout=%d k=%dx%d dil=%d)", B, Cp, Cout, KH, KW, dil);
+    COCOS_REQUIRE(B >= 1 && Cp >= 32 && Cp % 32 == 0 && Cout >= 1 && KH >= 1 && KW >= 1 && dil >= 1 && stride >= 1, COCOS_ERR_INVALID,
+                  "conv2d_nhwc_bf16: bad arguments (B=%d Cp=%d Cout=%d k=%dx%d dil=%d stride=%d)", B, Cp, Cout, KH, KW, dil, stride);
     NhwcGeom g;
-    g.B = B; g.Cp = Cp; g.Hp = Hp; g.Wp = Wp;
-    g.OH = Hp - dil * (KH - 1); g.OW = Wp - dil * (KW - 1);
-    COCOS_REQUIRE(g.OH >= 1 && g.OW >= 1, COCOS_ERR_INVALID, "conv2d_nhwc_bf16: kernel larger than the padded input");
+    g.B = B; g.Cp = Cp; g.Hp = Hp; g.Wp = Wp; g.stride = stride;
+    COCOS_REQUIRE(Hp > dil * (KH - 1) && Wp > dil * (KW - 1), COCOS_ERR_INVALID, "conv2d_nhwc_bf16: kernel larger than the padded input");
+    g.OH = (Hp - dil * (KH - 1) - 1) / stride + 1; g.OW = (Wp - dil * (KW - 1) - 1) / stride + 1;
     g.OHW = g.OH * g.OW;
     const long long ntot = (long long)B * g.OHW, xbytes = (long long)B * Hp * Wp * Cp * 2;
     g.Cout = Cout; g.T = KH * KW; g.KW = KW; g.dil = dil; g.ncb = Cp / 32; g.nsteps = g.ncb * g.T;
@@ -624,14 +626,14 @@ extern "C" int cocos_conv2d_nhwc_wgrad_bf16_slices(int B, int OH, int OW, int Cp
 // partial fp32 [S][Cout][KH*KW*Cp] (k' order of K16; summed and re-ordered by cocos_conv2d_wgrad_reduce), S = ..._slices(...);
 // xp as in cocos_conv2d_nhwc_bf16; dyp = bf16 NHWC [B][OH+2q][OW+2q][Cop] (cocos_conv2d_nhwc_prep_bf16 of dy with pad q, zeros).
 extern "C" int cocos_conv2d_nhwc_wgrad_bf16(const void* xp, const void* dyp, float* partial, int B, int Cp, int Hp, int Wp, int Cout,
-                                            int q, int KH, int KW, int dil, cocos_stream_t stream) {
+                                            int q, int KH, int KW, int dil, int stride, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(xp && dyp && partial, COCOS_ERR_INVALID, "conv2d_nhwc_wgrad_bf16: null pointer");
-    COCOS_REQUIRE(B >= 1 && Cp >= 32 && Cp % 32 == 0 && Cout >= 1 && KH >= 1 && KW >= 1 && dil >= 1 && q >= 0, COCOS_ERR_INVALID,
-                  "conv2d_nhwc_wgrad_bf16: bad arguments");
+    COCOS_REQUIRE(B >= 1 && Cp >= 32 && Cp % 32 == 0 && Cout >= 1 && KH >= 1 && KW >= 1 && dil >= 1 && q >= 0 && stride >= 1 &&
+                      Hp > dil * (KH - 1) && Wp > dil * (KW - 1), COCOS_ERR_INVALID, "conv2d_nhwc_wgrad_bf16: bad arguments");
     NhwcWgradGeom g;
-    g.B = B; g.Cp = Cp; g.Hp = Hp; g.Wp = Wp;
-    g.OH = Hp - dil * (KH - 1); g.OW = Wp - dil * (KW - 1);
+    g.B = B; g.Cp = Cp; g.Hp = Hp; g.Wp = Wp; g.stride = stride;
+    g.OH = (Hp - dil * (KH - 1) - 1) / stride + 1; g.OW = (Wp - dil * (KW - 1) - 1) / stride + 1;
     COCOS_REQUIRE(g.OH >= 1 && g.OW >= 32 && g.OW % 32 == 0, COCOS_ERR_UNSUPPORTED,
                   "conv2d_nhwc_wgrad_bf16: output rows must be whole k-steps of 32 positions (OW=%d)", g.OW);
     g.Cop = (Cout + 31) / 32 * 32; g.q = q; g.Hq = g.OH + 2 * q; g.Wq = g.OW + 2 * q;

@@ -933,15 +933,15 @@ def _conv_nhwc_workspace(device):
     return ws
 
 
-def _conv_nhwc_call(xp, planes, bias, Cout, KH, KW, dil):
+def _conv_nhwc_call(xp, planes, bias, Cout, KH, KW, dil, stride=1):
     B, Hp, Wp, Cp = xp.shape
-    OH, OW = Hp - dil * (KH - 1), Wp - dil * (KW - 1)
-    if OH < 1 or OW < 1:
+    OH, OW = (Hp - dil * (KH - 1) - 1) // stride + 1, (Wp - dil * (KW - 1) - 1) // stride + 1
+    if Hp <= dil * (KH - 1) or Wp <= dil * (KW - 1):
         raise ValueError(f"conv2d: kernel {KH}x{KW} (dilation {dil}) does not fit the padded input {tuple(xp.shape)}")
     y = torch.empty((B, Cout, OH, OW), device=xp.device, dtype=torch.float32)
     ws = _conv_nhwc_workspace(xp.device)
     _call("conv2d_fwd", "cocos_conv2d_nhwc_bf16", xp.data_ptr(), planes.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(ws),
-          ws.numel() * 4 if ws is not None else 0, B, Cp, Hp, Wp, Cout, KH, KW, dil, _stream())
+          ws.numel() * 4 if ws is not None else 0, B, Cp, Hp, Wp, Cout, KH, KW, dil, int(stride), _stream())
     return y
 
 
@@ -1007,7 +1007,7 @@ class _Conv2d(torch.autograd.Function):
         if wa is None and _conv_nhwc_ok(Cin, Cout, KH, KW, stride):
             # K16b: operands bf16 in memory (NHWC, border included), LDS-DMA GEMM — conv_nhwc_bf16.hip
             xp = conv_nhwc_prep(x, reflect if reflect else pad, bool(reflect))    # the border: zeros, or the layer's ReflectionPad2d
-            y = _conv_nhwc_call(xp, wh, bb, Cout, KH, KW, dil)
+            y = _conv_nhwc_call(xp, wh, bb, Cout, KH, KW, dil, stride)
             if y.shape[3] % 32 != 0:
                 xp = None               # its weight gradient takes whole rows of 32 positions: this layer's stays on K16
         else:
@@ -1064,7 +1064,7 @@ class _Conv2d(torch.autograd.Function):
             S = lib.cocos_conv2d_nhwc_wgrad_bf16_slices(B, dy.shape[2], dy.shape[3], Cp, Cout, KH, KW)
             part = torch.empty((S, Cout, lib.cocos_conv2d_kdim(Cin, KH, KW)), device=dy.device, dtype=torch.float32)
             _call("conv2d_wgrad", "cocos_conv2d_nhwc_wgrad_bf16", xp.data_ptr(), dyp.data_ptr(), part.data_ptr(), B, Cp, Hp, Wp, Cout,
-                  q if dx_nhwc else 0, KH, KW, dil, _stream())
+                  q if dx_nhwc else 0, KH, KW, dil, stride, _stream())
             dw = torch.empty_like(weight)
             _call("conv2d_wgrad", "cocos_conv2d_wgrad_reduce", part.data_ptr(), dw.data_ptr(), S, Cout, Cin, KH, KW, _stream())
         elif need_w:

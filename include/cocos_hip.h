@@ -629,8 +629,8 @@ int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);
  * cocos_conv2d_wgrad_bf16 (ResidualBlock correspondence.py:13-36, adaptors :150-173, SPADE mlp normalization.py:118-127).
  *   cocos_conv2d_nhwc_prep_bf16:  x fp32 [B][C][H][W] -> xp bf16 [B][H+2 pad][W+2 pad][Cp], Cp = 32 ceil(C/32), channels
  *       beyond C zero, the border zero (reflect = 0) or mirrored as nn.ReflectionPad2d (reflect = 1).
- *   cocos_conv2d_nhwc_bf16:  y fp32 [B][Cout][OH][OW] = bias + conv(xp) with stride 1 and NO further padding,
- *       OH = Hp - dil (KH-1), OW = Wp - dil (KW-1); w_planes = cocos_conv2d_weight_planes(mode | 2) ([KH*KW*Cp/32][Cout][32] bf16).
+ *   cocos_conv2d_nhwc_bf16:  y fp32 [B][Cout][OH][OW] = bias + conv(xp) with NO further padding,
+ *       OH = (Hp - dil (KH-1) - 1) / stride + 1, OW likewise; w_planes = cocos_conv2d_weight_planes(mode | 2) ([KH*KW*Cp/32][Cout][32] bf16).
  *       The input gradient of a stride-1 layer is this call on prep(dy, dil (K-1) - pad, 0) with the mode-1 planes.
  *       workspace: zero-initialised scratch of cocos_conv2d_nhwc_bf16_workspace_bytes() bytes, one per stream, cleared once by
  *       the caller (every launch leaves its flags zero): with it, a layer whose tile count is just above a multiple of the CU
@@ -638,16 +638,17 @@ int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);
  *       meet through the workspace) instead of paying a whole extra round; without it every workgroup owns one tile.
  *   cocos_conv2d_nhwc_wgrad_bf16:  partial fp32 [S][Cout][KH*KW*Cp] (summed / re-ordered by cocos_conv2d_wgrad_reduce),
  *       S = cocos_conv2d_nhwc_wgrad_bf16_slices(...) (0: shape not taken — OW must be a multiple of 32); dyp = prep(dy, q, 0).
- *   cocos_conv2d_nhwc_bf16_supported: 1 when the layer shape takes this path (stride 1, >= 128 output rows, >= 32 input channels). */
+ *   cocos_conv2d_nhwc_bf16_supported: 1 when the layer shape takes this path (>= 128 output rows, >= 32 input channels; strided layers: forward and weight
+ *       gradient — their input gradient stays on cocos_conv2d_fwd_scatter_f16x3's parity classes). */
 int cocos_conv2d_nhwc_bf16_supported(int Cin, int Cout, int KH, int KW, int stride);
 int cocos_conv2d_nhwc_prep_bf16(const float* x, void* xp, int B, int C, int H, int W, int pad, int reflect, cocos_stream_t stream);
 long long cocos_conv2d_nhwc_bf16_workspace_bytes(void);
 int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias /* nullable */, float* y,
                            void* workspace /* nullable */, long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH,
-                           int KW, int dil, cocos_stream_t stream);
+                           int KW, int dil, int stride, cocos_stream_t stream);
 int cocos_conv2d_nhwc_wgrad_bf16_slices(int B, int OH, int OW, int Cp, int Cout, int KH, int KW);
 int cocos_conv2d_nhwc_wgrad_bf16(const void* xp, const void* dyp, float* partial, int B, int Cp, int Hp, int Wp, int Cout, int q,
-                                 int KH, int KW, int dil, cocos_stream_t stream);
+                                 int KH, int KW, int dil, int stride, cocos_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -233,6 +233,8 @@ BF16_CASES = [
     (2, 32, 16, 32, 128, 1, 1, 0),       # ONE k-step (the pipeline's prologue is everything)
     (1, 64, 6, 64, 160, 5, 1, 2),        # 5x5, 50 k-steps
     (9, 256, 64, 64, 256, 3, 1, 1),      # 36864 positions: 256-column tiles, two slices of the weight gradient per tile
+    (2, 64, 64, 128, 160, 3, 2, 1),      # stride 2 on K16b (forward + weight gradient; input gradient by parity classes), OW = 64
+    (2, 32, 33, 37, 128, 4, 2, 2),       # stride 2, k4, ragged output (weight gradient on K16)
 ]
 
 
