@@ -135,17 +135,21 @@ __global__ __launch_bounds__(256) void conv_nhwc_prep_kernel(const float* __rest
 // (k-steps 0..) is the LAST thing workgroup w does, its tail the FIRST thing workgroup w+1 does.  The early finisher
 // parks its partial tile in a workspace slot and raises a flag; the late one adds the parked tile to its own and stores.
 // No atomics on the output (same-address-class fp32 atomics ran at ~140 G/s in the K2 experiments: 0.1 ms for this tensor).
-template <int BM, int BN, bool SK>
-__global__ __launch_bounds__(256, 1) void conv_nhwc_bf16_kernel(const void* __restrict__ xp, const void* __restrict__ wpl,
+template <int BM, int BN, bool SK, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* __restrict__ xp, const void* __restrict__ wpl,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 float* __restrict__ ws, int* __restrict__ flags, const NhwcGeom g,
                                                                 const int units_per_wg) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char nb_smem[];
     constexpr int A_BYTES = BM * NB_ROW, B_BYTES = BN * NB_ROW, ST_BYTES = A_BYTES + B_BYTES;
-    constexpr int NI = BM / 64, NJ = BN / 64;           // 32x32 MFMA tiles of a wave: BM/2 rows x BN/2 columns
-    constexpr int NAI = BM / 64;                        // weight DMA instructions per wave and stage (16 rows each)
-    constexpr int NBI = BN / 64;                        // activation DMA instructions per wave and stage (16 positions each)
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    // NW waves as 2 (rows) x NW/2 (columns).  NW = 8: two waves per SIMD, 128 accumulator registers each — while one issues its DMA
+    // pieces / fragment reads (~60 cycles per piece even between MFMAs) the other keeps the matrix pipe busy
+    constexpr int WNW = NW / 2, NT = NW * 64;
+    constexpr int NI = BM / 64, NJ = BN / (32 * WNW);   // 32x32 MFMA tiles of a wave: BM/2 rows x BN/WNW columns
+    constexpr int NAI = BM / (16 * NW);                 // weight DMA instructions per wave and stage (16 rows each)
+    constexpr int NBI = BN / (16 * NW);                 // activation DMA instructions per wave and stage (16 positions each)
+    static_assert(NAI >= 1 && NBI >= 1 && NJ >= 1, "tile too small for the wave count");
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w / WNW, wn = w % WNW;
     const int ntm = (g.Cout + BM - 1) / BM;
     const int nsteps = g.nsteps, T = g.T;
 
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_bf16_kernel(const void* __re
     // fragment addresses: row (lane & 31) of a 32-row MFMA tile, logical chunk kk*2 + (lane >> 5), swizzled by the row
     const int frow = lane & 31, fsw = (lane >> 2) & 3, fh = lane >> 5;
     const int fo0 = frow * NB_ROW + ((0 + fh) ^ fsw) * 16, fo1 = frow * NB_ROW + ((2 + fh) ^ fsw) * 16;
-    const int fbaseA = wm * ((BM / 2) * NB_ROW), fbaseB = A_BYTES + wn * ((BN / 2) * NB_ROW);
+    const int fbaseA = wm * ((BM / 2) * NB_ROW), fbaseB = A_BYTES + wn * ((BN / WNW) * NB_ROW);
 
     int u0 = SK ? (int)blockIdx.x * units_per_wg : (int)blockIdx.x * nsteps;
     const int u1 = SK ? min(u0 + units_per_wg, g.ntiles * nsteps) : u0 + nsteps;
@@ -169,12 +173,12 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_bf16_kernel(const void* __re
         unsigned voffA[NAI], voffB[NBI];
 #pragma unroll
         for (int i = 0; i < NAI; ++i) {
-            const int row = min(m0 + w * (BM / 4) + i * 16 + (lane >> 2), g.Cout - 1);
+            const int row = min(m0 + w * (BM / NW) + i * 16 + (lane >> 2), g.Cout - 1);
             voffA[i] = (unsigned)row * NB_ROW + chunk * 16;
         }
 #pragma unroll
         for (int i = 0; i < NBI; ++i) {
-            const int n = min(n0 + w * (BN / 4) + i * 16 + (lane >> 2), g.Ntot - 1);
+            const int n = min(n0 + w * (BN / NW) + i * 16 + (lane >> 2), g.Ntot - 1);
             const int b = n / g.OHW, rem = n - b * g.OHW, oy = rem / g.OW, ox = rem - oy * g.OW;
             voffB[i] = (unsigned)(((b * g.Hp + oy * g.stride) * g.Wp + ox * g.stride) * g.Cp) * 2u + chunk * 16;
         }
@@ -185,10 +189,10 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_bf16_kernel(const void* __re
             unsigned char* st = nb_smem + buf * ST_BYTES;
 #pragma unroll
             for (int i = 0; i < NAI; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (nb_lds_ptr)(st + w * (BM * 16) + i * 1024), 16, (int)voffA[i], (int)sA, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (nb_lds_ptr)(st + w * (NAI * 1024) + i * 1024), 16, (int)voffA[i], (int)sA, 0, 0);
 #pragma unroll
             for (int i = 0; i < NBI; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (nb_lds_ptr)(st + A_BYTES + w * (BN * 16) + i * 1024), 16, (int)voffB[i],
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (nb_lds_ptr)(st + A_BYTES + w * (NBI * 1024) + i * 1024), 16, (int)voffB[i],
                                                          (int)sB, 0, 0);
         };
 
@@ -281,10 +285,10 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_bf16_kernel(const void* __re
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    float* p = slot + (i * NJ + j) * (16 * 256);
+                    float* p = slot + (i * NJ + j) * (16 * NT);
                     asm volatile("" : "+v"(p));          // addresses made here, not 256 loop-invariant pointers spilled to scratch
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) p[r * 256] = acc[i][j][r];
+                    for (int r = 0; r < 16; ++r) p[r * NT] = acc[i][j][r];
                 }
             __threadfence();
             __syncthreads();
@@ -304,10 +308,10 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_bf16_kernel(const void* __re
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         float pv[16];               // 16 loads in flight, then their adds: not 256 (the register file is full of accumulators)
-                        const float* p = slot + (i * NJ + j) * (16 * 256);
+                        const float* p = slot + (i * NJ + j) * (16 * NT);
                         asm volatile("" : "+v"(p));
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) pv[r] = __builtin_nontemporal_load(p + r * 256);
+                        for (int r = 0; r < 16; ++r) pv[r] = __builtin_nontemporal_load(p + r * NT);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[i][j][r] += pv[r];
                         asm volatile("" ::: "memory");
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_bf16_kernel(const void* __re
                 for (int r = 0; r < 16; ++r) bv[r] = buf_load1(rbias, (unsigned)(corow + i * 32 + (r & 3) + 8 * (r >> 2)) * 4u);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+                    const int n = n0 + wn * (BN / WNW) + j * 32 + (lane & 31);
                     if (n >= g.Ntot) continue;
                     const int b = n / g.OHW, rem = n - b * g.OHW;
                     float* yp = y + (size_t)b * g.Cout * g.OHW + rem;
@@ -593,23 +597,26 @@ extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, cons
     int* flags = static_cast<int*>(workspace);
     float* slots = workspace ? reinterpret_cast<float*>(static_cast<char*>(workspace) + kNhwcFlagBytes) : nullptr;
     const int units = sk ? (int)((tiles * g.nsteps + cus - 1) / cus) : g.nsteps;
-#define COCOS_NHWC_GO(BMv, BNv, SKv)                                                                                     \
+#define COCOS_NHWC_GO(BMv, BNv, SKv) COCOS_NHWC_GO_W(BMv, BNv, SKv, 4)
+#define COCOS_NHWC_GO_W(BMv, BNv, SKv, NWv)                                                                              \
     do {                                                                                                                 \
-        auto kern = conv_nhwc_bf16_kernel<BMv, BNv, SKv>;                                                                \
+        auto kern = conv_nhwc_bf16_kernel<BMv, BNv, SKv, NWv>;                                                           \
         const size_t smem = (size_t)NB_STAGES * (BMv + BNv) * NB_ROW;                                                    \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                             (int)smem));                                                                \
-        hipLaunchKernelGGL(kern, dim3((unsigned)(SKv ? cus : tiles)), dim3(256), smem, s, xp, w_planes, bias, y, slots, flags, g, \
-                           units);                                                                                      \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(SKv ? cus : tiles)), dim3(NWv * 64), smem, s, xp, w_planes, bias, y, slots, flags, \
+                           g, units);                                                                                   \
     } while (0)
     if (bm == 128) {
         if (bn == 256) COCOS_NHWC_GO(128, 256, false); else COCOS_NHWC_GO(128, 128, false);
     } else if (bn == 256) {
-        if (sk) COCOS_NHWC_GO(256, 256, true); else COCOS_NHWC_GO(256, 256, false);
+        static const bool w8 = [] { const char* e = getenv("COCOS_CONV_NHWC_WAVES"); return !(e && e[0] == '4'); }();
+        if (sk) COCOS_NHWC_GO(256, 256, true); else if (w8) COCOS_NHWC_GO_W(256, 256, false, 8); else COCOS_NHWC_GO(256, 256, false);
     } else {
         COCOS_NHWC_GO(256, 128, false);
     }
 #undef COCOS_NHWC_GO
+#undef COCOS_NHWC_GO_W
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
