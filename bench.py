@@ -46,6 +46,13 @@ SEM_NC = 151
 KDIM = 256
 
 
+def _conv_flavour():
+    """How the module scope's nn.Conv2d layers run (COCOS_CONV): 'f16x3' fp32-accurate split (default, parity-safe upstream of
+    the softmax at T = 0.01), 'bf16' one term (K16b, the precision of the reference's --amp), 'torch' the framework's MIOpen."""
+    from cocosnet_amd import producers
+    return producers.CONV_BACKEND
+
+
 def build_inputs(device, scope):
     g = torch.Generator(device=device).manual_seed(1234 + (torch.distributed.get_rank()
                                                            if torch.distributed.is_initialized() else 0))
@@ -524,7 +531,8 @@ def main():
                                    f"precision={headline_precision}; scope={args.scope}: "
                                    + ("theta/phi 1x1 conv + centre/L2norm + fused corr-softmax-warp fwd+bwd"
                                       if args.scope == "hotpath" else
-                                      "whole NoVGGCorrespondence module fwd+bwd (convolutions K16, norms K9/K13/K17, theta/phi K0)"),
+                                      "whole NoVGGCorrespondence module fwd+bwd (convolutions K16, norms K9/K13/K17, theta/phi K0); "
+                                      f"convolutions={_conv_flavour()}"),
                        "untimed_steps_before_window": SETUP_STEPS + args.warmup,
                        "context": context,
                        "global_batch": BATCH_PER_GPU * world, "parallelism": f"dp{world}",
