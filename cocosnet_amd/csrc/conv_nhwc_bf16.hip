@@ -12,12 +12,12 @@
 //   GEMM   Y[co][n] = bias[co] + sum_k Wt[co][k] Xp[n][k],  k = ((ci/32) T + tap) 32 + ci%32 (the k order of K16: one k-block =
 //          32 consecutive channels at one tap = 64 contiguous bytes of xp per position, 64 contiguous bytes of the weight
 //          planes [K/32][Cout][32] per row).  Both tiles go HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`,
-//          16 bytes per lane, no registers, no LDS write instructions), three stages deep, ONE raw s_barrier per k-step
-//          and counted vmcnt waits (the CDNA guide's "3-buffer span" recipe).  An LDS-DMA writes lane-linear (wave base +
+//          16 bytes per lane, no registers, no LDS write instructions), four stages deep, ONE raw s_barrier per k-step
+//          and counted vmcnt waits (the CDNA guide's "3-buffer span" recipe); DMA pieces placed between the MFMAs.  An LDS-DMA writes lane-linear (wave base +
 //          lane x 16), so the bank swizzle of the 64-byte rows is applied to the SOURCE chunk each lane fetches:
 //          physical chunk = logical chunk ^ ((row >> 2) & 3), conflict-free `ds_read_b128` fragments.
-//          Tile 256 (Cout) x 256 | 128 (positions) x 32, 4 waves as 2 x 2, wave tile 128 x 128 | 64: all 256 accumulator
-//          registers, 0.5 KB of LDS operand reads per MFMA.                     [conv_nhwc_bf16_kernel]
+//          Tile 256 | 128 (Cout) x 256 | 128 (positions) x 32; 256 x 256 with 8 waves as 2 x 4 (two per SIMD, wave tile 128 x 64),
+//          the others with 4 waves as 2 x 2.                                     [conv_nhwc_bf16_kernel]
 //   The input gradient of a stride-1 layer is the same GEMM on prep(dy, pad = d(K-1)-p, zeros) with the flipped,
 //   transposed weight planes (cocos_conv2d_weight_planes mode 1|2).
 //   The weight gradient contracts over positions, which are the STRIDED index of both NHWC operands: its fragments come out
@@ -25,7 +25,11 @@
 //
 // Reference lines served: every stride-1 nn.Conv2d of the feature producers — ResidualBlock correspondence.py:13-36,
 // adaptor layers :150-173, SPADE mlp convolutions normalization.py:118-127 — under `COCOS_CONV=bf16` (the precision of the
-// reference's --amp run).  Strided layers and layers with fewer than 192 output channels stay on conv_f16x3.hip's kernels.
+// reference's --amp run).  Layers with fewer than 128 output or 32 input channels, the input gradient of strided layers and weight
+// gradients whose output rows are not whole k-steps of 32 positions stay on conv_f16x3.hip's kernels.
+// Measured and dropped: the bias gradient taken inside the prep pass over dy (wave reductions + per-workgroup partials: the prep
+// kernels of a module step +1.5 ms for 1.1 ms of cocos_channel_sum saved; with atomics instead — every CU on the same 13 cache
+// lines — 3 -> 26 ms).
 #include "common.h"
 
 namespace cocos {
