@@ -221,9 +221,11 @@ PAYLOAD_PARAMS = {"path": 0, "netcorr": 59_000_000, "full": 156_000_000}
 PMC_FILE = {"f16x3": "r03_pmc_f16x3.json" if os.path.exists(os.path.join(REPO, "profiles", "r03_pmc_f16x3.json"))
             else "r02_pmc_f16x3.json", "fp32": "r01_pmc_final.json"}
 # (the counters were taken on the general instantiations <..., 0>; the one that skips exact value blocks moves 8 MB less)
-PMC_KEY = {"f16x3": {"corr_softmax_warp_fwd": "corr_fwd_f16x3_kernel<5, 1, 0, 0",
-                     "corr_softmax_warp_bwd_query": "corr_bwd_query_f16x3_kernel<5, 1, 0, 0, 0",
-                     "corr_softmax_warp_bwd_key_from_ds": "hgemm_f16x3_kernel"},
+# substrings of the PMC file's kernel names (the training flavours: template arguments after these differ between rounds — value-lo
+# skip, device scales — so the entry with the most dispatches among the matches is taken)
+PMC_KEY = {"f16x3": {"corr_softmax_warp_fwd": "corr_fwd_f16x3_kernel<5, 1,",
+                     "corr_softmax_warp_bwd_query": "corr_bwd_query_f16x3_kernel<5, 1,",
+                     "corr_softmax_warp_bwd_key_from_ds": "hgemm_f16x3_kernel<1, 2"},
            "fp32": {"corr_softmax_warp_fwd": "corr_softmax_warp_fwd_kernel<256, 5, true",
                     "corr_softmax_warp_bwd_query": "corr_bwd_query_saved_kernel<256, 5, true",
                     "corr_softmax_warp_bwd_key_from_ds": "sgemm_mfma_kernel<true, true>"}}
@@ -288,8 +290,10 @@ def roofline_of(kernels, precision):
     traffic, traffic_src = None, None
     pmc_file = os.path.join(REPO, "profiles", PMC_FILE[precision])
     if dom in PMC_KEY[precision] and os.path.exists(pmc_file):
+        best = -1
         for name, rec in json.load(open(pmc_file)).items():
-            if PMC_KEY[precision][dom] in name:
+            if PMC_KEY[precision][dom] in name and rec.get("dispatches", 0) > best:
+                best = rec.get("dispatches", 0)
                 traffic = rec["hbm_bytes"]
                 traffic_src = f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes)"
     # the same kernel's HBM coordinate (the second roofline north_star names): PMC bytes per launch / measured time

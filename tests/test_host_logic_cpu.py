@@ -126,7 +126,7 @@ def test_bench_roofline_and_kernel_table_contract():
     roof = bench.roofline_of(tab, "f16x3")
     assert roof["kernel"] == "corr_softmax_warp_bwd_query" and roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s"
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["frac_issued"] <= roof["frac"] + 1e-6
-    assert roof["traffic"] is None or roof["traffic"] > 1e8          # bytes per launch from profiles/r02_pmc_f16x3.json
+    assert roof["traffic"] is not None and roof["traffic"] > 1e8          # bytes per launch from the committed PMC file (profiles/r03_pmc_f16x3.json)
     if roof["traffic"]:                                              # the HBM coordinate of the same kernel
         assert roof["hbm"]["unit"] == "GB/s" and roof["hbm"]["peak"] == bench.HBM_PEAK_GBS
         assert abs(roof["hbm"]["achieved"] - roof["traffic"] / 0.35e-3 / 1e9) < 1.0
