@@ -18,8 +18,9 @@ carries, measured in the same process after the headline window: the exact-fp32-
 >= 300-step stability window (`stability`), and the CPU baseline (the reference's torch op sequence on all host cores,
 plus the numpy port).  `--grad-payload` sizes the gradient exchange of N > 1 runs like BASELINE config 4 (netCorr's
 59 M or the full G+Corr 156 M fp32 parameters) — the hot path alone exchanges only theta/phi's 0.8 MB.
-`--scope netcorr` times the whole drop-in NoVGGCorrespondence module (feature producers on stock
-PyTorch-ROCm) instead; it is reported for context in DESIGN.md and is not the headline line.
+`--scope netcorr` times the whole drop-in NoVGGCorrespondence module instead (feature producers on the K16 / K16b
+convolutions, K9 / K13 / K17 norms; `COCOS_CONV=f16x3|bf16|torch` picks the convolution flavour, named in
+config.workload); it is reported for context in DESIGN.md and is not the headline line.
 """
 from __future__ import annotations
 
