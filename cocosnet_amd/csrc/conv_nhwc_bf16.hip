@@ -39,6 +39,7 @@ typedef __bf16 nb_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float nb_f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* nb_lds_ptr;
 typedef short s16x4_nb __attribute__((ext_vector_type(4)));
+typedef _Float16 nb_f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int NB_BM = 256, NB_BK = 32, NB_STAGES = 4;     // 4 stages: a tile is requested 3 k-steps (~1.4 us) before it is read
 constexpr int NB_ROW = NB_BK * 2;                       // bytes per LDS row (one position / one weight row, 32 k)
@@ -77,9 +78,23 @@ __device__ __forceinline__ int nb_reflect(int i, int n) {                  // to
 // of the chunk for its lane's position (each load 256 bytes coalesced across the wave), the packed pairs cross through LDS
 // ([position][64 channels], 144-byte rows: conflict-free 16-byte writes), and go out as 128 contiguous bytes per position.
 // ---------------------------------------------------------------------------------------------------------------------
+// SPLIT (K16c, the fp32-accurate flavour): x * s as f16 hi (round toward zero) + f16 lo, s the power of two from *amax
+// (cv's convention: |x s| < 2^10); two planes, the lo plane `plane_bytes` behind the hi plane.
+__device__ __forceinline__ float nb_scale_from_amax(const float* amax) {
+    if (!amax) return 1.0f;
+    const float a = *amax;
+    if (!(a > 0.f) || !(a < INFINITY)) return 1.0f;
+    int e;
+    frexpf(a, &e);
+    return ldexpf(1.0f, 10 - e);
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void conv_nhwc_prep_kernel(const float* __restrict__ x, unsigned char* __restrict__ xp, int B, int C,
-                                                             int H, int W, int Hp, int Wp, int Cp, int pad, int reflect) {
-    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * 144];
+                                                             int H, int W, int Hp, int Wp, int Cp, int pad, int reflect,
+                                                             const float* __restrict__ amax, size_t plane_bytes) {
+    __shared__ __attribute__((aligned(16))) unsigned char tile[(SPLIT ? 2 : 1) * 64 * 144];
+    const float sc = SPLIT ? nb_scale_from_amax(amax) : 1.0f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int npos = Hp * Wp, chunks = (npos + 63) >> 6;
     const int b = blockIdx.x / chunks, q0 = (blockIdx.x - b * chunks) * 64;
@@ -104,19 +119,38 @@ __global__ __launch_bounds__(256) void conv_nhwc_prep_kernel(const float* __rest
             const int c = c0 + wave * 16 + i;
             v[i] = (inside && c < C) ? src[(size_t)c * plane] : 0.f;
         }
-        u32x4 o0 = {nb_pack_bf16(v[0], v[1]), nb_pack_bf16(v[2], v[3]), nb_pack_bf16(v[4], v[5]), nb_pack_bf16(v[6], v[7])};
-        u32x4 o1 = {nb_pack_bf16(v[8], v[9]), nb_pack_bf16(v[10], v[11]), nb_pack_bf16(v[12], v[13]), nb_pack_bf16(v[14], v[15])};
+        u32x4 o0, o1, l0, l1;
+        if (SPLIT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned h, l;
+                split_pair_rtz(v[2 * i] * sc, v[2 * i + 1] * sc, h, l);
+                o0[i] = h; l0[i] = l;
+                split_pair_rtz(v[8 + 2 * i] * sc, v[9 + 2 * i] * sc, h, l);
+                o1[i] = h; l1[i] = l;
+            }
+        } else {
+            o0 = u32x4{nb_pack_bf16(v[0], v[1]), nb_pack_bf16(v[2], v[3]), nb_pack_bf16(v[4], v[5]), nb_pack_bf16(v[6], v[7])};
+            o1 = u32x4{nb_pack_bf16(v[8], v[9]), nb_pack_bf16(v[10], v[11]), nb_pack_bf16(v[12], v[13]), nb_pack_bf16(v[14], v[15])};
+        }
         if (c0) __syncthreads();                           // the previous chunk has been read out
         *reinterpret_cast<u32x4*>(tile + lane * 144 + wave * 32) = o0;
         *reinterpret_cast<u32x4*>(tile + lane * 144 + wave * 32 + 16) = o1;
+        if (SPLIT) {
+            *reinterpret_cast<u32x4*>(tile + 64 * 144 + lane * 144 + wave * 32) = l0;
+            *reinterpret_cast<u32x4*>(tile + 64 * 144 + lane * 144 + wave * 32 + 16) = l1;
+        }
         __syncthreads();
         if (c0 + so * 8 < Cp) {
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
                 const int pl = sp + 32 * pass;
-                if (q0 + pl < npos)
-                    *reinterpret_cast<u32x4*>(xp + (((size_t)b * npos + q0 + pl) * Cp + c0 + so * 8) * 2) =
-                        *reinterpret_cast<const u32x4*>(tile + pl * 144 + so * 16);
+                if (q0 + pl < npos) {
+                    unsigned char* dst = xp + (((size_t)b * npos + q0 + pl) * Cp + c0 + so * 8) * 2;
+                    *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(tile + pl * 144 + so * 16);
+                    if (SPLIT)
+                        *reinterpret_cast<u32x4*>(dst + plane_bytes) = *reinterpret_cast<const u32x4*>(tile + 64 * 144 + pl * 144 + so * 16);
+                }
             }
         }
     }
@@ -139,13 +173,25 @@ __global__ __launch_bounds__(256) void conv_nhwc_prep_kernel(const float* __rest
 // (k-steps 0..) is the LAST thing workgroup w does, its tail the FIRST thing workgroup w+1 does.  The early finisher
 // parks its partial tile in a workspace slot and raises a flag; the late one adds the parked tile to its own and stores.
 // No atomics on the output (same-address-class fp32 atomics ran at ~140 G/s in the K2 experiments: 0.1 ms for this tensor).
-template <int BM, int BN, bool SK, int NW = 4>
+// TERMS = 3 (K16c): every operand is TWO f16 planes (hi, lo), every product three MFMAs (hi hi + hi lo + lo hi) — the arithmetic of
+// conv_f16x3.hip on this kernel's data path; a stage holds four tiles (two stages of 64 KB at 256 x 256), the result is scaled
+// back by 1 / (s_x s_w) in the epilogue.  The stage count follows: TERMS = 1 four stages, TERMS = 3 two.
+struct NhwcSplit {
+    const void* w_lo;            // lo plane of the weights (same layout as the hi plane)
+    unsigned xp_plane_bytes;     // the activations' lo plane lies this far behind their hi plane
+    const float* x_amax;         // device cells: max|x| the activation planes were scaled by, the weight planes' scale
+    const float* w_scale;
+};
+
+template <int BM, int BN, bool SK, int NW = 4, int TERMS = 1>
 __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* __restrict__ xp, const void* __restrict__ wpl,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 float* __restrict__ ws, int* __restrict__ flags, const NhwcGeom g,
-                                                                const int units_per_wg) {
+                                                                const int units_per_wg, const NhwcSplit sp) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char nb_smem[];
-    constexpr int A_BYTES = BM * NB_ROW, B_BYTES = BN * NB_ROW, ST_BYTES = A_BYTES + B_BYTES;
+    constexpr int NP = TERMS == 3 ? 2 : 1, NST = TERMS == 3 ? 2 : NB_STAGES;
+    constexpr int A_PLANE = BM * NB_ROW, B_PLANE = BN * NB_ROW;
+    constexpr int A_BYTES = NP * A_PLANE, B_BYTES = NP * B_PLANE, ST_BYTES = A_BYTES + B_BYTES;
     // NW waves as 2 (rows) x NW/2 (columns).  NW = 8: two waves per SIMD, 128 accumulator registers each — while one issues its DMA
     // pieces / fragment reads (~60 cycles per piece even between MFMAs) the other keeps the matrix pipe busy
     constexpr int WNW = NW / 2, NT = NW * 64;
@@ -157,7 +203,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
     const int ntm = (g.Cout + BM - 1) / BM;
     const int nsteps = g.nsteps, T = g.T;
 
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(wpl, g.w_bytes), rB = make_rsrc(xp, g.xp_bytes);
+    // (no arrays of __amdgpu_buffer_rsrc_t: hipcc then silently drops the kernel's HOST stub — the library fails to load)
+    const __amdgpu_buffer_rsrc_t rA0 = make_rsrc(wpl, g.w_bytes), rB0 = make_rsrc(xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rA1 = make_rsrc(NP == 2 ? sp.w_lo : wpl, g.w_bytes);
+    const __amdgpu_buffer_rsrc_t rB1 = make_rsrc(static_cast<const unsigned char*>(xp) + (NP == 2 ? sp.xp_plane_bytes : 0u), g.xp_bytes);
     const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias, bias ? (size_t)g.Cout * 4 : 0);      // no bias: every read returns 0
     const int chunk = (lane & 3) ^ ((lane >> 4) & 3);   // the 16-byte piece of its row this lane fetches (source-side swizzle)
     const unsigned stepA = (unsigned)g.Cout * NB_ROW;
@@ -194,12 +243,16 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
             const unsigned sB = (unsigned)(((ky * g.Wp + kx) * g.dil) * g.Cp + cb * 32) * 2u;
             unsigned char* st = nb_smem + buf * ST_BYTES;
 #pragma unroll
-            for (int i = 0; i < NAI; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (nb_lds_ptr)(st + w * (NAI * 1024) + i * 1024), 16, (int)voffA[i], (int)sA, 0, 0);
+            for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int i = 0; i < NBI; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (nb_lds_ptr)(st + A_BYTES + w * (NBI * 1024) + i * 1024), 16, (int)voffB[i],
-                                                         (int)sB, 0, 0);
+                for (int i = 0; i < NAI; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(p ? rA1 : rA0, (nb_lds_ptr)(st + p * A_PLANE + w * (NAI * 1024) + i * 1024), 16,
+                                                             (int)voffA[i], (int)sA, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NBI; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(p ? rB1 : rB0, (nb_lds_ptr)(st + A_BYTES + p * B_PLANE + w * (NBI * 1024) + i * 1024),
+                                                             16, (int)voffB[i], (int)sB, 0, 0);
+            }
         };
 
         f32x16 acc[NI][NJ];
@@ -210,31 +263,44 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        nb_bf16x8 fa[2][NI], fb[2][NJ];
+        u32x4 fa[2][NP][NI], fb[2][NP][NJ];
         auto frags = [&](int buf, int kk) {
             const unsigned char* st = nb_smem + buf * ST_BYTES + (kk ? fo1 : fo0);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) fa[kk][i] = *reinterpret_cast<const nb_bf16x8*>(st + fbaseA + i * (32 * NB_ROW));
+            for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) fb[kk][j] = *reinterpret_cast<const nb_bf16x8*>(st + fbaseB + j * (32 * NB_ROW));
+                for (int i = 0; i < NI; ++i) fa[kk][p][i] = *reinterpret_cast<const u32x4*>(st + p * A_PLANE + fbaseA + i * (32 * NB_ROW));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[kk][p][j] = *reinterpret_cast<const u32x4*>(st + p * B_PLANE + fbaseB + j * (32 * NB_ROW));
+            }
         };
         auto mfmas = [&](int kk) {
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (TERMS == 1) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nb_bf16x8, fa[kk][0][i]),
+                                                                            __builtin_bit_cast(nb_bf16x8, fb[kk][0][j]), acc[i][j], 0, 0, 0);
+                    } else {
+                        const nb_f16x8 ah = __builtin_bit_cast(nb_f16x8, fa[kk][0][i]), al = __builtin_bit_cast(nb_f16x8, fa[kk][NP - 1][i]);
+                        const nb_f16x8 bh = __builtin_bit_cast(nb_f16x8, fb[kk][0][j]), bl = __builtin_bit_cast(nb_f16x8, fb[kk][NP - 1][j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);
+                    }
+                }
         };
 
         // prologue: the first NB_STAGES k-steps in flight; the first landed and visible
         int it = s0, icb = s0 / T, itap = s0 - icb * T;      // the next k-step to issue
         const int nseg = s1 - s0;
 #pragma unroll 1
-        for (int u = 0; u < NB_STAGES && it < s1; ++u, ++it) {
+        for (int u = 0; u < NST && it < s1; ++u, ++it) {
             issue(icb, itap, it, u);
             if (++itap == T) { itap = 0; ++icb; }
         }
-        NB_WAIT_BARRIER(it - s0 - 1, NAI + NBI, "");          // all but the first of the issued stages may still be in flight
+        NB_WAIT_BARRIER(it - s0 - 1, NP * (NAI + NBI), "");   // all but the first of the issued stages may still be in flight
         frags(0, 0);
 
         int buf = 0, t = s0;
@@ -242,16 +308,16 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
         // MFMAs of the second half — issued as a block after the barrier they cost 100-185 cycles each with the matrix pipe idle
         // (MI355X guide, "LDS-DMA piece issue cost"): that, not latency, was 1000 of a step's 2100 cycles
 #pragma unroll 1
-        for (; t + NB_STAGES < s1; ++t) {
+        for (; t + NST < s1; ++t) {
             frags(buf, 1);
             mfmas(0);
 #pragma unroll
             for (int q = 0; q < (NI * NJ) / 2; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                if (q < NI + NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TERMS, 0);
+                if (q < NI + NJ) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
             }
-            const int nbuf = buf == NB_STAGES - 1 ? 0 : buf + 1;
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NB_STAGES - 2) * (NAI + NBI)) : "memory");
+            const int nbuf = buf == NST - 1 ? 0 : buf + 1;
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NST - 2) * NP * (NAI + NBI)) : "memory");
             issue(icb, itap, it, buf);
             ++it;
             if (++itap == T) { itap = 0; ++icb; }
@@ -259,9 +325,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
             mfmas(1);
 #pragma unroll
             for (int q = 0; q < (NI * NJ) / 2; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                if (q < NAI + NBI) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                if (q < NI + NJ) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * TERMS, 0);
+                if (q < NAI + NBI) __builtin_amdgcn_sched_group_barrier(0x010, NP, 0);
+                if (q < NI + NJ) __builtin_amdgcn_sched_group_barrier(0x100, NP, 0);
             }
             buf = nbuf;
         }
@@ -269,9 +335,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
         for (; t < s1; ++t) {
             frags(buf, 1);
             mfmas(0);
-            const int nbuf = buf == NB_STAGES - 1 ? 0 : buf + 1;
+            const int nbuf = buf == NST - 1 ? 0 : buf + 1;
             if (t + 1 < s1) {
-                NB_WAIT_BARRIER(it - (t + 2), NAI + NBI, " lgkmcnt(0)");     // stage t+1 landed; the stages issued beyond it stay in flight
+                NB_WAIT_BARRIER(it - (t + 2), NP * (NAI + NBI), " lgkmcnt(0)");     // stage t+1 landed; the stages issued beyond it stay in flight
                 if (it < s1) {
                     issue(icb, itap, it, buf);
                     ++it;
@@ -326,6 +392,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
                 if (tid == 0) __hip_atomic_store(flags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
             }
             const int corow = m0 + wm * (BM / 2) + 4 * (lane >> 5);
+            const float oscale = TERMS == 3 ? 1.0f / (nb_scale_from_amax(sp.x_amax) * (sp.w_scale ? *sp.w_scale : 1.0f)) : 1.0f;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 float bv[16];
@@ -340,7 +407,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int co = corow + i * 32 + (r & 3) + 8 * (r >> 2);
-                        if (co < g.Cout) yp[(size_t)co * g.OHW] = acc[i][j][r] + bv[r];
+                        if (co < g.Cout) yp[(size_t)co * g.OHW] = acc[i][j][r] * oscale + bv[r];
                     }
                 }
             }
@@ -360,6 +427,12 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
 // instruction fills 8 such blocks (4 positions x 128 channels): per position its 16 lanes fetch 256 contiguous bytes.
 // Requires OW % 32 == 0 (a k-step of 32 positions lies in one output row: its address is a scalar base + lane constants).
 // dyp = dy as bf16 NHWC [B][OH + 2q][OW + 2q][Cop] (the input-gradient GEMM's operand, border q, or q = 0).
+struct NhwcWgradSplit {
+    unsigned xp_plane_bytes, dy_plane_bytes;     // lo planes behind the hi planes
+    const float* x_amax;                         // device cells the two operands were scaled by
+    const float* g_amax;
+};
+
 struct NhwcWgradGeom {
     int B, Cp, Hp, Wp;          // xp (the forward's operand)
     int Cop, Hq, Wq, q;         // dyp
@@ -370,10 +443,14 @@ struct NhwcWgradGeom {
     unsigned xp_bytes, dy_bytes;
 };
 
+template <int TERMS>
 __global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void* __restrict__ xp, const void* __restrict__ dyp,
-                                                                      float* __restrict__ partial, const NhwcWgradGeom g) {
+                                                                      float* __restrict__ partial, const NhwcWgradGeom g,
+                                                                      const NhwcWgradSplit sp) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char nb_smem[];
-    constexpr int A_BYTES = 256 * NB_ROW, ST_BYTES = 2 * A_BYTES;       // 32 positions x 256 columns, both operands
+    constexpr int NP = TERMS == 3 ? 2 : 1, NST = TERMS == 3 ? 2 : NB_STAGES;
+    constexpr int PLANE = 256 * NB_ROW;                                  // 32 positions x 256 columns of one plane
+    constexpr int A_BYTES = NP * PLANE, ST_BYTES = 2 * A_BYTES;          // both operands
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
     const int ntm = (g.Cout + 255) / 256, ntn = (g.nkb * 32 + 255) / 256;
     // slice-major virtual ids, consecutive ids on one XCD: the workgroups that read one position slice share an L2 (PMC before:
@@ -383,7 +460,9 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void
     const int m0 = mt * 256, k0 = ntile * 256;
     const int t_begin = slice * g.steps_per_slice, nsteps = min(g.steps_per_slice, g.steps_total - t_begin);
 
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(dyp, g.dy_bytes), rB = make_rsrc(xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rA0 = make_rsrc(dyp, g.dy_bytes), rB0 = make_rsrc(xp, g.xp_bytes);
+    const __amdgpu_buffer_rsrc_t rA1 = make_rsrc(static_cast<const unsigned char*>(dyp) + (NP == 2 ? sp.dy_plane_bytes : 0u), g.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rB1 = make_rsrc(static_cast<const unsigned char*>(xp) + (NP == 2 ? sp.xp_plane_bytes : 0u), g.xp_bytes);
     // DMA instruction id = w*4 + i: positions 4 (id >> 1) + ((lane >> 1) & 3), columns ((id & 1) * 8 + (lane >> 3)) * 16 + (lane & 1) * 8 .. +7
     unsigned voffA[4], voffB[4];
 #pragma unroll
@@ -408,11 +487,16 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void
         const unsigned sB = (unsigned)(((ib * g.Hp + ioy * g.stride) * g.Wp + iox * g.stride) * g.Cp) * 2u;
         unsigned char* st = nb_smem + buf * ST_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (nb_lds_ptr)(st + (w * 4 + i) * 1024), 16, (int)voffA[i], (int)sA, 0, 0);
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (nb_lds_ptr)(st + A_BYTES + (w * 4 + i) * 1024), 16, (int)voffB[i], (int)sB, 0, 0);
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(p ? rA1 : rA0, (nb_lds_ptr)(st + p * PLANE + (w * 4 + i) * 1024), 16, (int)voffA[i], (int)sA,
+                                                         0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(p ? rB1 : rB0, (nb_lds_ptr)(st + A_BYTES + p * PLANE + (w * 4 + i) * 1024), 16, (int)voffB[i],
+                                                         (int)sB, 0, 0);
+        }
         ++it;
         iox += 32;
         if (iox >= g.OW) { iox = 0; if (++ioy == g.OH) { ioy = 0; ++ib; } }
@@ -431,58 +515,66 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void
     const int tr_off = (kg * 32 + nb) * 128 + (li >> 2) * 32 + (li & 3) * 8;
     const int fbaseA = wm * (8 * 128) + tr_off, fbaseB = A_BYTES + wn * (8 * 128) + tr_off;     // 128 columns = 8 blocks of 16
 
-    nb_bf16x8 fa[2][4], fb[2][4];
+    u32x4 fa[2][NP][4], fb[2][NP][4];
+    auto tr8 = [&](const unsigned char* p) {
+        const s16x4_nb v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_nb __attribute__((address_space(3)))*)(p));
+        const s16x4_nb v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_nb __attribute__((address_space(3)))*)(p + 2048));
+        return __builtin_bit_cast(u32x4, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
     auto frags = [&](int buf, int kk) {
         const unsigned char* st = nb_smem + buf * ST_BYTES + kk * 8192;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned char* p = st + fbaseA + i * 256;
-            const s16x4_nb v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_nb __attribute__((address_space(3)))*)(p));
-            const s16x4_nb v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_nb __attribute__((address_space(3)))*)(p + 2048));
-            fa[kk][i] = __builtin_bit_cast(nb_bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
+        for (int p = 0; p < NP; ++p) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned char* p = st + fbaseB + j * 256;
-            const s16x4_nb v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_nb __attribute__((address_space(3)))*)(p));
-            const s16x4_nb v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_nb __attribute__((address_space(3)))*)(p + 2048));
-            fb[kk][j] = __builtin_bit_cast(nb_bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+            for (int i = 0; i < 4; ++i) fa[kk][p][i] = tr8(st + p * PLANE + fbaseA + i * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[kk][p][j] = tr8(st + p * PLANE + fbaseB + j * 256);
         }
     };
     auto mfmas = [&](int kk) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (TERMS == 1) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nb_bf16x8, fa[kk][0][i]),
+                                                                        __builtin_bit_cast(nb_bf16x8, fb[kk][0][j]), acc[i][j], 0, 0, 0);
+                } else {
+                    const nb_f16x8 ah = __builtin_bit_cast(nb_f16x8, fa[kk][0][i]), al = __builtin_bit_cast(nb_f16x8, fa[kk][NP - 1][i]);
+                    const nb_f16x8 bh = __builtin_bit_cast(nb_f16x8, fb[kk][0][j]), bl = __builtin_bit_cast(nb_f16x8, fb[kk][NP - 1][j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);
+                }
+            }
     };
 
 #pragma unroll 1
-    for (int u = 0; u < NB_STAGES && u < nsteps; ++u) issue(u);
-    NB_WAIT_BARRIER(it - 1, 8, "");
+    for (int u = 0; u < NST && u < nsteps; ++u) issue(u);
+    NB_WAIT_BARRIER(it - 1, 8 * NP, "");
     if (nsteps > 0) frags(0, 0);
 
     int buf = 0, t = 0;
     // steady state: DMA pieces and the next fragments between the MFMAs (see conv_nhwc_bf16_kernel)
 #pragma unroll 1
-    for (; t + NB_STAGES < nsteps; ++t) {
+    for (; t + NST < nsteps; ++t) {
         frags(buf, 1);
         mfmas(0);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TERMS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
         }
-        const int nbuf = buf == NB_STAGES - 1 ? 0 : buf + 1;
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NB_STAGES - 2) * 8) : "memory");
+        const int nbuf = buf == NST - 1 ? 0 : buf + 1;
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NST - 2) * 8 * NP) : "memory");
         issue(buf);
         frags(nbuf, 0);
         mfmas(1);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TERMS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, NP, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NP, 0);
         }
         buf = nbuf;
     }
@@ -490,9 +582,9 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void
     for (; t < nsteps; ++t) {
         frags(buf, 1);
         mfmas(0);
-        const int nbuf = buf == NB_STAGES - 1 ? 0 : buf + 1;
+        const int nbuf = buf == NST - 1 ? 0 : buf + 1;
         if (t + 1 < nsteps) {
-            NB_WAIT_BARRIER(it - (t + 2), 8, " lgkmcnt(0)");
+            NB_WAIT_BARRIER(it - (t + 2), 8 * NP, " lgkmcnt(0)");
             if (it < nsteps) issue(buf);
             frags(nbuf, 0);
         }
@@ -501,6 +593,7 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void
     }
 
     const int Ktot = g.nkb * 32;
+    const float oscale = TERMS == 3 ? 1.0f / (nb_scale_from_amax(sp.x_amax) * nb_scale_from_amax(sp.g_amax)) : 1.0f;
     float* out = partial + (size_t)slice * g.Cout * Ktot;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -511,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < g.Cout) out[(size_t)co * Ktot + k] = acc[i][j][r];
+                if (co < g.Cout) out[(size_t)co * Ktot + k] = acc[i][j][r] * oscale;
             }
         }
     }
@@ -519,21 +612,36 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void
 
 }  // namespace cocos
 
-extern "C" int cocos_conv2d_nhwc_prep_bf16(const float* x, void* xp, int B, int C, int H, int W, int pad, int reflect,
-                                           cocos_stream_t stream) {
+extern "C" int cocos_nhwc_prep_impl(const float* x, void* xp, const float* amax_dev, bool split, int B, int C, int H, int W, int pad,
+                          int reflect, cocos_stream_t stream, const char* who) {
     using namespace cocos;
-    COCOS_REQUIRE(x && xp, COCOS_ERR_INVALID, "conv2d_nhwc_prep_bf16: null pointer");
+    COCOS_REQUIRE(x && xp, COCOS_ERR_INVALID, "%s: null pointer", who);
     COCOS_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1 && pad >= 0 && (!reflect || (pad < H && pad < W)), COCOS_ERR_INVALID,
-                  "conv2d_nhwc_prep_bf16: bad arguments (B=%d C=%d H=%d W=%d pad=%d reflect=%d)", B, C, H, W, pad, reflect);
+                  "%s: bad arguments (B=%d C=%d H=%d W=%d pad=%d reflect=%d)", who, B, C, H, W, pad, reflect);
     const int Hp = H + 2 * pad, Wp = W + 2 * pad, Cp = (C + 31) / 32 * 32;
-    const long long total = (long long)B * Hp * Wp * Cp * 2;
-    COCOS_REQUIRE(total < 0x7fffffffLL && aligned16(xp), COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_prep_bf16: tensor too large / xp unaligned");
+    const long long plane = (long long)B * Hp * Wp * Cp * 2;
+    COCOS_REQUIRE(plane * (split ? 2 : 1) < 0x7fffffffLL && aligned16(xp), COCOS_ERR_UNSUPPORTED, "%s: tensor too large / xp unaligned", who);
     const long long blocks = (long long)B * (((long long)Hp * Wp + 63) / 64);
-    COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_prep_bf16: grid too large");
-    hipLaunchKernelGGL(conv_nhwc_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, static_cast<unsigned char*>(xp),
-                       B, C, H, W, Hp, Wp, Cp, pad, reflect ? 1 : 0);
+    COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "%s: grid too large", who);
+    if (split)
+        hipLaunchKernelGGL(conv_nhwc_prep_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x,
+                           static_cast<unsigned char*>(xp), B, C, H, W, Hp, Wp, Cp, pad, reflect ? 1 : 0, amax_dev, (size_t)plane);
+    else
+        hipLaunchKernelGGL(conv_nhwc_prep_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x,
+                           static_cast<unsigned char*>(xp), B, C, H, W, Hp, Wp, Cp, pad, reflect ? 1 : 0, nullptr, (size_t)0);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+extern "C" int cocos_conv2d_nhwc_prep_bf16(const float* x, void* xp, int B, int C, int H, int W, int pad, int reflect,
+                                           cocos_stream_t stream) {
+    return cocos_nhwc_prep_impl(x, xp, nullptr, false, B, C, H, W, pad, reflect, stream, "conv2d_nhwc_prep_bf16");
+}
+
+// K16c: xp = TWO f16 planes [2][B][Hp][Wp][Cp] (hi, lo) of x * 2^k, k from *amax_dev (max|x|, nullable = 1.0)
+extern "C" int cocos_conv2d_nhwc_prep_f16x3(const float* x, void* xp, const float* amax_dev, int B, int C, int H, int W, int pad,
+                                            int reflect, cocos_stream_t stream) {
+    return cocos_nhwc_prep_impl(x, xp, amax_dev, true, B, C, H, W, pad, reflect, stream, "conv2d_nhwc_prep_f16x3");
 }
 
 extern "C" int cocos_conv2d_nhwc_bf16_supported(int Cin, int Cout, int KH, int KW, int stride) {
@@ -565,28 +673,28 @@ extern "C" long long cocos_conv2d_nhwc_bf16_workspace_bytes(void) {
     return kNhwcFlagBytes + (long long)(cus < 1024 ? cus : 1024) * kNhwcSlotBytes;
 }
 
-// y fp32 [B][Cout][OH][OW] = bias + conv(xp), xp bf16 [B][Hp][Wp][Cp] already padded (cocos_conv2d_nhwc_prep_bf16),
-// OH = (Hp - dil (KH-1) - 1) / stride + 1, OW likewise; w_planes = cocos_conv2d_weight_planes(mode | 2): bf16 [KH*KW*Cp/32][Cout][32].
-// workspace (nullable): see cocos_conv2d_nhwc_bf16_workspace_bytes — without it every launch is one tile per workgroup.
-extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias, float* y, void* workspace,
-                                      long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil,
-                                      int stride, cocos_stream_t stream) {
+extern "C" int cocos_nhwc_gemm_impl(const void* xp, const void* w_hi, const void* w_lo, const float* w_scale_dev, const float* x_amax_dev,
+                          const float* bias, float* y, void* workspace, long long workspace_bytes, int B, int Cp, int Hp, int Wp,
+                          int Cout, int KH, int KW, int dil, int stride, cocos_stream_t stream, const char* who) {
     using namespace cocos;
-    COCOS_REQUIRE(xp && w_planes && y, COCOS_ERR_INVALID, "conv2d_nhwc_bf16: null pointer");
+    const bool split = w_lo != nullptr;
+    COCOS_REQUIRE(xp && w_hi && y, COCOS_ERR_INVALID, "%s: null pointer", who);
     COCOS_REQUIRE(B >= 1 && Cp >= 32 && Cp % 32 == 0 && Cout >= 1 && KH >= 1 && KW >= 1 && dil >= 1 && stride >= 1, COCOS_ERR_INVALID,
-                  "conv2d_nhwc_bf16: bad arguments (B=%d Cp=%d Cout=%d k=%dx%d dil=%d stride=%d)", B, Cp, Cout, KH, KW, dil, stride);
+                  "%s: bad arguments (B=%d Cp=%d Cout=%d k=%dx%d dil=%d stride=%d)", who, B, Cp, Cout, KH, KW, dil, stride);
     NhwcGeom g;
     g.B = B; g.Cp = Cp; g.Hp = Hp; g.Wp = Wp; g.stride = stride;
-    COCOS_REQUIRE(Hp > dil * (KH - 1) && Wp > dil * (KW - 1), COCOS_ERR_INVALID, "conv2d_nhwc_bf16: kernel larger than the padded input");
+    COCOS_REQUIRE(Hp > dil * (KH - 1) && Wp > dil * (KW - 1), COCOS_ERR_INVALID, "%s: kernel larger than the padded input", who);
     g.OH = (Hp - dil * (KH - 1) - 1) / stride + 1; g.OW = (Wp - dil * (KW - 1) - 1) / stride + 1;
     g.OHW = g.OH * g.OW;
     const long long ntot = (long long)B * g.OHW, xbytes = (long long)B * Hp * Wp * Cp * 2;
     g.Cout = Cout; g.T = KH * KW; g.KW = KW; g.dil = dil; g.ncb = Cp / 32; g.nsteps = g.ncb * g.T;
     const long long wbytes = (long long)g.nsteps * Cout * NB_ROW;
-    COCOS_REQUIRE(ntot < 0x7fffffffLL && xbytes < 0x7fffffffLL && wbytes < 0x7fffffffLL && (long long)B * Cout * g.OHW < (1LL << 40),
-                  COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_bf16: tensor too large");
-    COCOS_REQUIRE(aligned16(xp) && aligned16(w_planes), COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_bf16: operands must be 16-byte aligned");
+    COCOS_REQUIRE(ntot < 0x7fffffffLL && xbytes * (split ? 2 : 1) < 0x7fffffffLL && wbytes < 0x7fffffffLL &&
+                      (long long)B * Cout * g.OHW < (1LL << 40), COCOS_ERR_UNSUPPORTED, "%s: tensor too large", who);
+    COCOS_REQUIRE(aligned16(xp) && aligned16(w_hi) && (!split || aligned16(w_lo)), COCOS_ERR_UNSUPPORTED,
+                  "%s: operands must be 16-byte aligned", who);
     g.Ntot = (int)ntot; g.xp_bytes = (unsigned)xbytes; g.w_bytes = (unsigned)wbytes;
+    NhwcSplit sp{w_lo, (unsigned)xbytes, x_amax_dev, w_scale_dev};
     // tile: 256 rows unless the layer has at most 128 (a half-empty 256-row tile costs what a full one does); 256 columns
     // when that still gives the CUs something each
     const int cus = nhwc_cu_count() < 1024 ? nhwc_cu_count() : 1024;
@@ -594,11 +702,11 @@ extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, cons
     const long long ntm = (Cout + bm - 1) / bm;
     const int bn = (bm == 128 ? (ntot + 255) / 256 >= 100 : ntm * ((ntot + 255) / 256) >= 200) ? 256 : 128;
     const long long tiles = ntm * ((ntot + bn - 1) / bn);
-    COCOS_REQUIRE(tiles * g.nsteps < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_bf16: too many tiles");
+    COCOS_REQUIRE(tiles * g.nsteps < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "%s: too many tiles", who);
     g.ntiles = (int)tiles;
     // stream-K when the last round of one-tile workgroups would leave more than a fifth of the chip idle
     const long long rounds = (tiles + cus - 1) / cus;
-    const bool sk = workspace && tiles > cus && tiles * 5 < rounds * cus * 4 &&
+    const bool sk = !split && workspace && tiles > cus && tiles * 5 < rounds * cus * 4 &&
                     workspace_bytes >= kNhwcFlagBytes + (long long)cus * kNhwcSlotBytes && bm == 256 && bn == 256;
     // (measured, B = 8, 66 x 66 outputs: 407 -> 407 0.232 -> 0.204 ms, 512 -> 512 0.268 -> 0.250; nearly every tile is cut, so the
     //  parked partials are 128 MB of extra traffic — with 256 x 128 tiles, 273 of them, stream-K LOST: 0.089 -> 0.101 ms)
@@ -606,28 +714,52 @@ extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, cons
     int* flags = static_cast<int*>(workspace);
     float* slots = workspace ? reinterpret_cast<float*>(static_cast<char*>(workspace) + kNhwcFlagBytes) : nullptr;
     const int units = sk ? (int)((tiles * g.nsteps + cus - 1) / cus) : g.nsteps;
-#define COCOS_NHWC_GO(BMv, BNv, SKv) COCOS_NHWC_GO_W(BMv, BNv, SKv, 4)
-#define COCOS_NHWC_GO_W(BMv, BNv, SKv, NWv)                                                                              \
+#define COCOS_NHWC_GO_W(BMv, BNv, SKv, NWv, TERMSv)                                                                      \
     do {                                                                                                                 \
-        auto kern = conv_nhwc_bf16_kernel<BMv, BNv, SKv, NWv>;                                                           \
-        const size_t smem = (size_t)NB_STAGES * (BMv + BNv) * NB_ROW;                                                    \
+        auto kern = conv_nhwc_bf16_kernel<BMv, BNv, SKv, NWv, TERMSv>;                                                   \
+        const size_t smem = (size_t)(TERMSv == 3 ? 2 * 2 : NB_STAGES) * (BMv + BNv) * NB_ROW;                            \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                             (int)smem));                                                                \
-        hipLaunchKernelGGL(kern, dim3((unsigned)(SKv ? cus : tiles)), dim3(NWv * 64), smem, s, xp, w_planes, bias, y, slots, flags, \
-                           g, units);                                                                                   \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(SKv ? cus : tiles)), dim3(NWv * 64), smem, s, xp, w_hi, bias, y, slots, flags, g, \
+                           units, sp);                                                                                  \
     } while (0)
+#define COCOS_NHWC_GO(BMv, BNv) do { if (split) COCOS_NHWC_GO_W(BMv, BNv, false, 4, 3); else COCOS_NHWC_GO_W(BMv, BNv, false, 4, 1); } while (0)
     if (bm == 128) {
-        if (bn == 256) COCOS_NHWC_GO(128, 256, false); else COCOS_NHWC_GO(128, 128, false);
+        if (bn == 256) COCOS_NHWC_GO(128, 256); else COCOS_NHWC_GO(128, 128);
     } else if (bn == 256) {
         static const bool w8 = [] { const char* e = getenv("COCOS_CONV_NHWC_WAVES"); return !(e && e[0] == '4'); }();
-        if (sk) COCOS_NHWC_GO(256, 256, true); else if (w8) COCOS_NHWC_GO_W(256, 256, false, 8); else COCOS_NHWC_GO(256, 256, false);
+        if (split) COCOS_NHWC_GO_W(256, 256, false, 4, 3);
+        else if (sk) COCOS_NHWC_GO_W(256, 256, true, 4, 1);
+        else if (w8) COCOS_NHWC_GO_W(256, 256, false, 8, 1);
+        else COCOS_NHWC_GO_W(256, 256, false, 4, 1);
     } else {
-        COCOS_NHWC_GO(256, 128, false);
+        COCOS_NHWC_GO(256, 128);
     }
 #undef COCOS_NHWC_GO
 #undef COCOS_NHWC_GO_W
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+// y fp32 [B][Cout][OH][OW] = bias + conv(xp), xp bf16 [B][Hp][Wp][Cp] already padded (cocos_conv2d_nhwc_prep_bf16),
+// OH = (Hp - dil (KH-1) - 1) / stride + 1, OW likewise; w_planes = cocos_conv2d_weight_planes(mode | 2): bf16 [KH*KW*Cp/32][Cout][32].
+// workspace (nullable): see cocos_conv2d_nhwc_bf16_workspace_bytes — without it every launch is one tile per workgroup.
+extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias, float* y, void* workspace,
+                                      long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil,
+                                      int stride, cocos_stream_t stream) {
+    return cocos_nhwc_gemm_impl(xp, w_planes, nullptr, nullptr, nullptr, bias, y, workspace, workspace_bytes, B, Cp, Hp, Wp, Cout, KH, KW,
+                          dil, stride, stream, "conv2d_nhwc_bf16");
+}
+
+// K16c: the same GEMM on f16 hi/lo planes with three MFMA terms per product (fp32-accurate): xp from cocos_conv2d_nhwc_prep_f16x3
+// (scaled by the power of two of *x_amax_dev), w_hi / w_lo / *w_scale_dev from cocos_conv2d_weight_planes (mode 0 | 1).
+extern "C" int cocos_conv2d_nhwc_f16x3(const void* xp, const void* w_hi, const void* w_lo, const float* w_scale_dev,
+                                       const float* x_amax_dev, const float* bias, float* y, int B, int Cp, int Hp, int Wp, int Cout,
+                                       int KH, int KW, int dil, int stride, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(w_lo && w_scale_dev, COCOS_ERR_INVALID, "conv2d_nhwc_f16x3: null pointer");
+    return cocos_nhwc_gemm_impl(xp, w_hi, w_lo, w_scale_dev, x_amax_dev, bias, y, nullptr, 0, B, Cp, Hp, Wp, Cout, KH, KW, dil, stride, stream,
+                          "conv2d_nhwc_f16x3");
 }
 
 extern "C" int cocos_conv2d_nhwc_wgrad_bf16_slices(int B, int OH, int OW, int Cp, int Cout, int KH, int KW) {
@@ -639,35 +771,58 @@ extern "C" int cocos_conv2d_nhwc_wgrad_bf16_slices(int B, int OH, int OW, int Cp
     return (int)(s < 1 ? 1 : s);
 }
 
-// partial fp32 [S][Cout][KH*KW*Cp] (k' order of K16; summed and re-ordered by cocos_conv2d_wgrad_reduce), S = ..._slices(...);
-// xp as in cocos_conv2d_nhwc_bf16; dyp = bf16 NHWC [B][OH+2q][OW+2q][Cop] (cocos_conv2d_nhwc_prep_bf16 of dy with pad q, zeros).
-extern "C" int cocos_conv2d_nhwc_wgrad_bf16(const void* xp, const void* dyp, float* partial, int B, int Cp, int Hp, int Wp, int Cout,
-                                            int q, int KH, int KW, int dil, int stride, cocos_stream_t stream) {
+extern "C" int cocos_nhwc_wgrad_impl(const void* xp, const void* dyp, const float* x_amax_dev, const float* g_amax_dev, bool split, float* partial,
+                           int B, int Cp, int Hp, int Wp, int Cout, int q, int KH, int KW, int dil, int stride, cocos_stream_t stream,
+                           const char* who) {
     using namespace cocos;
-    COCOS_REQUIRE(xp && dyp && partial, COCOS_ERR_INVALID, "conv2d_nhwc_wgrad_bf16: null pointer");
+    COCOS_REQUIRE(xp && dyp && partial, COCOS_ERR_INVALID, "%s: null pointer", who);
     COCOS_REQUIRE(B >= 1 && Cp >= 32 && Cp % 32 == 0 && Cout >= 1 && KH >= 1 && KW >= 1 && dil >= 1 && q >= 0 && stride >= 1 &&
-                      Hp > dil * (KH - 1) && Wp > dil * (KW - 1), COCOS_ERR_INVALID, "conv2d_nhwc_wgrad_bf16: bad arguments");
+                      Hp > dil * (KH - 1) && Wp > dil * (KW - 1), COCOS_ERR_INVALID, "%s: bad arguments", who);
     NhwcWgradGeom g;
     g.B = B; g.Cp = Cp; g.Hp = Hp; g.Wp = Wp; g.stride = stride;
     g.OH = (Hp - dil * (KH - 1) - 1) / stride + 1; g.OW = (Wp - dil * (KW - 1) - 1) / stride + 1;
     COCOS_REQUIRE(g.OH >= 1 && g.OW >= 32 && g.OW % 32 == 0, COCOS_ERR_UNSUPPORTED,
-                  "conv2d_nhwc_wgrad_bf16: output rows must be whole k-steps of 32 positions (OW=%d)", g.OW);
+                  "%s: output rows must be whole k-steps of 32 positions (OW=%d)", who, g.OW);
     g.Cop = (Cout + 31) / 32 * 32; g.q = q; g.Hq = g.OH + 2 * q; g.Wq = g.OW + 2 * q;
     g.Cout = Cout; g.T = KH * KW; g.KW = KW; g.dil = dil; g.nkb = g.T * (Cp / 32);
     const long long ntot = (long long)B * g.OH * g.OW, xbytes = (long long)B * Hp * Wp * Cp * 2,
                     ybytes = (long long)B * g.Hq * g.Wq * g.Cop * 2;
-    COCOS_REQUIRE(ntot < 0x7fffffffLL && xbytes < 0x7fffffffLL && ybytes < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED,
-                  "conv2d_nhwc_wgrad_bf16: tensor too large");
-    COCOS_REQUIRE(aligned16(xp) && aligned16(dyp), COCOS_ERR_UNSUPPORTED, "conv2d_nhwc_wgrad_bf16: operands must be 16-byte aligned");
+    COCOS_REQUIRE(ntot < 0x7fffffffLL && xbytes * (split ? 2 : 1) < 0x7fffffffLL && ybytes * (split ? 2 : 1) < 0x7fffffffLL,
+                  COCOS_ERR_UNSUPPORTED, "%s: tensor too large", who);
+    COCOS_REQUIRE(aligned16(xp) && aligned16(dyp), COCOS_ERR_UNSUPPORTED, "%s: operands must be 16-byte aligned", who);
     g.Ntot = (int)ntot; g.xp_bytes = (unsigned)xbytes; g.dy_bytes = (unsigned)ybytes;
     const int S = cocos_conv2d_nhwc_wgrad_bf16_slices(B, g.OH, g.OW, Cp, Cout, KH, KW);
     g.steps_total = (int)(ntot / 32);
     g.steps_per_slice = (g.steps_total + S - 1) / S;
     const int ntm = (Cout + 255) / 256, ntn = (g.nkb * 32 + 255) / 256;
-    auto kern = conv_nhwc_wgrad_bf16_kernel;
-    const size_t smem = (size_t)NB_STAGES * 2 * 256 * NB_ROW;
-    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn * S)), dim3(256), smem, as_stream(stream), xp, dyp, partial, g);
+    NhwcWgradSplit sp{(unsigned)xbytes, (unsigned)ybytes, x_amax_dev, g_amax_dev};
+    if (split) {
+        auto kern = conv_nhwc_wgrad_bf16_kernel<3>;
+        const size_t smem = (size_t)2 * 2 * 2 * 256 * NB_ROW;
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn * S)), dim3(256), smem, as_stream(stream), xp, dyp, partial, g, sp);
+    } else {
+        auto kern = conv_nhwc_wgrad_bf16_kernel<1>;
+        const size_t smem = (size_t)NB_STAGES * 2 * 256 * NB_ROW;
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(ntm * ntn * S)), dim3(256), smem, as_stream(stream), xp, dyp, partial, g, sp);
+    }
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+// partial fp32 [S][Cout][KH*KW*Cp] (k' order of K16; summed and re-ordered by cocos_conv2d_wgrad_reduce), S = ..._slices(...);
+// xp as in cocos_conv2d_nhwc_bf16; dyp = bf16 NHWC [B][OH+2q][OW+2q][Cop] (cocos_conv2d_nhwc_prep_bf16 of dy with pad q, zeros).
+extern "C" int cocos_conv2d_nhwc_wgrad_bf16(const void* xp, const void* dyp, float* partial, int B, int Cp, int Hp, int Wp, int Cout,
+                                            int q, int KH, int KW, int dil, int stride, cocos_stream_t stream) {
+    return cocos_nhwc_wgrad_impl(xp, dyp, nullptr, nullptr, false, partial, B, Cp, Hp, Wp, Cout, q, KH, KW, dil, stride, stream,
+                           "conv2d_nhwc_wgrad_bf16");
+}
+
+// K16c: both operands as f16 hi/lo plane pairs (cocos_conv2d_nhwc_prep_f16x3 with their max|.| cells), three terms per product
+extern "C" int cocos_conv2d_nhwc_wgrad_f16x3(const void* xp, const void* dyp, const float* x_amax_dev, const float* g_amax_dev,
+                                             float* partial, int B, int Cp, int Hp, int Wp, int Cout, int q, int KH, int KW, int dil,
+                                             int stride, cocos_stream_t stream) {
+    return cocos_nhwc_wgrad_impl(xp, dyp, x_amax_dev, g_amax_dev, true, partial, B, Cp, Hp, Wp, Cout, q, KH, KW, dil, stride, stream,
+                           "conv2d_nhwc_wgrad_f16x3");
 }

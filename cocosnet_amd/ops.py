@@ -901,6 +901,33 @@ def _conv_nhwc_ok(Cin, Cout, KH, KW, stride):
     return CONV_NHWC and bool(_lib.load().cocos_conv2d_nhwc_bf16_supported(Cin, Cout, KH, KW, stride))
 
 
+#: "0": the fp32-accurate flavour keeps every layer on conv_f16x3.hip's gather kernels (A/B runs); default: K16c, the same
+#: arithmetic on K16b's data path (f16 hi/lo planes NHWC in memory, LDS-DMA GEMMs)
+CONV_NHWC_F16X3 = os.environ.get("COCOS_CONV_NHWC_F16X3", "1") != "0"
+
+
+def conv_nhwc_prep_split(x: torch.Tensor, pad: int, reflect: bool, amax: torch.Tensor) -> torch.Tensor:
+    """fp32 [B,C,H,W] -> f16 [2,B,H+2p,W+2p,Cp]: hi and lo plane of x * 2^k (k from the max|x| cell `amax`), NHWC, border zero or
+    mirrored: the operand of K16c (cocos_conv2d_nhwc_prep_f16x3)."""
+    x = _chk(x, "conv_nhwc_prep_split: x")
+    B, C, H, W = x.shape
+    xp = torch.empty((2, B, H + 2 * pad, W + 2 * pad, (C + 31) // 32 * 32), device=x.device, dtype=torch.float16)
+    _call("conv2d_nhwc_prep", "cocos_conv2d_nhwc_prep_f16x3", x.data_ptr(), xp.data_ptr(), _ptr(amax), B, C, H, W, int(pad),
+          int(bool(reflect)), _stream())
+    return xp
+
+
+def _conv_nhwc_split_call(xp, wh, wl, ws, xa, bias, Cout, KH, KW, dil, stride=1):
+    _, B, Hp, Wp, Cp = xp.shape
+    if Hp <= dil * (KH - 1) or Wp <= dil * (KW - 1):
+        raise ValueError(f"conv2d: kernel {KH}x{KW} (dilation {dil}) does not fit the padded input {tuple(xp.shape)}")
+    OH, OW = (Hp - dil * (KH - 1) - 1) // stride + 1, (Wp - dil * (KW - 1) - 1) // stride + 1
+    y = torch.empty((B, Cout, OH, OW), device=xp.device, dtype=torch.float32)
+    _call("conv2d_fwd", "cocos_conv2d_nhwc_f16x3", xp.data_ptr(), wh.data_ptr(), wl.data_ptr(), ws.data_ptr(), _ptr(xa), _ptr(bias),
+          y.data_ptr(), B, Cp, Hp, Wp, Cout, KH, KW, dil, int(stride), _stream())
+    return y
+
+
 def conv_nhwc_prep(x: torch.Tensor, pad: int, reflect: bool = False) -> torch.Tensor:
     """fp32 [B,C,H,W] -> bf16 [B,H+2p,W+2p,Cp] (channels padded to 32, border zero or mirrored): the operand layout of K16b
     (cocos_conv2d_nhwc_prep_bf16)."""
@@ -1004,7 +1031,13 @@ class _Conv2d(torch.autograd.Function):
             wa = absmax(weight)
         wh, wl, ws = _conv_weight_planes(weight, wa, 0)
         xp = None
-        if wa is None and _conv_nhwc_ok(Cin, Cout, KH, KW, stride):
+        if wa is not None and CONV_NHWC_F16X3 and _conv_nhwc_ok(Cin, Cout, KH, KW, stride):
+            # K16c: the split arithmetic on K16b's data path — hi/lo planes NHWC in memory, LDS-DMA GEMM, three terms
+            xp = conv_nhwc_prep_split(x, reflect if reflect else pad, bool(reflect), xa)
+            y = _conv_nhwc_split_call(xp, wh, wl, ws, xa, bb, Cout, KH, KW, dil, stride)
+            if y.shape[3] % 32 != 0:
+                xp = None
+        elif wa is None and _conv_nhwc_ok(Cin, Cout, KH, KW, stride):
             # K16b: operands bf16 in memory (NHWC, border included), LDS-DMA GEMM — conv_nhwc_bf16.hip
             xp = conv_nhwc_prep(x, reflect if reflect else pad, bool(reflect))    # the border: zeros, or the layer's ReflectionPad2d
             y = _conv_nhwc_call(xp, wh, bb, Cout, KH, KW, dil, stride)
@@ -1042,12 +1075,17 @@ class _Conv2d(torch.autograd.Function):
             if ga is None:
                 ga = absmax(dy)
         q = dil * (KH - 1) - pad
-        dx_nhwc = need_x and bf and stride == 1 and q >= 0 and KW == KH and _conv_nhwc_ok(Cout, Cin, KH, KW, 1)
+        nhwc = bf or CONV_NHWC_F16X3
+        dx_nhwc = need_x and nhwc and stride == 1 and q >= 0 and KW == KH and _conv_nhwc_ok(Cout, Cin, KH, KW, 1)
         dyp = None
         if dx_nhwc or (need_w and xp is not None):
-            dyp = conv_nhwc_prep(dy, q if dx_nhwc else 0)        # bf16 NHWC, the border the input gradient needs
+            # dy as the NHWC operand (bf16, or f16 hi/lo planes), with the border the input gradient needs
+            dyp = conv_nhwc_prep(dy, q if dx_nhwc else 0) if bf else conv_nhwc_prep_split(dy, q if dx_nhwc else 0, False, ga)
         if need_x:
-            if dx_nhwc:
+            if dx_nhwc and not bf:
+                th, tl, ts = _conv_weight_planes(weight, wa, 1)
+                dx = _conv_nhwc_split_call(dyp, th, tl, ts, ga, None, Cin, KH, KW, dil)
+            elif dx_nhwc:
                 th, _, _ = _conv_weight_planes(weight, None, 1)
                 dx = _conv_nhwc_call(dyp, th, None, Cin, KH, KW, dil)
             elif stride == 1 and q >= 0 and KW == KH:
@@ -1060,11 +1098,15 @@ class _Conv2d(torch.autograd.Function):
                 dx = torch.nn.grad.conv2d_input((B, Cin, H, W), weight, dy, stride=stride, padding=pad, dilation=dil)
         if need_w and xp is not None:
             lib = _lib.load()
-            _, Hp, Wp, Cp = xp.shape
+            Hp, Wp, Cp = xp.shape[-3:]
             S = lib.cocos_conv2d_nhwc_wgrad_bf16_slices(B, dy.shape[2], dy.shape[3], Cp, Cout, KH, KW)
             part = torch.empty((S, Cout, lib.cocos_conv2d_kdim(Cin, KH, KW)), device=dy.device, dtype=torch.float32)
-            _call("conv2d_wgrad", "cocos_conv2d_nhwc_wgrad_bf16", xp.data_ptr(), dyp.data_ptr(), part.data_ptr(), B, Cp, Hp, Wp, Cout,
-                  q if dx_nhwc else 0, KH, KW, dil, stride, _stream())
+            if bf:
+                _call("conv2d_wgrad", "cocos_conv2d_nhwc_wgrad_bf16", xp.data_ptr(), dyp.data_ptr(), part.data_ptr(), B, Cp, Hp, Wp,
+                      Cout, q if dx_nhwc else 0, KH, KW, dil, stride, _stream())
+            else:
+                _call("conv2d_wgrad", "cocos_conv2d_nhwc_wgrad_f16x3", xp.data_ptr(), dyp.data_ptr(), xa.data_ptr(), ga.data_ptr(),
+                      part.data_ptr(), B, Cp, Hp, Wp, Cout, q if dx_nhwc else 0, KH, KW, dil, stride, _stream())
             dw = torch.empty_like(weight)
             _call("conv2d_wgrad", "cocos_conv2d_wgrad_reduce", part.data_ptr(), dw.data_ptr(), S, Cout, Cin, KH, KW, _stream())
         elif need_w:
@@ -1099,7 +1141,7 @@ def conv2d(x, weight, bias=None, stride: int = 1, padding: int = 0, dilation: in
     if reflect:
         Cout, Cin, KH, KW = weight.shape
         ow = x.shape[3] + 2 * reflect + 2 * int(padding) - int(dilation) * (KW - 1)
-        fused = (_conv_bf16() and int(stride) == 1 and int(padding) == 0 and x.dim() == 4 and reflect < min(x.shape[2:])
+        fused = ((_conv_bf16() or CONV_NHWC_F16X3) and int(stride) == 1 and int(padding) == 0 and x.dim() == 4 and reflect < min(x.shape[2:])
                  and ow >= 32 and ow % 32 == 0 and _conv_nhwc_ok(Cin, Cout, KH, KW, 1))
         if not fused:
             x, reflect = reflect_pad2d(x, reflect), 0

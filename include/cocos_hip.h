@@ -641,6 +641,18 @@ int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);
  *   cocos_conv2d_nhwc_bf16_supported: 1 when the layer shape takes this path (>= 128 output rows, >= 32 input channels; strided layers: forward and weight
  *       gradient — their input gradient stays on cocos_conv2d_fwd_scatter_f16x3's parity classes). */
 int cocos_conv2d_nhwc_bf16_supported(int Cin, int Cout, int KH, int KW, int stride);
+/* K16c: the same three kernels for the fp32-accurate flavour — every operand as TWO f16 planes (hi, lo; the lo plane directly
+ * behind the hi plane: [2][B][Hp][Wp][Cp]) of x * 2^k, k from the tensor's max|x| cell, three MFMA terms per product, results
+ * scaled back in the epilogues: the arithmetic of cocos_conv2d_fwd_f16x3 / cocos_conv2d_wgrad_f16x3 (same reference lines) on
+ * K16b's data path.  w_hi / w_lo / *w_scale_dev = cocos_conv2d_weight_planes(mode 0 | 1). */
+int cocos_conv2d_nhwc_prep_f16x3(const float* x, void* xp, const float* amax_dev /* nullable: scale 1 */, int B, int C, int H, int W,
+                                 int pad, int reflect, cocos_stream_t stream);
+int cocos_conv2d_nhwc_f16x3(const void* xp, const void* w_hi, const void* w_lo, const float* w_scale_dev, const float* x_amax_dev,
+                            const float* bias /* nullable */, float* y, int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil,
+                            int stride, cocos_stream_t stream);
+int cocos_conv2d_nhwc_wgrad_f16x3(const void* xp, const void* dyp, const float* x_amax_dev, const float* g_amax_dev, float* partial,
+                                  int B, int Cp, int Hp, int Wp, int Cout, int q, int KH, int KW, int dil, int stride,
+                                  cocos_stream_t stream);
 int cocos_conv2d_nhwc_prep_bf16(const float* x, void* xp, int B, int C, int H, int W, int pad, int reflect, cocos_stream_t stream);
 long long cocos_conv2d_nhwc_bf16_workspace_bytes(void);
 int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias /* nullable */, float* y,

@@ -284,11 +284,12 @@ def test_conv_nhwc_prep_is_pad_plus_bf16_plus_permute(B, C, H, W, pad, reflect):
     assert torch.equal(xp, ref)
 
 
-def test_conv2d_bf16_nhwc_matches_the_gather_flavour(monkeypatch):
-    """Same arithmetic (one bf16 term, fp32 accumulate) through the two data paths: K16b (operands bf16 NHWC in memory,
-    LDS-DMA) against conv_f16x3.hip's one-term kernels (fp32 NCHW gathered per tap) — differences are summation order only."""
+@pytest.mark.parametrize("prec,tol", [("bf16", 2e-5), ("f16x3", 2e-6)])
+def test_conv2d_bf16_nhwc_matches_the_gather_flavour(prec, tol, monkeypatch):
+    """Same arithmetic (one bf16 term / three f16 terms, fp32 accumulate) through the two data paths: K16b / K16c (operands 16-bit NHWC
+    in memory, LDS-DMA) against conv_f16x3.hip's kernels (fp32 NCHW gathered per tap) — differences are summation order only."""
     from cocosnet_amd import ops
-    monkeypatch.setattr(ops, "CONV_PRECISION", "bf16")
+    monkeypatch.setattr(ops, "CONV_PRECISION", prec)
     g = torch.Generator(device="cuda").manual_seed(8)
     x0 = torch.randn(2, 96, 34, 66, device="cuda", generator=g)
     w0 = torch.randn(288, 96, 3, 3, device="cuda", generator=g) / 30
@@ -297,6 +298,7 @@ def test_conv2d_bf16_nhwc_matches_the_gather_flavour(monkeypatch):
     res = {}
     for nhwc in (True, False):
         monkeypatch.setattr(ops, "CONV_NHWC", nhwc)
+        monkeypatch.setattr(ops, "CONV_NHWC_F16X3", nhwc)
         x, w, b = (t.clone().requires_grad_(True) for t in (x0, w0, b0))
         with ops.KernelTimer() as kt:
             y = ops.conv2d(x, w, b, 1, 0, 1)
@@ -305,14 +307,15 @@ def test_conv2d_bf16_nhwc_matches_the_gather_flavour(monkeypatch):
         res[nhwc] = (y.detach(), x.grad, w.grad, b.grad)
     for a, r, what in zip(res[True], res[False], ("y", "dx", "dw", "db")):
         e = (a - r).abs().max().item() / r.abs().max().item()
-        assert e <= 2e-5, f"{what}: {e:.3e}"
+        assert e <= tol, f"{what}: {e:.3e}"
 
 
-def test_conv2d_reflect_fused_equals_pad_then_conv(monkeypatch):
+@pytest.mark.parametrize("prec", ["bf16", "f16x3"])
+def test_conv2d_reflect_fused_equals_pad_then_conv(prec, monkeypatch):
     """ops.conv2d(reflect=r) on the K16b path (mirrored border written by the operand preparation, input gradient folded back by
     K18's backward) against reflect_pad2d followed by the same layer; shapes the fused path does not take fall back to exactly that."""
     from cocosnet_amd import ops
-    monkeypatch.setattr(ops, "CONV_PRECISION", "bf16")
+    monkeypatch.setattr(ops, "CONV_PRECISION", prec)
     g = torch.Generator(device="cuda").manual_seed(9)
     for (B, Cin, H, W, Cout, r, fused) in ((2, 64, 32, 64, 192, 1, True), (1, 40, 12, 64, 128, 2, True), (2, 64, 20, 36, 192, 1, False)):
         k = 2 * r + 1

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cocosnet_amd import ops
 
-ops.CONV_PRECISION = "bf16"
+ops.CONV_PRECISION = os.environ.get("PREC", "bf16")          # PREC=f16x3: K16c against the split gather kernels
 SHAPES = [("ResidualBlock 407->407 on 66x66", (8, 407, 66, 66, 407, 3, 0)),
           ("SPADE 128->512 on 66x66", (8, 128, 66, 66, 512, 3, 0)),
           ("512->512 on 66x66", (8, 512, 66, 66, 512, 3, 0)),
@@ -17,7 +17,7 @@ for name, (b, ci, h, w, co, k, p) in SHAPES:
     bias = torch.randn(co, device="cuda", requires_grad=True)
     rec = {"shape": name}
     for nhwc in (False, True):
-        ops.CONV_NHWC = nhwc
+        ops.CONV_NHWC = ops.CONV_NHWC_F16X3 = nhwc
         y = ops.conv2d(x, wt, bias, 1, p)
         go = torch.randn_like(y)
         flops = 2.0 * y.numel() * ci * k * k
