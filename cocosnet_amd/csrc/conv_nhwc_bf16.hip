@@ -706,7 +706,7 @@ extern "C" int cocos_nhwc_gemm_impl(const void* xp, const void* w_hi, const void
     g.ntiles = (int)tiles;
     // stream-K when the last round of one-tile workgroups would leave more than a fifth of the chip idle
     const long long rounds = (tiles + cus - 1) / cus;
-    const bool sk = !split && workspace && tiles > cus && tiles * 5 < rounds * cus * 4 &&
+    const bool sk = workspace && tiles > cus && tiles * 5 < rounds * cus * 4 &&
                     workspace_bytes >= kNhwcFlagBytes + (long long)cus * kNhwcSlotBytes && bm == 256 && bn == 256;
     // (measured, B = 8, 66 x 66 outputs: 407 -> 407 0.232 -> 0.204 ms, 512 -> 512 0.268 -> 0.250; nearly every tile is cut, so the
     //  parked partials are 128 MB of extra traffic — with 256 x 128 tiles, 273 of them, stream-K LOST: 0.089 -> 0.101 ms)
@@ -728,7 +728,8 @@ extern "C" int cocos_nhwc_gemm_impl(const void* xp, const void* w_hi, const void
         if (bn == 256) COCOS_NHWC_GO(128, 256); else COCOS_NHWC_GO(128, 128);
     } else if (bn == 256) {
         static const bool w8 = [] { const char* e = getenv("COCOS_CONV_NHWC_WAVES"); return !(e && e[0] == '4'); }();
-        if (split) COCOS_NHWC_GO_W(256, 256, false, 4, 3);
+        if (split && sk) COCOS_NHWC_GO_W(256, 256, true, 4, 3);
+        else if (split) COCOS_NHWC_GO_W(256, 256, false, 4, 3);
         else if (sk) COCOS_NHWC_GO_W(256, 256, true, 4, 1);
         else if (w8) COCOS_NHWC_GO_W(256, 256, false, 8, 1);
         else COCOS_NHWC_GO_W(256, 256, false, 4, 1);
@@ -754,12 +755,13 @@ extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, cons
 // K16c: the same GEMM on f16 hi/lo planes with three MFMA terms per product (fp32-accurate): xp from cocos_conv2d_nhwc_prep_f16x3
 // (scaled by the power of two of *x_amax_dev), w_hi / w_lo / *w_scale_dev from cocos_conv2d_weight_planes (mode 0 | 1).
 extern "C" int cocos_conv2d_nhwc_f16x3(const void* xp, const void* w_hi, const void* w_lo, const float* w_scale_dev,
-                                       const float* x_amax_dev, const float* bias, float* y, int B, int Cp, int Hp, int Wp, int Cout,
-                                       int KH, int KW, int dil, int stride, cocos_stream_t stream) {
+                                       const float* x_amax_dev, const float* bias, float* y, void* workspace, long long workspace_bytes,
+                                       int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil, int stride,
+                                       cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(w_lo && w_scale_dev, COCOS_ERR_INVALID, "conv2d_nhwc_f16x3: null pointer");
-    return cocos_nhwc_gemm_impl(xp, w_hi, w_lo, w_scale_dev, x_amax_dev, bias, y, nullptr, 0, B, Cp, Hp, Wp, Cout, KH, KW, dil, stride, stream,
-                          "conv2d_nhwc_f16x3");
+    return cocos_nhwc_gemm_impl(xp, w_hi, w_lo, w_scale_dev, x_amax_dev, bias, y, workspace, workspace_bytes, B, Cp, Hp, Wp, Cout, KH, KW,
+                                dil, stride, stream, "conv2d_nhwc_f16x3");
 }
 
 extern "C" int cocos_conv2d_nhwc_wgrad_bf16_slices(int B, int OH, int OW, int Cp, int Cout, int KH, int KW) {

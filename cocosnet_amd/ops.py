@@ -923,8 +923,9 @@ def _conv_nhwc_split_call(xp, wh, wl, ws, xa, bias, Cout, KH, KW, dil, stride=1)
         raise ValueError(f"conv2d: kernel {KH}x{KW} (dilation {dil}) does not fit the padded input {tuple(xp.shape)}")
     OH, OW = (Hp - dil * (KH - 1) - 1) // stride + 1, (Wp - dil * (KW - 1) - 1) // stride + 1
     y = torch.empty((B, Cout, OH, OW), device=xp.device, dtype=torch.float32)
+    wsp = _conv_nhwc_workspace(xp.device, split=True)
     _call("conv2d_fwd", "cocos_conv2d_nhwc_f16x3", xp.data_ptr(), wh.data_ptr(), wl.data_ptr(), ws.data_ptr(), _ptr(xa), _ptr(bias),
-          y.data_ptr(), B, Cp, Hp, Wp, Cout, KH, KW, dil, int(stride), _stream())
+          y.data_ptr(), _ptr(wsp), wsp.numel() * 4 if wsp is not None else 0, B, Cp, Hp, Wp, Cout, KH, KW, dil, int(stride), _stream())
     return y
 
 
@@ -943,12 +944,15 @@ def conv_nhwc_prep(x: torch.Tensor, pad: int, reflect: bool = False) -> torch.Te
 #: DMA pieces were interleaved with the MFMAs a tile got 20 % faster and the parked partials (nearly every tile is cut: 128 MB)
 #: cost what the second round costs (407 -> 407 input gradient 0.191 vs 0.192 ms, 512 -> 512 0.224 vs 0.239).
 CONV_NHWC_STREAMK = os.environ.get("COCOS_CONV_STREAMK", "0") == "1"
+#: the three-term flavour (K16c) is the other way round: a tile takes 3x as long, the parked partials cost the same — stream-K on
+#: unless COCOS_CONV_STREAMK=0 (407 -> 407 input gradient on 66 x 66: two rounds of 0.3 ms against 1.07 rounds + 0.04 ms)
+CONV_NHWC_STREAMK_SPLIT = os.environ.get("COCOS_CONV_STREAMK", "1") != "0"
 
 
-def _conv_nhwc_workspace(device):
-    """K16b's stream-K scratch: one zero-initialised buffer per (thread, device, stream), cleared when it is allocated (the kernel
-    leaves its flags zero)."""
-    if not CONV_NHWC_STREAMK:
+def _conv_nhwc_workspace(device, split=False):
+    """K16b / K16c's stream-K scratch: one zero-initialised buffer per (thread, device, stream), cleared when it is allocated (the
+    kernel leaves its flags zero)."""
+    if not (CONV_NHWC_STREAMK_SPLIT if split else CONV_NHWC_STREAMK):
         return None
     pool = getattr(_tls, "nhwc_ws", None)
     if pool is None:

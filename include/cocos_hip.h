@@ -648,8 +648,9 @@ int cocos_conv2d_nhwc_bf16_supported(int Cin, int Cout, int KH, int KW, int stri
 int cocos_conv2d_nhwc_prep_f16x3(const float* x, void* xp, const float* amax_dev /* nullable: scale 1 */, int B, int C, int H, int W,
                                  int pad, int reflect, cocos_stream_t stream);
 int cocos_conv2d_nhwc_f16x3(const void* xp, const void* w_hi, const void* w_lo, const float* w_scale_dev, const float* x_amax_dev,
-                            const float* bias /* nullable */, float* y, int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil,
-                            int stride, cocos_stream_t stream);
+                            const float* bias /* nullable */, float* y, void* workspace /* nullable: as cocos_conv2d_nhwc_bf16 */,
+                            long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil, int stride,
+                            cocos_stream_t stream);
 int cocos_conv2d_nhwc_wgrad_f16x3(const void* xp, const void* dyp, const float* x_amax_dev, const float* g_amax_dev, float* partial,
                                   int B, int Cp, int Hp, int Wp, int Cout, int q, int KH, int KW, int dil, int stride,
                                   cocos_stream_t stream);

@@ -358,28 +358,31 @@ def test_reflect_conv_helper_keeps_module_semantics(monkeypatch):
             assert getattr(producers._pending, "reflect", 0) == 0
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16x3"])
 @pytest.mark.parametrize("Cout,tile", [(288, "256x256 (stream-K)"), (256, "256x128 (never stream-K: measured slower)")])
-def test_conv2d_bf16_nhwc_stream_k_equals_one_tile_per_workgroup(Cout, tile, monkeypatch):
+def test_conv2d_bf16_nhwc_stream_k_equals_one_tile_per_workgroup(Cout, tile, prec, monkeypatch):
     """8 x 66 x 66 output positions are 136.1 column tiles of 256 (272.3 of 128): with two row tiles 274 (273) workgroups for 256
     CUs.  With the workspace K16b runs such a layer as ONE workgroup per CU over contiguous (tile, k-step) ranges, cut tiles meeting
     through the parked partials; the result must be the one-tile-per-workgroup result up to fp32 summation order — on every repeat
     (the flags are left clean) and next to a layer that does not take the path."""
     from cocosnet_amd import ops
-    monkeypatch.setattr(ops, "CONV_PRECISION", "bf16")
+    monkeypatch.setattr(ops, "CONV_PRECISION", prec)
     g = torch.Generator(device="cuda").manual_seed(12)
     x = torch.randn(8, 32, 68, 68, device="cuda", generator=g)
     w = torch.randn(Cout, 32, 3, 3, device="cuda", generator=g) / 17
     b = torch.randn(Cout, device="cuda", generator=g)
     monkeypatch.setattr(ops, "CONV_NHWC_STREAMK", False)
+    monkeypatch.setattr(ops, "CONV_NHWC_STREAMK_SPLIT", False)
     ref = ops.conv2d(x, w, b, 1, 0, 1)
     monkeypatch.setattr(ops, "CONV_NHWC_STREAMK", True)
+    monkeypatch.setattr(ops, "CONV_NHWC_STREAMK_SPLIT", True)
     small = ops.conv2d(x[:1], w, b, 1, 0, 1)
     for rep in range(3):
         y = ops.conv2d(x, w, b, 1, 0, 1)
         e = (y - ref).abs().max().item() / ref.abs().max().item()
         assert e <= 2e-6, f"{tile} repeat {rep}: {e:.3e}"
         assert torch.equal(ops.conv2d(x[:1], w, b, 1, 0, 1), small)
-    ws = ops._conv_nhwc_workspace(x.device)
+    ws = ops._conv_nhwc_workspace(x.device, split=prec == "f16x3")
     assert ws is not None and int(ws[:1024].abs().sum()) == 0          # every flag back to zero
     yr = torch.nn.functional.conv2d(x.double(), w.double(), b.double())
-    assert (y.double() - yr).abs().max().item() / yr.abs().max().item() <= 1.5e-2
+    assert (y.double() - yr).abs().max().item() / yr.abs().max().item() <= (1.5e-2 if prec == "bf16" else 1e-5)
