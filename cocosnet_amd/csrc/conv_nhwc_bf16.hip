@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256, 1) void conv_nhwc_wgrad_bf16_kernel(const void
 
 }  // namespace cocos
 
-extern "C" int cocos_nhwc_prep_impl(const float* x, void* xp, const float* amax_dev, bool split, int B, int C, int H, int W, int pad,
+static int cocos_nhwc_prep_impl(const float* x, void* xp, const float* amax_dev, bool split, int B, int C, int H, int W, int pad,
                           int reflect, cocos_stream_t stream, const char* who) {
     using namespace cocos;
     COCOS_REQUIRE(x && xp, COCOS_ERR_INVALID, "%s: null pointer", who);
@@ -673,7 +673,7 @@ extern "C" long long cocos_conv2d_nhwc_bf16_workspace_bytes(void) {
     return kNhwcFlagBytes + (long long)(cus < 1024 ? cus : 1024) * kNhwcSlotBytes;
 }
 
-extern "C" int cocos_nhwc_gemm_impl(const void* xp, const void* w_hi, const void* w_lo, const float* w_scale_dev, const float* x_amax_dev,
+static int cocos_nhwc_gemm_impl(const void* xp, const void* w_hi, const void* w_lo, const float* w_scale_dev, const float* x_amax_dev,
                           const float* bias, float* y, void* workspace, long long workspace_bytes, int B, int Cp, int Hp, int Wp,
                           int Cout, int KH, int KW, int dil, int stride, cocos_stream_t stream, const char* who) {
     using namespace cocos;
@@ -773,7 +773,7 @@ extern "C" int cocos_conv2d_nhwc_wgrad_bf16_slices(int B, int OH, int OW, int Cp
     return (int)(s < 1 ? 1 : s);
 }
 
-extern "C" int cocos_nhwc_wgrad_impl(const void* xp, const void* dyp, const float* x_amax_dev, const float* g_amax_dev, bool split, float* partial,
+static int cocos_nhwc_wgrad_impl(const void* xp, const void* dyp, const float* x_amax_dev, const float* g_amax_dev, bool split, float* partial,
                            int B, int Cp, int Hp, int Wp, int Cout, int q, int KH, int KW, int dil, int stride, cocos_stream_t stream,
                            const char* who) {
     using namespace cocos;
