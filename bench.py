@@ -54,6 +54,42 @@ def _conv_flavour():
     return producers.CONV_BACKEND
 
 
+def module_scope_context(device, d, steps=5, warmup=3):
+    """ms per forward + backward of the whole NoVGGCorrespondence module (batch 8, 256x256, ADE20k flags) with the convolutions
+    on K16c (f16x3, the parity-safe default) and on K16b (bf16): what `--scope netcorr` times, reported beside the headline."""
+    from cocosnet_amd import ops, producers
+    out = {}
+    saved = (producers.CONV_BACKEND, ops.CONV_PRECISION)
+    try:
+        for flavour in ("f16x3", "bf16"):
+            producers.CONV_BACKEND = ops.CONV_PRECISION = flavour
+            torch.manual_seed(0)
+            model, fwd = make_step("netcorr", device)
+            params = list(model.parameters())
+
+            def step():
+                for p in params:
+                    p.grad = None
+                o = fwd(d)
+                torch.autograd.backward([o["warp_out"], o["warp_mask"]], [d["g_out"], d["g_mask"]])
+
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            out[flavour] = {"ms_per_step": round(ms, 3), "images_per_s": round(BATCH_PER_GPU / ms * 1e3, 1), "steps": steps}
+            del model, params
+        out["note"] = ("whole module fwd+bwd (adaptors, ResidualBlocks, SPADE blocks, theta/phi, the path); convolutions f16x3 = "
+                       "three-term f16 hi/lo on the NHWC / LDS-DMA kernels (K16c, default), bf16 = one term (K16b, COCOS_CONV=bf16)")
+    finally:
+        producers.CONV_BACKEND, ops.CONV_PRECISION = saved
+    return out
+
+
 def build_inputs(device, scope):
     g = torch.Generator(device=device).manual_seed(1234 + (torch.distributed.get_rank()
                                                            if torch.distributed.is_initialized() else 0))
@@ -489,6 +525,14 @@ def main():
                 fwd_box[0] = fwd
                 del params[n_own:]
             del model3
+        # context: the whole drop-in module (feature producers + the path) on the same inputs, in its two convolution flavours —
+        # never part of `value`, never allowed to cost the line
+        if args.scope == "hotpath":
+            try:
+                context = dict(context or {})
+                context["module_scope"] = module_scope_context(device, d)
+            except Exception as e:       # noqa: BLE001
+                context["module_scope"] = {"error": repr(e)}
 
     # N > 1: what BASELINE config 4's exchanges cost on this node — timed AFTER the contract window, never part of `value`:
     # one in-place all-reduce (RCCL) of a flat fp32 buffer of netCorr's 59 M and of netG+netCorr's 156 M gradients
