@@ -126,11 +126,12 @@ _SIGNATURES = {
     "cocos_conv2d_nhwc_bf16_supported": (ctypes.c_int, [ctypes.c_int] * 5),
     "cocos_conv2d_nhwc_prep_bf16": (ctypes.c_int, [_c_float_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [_stream_t]),
     "cocos_conv2d_nhwc_bf16_workspace_bytes": (ctypes.c_longlong, []),
-    "cocos_conv2d_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_void_p,
+    "cocos_conv2d_nhwc_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p,
                                                ctypes.c_longlong] + [ctypes.c_int] * 9 + [_stream_t]),
     "cocos_conv2d_nhwc_prep_f16x3": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 6 + [_stream_t]),
     "cocos_conv2d_nhwc_f16x3": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p,
-                                                _c_float_p, ctypes.c_void_p, ctypes.c_longlong] + [ctypes.c_int] * 9 + [_stream_t]),
+                                                _c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_longlong] + [ctypes.c_int] * 9
+                                + [_stream_t]),
     "cocos_conv2d_nhwc_wgrad_f16x3": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p]
                                       + [ctypes.c_int] * 10 + [_stream_t]),
     "cocos_conv2d_nhwc_wgrad_bf16_slices": (ctypes.c_int, [ctypes.c_int] * 7),

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_prep_kernel(const float* __rest
 // conv_f16x3.hip on this kernel's data path; a stage holds four tiles (two stages of 64 KB at 256 x 256), the result is scaled
 // back by 1 / (s_x s_w) in the epilogue.  The stage count follows: TERMS = 1 four stages, TERMS = 3 two.
 struct NhwcSplit {
+    float* ring;                 // fold mode (input gradient of a ReflectionPad2d(1) layer): the border ring, see the epilogue
     const void* w_lo;            // lo plane of the weights (same layout as the hi plane)
     unsigned xp_plane_bytes;     // the activations' lo plane lies this far behind their hi plane
     const float* x_amax;         // device cells: max|x| the activation planes were scaled by, the weight planes' scale
@@ -404,10 +405,24 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
                     if (n >= g.Ntot) continue;
                     const int b = n / g.OHW, rem = n - b * g.OHW;
                     float* yp = y + (size_t)b * g.Cout * g.OHW + rem;
+                    size_t cs = (size_t)g.OHW;               // elements between two output channels of this position
+                    if (sp.ring) {
+                        // the (H + 2) x (W + 2) gradient of a mirrored input: interior pixels go straight into dx [H][W], the border
+                        // ring (top row, bottom row, left column, right column) into `ring`; conv_nhwc_fold_ring_kernel adds it back
+                        const int oy = rem / g.OW, ox = rem - oy * g.OW, fH = g.OH - 2, fW = g.OW - 2, RL = 2 * g.OW + 2 * fH;
+                        if (oy >= 1 && oy <= fH && ox >= 1 && ox <= fW) {
+                            cs = (size_t)fH * fW;
+                            yp = y + (size_t)b * g.Cout * cs + (size_t)(oy - 1) * fW + (ox - 1);
+                        } else {
+                            cs = (size_t)RL;
+                            const int ri = oy == 0 ? ox : oy == fH + 1 ? g.OW + ox : ox == 0 ? 2 * g.OW + (oy - 1) : 2 * g.OW + fH + (oy - 1);
+                            yp = sp.ring + (size_t)b * g.Cout * cs + ri;
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int co = corow + i * 32 + (r & 3) + 8 * (r >> 2);
-                        if (co < g.Cout) yp[(size_t)co * g.OHW] = acc[i][j][r] * oscale + bv[r];
+                        if (co < g.Cout) yp[(size_t)co * cs] = acc[i][j][r] * oscale + bv[r];
                     }
                 }
             }
@@ -415,6 +430,42 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
         u0 += nseg;
         if (SK && u0 < u1) __syncthreads();      // every wave is done with the LDS stages before the next segment refills them
     } while (SK && u0 < u1);
+}
+
+// dx [H][W] += the mirrored border of the padded gradient (nn.ReflectionPad2d(1) backward): padded row 0 folds onto row 1, row H+1
+// onto row H-2, likewise the columns (corners onto (1,1), (1,W-2), ...).  One thread per TARGET pixel (rows 1 / H-2, columns
+// 1 / W-2: 2 W + 2 (H - 2) of them per plane) gathers its up to three ring elements: no atomics.  ring = [top W+2 | bottom W+2 |
+// left H | right H] per plane, written by the GEMM epilogue above.
+__global__ __launch_bounds__(256) void conv_nhwc_fold_ring_kernel(const float* __restrict__ ring, float* __restrict__ dx, int H, int W) {
+    const int OW = W + 2, RL = 2 * OW + 2 * H, NTG = 2 * W + 2 * (H - 2);
+    const float* rg = ring + (size_t)blockIdx.x * RL;
+    float* o = dx + (size_t)blockIdx.x * H * W;
+    for (int t = threadIdx.x; t < NTG; t += 256) {
+        int y, x;
+        if (t < W) { y = 1; x = t; }
+        else if (t < 2 * W) { y = H - 2; x = t - W; }
+        else {                                             // the two columns, rows other than 1 and H-2
+            const int u = t - 2 * W, k = u >> 1;
+            y = k == 0 ? 0 : k + 1;                        // 0, 2, 3, ..., H-3, H-1  (skipping 1 and H-2)
+            if (y >= H - 2) y += 1;
+            x = (u & 1) ? W - 2 : 1;
+        }
+        float acc = 0.f;
+        // rows: padded row 0 -> y == 1, padded row H+1 -> y == H-2; the ring rows hold padded columns 0 .. W+1
+        const float* rows[2] = {rg, rg + OW};
+        const bool hit[2] = {y == 1, y == H - 2};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+            if (hit[a]) {
+                acc += rows[a][x + 1];
+                if (x == 1) acc += rows[a][0];
+                if (x == W - 2) acc += rows[a][W + 1];
+            }
+        // columns: padded column 0 -> x == 1, padded column W+1 -> x == W-2; the ring columns hold padded rows 1 .. H
+        if (x == 1) acc += rg[2 * OW + y];
+        if (x == W - 2) acc += rg[2 * OW + H + y];
+        o[(size_t)y * W + x] += acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -674,8 +725,8 @@ extern "C" long long cocos_conv2d_nhwc_bf16_workspace_bytes(void) {
 }
 
 static int cocos_nhwc_gemm_impl(const void* xp, const void* w_hi, const void* w_lo, const float* w_scale_dev, const float* x_amax_dev,
-                          const float* bias, float* y, void* workspace, long long workspace_bytes, int B, int Cp, int Hp, int Wp,
-                          int Cout, int KH, int KW, int dil, int stride, cocos_stream_t stream, const char* who) {
+                          const float* bias, float* y, float* fold_ring, void* workspace, long long workspace_bytes, int B, int Cp,
+                          int Hp, int Wp, int Cout, int KH, int KW, int dil, int stride, cocos_stream_t stream, const char* who) {
     using namespace cocos;
     const bool split = w_lo != nullptr;
     COCOS_REQUIRE(xp && w_hi && y, COCOS_ERR_INVALID, "%s: null pointer", who);
@@ -694,7 +745,8 @@ static int cocos_nhwc_gemm_impl(const void* xp, const void* w_hi, const void* w_
     COCOS_REQUIRE(aligned16(xp) && aligned16(w_hi) && (!split || aligned16(w_lo)), COCOS_ERR_UNSUPPORTED,
                   "%s: operands must be 16-byte aligned", who);
     g.Ntot = (int)ntot; g.xp_bytes = (unsigned)xbytes; g.w_bytes = (unsigned)wbytes;
-    NhwcSplit sp{w_lo, (unsigned)xbytes, x_amax_dev, w_scale_dev};
+    COCOS_REQUIRE(!fold_ring || (stride == 1 && g.OH >= 6 && g.OW >= 6), COCOS_ERR_INVALID, "%s: fold mode needs stride 1 and H, W >= 4", who);
+    NhwcSplit sp{fold_ring, w_lo, (unsigned)xbytes, x_amax_dev, w_scale_dev};
     // tile: 256 rows unless the layer has at most 128 (a half-empty 256-row tile costs what a full one does); 256 columns
     // when that still gives the CUs something each
     const int cus = nhwc_cu_count() < 1024 ? nhwc_cu_count() : 1024;
@@ -738,6 +790,8 @@ static int cocos_nhwc_gemm_impl(const void* xp, const void* w_hi, const void* w_
     }
 #undef COCOS_NHWC_GO
 #undef COCOS_NHWC_GO_W
+    if (fold_ring)
+        hipLaunchKernelGGL(conv_nhwc_fold_ring_kernel, dim3((unsigned)(B * Cout)), dim3(256), 0, s, fold_ring, y, g.OH - 2, g.OW - 2);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -745,23 +799,23 @@ static int cocos_nhwc_gemm_impl(const void* xp, const void* w_hi, const void* w_
 // y fp32 [B][Cout][OH][OW] = bias + conv(xp), xp bf16 [B][Hp][Wp][Cp] already padded (cocos_conv2d_nhwc_prep_bf16),
 // OH = (Hp - dil (KH-1) - 1) / stride + 1, OW likewise; w_planes = cocos_conv2d_weight_planes(mode | 2): bf16 [KH*KW*Cp/32][Cout][32].
 // workspace (nullable): see cocos_conv2d_nhwc_bf16_workspace_bytes — without it every launch is one tile per workgroup.
-extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias, float* y, void* workspace,
-                                      long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil,
-                                      int stride, cocos_stream_t stream) {
-    return cocos_nhwc_gemm_impl(xp, w_planes, nullptr, nullptr, nullptr, bias, y, workspace, workspace_bytes, B, Cp, Hp, Wp, Cout, KH, KW,
-                          dil, stride, stream, "conv2d_nhwc_bf16");
+extern "C" int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias, float* y, float* fold_ring,
+                                      void* workspace, long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW,
+                                      int dil, int stride, cocos_stream_t stream) {
+    return cocos_nhwc_gemm_impl(xp, w_planes, nullptr, nullptr, nullptr, bias, y, fold_ring, workspace, workspace_bytes, B, Cp, Hp, Wp,
+                                Cout, KH, KW, dil, stride, stream, "conv2d_nhwc_bf16");
 }
 
 // K16c: the same GEMM on f16 hi/lo planes with three MFMA terms per product (fp32-accurate): xp from cocos_conv2d_nhwc_prep_f16x3
 // (scaled by the power of two of *x_amax_dev), w_hi / w_lo / *w_scale_dev from cocos_conv2d_weight_planes (mode 0 | 1).
 extern "C" int cocos_conv2d_nhwc_f16x3(const void* xp, const void* w_hi, const void* w_lo, const float* w_scale_dev,
-                                       const float* x_amax_dev, const float* bias, float* y, void* workspace, long long workspace_bytes,
-                                       int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil, int stride,
-                                       cocos_stream_t stream) {
+                                       const float* x_amax_dev, const float* bias, float* y, float* fold_ring, void* workspace,
+                                       long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil,
+                                       int stride, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(w_lo && w_scale_dev, COCOS_ERR_INVALID, "conv2d_nhwc_f16x3: null pointer");
-    return cocos_nhwc_gemm_impl(xp, w_hi, w_lo, w_scale_dev, x_amax_dev, bias, y, workspace, workspace_bytes, B, Cp, Hp, Wp, Cout, KH, KW,
-                                dil, stride, stream, "conv2d_nhwc_f16x3");
+    return cocos_nhwc_gemm_impl(xp, w_hi, w_lo, w_scale_dev, x_amax_dev, bias, y, fold_ring, workspace, workspace_bytes, B, Cp, Hp, Wp,
+                                Cout, KH, KW, dil, stride, stream, "conv2d_nhwc_f16x3");
 }
 
 extern "C" int cocos_conv2d_nhwc_wgrad_bf16_slices(int B, int OH, int OW, int Cp, int Cout, int KH, int KW) {

@@ -917,15 +917,26 @@ def conv_nhwc_prep_split(x: torch.Tensor, pad: int, reflect: bool, amax: torch.T
     return xp
 
 
-def _conv_nhwc_split_call(xp, wh, wl, ws, xa, bias, Cout, KH, KW, dil, stride=1):
-    _, B, Hp, Wp, Cp = xp.shape
+def _nhwc_out(xp_shape, Cout, KH, KW, dil, stride, fold, device):
+    """Output (and, in fold mode, the border ring) of a K16b / K16c GEMM: fold = the layer sits behind nn.ReflectionPad2d(1) and this
+    is its input gradient — y is the UNPADDED dx, the mirrored border comes back through the ring."""
+    B, Hp, Wp = xp_shape[-4], xp_shape[-3], xp_shape[-2]
     if Hp <= dil * (KH - 1) or Wp <= dil * (KW - 1):
-        raise ValueError(f"conv2d: kernel {KH}x{KW} (dilation {dil}) does not fit the padded input {tuple(xp.shape)}")
+        raise ValueError(f"conv2d: kernel {KH}x{KW} (dilation {dil}) does not fit the padded input {tuple(xp_shape)}")
     OH, OW = (Hp - dil * (KH - 1) - 1) // stride + 1, (Wp - dil * (KW - 1) - 1) // stride + 1
-    y = torch.empty((B, Cout, OH, OW), device=xp.device, dtype=torch.float32)
+    if not fold:
+        return torch.empty((B, Cout, OH, OW), device=device, dtype=torch.float32), None
+    return (torch.empty((B, Cout, OH - 2, OW - 2), device=device, dtype=torch.float32),
+            torch.empty((B, Cout, 2 * OW + 2 * (OH - 2)), device=device, dtype=torch.float32))
+
+
+def _conv_nhwc_split_call(xp, wh, wl, ws, xa, bias, Cout, KH, KW, dil, stride=1, fold=False):
+    _, B, Hp, Wp, Cp = xp.shape
+    y, ring = _nhwc_out(xp.shape, Cout, KH, KW, dil, stride, fold, xp.device)
     wsp = _conv_nhwc_workspace(xp.device, split=True)
     _call("conv2d_fwd", "cocos_conv2d_nhwc_f16x3", xp.data_ptr(), wh.data_ptr(), wl.data_ptr(), ws.data_ptr(), _ptr(xa), _ptr(bias),
-          y.data_ptr(), _ptr(wsp), wsp.numel() * 4 if wsp is not None else 0, B, Cp, Hp, Wp, Cout, KH, KW, dil, int(stride), _stream())
+          y.data_ptr(), _ptr(ring), _ptr(wsp), wsp.numel() * 4 if wsp is not None else 0, B, Cp, Hp, Wp, Cout, KH, KW, dil, int(stride),
+          _stream())
     return y
 
 
@@ -964,14 +975,11 @@ def _conv_nhwc_workspace(device, split=False):
     return ws
 
 
-def _conv_nhwc_call(xp, planes, bias, Cout, KH, KW, dil, stride=1):
+def _conv_nhwc_call(xp, planes, bias, Cout, KH, KW, dil, stride=1, fold=False):
     B, Hp, Wp, Cp = xp.shape
-    OH, OW = (Hp - dil * (KH - 1) - 1) // stride + 1, (Wp - dil * (KW - 1) - 1) // stride + 1
-    if Hp <= dil * (KH - 1) or Wp <= dil * (KW - 1):
-        raise ValueError(f"conv2d: kernel {KH}x{KW} (dilation {dil}) does not fit the padded input {tuple(xp.shape)}")
-    y = torch.empty((B, Cout, OH, OW), device=xp.device, dtype=torch.float32)
+    y, ring = _nhwc_out(xp.shape, Cout, KH, KW, dil, stride, fold, xp.device)
     ws = _conv_nhwc_workspace(xp.device)
-    _call("conv2d_fwd", "cocos_conv2d_nhwc_bf16", xp.data_ptr(), planes.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(ws),
+    _call("conv2d_fwd", "cocos_conv2d_nhwc_bf16", xp.data_ptr(), planes.data_ptr(), _ptr(bias), y.data_ptr(), _ptr(ring), _ptr(ws),
           ws.numel() * 4 if ws is not None else 0, B, Cp, Hp, Wp, Cout, KH, KW, dil, int(stride), _stream())
     return y
 
@@ -1085,13 +1093,14 @@ class _Conv2d(torch.autograd.Function):
         if dx_nhwc or (need_w and xp is not None):
             # dy as the NHWC operand (bf16, or f16 hi/lo planes), with the border the input gradient needs
             dyp = conv_nhwc_prep(dy, q if dx_nhwc else 0) if bf else conv_nhwc_prep_split(dy, q if dx_nhwc else 0, False, ga)
+        fold = bool(dx_nhwc and reflect == 1 and H - 2 >= 4 and W - 2 >= 4)     # the mirrored border folded back by the GEMM itself
         if need_x:
             if dx_nhwc and not bf:
                 th, tl, ts = _conv_weight_planes(weight, wa, 1)
-                dx = _conv_nhwc_split_call(dyp, th, tl, ts, ga, None, Cin, KH, KW, dil)
+                dx = _conv_nhwc_split_call(dyp, th, tl, ts, ga, None, Cin, KH, KW, dil, fold=fold)
             elif dx_nhwc:
                 th, _, _ = _conv_weight_planes(weight, None, 1)
-                dx = _conv_nhwc_call(dyp, th, None, Cin, KH, KW, dil)
+                dx = _conv_nhwc_call(dyp, th, None, Cin, KH, KW, dil, fold=fold)
             elif stride == 1 and q >= 0 and KW == KH:
                 # dx = conv(dy, flipped weights with the channel roles swapped, padding d(K-1)-p): the same kernel
                 th, tl, ts = _conv_weight_planes(weight, wa, 1)
@@ -1128,7 +1137,7 @@ class _Conv2d(torch.autograd.Function):
             _call("conv2d_wgrad", "cocos_conv2d_wgrad_reduce", part.data_ptr(), dw.data_ptr(), S, Cout, Cin, KH, KW, _stream())
         if need_b and has_bias:
             db = channel_sum(dy)
-        if reflect and dx is not None:          # fold the mirrored border back (K18's backward gather)
+        if reflect and dx is not None and not fold:          # fold the mirrored border back (K18's backward gather)
             dxp, dx = dx, torch.empty(ctx.x_shape, device=dy.device, dtype=torch.float32)
             _call("reflect_pad2d_bwd", "cocos_reflect_pad2d_bwd", dxp.data_ptr(), dx.data_ptr(), B * Cin, ctx.x_shape[2], ctx.x_shape[3],
                   reflect, _stream())

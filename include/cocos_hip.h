@@ -632,6 +632,10 @@ int cocos_debug_mfma_probe(float* out, cocos_stream_t stream);
  *   cocos_conv2d_nhwc_bf16:  y fp32 [B][Cout][OH][OW] = bias + conv(xp) with NO further padding,
  *       OH = (Hp - dil (KH-1) - 1) / stride + 1, OW likewise; w_planes = cocos_conv2d_weight_planes(mode | 2) ([KH*KW*Cp/32][Cout][32] bf16).
  *       The input gradient of a stride-1 layer is this call on prep(dy, dil (K-1) - pad, 0) with the mode-1 planes.
+ *       fold_ring (input gradient of a layer behind nn.ReflectionPad2d(1), stride 1): y is then dx [B][Cout][OH-2][OW-2] — the
+ *       interior of the (OH x OW) padded gradient is stored straight into it, the border ring goes to fold_ring
+ *       ([B][Cout][2 OW + 2 (OH-2)] floats) and a second small launch adds it back mirrored: nn.ReflectionPad2d's backward without
+ *       the padded tensor or a pass over it.
  *       workspace: zero-initialised scratch of cocos_conv2d_nhwc_bf16_workspace_bytes() bytes, one per stream, cleared once by
  *       the caller (every launch leaves its flags zero): with it, a layer whose tile count is just above a multiple of the CU
  *       count runs as ONE workgroup per CU over contiguous ranges of (tile, k-step) units ("stream-K"; a cut tile's two parts
@@ -648,17 +652,17 @@ int cocos_conv2d_nhwc_bf16_supported(int Cin, int Cout, int KH, int KW, int stri
 int cocos_conv2d_nhwc_prep_f16x3(const float* x, void* xp, const float* amax_dev /* nullable: scale 1 */, int B, int C, int H, int W,
                                  int pad, int reflect, cocos_stream_t stream);
 int cocos_conv2d_nhwc_f16x3(const void* xp, const void* w_hi, const void* w_lo, const float* w_scale_dev, const float* x_amax_dev,
-                            const float* bias /* nullable */, float* y, void* workspace /* nullable: as cocos_conv2d_nhwc_bf16 */,
-                            long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH, int KW, int dil, int stride,
-                            cocos_stream_t stream);
+                            const float* bias /* nullable */, float* y, float* fold_ring /* nullable */,
+                            void* workspace /* nullable: as cocos_conv2d_nhwc_bf16 */, long long workspace_bytes, int B, int Cp, int Hp,
+                            int Wp, int Cout, int KH, int KW, int dil, int stride, cocos_stream_t stream);
 int cocos_conv2d_nhwc_wgrad_f16x3(const void* xp, const void* dyp, const float* x_amax_dev, const float* g_amax_dev, float* partial,
                                   int B, int Cp, int Hp, int Wp, int Cout, int q, int KH, int KW, int dil, int stride,
                                   cocos_stream_t stream);
 int cocos_conv2d_nhwc_prep_bf16(const float* x, void* xp, int B, int C, int H, int W, int pad, int reflect, cocos_stream_t stream);
 long long cocos_conv2d_nhwc_bf16_workspace_bytes(void);
 int cocos_conv2d_nhwc_bf16(const void* xp, const void* w_planes, const float* bias /* nullable */, float* y,
-                           void* workspace /* nullable */, long long workspace_bytes, int B, int Cp, int Hp, int Wp, int Cout, int KH,
-                           int KW, int dil, int stride, cocos_stream_t stream);
+                           float* fold_ring /* nullable */, void* workspace /* nullable */, long long workspace_bytes, int B, int Cp,
+                           int Hp, int Wp, int Cout, int KH, int KW, int dil, int stride, cocos_stream_t stream);
 int cocos_conv2d_nhwc_wgrad_bf16_slices(int B, int OH, int OW, int Cp, int Cout, int KH, int KW);
 int cocos_conv2d_nhwc_wgrad_bf16(const void* xp, const void* dyp, float* partial, int B, int Cp, int Hp, int Wp, int Cout, int q,
                                  int KH, int KW, int dil, int stride, cocos_stream_t stream);
