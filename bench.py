@@ -54,7 +54,7 @@ def _conv_flavour():
     return producers.CONV_BACKEND
 
 
-def module_scope_context(device, d, steps=5, warmup=3):
+def module_scope_context(device, d, steps=8, warmup=6):
     """ms per forward + backward of the whole NoVGGCorrespondence module (batch 8, 256x256, ADE20k flags) with the convolutions
     on K16c (f16x3, the parity-safe default) and on K16b (bf16): what `--scope netcorr` times, reported beside the headline."""
     from cocosnet_amd import ops, producers
