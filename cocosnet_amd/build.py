@@ -53,6 +53,7 @@ HIP_SOURCES = [
     "conv_nhwc_bf16.hip",
     "spade_modulate.hip",
     "reflect_pad.hip",
+    "spectral_norm.hip",
 ]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
              "-Wall", "-Wno-unused-function"]

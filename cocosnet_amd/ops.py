@@ -1718,6 +1718,46 @@ def instnorm_prelu(x, residual, weight, eps: float = INSTNORM_EPS):
     return _InstNormPReLU.apply(x, residual, weight, eps)
 
 
+# ------------------------------------------------------------------------------------------
+# K21  torch.nn.utils.spectral_norm's weight: power iteration + W / sigma, and its backward   (spectral_norm.hip)
+# ------------------------------------------------------------------------------------------
+class _SpectralWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, u, v, power_iteration: bool, eps: float):
+        w = _chk(weight, "spectral_weight: weight")
+        R = w.shape[0]
+        K = w.numel() // R
+        if u.shape != (R,) or v.shape != (K,) or not (u.is_contiguous() and v.is_contiguous()):
+            raise ValueError(f"spectral_weight: weight {tuple(w.shape)} with u {tuple(u.shape)} / v {tuple(v.shape)}")
+        lib = _lib.load()
+        wsn = torch.empty_like(w)
+        sigma = torch.empty(1, device=w.device, dtype=torch.float32)
+        ws = torch.empty(lib.cocos_spectral_weight_workspace_floats(R, K), device=w.device, dtype=torch.float32)
+        _call("spectral_weight_fwd", "cocos_spectral_weight_fwd", w.data_ptr(), u.data_ptr(), v.data_ptr(), wsn.data_ptr(), sigma.data_ptr(),
+              ws.data_ptr(), R, K, float(eps), int(bool(power_iteration)), _stream())
+        # the vectors sigma was taken with: copies, because the next forward (GAN training: D(real), D(fake)) updates the buffers in place
+        ctx.save_for_backward(w, u.clone(), v.clone(), sigma)
+        return wsn
+
+    @staticmethod
+    def backward(ctx, g):
+        w, u, v, sigma = ctx.saved_tensors
+        g = _chk(g, "spectral_weight: grad")
+        R = w.shape[0]
+        K = w.numel() // R
+        dw = torch.empty_like(w)
+        ws = torch.empty(1024, device=w.device, dtype=torch.float32)
+        _call("spectral_weight_bwd", "cocos_spectral_weight_bwd", g.data_ptr(), w.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(),
+              dw.data_ptr(), ws.data_ptr(), R, K, _stream())
+        return dw, None, None, None, None
+
+
+def spectral_weight(weight, u, v, power_iteration: bool, eps: float = 1e-12):
+    """`SpectralNorm.compute_weight` of torch.nn.utils.spectral_norm (dim 0, one power iteration): u, v updated in place when
+    `power_iteration`, returns weight / (u . W v) with the framework's gradient (through sigma as well) — K21."""
+    return _SpectralWeight.apply(weight, u, v, bool(power_iteration), float(eps))
+
+
 #: softmax_attention on the fused kernels for K < 256 as well (channels zero-padded to 256); "0": the materialised family
 ATTENTION_FUSED = os.environ.get("COCOS_ATTENTION_FUSED", "1") != "0"
 

@@ -61,6 +61,37 @@ class Conv2d(nn.Conv2d):
         return super()._conv_forward(input, weight, bias)
 
 
+#: "0": spectral-normed layers keep the framework's compute_weight (A/B runs)
+SPECTRAL_HIP = os.environ.get("COCOS_SPECTRAL", "1") != "0"
+
+import importlib                                            # noqa: E402
+_sn_mod = importlib.import_module("torch.nn.utils.spectral_norm")    # the MODULE (torch.nn.utils re-exports its function under the same name)
+
+
+class _SpectralNormHIP(_sn_mod.SpectralNorm):
+    """torch.nn.utils.spectral_norm's hook with `compute_weight` on K21 (ops.spectral_weight) for fp32 GPU weights: same buffers
+    (weight_orig / weight_u / weight_v: checkpoints unchanged), same in-place update of u and v, same gradient — four launches
+    forward and two backward instead of ~20 framework launches per layer and step."""
+
+    def compute_weight(self, module, do_power_iteration):
+        weight = getattr(module, self.name + "_orig")
+        if (SPECTRAL_HIP and CONV_BACKEND in _HIP_BACKENDS and weight.is_cuda and weight.dtype == torch.float32 and self.dim == 0
+                and self.n_power_iterations == 1 and weight.is_contiguous() and weight.numel() // weight.shape[0] <= 16384):
+            from . import ops
+            return ops.spectral_weight(weight, getattr(module, self.name + "_u"), getattr(module, self.name + "_v"),
+                                       do_power_iteration, self.eps)
+        return super().compute_weight(module, do_power_iteration)
+
+
+def hip_spectral_norm(module: nn.Module, name: str = "weight") -> nn.Module:
+    """torch.nn.utils.spectral_norm(module), with the hook's weight computation on K21."""
+    module = spectral_norm(module, name)
+    for hook in module._forward_pre_hooks.values():
+        if type(hook) is _sn_mod.SpectralNorm and hook.name == name:
+            hook.__class__ = _SpectralNormHIP
+    return module
+
+
 _pending = threading.local()
 
 
@@ -229,10 +260,10 @@ class SPADEResnetBlock(nn.Module):
         if self.learned_shortcut:
             self.conv_s = Conv2d(fin, fout, 1, bias=False)
         if "spectral" in opt.norm_G:
-            self.conv_0 = spectral_norm(self.conv_0)
-            self.conv_1 = spectral_norm(self.conv_1)
+            self.conv_0 = hip_spectral_norm(self.conv_0)
+            self.conv_1 = hip_spectral_norm(self.conv_1)
             if self.learned_shortcut:
-                self.conv_s = spectral_norm(self.conv_s)
+                self.conv_s = hip_spectral_norm(self.conv_s)
         cfg = opt.norm_G.replace("spectral", "")
         ic = _spade_label_nc(opt)
         self.norm_0 = SPADE(cfg, fin, ic, opt.PONO)
@@ -262,7 +293,7 @@ def nonspade_norm_layer(opt, norm_type):
     def wrap(layer):
         sub = norm_type
         if norm_type.startswith("spectral"):
-            layer = spectral_norm(layer)
+            layer = hip_spectral_norm(layer)
             sub = norm_type[len("spectral"):]
         if sub in ("none", ""):
             return layer

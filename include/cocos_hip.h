@@ -667,6 +667,17 @@ int cocos_conv2d_nhwc_wgrad_bf16_slices(int B, int OH, int OW, int Cp, int Cout,
 int cocos_conv2d_nhwc_wgrad_bf16(const void* xp, const void* dyp, float* partial, int B, int Cp, int Hp, int Wp, int Cout, int q,
                                  int KH, int KW, int dil, int stride, cocos_stream_t stream);
 
+/* K21 (round 3): the weight of torch.nn.utils.spectral_norm — every convolution of the reference's generator / discriminator and of
+ * netCorr's feature producers is wrapped in it (normalization.py:21-61, architecture.py:41-52).  W viewed as [R = out channels][K],
+ * u [R] / v [K] the module's buffers.  fwd: (power_iteration: v <- normalize(W^T u), u <- normalize(W v), in place, ONE iteration)
+ * sigma = u . (W v), wsn = W / sigma, *sigma_out = sigma; workspace: cocos_spectral_weight_workspace_floats(R, K) floats.
+ * bwd: dW = G / sigma - (sum(G o W) / sigma^2) u v^T with the u, v sigma was taken with; workspace: 1024 floats. */
+long long cocos_spectral_weight_workspace_floats(int R, int K);
+int cocos_spectral_weight_fwd(const float* W, float* u, float* v, float* wsn, float* sigma_out, float* workspace, int R, int K, float eps,
+                              int power_iteration, cocos_stream_t stream);
+int cocos_spectral_weight_bwd(const float* G, const float* W, const float* u, const float* v, const float* sigma_dev, float* dW,
+                              float* workspace, int R, int K, cocos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -391,3 +391,34 @@ def test_conv2d_bf16_nhwc_stream_k_equals_one_tile_per_workgroup(Cout, tile, pre
     assert ws is not None and int(ws[:1024].abs().sum()) == 0          # every flag back to zero
     yr = torch.nn.functional.conv2d(x.double(), w.double(), b.double())
     assert (y.double() - yr).abs().max().item() / yr.abs().max().item() <= (1.5e-2 if prec == "bf16" else 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(407, 407, 3, 3), (64, 151, 3, 3), (512, 128, 3, 3), (256, 256, 1, 1), (5, 3, 4, 4)])
+def test_spectral_weight_matches_the_framework_hook(shape, monkeypatch):
+    """K21 against torch.nn.utils.spectral_norm's own compute_weight on the same buffers: the normalised weight, the IN-PLACE update of
+    u and v, the gradient through W / sigma (sigma = u . W v depends on W), training and eval mode, two forwards before one backward
+    (the GAN pattern the framework clones u / v for)."""
+    from cocosnet_amd import producers
+    monkeypatch.setattr(producers, "CONV_BACKEND", "f16x3")
+    cout, cin, k, _ = shape
+    res = {}
+    for hip in (True, False):
+        monkeypatch.setattr(producers, "SPECTRAL_HIP", hip)
+        torch.manual_seed(3)
+        conv = producers.hip_spectral_norm(torch.nn.Conv2d(cin, cout, k)).cuda()
+        g = torch.Generator(device="cuda").manual_seed(4)
+        x1 = torch.randn(2, cin, 8, 8, device="cuda", generator=g)
+        x2 = torch.randn(2, cin, 8, 8, device="cuda", generator=g)
+        conv.train()
+        monkeypatch.setattr(producers, "CONV_BACKEND", "torch" if not hip else "f16x3")     # reference arm: everything on the framework
+        y = conv(x1).square().mean() - conv(x2).square().mean()       # two forwards (two power iterations), then backward
+        w_train = conv.weight.detach().clone()
+        y.backward()
+        conv.eval()
+        with torch.no_grad():
+            conv(x1)
+        res[hip] = (w_train, conv.weight_u.clone(), conv.weight_v.clone(), conv.weight_orig.grad.clone(), conv.weight.detach().clone())
+        monkeypatch.setattr(producers, "CONV_BACKEND", "f16x3")
+    for a, r, what in zip(res[True], res[False], ("weight (train)", "u", "v", "d weight_orig", "weight (eval)")):
+        e = (a - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+        assert e <= (2e-4 if what == "d weight_orig" else 2e-5), f"{shape} {what}: {e:.3e}"
