@@ -422,3 +422,47 @@ def test_spectral_weight_matches_the_framework_hook(shape, monkeypatch):
     for a, r, what in zip(res[True], res[False], ("weight (train)", "u", "v", "d weight_orig", "weight (eval)")):
         e = (a - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
         assert e <= (2e-4 if what == "d weight_orig" else 2e-5), f"{shape} {what}: {e:.3e}"
+
+
+def _sweep_cases():
+    """Seeded sweep of layer shapes around the K16b / K16c limits: output widths that are and are not whole k-steps of 32, channel
+    counts next to the 32 / 128 / 256 boundaries, batch sizes that leave position tails, kernel sizes 1..5, strides and dilations."""
+    import random
+    rnd = random.Random(20250926)
+    cases = []
+    while len(cases) < 14:
+        k = rnd.choice([1, 3, 3, 3, 4, 5])
+        stride = rnd.choice([1, 1, 1, 2, 3])
+        dil = rnd.choice([1, 1, 2]) if k > 1 else 1
+        pad = rnd.choice([0, (dil * (k - 1)) // 2, dil * (k - 1)])
+        cin = rnd.choice([32, 33, 47, 64, 96, 127, 128, 130, 200])
+        cout = rnd.choice([128, 129, 160, 255, 256, 257, 300])
+        B = rnd.choice([1, 2, 3, 5])
+        ow = rnd.choice([32, 64, 96, 33, 40, 7])
+        oh = rnd.choice([1, 3, 8, 17])
+        H = (oh - 1) * stride + dil * (k - 1) + 1 - 2 * pad
+        W = (ow - 1) * stride + dil * (k - 1) + 1 - 2 * pad
+        if H < 1 or W < 1 or B * cin * H * W > 6e6:
+            continue
+        cases.append((B, cin, H, W, cout, k, stride, pad, dil))
+    return cases
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16", 1.5e-2), ("f16x3", 1e-5)])
+@pytest.mark.parametrize("case", _sweep_cases(), ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_nhwc_shape_sweep_vs_fp64(case, prec, tol, monkeypatch):
+    from cocosnet_amd import ops
+    B, Cin, H, W, Cout, k, stride, pad, dil = case
+    monkeypatch.setattr(ops, "CONV_PRECISION", prec)
+    g = torch.Generator(device="cuda").manual_seed(31)
+    x0 = torch.randn(B, Cin, H, W, device="cuda", generator=g)
+    w0 = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) / (Cin * k * k) ** 0.5
+    b0 = torch.randn(Cout, device="cuda", generator=g)
+    x, w, b = (t.clone().requires_grad_(True) for t in (x0, w0, b0))
+    y = ops.conv2d(x, w, b, stride, pad, dil)
+    go = torch.randn(y.shape, device="cuda", generator=g)
+    y.backward(go)
+    yr, dxr, dwr, dbr = _ref(x0, w0, b0, stride, pad, go, dil)
+    for a, r, what in ((y, yr, "y"), (x.grad, dxr, "dx"), (w.grad, dwr, "dw"), (b.grad, dbr, "db")):
+        e = (a.double() - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
+        assert e <= tol, f"{prec} {what}: {e:.3e}"
