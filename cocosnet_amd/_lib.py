@@ -137,7 +137,7 @@ _SIGNATURES = {
     "cocos_conv2d_nhwc_wgrad_bf16_slices": (ctypes.c_int, [ctypes.c_int] * 7),
     "cocos_conv2d_nhwc_wgrad_bf16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 10 + [_stream_t]),
     "cocos_spectral_weight_workspace_floats": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int]),
-    "cocos_spectral_weight_fwd": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _stream_t]),
+    "cocos_spectral_weight_fwd": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _stream_t]),
     "cocos_spectral_weight_bwd": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int, ctypes.c_int, _stream_t]),
     "cocos_channel_sum_slices": (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong]),
     "cocos_channel_sum": (ctypes.c_int, [_c_float_p, _c_float_p, _c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, _stream_t]),

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ W,
 // sigma from s (every workgroup recomputes it: R values), optionally u <- normalize(s) (workgroup 0 writes), then Wsn = W / sigma
 __global__ __launch_bounds__(256) void sn_apply_kernel(const float* __restrict__ W, const float* __restrict__ s, float* __restrict__ u,
                                                        float* __restrict__ wsn, float* __restrict__ sigma_out, int R, size_t n,
-                                                       float eps, int update_u) {
+                                                       float eps, int update_u, unsigned* __restrict__ amax_cell) {
     __shared__ float red[4];
     float a = 0.f;
     if (update_u) {
@@ -90,7 +90,20 @@ __global__ __launch_bounds__(256) void sn_apply_kernel(const float* __restrict__
         sigma = tot;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *sigma_out = sigma;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) wsn[i] = W[i] / sigma;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float q = W[i] / sigma;
+        wsn[i] = q;
+        m = fmaxf(m, fabsf(q));
+    }
+    if (amax_cell) {          // max|W / sigma| for the consumer's f16 split (one atomic per workgroup, <= 512 of them: finding 14)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(amax_cell, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    }
 }
 
 // backward:  dW = G / sigma - (sum(G o W) / sigma^2) u v^T      (W the ORIGINAL weight; u, v the vectors sigma was taken with)
@@ -126,8 +139,8 @@ extern "C" long long cocos_spectral_weight_workspace_floats(int R, int K) {
 
 // wsn = W / sigma with sigma = u . (W v); power_iteration != 0: first v <- normalize(W^T u), u <- normalize(W v) in place (one
 // iteration: torch.nn.utils.spectral_norm's n_power_iterations = 1).  sigma_out: device float (kept for the backward).
-extern "C" int cocos_spectral_weight_fwd(const float* W, float* u, float* v, float* wsn, float* sigma_out, float* workspace, int R,
-                                         int K, float eps, int power_iteration, cocos_stream_t stream) {
+extern "C" int cocos_spectral_weight_fwd(const float* W, float* u, float* v, float* wsn, float* sigma_out, float* amax_inout_dev,
+                                         float* workspace, int R, int K, float eps, int power_iteration, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(W && u && v && wsn && sigma_out && workspace, COCOS_ERR_INVALID, "spectral_weight_fwd: null pointer");
     COCOS_REQUIRE(R >= 1 && K >= 1 && eps >= 0.f, COCOS_ERR_INVALID, "spectral_weight_fwd: bad dims R=%d K=%d", R, K);
@@ -144,8 +157,9 @@ extern "C" int cocos_spectral_weight_fwd(const float* W, float* u, float* v, flo
     hipLaunchKernelGGL(sn_wv_kernel, dim3((unsigned)R), dim3(256), 0, st, W, v, s, R, K);
     const size_t n = (size_t)R * K;
     const size_t blocks = (n + 256 * 8 - 1) / (256 * 8);
-    hipLaunchKernelGGL(sn_apply_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, W, s, u, wsn, sigma_out, R, n,
-                       eps, power_iteration ? 1 : 0);
+    const size_t cap = amax_inout_dev ? 512 : 2048;
+    hipLaunchKernelGGL(sn_apply_kernel, dim3((unsigned)(blocks > cap ? cap : blocks)), dim3(256), 0, st, W, s, u, wsn, sigma_out, R, n,
+                       eps, power_iteration ? 1 : 0, reinterpret_cast<unsigned*>(amax_inout_dev));
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

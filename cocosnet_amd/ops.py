@@ -1040,7 +1040,9 @@ class _Conv2d(torch.autograd.Function):
             xa = _recall_amax(x)
             if xa is None:
                 xa = absmax(x)
-            wa = absmax(weight)
+            wa = _recall_amax(weight)          # K21 leaves it for spectral-normed layers
+            if wa is None:
+                wa = absmax(weight)
         wh, wl, ws = _conv_weight_planes(weight, wa, 0)
         xp = None
         if wa is not None and CONV_NHWC_F16X3 and _conv_nhwc_ok(Cin, Cout, KH, KW, stride):
@@ -1733,8 +1735,10 @@ class _SpectralWeight(torch.autograd.Function):
         wsn = torch.empty_like(w)
         sigma = torch.empty(1, device=w.device, dtype=torch.float32)
         ws = torch.empty(lib.cocos_spectral_weight_workspace_floats(R, K), device=w.device, dtype=torch.float32)
+        cell = _zero_cell(w.device)        # max|W / sigma| as a by-product: the convolution that consumes the weight splits it with it
         _call("spectral_weight_fwd", "cocos_spectral_weight_fwd", w.data_ptr(), u.data_ptr(), v.data_ptr(), wsn.data_ptr(), sigma.data_ptr(),
-              ws.data_ptr(), R, K, float(eps), int(bool(power_iteration)), _stream())
+              cell.data_ptr(), ws.data_ptr(), R, K, float(eps), int(bool(power_iteration)), _stream())
+        _remember_amax(wsn, cell)
         # the vectors sigma was taken with: copies, because the next forward (GAN training: D(real), D(fake)) updates the buffers in place
         ctx.save_for_backward(w, u.clone(), v.clone(), sigma)
         return wsn

@@ -673,8 +673,9 @@ int cocos_conv2d_nhwc_wgrad_bf16(const void* xp, const void* dyp, float* partial
  * sigma = u . (W v), wsn = W / sigma, *sigma_out = sigma; workspace: cocos_spectral_weight_workspace_floats(R, K) floats.
  * bwd: dW = G / sigma - (sum(G o W) / sigma^2) u v^T with the u, v sigma was taken with; workspace: 1024 floats. */
 long long cocos_spectral_weight_workspace_floats(int R, int K);
-int cocos_spectral_weight_fwd(const float* W, float* u, float* v, float* wsn, float* sigma_out, float* workspace, int R, int K, float eps,
-                              int power_iteration, cocos_stream_t stream);
+int cocos_spectral_weight_fwd(const float* W, float* u, float* v, float* wsn, float* sigma_out,
+                              float* amax_inout_dev /* nullable: max(*cell, max|wsn|), cell zeroed by the caller */, float* workspace,
+                              int R, int K, float eps, int power_iteration, cocos_stream_t stream);
 int cocos_spectral_weight_bwd(const float* G, const float* W, const float* u, const float* v, const float* sigma_dev, float* dW,
                               float* workspace, int R, int K, cocos_stream_t stream);
 
