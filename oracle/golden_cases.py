@@ -55,11 +55,36 @@ CASES = {
     "patch_256": dict(opt=dict(match_kernel=1, warp_patch=True, warp_cycle_w=1.0,
                                warp_mask_losstype="none", isTrain=True),
                       B=1, size=256, nc=3, seg="float", sample=4096),
+    # ---- round 4: README flag sets that had no fixture ------------------------------------
+    # CelebA-HQ mask-to-face TRAINING (README.md:97): `--warp_mask_losstype direct` together with `--warp_cycle_w 0.1`
+    # and `--warp_bilinear`, on the shipped default match_kernel 3 and on match_kernel 1; label_nc = 19
+    # (celebahq_dataset.py:25).  R1 carries [rgb | 19 labels], C1 the cycle term: both softmax directions, V of C1
+    # differentiated, in ONE graph.
+    "celebamask_train_mk3": dict(opt=dict(match_kernel=3, warp_bilinear=True, warp_cycle_w=0.1,
+                                          warp_mask_losstype="direct", isTrain=True),
+                                 B=2, size=32, nc=19, seg="onehot", grads=True, seed=2001),
+    "celebamask_train_mk1": dict(opt=dict(match_kernel=1, warp_bilinear=True, warp_cycle_w=0.1,
+                                          warp_mask_losstype="direct", isTrain=True),
+                                 B=2, size=32, nc=19, seg="onehot", grads=True, seed=2002),
+    # DeepFashion TRAINING (README.md:115): `--warp_patch` on the default match_kernel 3 (+ `--warp_bilinear`, no mask
+    # loss); label_nc = 20 float maps (deepfashion_dataset.py:27).  256x256 image (F.fold(y, 256, ...) at :321) ->
+    # 64x64 grid, V = 48 patch channels: the fused match_kernel-3 family at its real width.  Outputs AND gradients are
+    # stored as seeded samples (the full gradients would be 8 MB).
+    "fashion_patch_mk3": dict(opt=dict(match_kernel=3, warp_patch=True, warp_bilinear=True,
+                                       warp_mask_losstype="none", isTrain=True),
+                              B=1, size=256, nc=20, seg="float", sample=4096, grads=True, seed=2003),
 }
+
+# Seeds of the round-1 cases = 1000 + their rank in the sorted list of the round-1 names (frozen: adding a case must
+# not move anyone else's seed); later cases carry an explicit `seed`.
+_ROUND1_ORDER = ("ade_mk1", "ade_mk3", "b1_showcorr", "celeba_cycle", "mask_cycle", "noponoc_mk1", "noponoc_mk3",
+                 "patch_256", "ragged_44", "return_corr", "stride2", "temp_005", "wta_half")
 
 
 def case_seed(name: str) -> int:
-    return 1000 + sorted(CASES).index(name)
+    if "seed" in CASES[name]:
+        return int(CASES[name]["seed"])
+    return 1000 + _ROUND1_ORDER.index(name)
 
 
 def make_inputs(name: str):
@@ -103,6 +128,19 @@ def sample_index(name: str, key: str, numel: int, n: int):
     """Seeded flat indices used when only a sample of a big output tensor is stored."""
     rs = np.random.RandomState(case_seed(name) + 104729 + sum(map(ord, key)))
     return np.sort(rs.choice(numel, size=min(n, numel), replace=False))
+
+
+def grad_error(name: str, key: str, got, golden) -> float:
+    """max |got - ref| / max |ref| of a stored gradient (`key` = 'theta_raw' | 'phi_raw'); sampled cases store a
+    seeded sample of the gradient (`gsample__*`) and compare that sample."""
+    got = np.asarray(got, dtype=np.float64)
+    if "grad__" + key in golden.files:
+        ref = golden["grad__" + key].astype(np.float64)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+    else:
+        idx = sample_index(name, "grad:" + key, got.size, CASES[name]["sample"])
+        got, ref = got.reshape(-1)[idx], golden["gsample__" + key].astype(np.float64)
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
 
 
 def hot_path_flags(name: str) -> dict:

@@ -64,8 +64,12 @@ def run_reference_case(name: str):
         G = gc.grad_weights(name, {k: tuple(v.shape) for k, v in outs.items()})
         loss = sum((outs[k] * t(G[k])).sum() for k in outs)
         loss.backward()
-        store["grad__theta_raw"] = theta_raw.grad.numpy().astype(np.float32)
-        store["grad__phi_raw"] = phi_raw.grad.numpy().astype(np.float32)
+        for key, g in (("theta_raw", theta_raw.grad), ("phi_raw", phi_raw.grad)):
+            a = g.numpy().astype(np.float32)
+            if c.get("sample", 0):     # big grids: a seeded sample of the gradient (golden_cases.grad_error)
+                store["gsample__" + key] = a.reshape(-1)[gc.sample_index(name, "grad:" + key, a.size, c["sample"])]
+            else:
+                store["grad__" + key] = a
     n_sample = c.get("sample", 0)
     for k, v in outs.items():
         a = v.detach().numpy().astype(np.float32)

@@ -69,8 +69,9 @@ def test_hot_path_matches_reference_fixtures(name, precision):
         G = gc.grad_weights(name, {k: tuple(v.shape) for k, v in res.items()})
         loss = sum((res[k] * dev(G[k])).sum() for k in res)
         loss.backward()
-        assert rel(th.grad, golden["grad__theta_raw"]) < GRAD_TOL
-        assert rel(ph.grad, golden["grad__phi_raw"]) < GRAD_TOL
+        for g, key in ((th.grad, "theta_raw"), (ph.grad, "phi_raw")):
+            err = gc.grad_error(name, key, g.detach().double().cpu().numpy(), golden)
+            assert err < GRAD_TOL, (key, err)
 
 
 # ------------------------------------------------------------------ kernels vs oracle (fp64)
