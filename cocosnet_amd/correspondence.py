@@ -32,9 +32,9 @@ _EPS = __import__("sys").float_info.epsilon
 
 def feature_normalize(x):
     """util.feature_normalize (util/util.py:31-34): x / (||x||_2 over channels + epsilon)."""
-    if x.is_cuda:                       # K1 without the centring: one HBM pass instead of four
+    if x.is_cuda and x.dtype == torch.float32:      # K1 without the centring: one HBM pass instead of four
         return ops.feature_normalize(x, _EPS)
-    return x / (torch.norm(x, 2, 1, keepdim=True) + _EPS)   # CPU: producer parity tests only
+    return x / (torch.norm(x, 2, 1, keepdim=True) + _EPS)   # CPU / fp64: producer parity tests only (the fp64 arbiter of tests/)
 
 
 class NetworkBase(nn.Module):
@@ -150,10 +150,10 @@ class NoVGGCorrespondence(NetworkBase):
                 ref = self.layer(torch.cat((feat_img, ref_seg), 1))
         else:
             cont, ref = self.layer(feat_seg), self.layer(feat_img)
-        if cont.is_cuda:   # :272 / :282 on the fp32-MFMA GEMM (same parameters: checkpoints are unaffected)
+        if cont.is_cuda and cont.dtype == torch.float32:   # :272 / :282 on K0 (same parameters: checkpoints are unaffected)
             return (ops.proj1x1(cont, self.theta.weight, self.theta.bias),
                     ops.proj1x1(ref, self.phi.weight, self.phi.bias))
-        return self.theta(cont), self.phi(ref)   # CPU: producer parity tests only; the hot path needs a GPU
+        return self.theta(cont), self.phi(ref)   # CPU / fp64: producer parity tests only; the hot path needs a GPU and fp32
 
     def forward(self, ref_img, real_img, seg_map, ref_seg_map, temperature=0.01, detach_flag=False,
                 WTA_scale_weight=1, alpha=1, return_corr=False):

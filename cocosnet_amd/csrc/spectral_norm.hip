@@ -10,8 +10,9 @@
 
 namespace cocos {
 
-constexpr int SN_ROWS = 8;       // rows per workgroup of W^T u (R / 8 x K / 256 workgroups: the first version, 64 rows per thread and
-                                 // one workgroup reducing the slices, took 58 us per layer — slower than the framework's gemv chain)
+constexpr int SN_ROWS = 32;      // rows per workgroup of W^T u (R / 32 x K / 256 workgroups, one partial row of t each: the first
+                                 // version, 64 rows per thread and one workgroup reducing the slices, took 58 us per layer — slower
+                                 // than the framework's gemv chain; round 3 had 8 rows and atomics: not reproducible run to run)
 
 __device__ __forceinline__ float sn_block_sum(float v, float* red) {
 #pragma unroll
@@ -25,27 +26,32 @@ __device__ __forceinline__ float sn_block_sum(float v, float* red) {
     return s;
 }
 
-// t[k] += sum over the workgroup's 8 rows of u[r] W[r][k]  (t zeroed by the caller)     grid (ceil(K / 256), ceil(R / 8))
+// part[blockIdx.y][k] = sum over the workgroup's 32 rows of u[r] W[r][k]     grid (ceil(K / 256), ceil(R / 32))
+// Deterministic: every partial is written once and sn_v_kernel adds them in a fixed order — the buffers u / v, and
+// with them W / sigma, are bit-reproducible run to run and rank to rank, as torch's mv is.
 __global__ __launch_bounds__(256) void sn_wtu_partial_kernel(const float* __restrict__ W, const float* __restrict__ u,
-                                                             float* __restrict__ t, int R, int K) {
+                                                             float* __restrict__ part, int R, int K) {
     const int k = blockIdx.x * 256 + threadIdx.x, r0 = blockIdx.y * SN_ROWS;
     if (k >= K) return;
     float acc = 0.f;
-#pragma unroll
+#pragma unroll 8
     for (int j = 0; j < SN_ROWS; ++j)
         if (r0 + j < R) acc += u[r0 + j] * W[(size_t)(r0 + j) * K + k];
-    unsafeAtomicAdd(t + k, acc);
+    part[(size_t)blockIdx.y * K + k] = acc;
 }
 
-// v = normalize(t)      ONE workgroup of 1024 threads, K <= 16 * 1024
-__global__ __launch_bounds__(1024) void sn_v_kernel(const float* __restrict__ tsum, float* __restrict__ v, int K, float eps) {
+// v = normalize(t), t[k] = sum of the RS partial rows      ONE workgroup of 1024 threads, K <= 16 * 1024
+__global__ __launch_bounds__(1024) void sn_v_kernel(const float* __restrict__ part, int RS, float* __restrict__ v, int K, float eps) {
     __shared__ float red[16];
     float t[16];
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int k = j * 1024 + threadIdx.x;
-        t[j] = k < K ? tsum[k] : 0.f;
+        float a = 0.f;
+        if (k < K)
+            for (int r = 0; r < RS; ++r) a += part[(size_t)r * K + k];
+        t[j] = a;
         ss += t[j] * t[j];
     }
     const float nrm = sqrtf(sn_block_sum(ss, red));
@@ -132,9 +138,10 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
 
 }  // namespace cocos
 
+static_assert(cocos::SN_ROWS == 32, "cocos_spectral_weight_workspace_floats assumes 32 rows per partial");
 extern "C" long long cocos_spectral_weight_workspace_floats(int R, int K) {
     if (R < 1 || K < 1) return 0;
-    return (long long)K + R;     // t = W^T u, then s = W v
+    return (long long)K * ((R + 31) / 32) + R;     // the partial rows of t = W^T u, then s = W v
 }
 
 // wsn = W / sigma with sigma = u . (W v); power_iteration != 0: first v <- normalize(W^T u), u <- normalize(W v) in place (one
@@ -148,11 +155,10 @@ extern "C" int cocos_spectral_weight_fwd(const float* W, float* u, float* v, flo
     hipStream_t st = as_stream(stream);
     const int RS = (R + SN_ROWS - 1) / SN_ROWS;
     float* t = workspace;
-    float* s = workspace + K;
+    float* s = workspace + (size_t)K * RS;
     if (power_iteration) {
-        COCOS_HIP_CHECK(hipMemsetAsync(t, 0, (size_t)K * sizeof(float), st));
         hipLaunchKernelGGL(sn_wtu_partial_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)RS), dim3(256), 0, st, W, u, t, R, K);
-        hipLaunchKernelGGL(sn_v_kernel, dim3(1), dim3(1024), 0, st, t, v, K, eps);
+        hipLaunchKernelGGL(sn_v_kernel, dim3(1), dim3(1024), 0, st, t, RS, v, K, eps);
     }
     hipLaunchKernelGGL(sn_wv_kernel, dim3((unsigned)R), dim3(256), 0, st, W, v, s, R, K);
     const size_t n = (size_t)R * K;

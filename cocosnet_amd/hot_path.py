@@ -252,8 +252,9 @@ def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_
         if (ops.NORM_PLANES and cfg.PONO_C and _hip_fp32(theta_raw)
                 and ops.corr_split_ok(B, C, fh * fw, fh * fw, 1, keep)):
             # K1 writes the operand planes of the split kernels itself: fp32 qn / kn never exist (ops.center_l2norm_planes)
-            qn = ops.center_l2norm_planes(th_f, 1, planes)
-            kn = ops.center_l2norm_planes(ph_f, 1, planes)
+            # (channel-major planes of BOTH operands whenever either is differentiated: the K2 backward reads both)
+            qn = ops.center_l2norm_planes(th_f, 1, planes, want_chan=keep)
+            kn = ops.center_l2norm_planes(ph_f, 1, planes, want_chan=keep)
         else:
             qn = ops.center_l2norm(th_f, cfg.PONO_C)
             kn = ops.center_l2norm(ph_f, cfg.PONO_C)

@@ -10,6 +10,7 @@ from __future__ import annotations
 import os
 import sys
 import threading
+import weakref
 
 import torch
 
@@ -208,12 +209,18 @@ class _CenterL2NormPlanes(torch.autograd.Function):
         return dx, None, None, None, None
 
 
-def center_l2norm_planes(x: torch.Tensor, center_over_channels, planes: OperandPlanes, eps: float = NORM_EPS):
+def center_l2norm_planes(x: torch.Tensor, center_over_channels, planes: OperandPlanes, eps: float = NORM_EPS,
+                         want_chan=None):
     """K1 whose only products are the operand planes of the split correlation kernels (registered in `planes`) — see
     _CenterL2NormPlanes.  Returns the autograd handle to pass to corr_softmax_warp(..., planes=planes) as qn / kn.  Only
-    for callers that take the split path (corr_split_ok)."""
-    want_chan = torch.is_grad_enabled() and x.requires_grad
-    return _CenterL2NormPlanes.apply(x, int(center_over_channels), eps, planes, want_chan)
+    for callers that take the split path (corr_split_ok).
+
+    `want_chan`: also write the channel-major planes.  The K2 backward reads them of BOTH operands as soon as EITHER
+    theta or phi is differentiated (d qn contracts dS with kn's planes and vice versa), so a caller with two operands
+    passes its `keep` (= either requires grad) for both; None = this tensor's own requires_grad (single-operand use)."""
+    if want_chan is None:
+        want_chan = torch.is_grad_enabled() and x.requires_grad
+    return _CenterL2NormPlanes.apply(x, int(center_over_channels), eps, planes, bool(want_chan))
 
 
 def corr_split_ok(B, K, Nq, Nk, Cv, keep: bool) -> bool:
@@ -248,6 +255,12 @@ class OperandPlanes:
             if ent[1] != x._version:
                 raise _lib.CocosHipError("OperandPlanes: the tensor behind producer-made operand planes was modified in place")
             return ent[2], ent[3]
+        if ent is None and any(k[0] == id(x) and len(e) > 4 and e[0] is x for k, e in self._planes.items()):
+            # x is a producer's HANDLE (its values are the raw features, not the normalised tensor): splitting it here
+            # would hand the kernels planes of the wrong tensor — the producer must be asked for this orientation
+            raise _lib.CocosHipError(
+                f"OperandPlanes: {'position' if transpose else 'channel'}-major planes (scale {scale}) of a tensor that exists "
+                "as producer-made planes only were not written by the producer (center_l2norm_planes(..., want_chan=True))")
         if ent is None or ent[0] is not x or ent[1] != x._version:
             hi, lo = split_f16(x, transpose, scale)
             ent = self._planes[key] = (x, x._version, hi, lo)     # holds x: its id cannot be recycled meanwhile
@@ -459,23 +472,26 @@ def _wants_logits(qn, kn):
     return torch.is_grad_enabled() and (qn.requires_grad or kn.requires_grad)
 
 
-def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes | None = None, operand_amax: bool = False):
+def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes | None = None, operand_amax: bool = False,
+                      precision: str | None = None):
     """out[b,c,i] = sum_j softmax_j(<qn[b,:,i], kn[b,:,j]> * inv_temperature) * v[b,c,j].
 
     qn [B,256,Nq], kn [B,256,Nk], v [B,Cv,Nk] -> [B,Cv,Nq].  Wider V is processed in chunks of
     159 channels (each chunk recomputes the logits; no materialisation).  `planes`: the caller's per-forward
     OperandPlanes (theta/phi planes shared by several launches); None = made for this call only.  `operand_amax`: qn / kn
     are NOT unit-norm columns (softmax_attention): their planes get device-side power-of-two scales from max|.| instead of
-    the fixed SPLIT_OPERAND_SCALE (split flavour only; raises if this shape cannot take it)."""
+    the fixed SPLIT_OPERAND_SCALE (split flavour only; raises if this shape cannot take it).  `precision`: overrides the
+    module-level PRECISION for this call (a per-call argument, not a global: threads do not see each other's choice)."""
     B, K, Nq = qn.shape
     Nk, Cv = kn.shape[2], v.shape[1]
     keep = _wants_logits(qn, kn)
-    if PRECISION not in ("fp32", "f16x3"):
-        raise ValueError(f"cocosnet_amd.ops.PRECISION = {PRECISION!r}: expected 'fp32' or 'f16x3'")
+    prec = PRECISION if precision is None else precision
+    if prec not in ("fp32", "f16x3"):
+        raise ValueError(f"cocosnet_amd.ops.PRECISION = {prec!r}: expected 'fp32' or 'f16x3'")
     chunk = min(Cv, MAX_FUSED_SPLIT_CV)
     # the split flavour saves its logits in a private layout only its own backward reads: a training pass takes it
     # only for shapes that backward takes too (otherwise the exact-fp32 kernels run, forward and backward)
-    split = (PRECISION == "f16x3" and K == FUSED_K and Nk % 4 == 0
+    split = (prec == "f16x3" and K == FUSED_K and Nk % 4 == 0
              and (not keep or _split_bwd_ok(B, Nq, Nk, chunk)))
     if planes is None:
         planes = OperandPlanes()
@@ -661,16 +677,24 @@ _tls = _ThreadState()
 _KNOWN_AMAX_MAX = 4      # entries per thread
 
 
+#: tensors at least this large are remembered through a weak reference only (see _remember_amax)
+_AMAX_WEAK_BYTES = 32 << 20
+
+
 def _remember_amax(t: torch.Tensor, cell: torch.Tensor):
     """A producer kernel computed max|t| while writing t: keep it for the consumer (autograd hands the gradient on
-    as a view of the same storage; producer and consumer of one device's backward run in the same thread).  The entry
-    holds the tensor itself, so its address cannot be recycled for other data while the entry exists; it is dropped
-    when the consumer picks it up, or when two younger ones arrive — producers only register tensors whose consumer
-    is one of our own kernels (K0 / K3), so at most two gradients per thread outlive their step."""
+    as a view of the same storage; producer and consumer of one device's backward run in the same thread).  Small
+    tensors are held by the entry itself, so their address cannot be recycled for other data while the entry exists;
+    it is dropped when the consumer picks it up, or when younger ones arrive.  LARGE tensors (the HWxHW box-adjoint
+    gradient of match_kernel 3: 0.5 GB at B = 8) are held through a WEAK reference: a strong one kept up to
+    four of them alive across steps and, by raising the use count of a gradient, forced autograd's accumulation of
+    several passes' gradients out of place.  A dead weak reference means the tensor was summed into another one or
+    freed: the entry is void and the consumer takes its own max|.| pass — never a stale value."""
     table = _tls.known_amax
     while len(table) >= _KNOWN_AMAX_MAX:
         table.pop(next(iter(table)), None)
-    table[(t.device, t.untyped_storage().data_ptr())] = (t, t._version, cell)
+    big = t.numel() * t.element_size() >= _AMAX_WEAK_BYTES
+    table[(t.device, t.untyped_storage().data_ptr())] = (weakref.ref(t) if big else t, t._version, cell)
 
 
 def _recall_amax(t: torch.Tensor, consume: bool = True):
@@ -680,6 +704,11 @@ def _recall_amax(t: torch.Tensor, consume: bool = True):
     if ent is None:
         return None
     src, version, cell = ent
+    if isinstance(src, weakref.ref):
+        src = src()
+        if src is None:
+            table.pop(key, None)
+            return None
     if (t.numel() != src.numel() or t.storage_offset() != src.storage_offset() or not t.is_contiguous()
             or t._version != version or src._version != version):
         return None
@@ -745,7 +774,8 @@ class _Proj1x1(torch.autograd.Function):
         stream = (split and PROJ_STREAM and (h * w) % 64 == 0 and lib.cocos_proj1x1_stream_kpad(Cin) != 0
                   and lib.cocos_proj1x1_stream_kpad(Cout) != 0)
         if split:      # products on the f16 MFMA, operands split on the fly (sgemm_f16x3.hip)
-            xa, wa = absmax(x), absmax(w2)
+            wa = _recall_amax(w2)      # left by K21 when the layer is spectral-normed (W / sigma), else one small pass
+            xa, wa = absmax(x), (absmax(w2) if wa is None else wa)
             if stream:
                 # A = W as planes [Cout][Kpad], rows zero-padded to whole MFMA k-steps
                 kp = lib.cocos_proj1x1_stream_kpad(Cin)
@@ -853,12 +883,17 @@ def proj1x1(x, weight, bias=None):
 #: K16's arithmetic: "f16x3" = f16 hi/lo split, three MFMA terms (fp32-class accuracy: everything upstream of the correlation);
 #: "bf16" = single bf16 planes, one MFMA term (BASELINE config 3's precision for the generator / discriminator stacks behind
 #: InstanceNorm / SPADE — ~3x less matrix work, no max|x| passes).  Module attribute, read at call time.
+#: "torch" (A/B runs): producers.Conv2d / ReflectionPad2d / the spectral-norm hook keep the framework's kernels; a DIRECT
+#: ops.conv2d call is an error in that setting.  This is the only copy of the switch (producers.conv_backend() reads it).
 CONV_PRECISION = os.environ.get("COCOS_CONV", "f16x3")
 
 
 def _conv_bf16() -> bool:
+    if CONV_PRECISION == "torch":
+        raise ValueError("cocosnet_amd.ops.conv2d called with CONV_PRECISION = 'torch': that setting routes the producers' "
+                         "convolutions to the framework (producers.Conv2d); the HIP entry point needs 'f16x3' or 'bf16'")
     if CONV_PRECISION not in ("f16x3", "bf16"):
-        raise ValueError(f"cocosnet_amd.ops.CONV_PRECISION = {CONV_PRECISION!r}: expected 'f16x3' or 'bf16'")
+        raise ValueError(f"cocosnet_amd.ops.CONV_PRECISION = {CONV_PRECISION!r}: expected 'f16x3', 'bf16' or 'torch'")
     return CONV_PRECISION == "bf16"
 
 
@@ -1735,10 +1770,13 @@ class _SpectralWeight(torch.autograd.Function):
         wsn = torch.empty_like(w)
         sigma = torch.empty(1, device=w.device, dtype=torch.float32)
         ws = torch.empty(lib.cocos_spectral_weight_workspace_floats(R, K), device=w.device, dtype=torch.float32)
-        cell = _zero_cell(w.device)        # max|W / sigma| as a by-product: the convolution that consumes the weight splits it with it
+        # max|W / sigma| as a by-product: the convolution that consumes the weight splits it with it — only the f16x3
+        # flavour does (bf16 planes carry no scale: the entries would pile up in the table and evict useful ones)
+        cell = _zero_cell(w.device) if CONV_PRECISION != "bf16" else None
         _call("spectral_weight_fwd", "cocos_spectral_weight_fwd", w.data_ptr(), u.data_ptr(), v.data_ptr(), wsn.data_ptr(), sigma.data_ptr(),
-              cell.data_ptr(), ws.data_ptr(), R, K, float(eps), int(bool(power_iteration)), _stream())
-        _remember_amax(wsn, cell)
+              _ptr(cell), ws.data_ptr(), R, K, float(eps), int(bool(power_iteration)), _stream())
+        if cell is not None:
+            _remember_amax(wsn, cell)
         # the vectors sigma was taken with: copies, because the next forward (GAN training: D(real), D(fake)) updates the buffers in place
         ctx.save_for_backward(w, u.clone(), v.clone(), sigma)
         return wsn
@@ -1786,6 +1824,10 @@ def softmax_attention(q, k, v, scale: float = 1.0):
             q = torch.nn.functional.pad(q, (0, 0, 0, FUSED_K - K))
             k = torch.nn.functional.pad(k, (0, 0, 0, FUSED_K - K))
         return corr_softmax_warp(q, k, v, scale, operand_amax=True)
+    if K == FUSED_K and q.is_cuda and q.dtype == torch.float32:
+        # the split path is not available (COCOS_PRECISION=fp32, odd Nq / Nk): K = 256 still takes the FUSED exact-fp32
+        # kernels, which materialise nothing either (this branch had been lost — a B x Nq x Nk matrix at 4096^2)
+        return corr_softmax_warp(q, k, v, scale, precision="fp32")
     return warp_materialized(row_softmax(corr_materialize(q, k, scale)), v)
 
 

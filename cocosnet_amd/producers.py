@@ -14,7 +14,6 @@ PONO or instance/batch/sync-batch parameter-free norms.  Unsupported flags raise
 from __future__ import annotations
 
 import os
-import threading
 import re
 
 import torch
@@ -23,11 +22,17 @@ import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
 
-#: "f16x3" / "bf16": K16 in that arithmetic (ops.CONV_PRECISION follows the same variable; bf16 is BASELINE config 3's
-#: precision for the generator / discriminator stacks — inside netCorr it is a timing reference only: everything there is
-#: upstream of the correlation); "torch": the framework's convolution (A/B measurements)
-CONV_BACKEND = os.environ.get("COCOS_CONV", "f16x3")
 _HIP_BACKENDS = ("f16x3", "bf16")
+
+
+def conv_backend() -> str:
+    """The ONE switch of the convolution flavour, `cocosnet_amd.ops.CONV_PRECISION` (env COCOS_CONV), read at call time:
+    "f16x3" / "bf16": K16 in that arithmetic (bf16 is BASELINE config 3's precision for the generator / discriminator
+    stacks — inside netCorr it is a timing reference only: everything there is upstream of the correlation); "torch": the
+    framework's convolution, spectral norm and padding (A/B measurements).  (Round 3 kept a second, import-time copy
+    here; setting one of the two mixed flavours — ADVICE r3.)"""
+    from . import ops
+    return ops.CONV_PRECISION
 
 
 class Conv2d(nn.Conv2d):
@@ -36,13 +41,17 @@ class Conv2d(nn.Conv2d):
     `.weight`).  Anything the kernels do not cover (groups, non-zero padding modes, rectangular stride / padding /
     dilation, other dtypes, CPU) takes the framework path."""
 
-    def _conv_forward(self, input, weight, bias):
+    def forward(self, input, reflect: int = 0):
+        """`reflect` = r: this call is conv(ReflectionPad2d(r)(input)) — passed explicitly by reflect_conv() THROUGH the
+        module call (forward pre-hooks such as spectral norm see only the positional input and still run)."""
+        return self._conv_forward(input, self.weight, self.bias, int(reflect))
+
+    def _conv_forward(self, input, weight, bias, reflect: int = 0):
         s, p, k, d = self.stride, self.padding, self.kernel_size, self.dilation
-        reflect = getattr(_pending, "reflect", 0)          # set by reflect_conv(): this call is conv(ReflectionPad2d(r)(input))
-        _pending.reflect = 0
-        if reflect and not (CONV_BACKEND in _HIP_BACKENDS and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4):
+        hip = conv_backend() in _HIP_BACKENDS
+        if reflect and not (hip and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4):
             input, reflect = nn.functional.pad(input, (reflect,) * 4, mode="reflect"), 0
-        if (CONV_BACKEND in _HIP_BACKENDS and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32
+        if (hip and input.is_cuda and input.dtype == torch.float32 and weight.dtype == torch.float32
                 and input.dim() == 4 and self.groups == 1 and self.padding_mode == "zeros"
                 and not isinstance(p, str) and s[0] == s[1] and p[0] == p[1] and d[0] == d[1]):
             from . import _lib, ops
@@ -75,7 +84,7 @@ class _SpectralNormHIP(_sn_mod.SpectralNorm):
 
     def compute_weight(self, module, do_power_iteration):
         weight = getattr(module, self.name + "_orig")
-        if (SPECTRAL_HIP and CONV_BACKEND in _HIP_BACKENDS and weight.is_cuda and weight.dtype == torch.float32 and self.dim == 0
+        if (SPECTRAL_HIP and conv_backend() in _HIP_BACKENDS and weight.is_cuda and weight.dtype == torch.float32 and self.dim == 0
                 and self.n_power_iterations == 1 and weight.is_contiguous() and weight.numel() // weight.shape[0] <= 16384):
             from . import ops
             return ops.spectral_weight(weight, getattr(module, self.name + "_u"), getattr(module, self.name + "_v"),
@@ -92,21 +101,14 @@ def hip_spectral_norm(module: nn.Module, name: str = "weight") -> nn.Module:
     return module
 
 
-_pending = threading.local()
-
-
 def reflect_conv(pad: nn.Module, conv: nn.Module, x):
     """conv(pad(x)) for a ReflectionPad2d directly in front of one of this module's Conv2d layers.  The convolution is still
-    CALLED as a module (spectral-norm and other forward hooks run); the padding travels to its `_conv_forward` as a
-    per-thread note, so that the bf16 / NHWC path can write the mirrored border while it prepares its operand
-    (ops.conv2d(reflect=r)) instead of materialising the padded fp32 tensor first."""
+    CALLED as a module (spectral-norm and other forward hooks run); the padding is an explicit keyword of its forward, so
+    that the bf16 / NHWC path can write the mirrored border while it prepares its operand (ops.conv2d(reflect=r)) instead
+    of materialising the padded fp32 tensor first."""
     p = pad.padding
     if isinstance(conv, Conv2d) and len(set(p)) == 1 and p[0] > 0 and torch.is_tensor(x) and x.dim() == 4 and p[0] < min(x.shape[2:]):
-        _pending.reflect = int(p[0])
-        try:
-            return conv(x)
-        finally:
-            _pending.reflect = 0
+        return conv(x, reflect=int(p[0]))
     return conv(pad(x))
 
 
@@ -116,7 +118,7 @@ class ReflectionPad2d(nn.ReflectionPad2d):
 
     def forward(self, input):
         p = self.padding
-        if (CONV_BACKEND in _HIP_BACKENDS and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
+        if (conv_backend() in _HIP_BACKENDS and input.is_cuda and input.dtype == torch.float32 and input.dim() == 4
                 and len(set(p)) == 1 and 0 <= p[0] < min(input.shape[2:])):
             from . import ops
             return ops.reflect_pad2d(input, p[0])
@@ -355,7 +357,7 @@ class AdaptiveFeatureGenerator(nn.Module):
         InstanceNorm and the activation are K13 — one HBM pass forward, one backward — instead of the framework's batch-norm
         kernels + leaky_relu (generator.py:133-138 calls them as `layerK(self.actvn(x))`: same values, other grouping)."""
         if (isinstance(layer, nn.Sequential) and len(layer) == 2 and type(layer[1]) is nn.InstanceNorm2d and not layer[1].affine
-                and not layer[1].track_running_stats and x.is_cuda and x.dtype == torch.float32 and CONV_BACKEND in _HIP_BACKENDS):
+                and not layer[1].track_running_stats and x.is_cuda and x.dtype == torch.float32 and conv_backend() in _HIP_BACKENDS):
             from . import ops
             y = layer[0](x)
             if y.shape[2] * y.shape[3] > 16384:

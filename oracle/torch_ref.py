@@ -110,14 +110,22 @@ def hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_seg_map, opt, t
 
 
 def forward_backward(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_seg_map, opt, cotangents,
-                     dtype=torch.float64, **fwd):
-    """numpy in -> (outputs dict, d theta_raw, d phi_raw) as numpy, for loss = sum_k <out_k, cotangents[k]>
-    (keys missing from `cotangents` do not enter the loss)."""
+                     dtype=torch.float64, device=None, **fwd):
+    """numpy (or torch) in -> (outputs dict, d theta_raw, d phi_raw) as numpy, for loss = sum_k <out_k, cotangents[k]>
+    (keys missing from `cotangents` do not enter the loss).  `device`: where the framework's fp64 ops run (None = CPU);
+    the GPU tests at BASELINE sizes pass "cuda" so that EVERY sample of a batch can be checked (a K = 2304 unfolded
+    sample is 77 GFLOP in fp64: seconds on the host, milliseconds on the device) and cross-check one sample against the
+    CPU run of the same code."""
     import numpy as np
-    t = lambda a, g=False: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dtype).requires_grad_(g)
+
+    def t(a, g=False):
+        if a is None:
+            return None
+        a = a.detach() if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+        return a.to(device=device or "cpu", dtype=dtype).clone().requires_grad_(g)
     th, ph = t(theta_raw, True), t(phi_raw, True)
     out = hot_path(th, ph, t(ref_img), t(real_img), t(seg_map), t(ref_seg_map), opt, **fwd)
     res = out if isinstance(out, dict) else {"corr": out}
     loss = sum((res[k] * t(g)).sum() for k, g in cotangents.items() if k in res)
     loss.backward()
-    return ({k: v.detach().numpy() for k, v in res.items()}, th.grad.numpy(), ph.grad.numpy())
+    return ({k: v.detach().cpu().numpy() for k, v in res.items()}, th.grad.cpu().numpy(), ph.grad.cpu().numpy())

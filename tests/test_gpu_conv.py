@@ -167,36 +167,87 @@ def test_patchgan_stack_on_hip_convs_matches_the_framework():
         assert (a - r).abs().max().item() <= 2e-4 * max(r.abs().max().item(), 1e-6), (a.shape, (a - r).abs().max().item())
 
 
-def test_feature_producers_on_k16_agree_with_the_framework_convolutions(monkeypatch):
-    """The whole drop-in module up to theta/phi (adaptors with SPADE blocks, the four ResidualBlocks, the 1x1 projections):
-    the same weights and inputs through K16 / K0 and through the framework's fp32 convolutions (COCOS_CONV=torch: MIOpen
-    Winograd / implicit GEMM, themselves ~1e-4 from fp64 — K16's own error is measured against fp64 per layer above).
-    End-to-end wiring check: features to 1e-3, parameter gradients (instance norms and PONO in the chain amplify
-    round-off) to 1e-2 of their range."""
+def _module_e2e(monkeypatch, flags, size=64, B=2):
+    """The whole drop-in module — adaptors with SPADE blocks, feature_normalize, four ResidualBlocks, theta / phi, AND the hot
+    path behind them — in one graph: ours (every convolution / norm / correlation kernel on HIP, `arm` = f16x3 | bf16 | torch)
+    against a torch-FP64 copy of the same module (same parameters and buffers; framework ops in double up to theta / phi, the
+    oracle's restatement of correspondence.py:272-372 in double from there on).  Returns {arm: {name: relative error}} for
+    features, outputs and parameter gradients of loss = sum_k <out_k, G_k>."""
+    import copy
     from cocosnet_amd import correspondence as cc
-    from cocosnet_amd import producers
-    opt = cc.base_options(semantic_nc=6, match_kernel=1, maskmix=True, PONO=True, PONO_C=True, use_attention=False)
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    from oracle import torch_ref as tr
+    opt = cc.base_options(**flags)
     torch.manual_seed(0)
     net = cc.NoVGGCorrespondence(opt).cuda()
     net.init_weights(opt.init_type, opt.init_variance)
-    net.eval()                     # freezes the spectral-norm power iteration
+    net.eval()                     # freezes the spectral-norm power iteration: both copies see the same W / sigma
     g = torch.Generator(device="cuda").manual_seed(2)
-    img = torch.rand(2, 3, 64, 64, device="cuda", generator=g) * 2 - 1
-    real = torch.rand(2, 3, 64, 64, device="cuda", generator=g) * 2 - 1
-    lab = torch.randint(0, 6, (2, 1, 8, 8), device="cuda", generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
-    seg = torch.zeros(2, 6, 64, 64, device="cuda").scatter_(1, lab, 1.0)
-    probes = (net.theta.weight, net.layer[0].conv1.weight, net.adaptive_model_img.layer1[0].weight_orig)
+    nc = flags["semantic_nc"]
+    img = torch.rand(B, 3, size, size, device="cuda", generator=g) * 2 - 1
+    real = torch.rand(B, 3, size, size, device="cuda", generator=g) * 2 - 1
+    lab = torch.randint(0, nc, (B, 1, size // 8, size // 8), device="cuda", generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    seg = torch.zeros(B, nc, size, size, device="cuda").scatter_(1, lab, 1.0)
+    ref_seg = seg.flip(0).contiguous()
+    probes = {"theta.weight": lambda n: n.theta.weight, "phi.bias": lambda n: n.phi.bias,
+              "layer.0.conv1.weight": lambda n: n.layer[0].conv1.weight, "layer.3.conv2.weight": lambda n: n.layer[3].conv2.weight,
+              "layer.0.prelu.weight": lambda n: n.layer[0].prelu.weight,
+              "adaptive_model_img.layer1.0.weight_orig": lambda n: n.adaptive_model_img.layer1[0].weight_orig,
+              "adaptive_model_seg.G_middle_1.conv_0.weight_orig": lambda n: n.adaptive_model_seg.G_middle_1.conv_0.weight_orig,
+              "adaptive_model_seg.head_0.norm_0.mlp_gamma.weight": lambda n: n.adaptive_model_seg.head_0.norm_0.mlp_gamma.weight}
+    cfg = HotPathConfig.from_opt(opt, down=opt.down)
 
-    def run(backend):
-        monkeypatch.setattr(producers, "CONV_BACKEND", backend)
+    # ---- the fp64 arbiter -------------------------------------------------------------------------------------------------
+    net64 = copy.deepcopy(net).double()
+    d = lambda t: t.double()
+    th64, ph64 = net64.project(d(img), d(real), d(seg), d(ref_seg))
+    out64 = tr.hot_path(th64, ph64, d(img), d(real), d(seg), d(ref_seg), cfg)
+    keys = sorted(out64)
+    G = {k: torch.randn(out64[k].shape, device="cuda", generator=g) for k in keys}
+    torch.autograd.backward([out64[k] for k in keys], [d(G[k]) for k in keys])
+    want = {"theta_raw": th64.detach(), "phi_raw": ph64.detach()}
+    want.update({k: out64[k].detach() for k in keys})
+    want.update({"d " + n: f(net64).grad.clone() for n, f in probes.items()})
+
+    def arm(backend):
+        monkeypatch.setattr(ops, "CONV_PRECISION", backend)
         net.zero_grad()
-        th, ph = net.project(img, real, seg, seg.flip(0))
-        (th.square().mean() + ph.square().mean()).backward()
-        return [th.detach(), ph.detach()] + [p.grad.clone() for p in probes]
-    ref, got = run("torch"), run("f16x3")
-    for i, (a, r) in enumerate(zip(got, ref)):
-        err = (a - r).abs().max().item() / r.abs().max().item()
-        assert err <= (1e-3 if i < 2 else 1e-2), (i, tuple(a.shape), err)
+        th, ph = net.project(img, real, seg, ref_seg)
+        out = correspondence_hot_path(th, ph, img, real, seg, ref_seg, cfg)
+        assert sorted(out) == keys
+        torch.autograd.backward([out[k] for k in keys], [G[k] for k in keys])
+        got = {"theta_raw": th.detach(), "phi_raw": ph.detach()}
+        got.update({k: out[k].detach() for k in keys})
+        got.update({"d " + n: f(net).grad.clone() for n, f in probes.items()})
+        return {k: float((got[k].double() - want[k]).abs().max() / (want[k].abs().max() + 1e-300)) for k in want}
+    return {b: arm(b) for b in ("f16x3", "torch", "bf16")}
+
+
+E2E_FLAGS = {
+    # README.md:45 / :88 ADE20k: maskmix, direct mask, on match_kernel 1 and on the shipped default 3
+    "ade20k_mk1": dict(semantic_nc=6, match_kernel=1, maskmix=True, PONO=True, PONO_C=True, warp_mask_losstype="direct", isTrain=True),
+    "ade20k_mk3": dict(semantic_nc=6, match_kernel=3, maskmix=True, PONO=True, PONO_C=True, warp_mask_losstype="direct", isTrain=True),
+    # README.md:106 CelebA-HQ edge training: adaptor_kernel 4, bilinear, cycle terms (both softmax directions)
+    "celebaedge_mk1": dict(semantic_nc=5, match_kernel=1, maskmix=True, PONO=True, PONO_C=True, warp_bilinear=True, adaptor_kernel=4,
+                           warp_cycle_w=1.0, isTrain=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(E2E_FLAGS))
+def test_module_end_to_end_against_an_fp64_copy_of_itself(name, monkeypatch):
+    """VERDICT r3 weak 1a / 1b.  project() + the hot path in ONE graph against torch-fp64: features, outputs AND parameter
+    gradients within north_star's 1e-3 for the default flavour (f16x3 convolutions); the framework-fp32 arm (`torch`: MIOpen
+    convolutions, our hot path) is the yardstick of what fp32 arithmetic itself loses through instance norms, PONO and a
+    softmax at T = 0.01; the bf16 arm's figures are REPORTED (printed, and written by tools/final_artifacts.sh into
+    profiles/) — they are what bench.py's `module_scope.bf16` number has to be read with."""
+    errs = _module_e2e(monkeypatch, E2E_FLAGS[name])
+    import json
+    print("E2E_FP64", name, json.dumps(errs))
+    bad = {k: v for k, v in errs["f16x3"].items() if not v < 1e-3}
+    assert not bad, (bad, {k: errs["torch"][k] for k in bad})
+    # the one-term flavour is not held to 1e-3 (it is not parity-qualified: DESIGN.md §3.6); it must be finite and sane
+    assert all(v < 0.5 for v in errs["bf16"].values()), errs["bf16"]
 
 
 @pytest.mark.parametrize("shape,pad", [((2, 5, 8, 11), 1), ((1, 3, 4, 4), 3), ((2, 16, 64, 64), 1), ((1, 2, 7, 5), 2), ((1, 1, 3, 9), 0)])
@@ -350,7 +401,6 @@ def test_reflect_conv_helper_keeps_module_semantics(monkeypatch):
     x = torch.randn(2, 64, 32, 32, device="cuda", generator=g)
     for prec in ("bf16", "f16x3"):
         monkeypatch.setattr(ops, "CONV_PRECISION", prec)
-        monkeypatch.setattr(producers, "CONV_BACKEND", prec)
         for cout in (160, 24):
             torch.manual_seed(0)
             conv = torch.nn.utils.spectral_norm(producers.Conv2d(64, cout, 3)).cuda()
@@ -399,7 +449,7 @@ def test_spectral_weight_matches_the_framework_hook(shape, monkeypatch):
     u and v, the gradient through W / sigma (sigma = u . W v depends on W), training and eval mode, two forwards before one backward
     (the GAN pattern the framework clones u / v for)."""
     from cocosnet_amd import producers
-    monkeypatch.setattr(producers, "CONV_BACKEND", "f16x3")
+    monkeypatch.setattr(ops, "CONV_PRECISION", "f16x3")
     cout, cin, k, _ = shape
     res = {}
     for hip in (True, False):
@@ -410,7 +460,7 @@ def test_spectral_weight_matches_the_framework_hook(shape, monkeypatch):
         x1 = torch.randn(2, cin, 8, 8, device="cuda", generator=g)
         x2 = torch.randn(2, cin, 8, 8, device="cuda", generator=g)
         conv.train()
-        monkeypatch.setattr(producers, "CONV_BACKEND", "torch" if not hip else "f16x3")     # reference arm: everything on the framework
+        monkeypatch.setattr(ops, "CONV_PRECISION", "torch" if not hip else "f16x3")     # reference arm: everything on the framework
         y = conv(x1).square().mean() - conv(x2).square().mean()       # two forwards (two power iterations), then backward
         w_train = conv.weight.detach().clone()
         y.backward()
@@ -418,7 +468,7 @@ def test_spectral_weight_matches_the_framework_hook(shape, monkeypatch):
         with torch.no_grad():
             conv(x1)
         res[hip] = (w_train, conv.weight_u.clone(), conv.weight_v.clone(), conv.weight_orig.grad.clone(), conv.weight.detach().clone())
-        monkeypatch.setattr(producers, "CONV_BACKEND", "f16x3")
+        monkeypatch.setattr(ops, "CONV_PRECISION", "f16x3")
     for a, r, what in zip(res[True], res[False], ("weight (train)", "u", "v", "d weight_orig", "weight (eval)")):
         e = (a - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
         assert e <= (2e-4 if what == "d weight_orig" else 2e-5), f"{shape} {what}: {e:.3e}"

@@ -4,10 +4,12 @@ BASELINE.json's real sizes, through the C ABI, against torch-fp64 autograd of th
 fixtures by tests/test_oracle_golden.py incl. `ade_mk3`).
 
 Round-2 VERDICT, missing 1 / weak 1: match_kernel 3 was only checked up to 33x31 grids.  Here:
-  cfg2'  ADE20k 256^2, B = 8, 64x64 grid, Cv = 3 + 151 (direct mask), PONO_C         — samples 0 and 7
-  cfg3'  CelebA-HQ edge, B = 16, warp_cycle + two_cycle (row AND column softmax of f) — sample 15
+  cfg2'  ADE20k 256^2, B = 8, 64x64 grid, Cv = 3 + 151 (direct mask), PONO_C         — ALL 8 samples
+  cfg3'  CelebA-HQ edge, B = 16, warp_cycle + two_cycle (row AND column softmax of f) — samples 0, 5, 10, 15
 outputs and d theta / d phi, both arithmetic flavours.  The oracle unfolds to K = 2304 in fp64 (77 GFLOP per sample
-forward): a few seconds per sample on the host cores; it is computed once per configuration and shared by the flavours.
+forward).  Round 4: the oracle's torch ops run in fp64 ON THE DEVICE (oracle/torch_ref.py is
+device-agnostic), so every sample is affordable; sample 0 is additionally run on the host cores and the two runs of the
+same code must agree to 1e-9 — the arbiter itself is cross-checked.  Computed once per configuration, shared by the flavours.
 
 Also here (VERDICT "weak 1", tolerance kind): an ELEMENTWISE relative check — north_star's "1e-3 relative" read
 literally — of `warp_mask` (the loss takes its log, pix2pix_model.py:276) on every entry above 1e-6.
@@ -76,16 +78,26 @@ def cfg2_mk3():
     G = {"warp_out": torch.randn(B, 3, S, S, device=DEV, generator=g),
          "warp_mask": torch.randn(B, nc, fh, fh, device=DEV, generator=g)}
     oracle = {}
-    for b in (0, B - 1):
+    for b in range(B):
         sl = slice(b, b + 1)
-        oracle[b] = tr.forward_backward(f64(th[sl]), f64(ph[sl]), f64(ref_img[sl]), f64(ref_img[sl]), f64(ref_seg[sl]),
-                                        f64(ref_seg[sl]), co.default_opt(**flags), {k: f64(v[sl]) for k, v in G.items()})
+        oracle[b] = tr.forward_backward(th[sl], ph[sl], ref_img[sl], ref_img[sl], ref_seg[sl], ref_seg[sl],
+                                        co.default_opt(**flags), {k: v[sl] for k, v in G.items()}, device=DEV)
+    _cross_check_arbiter(oracle[0], tr.forward_backward(f64(th[:1]), f64(ph[:1]), f64(ref_img[:1]), f64(ref_img[:1]), f64(ref_seg[:1]),
+                                                        f64(ref_seg[:1]), co.default_opt(**flags), {k: f64(v[:1]) for k, v in G.items()}))
     return dict(th=th, ph=ph, ref_img=ref_img, ref_seg=ref_seg, flags=flags, G=G, oracle=oracle)
 
 
+def _cross_check_arbiter(on_device, on_host):
+    """The fp64 oracle run on the device and on the host cores (same code, two BLAS libraries) must agree far below TOL."""
+    (o1, a1, b1), (o2, a2, b2) = on_device, on_host
+    for k in o2:
+        assert rel(o1[k], o2[k]) < 1e-9, k
+    assert rel(a1, a2) < 1e-9 and rel(b1, b2) < 1e-9
+
+
 def test_config2_match_kernel3_b8_vs_fp64(cfg2_mk3, precision):
-    """cfg2': the benchmark shape with the reference's default match_kernel — outputs and d theta / d phi of samples 0
-    and 7 (the K6 backward's scratch is size-dependent: cocos_box3_logits_bwd_workspace_bytes)."""
+    """cfg2': the benchmark shape with the reference's default match_kernel — outputs and d theta / d phi of ALL 8
+    samples (the K6 backward's scratch is size-dependent: cocos_box3_logits_bwd_workspace_bytes)."""
     from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
     c = cfg2_mk3
     th, ph = c["th"].clone().requires_grad_(True), c["ph"].clone().requires_grad_(True)
@@ -121,15 +133,16 @@ def cfg3_mk3():
     G = {"warp_out": torch.randn(B, 3, S, S, device=DEV, generator=g)}
     for k in ("warp_cycle", "warp_i2r", "warp_i2r2i"):
         G[k] = torch.randn(B, 3, fh, fh, device=DEV, generator=g)
-    b = B - 1
-    sl = slice(b, b + 1)
-    oracle = {b: tr.forward_backward(f64(th[sl]), f64(ph[sl]), f64(ref_img[sl]), f64(real_img[sl]), f64(seg[sl]),
-                                     f64(ref_seg[sl]), co.default_opt(**flags), {k: f64(v[sl]) for k, v in G.items()})}
+    oracle = {}
+    for b in (0, 5, 10, B - 1):
+        sl = slice(b, b + 1)
+        oracle[b] = tr.forward_backward(th[sl], ph[sl], ref_img[sl], real_img[sl], seg[sl], ref_seg[sl],
+                                        co.default_opt(**flags), {k: v[sl] for k, v in G.items()}, device=DEV)
     return dict(th=th, ph=ph, ref_img=ref_img, real_img=real_img, seg=seg, ref_seg=ref_seg, flags=flags, G=G,
                 oracle=oracle)
 
 
-def test_config3_match_kernel3_cycle_b16_last_sample(cfg3_mk3, precision):
+def test_config3_match_kernel3_cycle_b16_four_samples(cfg3_mk3, precision):
     """cfg3': CelebA training flags with the default match_kernel — row and column softmax of the same box-filtered
     correlation, V differentiated (warp_cycle feeds warp_out back through the column pass)."""
     from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path

@@ -396,6 +396,39 @@ def test_module_end_to_end(flags, extra_keys):
         assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0
 
 
+@pytest.mark.parametrize("which", ["theta", "phi"])
+@pytest.mark.parametrize("cycle", [False, True])
+def test_hot_path_with_only_one_of_theta_phi_differentiated(which, cycle):
+    """with exactly one of theta / phi requiring grad, K1's planes flavour must still write the
+    channel-major planes of BOTH operands — the K2 backward contracts dS with the OTHER operand's planes.  (Before the
+    fix the planes of the non-differentiated operand were re-made from its handle, i.e. from the raw, un-normalised
+    features: silently wrong gradients.)  Checked against torch-fp64 autograd."""
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    from oracle import torch_ref as tr
+    rs = np.random.RandomState(5)
+    B, fh, fw, nc = 2, 8, 16, 6
+    theta = rs.standard_normal((B, 256, fh, fw)).astype(np.float32) * 3.0 + 0.5      # far from unit norm
+    phi = (0.3 * np.roll(theta, 5, axis=3) + rs.standard_normal(theta.shape) * 2.0).astype(np.float32)
+    img = rs.uniform(-1, 1, (B, 3, fh * 4, fw * 4)).astype(np.float32)
+    real = rs.uniform(-1, 1, img.shape).astype(np.float32)
+    lab = rs.randint(0, nc, (B, fh * 4, fw * 4))
+    seg = (lab[:, None] == np.arange(nc)[None, :, None, None]).astype(np.float32)
+    flags = dict(match_kernel=1, PONO_C=True, down=4, warp_mask_losstype="direct", isTrain=True,
+                 warp_cycle_w=1.0 if cycle else 0.0, two_cycle=cycle)
+    th, ph = dev(theta, which == "theta"), dev(phi, which == "phi")
+    out = correspondence_hot_path(th, ph, dev(img), dev(real), dev(seg), dev(seg), HotPathConfig(**flags))
+    G = {k: rs.standard_normal(tuple(v.shape)).astype(np.float32) for k, v in sorted(out.items())}
+    torch.autograd.backward([out[k] for k in sorted(out)], [dev(G[k]) for k in sorted(out)])
+    f64 = lambda a: a.astype(np.float64)
+    ref, dth, dph = tr.forward_backward(f64(theta), f64(phi), f64(img), f64(real), f64(seg), f64(seg),
+                                        co.default_opt(**flags), {k: f64(g) for k, g in G.items()})
+    for k in ref:
+        assert rel(out[k], ref[k]) < OUT_TOL, k
+    got, want, other = (th.grad, dth, ph.grad) if which == "theta" else (ph.grad, dph, th.grad)
+    assert other is None
+    assert rel(got, want) < OUT_TOL, rel(got, want)
+
+
 def test_module_return_corr_and_wta_and_detach():
     from cocosnet_amd import correspondence as cc
     opt = cc.base_options(semantic_nc=3, match_kernel=1, maskmix=True, PONO=True, PONO_C=True)
