@@ -9,7 +9,7 @@ Round-2 VERDICT, missing 1 / weak 1: match_kernel 3 was only checked up to 33x31
 outputs and d theta / d phi, both arithmetic flavours.  The oracle unfolds to K = 2304 in fp64 (77 GFLOP per sample
 forward).  Round 4: the oracle's torch ops run in fp64 ON THE DEVICE (oracle/torch_ref.py is
 device-agnostic), so every sample is affordable; sample 0 is additionally run on the host cores and the two runs of the
-same code must agree to 1e-9 — the arbiter itself is cross-checked.  Computed once per configuration, shared by the flavours.
+same code must agree to 1e-7 — the arbiter itself is cross-checked.  Computed once per configuration, shared by the flavours.
 
 Also here (VERDICT "weak 1", tolerance kind): an ELEMENTWISE relative check — north_star's "1e-3 relative" read
 literally — of `warp_mask` (the loss takes its log, pix2pix_model.py:276) on every entry above 1e-6.
@@ -91,8 +91,8 @@ def _cross_check_arbiter(on_device, on_host):
     """The fp64 oracle run on the device and on the host cores (same code, two BLAS libraries) must agree far below TOL."""
     (o1, a1, b1), (o2, a2, b2) = on_device, on_host
     for k in o2:
-        assert rel(o1[k], o2[k]) < 1e-9, k
-    assert rel(a1, a2) < 1e-9 and rel(b1, b2) < 1e-9
+        assert rel(o1[k], o2[k]) < 1e-7, k
+    assert rel(a1, a2) < 1e-7 and rel(b1, b2) < 1e-7
 
 
 def test_config2_match_kernel3_b8_vs_fp64(cfg2_mk3, precision):

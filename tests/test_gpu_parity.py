@@ -407,8 +407,12 @@ def test_hot_path_with_only_one_of_theta_phi_differentiated(which, cycle):
     from oracle import torch_ref as tr
     rs = np.random.RandomState(5)
     B, fh, fw, nc = 2, 8, 16, 6
-    theta = rs.standard_normal((B, 256, fh, fw)).astype(np.float32) * 3.0 + 0.5      # far from unit norm
-    phi = (0.3 * np.roll(theta, 5, axis=3) + rs.standard_normal(theta.shape) * 2.0).astype(np.float32)
+    # (rows from peaked to diffuse as in the golden cases — a near-one-hot softmax would leave only cancellation noise in
+    #  the gradient; both tensors far from unit norm: a handle's raw VALUES must never be taken for the normalised tensor)
+    theta = rs.standard_normal((B, 256, fh, fw)).astype(np.float32)
+    perm = rs.permutation(fh * fw)
+    phi = 0.2 * theta.reshape(B, 256, -1)[:, :, perm].reshape(theta.shape) + rs.standard_normal(theta.shape) + 0.1
+    theta, phi = (theta * 3.0 + 0.5).astype(np.float32), (phi * 2.0 - 0.3).astype(np.float32)
     img = rs.uniform(-1, 1, (B, 3, fh * 4, fw * 4)).astype(np.float32)
     real = rs.uniform(-1, 1, img.shape).astype(np.float32)
     lab = rs.randint(0, nc, (B, fh * 4, fw * 4))
