@@ -43,10 +43,9 @@ __device__ __forceinline__ void xbox_zero_border(float* img, int lane) {
     img[(1 + lane) * kXbStride + 68] = 0.f;
 }
 
-// In place: t[kt][qt] (32 keys x 32 queries accumulator images; kt / qt = left / right half of a 64-wide image row of
-// keys / queries) <- xbox.  `img` = this wave's kXbFloats floats of LDS with a zeroed border.  One wave's LDS
-// instructions execute in order, so the writes below are visible to the reads that follow without a barrier.
-__device__ __forceinline__ void xbox_64x64(f32x16 (&t)[2][2], float* img, int lane) {
+// The interior of a wave's image <- its 64 x 64 chunk t[kt][qt] (32 keys x 32 queries accumulator images; kt / qt = left /
+// right half of the chunk's 64 keys / queries).
+__device__ __forceinline__ void xbox_write_chunk(const f32x16 (&t)[2][2], float* img, int lane) {
     const int h = lane >> 5, c = lane & 31;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -56,7 +55,12 @@ __device__ __forceinline__ void xbox_64x64(f32x16 (&t)[2][2], float* img, int la
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<f32x4*>(img + (qt * 32 + c + 1) * kXbStride + 4 + kt * 32 + 8 * g + 4 * h) =
                     f32x4{t[kt][qt][4 * g], t[kt][qt][4 * g + 1], t[kt][qt][4 * g + 2], t[kt][qt][4 * g + 3]};
-    __builtin_amdgcn_wave_barrier();
+}
+
+// t[kt][qt][key, query] += img[key - 1, query - 1] + img[key + 1, query + 1]  (whatever the border cells hold: zeros at a
+// grid edge, a neighbouring chunk's values inside an image row)
+__device__ __forceinline__ void xbox_add_diagonals(f32x16 (&t)[2][2], const float* img, int lane) {
+    const int h = lane >> 5, c = lane & 31;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -74,7 +78,80 @@ __device__ __forceinline__ void xbox_64x64(f32x16 (&t)[2][2], float* img, int la
                 t[kt][qt][4 * g + 2] += d4[1] + u4[3];
                 t[kt][qt][4 * g + 3] += d4[2] + u5;
             }
+}
+
+// In place: t[kt][qt] <- xbox, for a chunk that holds WHOLE image rows in both directions (64-wide grid).  `img` = this
+// wave's kXbFloats floats of LDS with a zeroed border.  One wave's LDS instructions execute in order, so the writes are
+// visible to the reads that follow without a barrier.
+__device__ __forceinline__ void xbox_64x64(f32x16 (&t)[2][2], float* img, int lane) {
+    xbox_write_chunk(t, img, lane);
     __builtin_amdgcn_wave_barrier();
+    xbox_add_diagonals(t, img, lane);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- 128-wide grids (round 4): an image row is TWO 64-position chunks in either direction, so a chunk's image needs its
+// neighbours' edge values in the border cells that face the inside of the row (the outward-facing ones stay zero):
+//   column 3  = key - 1  of the chunk  (the last key of the chunk to the left),   column 68 = key 64 (first key of the right one)
+//   row 0     = query - 1              (the last query of the chunk before),      row 65    = query 64
+// and the four corner cells from the diagonal neighbours.  The helpers below write ONE edge of a chunk t[kt][qt] into a
+// neighbour's image; the callers (the correlation GEMM's epilogue, where the key-direction neighbour is the same wave's other
+// half, and K20, where all four chunks of a row pair are four waves) put a workgroup barrier between the writes and
+// xbox_add_diagonals.
+//
+// one key of a chunk for every query of the chunk -> border column `col` of `dst` (rows 1..64; `dst` may be the writer's own
+// image).  v0 / v1 = the lane's values for the two query tiles, held by the half-wave `hsel` (key 63 of a chunk = register 15 of
+// key tile 1 in the UPPER half-wave, key 0 = register 0 of key tile 0 in the LOWER one).
+__device__ __forceinline__ void xbox_put_key_column(float* dst, int col, float v0, float v1, int lane, int hsel) {
+    const int h = lane >> 5, c = lane & 31;
+    if (h == hsel) {
+        dst[(c + 1) * kXbStride + col] = v0;
+        dst[(32 + c + 1) * kXbStride + col] = v1;
+    }
+}
+// the last key (63) of chunk t -> column 3 of `dst`;  the first key (0) of chunk t -> column 68
+__device__ __forceinline__ void xbox_put_last_key(const f32x16 (&t)[2][2], float* dst, int lane) {
+    xbox_put_key_column(dst, 3, t[1][0][15], t[1][1][15], lane, 1);
+}
+__device__ __forceinline__ void xbox_put_first_key(const f32x16 (&t)[2][2], float* dst, int lane) {
+    xbox_put_key_column(dst, 68, t[0][0][0], t[0][1][0], lane, 0);
+}
+// the last query (63) of chunk t, keys 0..63 -> row 0 of `dst`, columns 4..67
+__device__ __forceinline__ void xbox_put_last_query(const f32x16 (&t)[2][2], float* dst, int lane) {
+    const int h = lane >> 5, c = lane & 31;
+    if (c == 31)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(dst + 4 + kt * 32 + 8 * g + 4 * h) =
+                    f32x4{t[kt][1][4 * g], t[kt][1][4 * g + 1], t[kt][1][4 * g + 2], t[kt][1][4 * g + 3]};
+}
+// the first query (0) of chunk t, keys 0..63 -> row 65 of `dst`
+__device__ __forceinline__ void xbox_put_first_query(const f32x16 (&t)[2][2], float* dst, int lane) {
+    const int h = lane >> 5, c = lane & 31;
+    if (c == 0)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(dst + 65 * kXbStride + 4 + kt * 32 + 8 * g + 4 * h) =
+                    f32x4{t[kt][0][4 * g], t[kt][0][4 * g + 1], t[kt][0][4 * g + 2], t[kt][0][4 * g + 3]};
+}
+// corner cells: element (key 63, query 63) of t -> dst[row 0][col 3];  (63, 0) -> [65][3];  (0, 63) -> [0][68];  (0, 0) -> [65][68]
+// (v_q0 / v_q63: the lane's value of that key for query tile 0 / 1 — the same registers xbox_put_key_column takes)
+__device__ __forceinline__ void xbox_put_corner_value(float* dst, int lane, bool last_key, bool last_query, float v_q0, float v_q63) {
+    const int h = lane >> 5, c = lane & 31;
+    if (h == (last_key ? 1 : 0) && c == (last_query ? 31 : 0))
+        dst[(last_query ? 0 : 65) * kXbStride + (last_key ? 3 : 68)] = last_query ? v_q63 : v_q0;
+}
+__device__ __forceinline__ void xbox_put_corner(const f32x16 (&t)[2][2], float* dst, int lane, bool last_key, bool last_query) {
+    xbox_put_corner_value(dst, lane, last_key, last_query, last_key ? t[1][0][15] : t[0][0][0], last_key ? t[1][1][15] : t[0][1][0]);
+}
+// one border column (3 or 68) of rows 0..65, or one border row's corner cells, back to zero (a cell that held a neighbour's
+// value in the previous pass and faces the grid edge in this one)
+__device__ __forceinline__ void xbox_zero_column(float* img, int col, int lane) {
+    for (int r = lane; r < kXbRows; r += 64) img[r * kXbStride + col] = 0.f;
 }
 
 }  // namespace cocos

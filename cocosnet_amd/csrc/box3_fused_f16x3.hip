@@ -38,6 +38,10 @@ constexpr int BX_VROW = 40;             // halfs per channel row of the forward 
 constexpr float kBxRescaleThr = 6.0f;   // lazy rescale of the running maximum (corr_fused_fwd_f16x3.hip)
 constexpr float kBxPBias = 9.0f;
 constexpr float kBxPPlaneScale = 16384.0f;
+// Per-key statistics in LDS: the whole sample while it has <= 4096 keys (32 KB); beyond that (128-wide grids: 16384 keys)
+// a ring of two chunks of BX_KCH keys — chunk c + 1 is staged by the whole workgroup during the first tile of chunk c, into
+// the buffer that chunk c - 1 was read from (every wave passed that chunk's last barrier), and is first read 64 barriers later.
+constexpr int BX_KCH = 2048, BX_TCH = BX_KCH / 32;
 
 __device__ __forceinline__ f32x16 bx_mfma(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -53,8 +57,8 @@ struct BxGeom {
     __amdgpu_buffer_rsrc_t t_rs;
     int qblk, py, tpr, himg, nqblk;
     unsigned lane_off;      // lane * 16
-    const float* kstat;     // LDS: [b_q (Nk floats) | kc * nu_q * b_q (Nk floats)] of this sample's keys
-    int nk;
+    const float* kstat;     // LDS: [b_q (nk floats) | kc * nu_q * b_q (nk floats)] of this sample's keys (x 2 buffers when chunked)
+    int nk;                 // keys per LDS buffer: Nk, or BX_KCH when chunked
 };
 
 __device__ __forceinline__ void bx_fetch(BxTile& tl, const BxGeom& gm, int t, int ntiles) {
@@ -77,23 +81,36 @@ __device__ __forceinline__ void bx_fetch(BxTile& tl, const BxGeom& gm, int t, in
 // The per-key statistics of the whole sample go to LDS once per workgroup (b_q and kn_q = kc * nu_q * b_q: 8 Nk bytes);
 // every tile then reads its 2 x 16 values per lane as broadcast 16-byte LDS reads.  (Round-3 ablation: fetching them from
 // global memory per tile — 8 buffer loads whose 32 lanes share an address — cost 0.06 ms of the 0.46 ms backward.)
+// (`cap` = floats per array of the LDS buffer, `n` <= cap = keys staged)
 __device__ __forceinline__ void bx_stage_stats(float* kstat, const float* __restrict__ b_k, const float* __restrict__ nu_k,
-                                               int Nk, float kc, int tid) {
-    for (int i = tid; i < Nk; i += 256) {
+                                               int cap, int n, float kc, int tid) {
+    for (int i = tid; i < n; i += 256) {
         const float bq = b_k[i];
         kstat[i] = bq;
-        kstat[Nk + i] = kc * nu_k[i] * bq;
+        kstat[cap + i] = kc * nu_k[i] * bq;
+    }
+}
+// chunked flavour: behind the barrier that ended tile t - 1; stages the chunk AFTER the one tile t opens
+template <bool CHUNKED>
+__device__ __forceinline__ void bx_stage_next_chunk(float* kstat, const float* __restrict__ b_k, const float* __restrict__ nu_k,
+                                                    int t, int ntiles, float kc, int tid) {
+    if (CHUNKED && (t & (BX_TCH - 1)) == 0 && t + BX_TCH < ntiles) {
+        const int c1 = t / BX_TCH + 1;
+        bx_stage_stats(kstat + (c1 & 1) * 2 * BX_KCH, b_k + c1 * BX_KCH, nu_k + c1 * BX_KCH, BX_KCH,
+                       min(BX_KCH, ntiles * 32 - c1 * BX_KCH), kc, tid);
     }
 }
 
 // tt[r] = b_q * (T_sum) - mu_p * kc * nu_q * b_q  (the logit without its per-query factor scale * a_p); also returns
 // b_q and kn_q per register for the backward.
+template <bool CHUNKED>
 __device__ __forceinline__ void bx_logits(const BxTile& tl, const BxGeom& gm, int t, int h, float mu_p, float (&tt)[16],
                                           float (&bq)[16], float (&kn)[16]) {
+    const float* ks = gm.kstat + (CHUNKED ? ((t / BX_TCH) & 1) * 2 * BX_KCH + (t & (BX_TCH - 1)) * 32 : t * 32);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(gm.kstat + t * 32 + 8 * g + 4 * h);
-        const f32x4 k4 = *reinterpret_cast<const f32x4*>(gm.kstat + gm.nk + t * 32 + 8 * g + 4 * h);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(ks + 8 * g + 4 * h);
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(ks + gm.nk + 8 * g + 4 * h);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
@@ -110,7 +127,7 @@ __device__ __forceinline__ void bx_logits(const BxTile& tl, const BxGeom& gm, in
 // ---------------------------------------------------------------------------------------------------------
 // VLO0 (as in the K2 split kernels, corr_fused_fwd_f16x3.hip): only value block 0 has a non-zero f16 lo plane (one-hot label
 // channels are exact in f16) — the V_lo . P_hi term, its fragment reads and its staging are skipped for the other blocks.
-template <int CVB, bool VLO0>
+template <int CVB, bool VLO0, bool CHUNKED>
 __device__ __forceinline__ void box3_sw_fwd_body(
     const float* __restrict__ T, const float* __restrict__ mu_q, const float* __restrict__ a_q,
     const float* __restrict__ nu_k, const float* __restrict__ b_k, const _Float16* __restrict__ vh,
@@ -127,7 +144,9 @@ __device__ __forceinline__ void box3_sw_fwd_body(
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
     const int b = vb / nqb, q0 = (vb % nqb) * 128;
     const int i_lane = q0 + wave * 32 + c;
-    bx_stage_stats(kstat, b_k + (size_t)b * Nk, nu_k + (size_t)b * Nk, Nk, kc, tid);
+    const float* const bk_b = b_k + (size_t)b * Nk;
+    const float* const nu_b = nu_k + (size_t)b * Nk;
+    bx_stage_stats(kstat, bk_b, nu_b, CHUNKED ? BX_KCH : Nk, CHUNKED ? BX_KCH : Nk, kc, tid);
 
     const size_t vbytes = (size_t)Cv * Nk * 2;
     const __amdgpu_buffer_rsrc_t vh_rs = make_rsrc(vh + (size_t)b * Cv * Nk, vbytes);
@@ -135,7 +154,7 @@ __device__ __forceinline__ void box3_sw_fwd_body(
     BxGeom gm;
     gm.t_rs = make_rsrc(T + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
     gm.kstat = kstat;
-    gm.nk = Nk;
+    gm.nk = CHUNKED ? BX_KCH : Nk;
     gm.tpr = wimg / 32;
     gm.qblk = (q0 >> 5) + wave;
     gm.py = gm.qblk / gm.tpr;
@@ -186,8 +205,9 @@ __device__ __forceinline__ void box3_sw_fwd_body(
 
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 32, buf = t & 1;
+        bx_stage_next_chunk<CHUNKED>(kstat, bk_b, nu_b, t, ntiles, kc, tid);
         float tt[16], bq[16], kn[16];
-        bx_logits(tl, gm, t, h, mu_p, tt, bq, kn);
+        bx_logits<CHUNKED>(tl, gm, t, h, mu_p, tt, bq, kn);
         bx_fetch(tl, gm, t + 1, ntiles);                  // the next tile's blocks have the whole MFMA loop to arrive
         float tmax = tt[0];
 #pragma unroll
@@ -275,7 +295,7 @@ __device__ __forceinline__ void box3_sw_fwd_body(
 
 // One launch holds both flavours of the body and picks one, workgroup-uniformly, from the device-side mask of V's lo plane
 // (cocos_split_f16_chan_mask) as its first action.  DUAL = false: no mask / a single value block.
-template <int CVB, bool DUAL>
+template <int CVB, bool DUAL, bool CHUNKED>
 __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
     const float* __restrict__ T, const float* __restrict__ mu_q, const float* __restrict__ a_q,
     const float* __restrict__ nu_k, const float* __restrict__ b_k, const _Float16* __restrict__ vh,
@@ -283,9 +303,9 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
     const float* __restrict__ v_scale, const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, int himg,
     int wimg, float kc, float scale) {
     if (DUAL && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
-        box3_sw_fwd_body<CVB, DUAL>(T, mu_q, a_q, nu_k, b_k, vh, vl, out, lse, v_scale, B, Nq, Nk, Cv, himg, wimg, kc, scale);
+        box3_sw_fwd_body<CVB, DUAL, CHUNKED>(T, mu_q, a_q, nu_k, b_k, vh, vl, out, lse, v_scale, B, Nq, Nk, Cv, himg, wimg, kc, scale);
     else
-        box3_sw_fwd_body<CVB, false>(T, mu_q, a_q, nu_k, b_k, vh, vl, out, lse, v_scale, B, Nq, Nk, Cv, himg, wimg, kc, scale);
+        box3_sw_fwd_body<CVB, false, CHUNKED>(T, mu_q, a_q, nu_k, b_k, vh, vl, out, lse, v_scale, B, Nq, Nk, Cv, himg, wimg, kc, scale);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -334,7 +354,7 @@ __device__ __forceinline__ float bx_colsum4(const float (&x)[4], int c) {
     T, mu_q, a_q, nu_k, b_k, vph, vpl, gph, gpl, g_scale, v_scale, outp, dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, \
     Nk, Cv, himg, wimg, kc, scale
 
-template <int CVB, bool STORE_P, bool VLO0>
+template <int CVB, bool STORE_P, bool VLO0, bool CHUNKED>
 __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     constexpr int CVP = CVB * 32, CVS = CVP / 16, VROW = CVP + 8, VPLANE = 32 * VROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
@@ -348,7 +368,9 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
     const int b = vb / nqb, wg = vb % nqb, q0 = wg * 128;
     const int i_lane = q0 + wave * 32 + c;
-    bx_stage_stats(kstat, b_k + (size_t)b * Nk, nu_k + (size_t)b * Nk, Nk, kc, tid);
+    const float* const bk_b = b_k + (size_t)b * Nk;
+    const float* const nu_b = nu_k + (size_t)b * Nk;
+    bx_stage_stats(kstat, bk_b, nu_b, CHUNKED ? BX_KCH : Nk, CHUNKED ? BX_KCH : Nk, kc, tid);
 
     const size_t vbytes = (size_t)Nk * CVP * 2, gbytes = (size_t)Nq * CVP * 2;
     const __amdgpu_buffer_rsrc_t vh_rs = make_rsrc(vph + (size_t)b * Nk * CVP, vbytes);
@@ -363,7 +385,7 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     BxGeom gm;
     gm.t_rs = make_rsrc(T + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
     gm.kstat = kstat;
-    gm.nk = Nk;
+    gm.nk = CHUNKED ? BX_KCH : Nk;
     gm.tpr = wimg / 32;
     gm.qblk = (q0 >> 5) + wave;
     gm.py = gm.qblk / gm.tpr;
@@ -451,8 +473,9 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     for (int t = 0; t < ntiles; ++t) {
         const int j0 = t * 32, buf = t & 1;
         if (t > 0) reduce_cols(t - 1);
+        bx_stage_next_chunk<CHUNKED>(kstat, bk_b, nu_b, t, ntiles, kc, tid);
         float tt[16], bq[16], kn[16];
-        bx_logits(tl, gm, t, h, mu_p, tt, bq, kn);
+        bx_logits<CHUNKED>(tl, gm, t, h, mu_p, tt, bq, kn);
         bx_fetch(tl, gm, t + 1, ntiles);
         float p[16];
 #pragma unroll
@@ -557,12 +580,12 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(gmax), __builtin_bit_cast(unsigned, gabs));   // >= 0: ordered as integers
 }
 
-template <int CVB, bool STORE_P, bool DUAL>
+template <int CVB, bool STORE_P, bool DUAL, bool CHUNKED>
 __global__ __launch_bounds__(256, 1) void box3_sw_bwd_kernel(COCOS_BXB_PARAMS, const unsigned* __restrict__ v_lo_mask) {
     if (DUAL && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
-        box3_sw_bwd_body<CVB, STORE_P, DUAL>(COCOS_BXB_ARGS);
+        box3_sw_bwd_body<CVB, STORE_P, DUAL, CHUNKED>(COCOS_BXB_ARGS);
     else
-        box3_sw_bwd_body<CVB, STORE_P, false>(COCOS_BXB_ARGS);
+        box3_sw_bwd_body<CVB, STORE_P, false, CHUNKED>(COCOS_BXB_ARGS);
 }
 
 // d nu[b,q] = -kc * b_q * sum_wg colpart[b,wg,1,q];   d b[b,q] = sum_wg colpart[b,wg,0,q] / b_q
@@ -675,13 +698,117 @@ __global__ __launch_bounds__(256, 1) void box3_adjoint_planes_kernel(const float
         }
 }
 
+// K20 on a 128-wide grid: a (key image row, query image row) pair is 128 x 128 = FOUR 64 x 64 chunks; one workgroup per
+// pair, wave = chunk (kq = key half, qq = query half).  Every chunk's image gets its inward-facing border cells from the
+// three other waves (box3_common.h), with one workgroup barrier between the writes and the reads.
+__global__ __launch_bounds__(256, 1) void box3_adjoint_planes_w128_kernel(const float* __restrict__ G,
+                                                                          const float* __restrict__ gmax,
+                                                                          _Float16* __restrict__ dch, _Float16* __restrict__ dcl,
+                                                                          float* __restrict__ scale_out, int B, int Nq, int Nk,
+                                                                          int himg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    float* const img0 = reinterpret_cast<float*>(bx_smem);
+    float* const img = img0 + wave * kXbFloats;
+    xbox_zero_border(img, lane);
+
+    const int grp = blockIdx.x;                                // (b, ky, py): the grid is exactly B * himg * himg
+    const int per = himg * himg;
+    const int b = grp / per, ky = (grp % per) / himg, py = grp % himg;
+    const int kq = wave >> 1, qq = wave & 1;
+    constexpr int TPR = 4;                                     // 32-position tiles per image row
+    const int nqblk = Nq >> 5;
+    const __amdgpu_buffer_rsrc_t g_rs = make_rsrc(G + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 4);
+    const __amdgpu_buffer_rsrc_t h_rs = make_rsrc(dch + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 2);
+    const __amdgpu_buffer_rsrc_t l_rs = make_rsrc(dcl + (size_t)b * Nk * Nq, (size_t)Nk * Nq * 2);
+
+    float s = 1.0f;      // power-of-two scale: max|G| -> [2^6, 2^7), so |dC| <= 9 max|G| stays below 2^11
+    {
+        const float m = *gmax;
+        if (m > 0.f && m < INFINITY) {
+            int e;
+            frexpf(m, &e);
+            s = ldexpf(1.0f, min(max(7 - e, -100), 100));
+        }
+        if (blockIdx.x == 0 && tid == 0) *scale_out = s;
+    }
+
+    f32x16 t[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[kt][qt][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {                              // y box: three diagonal neighbours, whole tiles apart
+        const int dy = d - 1;
+        const bool ok = (unsigned)(py + dy) < (unsigned)himg && (unsigned)(ky + dy) < (unsigned)himg;
+        f32x4 ld[2][2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int blk = ok ? ((ky + dy) * TPR + kq * 2 + kt) * nqblk + (py + dy) * TPR + qq * 2 + qt : 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    ld[kt][qt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        g_rs, (int)(ok ? (unsigned)lane * 16u : kBufOob), (int)((unsigned)blk * 4096u + (unsigned)g * 1024u), 0));
+            }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[kt][qt][r] += ld[kt][qt][r >> 2][r & 3];
+    }
+    __syncthreads();                                            // every image's border is zero before the neighbours write into it
+    xbox_write_chunk(t, img, lane);
+    float* const img_k = img0 + (wave ^ 2) * kXbFloats;        // the other key half, same query half
+    float* const img_q = img0 + (wave ^ 1) * kXbFloats;        // same key half, the other query half
+    float* const img_d = img0 + (wave ^ 3) * kXbFloats;        // the diagonal chunk
+    if (kq == 0) xbox_put_last_key(t, img_k, lane); else xbox_put_first_key(t, img_k, lane);
+    if (qq == 0) xbox_put_last_query(t, img_q, lane); else xbox_put_first_query(t, img_q, lane);
+    xbox_put_corner(t, img_d, lane, kq == 0, qq == 0);
+    __syncthreads();
+    xbox_add_diagonals(t, img, lane);
+
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            unsigned hw[8], lw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) split_pair_rtz(t[kt][qt][2 * j] * s, t[kt][qt][2 * j + 1] * s, hw[j], lw[j]);
+            const unsigned blk = (unsigned)(((py * TPR + qq * 2 + qt) * (Nk >> 5) + ky * TPR + kq * 2 + kt) * 2048);
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int m0 = 2 * pp, m1 = 2 * pp + 1;
+                u32x4 xh, xl;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const auto sh = __builtin_amdgcn_permlane32_swap(hw[2 * m0 + i], hw[2 * m1 + i], false, false);
+                    const auto sl = __builtin_amdgcn_permlane32_swap(lw[2 * m0 + i], lw[2 * m1 + i], false, false);
+                    xh[i] = sh[0]; xh[2 + i] = sh[1];
+                    xl[i] = sl[0]; xl[2 + i] = sl[1];
+                }
+                const unsigned off = blk + (unsigned)(pp * 1024 + c * 32 + h * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(xh, h_rs, (int)off, 0, 2);      // nt: streams for the two GEMMs
+                __builtin_amdgcn_raw_buffer_store_b128(xl, l_rs, (int)off, 0, 2);
+            }
+        }
+}
+
 template <int CVB>
 static int bx_fwd_launch(const float* T, const float* mu, const float* a, const float* nu, const float* bk,
                          const _Float16* vh, const _Float16* vl, float* out, float* lse, const float* vs,
                          const unsigned* mask, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale,
                          hipStream_t s) {
-    const size_t smem = (size_t)2 * 3 * CVB * 32 * BX_VROW * sizeof(_Float16) + (size_t)2 * Nk * sizeof(float);
-    auto kern = (CVB > 1 && mask) ? box3_sw_fwd_kernel<CVB, (CVB > 1)> : box3_sw_fwd_kernel<CVB, false>;
+    const bool chunked = Nk > 2 * BX_KCH;
+    const size_t smem = (size_t)2 * 3 * CVB * 32 * BX_VROW * sizeof(_Float16) + (size_t)(chunked ? 4 * BX_KCH : 2 * Nk) * sizeof(float);
+    auto kern = chunked ? ((CVB > 1 && mask) ? box3_sw_fwd_kernel<CVB, (CVB > 1), true> : box3_sw_fwd_kernel<CVB, false, true>)
+                        : ((CVB > 1 && mask) ? box3_sw_fwd_kernel<CVB, (CVB > 1), false> : box3_sw_fwd_kernel<CVB, false, false>);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3(B * (Nq / 128)), dim3(256), smem, s, T, mu, a, nu, bk, vh, vl, out, lse, vs, mask, B, Nq, Nk,
                        Cv, himg, wimg, kc, scale);
@@ -696,23 +823,27 @@ static int bx_bwd_launch(const float* T, const float* mu, const float* a, const 
                          float* dmu, float* da, float* colpart, float* gmax, _Float16* psh, _Float16* psl,
                          const unsigned* mask, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale,
                          hipStream_t s) {
-    const size_t smem = (size_t)2 * 2 * 32 * (CVB * 32 + 8) * sizeof(_Float16) + (size_t)(2 * 4 * 2048 + 2 * Nk) * sizeof(float);
-#define COCOS_BX_GO(SP)                                                                                                  \
+    const bool chunked = Nk > 2 * BX_KCH;
+    const size_t smem = (size_t)2 * 2 * 32 * (CVB * 32 + 8) * sizeof(_Float16) +
+                        (size_t)(2 * 4 * 2048 + (chunked ? 4 * BX_KCH : 2 * Nk)) * sizeof(float);
+#define COCOS_BX_GO(SP, CH)                                                                                              \
     do {                                                                                                                 \
-        auto kern = (CVB > 1 && mask) ? box3_sw_bwd_kernel<CVB, SP, (CVB > 1)> : box3_sw_bwd_kernel<CVB, SP, false>;     \
+        auto kern = (CVB > 1 && mask) ? box3_sw_bwd_kernel<CVB, SP, (CVB > 1), CH> : box3_sw_bwd_kernel<CVB, SP, false, CH>; \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         hipLaunchKernelGGL(kern, dim3(B * (Nq / 128)), dim3(256), smem, s, T, mu, a, nu, bk, vph, vpl, gph, gpl, gs, vs, outp, \
                            dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, Nk, Cv, himg, wimg, kc, scale, mask);  \
     } while (0)
-    if (psh) COCOS_BX_GO(true); else COCOS_BX_GO(false);
+    if (chunked) { if (psh) COCOS_BX_GO(true, true); else COCOS_BX_GO(false, true); }
+    else { if (psh) COCOS_BX_GO(true, false); else COCOS_BX_GO(false, false); }
 #undef COCOS_BX_GO
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
 
 static bool bx_shape_ok(int Nq, int Nk, int Cv, int himg, int wimg) {
-    return himg >= 1 && wimg == 64 && Nq == himg * wimg && Nk == Nq && Nq % 256 == 0 && Nk <= 8192 && Cv >= 1 && Cv <= 160 &&
-           (size_t)Nq * Nk * 4 < 0x7fffffffull;       // (Nk <= 8192: the per-key statistics of a sample live in LDS)
+    // (T / G of one sample below 2 GiB: 16384 x 16384 fp32 is 1 GiB)
+    return himg >= 1 && (wimg == 64 || wimg == 128) && Nq == himg * wimg && Nk == Nq && Nq % 256 == 0 &&
+           Cv >= 1 && Cv <= 160 && (size_t)Nq * Nk * 4 < 0x7fffffffull;
 }
 
 }  // namespace cocos
@@ -732,7 +863,7 @@ extern "C" int cocos_box3_softmax_warp_fwd_f16x3(const float* t_blocked, const f
                   "box3_softmax_warp_fwd_f16x3: null pointer");
     COCOS_REQUIRE(B >= 1 && scale > 0.f, COCOS_ERR_INVALID, "box3_softmax_warp_fwd_f16x3: bad B=%d / scale", B);
     COCOS_REQUIRE(bx_shape_ok(Nq, Nk, Cv, grid_h, grid_w), COCOS_ERR_UNSUPPORTED,
-                  "box3_softmax_warp_fwd_f16x3: needs a 64-wide grid with Nq == Nk == h*w, Nq %% 256 == 0, Cv <= 160 "
+                  "box3_softmax_warp_fwd_f16x3: needs a 64- or 128-wide grid with Nq == Nk == h*w, Nq %% 256 == 0, Cv <= 160 "
                   "(Nq=%d Nk=%d Cv=%d grid %dx%d)", Nq, Nk, Cv, grid_h, grid_w);
     COCOS_REQUIRE(aligned16(t_blocked) && aligned16(nu_k) && aligned16(b_k), COCOS_ERR_INVALID,
                   "box3_softmax_warp_fwd_f16x3: T / nu / b must be 16-byte aligned");
@@ -771,7 +902,7 @@ extern "C" int cocos_box3_softmax_warp_bwd_f16x3(
                   "box3_softmax_warp_bwd_f16x3: P plane pointers come as a hi/lo pair");
     COCOS_REQUIRE(B >= 1 && scale > 0.f, COCOS_ERR_INVALID, "box3_softmax_warp_bwd_f16x3: bad B=%d / scale", B);
     COCOS_REQUIRE(bx_shape_ok(Nq, Nk, Cv, grid_h, grid_w), COCOS_ERR_UNSUPPORTED,
-                  "box3_softmax_warp_bwd_f16x3: needs a 64-wide grid with Nq == Nk == h*w, Nq %% 256 == 0, Cv <= 160 "
+                  "box3_softmax_warp_bwd_f16x3: needs a 64- or 128-wide grid with Nq == Nk == h*w, Nq %% 256 == 0, Cv <= 160 "
                   "(Nq=%d Nk=%d Cv=%d grid %dx%d)", Nq, Nk, Cv, grid_h, grid_w);
     const int cvb = (Cv + 31) / 32;
     COCOS_REQUIRE(CvPad == cvb * 32, COCOS_ERR_INVALID, "box3_softmax_warp_bwd_f16x3: CvPad=%d, expected %d", CvPad, cvb * 32);
@@ -807,12 +938,21 @@ extern "C" int cocos_box3_adjoint_planes_f16x3(const float* g_blocked, const flo
     COCOS_REQUIRE(g_blocked && gmax_dev && dc_hi && dc_lo && scale_out_dev, COCOS_ERR_INVALID,
                   "box3_adjoint_planes_f16x3: null pointer");
     COCOS_REQUIRE(B >= 1 && bx_shape_ok(Nq, Nk, 1, grid_h, grid_w), COCOS_ERR_UNSUPPORTED,
-                  "box3_adjoint_planes_f16x3: needs a 64-wide grid with Nq == Nk == h*w, Nq %% 256 == 0 (Nq=%d Nk=%d grid %dx%d)",
+                  "box3_adjoint_planes_f16x3: needs a 64- or 128-wide grid with Nq == Nk == h*w, Nq %% 256 == 0 (Nq=%d Nk=%d grid %dx%d)",
                   Nq, Nk, grid_h, grid_w);
     for (const void* p : {(const void*)g_blocked, (const void*)dc_hi, (const void*)dc_lo})
         COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "box3_adjoint_planes_f16x3: pointers must be 16-byte aligned");
     const long long groups = (long long)B * grid_h * grid_h;
     const size_t smem = (size_t)4 * kXbFloats * sizeof(float);
+    COCOS_REQUIRE(groups <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "box3_adjoint_planes_f16x3: grid too large");
+    if (grid_w == 128) {            // one workgroup per (key row, query row) pair, wave = 64 x 64 chunk
+        auto kw = box3_adjoint_planes_w128_kernel;
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kw, dim3((unsigned)groups), dim3(256), smem, as_stream(stream), g_blocked, gmax_dev,
+                           static_cast<_Float16*>(dc_hi), static_cast<_Float16*>(dc_lo), scale_out_dev, B, Nq, Nk, grid_h);
+        COCOS_HIP_CHECK(hipGetLastError());
+        return COCOS_OK;
+    }
     auto kern = box3_adjoint_planes_kernel;
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3((unsigned)((groups + 3) / 4)), dim3(256), smem, as_stream(stream), g_blocked, gmax_dev,

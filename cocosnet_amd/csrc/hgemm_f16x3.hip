@@ -33,6 +33,9 @@ constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row
 // in the columns; the epilogue applies the x-direction diagonal box filter to the wave's 128 x 64 sub-tile (= two image
 // rows of keys x one image row of queries on a 64-wide grid) through a per-wave LDS image laid over the dead staging
 // buffers, and stores the result in the tile-blocked layout the fused box -> softmax -> warp kernels read.
+// EPI 2 (round 4): the same on a 128-wide grid — the sub-tile is ONE image row of keys x HALF an image row of queries;
+// the halo between the two key chunks comes from the wave's own registers, the halo between the query halves from the
+// neighbouring wave (wave ^ 1) through the LDS images, with workgroup barriers around the exchange.
 template <bool EXACT, int BMODE, int EPI = 0>
 __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __restrict__ ah,
                                                              const _Float16* __restrict__ al,
@@ -221,16 +224,45 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
     if (t < nsteps) step(t, st1);
 
     const float scale = host_scale / ((dev_scale ? *dev_scale : 1.0f) * (dev_scale2 ? *dev_scale2 : 1.0f));
-    if (EPI == 1) {
+    if (EPI == 1 || EPI == 2) {
         // (the last step() ended with a barrier: the staging buffers are dead)
         float* const img = reinterpret_cast<float*>(smem_raw) + wave * kXbFloats;
         xbox_zero_border(img, lane);
         const int nqblk = N >> 5;
         const __amdgpu_buffer_rsrc_t t_rs = make_rsrc(C + (size_t)b * M * N, (size_t)M * N * 4);
+        float* const nbr = reinterpret_cast<float*>(smem_raw) + (wave ^ 1) * kXbFloats;     // EPI 2: the other half of my query row
+        if (EPI == 2) __syncthreads();          // every image's border is zero before a neighbour writes into it
+        // EPI 2: the RAW last key of chunk 0 (pass 0 replaces acc[0..1] by their filtered values before pass 1 needs it)
+        const float k63_q0 = acc[1][0][15], k63_q1 = acc[1][1][15];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             f32x16 (&t)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * hh]);
-            xbox_64x64(t, img, lane);
+            if (EPI == 1) {
+                xbox_64x64(t, img, lane);
+            } else {
+                // 128-wide grid (box3_common.h): the wave's 128 keys are ONE image row (two chunks hh = 0, 1, handled one after
+                // the other), its 64 queries HALF a row whose other half belongs to wave ^ 1.
+                const f32x16 (&t1)[2][2] = *reinterpret_cast<const f32x16 (*)[2][2]>(&acc[2]);     // (raw in pass 0)
+                xbox_write_chunk(t, img, lane);
+                if (hh == 0) {
+                    xbox_put_first_key(t1, img, lane);                       // key 64 of chunk 0 = key 0 of chunk 1
+                } else {
+                    xbox_put_key_column(img, 3, k63_q0, k63_q1, lane, 1);    // key -1 of chunk 1 = key 63 of chunk 0
+                    xbox_zero_column(img, 68, lane);                         // chunk 1 ends at the grid's right edge
+                }
+                if (wn == 0) {                                               // my last query is the neighbour's query -1
+                    xbox_put_last_query(t, nbr, lane);
+                    if (hh == 0) xbox_put_corner(t1, nbr, lane, false, true);                          // (key 64, query -1)
+                    else xbox_put_corner_value(nbr, lane, true, true, k63_q0, k63_q1);                // (key -1, query -1)
+                } else {                                                     // my first query is the neighbour's query 64
+                    xbox_put_first_query(t, nbr, lane);
+                    if (hh == 0) xbox_put_corner(t1, nbr, lane, false, false);                         // (key 64, query 64)
+                    else xbox_put_corner_value(nbr, lane, true, false, k63_q0, k63_q1);               // (key -1, query 64)
+                }
+                __syncthreads();
+                xbox_add_diagonals(t, img, lane);
+                __syncthreads();                                             // the next pass overwrites the images
+            }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -305,8 +337,8 @@ extern "C" int cocos_box3_corr_xbox_f16x3(const void* k_hi, const void* k_lo, co
     COCOS_REQUIRE(k_hi && k_lo && q_hi && q_lo && t_blocked, COCOS_ERR_INVALID, "box3_corr_xbox_f16x3: null pointer");
     COCOS_REQUIRE(batch >= 1 && Nk >= 1 && Nq >= 1 && K >= 1, COCOS_ERR_INVALID,
                   "box3_corr_xbox_f16x3: bad dims batch=%d Nk=%d Nq=%d K=%d", batch, Nk, Nq, K);
-    COCOS_REQUIRE(grid_w == 64 && Nk % HG_BM == 0 && Nq % HG_BN == 0 && K % HG_BK == 0, COCOS_ERR_UNSUPPORTED,
-                  "box3_corr_xbox_f16x3: needs a 64-wide grid, Nk %% 256 == 0, Nq %% 128 == 0, K %% 32 == 0 "
+    COCOS_REQUIRE((grid_w == 64 || grid_w == 128) && Nk % HG_BM == 0 && Nq % HG_BN == 0 && K % HG_BK == 0, COCOS_ERR_UNSUPPORTED,
+                  "box3_corr_xbox_f16x3: needs a 64- or 128-wide grid, Nk %% 256 == 0, Nq %% 128 == 0, K %% 32 == 0 "
                   "(w=%d Nk=%d Nq=%d K=%d)", grid_w, Nk, Nq, K);
     COCOS_REQUIRE((size_t)Nk * K * 2 < 0x7fffffffull && (size_t)Nq * K * 2 < 0x7fffffffull &&
                       (size_t)Nk * Nq * 4 < 0x7fffffffull,
@@ -318,7 +350,7 @@ extern "C" int cocos_box3_corr_xbox_f16x3(const void* k_hi, const void* k_lo, co
     const size_t smem = (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16);
     static_assert((size_t)4 * kXbFloats * sizeof(float) <= (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16),
                   "the four x-box images must fit the staging buffers");
-    auto kern = hgemm_f16x3_kernel<true, 0, 1>;
+    auto kern = grid_w == 64 ? hgemm_f16x3_kernel<true, 0, 1> : hgemm_f16x3_kernel<true, 0, 2>;
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),

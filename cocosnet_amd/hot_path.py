@@ -144,7 +144,7 @@ class _Attention:
 
 
 class _BoxedCorr:
-    """match_kernel 3, PONO_C, 64-wide grid: the statistics of the unfolded vectors (K12) and, per orientation that is
+    """match_kernel 3, PONO_C, 64- or 128-wide grid: the statistics of the unfolded vectors (K12) and, per orientation that is
     actually used, T = xbox(C_raw) from the correlation GEMM's epilogue; every softmax + warp pass then reads T three
     blocks at a time (K19).  Nothing box-filtered and no logits matrix reaches HBM."""
 

@@ -1258,7 +1258,7 @@ BOX3_FUSED = os.environ.get("COCOS_BOX3_FUSED", "1") != "0"
 
 
 def box3_fused_ok(B, C, h, w, Cv=1):
-    """Shapes the fused match_kernel-3 family takes (64-wide grid, whole 256-position tiles) on the split flavour."""
+    """Shapes the fused match_kernel-3 family takes (64- or 128-wide grid, whole 256-position tiles) on the split flavour."""
     return (BOX3_FUSED and PRECISION == "f16x3" and C == FUSED_K
             and bool(_lib.load().cocos_box3_fused_supported(h * w, h * w, min(Cv, MAX_FUSED_CV), h, w)))
 
@@ -1316,7 +1316,7 @@ class _Box3CorrXbox(torch.autograd.Function):
 
 
 def box3_corr_xbox(q_raw, k_raw):
-    """x-direction diagonal box filter of the K = 256 correlation of two raw [B,256,h,w] feature maps (64-wide grid),
+    """x-direction diagonal box filter of the K = 256 correlation of two raw [B,256,h,w] feature maps (64- or 128-wide grid),
     keys in the rows, in the tile-blocked layout of K19 (an opaque 1-D tensor of B*N*N floats)."""
     return _Box3CorrXbox.apply(q_raw, k_raw)
 

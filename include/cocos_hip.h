@@ -543,7 +543,7 @@ int cocos_conv2d_wgrad_bf16(const float* x, const float* dy, float* partials, in
 
 /* K19 / K20 — match_kernel = 3 (the reference's DEFAULT, options/base_options.py:70) fused, round 3: replaces
  * F.unfold(k=3) + centre + normalise (correspondence.py:276-280, :286-289), the K = 2304 matmul (:291), /temperature (:304),
- * softmax (:307) and the warp matmul (:318 / :334) — and their autograd — for --PONO_C on a 64-wide feature grid, without a
+ * softmax (:307) and the warp matmul (:318 / :334) — and their autograd — for --PONO_C on a 64- or 128-wide feature grid, without a
  * [B,2304,HW] tensor, without the box-filtered logits matrix and without saved logits.  Decomposition (csrc/box3_common.h):
  *     S[p,q] = sum over the 3x3 offsets d of C[p+d, q+d]   (C = the K = 256 correlation; zero outside the grid)
  *            = ybox(xbox(C)),   xbox along a row (both indices +-1), ybox across rows (both indices +-w)
@@ -566,8 +566,12 @@ int cocos_conv2d_wgrad_bf16(const float* x, const float* dy, float* partials, in
  *           d theta_raw [256][Nq] = hgemm(A = channel-major planes of phi_raw,  B = dC planes, b_blocked = 3)
  *           d phi_raw   [256][Nk] = hgemm(A = channel-major planes of theta_raw, B = dC planes, b_blocked = 2)
  *       (b_blocked = 3: the same blocks read with n = queries, k = keys).
- *   cocos_box3_fused_supported: 1 when this family takes the shape (64-wide grid, Nq == Nk == h*w, Nq % 256 == 0, Cv <= 160);
- *       every other match_kernel-3 shape keeps the K3 -> K6 -> K7 chain. */
+ *   cocos_box3_fused_supported: 1 when this family takes the shape (64- or 128-wide grid — every BASELINE configuration: 256^2 at
+ *       down 4; 512^2 at down 4 and 256^2 at --warp_stride 2 are 128 x 128 — Nq == Nk == h*w, Nq % 256 == 0, Cv <= 160, one sample's
+ *       T below 2 GiB); every other match_kernel-3 shape keeps the K3 -> K6 -> K7 chain.  Round 4: on 128-wide grids the x box
+ *       exchanges its halo between the two 64-position chunks of an image row (GEMM epilogue: within a wave for the keys,
+ *       between neighbouring waves for the queries; K20: four waves per row pair), the y box spans grid_w / 32 tiles, and the
+ *       per-key statistics of samples with more than 4096 keys pass through LDS in a ring of 2048-key chunks. */
 int cocos_box3_fused_supported(int Nq, int Nk, int Cv, int grid_h, int grid_w);
 int cocos_box3_corr_xbox_f16x3(const void* k_hi, const void* k_lo, const void* q_hi, const void* q_lo, float* t_blocked,
                                int batch, int Nk, int Nq, int K, int grid_w, const float* k_scale_dev /* nullable */,

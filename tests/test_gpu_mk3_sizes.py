@@ -251,3 +251,105 @@ def test_box3_fused_family_on_small_grids_vs_fp64_and_vs_the_materialised_chain(
             assert rel(out[k], outs[k]) < TOL, (fused, k)
         assert rel(gt, dth) < TOL, fused
         assert rel(gp, dph) < TOL, fused
+
+
+# ------------------------------------------------------------------ round 4: the fused family on 128-wide grids (BASELINE config 5)
+@pytest.mark.parametrize("fh,flags", [
+    (2, dict(warp_mask_losstype="direct")),                                          # every row is a border row
+    (4, dict(warp_mask_losstype="cycle", warp_cycle_w=1.0, two_cycle=True)),
+    (6, dict(warp_patch=True, warp_cycle_w=1.0, warp_mask_losstype="none")),          # Cv = 48 patches, folded back
+    (32, dict(warp_mask_losstype="direct")),       # N = 4096: the last size whose per-key statistics sit in LDS whole
+    (40, dict(warp_mask_losstype="direct")),       # N = 5120: statistics in chunks of 2048 keys, the last one partial
+])
+def test_box3_fused_family_on_128_wide_grids_vs_fp64_and_vs_the_materialised_chain(fh, flags, monkeypatch):
+    """fh x 128 grids (N = 256 .. 768): an image row is FOUR 32-position tiles, so the x box of the correlation GEMM's
+    epilogue exchanges its halo between the two key chunks of a wave and between neighbouring waves, the y box shifts by
+    four tiles, and K20 runs four waves per row pair (box3_common.h, round 4).  Against torch-fp64 autograd of the unfolded
+    formulation and against the round-2 chain (COCOS_BOX3_FUSED=0) on the same inputs; row and column softmax, V
+    differentiated."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    B, d, fw, nc = 2, 4, 128, 7
+    g = torch.Generator(device=DEV).manual_seed(300 + fh)
+    th = torch.randn(B, 256, fh, fw, device=DEV, generator=g) + 0.15
+    ph = 0.4 * th.roll((1, 37), (2, 3)) + torch.randn(B, 256, fh, fw, device=DEV, generator=g) - 0.1
+    H, W = fh * d, fw * d
+    ref_img = torch.rand(B, 3, H, W, device=DEV, generator=g) * 2 - 1
+    real_img = torch.rand(B, 3, H, W, device=DEV, generator=g) * 2 - 1
+    seg = torch.rand(B, nc, H, W, device=DEV, generator=g)
+    ref_seg = torch.rand(B, nc, H, W, device=DEV, generator=g)
+    cfg = dict(match_kernel=3, PONO_C=True, down=d, isTrain=True, **flags)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "BOX3_FUSED", fused)
+        t, p = th.clone().requires_grad_(True), ph.clone().requires_grad_(True)
+        with ops.KernelTimer() as kt:
+            out = correspondence_hot_path(t, p, ref_img, real_img, seg, ref_seg, HotPathConfig(**cfg))
+            if fused:
+                G = {k: torch.randn(v.shape, device=DEV, generator=g) for k, v in sorted(out.items())}
+            torch.autograd.backward([out[k] for k in sorted(out)], [G[k] for k in sorted(out)])
+        res[fused] = (out, t.grad, p.grad, set(kt.summary()))
+    assert "box3_softmax_warp_fwd" in res[True][3] and "box3_adjoint_planes" in res[True][3]
+    assert "box3_logits_fwd" in res[False][3] and "box3_softmax_warp_fwd" not in res[False][3]
+    outs, dth, dph = tr.forward_backward(th, ph, ref_img, real_img, seg, ref_seg, co.default_opt(**cfg), G, device=DEV)
+    errs = {}
+    for fused in (True, False):
+        out, gt, gp, _ = res[fused]
+        assert set(out) == set(outs)
+        errs[fused] = {**{k: rel(out[k], outs[k]) for k in outs}, "d theta": rel(gt, dth), "d phi": rel(gp, dph)}
+    print("BOX3_128", fh, errs)
+    # outputs at TOL; gradients at 5e-4 (north_star: 1e-3): at N = 5120 BOTH chains — two independent kernel families — sit at
+    # the same 2.5e-4 from fp64: the floor is the fp32 evaluation of the statistics' gradients (sums of L * z with z up to
+    # +-100 that cancel to first order), not a kernel
+    for fused in (True, False):
+        assert max(v for k, v in errs[fused].items() if not k.startswith("d ")) < TOL, (fused, errs)
+        assert max(v for k, v in errs[fused].items() if k.startswith("d ")) < 5e-4, (fused, errs)
+
+
+@pytest.mark.parametrize("route", ["512_patch48", "256_stride2_patch12"])
+def test_config5_match_kernel3_hw16384_vs_fp64(route, monkeypatch):
+    """BASELINE config 5 AS THE REFERENCE RUNS IT: DeepFashion flags (README.md:69,115: --warp_patch --warp_bilinear, no mask
+    loss) on the DEFAULT match_kernel 3 (options/base_options.py:70), 128 x 128 grid, HW = 16384 — both routes of SURVEY §8d:
+    512^2 input at down 4 (48 patch channels; the reference's F.fold hard-codes 256, the oracle folds to the true size) and
+    256^2 input with --warp_stride 2 (12 patch channels).  B = 2, training graph; outputs and d theta / d phi of BOTH samples
+    against torch-fp64 autograd of the unfolded K = 2304 formulation, evaluated on the device (16384^2 x 2304 in fp64: 1.2
+    TFLOP per sample forward).  The fused family must be what runs: no materialised logits (the K3 -> K6 -> K7 chain would be
+    three 1 GiB matrices per sample and orientation)."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    B, fh = 2, 128
+    d = 4 if route == "512_patch48" else 2
+    S = fh * d
+    g = torch.Generator(device=DEV).manual_seed(77)
+    th = torch.randn(B, 256, fh, fh, device=DEV, generator=g)
+    blk = fh // 8
+    perm = torch.randperm(64, device=DEV, generator=g)
+    t = th.reshape(B, 256, 8, blk, 8, blk).permute(0, 1, 2, 4, 3, 5).reshape(B, 256, 64, blk, blk)
+    t = t[:, :, perm].reshape(B, 256, 8, 8, blk, blk).permute(0, 1, 2, 4, 3, 5).reshape(B, 256, fh, fh)
+    ph = 0.35 * t + torch.randn(B, 256, fh, fh, device=DEV, generator=g)
+    ref_img = torch.rand(B, 3, S, S, device=DEV, generator=g) * 2 - 1
+    seg = torch.rand(B, 20, S, S, device=DEV, generator=g)
+    flags = dict(match_kernel=3, PONO_C=True, down=d, warp_patch=True, warp_bilinear=True, isTrain=True, warp_mask_losstype="none")
+    tq, pq = th.clone().requires_grad_(True), ph.clone().requires_grad_(True)
+    torch.cuda.reset_peak_memory_stats()
+    with ops.KernelTimer() as kt:
+        out = correspondence_hot_path(tq, pq, ref_img, ref_img, seg, seg, HotPathConfig(**flags))
+        G = {"warp_out": torch.randn(out["warp_out"].shape, device=DEV, generator=g)}
+        out["warp_out"].backward(G["warp_out"])
+    tags = set(kt.summary())
+    peak_gib = torch.cuda.max_memory_allocated() / 2 ** 30
+    assert set(out) == {"warp_out"} and out["warp_out"].shape == (B, 3, S, S)
+    assert {"box3_corr_xbox", "box3_softmax_warp_fwd", "box3_softmax_warp_bwd", "box3_adjoint_planes"} <= tags, tags
+    assert not ({"box3_logits_fwd", "corr_materialize", "logits_softmax_warp_fwd"} & tags), tags
+    print("CFG5_MK3", route, "peak GiB", round(peak_gib, 2))
+    assert peak_gib < 12.0, peak_gib          # T + G + the dC planes: 3 x 1 GiB per sample, + operands (the chain: > 20 GiB)
+    for b in range(B):
+        sl = slice(b, b + 1)
+        outs, dth, dph = tr.forward_backward(th[sl], ph[sl], ref_img[sl], ref_img[sl], seg[sl], seg[sl], co.default_opt(**flags),
+                                             {k: v[sl] for k, v in G.items()}, device=DEV)
+        assert rel(out["warp_out"][sl], outs["warp_out"]) < TOL, b
+        assert rel(tq.grad[sl], dth) < TOL, b
+        assert rel(pq.grad[sl], dph) < TOL, b
+        torch.cuda.empty_cache()
