@@ -110,6 +110,44 @@ def module_scope_context(device, d, steps=8, warmup=6):
     return out
 
 
+def config5_context(device, steps=5, warmup=3):
+    """BASELINE config 5 as the reference runs it: DeepFashion flags (README.md:69,115: --warp_patch --warp_bilinear, float pose maps,
+    no mask loss) on the DEFAULT match_kernel 3 (options/base_options.py:70), 512^2 input at down 4 = 128 x 128 grid, HW = 16384,
+    B = 2, forward + backward of the hot path from theta / phi on — the fused match_kernel-3 family on a 128-wide grid (round 4;
+    round 3 fell back to three materialised 1 GiB matrices per sample and orientation here).  Context, never part of `value`."""
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    B, S, fh = 2, 512, 128
+    g = torch.Generator(device=device).manual_seed(4321)
+    th = torch.randn(B, KDIM, fh, fh, device=device, generator=g).requires_grad_(True)
+    ph = (0.3 * th.detach().roll((3, 11), (2, 3)) + torch.randn(B, KDIM, fh, fh, device=device, generator=g)).requires_grad_(True)
+    img = torch.rand(B, 3, S, S, device=device, generator=g) * 2 - 1
+    seg = torch.rand(B, 20, S, S, device=device, generator=g)
+    gout = torch.randn(B, 3, S, S, device=device, generator=g)
+    out = {}
+    for mk in (3, 1):
+        cfg = HotPathConfig(match_kernel=mk, PONO_C=True, down=4, warp_patch=True, warp_bilinear=True, isTrain=True)
+
+        def step():
+            th.grad = ph.grad = None
+            o = correspondence_hot_path(th, ph, img, img, seg, seg, cfg)
+            o["warp_out"].backward(gout)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out[f"match_kernel_{mk}"] = {"ms_per_step": round(ms, 3), "images_per_s": round(B / ms * 1e3, 1), "steps": steps,
+                                     "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    out["note"] = ("DeepFashion 512^2 --warp_patch (Cv = 48), 128x128 grid (HW = 16384), B = 2, hot path fwd+bwd; match_kernel 3 is "
+                   "what every README command runs (base_options.py:70): fused family K19 / K20 on a 128-wide grid")
+    return out
+
+
 def build_inputs(device, scope):
     g = torch.Generator(device=device).manual_seed(1234 + (torch.distributed.get_rank()
                                                            if torch.distributed.is_initialized() else 0))
@@ -548,8 +586,12 @@ def main():
         # context: the whole drop-in module (feature producers + the path) on the same inputs, in its two convolution flavours —
         # never part of `value`, never allowed to cost the line
         if args.scope == "hotpath":
+            context = dict(context or {})
             try:
-                context = dict(context or {})
+                context["config5"] = config5_context(device)
+            except Exception as e:       # noqa: BLE001
+                context["config5"] = {"error": repr(e)}
+            try:
                 context["module_scope"] = module_scope_context(device, d)
             except Exception as e:       # noqa: BLE001
                 context["module_scope"] = {"error": repr(e)}

@@ -22,9 +22,17 @@ NORM_EPS = sys.float_info.epsilon
 MAX_FUSED_CV = 160
 #: ... of the split-precision forward: one padding channel of the V tile carries the softmax row sums
 MAX_FUSED_SPLIT_CV = 159
-#: largest dS^T scratch (bytes) the backward may allocate to replace the second logits recompute by
+#: largest dS^T scratch (bytes) the EXACT-FP32 backward may allocate to replace the second logits recompute by
 #: a GEMM; above it (e.g. 128x128 grids at large batch) the flash-style key kernel is used
 MAX_DS_WORKSPACE_BYTES = 16 << 30
+#: split flavour: a training forward SAVES its logits (B*Nq*Nk*4 bytes) for the backward only up to this size; above it the
+#: forward keeps the row LSE alone and the backward RECOMPUTES the logits, one chunk of keys at a time (round 4:
+#: _CorrSoftmaxWarp._backward_recompute — same kernels, HWxHW scratch bounded by RECOMPUTE_CHUNK_BYTES per matrix).  1 GiB keeps
+#: every 64x64-grid configuration (B <= 16) on the saved-logits chain, which is ~25 % faster where it fits,
+#: and puts BASELINE config 5 (128x128 grid: 1 GiB PER SAMPLE) on the bounded-memory route.  Module attribute, read at call time.
+MAX_SAVED_LOGITS_BYTES = int(os.environ.get("COCOS_MAX_SAVED_LOGITS_BYTES", 1 << 30))
+#: ... the recomputed logits / dS'' / P planes of one key chunk (bytes per matrix)
+RECOMPUTE_CHUNK_BYTES = int(os.environ.get("COCOS_RECOMPUTE_CHUNK_BYTES", 512 << 20))
 #: channel count the fused kernels are specialised for (self.inter_channels, correspondence.py:170)
 FUSED_K = 256
 #: where the K2 forward's products run: "fp32" = v_mfma_f32_32x32x2_f32 (exact fp32 operands);
@@ -336,10 +344,27 @@ def f16_plane_block_mask(plane: torch.Tensor) -> torch.Tensor:
     return cell
 
 
-def _split_bwd_ok(B, Nq, Nk, Cv):
-    """Shapes the split-precision K2 backward takes (cocos_corr_softmax_warp_bwd_query_f16x3 + the planes GEMM)."""
-    return (Nk % 8 == 0 and Nq % 8 == 0 and Cv <= MAX_FUSED_CV and B * Nq * Nk * 4 <= MAX_DS_WORKSPACE_BYTES
+def _recompute_chunk(B, Nq, Nk):
+    """Keys per chunk of the recompute backward: whole 128-key groups (blocked planes), RECOMPUTE_CHUNK_BYTES per matrix."""
+    per_key = max(B * Nq * 4, 1)
+    kc = max(128, (RECOMPUTE_CHUNK_BYTES // per_key) // 128 * 128)
+    return min(kc, (Nk + 127) // 128 * 128)
+
+
+def _saves_logits(B, Nq, Nk) -> bool:
+    """Split flavour: does a training forward of this shape save its logits (else: LSE only, chunked recompute)?"""
+    return (B * Nq * Nk * 4 <= MAX_SAVED_LOGITS_BYTES
             and _lib.load().cocos_corr_softmax_warp_saved_logits_bytes(1, Nq, Nk) < 2 ** 31 - 1)
+
+
+def _split_bwd_ok(B, Nq, Nk, Cv):
+    """Shapes the split-precision K2 backward takes (cocos_corr_softmax_warp_bwd_query_f16x3 + the planes GEMM) — with saved
+    logits, or by recomputing them chunk by chunk (any size whose per-sample chunk stays below 2 GiB)."""
+    if not (Nk % 8 == 0 and Nq % 8 == 0 and Cv <= MAX_FUSED_CV):
+        return False
+    if _saves_logits(B, Nq, Nk):
+        return True
+    return Nk % 128 == 0 and Nq % 32 == 0 and Nq * _recompute_chunk(B, Nq, Nk) * 4 < 2 ** 31 - 1
 
 
 class _CorrSoftmaxWarp(torch.autograd.Function):
@@ -363,7 +388,8 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         if planes is not None:       # split-precision flavour: same outputs, f16x3 matrix products
             qh, ql, kh, kl, vh, vl, v_scale, v_amax, v_lomask = planes[:9]
             qk_scales = planes[13] if len(planes) > 13 else None      # (q_scale, k_scale) device scalars, or None
-            if keep_logits:          # the forward's private tile-blocked layout (cocos_hip.h), opaque here
+            ctx.recompute = bool(keep_logits) and not _saves_logits(B, Nq, Nk)
+            if keep_logits and not ctx.recompute:   # the forward's private tile-blocked layout (cocos_hip.h), opaque here
                 nbytes = _lib.load().cocos_corr_softmax_warp_saved_logits_bytes(B, Nq, Nk)
                 logits_t = torch.empty(nbytes // 4, device=qn.device, dtype=torch.float32)
             _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd_f16x3", qh.data_ptr(), ql.data_ptr(),
@@ -383,8 +409,11 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         ctx.save_for_backward(qn, kn, v, out, lse)
         ctx.logits_t = logits_t
         ctx.inv_t = float(inv_temperature)
-        # channel-major planes of k_scale*qn, k_scale*kn for the split-precision backward (when given)
-        ctx.cplanes = planes[9:13] if (planes is not None and len(planes) > 9 and logits_t is not None) else None
+        # channel-major planes of k_scale*qn, k_scale*kn for the split-precision backward (when given); the recompute
+        # backward also needs the position-major ones the forward multiplied
+        recompute = planes is not None and getattr(ctx, "recompute", False)
+        ctx.cplanes = planes[9:13] if (planes is not None and len(planes) > 9 and (logits_t is not None or recompute)) else None
+        ctx.pplanes = planes[0:4] if recompute else None
         return out
 
     @staticmethod
@@ -399,6 +428,8 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         dv = torch.empty_like(v) if need_v else None
         st = _stream()
         logits_t = ctx.logits_t
+        if ctx.split and getattr(ctx, "recompute", False):
+            return _CorrSoftmaxWarp._backward_recompute(ctx, qn, kn, v, out, lse, dout, dqn, dkn, dv, need_k)
         if ctx.split and logits_t is not None:
             # split-precision backward: everything on the f16 MFMA, fp32-class accuracy (see cocos_hip.h).  The
             # forward only takes this flavour (and saves its private logits layout) for shapes this branch takes.
@@ -464,6 +495,83 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                   kn.data_ptr(), v.data_ptr(), lse.data_ptr(), dout.data_ptr(), dvec.data_ptr(),
                   _ptr(dkn), _ptr(dv), *dims)
         return dqn, (dkn if need_k else None), dv, None, None, None
+
+
+def _corr_bwd_recompute(ctx, qn, kn, v, out, lse, dout, dqn, dkn, dv, need_k):
+    """Split-precision backward WITHOUT saved logits (the forward kept the row LSE only): the keys are walked in chunks of
+    _recompute_chunk() keys; per chunk the forward kernel is run again on the resident operand planes just for its logits
+    (one zero value channel: 6 instead of 30 P.V MFMAs per tile; its softmax output is discarded — the RAW logits it
+    saves do not depend on it), then the query kernel (global LSE and D: a chunk's dS'' is exact) and the key-side GEMM(s)
+    for that slice of d kn / d v; d qn accumulates over the chunks.  HWxHW scratch: RECOMPUTE_CHUNK_BYTES per matrix
+    instead of B*Nq*Nk*4 — BASELINE config 5 (HW = 16384, B = 2): 2 x 0.5 GiB instead of 2 x 2 GiB.  Same kernels, same
+    arithmetic per element as the saved-logits chain (bit-identical dS'')."""
+    qh, ql, kh, kl = ctx.pplanes
+    qch, qcl, kch, kcl = ctx.cplanes
+    qks = ctx.qk_scales
+    B, K, Nq = qn.shape
+    Nk, Cv = kn.shape[2], v.shape[1]
+    st = _stream()
+    lib = _lib.load()
+    cvp = (Cv + 31) // 32 * 32
+    g_amax, v_amax = _recall_amax(dout), ctx.v_amax
+    if g_amax is None:
+        g_amax = absmax(dout)
+    gph, gpl, g_scale = split_f16(dout, True, cpad=cvp, amax=g_amax)
+    vph, vpl, v_scale = split_f16(v, True, cpad=cvp, amax=v_amax)
+    gch = gcl = None
+    if dv is not None:
+        gch, gcl, _ = split_f16(dout, False, amax=g_amax)
+    dev, half = qn.device, dict(device=qn.device, dtype=torch.float16)
+    want_k = dkn is not None
+    kc = _recompute_chunk(B, Nq, Nk)
+    ds_scale = torch.empty(1, device=dev, dtype=torch.float32)
+    dq_acc = None
+    # scratch shared by the chunks (sized for a full chunk)
+    o1 = torch.empty((B, 1, Nq), device=dev, dtype=torch.float32)
+    l1 = torch.empty((B, Nq), device=dev, dtype=torch.float32)
+    for k0 in range(0, Nk, kc):
+        n = min(kc, Nk - k0)
+        khc, klc = kh[:, k0:k0 + n].contiguous(), kl[:, k0:k0 + n].contiguous()
+        vz = torch.zeros((B, 1, n), **half)                  # one zero value channel (hi and lo plane alike)
+        lg = torch.empty(lib.cocos_corr_softmax_warp_saved_logits_bytes(B, Nq, n) // 4, device=dev, dtype=torch.float32)
+        _call("corr_softmax_warp_recompute", "cocos_corr_softmax_warp_fwd_f16x3", qh.data_ptr(), ql.data_ptr(), khc.data_ptr(),
+              klc.data_ptr(), vz.data_ptr(), vz.data_ptr(), o1.data_ptr(), l1.data_ptr(), lg.data_ptr(), None, None, B, K, Nq, n, 1,
+              ctx.inv_t, SPLIT_OPERAND_SCALE, _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), st)
+        kchc, kclc = kch[:, :, k0:k0 + n].contiguous(), kcl[:, :, k0:k0 + n].contiguous()
+        vphc, vplc = vph[:, k0:k0 + n].contiguous(), vpl[:, k0:k0 + n].contiguous()
+        dsh = dsl = psh = psl = None
+        if want_k:
+            dsh, dsl = torch.empty((B, n, Nq), **half), torch.empty((B, n, Nq), **half)
+        if dv is not None:
+            psh, psl = torch.empty((B, n, Nq), **half), torch.empty((B, n, Nq), **half)
+        blocked = int(n % 128 == 0 and Nq % 32 == 0)
+        dq_c = torch.empty_like(qn)
+        _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3", kchc.data_ptr(), kclc.data_ptr(),
+              vphc.data_ptr(), vplc.data_ptr(), gph.data_ptr(), gpl.data_ptr(), g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(),
+              lse.data_ptr(), lg.data_ptr(), dq_c.data_ptr(), _ptr(dsh), _ptr(dsl), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
+              v_scale.data_ptr(), ds_scale.data_ptr(), _ptr(ctx.v_lomask), B, K, Nq, n, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE,
+              _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked, st)
+        del lg
+        dq_acc = dq_c if dq_acc is None else dq_acc.add_(dq_c)
+        if want_k:
+            dk_c = dkn if n == Nk else torch.empty((B, K, n), device=dev, dtype=torch.float32)
+            _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(), dsh.data_ptr(),
+                  dsl.data_ptr(), dk_c.data_ptr(), B, K, n, Nq, 1.0 if qks else 1.0 / SPLIT_OPERAND_SCALE, ds_scale.data_ptr(),
+                  _ptr(qks[0] if qks else None), 2 * blocked, st)
+            if dk_c is not dkn:
+                dkn[:, :, k0:k0 + n] = dk_c
+        if dv is not None:
+            dv_c = dv if n == Nk else torch.empty((B, Cv, n), device=dev, dtype=torch.float32)
+            _call("corr_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(), psl.data_ptr(),
+                  dv_c.data_ptr(), B, Cv, n, Nq, 1.0 / 16384.0, g_scale.data_ptr(), 0, 2 * blocked, st)
+            if dv_c is not dv:
+                dv[:, :, k0:k0 + n] = dv_c
+    if dqn is not None:
+        dqn = dq_acc
+    return dqn, (dkn if need_k else None), dv, None, None, None
+
+
+_CorrSoftmaxWarp._backward_recompute = staticmethod(_corr_bwd_recompute)
 
 
 def _wants_logits(qn, kn):

@@ -165,10 +165,13 @@ def _rows_oracle(qn, kn, v, g, idx, inv_t):
 
 
 def test_config5_hw16384_sampled_rows_and_key_side_vs_recompute(monkeypatch):
-    """DeepFashion --warp_patch at 512x512: 128x128 grid, Cv = 48, saved logits = 1 GiB per sample (just below the 2^31
-    per-sample guards).  Forward and d theta on sampled query rows vs fp64; d phi (a sum over ALL queries) against the
-    exact-fp32 recompute kernels — the path taken above MAX_DS_WORKSPACE_BYTES — which also exercises that fallback
-    at size.  Both flavours in one test (the comparison IS between them)."""
+    """DeepFashion --warp_patch at 512x512: 128x128 grid, Cv = 48, logits = 1 GiB per sample (just below the 2^31
+    per-sample guards).  Three routes through the same shape, all three in one test (the comparison IS between them):
+      split_saved      f16x3, logits saved (ops.MAX_SAVED_LOGITS_BYTES raised): the chain the 64x64 grids take;
+      split_recompute  f16x3, the DEFAULT for this shape since round 4: LSE only, logits recomputed per chunk of keys
+                       (ops._corr_bwd_recompute) — HWxHW scratch 2 x 0.5 GiB instead of 2 x 2 GiB;
+      fp32_recompute   exact-fp32 flash-style kernels (the path above MAX_DS_WORKSPACE_BYTES of that flavour).
+    Forward and d theta on sampled query rows vs fp64; d phi (a sum over ALL queries) between the routes."""
     from cocosnet_amd import ops
     B, N, Cv = 2, 16384, 48
     g = torch.Generator(device=DEV).manual_seed(5)
@@ -178,18 +181,28 @@ def test_config5_hw16384_sampled_rows_and_key_side_vs_recompute(monkeypatch):
     k = k - k.mean(1, keepdim=True); k = k / k.norm(dim=1, keepdim=True)
     v = torch.rand(B, Cv, N, device=DEV, generator=g) * 2 - 1
     go = torch.randn(B, Cv, N, device=DEV, generator=g)
-    res = {}
-    for name, prec, limit in (("split", "f16x3", 16 << 30), ("recompute", "fp32", 0)):
+    res, peak = {}, {}
+    for name, prec, limit, saved in (("split_saved", "f16x3", 16 << 30, 16 << 30), ("split_recompute", "f16x3", 16 << 30, 1 << 30),
+                                     ("fp32_recompute", "fp32", 0, 1 << 30)):
         monkeypatch.setattr(ops, "PRECISION", prec)
         monkeypatch.setattr(ops, "MAX_DS_WORKSPACE_BYTES", limit)
+        monkeypatch.setattr(ops, "MAX_SAVED_LOGITS_BYTES", saved)
         qq, kk = q.clone().requires_grad_(True), k.clone().requires_grad_(True)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
         with ops.KernelTimer() as kt:
             o = ops.corr_softmax_warp(qq, kk, v, 100.0)
             o.backward(go)
         tags = set(kt.summary())
+        peak[name] = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
         res[name] = (o.detach(), qq.grad, kk.grad, tags)
-    assert "corr_softmax_warp_bwd_key_from_ds" in res["split"][3]          # saved logits + planes GEMM
-    assert "corr_softmax_warp_bwd_key" in res["recompute"][3]              # flash-style fallback
+        del o
+    print("CFG5_ROUTES peak GiB above the inputs:", {k_: round(v_, 2) for k_, v_ in peak.items()})
+    assert "corr_softmax_warp_recompute" not in res["split_saved"][3] and "corr_softmax_warp_bwd_key_from_ds" in res["split_saved"][3]
+    assert "corr_softmax_warp_recompute" in res["split_recompute"][3]      # chunked recompute on the split kernels
+    assert "corr_softmax_warp_bwd_key" in res["fp32_recompute"][3]         # flash-style fp32 fallback
+    assert peak["split_saved"] > 4.0 and peak["split_recompute"] < 2.0, peak    # 2 x 2 GiB of HWxHW scratch vs 2 x 0.5 GiB
     idx = np.arange(7, N, 509)
     f64 = lambda t: t.double().cpu().numpy()
     for b in range(B):
@@ -197,8 +210,48 @@ def test_config5_hw16384_sampled_rows_and_key_side_vs_recompute(monkeypatch):
         for name in res:
             assert rel(res[name][0][b][:, idx], o_ref) < TOL, (name, b)
             assert rel(res[name][1][b][:, idx], dq_ref) < TOL, (name, b)
-    assert rel(res["split"][2], f64(res["recompute"][2])) < TOL
-    assert rel(res["split"][0], f64(res["recompute"][0])) < 1e-4
+    assert rel(res["split_saved"][2], f64(res["fp32_recompute"][2])) < TOL
+    assert rel(res["split_recompute"][2], f64(res["split_saved"][2])) < 1e-6     # the same dS'' per element: the same d kn
+    assert rel(res["split_recompute"][1], f64(res["split_saved"][1])) < 1e-5     # d qn: summed over the chunks in another order
+    assert rel(res["split_saved"][0], f64(res["fp32_recompute"][0])) < 1e-4
+
+
+@pytest.mark.parametrize("with_dv", [False, True])
+def test_chunked_recompute_backward_equals_the_saved_logits_chain(with_dv, monkeypatch):
+    """ops._corr_bwd_recompute forced on a small shape with FOUR key chunks (one of them shorter), against the saved-logits
+    chain on the same inputs — dqn / dkn / dv — and against fp64.  `with_dv`: V differentiated (P planes + second GEMM per chunk)."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    B, Nq, Nk, Cv = 2, 256, 896, 40
+    g = torch.Generator(device=DEV).manual_seed(15)
+    q = torch.randn(B, 256, Nq, device=DEV, generator=g)
+    k = torch.randn(B, 256, Nk, device=DEV, generator=g)
+    k[:, :, :Nq] += 0.3 * q
+    q = q / q.norm(dim=1, keepdim=True); k = k / k.norm(dim=1, keepdim=True)
+    v = torch.rand(B, Cv, Nk, device=DEV, generator=g) * 2 - 1
+    go = torch.randn(B, Cv, Nq, device=DEV, generator=g)
+    res = {}
+    for name, saved, chunk in (("saved", 1 << 30, 512 << 20), ("recompute", 0, B * Nq * 4 * 256)):     # 256 keys per chunk: 256+256+256+128
+        monkeypatch.setattr(ops, "MAX_SAVED_LOGITS_BYTES", saved)
+        monkeypatch.setattr(ops, "RECOMPUTE_CHUNK_BYTES", chunk)
+        qq, kk, vv = q.clone().requires_grad_(True), k.clone().requires_grad_(True), v.clone().requires_grad_(with_dv)
+        with ops.KernelTimer() as kt:
+            o = ops.corr_softmax_warp(qq, kk, vv, 100.0)
+            o.backward(go)
+        tags = kt.summary()
+        res[name] = (o.detach(), qq.grad, kk.grad, vv.grad, tags)
+    assert res["recompute"][4]["corr_softmax_warp_recompute"]["calls"] == 4 and "corr_softmax_warp_recompute" not in res["saved"][4]
+    f64 = lambda t: t.double().cpu().numpy()
+    assert torch.equal(res["saved"][0], res["recompute"][0])
+    assert rel(res["recompute"][1], f64(res["saved"][1])) < 1e-5
+    assert rel(res["recompute"][2], f64(res["saved"][2])) < 1e-6
+    if with_dv:
+        assert rel(res["recompute"][3], f64(res["saved"][3])) < 1e-6
+    o_ref = co.corr_softmax_warp(f64(q), f64(k), f64(v), 100.0)
+    dq_ref, dk_ref, dv_ref = co.corr_softmax_warp_bwd(f64(q), f64(k), f64(v), f64(go), 100.0)
+    assert rel(res["recompute"][0], o_ref) < TOL and rel(res["recompute"][1], dq_ref) < TOL and rel(res["recompute"][2], dk_ref) < TOL
+    if with_dv:
+        assert rel(res["recompute"][3], dv_ref) < TOL
 
 
 def test_config5_warp_patch_512_through_the_hot_path():

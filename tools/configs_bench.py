@@ -6,6 +6,7 @@ from cocosnet_amd import ops
 from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
 
 def run(name, B, size, nc, seg_float, cfg, steps=10):
+    torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
     g = torch.Generator(device="cuda").manual_seed(0)
     fh = size // cfg.down
     th = torch.randn(B, 256, fh, fh, device="cuda", generator=g).requires_grad_(True)
@@ -53,5 +54,26 @@ out.append(run("cfg5 DeepFashion 512^2 warp_patch, 128x128 grid, B=2 mk1", 2, 51
                C(match_kernel=1, PONO_C=True, warp_bilinear=True, warp_patch=True, isTrain=True)))
 out.append(run("cfg5' 256^2 warp_stride 2 warp_patch, 128x128 grid, B=2 mk1", 2, 256, 20, True,
                C(match_kernel=1, PONO_C=True, warp_bilinear=True, warp_patch=True, down=2, isTrain=True)))
+# the same two routes AS THE REFERENCE RUNS THEM: match_kernel 3 is the default of every README command (base_options.py:70)
+out.append(run("cfg5 mk3 DeepFashion 512^2 warp_patch, 128x128 grid, B=2, match_kernel 3 (fused family, round 4)", 2, 512, 20, True,
+               C(match_kernel=3, PONO_C=True, warp_bilinear=True, warp_patch=True, isTrain=True)))
+out.append(run("cfg5' mk3 256^2 warp_stride 2 warp_patch, 128x128 grid, B=2, match_kernel 3", 2, 256, 20, True,
+               C(match_kernel=3, PONO_C=True, warp_bilinear=True, warp_patch=True, down=2, isTrain=True)))
+ops.BOX3_FUSED = False     # what round 3 ran for these shapes: K3 -> K6 -> K7, three 1 GiB matrices per sample and orientation
+out.append(run("cfg5 mk3, round-3 route (materialised chain, COCOS_BOX3_FUSED=0)", 2, 512, 20, True,
+               C(match_kernel=3, PONO_C=True, warp_bilinear=True, warp_patch=True, isTrain=True), steps=3))
+ops.BOX3_FUSED = True
+# ---- saved logits vs chunked recompute on the split flavour: the same three shapes, the route forced ----
+def ab(name, *a, **k):
+    saved = (ops.MAX_SAVED_LOGITS_BYTES, ops.RECOMPUTE_CHUNK_BYTES)
+    try:
+        for route, lim in (("saved logits", 64 << 30), ("chunked recompute (512 MiB per matrix)", 0)):
+            ops.MAX_SAVED_LOGITS_BYTES = lim
+            out.append(run(f"A/B {name}: {route}", *a, **k))
+    finally:
+        ops.MAX_SAVED_LOGITS_BYTES, ops.RECOMPUTE_CHUNK_BYTES = saved
+ab("cfg2 mk1 B=8", 8, 256, 151, False, C(match_kernel=1, PONO_C=True, warp_mask_losstype="direct", isTrain=True))
+ab("cfg3 mk1 B=16 cycle", 16, 256, 15, True, C(match_kernel=1, PONO_C=True, warp_bilinear=True, warp_cycle_w=1.0, two_cycle=True, isTrain=True))
+ab("cfg5 mk1 B=2 HW=16384", 2, 512, 20, True, C(match_kernel=1, PONO_C=True, warp_bilinear=True, warp_patch=True, isTrain=True))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/configs_bench.json", "w"), indent=1)
