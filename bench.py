@@ -148,6 +148,78 @@ def config5_context(device, steps=5, warmup=3):
     return out
 
 
+def config3_context(device, steps=4, warmup=3):
+    """BASELINE config 3 as written — "CelebA-HQ edge->face 256x256 batch 16, + HIP SPADE generator / PatchGAN conv kernels, bf16
+    MFMA" — for the two networks behind the correspondence: cocosnet_amd.translation.SPADEGenerator (generator.py:17-89) and
+    MultiscaleDiscriminator (discriminator.py:14-177) with the README's training flags (README.md:106), B = 16, random-init
+    weights, synthetic inputs: forward + backward of G (conditioned on [warp_out | edge maps]) and of D on [maps | fake], in the
+    fp32-accurate flavour (f16x3) and in the one the config names (bf16), each with its END-TO-END error against an fp64 copy of
+    the same module evaluated by the framework (B = 2 of the same inputs).  Context, never part of `value`."""
+    import copy
+    from cocosnet_amd import ops, translation as tl
+    opt = tl.celebahq_edge_train_options()
+    B = 16
+    g = torch.Generator(device=device).manual_seed(77)
+    seg = torch.rand(B, 15, IMG, IMG, device=device, generator=g)
+    cbn = torch.cat((torch.rand(B, 3, IMG, IMG, device=device, generator=g) * 2 - 1, seg), 1)
+    real = torch.rand(B, 3, IMG, IMG, device=device, generator=g) * 2 - 1
+    gimg = torch.randn(B, 3, IMG, IMG, device=device, generator=g)
+    out, saved = {}, ops.CONV_PRECISION
+    try:
+        torch.manual_seed(0)
+        G = tl.SPADEGenerator(opt).to(device)
+        G.init_weights(opt.init_type, opt.init_variance)
+        D = tl.MultiscaleDiscriminator(opt).to(device)
+        D.init_weights(opt.init_type, opt.init_variance)
+        G.eval(); D.eval()                       # spectral norm does not iterate: every arm sees the same weights
+        G64, D64 = copy.deepcopy(G).double(), copy.deepcopy(D).double()
+        with torch.no_grad():
+            y64 = G64(seg[:2].double(), warp_out=cbn[:2].double())
+            d64 = D64(torch.cat((seg[:2].double(), y64), 1))[0]
+        G.train(); D.train()
+        gp, dp = list(G.parameters()), list(D.parameters())
+        for flavour in ("f16x3", "bf16"):
+            ops.CONV_PRECISION = flavour
+
+            def g_step():
+                for p in gp:
+                    p.grad = None
+                G(seg, warp_out=cbn).backward(gimg)
+
+            def d_step():
+                for p in dp:
+                    p.grad = None
+                res = D(torch.cat((seg, real), 1))[0]
+                torch.autograd.backward([r[-1] for r in res], [torch.ones_like(r[-1]) for r in res])
+
+            rec = {}
+            for name, fn in (("generator", g_step), ("discriminator", d_step)):
+                for _ in range(warmup):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    fn()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / steps * 1e3
+                rec[name] = {"ms_fwd_bwd": round(ms, 2), "images_per_s": round(B / ms * 1e3, 1)}
+            G.eval(); D.eval()
+            with torch.no_grad():
+                y = G(seg[:2], warp_out=cbn[:2])
+                dd = D(torch.cat((seg[:2], y64.float()), 1))[0]
+            G.train(); D.train()
+            rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+            rec["err_vs_fp64"] = {"fake_image": rel(y, y64), "D_logits": max(rel(a[-1], b[-1]) for a, b in zip(dd, d64))}
+            out[flavour] = rec
+        out["note"] = ("cocosnet_amd.translation.SPADEGenerator / MultiscaleDiscriminator, CelebA-HQ edge training flags, B = 16, 256x256, "
+                       "forward + backward each; err_vs_fp64 = max-norm error of the generated image / the PatchGAN logits against an "
+                       "fp64 copy of the same module (eval mode, 2 samples): bf16 is the precision BASELINE config 3 names for these two "
+                       "networks (behind InstanceNorm / SPADE, NOT upstream of the correlation)")
+    finally:
+        ops.CONV_PRECISION = saved
+    return out
+
+
 def build_inputs(device, scope):
     g = torch.Generator(device=device).manual_seed(1234 + (torch.distributed.get_rank()
                                                            if torch.distributed.is_initialized() else 0))
@@ -591,6 +663,11 @@ def main():
                 context["config5"] = config5_context(device)
             except Exception as e:       # noqa: BLE001
                 context["config5"] = {"error": repr(e)}
+            try:
+                context["config3"] = config3_context(device)
+            except Exception as e:       # noqa: BLE001
+                context["config3"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
             try:
                 context["module_scope"] = module_scope_context(device, d)
             except Exception as e:       # noqa: BLE001

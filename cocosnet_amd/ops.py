@@ -25,14 +25,17 @@ MAX_FUSED_SPLIT_CV = 159
 #: largest dS^T scratch (bytes) the EXACT-FP32 backward may allocate to replace the second logits recompute by
 #: a GEMM; above it (e.g. 128x128 grids at large batch) the flash-style key kernel is used
 MAX_DS_WORKSPACE_BYTES = 16 << 30
-#: split flavour: a training forward SAVES its logits (B*Nq*Nk*4 bytes) for the backward only up to this size; above it the
-#: forward keeps the row LSE alone and the backward RECOMPUTES the logits, one chunk of keys at a time (round 4:
-#: _CorrSoftmaxWarp._backward_recompute — same kernels, HWxHW scratch bounded by RECOMPUTE_CHUNK_BYTES per matrix).  1 GiB keeps
-#: every 64x64-grid configuration (B <= 16) on the saved-logits chain, which is ~25 % faster where it fits,
-#: and puts BASELINE config 5 (128x128 grid: 1 GiB PER SAMPLE) on the bounded-memory route.  Module attribute, read at call time.
-MAX_SAVED_LOGITS_BYTES = int(os.environ.get("COCOS_MAX_SAVED_LOGITS_BYTES", 1 << 30))
-#: ... the recomputed logits / dS'' / P planes of one key chunk (bytes per matrix)
-RECOMPUTE_CHUNK_BYTES = int(os.environ.get("COCOS_RECOMPUTE_CHUNK_BYTES", 512 << 20))
+#: split flavour: a training forward SAVES its logits (B*Nq*Nk*4 bytes, and the backward as much again for the dS'' planes)
+#: only up to this size; above it the forward keeps the row LSE alone and the backward RECOMPUTES the logits, one chunk of keys
+#: at a time (round 4: _corr_bwd_recompute — same kernels, HWxHW scratch bounded by RECOMPUTE_CHUNK_BYTES per matrix).
+#: Measured A/B at the three BASELINE shapes (profiles/r04_configs_bench.json): the saved-logits chain is 24 % (cfg2), 33 % (cfg3)
+#: and 45-68 % (cfg5) FASTER where it fits, so the default is speed first on a 288 GB part — 16 GiB, the cap of rounds 1-3, beyond
+#: which this route now replaces the exact-fp32 flash kernels; COCOS_MAX_SAVED_LOGITS_BYTES=1073741824 puts BASELINE config 5
+#: (1 GiB of logits PER SAMPLE) on the bounded-memory route: 4.3 -> 2.5 GiB peak.  Module attribute, read at call time.
+MAX_SAVED_LOGITS_BYTES = int(os.environ.get("COCOS_MAX_SAVED_LOGITS_BYTES", 16 << 30))
+#: ... the recomputed logits / dS'' / P planes of one key chunk (bytes per matrix).  1 GiB: at HW = 16384, B = 2 a chunk is 8192
+#: keys — the key-side GEMM of a chunk still has 128 workgroups (512 MiB chunks: 64 workgroups, its time tripled)
+RECOMPUTE_CHUNK_BYTES = int(os.environ.get("COCOS_RECOMPUTE_CHUNK_BYTES", 1 << 30))
 #: channel count the fused kernels are specialised for (self.inter_channels, correspondence.py:170)
 FUSED_K = 256
 #: where the K2 forward's products run: "fp32" = v_mfma_f32_32x32x2_f32 (exact fp32 operands);
@@ -347,7 +350,8 @@ def f16_plane_block_mask(plane: torch.Tensor) -> torch.Tensor:
 def _recompute_chunk(B, Nq, Nk):
     """Keys per chunk of the recompute backward: whole 128-key groups (blocked planes), RECOMPUTE_CHUNK_BYTES per matrix."""
     per_key = max(B * Nq * 4, 1)
-    kc = max(128, (RECOMPUTE_CHUNK_BYTES // per_key) // 128 * 128)
+    nchunks = max(1, -(-(per_key * Nk) // max(RECOMPUTE_CHUNK_BYTES, 1)))      # equal chunks: the last one is not a sliver
+    kc = max(128, -(-Nk // nchunks) // 128 * 128 + (128 if (-(-Nk // nchunks)) % 128 else 0))
     return min(kc, (Nk + 127) // 128 * 128)
 
 

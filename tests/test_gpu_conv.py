@@ -547,3 +547,54 @@ def test_conv2d_nhwc_shape_sweep_vs_fp64(case, prec, tol, monkeypatch):
     for a, r, what in ((y, yr, "y"), (x.grad, dxr, "dx"), (w.grad, dwr, "dw"), (b.grad, dbr, "db")):
         e = (a.double() - r).abs().max().item() / max(r.abs().max().item(), 1e-30)
         assert e <= tol, f"{prec} {what}: {e:.3e}"
+
+
+# ------------------------------------------------------------------ BASELINE config 3: SPADE generator + PatchGAN on the HIP kernels
+def test_config3_generator_and_patchgan_against_fp64_copies(monkeypatch):
+    """cocosnet_amd.translation.{SPADEGenerator, MultiscaleDiscriminator} with the CelebA-HQ edge training flags (README.md:106)
+    at 256x256: forward AND parameter gradients of both networks, every convolution / SPADE / InstanceNorm / attention kernel on
+    HIP, against fp64 copies of the same modules evaluated by the framework.  Default flavour (f16x3): outputs within north_star's
+    1e-3; gradients reported and bounded (they sit behind LeakyReLU kinks after InstanceNorm / PONO: see
+    test_module_end_to_end_against_an_fp64_copy_of_itself).  bf16 (the precision BASELINE config 3 names): reported."""
+    import copy
+    import json
+    from cocosnet_amd import ops, translation as tl
+    opt = tl.celebahq_edge_train_options()
+    torch.manual_seed(0)
+    G = tl.SPADEGenerator(opt).cuda(); G.init_weights(opt.init_type, opt.init_variance); G.eval()
+    D = tl.MultiscaleDiscriminator(opt).cuda(); D.init_weights(opt.init_type, opt.init_variance); D.eval()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    B = 2
+    seg = torch.rand(B, 15, 256, 256, device="cuda", generator=g)
+    cbn = torch.cat((torch.rand(B, 3, 256, 256, device="cuda", generator=g) * 2 - 1, seg), 1)
+    gy = torch.randn(B, 3, 256, 256, device="cuda", generator=g)
+    gprobes = {"fc.weight": lambda n: n.fc.weight, "conv_img.weight": lambda n: n.conv_img.weight,
+               "up_3.conv_1.weight_orig": lambda n: n.up_3.conv_1.weight_orig, "head_0.conv_0.weight_orig": lambda n: n.head_0.conv_0.weight_orig,
+               "up_1.norm_0.mlp_gamma.weight": lambda n: n.up_1.norm_0.mlp_gamma.weight, "attn.theta.weight_orig": lambda n: n.attn.theta.weight_orig,
+               "attn.gamma": lambda n: n.attn.gamma}
+    dprobes = {"discriminator_0.model0.0.weight": lambda n: n.discriminator_0.model0[0].weight,
+               "discriminator_0.model2.0.0.weight_orig": lambda n: n.discriminator_0.model2[0][0].weight_orig,
+               "discriminator_1.model4.0.weight": lambda n: n.discriminator_1.model4[0].weight}
+
+    def run(Gm, Dm, dt):
+        Gm.zero_grad(); Dm.zero_grad()
+        y = Gm(seg.to(dt), warp_out=cbn.to(dt))
+        y.backward(gy.to(dt))
+        res = Dm(torch.cat((seg.to(dt), y.detach()), 1))[0]
+        torch.autograd.backward([r[-1] for r in res], [torch.ones_like(r[-1]) for r in res])
+        out = {"fake_image": y.detach(), "D0_logits": res[0][-1].detach(), "D1_logits": res[1][-1].detach(), "D0_feat2": res[0][2].detach()}
+        out.update({"d G." + k: f(Gm).grad.clone() for k, f in gprobes.items()})
+        out.update({"d D." + k: f(Dm).grad.clone() for k, f in dprobes.items()})
+        return out
+    want = run(copy.deepcopy(G).double(), copy.deepcopy(D).double(), torch.float64)
+    errs = {}
+    for flavour in ("f16x3", "bf16"):
+        monkeypatch.setattr(ops, "CONV_PRECISION", flavour)
+        got = run(G, D, torch.float32)
+        errs[flavour] = {k: float((got[k].double() - want[k]).abs().max() / (want[k].abs().max() + 1e-300)) for k in want}
+    print("CFG3_FP64", json.dumps(errs))
+    e = errs["f16x3"]
+    assert all(e[k] < 1e-3 for k in ("fake_image", "D0_logits", "D1_logits", "D0_feat2")), e
+    grads = sorted(v for k, v in e.items() if k.startswith("d "))
+    assert grads[len(grads) // 2] < 1e-3 and grads[-1] < 0.1, e
+    assert all(v < 1.0 for v in errs["bf16"].values()), errs["bf16"]

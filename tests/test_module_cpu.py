@@ -241,3 +241,46 @@ def test_use_hip_convs_on_the_reference_discriminator():
     x = torch.randn(1, opt.label_nc + 1 + 3, 32, 32)
     out = net(x)
     assert len(out) >= 1
+
+
+# ------------------------------------------------------------------ BASELINE config 3: the translation generator and the PatchGAN
+def _cfg3_opts():
+    from cocosnet_amd import translation as tl
+    mine = tl.celebahq_edge_train_options()
+    ref = rh.make_opt(**{k: getattr(mine, k) for k in vars(mine) if k != "gpu_ids"})
+    ref.gpu_ids = []
+    return mine, ref
+
+
+@needs_ref
+def test_translation_generator_and_discriminator_state_dicts_equal_the_reference():
+    """cocosnet_amd.translation.{SPADEGenerator, MultiscaleDiscriminator} (BASELINE config 3) against the reference's own
+    classes (generator.py:17-89, discriminator.py:14-177), CelebA-HQ edge training flags: same state_dict keys and shapes —
+    `*_net_G.pth` / `*_net_D.pth` load unchanged — and, with the reference's parameters loaded, the same fp32 CPU outputs."""
+    import contextlib
+    from cocosnet_amd import translation as tl
+    mine, ref = _cfg3_opts()
+    networks = rh.load_reference()
+    import importlib
+    gen = importlib.import_module("models.networks.generator")
+    dis = importlib.import_module("models.networks.discriminator")
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(None):
+        rg, rd = gen.SPADEGenerator(ref).eval(), dis.MultiscaleDiscriminator(ref).eval()
+    g, d = tl.SPADEGenerator(mine).eval(), tl.MultiscaleDiscriminator(mine).eval()
+    for a, b in ((g, rg), (d, rd)):
+        assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == {k: tuple(v.shape) for k, v in b.state_dict().items()}
+        a.load_state_dict(b.state_dict(), strict=True)
+    gg = torch.Generator().manual_seed(3)
+    seg = torch.rand(1, 15, 256, 256, generator=gg)
+    cbn = torch.cat((torch.rand(1, 3, 256, 256, generator=gg) * 2 - 1, seg), 1)
+    with torch.no_grad():
+        y, yr = g(seg, warp_out=cbn), rg(seg, warp_out=cbn)
+        assert float((y - yr).abs().max()) < 1e-5 * float(yr.abs().max())
+        x = torch.cat((seg, y), 1)
+        (o, _, _), (orf, _, _) = d(x), rd(x)
+    assert len(o) == len(orf) == 2
+    for a, b in zip(o, orf):
+        assert len(a) == len(b) == 5
+        for u, v in zip(a, b):
+            assert u.shape == v.shape and float((u - v).abs().max()) <= 1e-5 * max(float(v.abs().max()), 1e-6)
