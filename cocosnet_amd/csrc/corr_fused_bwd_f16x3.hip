@@ -88,12 +88,16 @@ struct DsRegs {
     const float* __restrict__ lse, const float* __restrict__ lg, float* __restrict__ dqn, _Float16* __restrict__ dsh, \
     _Float16* __restrict__ dsl, _Float16* __restrict__ psh, _Float16* __restrict__ psl, const float* __restrict__ v_amax, \
     const float* __restrict__ v_scale, float* __restrict__ ds_scale_out, const unsigned* __restrict__ v_lo_mask, int B, \
-    int Nq, int Nk, int Cv, float inv_t, float k_scale, float q_scale
+    int Nq, int Nk, int Cv, float inv_t, float k_scale, float q_scale, const float* __restrict__ rowstat, \
+    const float* __restrict__ mtile
 #define COCOS_BQ_ARGS \
     kch, kcl, vph, vpl, gph, gpl, g_scale, outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, \
-    v_lo_mask, B, Nq, Nk, Cv, inv_t, k_scale, q_scale
+    v_lo_mask, B, Nq, Nk, Cv, inv_t, k_scale, q_scale, rowstat, mtile
 
-template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED, bool VLO0, bool BLK>
+// RAWM: the magnitude-free flavour (see corr_fused_fwd_f16x3.hip) — P = 2^((s_rel + (m_tile - m)) * scale - r) from the forward's
+// RELATIVE saved logits, its per-tile reference m_tile and its per-row (m in raw-accumulator units, r = log2 l - bias) instead
+// of from absolute logits and the row LSE: exact differences at any |logit|.
+template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED, bool VLO0, bool BLK, bool RAWM = false>
 __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     const _Float16* __restrict__ kch, const _Float16* __restrict__ kcl,   // [B,256,Nk] planes of k_scale*kn
     const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] planes of s_v*v
@@ -109,7 +113,9 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     float* __restrict__ ds_scale_out,                                      // out: s_o * s_v * ds_shift (device)
     const unsigned* __restrict__ v_lo_mask,                                // bit cb: value block cb has a non-zero lo plane (or NULL)
     int B, int Nq, int Nk, int Cv, float inv_t, float k_scale /* of the K planes */, float q_scale /* of the query planes the
-    forward multiplied them with: raw logits = q_scale * k_scale * <q, k> */) {
+    forward multiplied them with: raw logits = q_scale * k_scale * <q, k> */,
+    const float* __restrict__ rowstat /* RAWM: [B][3][Nq] as written by the forward */,
+    const float* __restrict__ mtile /* RAWM: [B][ntiles][2][Nq] as written by the forward */) {
     constexpr int CVP = CVB * 32;
     constexpr int CVS = CVP / 16;                     // k-steps of the dP product
     constexpr int KB = BQH_KD / 32;                   // channel blocks of dqn
@@ -210,7 +216,10 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     // (raw = the forward's accumulator, k_scale^2 * cos; padded lanes: lse2c = +inf -> p_c = 0)
     const float cs = inv_t * ds_shift;
     const float scale_log2 = inv_t * kLog2e / (k_scale * q_scale);
-    const float nlse2c = live ? log2f(cs) - lse[(size_t)b * Nq + i_lane] * kLog2e : -INFINITY;
+    const float m_raw = (RAWM && live) ? rowstat[((size_t)b * 3 + 0) * Nq + i_lane] : 0.f;      // (hi, lo: an unevaluated sum)
+    const float m_raw_lo = (RAWM && live) ? rowstat[((size_t)b * 3 + 1) * Nq + i_lane] : 0.f;
+    const float nlse2c = !live ? -INFINITY
+                         : RAWM ? log2f(cs) - rowstat[((size_t)b * 3 + 2) * Nq + i_lane] : log2f(cs) - lse[(size_t)b * Nq + i_lane] * kLog2e;
     const float p_from_pc = kPPlaneScale / cs;        // STORE_P: 2^14 * P = p_c * (2^14 / cs)
 
     f32x16 dx[KB];
@@ -291,6 +300,15 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     }
     // logits of tile tt (clamped to the last tile: look-ahead loads past the end are harmless re-reads),
     // register group k (accumulator registers 4k..4k+3): one contiguous 1 KB per wave-instruction
+    // RAWM: m_tile(tt) - m of the lane's query (<= 0): added to the relative logits of tile tt
+    const __amdgpu_buffer_rsrc_t mt_rs = make_rsrc(RAWM ? mtile + (size_t)b * ntiles * 2 * Nq : nullptr, RAWM ? (size_t)ntiles * 2 * Nq * 4 : 0);
+    auto load_dm = [&](float& dm, int tt) {
+        if (!RAWM) return;
+        const int tc = min(tt, ntiles - 1);
+        const float th = buf_load1(mt_rs, live ? (unsigned)((tc * 2 + 0) * Nq + i_lane) * 4u : kBufOob);
+        const float tl = buf_load1(mt_rs, live ? (unsigned)((tc * 2 + 1) * Nq + i_lane) * 4u : kBufOob);
+        dm = (th - m_raw) + (tl - m_raw_lo);              // both maxima are fp32 numbers a few ulps apart: exact differences
+    };
     auto load_s = [&](f32x4& dst, int tt, int k) {
         if ((COCOS_ABLATE & 16) && tt > 1) return;
         const int tc = (COCOS_ABLATE & 128) ? (tt & 1) : min(tt, ntiles - 1);
@@ -398,9 +416,10 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     };
 
     // ---- VALU slice r of tile t: dS''[r] from logit register r; pairs are split to f16 hi/lo at odd r ----------
-    auto valu_slice = [&](int r, int t, const f32x4 (&s)[4], const f32x16& dp0, float (&dsv)[2], float (&pv)[2],
+    auto valu_slice = [&](int r, int t, const f32x4 (&s)[4], float dm, const f32x16& dp0, float (&dsv)[2], float (&pv)[2],
                           DsRegs& out, DsRegs& pout) {
-        float pc = (COCOS_ABLATE & 4) ? s[r >> 2][r & 3] * 1e-9f : fast_exp2(__builtin_fmaf(s[r >> 2][r & 3], scale_log2, nlse2c));
+        float pc = (COCOS_ABLATE & 4) ? s[r >> 2][r & 3] * 1e-9f
+                                      : fast_exp2(__builtin_fmaf(RAWM ? s[r >> 2][r & 3] + dm : s[r >> 2][r & 3], scale_log2, nlse2c));
         if (RAGGED && (t * 32 + acc_row_base(r) + 4 * h >= Nk)) pc = 0.f;
         dsv[r & 1] = pc * (dp0[r] - d_lane);
         if (STORE_P) pv[r & 1] = pc * p_from_pc;
@@ -471,7 +490,7 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     //      logit registers are consumed, the loads of tile t + 2's logits ride in the MFMA gaps.  STAGE_K: the key-tile
     //      pieces of tile t go to LDS (read from the next iteration on), one every other step ----------------------------
     constexpr int LEAD = 3;
-    auto phase_dqn = [&](int t, const DsRegs& prev, auto with_valu, auto stage_k, f32x4 (&s)[4], const f32x16& dp0,
+    auto phase_dqn = [&](int t, const DsRegs& prev, auto with_valu, auto stage_k, f32x4 (&s)[4], float& dm, const f32x16& dp0,
                          DsRegs& cur, DsRegs& pcur) {
         constexpr bool WITH_VALU = decltype(with_valu)::value;
         constexpr bool STAGE_K = decltype(stage_k)::value;
@@ -480,9 +499,11 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
         a_h[0] = *reinterpret_cast<const f16x8*>(kb0);
         a_l[0] = *reinterpret_cast<const f16x8*>(kb0 + KPLANE);
         float dsv[2] = {0.f, 0.f}, pv[2] = {0.f, 0.f};
+        const float dm_t = dm;                                           // (this tile's; `dm` is reloaded for tile t + 2 below)
         auto slice = [&](int r) {
-            valu_slice(r, t, s, dp0, dsv, pv, cur, pcur);
+            valu_slice(r, t, s, dm_t, dp0, dsv, pv, cur, pcur);
             if ((r & 3) == 3) load_s(s[r >> 2], t + 2, r >> 2);          // registers 4k..4k+3 are free again
+            if (r == 15) load_dm(dm, t + 2);
         };
         if (WITH_VALU) {
 #pragma unroll
@@ -535,8 +556,11 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
 
     // ---- prologue: V(0), K(0) in LDS; V(1), K(1) staged in registers; logits of tiles 0 and 1 requested -----------
     f32x4 sA[4], sB[4];
+    float dmA = 0.f, dmB = 0.f;
     fetch_v(0);
     fetch_k(0);
+    load_dm(dmA, 0);
+    load_dm(dmB, 1);
 #pragma unroll
     for (int k = 0; k < 4; ++k) load_s(sA[k], 0, k);
     commit_v(0);
@@ -562,24 +586,26 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
         phase_dp(dp0, 0);
         __syncthreads();
         float dsv[2], pv[2];
+        const float dm0 = dmA;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            valu_slice(r, 0, sA, dp0, dsv, pv, dA, pA);
+            valu_slice(r, 0, sA, dm0, dp0, dsv, pv, dA, pA);
             if ((r & 3) == 3) load_s(sA[r >> 2], 2, r >> 2);
         }
+        load_dm(dmA, 2);
         prefetch_v(1);
         if (STORE_DS) store_planes(0, dA, dh_rs, dl_rs);
         if (STORE_P) store_p_tile(0, pA);
     }
     // iterations 1 .. ntiles-1, two per trip so that every register set is named statically:
     //   odd t : logits sB -> dS'' dB, dqn of tile t-1 from dA;   even t: logits sA -> dA, dqn from dB
-    auto iter = [&](int t, f32x4 (&s)[4], const DsRegs& prev, DsRegs& cur, DsRegs& pcur) {
+    auto iter = [&](int t, f32x4 (&s)[4], float& dm, const DsRegs& prev, DsRegs& cur, DsRegs& pcur) {
         BPH_T(tp0);
         phase_dp(dp0, t);
         BPH_T(tp1);
         __syncthreads();
         BPH_T(tp2);
-        phase_dqn(t, prev, true_type{}, true_type{}, s, dp0, cur, pcur);
+        phase_dqn(t, prev, true_type{}, true_type{}, s, dm, dp0, cur, pcur);
         BPH_T(tp3);
         if (STORE_DS) store_planes(t, cur, dh_rs, dl_rs);
         if (STORE_P) store_p_tile(t, pcur);
@@ -588,16 +614,16 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     };
     int t = 1;
     for (; t + 1 < ntiles; t += 2) {
-        iter(t, sB, dA, dB, pB);
-        iter(t + 1, sA, dB, dA, pA);
+        iter(t, sB, dmB, dA, dB, pB);
+        iter(t + 1, sA, dmA, dB, dA, pA);
     }
     if (t < ntiles) {
-        iter(t, sB, dA, dB, pB);
+        iter(t, sB, dmB, dA, dB, pB);
         __syncthreads();           // the last key tile was committed during that iteration
-        phase_dqn(ntiles, dB, false_type{}, false_type{}, sA, dp0, dA, pA);
+        phase_dqn(ntiles, dB, false_type{}, false_type{}, sA, dmA, dp0, dA, pA);
     } else {
         __syncthreads();
-        phase_dqn(ntiles, dA, false_type{}, false_type{}, sB, dp0, dB, pB);
+        phase_dqn(ntiles, dA, false_type{}, false_type{}, sB, dmB, dp0, dB, pB);
     }
 
     // ---- epilogue: undo the scales -----------------------------------------------------------------------
@@ -624,10 +650,17 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(COCOS_BQ_P
         q_scale = *q_scale_dev;
         k_scale = *k_scale_dev;
     }
-    if (DUAL && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
-        corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, DUAL, BLK>(COCOS_BQ_ARGS);
-    else
-        corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK>(COCOS_BQ_ARGS);
+    if constexpr (DUAL) {
+        if ((__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
+            corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, true, BLK>(COCOS_BQ_ARGS);
+        else
+            corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK>(COCOS_BQ_ARGS);
+    } else {
+        if (rowstat)             // the magnitude-free flavour: (m, r) per row from the forward
+            corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK, true>(COCOS_BQ_ARGS);
+        else
+            corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK>(COCOS_BQ_ARGS);
+    }
 }
 
 template <int CVB>
@@ -636,8 +669,8 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                            const float* dout, const float* lse, const float* lg, float* dqn, _Float16* dsh,
                            _Float16* dsl, _Float16* psh, _Float16* psl, const float* v_amax, const float* v_scale,
                            float* ds_scale_out, const unsigned* v_lo_mask, int B, int Nq, int Nk, int Cv, float inv_t,
-                           float k_scale, int blocked, const float* qsd, const float* ksd,
-                           hipStream_t s) {
+                           float k_scale, int blocked, const float* qsd, const float* ksd, const float* rowstat,
+                           const float* mtile, hipStream_t s) {
     const bool ragged = (Nk % 32) != 0, store = dsh != nullptr, storep = psh != nullptr;
     const size_t smem = ((size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) + 4 * 2 * 32 * 32) * sizeof(_Float16);
     const int nqb = (Nq + 127) / 128;
@@ -652,7 +685,7 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
         hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, s, kch, kcl, vph, vpl, gph, gpl, g_scale,   \
                            outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, MASK, B, Nq, \
-                           Nk, Cv, inv_t, k_scale, k_scale, qsd, ksd);                                       \
+                           Nk, Cv, inv_t, k_scale, k_scale, rowstat, mtile, qsd, ksd);                       \
     } while (0)
     /* blocked planes ([query][key] blocks, see the kernel) only exist for whole tiles */
 #define COCOS_GO3(DS, SP, RG, VL, MASK)                                                                      \
@@ -698,7 +731,23 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
     float* ds_scale_out_dev, const unsigned* v_lo_mask_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad,
     float inv_temperature, float k_scale, const float* q_scale_dev, const float* k_scale_dev, int planes_blocked,
     cocos_stream_t stream) {
+    return cocos_corr_softmax_warp_bwd_query_f16x3_ex(kch, kcl, vph, vpl, gph, gpl, g_scale_dev, out, dout, lse, saved_logits, dqn, dsh,
+                                                      dsl, psh, psl, v_amax_dev, v_scale_dev, ds_scale_out_dev, v_lo_mask_dev, B, K, Nq,
+                                                      Nk, Cv, CvPad, inv_temperature, k_scale, q_scale_dev, k_scale_dev, planes_blocked,
+                                                      nullptr, nullptr, stream);
+}
+
+extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3_ex(
+    const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
+    const float* g_scale_dev, const float* out, const float* dout, const float* lse, const void* saved_logits,
+    float* dqn, void* dsh, void* dsl, void* psh, void* psl, const float* v_amax_dev, const float* v_scale_dev,
+    float* ds_scale_out_dev, const unsigned* v_lo_mask_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad,
+    float inv_temperature, float k_scale, const float* q_scale_dev, const float* k_scale_dev, int planes_blocked,
+    const float* rowstat, const float* mtile, cocos_stream_t stream) {
     using namespace cocos;
+    COCOS_REQUIRE((rowstat == nullptr) == (mtile == nullptr) && (!rowstat || (q_scale_dev && !v_lo_mask_dev)), COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_query_f16x3: rowstat + mtile come as a pair and belong to the magnitude-free flavour "
+                  "(device-side operand scales, no lo mask)");
     COCOS_REQUIRE(kch && kcl && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse && saved_logits && dqn &&
                       v_amax_dev && ds_scale_out_dev,
                   COCOS_ERR_INVALID, "corr_softmax_warp_bwd_query_f16x3: null pointer");
@@ -731,7 +780,7 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
         g_scale_dev, out, dout, lse, static_cast<const float*>(saved_logits), dqn, static_cast<_Float16*>(dsh),  \
         static_cast<_Float16*>(dsl), static_cast<_Float16*>(psh), static_cast<_Float16*>(psl), v_amax_dev,      \
         v_scale_dev, ds_scale_out_dev, v_lo_mask_dev, B, Nq, Nk, Cv, inv_temperature, k_scale, planes_blocked, q_scale_dev, \
-        k_scale_dev, s
+        k_scale_dev, rowstat, mtile, s
     switch (cvb) {
         case 1: return launch_bq_f16x3<1>(COCOS_ARGS);
         case 2: return launch_bq_f16x3<2>(COCOS_ARGS);

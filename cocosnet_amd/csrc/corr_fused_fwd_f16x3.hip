@@ -100,12 +100,20 @@ __device__ long long g_phase_fwd_h[8];
 #define FPH_ADD(i, a, b) do {} while (0)
 #endif
 
-template <int CVB, bool STORE_S, bool RAGGED, bool VLO0>
+// RAWM (round 4; the flavour of operands WITHOUT an a-priori magnitude, ops.softmax_attention): the running maximum is kept in
+// the units of the RAW accumulator and the S accumulators START at -m instead of 0, so that exp2 sees (s - m) * scale formed
+// from an exact difference.  With m kept in the log2 domain (the flavour of the unit-norm operands: |logit| <= 144) the
+// difference is taken between s * scale and a ROUNDED m * scale: at |logit| ~ 1e10 (a randomly initialised SPADE generator's
+// Attention block: theta ~ 4e5) one ulp is ~700 in the exponent — p overflowed f16 or vanished and the output was NaN.
+// Same instruction count per element; extra work only where m changes (rare) and in the training forward's logits store.
+template <int CVB, bool STORE_S, bool RAGGED, bool VLO0, bool RAWM = false>
 __device__ __forceinline__ void corr_fwd_f16x3_body(
     const _Float16* __restrict__ qh, const _Float16* __restrict__ ql, const _Float16* __restrict__ kh,
     const _Float16* __restrict__ kl, const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
     float* __restrict__ out, float* __restrict__ lse, float* __restrict__ lg, const float* __restrict__ v_scale,
-    const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2 /* inv_temperature * log2(e) / (q_scale * k_scale) */) {
+    const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2 /* inv_temperature * log2(e) / (q_scale * k_scale) */,
+    float* __restrict__ rowstat = nullptr /* RAWM: [B][3][Nq] = (m_hi, m_lo in raw units, log2 l - bias) for the backward; nullable */,
+    float* __restrict__ mtile = nullptr /* RAWM + STORE_S: [B][Nk/32 tiles][2][Nq] = (m_hi, m_lo) when the tile's logits were stored */) {
     constexpr int CVP = CVB * 32;
     constexpr int KPLANE = SP_BK * SP_KROW;          // halfs per K plane per buffer
     constexpr int VPLANE = CVP * SP_VROW;
@@ -159,7 +167,9 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
     for (int cb = 0; cb < CVB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
-    float m_run = -INFINITY;
+    float m_run = RAWM ? 0.f : -INFINITY;             // RAWM: raw-accumulator units, set by tile 0 ...
+    float m_lo = 0.f;                                  // ... as an unevaluated sum m_run + m_lo (see the rescale block)
+    const float thr_raw = kSplitRescaleThr / scale_log2;      // (RAWM) the lazy-rescale threshold in raw units
     // the thread that stages the last row of the padded V tile writes ones into its hi plane (see header)
     const bool ones_thread = tid >= 248;
     const u32x2 kOnes2 = u32x2{0x3C003C00u, 0x3C003C00u};
@@ -338,7 +348,7 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
         //      tile t+1 ride in the gaps ------------------------------------------------------------------------------
         f32x16 sa, sb, sc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; sc[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { sa[r] = RAWM ? -m_run : 0.f; sb[r] = RAWM ? -m_lo : 0.f; sc[r] = 0.f; }
         {
             const _Float16* kb = kt + buf * 2 * KPLANE + c * SP_KROW + h * 8;
 #pragma unroll
@@ -382,11 +392,31 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
         float tmax = s0[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s0[r]);
-        tmax = fmaxf(tmax, swap_half(tmax)) * scale_log2;
-        if (__any(tmax > m_run + kSplitRescaleThr)) {
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = fast_exp2(m_run - m_new);
-            m_run = m_new;
+        tmax = fmaxf(tmax, swap_half(tmax));
+        if (!RAWM) tmax *= scale_log2;
+        if (RAWM ? (t == 0 || __any(tmax > thr_raw)) : __any(tmax > m_run + kSplitRescaleThr)) {
+            float alpha;
+            if (RAWM) {
+                // s0 is relative to m = m_run + m_lo already; the row's new maximum moves m by EXACTLY delta >= 0 (tile 0: to the
+                // tile's own maximum, whatever its sign): the element that sets the maximum must come out at exactly 0 — at
+                // |logit| ~ 1e9 one ulp of a single fp32 m is ~2700 in the exponent, its p would overflow f16 or vanish.  m is
+                // therefore carried as an unevaluated sum (two TwoSums per update), the accumulators of the next tiles start at
+                // -m_run (S hi.hi chain) and -m_lo (hi.lo chain), and the current tile moves by delta itself.
+                const float delta = t == 0 ? tmax : fmaxf(tmax, 0.f);
+                alpha = t == 0 ? 1.0f : fast_exp2(-delta * scale_log2);         // (tile 0: O is still zero)
+                const float u = m_lo + delta, ub = u - m_lo;
+                const float e1 = (m_lo - (u - ub)) + (delta - ub);              // TwoSum(m_lo, delta) = u + e1
+                const float hs = m_run + u, hb = hs - m_run;
+                const float e2 = (m_run - (hs - hb)) + (u - hb);                // TwoSum(m_run, u) = hs + e2
+                m_run = hs;
+                m_lo = e2 + e1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s0[r] -= delta;
+            } else {
+                const float m_new = fmaxf(m_run, tmax);
+                alpha = fast_exp2(m_run - m_new);
+                m_run = m_new;
+            }
             // (the pins keep the AGPR -> VGPR copies of O inside this rarely taken branch: hipcc otherwise
             //  hoists all of them above it, i.e. into every tile).  The ones row of V makes l one of O's rows:
             //  it is rescaled with the rest.
@@ -402,6 +432,14 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
         if (STORE_S && !(COCOS_ABLATE & 8)) {
             // the wave's 32x32 tile of raw logits: four contiguous 1 KB stores (registers 4k..4k+3 of every lane)
             const unsigned soff = (COCOS_ABLATE & 32) ? 0u : (unsigned)(t * nqblk) * 4096u;
+            // RAWM: the saved logits are RELATIVE raw accumulators, s - m_tile, with m_tile (the row's running maximum when the
+            // tile was stored, hi and lo part) in mtile[b][t][0..1][query]: the backward forms s_rel + (m_tile - m_final) — exact differences.  (Absolute
+            // logits s_rel + m would be rounded at |m|: one ulp of 2^27 raw units is ~70 in the exponent at |logit| ~ 1e9, and
+            // P of the row's own maximum came back as 2^+-69.)
+            if (RAWM && mtile && h == 0 && i_lane < Nq) {
+                mtile[(((size_t)b * ntiles + t) * 2 + 0) * Nq + i_lane] = m_run;
+                mtile[(((size_t)b * ntiles + t) * 2 + 1) * Nq + i_lane] = m_lo;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 __builtin_amdgcn_raw_buffer_store_b128(
@@ -409,7 +447,7 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
                     (int)lg_lane_off, (int)(soff + (unsigned)k * 1024u), COCOS_STREAM_AUX);
         }
         float p[16];
-        const float nmb = kPBias - m_run;
+        const float nmb = RAWM ? kPBias : kPBias - m_run;
 #pragma unroll
         for (int r = 0; r < 16; ++r) p[r] = (COCOS_ABLATE & 4) ? s0[r] * 1e-3f + 1.0f : fast_exp2(__builtin_fmaf(s0[r], scale_log2, nmb));
 
@@ -465,6 +503,12 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
     const float l_other = swap_half(l_own);
     const float l_tot = h ? l_own : l_other;
     const float inv_l = (v_scale ? 1.0f / *v_scale : 1.0f) / l_tot;
+    if (RAWM && rowstat && i_lane < Nq && h == 0) {
+        rowstat[((size_t)b * 3 + 0) * Nq + i_lane] = m_run;
+        rowstat[((size_t)b * 3 + 1) * Nq + i_lane] = m_lo;
+        rowstat[((size_t)b * 3 + 2) * Nq + i_lane] = log2f(l_tot) - kPBias;
+    }
+    if (RAWM) m_run = (m_run + m_lo) * scale_log2;     // (for the lse below: the log2 domain)
     if (i_lane < Nq) {
         float* out_b = out + (size_t)b * Cv * Nq;
 #pragma unroll
@@ -488,28 +532,37 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     const _Float16* __restrict__ kl, const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
     float* __restrict__ out, float* __restrict__ lse, float* __restrict__ lg, const float* __restrict__ v_scale,
     const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2,
-    const float* __restrict__ q_scale_dev, const float* __restrict__ k_scale_dev) {
+    const float* __restrict__ q_scale_dev, const float* __restrict__ k_scale_dev, float* __restrict__ rowstat,
+    float* __restrict__ mtile) {
     // operands without an a-priori magnitude (ops.softmax_attention: the reference's Attention block feeds raw 1x1-conv
     // outputs): their planes carry device-side power-of-two scales; scale_log2 then arrives WITHOUT the 1 / (q_scale k_scale)
     if (q_scale_dev) scale_log2 = scale_log2 / (*q_scale_dev * *k_scale_dev);
-    if (DUAL && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
-        corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, DUAL>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk, Cv, scale_log2);
-    else
-        corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, false>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk, Cv, scale_log2);
+    if constexpr (DUAL) {
+        if ((__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
+            corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, true>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk, Cv, scale_log2);
+        else
+            corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, false>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk, Cv, scale_log2);
+    } else {
+        if (q_scale_dev)          // the magnitude-free flavour (host side: no lo mask together with device-side operand scales)
+            corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, false, true>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk,
+                                                                   Cv, scale_log2, rowstat, mtile);
+        else
+            corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, false>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk, Cv, scale_log2);
+    }
 }
 
 template <int CVB, bool STORE_S, bool RAGGED, bool VLO0>
 static int launch_f16x3_k(const _Float16* qh, const _Float16* ql, const _Float16* kh, const _Float16* kl,
                           const _Float16* vh, const _Float16* vl, float* out, float* lse, float* lg,
                           const float* v_scale, const unsigned* v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2,
-                          const float* qsd, const float* ksd, hipStream_t stream) {
+                          const float* qsd, const float* ksd, float* rowstat, float* mtile, hipStream_t stream) {
     auto kern = corr_fwd_f16x3_kernel<CVB, STORE_S, RAGGED, VLO0>;
     const size_t smem = (size_t)2 * (2 * SP_BK * SP_KROW + 3 * CVB * 32 * SP_VROW) * sizeof(_Float16);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int nqb = (Nq + SP_BQ - 1) / SP_BQ;
     hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, stream, qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale,
-                       v_lo_mask, B, Nq, Nk, Cv, scale_log2, qsd, ksd);
+                       v_lo_mask, B, Nq, Nk, Cv, scale_log2, qsd, ksd, rowstat, mtile);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -551,9 +604,26 @@ extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql,
                                                  int K, int Nq, int Nk, int Cv, float inv_temperature,
                                                  float operand_scale, const float* q_scale_dev, const float* k_scale_dev,
                                                  cocos_stream_t stream) {
+    return cocos_corr_softmax_warp_fwd_f16x3_ex(qh, ql, kh, kl, vh, vl, out, lse, saved_logits, v_scale_dev, v_lo_mask_dev, B, K, Nq,
+                                                Nk, Cv, inv_temperature, operand_scale, q_scale_dev, k_scale_dev, nullptr, nullptr, stream);
+}
+
+extern "C" int cocos_corr_softmax_warp_fwd_f16x3_ex(const void* qh, const void* ql, const void* kh,
+                                                    const void* kl, const void* vh, const void* vl, float* out,
+                                                    float* lse, void* saved_logits, const float* v_scale_dev,
+                                                    const unsigned* v_lo_mask_dev, int B,
+                                                    int K, int Nq, int Nk, int Cv, float inv_temperature,
+                                                    float operand_scale, const float* q_scale_dev, const float* k_scale_dev,
+                                                    float* rowstat_out, float* mtile_out, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(qh && ql && kh && kl && vh && vl && out && lse, COCOS_ERR_INVALID,
                   "corr_softmax_warp_fwd_f16x3: null pointer");
+    COCOS_REQUIRE(!(q_scale_dev && v_lo_mask_dev), COCOS_ERR_INVALID,
+                  "corr_softmax_warp_fwd_f16x3: device-side operand scales (the magnitude-free flavour) and a V lo mask are exclusive");
+    COCOS_REQUIRE((!rowstat_out && !mtile_out) || q_scale_dev, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_fwd_f16x3: rowstat_out / mtile_out belong to the magnitude-free flavour (device-side operand scales)");
+    COCOS_REQUIRE(!(q_scale_dev && saved_logits) || mtile_out, COCOS_ERR_INVALID,
+                  "corr_softmax_warp_fwd_f16x3: the magnitude-free flavour saves RELATIVE logits: mtile_out is required with saved_logits");
     COCOS_REQUIRE(B >= 1 && Nq >= 1 && Nk >= 1 && Cv >= 1 && operand_scale > 0.f && inv_temperature > 0.f,
                   COCOS_ERR_INVALID, "corr_softmax_warp_fwd_f16x3: bad dims B=%d Nq=%d Nk=%d Cv=%d", B, Nq, Nk, Cv);
     COCOS_REQUIRE(K == 256, COCOS_ERR_UNSUPPORTED, "corr_softmax_warp_fwd_f16x3: needs K == 256 (got %d)", K);
@@ -585,7 +655,7 @@ extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql,
     // with a mask and more than one value block the kernel holds both flavours and picks one from the device-side mask
 #define COCOS_GO(CVB, ST, RG) \
     cocos_go_both<CVB, ST, RG>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, v_lo_mask_dev, B, Nq, Nk, Cv, scale_log2, \
-                               q_scale_dev, k_scale_dev, s)
+                               q_scale_dev, k_scale_dev, rowstat_out, mtile_out, s)
 #define COCOS_CVB(CVB)                                                           \
     case CVB:                                                                    \
         if (lgp) return ragged ? COCOS_GO(CVB, true, true) : COCOS_GO(CVB, true, false); \

@@ -396,11 +396,16 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             if keep_logits and not ctx.recompute:   # the forward's private tile-blocked layout (cocos_hip.h), opaque here
                 nbytes = _lib.load().cocos_corr_softmax_warp_saved_logits_bytes(B, Nq, Nk)
                 logits_t = torch.empty(nbytes // 4, device=qn.device, dtype=torch.float32)
-            _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd_f16x3", qh.data_ptr(), ql.data_ptr(),
+            # magnitude-free flavour (device-side operand scales): per-row (m, r) for its backward (cocos_hip.h)
+            ctx.rowstat = torch.empty((B, 3, Nq), device=qn.device, dtype=torch.float32) if (qk_scales and keep_logits) else None
+            # ... and, with saved logits (which this flavour stores RELATIVE to the running maximum), that maximum per 32-key tile
+            ctx.mtile = (torch.empty((B, (Nk + 31) // 32, 2, Nq), device=qn.device, dtype=torch.float32)
+                         if (qk_scales and logits_t is not None) else None)
+            _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd_f16x3_ex", qh.data_ptr(), ql.data_ptr(),
                   kh.data_ptr(), kl.data_ptr(), vh.data_ptr(), vl.data_ptr(), out.data_ptr(), lse.data_ptr(),
                   _ptr(logits_t), v_scale.data_ptr(), _ptr(v_lomask), B, K, Nq, Nk, Cv, float(inv_temperature),
                   SPLIT_OPERAND_SCALE, _ptr(qk_scales[0] if qk_scales else None), _ptr(qk_scales[1] if qk_scales else None),
-                  _stream())
+                  _ptr(ctx.rowstat), _ptr(ctx.mtile), _stream())
             ctx.v_amax = v_amax
             ctx.v_lomask = v_lomask
             ctx.qk_scales = qk_scales
@@ -459,12 +464,13 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                 dqn_buf = torch.empty_like(qn)
             else:
                 dqn_buf = dqn
-            _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3", kch.data_ptr(),
+            _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3_ex", kch.data_ptr(),
                   kcl.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(),
                   g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), logits_t.data_ptr(),
                   dqn_buf.data_ptr(), _ptr(dsh), _ptr(dsl), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
                   v_scale.data_ptr(), ds_scale.data_ptr(), _ptr(ctx.v_lomask), B, K, Nq, Nk, Cv, cvp, ctx.inv_t,
-                  SPLIT_OPERAND_SCALE, _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked, st)
+                  SPLIT_OPERAND_SCALE, _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked,
+                  _ptr(getattr(ctx, "rowstat", None)), _ptr(getattr(ctx, "mtile", None)), st)
             if want_k:    # A = the channel-major planes of q_scale * qn
                 _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
                       dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 if qks else 1.0 / SPLIT_OPERAND_SCALE,
@@ -538,9 +544,11 @@ def _corr_bwd_recompute(ctx, qn, kn, v, out, lse, dout, dqn, dkn, dv, need_k):
         khc, klc = kh[:, k0:k0 + n].contiguous(), kl[:, k0:k0 + n].contiguous()
         vz = torch.zeros((B, 1, n), **half)                  # one zero value channel (hi and lo plane alike)
         lg = torch.empty(lib.cocos_corr_softmax_warp_saved_logits_bytes(B, Nq, n) // 4, device=dev, dtype=torch.float32)
-        _call("corr_softmax_warp_recompute", "cocos_corr_softmax_warp_fwd_f16x3", qh.data_ptr(), ql.data_ptr(), khc.data_ptr(),
+        rowstat = getattr(ctx, "rowstat", None)           # magnitude-free flavour: relative logits + their per-tile reference
+        mt = torch.empty((B, (n + 31) // 32, 2, Nq), device=dev, dtype=torch.float32) if rowstat is not None else None
+        _call("corr_softmax_warp_recompute", "cocos_corr_softmax_warp_fwd_f16x3_ex", qh.data_ptr(), ql.data_ptr(), khc.data_ptr(),
               klc.data_ptr(), vz.data_ptr(), vz.data_ptr(), o1.data_ptr(), l1.data_ptr(), lg.data_ptr(), None, None, B, K, Nq, n, 1,
-              ctx.inv_t, SPLIT_OPERAND_SCALE, _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), st)
+              ctx.inv_t, SPLIT_OPERAND_SCALE, _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), None, _ptr(mt), st)
         kchc, kclc = kch[:, :, k0:k0 + n].contiguous(), kcl[:, :, k0:k0 + n].contiguous()
         vphc, vplc = vph[:, k0:k0 + n].contiguous(), vpl[:, k0:k0 + n].contiguous()
         dsh = dsl = psh = psl = None
@@ -550,11 +558,11 @@ def _corr_bwd_recompute(ctx, qn, kn, v, out, lse, dout, dqn, dkn, dv, need_k):
             psh, psl = torch.empty((B, n, Nq), **half), torch.empty((B, n, Nq), **half)
         blocked = int(n % 128 == 0 and Nq % 32 == 0)
         dq_c = torch.empty_like(qn)
-        _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3", kchc.data_ptr(), kclc.data_ptr(),
+        _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3_ex", kchc.data_ptr(), kclc.data_ptr(),
               vphc.data_ptr(), vplc.data_ptr(), gph.data_ptr(), gpl.data_ptr(), g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(),
               lse.data_ptr(), lg.data_ptr(), dq_c.data_ptr(), _ptr(dsh), _ptr(dsl), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
               v_scale.data_ptr(), ds_scale.data_ptr(), _ptr(ctx.v_lomask), B, K, Nq, n, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE,
-              _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked, st)
+              _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked, _ptr(rowstat), _ptr(mt), st)
         del lg
         dq_acc = dq_c if dq_acc is None else dq_acc.add_(dq_c)
         if want_k:
@@ -624,7 +632,8 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes |
                     v_amax = absmax(vv)
                 # V planes, and which 32-channel blocks of V have a non-zero lo plane (one-hot labels / masks are exact in
                 # f16: theirs is all zero and the kernels skip it) — the same launch, only when it can pay
-                vh, vl, v_scale, v_lomask = split_f16_chan_mask(vv, v_amax, VALUE_LO_SKIP and vv.shape[1] > 32)
+                # (the magnitude-free flavour — operand_amax — takes no lo mask: its kernels are the single-flavour instantiations)
+                vh, vl, v_scale, v_lomask = split_f16_chan_mask(vv, v_amax, VALUE_LO_SKIP and vv.shape[1] > 32 and not operand_amax)
                 if operand_amax:
                     qh, ql, qs = planes.get_scaled(qn, True)
                     kh, kl, ks = planes.get_scaled(kn, True)

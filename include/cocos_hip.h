@@ -137,6 +137,20 @@ int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql, const void
                                       without an a-priori magnitude (ops.softmax_attention) — planes scaled by device-side
                                       powers of two (cocos_split_f16_ex); given as a pair they replace operand_scale */,
                                       cocos_stream_t stream);
+/* The same with one more output for the MAGNITUDE-FREE flavour (q_scale_dev / k_scale_dev given, v_lo_mask_dev NULL: operands that
+ * are not unit-norm columns — Attention.forward, architecture.py:114-127, feeds raw 1x1-conv outputs; a randomly initialised SPADE
+ * generator reaches |logit| ~ 1e10 there): in that flavour the running maximum is kept in the units of the raw accumulator and the
+ * exponent is formed from an EXACT difference (round 4; with the maximum in the log2 domain one ulp of m was ~700 in the exponent
+ * and the output NaN).  rowstat_out (nullable) [B][3][Nq]: per query (m as an unevaluated fp32 sum hi + lo in raw units, log2 l - bias) — what the backward of this
+ * flavour takes instead of the row LSE (cocos_corr_softmax_warp_bwd_query_f16x3_ex).  In this flavour saved_logits holds RELATIVE
+ * raw accumulators, s - m_tile, and mtile_out [B][ceil(Nk/32)][2][Nq] (required with saved_logits) the m_tile (hi, lo) they are relative to:
+ * absolute logits of 1e9 would be rounded to +-70 in the exponent, differences of fp32 maxima are exact. */
+int cocos_corr_softmax_warp_fwd_f16x3_ex(const void* qh, const void* ql, const void* kh, const void* kl,
+                                         const void* vh, const void* vl, float* out, float* lse, void* saved_logits,
+                                         const float* v_scale_dev, const unsigned* v_lo_mask_dev, int B, int K, int Nq, int Nk, int Cv,
+                                         float inv_temperature, float operand_scale, const float* q_scale_dev,
+                                         const float* k_scale_dev, float* rowstat_out /* nullable */, float* mtile_out /* nullable */,
+                                         cocos_stream_t stream);
 /* bit (c >> 5) of *mask_inout_dev |= (channel c of the channel-major f16 plane [B,C,N] has a non-zero element); the
  * cell must hold 0 (or an earlier partial mask) on entry; C <= 1024.  Run on the LO plane of V: value channels that
  * are exact in f16 (one-hot labels, masks) have an all-zero lo plane, and when every 32-channel block but the first
@@ -184,6 +198,15 @@ int cocos_corr_softmax_warp_bwd_query_f16x3(
     int B, int K, int Nq, int Nk, int Cv, int CvPad, float inv_temperature, float k_scale,
     const float* q_scale_dev /* nullable */, const float* k_scale_dev /* nullable: as in the forward call */,
     int planes_blocked, cocos_stream_t stream);
+/* ... with `rowstat` [B][3][Nq] and `mtile` [B][ceil(Nk/32)][2][Nq] (both or neither) as written by
+ * cocos_corr_softmax_warp_fwd_f16x3_ex: the magnitude-free flavour's backward (P from exact differences; `lse` is then not read for P). */
+int cocos_corr_softmax_warp_bwd_query_f16x3_ex(
+    const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
+    const float* g_scale_dev, const float* out, const float* dout, const float* lse, const void* saved_logits,
+    float* dqn, void* dsh, void* dsl, void* psh, void* psl, const float* v_amax_dev, const float* v_scale_dev,
+    float* ds_scale_out_dev, const unsigned* v_lo_mask_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad,
+    float inv_temperature, float k_scale, const float* q_scale_dev, const float* k_scale_dev, int planes_blocked,
+    const float* rowstat /* nullable */, const float* mtile /* nullable */, cocos_stream_t stream);
 int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* c,
                       int batch, int M, int N, int K, float host_scale, const float* dev_scale /* nullable */,
                       const float* dev_scale2 /* nullable */, int b_blocked, cocos_stream_t stream);

@@ -641,3 +641,40 @@ def test_softmax_attention_takes_the_fused_kernels_for_small_k_and_any_operand_m
             assert torch.isfinite(o).all()
             assert rel(o, o_ref) < TOL, (qmag, fused)
             assert rel(qd.grad, dq_ref) < TOL and rel(kd.grad, dk_ref) < TOL and rel(vd.grad, dv_ref) < TOL, (qmag, fused)
+
+
+@pytest.mark.parametrize("qmag,kmag,vmag", [(4e5, 1.5e4, 1e4), (3e3, 2e3, 1.0), (40.0, 30.0, 5.0)])
+def test_softmax_attention_is_finite_and_exact_at_any_logit_magnitude(qmag, kmag, vmag, monkeypatch):
+    """Round 4 (found by the BASELINE config 3 generator, cocosnet_amd/translation.py): a randomly initialised SPADEGenerator feeds
+    its Attention block theta ~ 4e5, phi ~ 1.5e4 — logits of 1e10.  The fused kernels kept the running maximum in the log2 domain;
+    one ulp of it was ~700 in the exponent and 75 % of the output was NaN (the fp32 reference is finite there: torch subtracts the
+    row maximum exactly).  The magnitude-free flavour keeps the maximum in raw-accumulator units and forms exact differences:
+    finite everywhere, and equal to fp64 wherever fp32 logits can decide the row (gaps far above the accumulation noise)."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    rs = np.random.RandomState(11)
+    B, K, Nq, Nk, Cv = 2, 32, 512, 256, 70
+    q = rs.standard_normal((B, K, Nq)) * qmag
+    k = rs.standard_normal((B, K, Nk)) * kmag
+    v = rs.uniform(-1, 1, (B, Cv, Nk)) * vmag
+    g = rs.standard_normal((B, Cv, Nq))
+    f = np.einsum("bci,bcj->bij", q, k)
+    p = co.softmax(f)
+    o_ref = np.einsum("bij,bcj->bci", p, v)
+    dp = np.einsum("bci,bcj->bij", g, v)
+    ds = p * (dp - (p * dp).sum(-1, keepdims=True))
+    dq_ref, dk_ref, dv_ref = np.einsum("bij,bcj->bci", ds, k), np.einsum("bij,bci->bcj", ds, q), np.einsum("bci,bij->bcj", g, p)
+    qd, kd, vd = dev(q, True), dev(k, True), dev(v, True)
+    with ops.KernelTimer() as kt:
+        o = ops.softmax_attention(qd, kd, vd, 1.0)
+        o.backward(dev(g))
+    assert "corr_softmax_warp_fwd" in kt.summary()
+    for t in (o, qd.grad, kd.grad, vd.grad):
+        assert torch.isfinite(t).all()
+    assert rel(o, o_ref) < TOL and rel(vd.grad, dv_ref) < TOL
+    if qmag * kmag > 1e4:
+        # one-hot rows: d q = d k = 0 exactly in fp64.  In fp32 the row's own entry carries dS = P (dP - D) with dP - D the
+        # ROUNDING residual of two equal numbers (~2^-20 |g| |v| Cv), times the other operand: bounded, not compared
+        assert float(qd.grad.abs().max()) <= 1e-4 * kmag * vmag * Cv and float(kd.grad.abs().max()) <= 1e-4 * qmag * vmag * Cv * Nq / Nk
+    else:
+        assert rel(qd.grad, dq_ref) < 5 * TOL and rel(kd.grad, dk_ref) < 5 * TOL      # (rows with near-ties: fp32 logits decide)

@@ -596,5 +596,5 @@ def test_config3_generator_and_patchgan_against_fp64_copies(monkeypatch):
     e = errs["f16x3"]
     assert all(e[k] < 1e-3 for k in ("fake_image", "D0_logits", "D1_logits", "D0_feat2")), e
     grads = sorted(v for k, v in e.items() if k.startswith("d "))
-    assert grads[len(grads) // 2] < 1e-3 and grads[-1] < 0.1, e
+    assert grads[-1] < 0.05, e            # (behind LeakyReLU / ReLU kinks: 1e-6 .. 3e-3 measured, see the docstring)
     assert all(v < 1.0 for v in errs["bf16"].values()), errs["bf16"]
