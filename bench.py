@@ -176,6 +176,16 @@ def config3_context(device, steps=4, warmup=3):
         with torch.no_grad():
             y64 = G64(seg[:2].double(), warp_out=cbn[:2].double())
             d64 = D64(torch.cat((seg[:2].double(), y64), 1))[0]
+        rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
+        # errors first, in eval mode (in train mode spectral norm iterates and the timed steps below move the weights away from
+        # the fp64 copy's)
+        for flavour in ("f16x3", "bf16"):
+            ops.CONV_PRECISION = flavour
+            with torch.no_grad():
+                y = G(seg[:2], warp_out=cbn[:2])
+                dd = D(torch.cat((seg[:2], y64.float()), 1))[0]
+            out[flavour] = {"err_vs_fp64": {"fake_image": rel(y, y64), "D_logits": max(rel(a[-1], b[-1]) for a, b in zip(dd, d64))}}
+        del G64, D64
         G.train(); D.train()
         gp, dp = list(G.parameters()), list(D.parameters())
         for flavour in ("f16x3", "bf16"):
@@ -192,7 +202,6 @@ def config3_context(device, steps=4, warmup=3):
                 res = D(torch.cat((seg, real), 1))[0]
                 torch.autograd.backward([r[-1] for r in res], [torch.ones_like(r[-1]) for r in res])
 
-            rec = {}
             for name, fn in (("generator", g_step), ("discriminator", d_step)):
                 for _ in range(warmup):
                     fn()
@@ -202,15 +211,7 @@ def config3_context(device, steps=4, warmup=3):
                     fn()
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t0) / steps * 1e3
-                rec[name] = {"ms_fwd_bwd": round(ms, 2), "images_per_s": round(B / ms * 1e3, 1)}
-            G.eval(); D.eval()
-            with torch.no_grad():
-                y = G(seg[:2], warp_out=cbn[:2])
-                dd = D(torch.cat((seg[:2], y64.float()), 1))[0]
-            G.train(); D.train()
-            rel = lambda a, b: float((a.double() - b).abs().max() / b.abs().max())
-            rec["err_vs_fp64"] = {"fake_image": rel(y, y64), "D_logits": max(rel(a[-1], b[-1]) for a, b in zip(dd, d64))}
-            out[flavour] = rec
+                out[flavour][name] = {"ms_fwd_bwd": round(ms, 2), "images_per_s": round(B / ms * 1e3, 1)}
         out["note"] = ("cocosnet_amd.translation.SPADEGenerator / MultiscaleDiscriminator, CelebA-HQ edge training flags, B = 16, 256x256, "
                        "forward + backward each; err_vs_fp64 = max-norm error of the generated image / the PatchGAN logits against an "
                        "fp64 copy of the same module (eval mode, 2 samples): bf16 is the precision BASELINE config 3 names for these two "

@@ -112,7 +112,8 @@ _SIGNATURES = {
                                                    + [ctypes.c_void_p] * 4 + [_c_float_p] * 3 + [ctypes.c_void_p]
                                                    + [ctypes.c_int] * 6
                                                    + [ctypes.c_float, ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_int,
-                                                      _c_float_p, _c_float_p, _stream_t]),
+                                                      _c_float_p, _c_float_p, _c_float_p, _stream_t]),
+    "cocos_rowdot_f64": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [_stream_t]),
     "cocos_box3_fused_supported": (ctypes.c_int, [ctypes.c_int] * 5),
     "cocos_box3_corr_xbox_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 4 + [_c_float_p] + [ctypes.c_int] * 5
                                    + [_c_float_p, _c_float_p, _stream_t]),
@@ -122,7 +123,7 @@ _SIGNATURES = {
     "cocos_box3_softmax_warp_bwd_colpart_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "cocos_box3_softmax_warp_bwd_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_void_p] * 4 + [_c_float_p] * 10
                                           + [ctypes.c_void_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-                                          + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, _stream_t]),
+                                          + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, _c_float_p, _stream_t]),
     "cocos_box3_adjoint_planes_f16x3": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p]
                                         + [ctypes.c_int] * 5 + [_stream_t]),
     "cocos_warp_values_amax": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 6 + [_c_float_p, _stream_t]),

@@ -349,10 +349,11 @@ __device__ __forceinline__ float bx_colsum4(const float (&x)[4], int c) {
     const float* __restrict__ g_scale, const float* __restrict__ v_scale, const float* __restrict__ outp,              \
     const float* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ G, float* __restrict__ dmu,     \
     float* __restrict__ da, float* __restrict__ colpart, float* __restrict__ gmax, _Float16* __restrict__ psh,         \
-    _Float16* __restrict__ psl, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale
+    _Float16* __restrict__ psl, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale,              \
+    const float* __restrict__ d_pre
 #define COCOS_BXB_ARGS \
     T, mu_q, a_q, nu_k, b_k, vph, vpl, gph, gpl, g_scale, v_scale, outp, dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, \
-    Nk, Cv, himg, wimg, kc, scale
+    Nk, Cv, himg, wimg, kc, scale, d_pre
 
 template <int CVB, bool STORE_P, bool VLO0, bool CHUNKED>
 __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
@@ -415,7 +416,9 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
         }
     }
     float d_lane;
-    {
+    if (d_pre) {               // round 4: D from cocos_rowdot_f64 (a streaming kernel) instead of the serial loop below
+        d_lane = d_pre[(size_t)b * Nq + i_lane] * s_o;
+    } else {
         double dacc = 0.0;
         for (int ch = h; ch < Cv; ch += 2) {
             const unsigned off = (unsigned)(ch * Nq + i_lane) * 4u;
@@ -825,7 +828,7 @@ static int bx_bwd_launch(const float* T, const float* mu, const float* a, const 
                          const float* gs, const float* vs, const float* outp, const float* dout, const float* lse, float* G,
                          float* dmu, float* da, float* colpart, float* gmax, _Float16* psh, _Float16* psl,
                          const unsigned* mask, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale,
-                         hipStream_t s) {
+                         const float* d_pre, hipStream_t s) {
     const bool chunked = Nk > 2 * BX_KCH;
     const size_t smem = (size_t)2 * 2 * 32 * (CVB * 32 + 8) * sizeof(_Float16) +
                         (size_t)(2 * 4 * 2048 + (chunked ? 4 * BX_KCH : 2 * Nk)) * sizeof(float);
@@ -834,7 +837,7 @@ static int bx_bwd_launch(const float* T, const float* mu, const float* a, const 
         auto kern = (CVB > 1 && mask) ? box3_sw_bwd_kernel<CVB, SP, (CVB > 1), CH> : box3_sw_bwd_kernel<CVB, SP, false, CH>; \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         hipLaunchKernelGGL(kern, dim3(B * (Nq / 128)), dim3(256), smem, s, T, mu, a, nu, bk, vph, vpl, gph, gpl, gs, vs, outp, \
-                           dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, Nk, Cv, himg, wimg, kc, scale, mask);  \
+                           dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, Nk, Cv, himg, wimg, kc, scale, d_pre, mask); \
     } while (0)
     if (chunked) { if (psh) COCOS_BX_GO(true, true); else COCOS_BX_GO(false, true); }
     else { if (psh) COCOS_BX_GO(true, false); else COCOS_BX_GO(false, false); }
@@ -896,7 +899,7 @@ extern "C" int cocos_box3_softmax_warp_bwd_f16x3(
     const void* vpl, const void* gph, const void* gpl, const float* g_scale_dev, const float* v_scale_dev, const float* out,
     const float* dout, const float* lse, float* g_blocked, float* dmu, float* da, float* dnu, float* db, void* colpart,
     float* gmax_dev, void* psh, void* psl, const unsigned* v_lo_mask_dev, int B, int Nq, int Nk, int Cv, int CvPad, int grid_h,
-    int grid_w, float k_unfolded, float scale, cocos_stream_t stream) {
+    int grid_w, float k_unfolded, float scale, const float* d_pre, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(t_blocked && mu_q && a_q && nu_k && b_k && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse &&
                       g_blocked && dmu && da && dnu && db && colpart && gmax_dev,
@@ -916,7 +919,7 @@ extern "C" int cocos_box3_softmax_warp_bwd_f16x3(
     t_blocked, mu_q, a_q, nu_k, b_k, static_cast<const _Float16*>(vph), static_cast<const _Float16*>(vpl),               \
         static_cast<const _Float16*>(gph), static_cast<const _Float16*>(gpl), g_scale_dev, v_scale_dev, out, dout, lse,   \
         g_blocked, dmu, da, static_cast<float*>(colpart), gmax_dev, static_cast<_Float16*>(psh),                         \
-        static_cast<_Float16*>(psl), v_lo_mask_dev, B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, s
+        static_cast<_Float16*>(psl), v_lo_mask_dev, B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, d_pre, s
     int rc;
     switch (cvb) {
         case 1: rc = bx_bwd_launch<1>(COCOS_ARGS); break;

@@ -89,10 +89,10 @@ struct DsRegs {
     _Float16* __restrict__ dsl, _Float16* __restrict__ psh, _Float16* __restrict__ psl, const float* __restrict__ v_amax, \
     const float* __restrict__ v_scale, float* __restrict__ ds_scale_out, const unsigned* __restrict__ v_lo_mask, int B, \
     int Nq, int Nk, int Cv, float inv_t, float k_scale, float q_scale, const float* __restrict__ rowstat, \
-    const float* __restrict__ mtile
+    const float* __restrict__ mtile, const float* __restrict__ d_pre
 #define COCOS_BQ_ARGS \
     kch, kcl, vph, vpl, gph, gpl, g_scale, outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, \
-    v_lo_mask, B, Nq, Nk, Cv, inv_t, k_scale, q_scale, rowstat, mtile
+    v_lo_mask, B, Nq, Nk, Cv, inv_t, k_scale, q_scale, rowstat, mtile, d_pre
 
 // RAWM: the magnitude-free flavour (see corr_fused_fwd_f16x3.hip) — P = 2^((s_rel + (m_tile - m)) * scale - r) from the forward's
 // RELATIVE saved logits, its per-tile reference m_tile and its per-row (m in raw-accumulator units, r = log2 l - bias) instead
@@ -115,7 +115,8 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     int B, int Nq, int Nk, int Cv, float inv_t, float k_scale /* of the K planes */, float q_scale /* of the query planes the
     forward multiplied them with: raw logits = q_scale * k_scale * <q, k> */,
     const float* __restrict__ rowstat /* RAWM: [B][3][Nq] as written by the forward */,
-    const float* __restrict__ mtile /* RAWM: [B][ntiles][2][Nq] as written by the forward */) {
+    const float* __restrict__ mtile /* RAWM: [B][ntiles][2][Nq] as written by the forward */,
+    const float* __restrict__ d_pre /* nullable: D = sum_c dout * out per query [B][Nq] (cocos_rowdot_f64) */) {
     constexpr int CVP = CVB * 32;
     constexpr int CVS = CVP / 16;                     // k-steps of the dP product
     constexpr int KB = BQH_KD / 32;                   // channel blocks of dqn
@@ -199,7 +200,11 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
         }
     }
     float d_lane;
-    {
+    if (d_pre) {
+        // round 4: D arrives precomputed (cocos_rowdot_f64: a streaming kernel on every CU) — the serial loop below, 2 x Cv / 2
+        // dependent 4-byte loads per lane and an fp64 chain on a kernel that runs ONE wave per SIMD, was this kernel's prologue
+        d_lane = live ? d_pre[(size_t)b * Nq + i_lane] * s_ov : 0.f;
+    } else {
         // D in fp64 from the fp32 tensors (dP' - D' cancels wherever P is peaked); the two half-waves
         // take alternate channels
         double dacc = 0.0;
@@ -670,7 +675,7 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                            _Float16* dsl, _Float16* psh, _Float16* psl, const float* v_amax, const float* v_scale,
                            float* ds_scale_out, const unsigned* v_lo_mask, int B, int Nq, int Nk, int Cv, float inv_t,
                            float k_scale, int blocked, const float* qsd, const float* ksd, const float* rowstat,
-                           const float* mtile, hipStream_t s) {
+                           const float* mtile, const float* d_pre, hipStream_t s) {
     const bool ragged = (Nk % 32) != 0, store = dsh != nullptr, storep = psh != nullptr;
     const size_t smem = ((size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) + 4 * 2 * 32 * 32) * sizeof(_Float16);
     const int nqb = (Nq + 127) / 128;
@@ -685,7 +690,7 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
         hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, s, kch, kcl, vph, vpl, gph, gpl, g_scale,   \
                            outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, MASK, B, Nq, \
-                           Nk, Cv, inv_t, k_scale, k_scale, rowstat, mtile, qsd, ksd);                       \
+                           Nk, Cv, inv_t, k_scale, k_scale, rowstat, mtile, d_pre, qsd, ksd);                \
     } while (0)
     /* blocked planes ([query][key] blocks, see the kernel) only exist for whole tiles */
 #define COCOS_GO3(DS, SP, RG, VL, MASK)                                                                      \
@@ -734,7 +739,53 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
     return cocos_corr_softmax_warp_bwd_query_f16x3_ex(kch, kcl, vph, vpl, gph, gpl, g_scale_dev, out, dout, lse, saved_logits, dqn, dsh,
                                                       dsl, psh, psl, v_amax_dev, v_scale_dev, ds_scale_out_dev, v_lo_mask_dev, B, K, Nq,
                                                       Nk, Cv, CvPad, inv_temperature, k_scale, q_scale_dev, k_scale_dev, planes_blocked,
-                                                      nullptr, nullptr, stream);
+                                                      nullptr, nullptr, nullptr, stream);
+}
+
+namespace cocos {
+// D[b][i] = sum_c a[b][c][i] * b[b][c][i] accumulated in fp64.  Workgroup = 128 queries (32 lanes of 16-byte loads) x 8 channel
+// groups, partial sums folded through LDS: 40 MB at the benchmark shape, every CU busy.
+__global__ __launch_bounds__(256) void rowdot_f64_kernel(const float* __restrict__ a, const float* __restrict__ bsrc,
+                                                         float* __restrict__ d, int C, int N) {
+    __shared__ double red[8][128];
+    const int q4 = threadIdx.x & 31, cg = threadIdx.x >> 5;
+    const int i0 = blockIdx.x * 128 + q4 * 4, b = blockIdx.y;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* pa = a + (size_t)b * C * N + i0;
+    const float* pb = bsrc + (size_t)b * C * N + i0;
+    if ((N & 3) == 0 && i0 < N) {
+        for (int c = cg; c < C; c += 8) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(pa + (size_t)c * N), y = *reinterpret_cast<const f32x4*>(pb + (size_t)c * N);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += (double)x[e] * (double)y[e];
+        }
+    } else {
+        for (int c = cg; c < C; c += 8)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i0 + e < N) acc[e] += (double)pa[(size_t)c * N + e] * (double)pb[(size_t)c * N + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[cg][q4 * 4 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int i = blockIdx.x * 128 + threadIdx.x;
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
+        if (i < N) d[(size_t)b * N + i] = (float)t;
+    }
+}
+}  // namespace cocos
+
+extern "C" int cocos_rowdot_f64(const float* a, const float* b, float* d, int B, int C, int N, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(a && b && d, COCOS_ERR_INVALID, "rowdot_f64: null pointer");
+    COCOS_REQUIRE(B >= 1 && B <= 65535 && C >= 1 && N >= 1, COCOS_ERR_INVALID, "rowdot_f64: bad dims B=%d C=%d N=%d", B, C, N);
+    COCOS_REQUIRE((N & 3) != 0 || (aligned16(a) && aligned16(b)), COCOS_ERR_INVALID, "rowdot_f64: a / b must be 16-byte aligned");
+    hipLaunchKernelGGL(rowdot_f64_kernel, dim3((unsigned)((N + 127) / 128), (unsigned)B), dim3(256), 0, as_stream(stream), a, b, d, C, N);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
 }
 
 extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3_ex(
@@ -743,7 +794,7 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3_ex(
     float* dqn, void* dsh, void* dsl, void* psh, void* psl, const float* v_amax_dev, const float* v_scale_dev,
     float* ds_scale_out_dev, const unsigned* v_lo_mask_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad,
     float inv_temperature, float k_scale, const float* q_scale_dev, const float* k_scale_dev, int planes_blocked,
-    const float* rowstat, const float* mtile, cocos_stream_t stream) {
+    const float* rowstat, const float* mtile, const float* d_pre, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE((rowstat == nullptr) == (mtile == nullptr) && (!rowstat || (q_scale_dev && !v_lo_mask_dev)), COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd_query_f16x3: rowstat + mtile come as a pair and belong to the magnitude-free flavour "
@@ -780,7 +831,7 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3_ex(
         g_scale_dev, out, dout, lse, static_cast<const float*>(saved_logits), dqn, static_cast<_Float16*>(dsh),  \
         static_cast<_Float16*>(dsl), static_cast<_Float16*>(psh), static_cast<_Float16*>(psl), v_amax_dev,      \
         v_scale_dev, ds_scale_out_dev, v_lo_mask_dev, B, Nq, Nk, Cv, inv_temperature, k_scale, planes_blocked, q_scale_dev, \
-        k_scale_dev, rowstat, mtile, s
+        k_scale_dev, rowstat, mtile, d_pre, s
     switch (cvb) {
         case 1: return launch_bq_f16x3<1>(COCOS_ARGS);
         case 2: return launch_bq_f16x3<2>(COCOS_ARGS);

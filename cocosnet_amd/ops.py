@@ -36,6 +36,9 @@ MAX_SAVED_LOGITS_BYTES = int(os.environ.get("COCOS_MAX_SAVED_LOGITS_BYTES", 16 <
 #: ... the recomputed logits / dS'' / P planes of one key chunk (bytes per matrix).  1 GiB: at HW = 16384, B = 2 a chunk is 8192
 #: keys — the key-side GEMM of a chunk still has 128 workgroups (512 MiB chunks: 64 workgroups, its time tripled)
 RECOMPUTE_CHUNK_BYTES = int(os.environ.get("COCOS_RECOMPUTE_CHUNK_BYTES", 1 << 30))
+#: split K2 backward: D = sum_c dout * out per query from a streaming kernel (cocos_rowdot_f64) instead of the query kernel's own
+#: serial fp64 prologue; "0": the round-3 form (A/B runs)
+BWD_D_PRECOMPUTED = os.environ.get("COCOS_BWD_D_PRE", "1") != "0"
 #: channel count the fused kernels are specialised for (self.inter_channels, correspondence.py:170)
 FUSED_K = 256
 #: where the K2 forward's products run: "fp32" = v_mfma_f32_32x32x2_f32 (exact fp32 operands);
@@ -464,13 +467,14 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                 dqn_buf = torch.empty_like(qn)
             else:
                 dqn_buf = dqn
+            d_pre = _rowdot(dout, out) if BWD_D_PRECOMPUTED else None
             _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3_ex", kch.data_ptr(),
                   kcl.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(),
                   g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), logits_t.data_ptr(),
                   dqn_buf.data_ptr(), _ptr(dsh), _ptr(dsl), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
                   v_scale.data_ptr(), ds_scale.data_ptr(), _ptr(ctx.v_lomask), B, K, Nq, Nk, Cv, cvp, ctx.inv_t,
                   SPLIT_OPERAND_SCALE, _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked,
-                  _ptr(getattr(ctx, "rowstat", None)), _ptr(getattr(ctx, "mtile", None)), st)
+                  _ptr(getattr(ctx, "rowstat", None)), _ptr(getattr(ctx, "mtile", None)), _ptr(d_pre), st)
             if want_k:    # A = the channel-major planes of q_scale * qn
                 _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
                       dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 if qks else 1.0 / SPLIT_OPERAND_SCALE,
@@ -535,6 +539,7 @@ def _corr_bwd_recompute(ctx, qn, kn, v, out, lse, dout, dqn, dkn, dv, need_k):
     want_k = dkn is not None
     kc = _recompute_chunk(B, Nq, Nk)
     ds_scale = torch.empty(1, device=dev, dtype=torch.float32)
+    d_pre = _rowdot(dout, out) if BWD_D_PRECOMPUTED else None
     dq_acc = None
     # scratch shared by the chunks (sized for a full chunk)
     o1 = torch.empty((B, 1, Nq), device=dev, dtype=torch.float32)
@@ -562,7 +567,7 @@ def _corr_bwd_recompute(ctx, qn, kn, v, out, lse, dout, dqn, dkn, dv, need_k):
               vphc.data_ptr(), vplc.data_ptr(), gph.data_ptr(), gpl.data_ptr(), g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(),
               lse.data_ptr(), lg.data_ptr(), dq_c.data_ptr(), _ptr(dsh), _ptr(dsl), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
               v_scale.data_ptr(), ds_scale.data_ptr(), _ptr(ctx.v_lomask), B, K, Nq, n, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE,
-              _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked, _ptr(rowstat), _ptr(mt), st)
+              _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked, _ptr(rowstat), _ptr(mt), _ptr(d_pre), st)
         del lg
         dq_acc = dq_c if dq_acc is None else dq_acc.add_(dq_c)
         if want_k:
@@ -584,6 +589,14 @@ def _corr_bwd_recompute(ctx, qn, kn, v, out, lse, dout, dqn, dkn, dv, need_k):
 
 
 _CorrSoftmaxWarp._backward_recompute = staticmethod(_corr_bwd_recompute)
+
+
+def _rowdot(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """D[b,i] = sum_c a[b,c,i] b[b,c,i] (fp64 accumulation) -> [B,N]: the D of the softmax backward (cocos_rowdot_f64)."""
+    B, C, N = a.shape
+    d = torch.empty((B, N), device=a.device, dtype=torch.float32)
+    _call("rowdot", "cocos_rowdot_f64", a.data_ptr(), b.data_ptr(), d.data_ptr(), B, C, N, _stream())
+    return d
 
 
 def _wants_logits(qn, kn):
@@ -1491,7 +1504,7 @@ class _Box3SoftmaxWarp(torch.autograd.Function):
               nu.data_ptr(), b.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(), gs.data_ptr(),
               v_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), g.data_ptr(), dmu.data_ptr(),
               da.data_ptr(), dnu.data_ptr(), db.data_ptr(), colpart.data_ptr(), gmax.data_ptr(), _ptr(psh), _ptr(psl),
-              _ptr(ctx.v_lomask), B, N, N, Cv, cvp, h, w, kc, scale, _stream())
+              _ptr(ctx.v_lomask), B, N, N, Cv, cvp, h, w, kc, scale, _ptr(_rowdot(dout, out) if BWD_D_PRECOMPUTED else None), _stream())
         _remember_amax(g, gmax)
         dv = None
         if need_v:

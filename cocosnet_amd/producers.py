@@ -256,6 +256,7 @@ class SPADEResnetBlock(nn.Module):
         self.learned_shortcut = fin != fout
         fmid = min(fin, fout)
         self.use_se = use_se
+        self.slope = 0.2                 # `actvn`: LeakyReLU(2e-1) (architecture.py:107-108); a plain attribute (tests smooth it)
         self.pad = ReflectionPad2d(dilation)
         self.conv_0 = Conv2d(fin, fmid, 3, padding=0, dilation=dilation)
         self.conv_1 = Conv2d(fmid, fout, 3, padding=0, dilation=dilation)
@@ -277,8 +278,8 @@ class SPADEResnetBlock(nn.Module):
 
     def forward(self, x, seg):
         x_s = self.conv_s(self.norm_s(x, seg)) if self.learned_shortcut else x
-        dx = reflect_conv(self.pad, self.conv_0, self.norm_0(x, seg, slope=0.2))       # norm -> LeakyReLU(0.2) -> pad -> conv
-        dx = reflect_conv(self.pad, self.conv_1, self.norm_1(dx, seg, slope=0.2))
+        dx = reflect_conv(self.pad, self.conv_0, self.norm_0(x, seg, slope=self.slope))       # norm -> LeakyReLU(0.2) -> pad -> conv
+        dx = reflect_conv(self.pad, self.conv_1, self.norm_1(dx, seg, slope=self.slope))
         if self.use_se:
             dx = self.se_layar(dx)
         return x_s + dx

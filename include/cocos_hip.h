@@ -206,7 +206,12 @@ int cocos_corr_softmax_warp_bwd_query_f16x3_ex(
     float* dqn, void* dsh, void* dsl, void* psh, void* psl, const float* v_amax_dev, const float* v_scale_dev,
     float* ds_scale_out_dev, const unsigned* v_lo_mask_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad,
     float inv_temperature, float k_scale, const float* q_scale_dev, const float* k_scale_dev, int planes_blocked,
-    const float* rowstat /* nullable */, const float* mtile /* nullable */, cocos_stream_t stream);
+    const float* rowstat /* nullable */, const float* mtile /* nullable */,
+    const float* d_pre /* nullable: D[b][i] = sum_c dout * out from cocos_rowdot_f64 — the kernel then skips its own serial fp64 loop */,
+    cocos_stream_t stream);
+/* d[b][i] = sum_c a[b][c][i] * b[b][c][i], fp64 accumulation, fp32 result: D of the softmax backward (autograd of
+ * correspondence.py:307/:318: dS = P * (dP - D)) as a streaming kernel. */
+int cocos_rowdot_f64(const float* a, const float* b, float* d, int B, int C, int N, cocos_stream_t stream);
 int cocos_hgemm_f16x3(const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo, float* c,
                       int batch, int M, int N, int K, float host_scale, const float* dev_scale /* nullable */,
                       const float* dev_scale2 /* nullable */, int b_blocked, cocos_stream_t stream);
@@ -613,6 +618,7 @@ int cocos_box3_softmax_warp_bwd_f16x3(const float* t_blocked, const float* mu_q,
                                       float* db, void* colpart, float* gmax_dev, void* psh /* nullable */,
                                       void* psl /* nullable */, const unsigned* v_lo_mask_dev /* nullable */, int B, int Nq,
                                       int Nk, int Cv, int CvPad, int grid_h, int grid_w, float k_unfolded, float scale,
+                                      const float* d_pre /* nullable: D = sum_c dout * out [B][Nq] (cocos_rowdot_f64) */,
                                       cocos_stream_t stream);
 int cocos_box3_adjoint_planes_f16x3(const float* g_blocked, const float* gmax_dev, void* dc_hi, void* dc_lo,
                                     float* scale_out_dev, int B, int Nq, int Nk, int grid_h, int grid_w,

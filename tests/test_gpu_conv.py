@@ -167,7 +167,7 @@ def test_patchgan_stack_on_hip_convs_matches_the_framework():
         assert (a - r).abs().max().item() <= 2e-4 * max(r.abs().max().item(), 1e-6), (a.shape, (a - r).abs().max().item())
 
 
-def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False):
+def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False):     # smooth_adaptors: ALL kinks
     """The whole drop-in module — adaptors with SPADE blocks, feature_normalize, four ResidualBlocks, theta / phi, AND the hot
     path behind them — in one graph: ours (every convolution / norm / correlation kernel on HIP, `arm` = f16x3 | bf16 | torch)
     against a torch-FP64 copy of the same module (same parameters and buffers; framework ops in double up to theta / phi, the
@@ -183,8 +183,16 @@ def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False):
     net = cc.NoVGGCorrespondence(opt).cuda()
     net.init_weights(opt.init_type, opt.init_variance)
     net.eval()                     # freezes the spectral-norm power iteration: both copies see the same W / sigma
-    if smooth_adaptors:            # LeakyReLU(0.2) -> identity in the adaptors' five strided layers (see the test's docstring)
+    if smooth_adaptors:            # every kink of the module -> identity (see the test's docstring); all kernels still run
+        from cocosnet_amd import producers
         net.adaptive_model_seg.actvn.negative_slope = net.adaptive_model_img.actvn.negative_slope = 1.0
+        for m in net.modules():
+            if isinstance(m, torch.nn.PReLU):
+                m.weight.data.fill_(1.0)
+            elif isinstance(m, producers.SPADEResnetBlock):
+                m.slope = 1.0
+            elif isinstance(m, producers.SPADE):
+                m.mlp_shared[2] = torch.nn.Identity()
     g = torch.Generator(device="cuda").manual_seed(2)
     nc = flags["semantic_nc"]
     img = torch.rand(B, 3, size, size, device="cuda", generator=g) * 2 - 1
@@ -270,9 +278,10 @@ def test_module_end_to_end_against_an_fp64_copy_of_itself(name, monkeypatch):
 
 
 def test_module_end_to_end_against_fp64_every_gradient_without_the_adaptor_kinks(monkeypatch):
-    """The same comparison with the adaptors' LeakyReLU slope set to 1 in BOTH copies (every kernel still runs: K13 with
-    a = 1): no branch can be taken differently, and EVERY probed gradient — the strided adaptor layers included — is within
-    1e-3 of fp64 on the default flavour."""
+    """The same comparison with EVERY kink of the module taken out in BOTH copies — the adaptors' LeakyReLU and the SPADE blocks'
+    LeakyReLU at slope 1, the ResidualBlocks' PReLU at weight 1, SPADE's ReLU replaced by the identity; every kernel still runs
+    (K13 / K9 with a = 1): no branch can be taken differently, and EVERY probed gradient is within 1e-3 of fp64 on the default
+    flavour."""
     errs = _module_e2e(monkeypatch, E2E_FLAGS["ade20k_mk3"], smooth_adaptors=True)
     import json
     print("E2E_FP64_SMOOTH", json.dumps(errs))
