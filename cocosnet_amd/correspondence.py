@@ -28,6 +28,9 @@ from .hot_path import HotPathConfig, correspondence_hot_path
 from .producers import AdaptiveFeatureGenerator, ResidualBlock
 
 _EPS = __import__("sys").float_info.epsilon
+#: the four shared ResidualBlocks see content and exemplar features as ONE batch (False: two calls, as the reference writes it —
+#: a test / A-B hook, no environment variable)
+BATCH_SHARED_LAYERS = True
 
 
 def feature_normalize(x):
@@ -142,14 +145,23 @@ class NoVGGCorrespondence(NetworkBase):
         seg = F.interpolate(seg_map, size=feat_seg.shape[2:], mode="nearest")
         ref_seg = F.interpolate(ref_seg_map, size=feat_img.shape[2:], mode="nearest")
         if opt.maskmix:
-            cont = self.layer(torch.cat((feat_seg, seg), 1))
+            cont_in = torch.cat((feat_seg, seg), 1)
             if opt.noise_for_mask and ((not opt.isTrain) or (opt.isTrain and opt.epoch > opt.mask_epoch)):
                 noise = torch.randn_like(ref_seg, requires_grad=False) * 0.01
-                ref = self.layer(torch.cat((feat_img, noise), 1))
+                ref_in = torch.cat((feat_img, noise), 1)
             else:
-                ref = self.layer(torch.cat((feat_img, ref_seg), 1))
+                ref_in = torch.cat((feat_img, ref_seg), 1)
         else:
-            cont, ref = self.layer(feat_seg), self.layer(feat_img)
+            cont_in, ref_in = feat_seg, feat_img
+        if BATCH_SHARED_LAYERS and cont_in.is_cuda and cont_in.shape == ref_in.shape:
+            # `self.layer` (four ResidualBlocks, shared weights) is applied to both streams (:258-266): every op in it is
+            # per-sample (convolution, InstanceNorm2d, PReLU), so ONE pass over the concatenated batch gives the same values
+            # with half the launches — one weight-plane preparation, one weight gradient and one split-K reduction per
+            # convolution instead of two
+            both = self.layer(torch.cat((cont_in, ref_in), 0))
+            cont, ref = both[:cont_in.shape[0]], both[cont_in.shape[0]:]
+        else:
+            cont, ref = self.layer(cont_in), self.layer(ref_in)
         if cont.is_cuda and cont.dtype == torch.float32:   # :272 / :282 on K0 (same parameters: checkpoints are unaffected)
             return (ops.proj1x1(cont, self.theta.weight, self.theta.bias),
                     ops.proj1x1(ref, self.phi.weight, self.phi.bias))

@@ -249,7 +249,7 @@ def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_
             th_f, ph_f = th_f.detach(), ph_f.detach()
         keep = torch.is_grad_enabled() and (th_f.requires_grad or ph_f.requires_grad)
         planes = ops.OperandPlanes()
-        if (ops.NORM_PLANES and cfg.PONO_C and _hip_fp32(theta_raw)
+        if (cfg.PONO_C and _hip_fp32(theta_raw)
                 and ops.corr_split_ok(B, C, fh * fw, fh * fw, 1, keep)):
             # K1 writes the operand planes of the split kernels itself: fp32 qn / kn never exist (ops.center_l2norm_planes)
             # (channel-major planes of BOTH operands whenever either is differentiated: the K2 backward reads both)
@@ -280,7 +280,7 @@ def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_
 
     # ---- R1: exemplar colours (+ direct mask) through the row softmax  (:309-336) ----------------
     direct_mask = cfg.warp_mask_losstype == "direct" or cfg.show_warpmask
-    fused_values = (ops.WARP_VALUES_FUSED and direct_mask and not cfg.warp_patch and _hip_fp32(ref_img) and _hip_fp32(ref_seg_map)
+    fused_values = (direct_mask and not cfg.warp_patch and _hip_fp32(ref_img) and _hip_fp32(ref_seg_map)
                     and not (ref_img.requires_grad or ref_seg_map.requires_grad) and H % down == 0 and W % down == 0)
     if fused_values:
         n_ref = ref_img.shape[1]

@@ -38,7 +38,7 @@ MAX_SAVED_LOGITS_BYTES = int(os.environ.get("COCOS_MAX_SAVED_LOGITS_BYTES", 16 <
 RECOMPUTE_CHUNK_BYTES = int(os.environ.get("COCOS_RECOMPUTE_CHUNK_BYTES", 1 << 30))
 #: split K2 backward: D = sum_c dout * out per query from a streaming kernel (cocos_rowdot_f64) instead of the query kernel's own
 #: serial fp64 prologue; "0": the round-3 form (A/B runs)
-BWD_D_PRECOMPUTED = os.environ.get("COCOS_BWD_D_PRE", "1") != "0"
+BWD_D_PRECOMPUTED = True
 #: channel count the fused kernels are specialised for (self.inter_channels, correspondence.py:170)
 FUSED_K = 256
 #: where the K2 forward's products run: "fp32" = v_mfma_f32_32x32x2_f32 (exact fp32 operands);
@@ -49,12 +49,15 @@ PRECISION = os.environ.get("COCOS_PRECISION", "f16x3")
 #: the f16 MFMA — the streaming kernels below at the reference's shapes, else the split GEMM of sgemm_f16x3.hip
 #: (operands split on the fly, staged pieces converted/committed between MFMAs).
 PROJ_PRECISION = os.environ.get("COCOS_PROJ_PRECISION", "f16x3")
+# ---- switches below WITHOUT an environment variable are test / A-B hooks: plain module attributes, read at call time, every
+# ---- non-default value covered by a GPU test (the env surface is COCOS_PRECISION, COCOS_PROJ_PRECISION,
+# ---- COCOS_CONV, COCOS_MAX_SAVED_LOGITS_BYTES, COCOS_RECOMPUTE_CHUNK_BYTES and COCOS_LIB_PATH)
 #: K2 split kernels: test V's f16 lo plane per 32-channel block and skip all-zero blocks (exact label / mask channels)
-VALUE_LO_SKIP = os.environ.get("COCOS_VALUE_LO_SKIP", "1") != "0"
+VALUE_LO_SKIP = True
 #: K0 at the reference's own shapes (<= 416 input channels, HW % 64 == 0): y = W x and dx = W^T dy on the streaming
 #: kernel (proj_stream_f16x3.hip: weight planes resident in the accumulator file, x / y touched once), dw + db as one
 #: streaming reduction (proj_dw_f16x3.hip).  "0" = the general split GEMM everywhere (A/B, tests).
-PROJ_STREAM = os.environ.get("COCOS_PROJ_STREAM", "1") != "0"
+PROJ_STREAM = True
 #: power-of-two pre-scale of the unit-norm operands before the f16 split (keeps the lo plane normal)
 SPLIT_OPERAND_SCALE = 16.0
 
@@ -176,9 +179,6 @@ def feature_normalize(x: torch.Tensor, eps: float = NORM_EPS):
     return _CenterL2Norm.apply(x.reshape(B, C, -1), 2, eps).reshape(x.shape)
 
 
-#: K1 writes the f16 operand planes of the split correlation kernels itself (no fp32 qn / kn, no split launches); "0":
-#: fp32 K1 + cocos_split_f16 as in rounds 1-2 (A/B runs)
-NORM_PLANES = os.environ.get("COCOS_NORM_PLANES", "1") != "0"
 
 
 class _CenterL2NormPlanes(torch.autograd.Function):
@@ -1063,7 +1063,7 @@ def _conv_fwd_call(x, wh, wl, ws, xa, bias, Cout, KH, KW, stride, pad, dil):
 
 
 #: "0": COCOS_CONV=bf16 keeps every layer on conv_f16x3.hip's one-term kernels (fp32 NCHW operands gathered per tap) — A/B runs
-CONV_NHWC = os.environ.get("COCOS_CONV_NHWC", "1") != "0"
+CONV_NHWC = True
 
 
 def _conv_nhwc_ok(Cin, Cout, KH, KW, stride):
@@ -1072,7 +1072,7 @@ def _conv_nhwc_ok(Cin, Cout, KH, KW, stride):
 
 #: "0": the fp32-accurate flavour keeps every layer on conv_f16x3.hip's gather kernels (A/B runs); default: K16c, the same
 #: arithmetic on K16b's data path (f16 hi/lo planes NHWC in memory, LDS-DMA GEMMs)
-CONV_NHWC_F16X3 = os.environ.get("COCOS_CONV_NHWC_F16X3", "1") != "0"
+CONV_NHWC_F16X3 = True
 
 
 def conv_nhwc_prep_split(x: torch.Tensor, pad: int, reflect: bool, amax: torch.Tensor) -> torch.Tensor:
@@ -1123,10 +1123,10 @@ def conv_nhwc_prep(x: torch.Tensor, pad: int, reflect: bool = False) -> torch.Te
 #: "1": stream-K launches for K16b layers whose tile count is just above a whole round of the CUs.  Off by default: once the
 #: DMA pieces were interleaved with the MFMAs a tile got 20 % faster and the parked partials (nearly every tile is cut: 128 MB)
 #: cost what the second round costs (407 -> 407 input gradient 0.191 vs 0.192 ms, 512 -> 512 0.224 vs 0.239).
-CONV_NHWC_STREAMK = os.environ.get("COCOS_CONV_STREAMK", "0") == "1"
+CONV_NHWC_STREAMK = False
 #: the three-term flavour (K16c) is the other way round: a tile takes 3x as long, the parked partials cost the same — stream-K on
 #: unless COCOS_CONV_STREAMK=0 (407 -> 407 input gradient on 66 x 66: two rounds of 0.3 ms against 1.07 rounds + 0.04 ms)
-CONV_NHWC_STREAMK_SPLIT = os.environ.get("COCOS_CONV_STREAMK", "1") != "0"
+CONV_NHWC_STREAMK_SPLIT = True
 
 
 def _conv_nhwc_workspace(device, split=False):
@@ -1388,7 +1388,7 @@ def box3_logits(c_raw, mu, nu, a, b, h, w, k_unfolded, scale):
 #            nothing box-filtered and no logits in HBM   (correspondence.py:276-291, :304, :307, :318; box3_fused_f16x3.hip)
 # ------------------------------------------------------------------------------------------
 #: "0": match_kernel 3 keeps the round-2 chain (K3 -> K6 -> K7) everywhere (A/B runs, tests of that chain)
-BOX3_FUSED = os.environ.get("COCOS_BOX3_FUSED", "1") != "0"
+BOX3_FUSED = True
 
 
 def box3_fused_ok(B, C, h, w, Cv=1):
@@ -1800,8 +1800,6 @@ def upsample_nearest(x, scale: int):
     return _UpsampleNearest.apply(x, scale)
 
 
-#: build the first row pass's value tensor with K14 instead of avg_pool2d + interpolate + cat ("0": framework ops)
-WARP_VALUES_FUSED = os.environ.get("COCOS_WARP_VALUES", "1") != "0"
 
 
 def warp_values(img, seg_map, down: int):
@@ -1935,7 +1933,7 @@ def spectral_weight(weight, u, v, power_iteration: bool, eps: float = 1e-12):
 
 
 #: softmax_attention on the fused kernels for K < 256 as well (channels zero-padded to 256); "0": the materialised family
-ATTENTION_FUSED = os.environ.get("COCOS_ATTENTION_FUSED", "1") != "0"
+ATTENTION_FUSED = True
 
 
 def softmax_attention(q, k, v, scale: float = 1.0):

@@ -70,8 +70,8 @@ class Conv2d(nn.Conv2d):
         return super()._conv_forward(input, weight, bias)
 
 
-#: "0": spectral-normed layers keep the framework's compute_weight (A/B runs)
-SPECTRAL_HIP = os.environ.get("COCOS_SPECTRAL", "1") != "0"
+#: False: spectral-normed layers keep the framework's compute_weight (test / A-B hook, no environment variable)
+SPECTRAL_HIP = True
 
 import importlib                                            # noqa: E402
 _sn_mod = importlib.import_module("torch.nn.utils.spectral_norm")    # the MODULE (torch.nn.utils re-exports its function under the same name)

@@ -868,3 +868,62 @@ def test_instnorm_prelu_equals_torch_chain(B, C, h, w, with_res):
     assert rel(ad.grad, a64.grad.numpy(), floor=1.0) < 5e-5
     if with_res:
         assert rel(rd.grad, r64.grad.numpy()) < 1e-5
+
+
+# ------------------------------------------------------------------ non-default routes behind module-level hooks
+@pytest.mark.parametrize("hook,value", [("VALUE_LO_SKIP", False), ("BWD_D_PRECOMPUTED", False)])
+def test_non_default_hooks_of_the_split_kernels_give_the_default_result(hook, value, monkeypatch):
+    """ops.VALUE_LO_SKIP = False (every V_lo term issued also for exact one-hot label channels: bench.py's `general_v`) and
+    ops.BWD_D_PRECOMPUTED = False (D from the query kernel's own fp64 prologue instead of cocos_rowdot_f64): same outputs and
+    gradients as the defaults — bit-identical for the lo-skip (the skipped terms are exact zeros), to fp32 rounding for D —
+    and both against the fp64 oracle."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    rs = np.random.RandomState(31)
+    B, Nq, Nk, nc = 2, 256, 384, 151
+    q, k, _ = _qkv(B, Nq, Nk, 3, 31)
+    lab = rs.randint(0, nc, (B, Nk))
+    v = np.concatenate([rs.uniform(-1, 1, (B, 3, Nk)), (lab[:, None] == np.arange(nc)[None, :, None]).astype(np.float64)], 1)
+    g = rs.standard_normal((B, 3 + nc, Nq))
+    res = {}
+    for flag in (True, value):
+        monkeypatch.setattr(ops, hook, flag)
+        qd, kd = dev(q, True), dev(k, True)
+        o = ops.corr_softmax_warp(qd, kd, dev(v), 100.0)
+        o.backward(dev(g))
+        res[flag] = (o.detach(), qd.grad, kd.grad)
+    if hook == "VALUE_LO_SKIP":
+        assert all(torch.equal(a, b) for a, b in zip(res[True], res[value]))
+    else:
+        assert torch.equal(res[True][0], res[value][0])
+        assert rel(res[value][1], res[True][1].double().cpu().numpy()) < 1e-5 and rel(res[value][2], res[True][2].double().cpu().numpy()) < 1e-5
+    o_ref = co.corr_softmax_warp(q, k, v, 100.0)
+    dq_ref, dk_ref, _ = co.corr_softmax_warp_bwd(q, k, v, g, 100.0)
+    for r in res.values():
+        assert rel(r[0], o_ref) < OUT_TOL and rel(r[1], dq_ref) < OUT_TOL and rel(r[2], dk_ref) < OUT_TOL
+
+
+def test_shared_residual_blocks_batched_equal_two_calls(monkeypatch):
+    """correspondence.BATCH_SHARED_LAYERS: the four shared ResidualBlocks on content and exemplar features as ONE batch (the
+    default) against the reference's two calls (correspondence.py:258-266): every op in them is per-sample, so theta / phi and
+    every parameter gradient agree to fp32 rounding (the per-tensor power-of-two scales of the f16 splits see another maximum)."""
+    from cocosnet_amd import correspondence as cc
+    opt = cc.base_options(semantic_nc=6, match_kernel=1, maskmix=True, PONO=True, PONO_C=True)
+    torch.manual_seed(0)
+    net = cc.NoVGGCorrespondence(opt).to(DEV)
+    net.init_weights(opt.init_type, opt.init_variance)
+    net.eval()
+    rs = np.random.RandomState(2)
+    img = dev(rs.uniform(-1, 1, (2, 3, 64, 64))); real = dev(rs.uniform(-1, 1, (2, 3, 64, 64)))
+    lab = rs.randint(0, 6, (2, 8, 8)).repeat(8, 1).repeat(8, 2)
+    seg = dev((lab[:, None] == np.arange(6)[None, :, None, None]).astype(np.float32))
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(cc, "BATCH_SHARED_LAYERS", flag)
+        net.zero_grad()
+        th, ph = net.project(img, real, seg, seg.flip(0))
+        (th.square().mean() + ph.square().mean()).backward()
+        res[flag] = [th.detach(), ph.detach(), net.layer[0].conv1.weight.grad.clone(), net.layer[3].prelu.weight.grad.clone(),
+                     net.adaptive_model_seg.layer1[0].weight_orig.grad.clone()]
+    for a, b in zip(res[True], res[False]):
+        assert rel(a, b.double().cpu().numpy()) < 2e-5
