@@ -386,8 +386,9 @@ SPLIT_TAGS = ("corr_softmax_warp_fwd", "corr_softmax_warp_bwd_query", "corr_soft
 #: parameter counts of BASELINE config 4's exchange: theta/phi only (what the hot path owns),
 #: netCorr (59 M), netG + netCorr (156 M)
 PAYLOAD_PARAMS = {"path": 0, "netcorr": 59_000_000, "full": 156_000_000}
-PMC_FILE = {"f16x3": "r03_pmc_f16x3.json" if os.path.exists(os.path.join(REPO, "profiles", "r03_pmc_f16x3.json"))
-            else "r02_pmc_f16x3.json", "fp32": "r01_pmc_final.json"}
+PMC_FILE = {"f16x3": next((f for f in ("r04_pmc_f16x3.json", "r03_pmc_f16x3.json", "r02_pmc_f16x3.json")
+                           if os.path.exists(os.path.join(REPO, "profiles", f))), "r02_pmc_f16x3.json"),
+            "fp32": "r01_pmc_final.json"}
 # (the counters were taken on the general instantiations <..., 0>; the one that skips exact value blocks moves 8 MB less)
 # substrings of the PMC file's kernel names (the training flavours: template arguments after these differ between rounds — value-lo
 # skip, device scales — so the entry with the most dispatches among the matches is taken)
@@ -464,19 +465,31 @@ def roofline_of(kernels, precision):
                 best = rec.get("dispatches", 0)
                 traffic = rec["hbm_bytes"]
                 traffic_src = f"profiles/{os.path.basename(pmc_file)} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes)"
-    # the same kernel's HBM coordinate (the second roofline north_star names): PMC bytes per launch / measured time
+    # the same kernel's HBM coordinates (the second roofline north_star names), both ways of counting bytes:
+    #   moved       PMC bytes per launch / measured time — what the kernel actually pulls through HBM (saved logits in, dS'' out);
+    #   algorithmic SURVEY §8(d)'s fused minimum 4 * (2 K HW + 2 HW Cv) * B per launch / measured time
+    # `bound` below follows the contract (ALGORITHMIC flops vs ALGORITHMIC bytes: the matrix roof is the nearer one);
+    # `nearer_roof_by_moved_bytes` says which roof the kernel is closer to when its real traffic is counted (VERDICT r3 weak 2:
+    # the saved-logits design moves ~11x the algorithmic bytes, and by that count the kernel sits nearer the HBM roof)
     hbm = None
+    alg_bytes = 4.0 * (2 * KDIM * (IMG // DOWN) ** 2 + 2 * (IMG // DOWN) ** 2 * (3 + SEM_NC)) * BATCH_PER_GPU
+    alg_gbs = alg_bytes / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
     if traffic:
         gbs = traffic / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
         hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-               "note": "HBM bytes per launch (PMC, profiles/) / the launch time measured in this run; the kernel moves the "
-                       "saved logits and the dS'' planes (2 x HW^2 x 4 B per sample) next to its MFMA work, so this "
-                       "fraction, not only the MFMA one, says how close it is to a roof (a linear read reaches "
-                       "4.7-4.9 TB/s on this chip: tools/probes/strided_rows.hip)"}
+               "algorithmic_bytes": alg_bytes, "achieved_algorithmic": round(alg_gbs, 1),
+               "frac_algorithmic": round(alg_gbs / HBM_PEAK_GBS, 4), "moved_over_algorithmic": round(traffic / alg_bytes, 2),
+               "note": "moved bytes per launch (PMC, profiles/) / the launch time measured in this run; the kernel streams the "
+                       "saved logits in and the dS'' planes out (2 x HW^2 x 4 B per sample) next to its MFMA work — a measured "
+                       "design choice (saved logits beat recompute by 24-68 % at every BASELINE shape: config.context / "
+                       "profiles/r04_configs_bench.json); a linear read reaches 4.7-4.9 TB/s on this chip "
+                       "(tools/probes/strided_rows.hip)"}
     if split and dom in SPLIT_TAGS:
         peak = F16_MFMA_PEAK_TFLOPS / 3.0
-        return {"bound": "mfma", "kernel": dom, "hbm": hbm, "achieved": kernels[dom]["alg_tflops"], "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(kernels[dom]["alg_tflops"] / peak, 4),
+        mfma_frac = kernels[dom]["alg_tflops"] / peak
+        return {"bound": "mfma", "nearer_roof_by_moved_bytes": ("hbm" if hbm and hbm["frac"] > mfma_frac else "mfma"),
+                "kernel": dom, "hbm": hbm, "achieved": kernels[dom]["alg_tflops"], "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(mfma_frac, 4),
                 "frac_kind": "algorithmic FLOPs / (f16 MFMA peak / 3): the utilisation of the matrix pipe by ISSUED "
                              "instructions is frac_issued", "traffic": traffic,
                 "traffic_unit": "bytes/launch", "traffic_source": traffic_src,

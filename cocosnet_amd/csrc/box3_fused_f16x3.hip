@@ -626,6 +626,8 @@ __global__ __launch_bounds__(256, 1) void box3_adjoint_planes_kernel(const float
     float* const img = reinterpret_cast<float*>(bx_smem) + wave * kXbFloats;
     xbox_zero_border(img, lane);
 
+    // (the diagonal-major order of the 128-wide kernel below was measured here too: 0.21 -> 0.25 ms at cfg2' — a 64 x 64
+    //  grid's G (67 MB per sample) is served by the memory-side cache either way, and row-major keeps the STORES sequential)
     const int grp = blockIdx.x * 4 + wave;                     // (b, ky, py)
     const int per = himg * himg;
     const int b = grp / per, ky = (grp % per) / himg, py = grp % himg;
@@ -707,7 +709,8 @@ __global__ __launch_bounds__(256, 1) void box3_adjoint_planes_kernel(const float
 // K20 on a 128-wide grid: a (key image row, query image row) pair is 128 x 128 = FOUR 64 x 64 chunks; one workgroup per
 // pair, wave = chunk (kq = key half, qq = query half).  Every chunk's image gets its inward-facing border cells from the
 // three other waves (box3_common.h), with one workgroup barrier between the writes and the reads.
-__global__ __launch_bounds__(256, 1) void box3_adjoint_planes_w128_kernel(const float* __restrict__ G,
+// (two workgroups per CU: 2 x 80 KB of LDS; the barriers of one hide behind the other's loads)
+__global__ __launch_bounds__(256, 2) void box3_adjoint_planes_w128_kernel(const float* __restrict__ G,
                                                                           const float* __restrict__ gmax,
                                                                           _Float16* __restrict__ dch, _Float16* __restrict__ dcl,
                                                                           float* __restrict__ scale_out, int B, int Nq, int Nk,
@@ -719,9 +722,14 @@ __global__ __launch_bounds__(256, 1) void box3_adjoint_planes_w128_kernel(const 
     float* const img = img0 + wave * kXbFloats;
     xbox_zero_border(img, lane);
 
-    const int grp = blockIdx.x;                                // (b, ky, py): the grid is exactly B * himg * himg
+    // (b, ky, py): the grid is exactly B * himg * himg.  DIAGONAL-major order on XCD-contiguous virtual ids: block (r, s) of G is read
+    // by the three row pairs (r + d, s + d), d = -1, 0, 1 — neighbours along a (wrapped) diagonal ky - py = const; enumerated that
+    // way they run back to back on ONE XCD and the second and third read of a block are L2 hits (at HW = 16384 G is 1 GiB per
+    // sample: row-major order re-read it from HBM)
+    const int grp = xcd_remap(blockIdx.x, gridDim.x);
     const int per = himg * himg;
-    const int b = grp / per, ky = (grp % per) / himg, py = grp % himg;
+    const int b = grp / per, dg = (grp % per) / himg, py = grp % himg;
+    const int ky = (py + dg) % himg;
     const int kq = wave >> 1, qq = wave & 1;
     constexpr int TPR = 4;                                     // 32-position tiles per image row
     const int nqblk = Nq >> 5;
