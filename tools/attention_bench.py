@@ -29,3 +29,18 @@ def run(name, B, K, Nq, Nk, Cv, fused, steps=5):
 for fused in (True, False):
     run("netG Attention(256) at 128x128: B=4, K=32, Nq=16384, Nk=4096, Cv=128", 4, 32, 16384, 4096, 128, fused)
     run("adaptor Attention(512) at 64x64: B=8, K=64, Nq=4096, Nk=1024, Cv=256", 8, 64, 4096, 1024, 256, fused)
+# per-kernel breakdown of the fused route at the netG shape
+ops.ATTENTION_FUSED = True
+g = torch.Generator(device="cuda").manual_seed(0)
+q = torch.randn(4, 32, 16384, device="cuda", generator=g).requires_grad_(True)
+k = torch.randn(4, 32, 4096, device="cuda", generator=g).requires_grad_(True)
+v = torch.randn(4, 128, 4096, device="cuda", generator=g).requires_grad_(True)
+go = torch.randn(4, 128, 16384, device="cuda", generator=g)
+for _ in range(2):
+    q.grad = k.grad = v.grad = None
+    ops.softmax_attention(q, k, v, 1.0).backward(go)
+with ops.KernelTimer() as kt:
+    for _ in range(3):
+        q.grad = k.grad = v.grad = None
+        ops.softmax_attention(q, k, v, 1.0).backward(go)
+print(json.dumps({t: round(r["total_ms"] / 3, 3) for t, r in kt.summary().items()}))
