@@ -95,7 +95,7 @@ _SIGNATURES = {
     "cocos_corr_softmax_warp_fwd_f16x3_ex": (ctypes.c_int, [ctypes.c_void_p] * 6 + [_c_float_p] * 2 + [ctypes.c_void_p,
                                                                                                     _c_float_p, ctypes.c_void_p]
                                              + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_float, _c_float_p, _c_float_p,
-                                                                     _c_float_p, _c_float_p, _stream_t]),
+                                                                     _c_float_p, _c_float_p, ctypes.c_int, _stream_t]),
     "cocos_f16_plane_block_mask": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p, _stream_t]),
     "cocos_split_f16_ex": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5
                            + [ctypes.c_float, _c_float_p, _c_float_p, _stream_t]),
@@ -112,7 +112,7 @@ _SIGNATURES = {
                                                    + [ctypes.c_void_p] * 4 + [_c_float_p] * 3 + [ctypes.c_void_p]
                                                    + [ctypes.c_int] * 6
                                                    + [ctypes.c_float, ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_int,
-                                                      _c_float_p, _c_float_p, _c_float_p, _stream_t]),
+                                                      _c_float_p, _c_float_p, _c_float_p, ctypes.c_int, _stream_t]),
     "cocos_rowdot_f64": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 3 + [_stream_t]),
     "cocos_box3_fused_supported": (ctypes.c_int, [ctypes.c_int] * 5),
     "cocos_box3_corr_xbox_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 4 + [_c_float_p] + [ctypes.c_int] * 5

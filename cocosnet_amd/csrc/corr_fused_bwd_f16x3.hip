@@ -89,15 +89,15 @@ struct DsRegs {
     _Float16* __restrict__ dsl, _Float16* __restrict__ psh, _Float16* __restrict__ psl, const float* __restrict__ v_amax, \
     const float* __restrict__ v_scale, float* __restrict__ ds_scale_out, const unsigned* __restrict__ v_lo_mask, int B, \
     int Nq, int Nk, int Cv, float inv_t, float k_scale, float q_scale, const float* __restrict__ rowstat, \
-    const float* __restrict__ mtile, const float* __restrict__ d_pre
+    const float* __restrict__ mtile, const float* __restrict__ d_pre, int kblocks
 #define COCOS_BQ_ARGS \
     kch, kcl, vph, vpl, gph, gpl, g_scale, outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, \
-    v_lo_mask, B, Nq, Nk, Cv, inv_t, k_scale, q_scale, rowstat, mtile, d_pre
+    v_lo_mask, B, Nq, Nk, Cv, inv_t, k_scale, q_scale, rowstat, mtile, d_pre, kblocks
 
 // RAWM: the magnitude-free flavour (see corr_fused_fwd_f16x3.hip) — P = 2^((s_rel + (m_tile - m)) * scale - r) from the forward's
 // RELATIVE saved logits, its per-tile reference m_tile and its per-row (m in raw-accumulator units, r = log2 l - bias) instead
 // of from absolute logits and the row LSE: exact differences at any |logit|.
-template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED, bool VLO0, bool BLK, bool RAWM = false>
+template <int CVB, bool STORE_DS, bool STORE_P, bool RAGGED, bool VLO0, bool BLK, bool RAWM = false, int KBA = BQH_KD / 32>
 __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     const _Float16* __restrict__ kch, const _Float16* __restrict__ kcl,   // [B,256,Nk] planes of k_scale*kn
     const _Float16* __restrict__ vph, const _Float16* __restrict__ vpl,   // [B,Nk,CVP] planes of s_v*v
@@ -116,7 +116,12 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     forward multiplied them with: raw logits = q_scale * k_scale * <q, k> */,
     const float* __restrict__ rowstat /* RAWM: [B][3][Nq] as written by the forward */,
     const float* __restrict__ mtile /* RAWM: [B][ntiles][2][Nq] as written by the forward */,
-    const float* __restrict__ d_pre /* nullable: D = sum_c dout * out per query [B][Nq] (cocos_rowdot_f64) */) {
+    const float* __restrict__ d_pre /* nullable: D = sum_c dout * out per query [B][Nq] (cocos_rowdot_f64) */,
+    int /* kblocks: the kernel picks KBA from it */) {
+    // KBA (RAWM): 32-channel blocks of k that hold non-zero channels — the others are the zero padding of the Attention block's
+    // K = C/8 channels: their dqn MFMAs, fragment reads and key-tile fetches do not exist in the KBA = 1 / 2 instantiations
+    // (compile-time, like KST of the forward: run-time branches in the MFMA loop cost more than they save).
+    static_assert(KBA >= 1 && KBA <= BQH_KD / 32 && (RAWM || KBA == BQH_KD / 32), "KBA < 8 belongs to the magnitude-free flavour");
     constexpr int CVP = CVB * 32;
     constexpr int CVS = CVP / 16;                     // k-steps of the dP product
     constexpr int KB = BQH_KD / 32;                   // channel blocks of dqn
@@ -300,7 +305,8 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int g = u * 256 + tid, row = g >> 2, k8 = g & 3, kq = 2 * k8;
-        k_voff[u] = (unsigned)(row * Nk + 8 * k8) * 2u;
+        // (RAWM: rows of zero-padding channels are not fetched — out-of-range lanes return the zeros that are there anyway)
+        k_voff[u] = (row >= KBA * 32) ? kBufOob : (unsigned)(row * Nk + 8 * k8) * 2u;
         k_lds[u] = row * BQH_KROW + 16 * (kq >> 2) + 4 * ((kq >> 1) & 1);
     }
     // logits of tile tt (clamped to the last tile: look-ahead loads past the end are harmless re-reads),
@@ -529,9 +535,11 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
                 a_h[nxt] = *reinterpret_cast<const f16x8*>(kb0 + k2 * 32 * BQH_KROW + t2 * 16);
                 a_l[nxt] = *reinterpret_cast<const f16x8*>(kb0 + KPLANE + k2 * 32 * BQH_KROW + t2 * 16);
             }
-            dx[kb] = bq_mfma(a_h[cur_], sh[tt], dx[kb]);
-            dx[kb] = bq_mfma(a_h[cur_], sl[tt], dx[kb]);
-            dx[kb] = bq_mfma(a_l[cur_], sh[tt], dx[kb]);
+            if (kb < KBA) {      // (a compile-time fact after unrolling)
+                dx[kb] = bq_mfma(a_h[cur_], sh[tt], dx[kb]);
+                dx[kb] = bq_mfma(a_h[cur_], sl[tt], dx[kb]);
+                dx[kb] = bq_mfma(a_l[cur_], sh[tt], dx[kb]);
+            }
             if (WITH_VALU && i + LEAD < 16) slice(i + LEAD);
             if (STAGE_K && (i & 1) == 0) stage_piece(2 * VPT + (i >> 1), t + 1, t, false_type{});
             if (WITH_VALU && i == 2 * KB - 1) prefetch_v(t + 1);         // first fragments of the next iteration's dP'
@@ -636,7 +644,7 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
         const float undo = 1.0f / (k_scale * s_ov * ds_shift);
         float* dx_b = dqn + (size_t)b * BQH_KD * Nq;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int kb = 0; kb < KBA; ++kb)      // (KBA < 8: the rows of the padding channels are not written — dqn's real rows are a view)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = kb * 32 + acc_row_base(r) + 4 * h;
@@ -661,9 +669,15 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(COCOS_BQ_P
         else
             corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK>(COCOS_BQ_ARGS);
     } else {
-        if (rowstat)             // the magnitude-free flavour: (m, r) per row from the forward
-            corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK, true>(COCOS_BQ_ARGS);
-        else
+        if (rowstat) {           // the magnitude-free flavour: (m, r) per row from the forward
+            if constexpr (RAGGED || !BLK) {        // (odd shapes: the general instantiation only)
+                corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK, true>(COCOS_BQ_ARGS);
+            } else {
+                if (kblocks <= 1) corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK, true, 1>(COCOS_BQ_ARGS);
+                else if (kblocks <= 2) corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK, true, 2>(COCOS_BQ_ARGS);
+                else corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK, true>(COCOS_BQ_ARGS);
+            }
+        } else
             corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK>(COCOS_BQ_ARGS);
     }
 }
@@ -675,7 +689,7 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                            _Float16* dsl, _Float16* psh, _Float16* psl, const float* v_amax, const float* v_scale,
                            float* ds_scale_out, const unsigned* v_lo_mask, int B, int Nq, int Nk, int Cv, float inv_t,
                            float k_scale, int blocked, const float* qsd, const float* ksd, const float* rowstat,
-                           const float* mtile, const float* d_pre, hipStream_t s) {
+                           const float* mtile, const float* d_pre, int kblocks, hipStream_t s) {
     const bool ragged = (Nk % 32) != 0, store = dsh != nullptr, storep = psh != nullptr;
     const size_t smem = ((size_t)2 * 2 * (32 * (CVB * 32 + 8) + BQH_KD * BQH_KROW) + 4 * 2 * 32 * 32) * sizeof(_Float16);
     const int nqb = (Nq + 127) / 128;
@@ -690,7 +704,7 @@ static int launch_bq_f16x3(const _Float16* kch, const _Float16* kcl, const _Floa
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));        \
         hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, s, kch, kcl, vph, vpl, gph, gpl, g_scale,   \
                            outp, dout, lse, lg, dqn, dsh, dsl, psh, psl, v_amax, v_scale, ds_scale_out, MASK, B, Nq, \
-                           Nk, Cv, inv_t, k_scale, k_scale, rowstat, mtile, d_pre, qsd, ksd);                \
+                           Nk, Cv, inv_t, k_scale, k_scale, rowstat, mtile, d_pre, kblocks, qsd, ksd);       \
     } while (0)
     /* blocked planes ([query][key] blocks, see the kernel) only exist for whole tiles */
 #define COCOS_GO3(DS, SP, RG, VL, MASK)                                                                      \
@@ -739,7 +753,7 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3(
     return cocos_corr_softmax_warp_bwd_query_f16x3_ex(kch, kcl, vph, vpl, gph, gpl, g_scale_dev, out, dout, lse, saved_logits, dqn, dsh,
                                                       dsl, psh, psl, v_amax_dev, v_scale_dev, ds_scale_out_dev, v_lo_mask_dev, B, K, Nq,
                                                       Nk, Cv, CvPad, inv_temperature, k_scale, q_scale_dev, k_scale_dev, planes_blocked,
-                                                      nullptr, nullptr, nullptr, stream);
+                                                      nullptr, nullptr, nullptr, 0, stream);
 }
 
 namespace cocos {
@@ -794,8 +808,11 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3_ex(
     float* dqn, void* dsh, void* dsl, void* psh, void* psl, const float* v_amax_dev, const float* v_scale_dev,
     float* ds_scale_out_dev, const unsigned* v_lo_mask_dev, int B, int K, int Nq, int Nk, int Cv, int CvPad,
     float inv_temperature, float k_scale, const float* q_scale_dev, const float* k_scale_dev, int planes_blocked,
-    const float* rowstat, const float* mtile, const float* d_pre, cocos_stream_t stream) {
+    const float* rowstat, const float* mtile, const float* d_pre, int k_active, cocos_stream_t stream) {
     using namespace cocos;
+    COCOS_REQUIRE(k_active >= 0 && k_active <= K && (k_active == 0 || k_active == K || rowstat), COCOS_ERR_INVALID,
+                  "corr_softmax_warp_bwd_query_f16x3: k_active=%d (channels >= k_active are zero in k) belongs to the magnitude-free flavour", k_active);
+    const int kblocks = k_active ? (k_active + 31) / 32 : BQH_KD / 32;
     COCOS_REQUIRE((rowstat == nullptr) == (mtile == nullptr) && (!rowstat || (q_scale_dev && !v_lo_mask_dev)), COCOS_ERR_INVALID,
                   "corr_softmax_warp_bwd_query_f16x3: rowstat + mtile come as a pair and belong to the magnitude-free flavour "
                   "(device-side operand scales, no lo mask)");
@@ -831,7 +848,7 @@ extern "C" int cocos_corr_softmax_warp_bwd_query_f16x3_ex(
         g_scale_dev, out, dout, lse, static_cast<const float*>(saved_logits), dqn, static_cast<_Float16*>(dsh),  \
         static_cast<_Float16*>(dsl), static_cast<_Float16*>(psh), static_cast<_Float16*>(psl), v_amax_dev,      \
         v_scale_dev, ds_scale_out_dev, v_lo_mask_dev, B, Nq, Nk, Cv, inv_temperature, k_scale, planes_blocked, q_scale_dev, \
-        k_scale_dev, rowstat, mtile, d_pre, s
+        k_scale_dev, rowstat, mtile, d_pre, kblocks, s
     switch (cvb) {
         case 1: return launch_bq_f16x3<1>(COCOS_ARGS);
         case 2: return launch_bq_f16x3<2>(COCOS_ARGS);

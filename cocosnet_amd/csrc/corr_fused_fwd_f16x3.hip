@@ -106,7 +106,7 @@ __device__ long long g_phase_fwd_h[8];
 // difference is taken between s * scale and a ROUNDED m * scale: at |logit| ~ 1e10 (a randomly initialised SPADE generator's
 // Attention block: theta ~ 4e5) one ulp is ~700 in the exponent — p overflowed f16 or vanished and the output was NaN.
 // Same instruction count per element; extra work only where m changes (rare) and in the training forward's logits store.
-template <int CVB, bool STORE_S, bool RAGGED, bool VLO0, bool RAWM = false>
+template <int CVB, bool STORE_S, bool RAGGED, bool VLO0, bool RAWM = false, int KST = SP_KD / 16>
 __device__ __forceinline__ void corr_fwd_f16x3_body(
     const _Float16* __restrict__ qh, const _Float16* __restrict__ ql, const _Float16* __restrict__ kh,
     const _Float16* __restrict__ kl, const _Float16* __restrict__ vh, const _Float16* __restrict__ vl,
@@ -114,6 +114,11 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
     const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2 /* inv_temperature * log2(e) / (q_scale * k_scale) */,
     float* __restrict__ rowstat = nullptr /* RAWM: [B][3][Nq] = (m_hi, m_lo in raw units, log2 l - bias) for the backward; nullable */,
     float* __restrict__ mtile = nullptr /* RAWM + STORE_S: [B][Nk/32 tiles][2][Nq] = (m_hi, m_lo) when the tile's logits were stored */) {
+    // KST (RAWM): 16-channel steps that hold non-zero channels — the Attention block's K = C/8 = 32 or 64 channels sit zero-padded
+    // in 256-channel planes; the QK MFMAs, fragment reads and key-tile fetches of the all-padding steps do not exist in the
+    // KST = 2 / 4 instantiations.  (A run-time step count was tried first: 48 scalar branches per tile cost more than the MFMAs
+    // they skipped — QK phase 3250 cycles per tile against 2320 without them, tools/phase_timing_attention.py.)
+    static_assert(KST >= 1 && KST <= SP_KD / 16 && (RAWM || KST == SP_KD / 16), "KST < 16 belongs to the magnitude-free flavour");
     constexpr int CVP = CVB * 32;
     constexpr int KPLANE = SP_BK * SP_KROW;          // halfs per K plane per buffer
     constexpr int VPLANE = CVP * SP_VROW;
@@ -232,7 +237,9 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int g = u * 256 + tid, key = g >> 5, cc = g & 31;
-        k_voff[u] = (unsigned)(key * SP_KD + cc * 8) * 2u;
+        // (RAWM: chunks that hold only zero-padding channels are not fetched at all — an out-of-range lane costs no memory
+        //  access and returns the zeros that are there anyway: 8x less L2 traffic and footprint for the Attention block's K = 32)
+        k_voff[u] = (cc * 8 >= KST * 16) ? kBufOob : (unsigned)(key * SP_KD + cc * 8) * 2u;
         k_lds[u] = key * SP_KROW + cc * 8;
     }
 #pragma unroll
@@ -279,7 +286,7 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
     auto prefetch_k = [&](int buf) {
         const _Float16* kb = kt + buf * 2 * KPLANE + c * SP_KROW + h * 8;
 #pragma unroll
-        for (int s = 0; s < RA - 1; ++s) {
+        for (int s = 0; s < (RA - 1 < KST ? RA - 1 : KST); ++s) {
             ah[s] = *reinterpret_cast<const f16x8*>(kb + s * 16);
             al[s] = *reinterpret_cast<const f16x8*>(kb + KPLANE + s * 16);
         }
@@ -354,13 +361,14 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int cur = s % RA;
-                sa = mfma16h(ah[cur], qhr[s], sa);
-                if (!(COCOS_ABLATE & 2) && s + RA - 1 < NS) ah[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + (s + RA - 1) * 16);
+                const bool live = s < KST;      // (a compile-time fact after unrolling)
+                if (live) sa = mfma16h(ah[cur], qhr[s], sa);
+                if (!(COCOS_ABLATE & 2) && s + RA - 1 < KST) ah[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + (s + RA - 1) * 16);
                 __builtin_amdgcn_sched_barrier(0);
-                sb = mfma16h(ah[cur], qlr[s], sb);
-                if (!(COCOS_ABLATE & 2) && s + RA - 1 < NS) al[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + KPLANE + (s + RA - 1) * 16);
+                if (live) sb = mfma16h(ah[cur], qlr[s], sb);
+                if (!(COCOS_ABLATE & 2) && s + RA - 1 < KST) al[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + KPLANE + (s + RA - 1) * 16);
                 __builtin_amdgcn_sched_barrier(0);
-                sc = mfma16h(al[cur], qhr[s], sc);
+                if (live) sc = mfma16h(al[cur], qhr[s], sc);
                 if ((s & 1) == 0) piece(s >> 1, std::false_type{});   // the 8 key-tile pieces, every other step
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
     float* __restrict__ out, float* __restrict__ lse, float* __restrict__ lg, const float* __restrict__ v_scale,
     const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2,
     const float* __restrict__ q_scale_dev, const float* __restrict__ k_scale_dev, float* __restrict__ rowstat,
-    float* __restrict__ mtile) {
+    float* __restrict__ mtile, int ksteps) {
     // operands without an a-priori magnitude (ops.softmax_attention: the reference's Attention block feeds raw 1x1-conv
     // outputs): their planes carry device-side power-of-two scales; scale_log2 then arrives WITHOUT the 1 / (q_scale k_scale)
     if (q_scale_dev) scale_log2 = scale_log2 / (*q_scale_dev * *k_scale_dev);
@@ -543,10 +551,18 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
         else
             corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, false>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk, Cv, scale_log2);
     } else {
-        if (q_scale_dev)          // the magnitude-free flavour (host side: no lo mask together with device-side operand scales)
-            corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, false, true>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk,
-                                                                   Cv, scale_log2, rowstat, mtile);
-        else
+        if (q_scale_dev) {        // the magnitude-free flavour (host side: no lo mask together with device-side operand scales)
+#define COCOS_RAWM_BODY(KST_) corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, false, true, KST_>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, \
+                                                                                           v_lo_mask, B, Nq, Nk, Cv, scale_log2, rowstat, mtile)
+            if constexpr (RAGGED) {      // (odd key counts: the general instantiation only)
+                COCOS_RAWM_BODY(SP_KD / 16);
+            } else {
+                if (ksteps <= 2) COCOS_RAWM_BODY(2);
+                else if (ksteps <= 4) COCOS_RAWM_BODY(4);
+                else COCOS_RAWM_BODY(SP_KD / 16);
+            }
+#undef COCOS_RAWM_BODY
+        } else
             corr_fwd_f16x3_body<CVB, STORE_S, RAGGED, false>(qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale, v_lo_mask, B, Nq, Nk, Cv, scale_log2);
     }
 }
@@ -555,14 +571,14 @@ template <int CVB, bool STORE_S, bool RAGGED, bool VLO0>
 static int launch_f16x3_k(const _Float16* qh, const _Float16* ql, const _Float16* kh, const _Float16* kl,
                           const _Float16* vh, const _Float16* vl, float* out, float* lse, float* lg,
                           const float* v_scale, const unsigned* v_lo_mask, int B, int Nq, int Nk, int Cv, float scale_log2,
-                          const float* qsd, const float* ksd, float* rowstat, float* mtile, hipStream_t stream) {
+                          const float* qsd, const float* ksd, float* rowstat, float* mtile, int ksteps, hipStream_t stream) {
     auto kern = corr_fwd_f16x3_kernel<CVB, STORE_S, RAGGED, VLO0>;
     const size_t smem = (size_t)2 * (2 * SP_BK * SP_KROW + 3 * CVB * 32 * SP_VROW) * sizeof(_Float16);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     const int nqb = (Nq + SP_BQ - 1) / SP_BQ;
     hipLaunchKernelGGL(kern, dim3(B * nqb), dim3(256), smem, stream, qh, ql, kh, kl, vh, vl, out, lse, lg, v_scale,
-                       v_lo_mask, B, Nq, Nk, Cv, scale_log2, qsd, ksd, rowstat, mtile);
+                       v_lo_mask, B, Nq, Nk, Cv, scale_log2, qsd, ksd, rowstat, mtile, ksteps);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -605,7 +621,7 @@ extern "C" int cocos_corr_softmax_warp_fwd_f16x3(const void* qh, const void* ql,
                                                  float operand_scale, const float* q_scale_dev, const float* k_scale_dev,
                                                  cocos_stream_t stream) {
     return cocos_corr_softmax_warp_fwd_f16x3_ex(qh, ql, kh, kl, vh, vl, out, lse, saved_logits, v_scale_dev, v_lo_mask_dev, B, K, Nq,
-                                                Nk, Cv, inv_temperature, operand_scale, q_scale_dev, k_scale_dev, nullptr, nullptr, stream);
+                                                Nk, Cv, inv_temperature, operand_scale, q_scale_dev, k_scale_dev, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int cocos_corr_softmax_warp_fwd_f16x3_ex(const void* qh, const void* ql, const void* kh,
@@ -614,8 +630,11 @@ extern "C" int cocos_corr_softmax_warp_fwd_f16x3_ex(const void* qh, const void* 
                                                     const unsigned* v_lo_mask_dev, int B,
                                                     int K, int Nq, int Nk, int Cv, float inv_temperature,
                                                     float operand_scale, const float* q_scale_dev, const float* k_scale_dev,
-                                                    float* rowstat_out, float* mtile_out, cocos_stream_t stream) {
+                                                    float* rowstat_out, float* mtile_out, int k_active, cocos_stream_t stream) {
     using namespace cocos;
+    COCOS_REQUIRE(k_active >= 0 && k_active <= K && (k_active == 0 || k_active == K || q_scale_dev), COCOS_ERR_INVALID,
+                  "corr_softmax_warp_fwd_f16x3: k_active=%d (channels >= k_active are zero in q and k) belongs to the magnitude-free flavour", k_active);
+    const int ksteps = k_active ? (k_active + 15) / 16 : SP_KD / 16;
     COCOS_REQUIRE(qh && ql && kh && kl && vh && vl && out && lse, COCOS_ERR_INVALID,
                   "corr_softmax_warp_fwd_f16x3: null pointer");
     COCOS_REQUIRE(!(q_scale_dev && v_lo_mask_dev), COCOS_ERR_INVALID,
@@ -655,7 +674,7 @@ extern "C" int cocos_corr_softmax_warp_fwd_f16x3_ex(const void* qh, const void* 
     // with a mask and more than one value block the kernel holds both flavours and picks one from the device-side mask
 #define COCOS_GO(CVB, ST, RG) \
     cocos_go_both<CVB, ST, RG>(a, b2, c2, d, e, f, out, lse, lgp, v_scale_dev, v_lo_mask_dev, B, Nq, Nk, Cv, scale_log2, \
-                               q_scale_dev, k_scale_dev, rowstat_out, mtile_out, s)
+                               q_scale_dev, k_scale_dev, rowstat_out, mtile_out, ksteps, s)
 #define COCOS_CVB(CVB)                                                           \
     case CVB:                                                                    \
         if (lgp) return ragged ? COCOS_GO(CVB, true, true) : COCOS_GO(CVB, true, false); \

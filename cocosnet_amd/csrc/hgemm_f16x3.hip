@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
     const int b = vb / (ntn * ntm), rem = vb % (ntn * ntm);
     const int m0 = (rem / ntn) * HG_BM, n0 = (rem % ntn) * HG_BN;
+    // ragged M (the Attention block's key-side GEMM has M = C/8 = 32..64 rows, its dv GEMM M = C/2): 32-row tiles of this wave
+    // that hold a real row; the MFMAs of the others are skipped (wave-uniform) — such a GEMM is then bound by its B stream
+    const int rows_live = EXACT ? 4 : max(0, min(4, (M - m0 - wm * 128 + 31) >> 5));
 
     const size_t abytes = (size_t)M * K * 2, bbytes = (size_t)N * K * 2;
     const __amdgpu_buffer_rsrc_t ah_rs = make_rsrc(ah + (size_t)b * M * K, abytes);
@@ -203,9 +206,11 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                 const f16x8 avl = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * HG_ROW + s * 16);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, bvh[j], acc[i][j], 0, 0, 0);
+                    if (EXACT || i < rows_live) {     // (ragged M: a wave-uniform branch around the MFMAs of all-padding row tiles)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, bvh[j], acc[i][j], 0, 0, 0);
+                    }
                     // 16 (s, i, j) slots per step, 12 pieces: k-block t+1 -> LDS[buf ^ 1] (released by the barrier
                     // that ended step t-1), k-block t+3 -> the freed registers
                     const int slot = (s * 4 + i) * 2 + j;

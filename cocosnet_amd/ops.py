@@ -374,6 +374,41 @@ def _split_bwd_ok(B, Nq, Nk, Cv):
     return Nk % 128 == 0 and Nq % 32 == 0 and Nq * _recompute_chunk(B, Nq, Nk) * 4 < 2 ** 31 - 1
 
 
+GEMM_SPLIT_K_BELOW = 200      # workgroups: a backward GEMM with fewer tiles than this splits its reduction (256 CUs to fill)
+
+
+def _hgemm_planes(timer, ah, al, bh, bl, out, M, n, Kred, host, dev1, dev2, bmode, st):
+    """out[b] (M x n) = A[b] (M x Kred) . B[b] (Kred x n) on the split GEMM (cocos_hgemm_f16x3), A = channel-major planes [B,M,Kred].
+    With [query][key]-blocked B planes (bmode 2) and too few 256 x 128 output tiles to fill the chip (the Attention block:
+    M = C/8 rows, B = 4 samples -> 128 workgroups on 256 CUs, each streaming all of Kred) the reduction is cut into S
+    contiguous slices that run as S * B "samples" (a slice of a blocked plane is contiguous, so only A is re-laid out) and the
+    S partial products are summed in a fixed order: deterministic."""
+    B = out.shape[0]
+    tiles = B * ((M + 255) // 256) * ((n + 127) // 128)
+    S = 1
+    while bmode == 2 and tiles * S < GEMM_SPLIT_K_BELOW and S < 8 and Kred % (64 * S) == 0:
+        S *= 2
+    if S == 1:
+        _call(timer, "cocos_hgemm_f16x3", ah.data_ptr(), al.data_ptr(), bh.data_ptr(), bl.data_ptr(), out.data_ptr(), B, M, n, Kred,
+              host, _ptr(dev1), _ptr(dev2), bmode, st)
+        return
+    a2h = ah.view(B, M, S, Kred // S).transpose(1, 2).contiguous()
+    a2l = al.view(B, M, S, Kred // S).transpose(1, 2).contiguous()
+    part = torch.empty((B, S, M, n), device=out.device, dtype=torch.float32)
+    _call(timer, "cocos_hgemm_f16x3", a2h.data_ptr(), a2l.data_ptr(), bh.data_ptr(), bl.data_ptr(), part.data_ptr(), B * S, M, n,
+          Kred // S, host, _ptr(dev1), _ptr(dev2), bmode, st)
+    torch.sum(part, dim=1, out=out)
+
+
+def _key_gemm(qch, qcl, dsh, dsl, dk, n, Nq, k_active, qks, ds_scale, gemm_b, st):
+    """dk[b] = (q_scale qn)[b] . dS''[b] on the split GEMM (K5's key side); qch / qcl / dk have the REAL channel count (the
+    magnitude-free flavour's K < 256: M = K rows, see _hgemm_planes for what that means for the launch)."""
+    K = dk.shape[1]
+    assert qch.shape[1] == K and (not k_active or k_active == K)
+    _hgemm_planes("corr_softmax_warp_bwd_key_from_ds", qch, qcl, dsh, dsl, dk, K, n, Nq, 1.0 if qks else 1.0 / SPLIT_OPERAND_SCALE,
+                  ds_scale, qks[0] if qks else None, gemm_b, st)
+
+
 class _CorrSoftmaxWarp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qn, kn, v, inv_temperature: float, keep_logits: bool, planes=None):
@@ -395,6 +430,8 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
         if planes is not None:       # split-precision flavour: same outputs, f16x3 matrix products
             qh, ql, kh, kl, vh, vl, v_scale, v_amax, v_lomask = planes[:9]
             qk_scales = planes[13] if len(planes) > 13 else None      # (q_scale, k_scale) device scalars, or None
+            ctx.k_active = planes[14] if len(planes) > 14 else 0     # K < 256 (magnitude-free flavour): planes zero-padded to 256
+            Kp = FUSED_K if ctx.k_active else K
             ctx.recompute = bool(keep_logits) and not _saves_logits(B, Nq, Nk)
             if keep_logits and not ctx.recompute:   # the forward's private tile-blocked layout (cocos_hip.h), opaque here
                 nbytes = _lib.load().cocos_corr_softmax_warp_saved_logits_bytes(B, Nq, Nk)
@@ -406,9 +443,9 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                          if (qk_scales and logits_t is not None) else None)
             _call("corr_softmax_warp_fwd", "cocos_corr_softmax_warp_fwd_f16x3_ex", qh.data_ptr(), ql.data_ptr(),
                   kh.data_ptr(), kl.data_ptr(), vh.data_ptr(), vl.data_ptr(), out.data_ptr(), lse.data_ptr(),
-                  _ptr(logits_t), v_scale.data_ptr(), _ptr(v_lomask), B, K, Nq, Nk, Cv, float(inv_temperature),
+                  _ptr(logits_t), v_scale.data_ptr(), _ptr(v_lomask), B, Kp, Nq, Nk, Cv, float(inv_temperature),
                   SPLIT_OPERAND_SCALE, _ptr(qk_scales[0] if qk_scales else None), _ptr(qk_scales[1] if qk_scales else None),
-                  _ptr(ctx.rowstat), _ptr(ctx.mtile), _stream())
+                  _ptr(ctx.rowstat), _ptr(ctx.mtile), ctx.k_active, _stream())
             ctx.v_amax = v_amax
             ctx.v_lomask = v_lomask
             ctx.qk_scales = qk_scales
@@ -463,7 +500,12 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             ds_scale = torch.empty(1, device=qn.device, dtype=torch.float32)
             blocked = int(Nk % 128 == 0 and Nq % 32 == 0)     # [query][key]-blocked dS'' / P planes (see cocos_hip.h)
             gemm_b = 2 * blocked                               # ... which the GEMM reads as b_blocked = 2
-            if dqn is None:          # the query kernel always accumulates dqn; scratch when nobody wants it
+            ka = getattr(ctx, "k_active", 0)
+            Kp = FUSED_K if ka else K
+            if ka:                   # the kernel writes all 256 channel rows (zeros past K): dqn is the view of the real ones
+                dqn_buf = torch.empty((B, Kp, Nq), device=qn.device, dtype=torch.float32)
+                dqn = dqn_buf[:, :K] if dqn is not None else None
+            elif dqn is None:        # the query kernel always accumulates dqn; scratch when nobody wants it
                 dqn_buf = torch.empty_like(qn)
             else:
                 dqn_buf = dqn
@@ -472,17 +514,14 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                   kcl.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(),
                   g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), logits_t.data_ptr(),
                   dqn_buf.data_ptr(), _ptr(dsh), _ptr(dsl), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
-                  v_scale.data_ptr(), ds_scale.data_ptr(), _ptr(ctx.v_lomask), B, K, Nq, Nk, Cv, cvp, ctx.inv_t,
+                  v_scale.data_ptr(), ds_scale.data_ptr(), _ptr(ctx.v_lomask), B, Kp, Nq, Nk, Cv, cvp, ctx.inv_t,
                   SPLIT_OPERAND_SCALE, _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked,
-                  _ptr(getattr(ctx, "rowstat", None)), _ptr(getattr(ctx, "mtile", None)), _ptr(d_pre), st)
+                  _ptr(getattr(ctx, "rowstat", None)), _ptr(getattr(ctx, "mtile", None)), _ptr(d_pre), ka, st)
             if want_k:    # A = the channel-major planes of q_scale * qn
-                _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(),
-                      dsh.data_ptr(), dsl.data_ptr(), dkn.data_ptr(), B, K, Nk, Nq, 1.0 if qks else 1.0 / SPLIT_OPERAND_SCALE,
-                      ds_scale.data_ptr(), _ptr(qks[0] if qks else None), gemm_b, st)
+                _key_gemm(qch, qcl, dsh, dsl, dkn, Nk, Nq, ka, qks, ds_scale, gemm_b, st)
             if dv is not None:      # dv[c,j] = sum_i dout[c,i] P[i,j]
                 gch, gcl, _ = split_f16(dout, False, amax=g_amax)
-                _call("corr_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(),
-                      psl.data_ptr(), dv.data_ptr(), B, Cv, Nk, Nq, 1.0 / 16384.0, g_scale.data_ptr(), 0, gemm_b, st)
+                _hgemm_planes("corr_softmax_warp_bwd_dv", gch, gcl, psh, psl, dv, Cv, Nk, Nq, 1.0 / 16384.0, g_scale, None, gemm_b, st)
             return dqn, (dkn if need_k else None), dv, None, None, None
         # key side: GEMM over a materialised dS^T when it pays and fits (see cocos_hip.h), else the
         # flash-style kernel that recomputes the logits (always when dv is wanted: it needs P)
@@ -540,6 +579,8 @@ def _corr_bwd_recompute(ctx, qn, kn, v, out, lse, dout, dqn, dkn, dv, need_k):
     kc = _recompute_chunk(B, Nq, Nk)
     ds_scale = torch.empty(1, device=dev, dtype=torch.float32)
     d_pre = _rowdot(dout, out) if BWD_D_PRECOMPUTED else None
+    ka = getattr(ctx, "k_active", 0)
+    Kp = FUSED_K if ka else K        # (K < 256, magnitude-free flavour: the planes are zero-padded to the kernels' 256 channels)
     dq_acc = None
     # scratch shared by the chunks (sized for a full chunk)
     o1 = torch.empty((B, 1, Nq), device=dev, dtype=torch.float32)
@@ -552,8 +593,8 @@ def _corr_bwd_recompute(ctx, qn, kn, v, out, lse, dout, dqn, dkn, dv, need_k):
         rowstat = getattr(ctx, "rowstat", None)           # magnitude-free flavour: relative logits + their per-tile reference
         mt = torch.empty((B, (n + 31) // 32, 2, Nq), device=dev, dtype=torch.float32) if rowstat is not None else None
         _call("corr_softmax_warp_recompute", "cocos_corr_softmax_warp_fwd_f16x3_ex", qh.data_ptr(), ql.data_ptr(), khc.data_ptr(),
-              klc.data_ptr(), vz.data_ptr(), vz.data_ptr(), o1.data_ptr(), l1.data_ptr(), lg.data_ptr(), None, None, B, K, Nq, n, 1,
-              ctx.inv_t, SPLIT_OPERAND_SCALE, _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), None, _ptr(mt), st)
+              klc.data_ptr(), vz.data_ptr(), vz.data_ptr(), o1.data_ptr(), l1.data_ptr(), lg.data_ptr(), None, None, B, Kp, Nq, n, 1,
+              ctx.inv_t, SPLIT_OPERAND_SCALE, _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), None, _ptr(mt), ka, st)
         kchc, kclc = kch[:, :, k0:k0 + n].contiguous(), kcl[:, :, k0:k0 + n].contiguous()
         vphc, vplc = vph[:, k0:k0 + n].contiguous(), vpl[:, k0:k0 + n].contiguous()
         dsh = dsl = psh = psl = None
@@ -562,25 +603,24 @@ def _corr_bwd_recompute(ctx, qn, kn, v, out, lse, dout, dqn, dkn, dv, need_k):
         if dv is not None:
             psh, psl = torch.empty((B, n, Nq), **half), torch.empty((B, n, Nq), **half)
         blocked = int(n % 128 == 0 and Nq % 32 == 0)
-        dq_c = torch.empty_like(qn)
+        dq_c = torch.empty((B, Kp, Nq), device=dev, dtype=torch.float32)
         _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3_ex", kchc.data_ptr(), kclc.data_ptr(),
               vphc.data_ptr(), vplc.data_ptr(), gph.data_ptr(), gpl.data_ptr(), g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(),
               lse.data_ptr(), lg.data_ptr(), dq_c.data_ptr(), _ptr(dsh), _ptr(dsl), _ptr(psh), _ptr(psl), v_amax.data_ptr(),
-              v_scale.data_ptr(), ds_scale.data_ptr(), _ptr(ctx.v_lomask), B, K, Nq, n, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE,
-              _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked, _ptr(rowstat), _ptr(mt), _ptr(d_pre), st)
+              v_scale.data_ptr(), ds_scale.data_ptr(), _ptr(ctx.v_lomask), B, Kp, Nq, n, Cv, cvp, ctx.inv_t, SPLIT_OPERAND_SCALE,
+              _ptr(qks[0] if qks else None), _ptr(qks[1] if qks else None), blocked, _ptr(rowstat), _ptr(mt), _ptr(d_pre), ka, st)
         del lg
+        if ka:                   # (only the real rows are written, see cocos_hip.h)
+            dq_c = dq_c[:, :K]
         dq_acc = dq_c if dq_acc is None else dq_acc.add_(dq_c)
         if want_k:
             dk_c = dkn if n == Nk else torch.empty((B, K, n), device=dev, dtype=torch.float32)
-            _call("corr_softmax_warp_bwd_key_from_ds", "cocos_hgemm_f16x3", qch.data_ptr(), qcl.data_ptr(), dsh.data_ptr(),
-                  dsl.data_ptr(), dk_c.data_ptr(), B, K, n, Nq, 1.0 if qks else 1.0 / SPLIT_OPERAND_SCALE, ds_scale.data_ptr(),
-                  _ptr(qks[0] if qks else None), 2 * blocked, st)
+            _key_gemm(qch, qcl, dsh, dsl, dk_c, n, Nq, ka, qks, ds_scale, 2 * blocked, st)
             if dk_c is not dkn:
                 dkn[:, :, k0:k0 + n] = dk_c
         if dv is not None:
             dv_c = dv if n == Nk else torch.empty((B, Cv, n), device=dev, dtype=torch.float32)
-            _call("corr_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(), psl.data_ptr(),
-                  dv_c.data_ptr(), B, Cv, n, Nq, 1.0 / 16384.0, g_scale.data_ptr(), 0, 2 * blocked, st)
+            _hgemm_planes("corr_softmax_warp_bwd_dv", gch, gcl, psh, psl, dv_c, Cv, n, Nq, 1.0 / 16384.0, g_scale, None, 2 * blocked, st)
             if dv_c is not dv:
                 dv[:, :, k0:k0 + n] = dv_c
     if dqn is not None:
@@ -614,7 +654,9 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes |
     OperandPlanes (theta/phi planes shared by several launches); None = made for this call only.  `operand_amax`: qn / kn
     are NOT unit-norm columns (softmax_attention): their planes get device-side power-of-two scales from max|.| instead of
     the fixed SPLIT_OPERAND_SCALE (split flavour only; raises if this shape cannot take it).  `precision`: overrides the
-    module-level PRECISION for this call (a per-call argument, not a global: threads do not see each other's choice)."""
+    module-level PRECISION for this call (a per-call argument, not a global: threads do not see each other's choice).
+    With operand_amax K may be < 256 (softmax_attention: K = C/8): the planes are zero-padded and the kernels' K = 32 / 64
+    instantiations skip the matrix steps, fragment reads and fetches of the padding."""
     B, K, Nq = qn.shape
     Nk, Cv = kn.shape[2], v.shape[1]
     keep = _wants_logits(qn, kn)
@@ -624,7 +666,7 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes |
     chunk = min(Cv, MAX_FUSED_SPLIT_CV)
     # the split flavour saves its logits in a private layout only its own backward reads: a training pass takes it
     # only for shapes that backward takes too (otherwise the exact-fp32 kernels run, forward and backward)
-    split = (prec == "f16x3" and K == FUSED_K and Nk % 4 == 0
+    split = (prec == "f16x3" and (K == FUSED_K or (operand_amax and K < FUSED_K)) and Nk % 4 == 0
              and (not keep or _split_bwd_ok(B, Nq, Nk, chunk)))
     if planes is None:
         planes = OperandPlanes()
@@ -633,6 +675,28 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes |
     if not split and (planes.has(qn) or planes.has(kn)):
         raise _lib.CocosHipError("corr_softmax_warp: qn / kn exist as operand planes only (center_l2norm_planes) but this "
                                  "shape does not take the split-precision kernels")
+
+    qk_made = []
+
+    def qk_planes():
+        # the magnitude-free flavour's q / k planes, once per call (the value chunks share them).  K <= 256 real channels:
+        # the position-major planes the forward multiplies are written zero-padded to 256 by the split kernel itself; of the
+        # channel-major ones (backward) q's keep the real K rows (the key-side GEMM's M) and k's are padded (the query
+        # kernel stages 256-row tiles, fetching only the real rows)
+        if not qk_made:
+            qa, ka_ = absmax(qn), absmax(kn)
+            qh, ql, qs = split_f16(qn, True, cpad=FUSED_K, amax=qa)
+            kh, kl, ks = split_f16(kn, True, cpad=FUSED_K, amax=ka_)
+            cpl = (None,) * 4
+            if keep:
+                qch, qcl, _ = split_f16(qn, False, amax=qa)
+                kch, kcl, _ = split_f16(kn, False, amax=ka_)
+                if K < FUSED_K:
+                    pad = lambda t: torch.cat([t, t.new_zeros((B, FUSED_K - K, Nk))], dim=1)
+                    kch, kcl = pad(kch), pad(kcl)
+                cpl = (qch, qcl, kch, kcl)
+            qk_made.append((qh, ql, kh, kl, *cpl, (qs, ks), K if K < FUSED_K else 0))
+        return qk_made[0]
 
     def run(vv):
         pl = None
@@ -648,11 +712,7 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes |
                 # (the magnitude-free flavour — operand_amax — takes no lo mask: its kernels are the single-flavour instantiations)
                 vh, vl, v_scale, v_lomask = split_f16_chan_mask(vv, v_amax, VALUE_LO_SKIP and vv.shape[1] > 32 and not operand_amax)
                 if operand_amax:
-                    qh, ql, qs = planes.get_scaled(qn, True)
-                    kh, kl, ks = planes.get_scaled(kn, True)
-                    pl = (qh, ql, kh, kl, vh, vl, v_scale, v_amax, v_lomask)
-                    cpl = (*planes.get_scaled(qn, False)[:2], *planes.get_scaled(kn, False)[:2]) if keep else (None,) * 4
-                    pl += cpl + ((qs, ks),)
+                    pl = (*qk_planes()[:4], vh, vl, v_scale, v_amax, v_lomask, *qk_planes()[4:])
                 else:
                     pl = (*planes.get(qn, True, SPLIT_OPERAND_SCALE), *planes.get(kn, True, SPLIT_OPERAND_SCALE),
                           vh, vl, v_scale, v_amax, v_lomask)
@@ -1943,18 +2003,17 @@ def softmax_attention(q, k, v, scale: float = 1.0):
 
     K <= 256 on the split flavour: the FUSED kernels (K2) — nothing HWxHW is materialised in inference, training keeps the
     saved logits like the correspondence itself.  q / k are raw 1x1-conv outputs here, not unit-norm columns: their operand
-    planes get device-side power-of-two scales from max|q|, max|k| (no fixed 2^4: ADVICE r2), and K < 256 is zero-padded to
-    the 256 channels the kernels are specialised for (the padded products are zeros: exact; 256 / K of the QK^T matrix work
-    is spent on them — still ~1.5x faster than the materialised route at the reference's shape and 4x less memory, see
+    planes get device-side power-of-two scales from max|q|, max|k| (no fixed 2^4: ADVICE r2) and the kernels run in their
+    magnitude-free flavour (exact exponent differences at any |logit|).  K < 256 sits zero-padded in the 256-channel planes
+    the kernels are built for, and their K = 32 / K = 64 instantiations leave out the matrix steps, fragment reads and
+    fetches of the padding; the two backward GEMMs (M = K resp. Cv rows: too few tiles for 256 CUs) split their reduction.
+    netG's shape (B=4, K=32, 128x128 queries, 64x64 keys, Cv=128): 2.2 ms fwd+bwd against 6.3 ms materialised (round 3: 3.0;
     tools/attention_bench.py).  Everything else: the materialised family on the same MFMA GEMMs (K3 -> K4 -> K5)."""
     B, K, Nq = q.shape
     Nk = k.shape[2]
     keep = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)
     if (ATTENTION_FUSED and K <= FUSED_K and q.is_cuda and q.dtype == torch.float32
             and corr_split_ok(B, FUSED_K, Nq, Nk, v.shape[1], keep)):
-        if K < FUSED_K:      # zero channels: autograd slices the gradient back
-            q = torch.nn.functional.pad(q, (0, 0, 0, FUSED_K - K))
-            k = torch.nn.functional.pad(k, (0, 0, 0, FUSED_K - K))
         return corr_softmax_warp(q, k, v, scale, operand_amax=True)
     if K == FUSED_K and q.is_cuda and q.dtype == torch.float32:
         # the split path is not available (COCOS_PRECISION=fp32, odd Nq / Nk): K = 256 still takes the FUSED exact-fp32

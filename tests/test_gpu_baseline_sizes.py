@@ -212,7 +212,8 @@ def test_config5_hw16384_sampled_rows_and_key_side_vs_recompute(monkeypatch):
             assert rel(res[name][0][b][:, idx], o_ref) < TOL, (name, b)
             assert rel(res[name][1][b][:, idx], dq_ref) < TOL, (name, b)
     assert rel(res["split_saved"][2], f64(res["fp32_recompute"][2])) < TOL
-    assert rel(res["split_recompute"][2], f64(res["split_saved"][2])) < 1e-6     # the same dS'' per element: the same d kn
+    # the same dS'' per element; a chunk's key-side GEMM may split its reduction in two (ops._hgemm_planes): fp32 summation order
+    assert rel(res["split_recompute"][2], f64(res["split_saved"][2])) < 3e-6
     assert rel(res["split_recompute"][1], f64(res["split_saved"][1])) < 1e-5     # d qn: summed over the chunks in another order
     assert rel(res["split_saved"][0], f64(res["fp32_recompute"][0])) < 1e-4
 
@@ -641,6 +642,40 @@ def test_softmax_attention_takes_the_fused_kernels_for_small_k_and_any_operand_m
             assert torch.isfinite(o).all()
             assert rel(o, o_ref) < TOL, (qmag, fused)
             assert rel(qd.grad, dq_ref) < TOL and rel(kd.grad, dk_ref) < TOL and rel(vd.grad, dv_ref) < TOL, (qmag, fused)
+
+
+@pytest.mark.parametrize("K,Nq,Nk", [(8, 1024, 256), (32, 2048, 384), (48, 1024, 256), (64, 1024, 128), (100, 512, 256),
+                                     (128, 512, 256), (256, 512, 128), (32, 1000, 200), (64, 520, 36)])
+def test_softmax_attention_channel_counts_and_split_reductions(K, Nq, Nk, monkeypatch):
+    """Round 4: the fused attention op for every channel-count class — K <= 32 / K <= 64 (the kernels' instantiations without the
+    matrix steps, fragment reads and fetches of the zero padding; d q's padding rows are never written), 64 < K < 256 (general
+    instantiation on padded planes), K = 256 — on blocked shapes (Nk % 128 == 0, Nq % 32 == 0: the two backward GEMMs have
+    too few output tiles at B = 1 and split their reduction, ops._hgemm_planes) and on ragged ones.  Outputs and all three
+    gradients vs fp64."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    rs = np.random.RandomState(K + Nq)
+    B, Cv = 1, 70
+    q = rs.standard_normal((B, K, Nq)) * 1.5
+    k = rs.standard_normal((B, K, Nk))
+    v = rs.uniform(-1, 1, (B, Cv, Nk))
+    g = rs.standard_normal((B, Cv, Nq))
+    sc = 1.0 / np.sqrt(K)
+    f = np.einsum("bci,bcj->bij", q, k) * sc
+    p = co.softmax(f)
+    o_ref = np.einsum("bij,bcj->bci", p, v)
+    dp = np.einsum("bci,bcj->bij", g, v)
+    ds = p * (dp - (p * dp).sum(-1, keepdims=True)) * sc
+    dq_ref, dk_ref, dv_ref = np.einsum("bij,bcj->bci", ds, k), np.einsum("bij,bci->bcj", ds, q), np.einsum("bci,bij->bcj", g, p)
+    qd, kd, vd = dev(q, True), dev(k, True), dev(v, True)
+    with ops.KernelTimer() as kt:
+        o = ops.softmax_attention(qd, kd, vd, float(sc))
+        o.backward(dev(g))
+    if Nk % 8 == 0:      # (else: the split backward does not take the shape — the materialised family, same contract)
+        assert "corr_softmax_warp_fwd" in kt.summary() and "corr_softmax_warp_bwd_query" in kt.summary()
+    assert qd.grad.shape == qd.shape and kd.grad.shape == kd.shape
+    assert rel(o, o_ref) < TOL
+    assert rel(qd.grad, dq_ref) < TOL and rel(kd.grad, dk_ref) < TOL and rel(vd.grad, dv_ref) < TOL
 
 
 @pytest.mark.parametrize("qmag,kmag,vmag", [(4e5, 1.5e4, 1e4), (3e3, 2e3, 1.0), (40.0, 30.0, 5.0)])

@@ -20,7 +20,7 @@ def run(name, B, K, Nq, Nk, Cv, fused, steps=5):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    rec = {"shape": name, "route": "fused (K padded to 256)" if fused else "materialised", "ms_fwd_bwd": round(dt * 1e3, 3),
+    rec = {"shape": name, "route": "fused" if fused else "materialised", "ms_fwd_bwd": round(dt * 1e3, 3),
            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
     print(json.dumps(rec), flush=True)
     del q, k, v, go
@@ -36,11 +36,16 @@ q = torch.randn(4, 32, 16384, device="cuda", generator=g).requires_grad_(True)
 k = torch.randn(4, 32, 4096, device="cuda", generator=g).requires_grad_(True)
 v = torch.randn(4, 128, 4096, device="cuda", generator=g).requires_grad_(True)
 go = torch.randn(4, 128, 16384, device="cuda", generator=g)
-for _ in range(2):
+def step():
     q.grad = k.grad = v.grad = None
     ops.softmax_attention(q, k, v, 1.0).backward(go)
-with ops.KernelTimer() as kt:
-    for _ in range(3):
-        q.grad = k.grad = v.grad = None
-        ops.softmax_attention(q, k, v, 1.0).backward(go)
-print(json.dumps({t: round(r["total_ms"] / 3, 3) for t, r in kt.summary().items()}))
+def infer():
+    with torch.no_grad():
+        ops.softmax_attention(q, k, v, 1.0)
+for fn, tag in ((step, "train"), (infer, "inference")):
+    for _ in range(2):
+        fn()
+    with ops.KernelTimer() as kt:
+        for _ in range(3):
+            fn()
+    print(json.dumps({"pass": tag, **{t: round(r["total_ms"] / 3, 3) for t, r in kt.summary().items()}}))
