@@ -119,7 +119,7 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     const float* __restrict__ d_pre /* nullable: D = sum_c dout * out per query [B][Nq] (cocos_rowdot_f64) */,
     int /* kblocks: the kernel picks KBA from it */) {
     // KBA (RAWM): 32-channel blocks of k that hold non-zero channels — the others are the zero padding of the Attention block's
-    // K = C/8 channels: their dqn MFMAs, fragment reads and key-tile fetches do not exist in the KBA = 1 / 2 instantiations
+    // K = C/8 channels: their dqn MFMAs, fragment reads and key-tile fetches do not exist in the KBA = 1 / 2 / 4 instantiations (K <= 32 / 64 / 128)
     // (compile-time, like KST of the forward: run-time branches in the MFMA loop cost more than they save).
     static_assert(KBA >= 1 && KBA <= BQH_KD / 32 && (RAWM || KBA == BQH_KD / 32), "KBA < 8 belongs to the magnitude-free flavour");
     constexpr int CVP = CVB * 32;
@@ -675,6 +675,7 @@ __global__ __launch_bounds__(256, 1) void corr_bwd_query_f16x3_kernel(COCOS_BQ_P
             } else {
                 if (kblocks <= 1) corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK, true, 1>(COCOS_BQ_ARGS);
                 else if (kblocks <= 2) corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK, true, 2>(COCOS_BQ_ARGS);
+                else if (kblocks <= 4) corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK, true, 4>(COCOS_BQ_ARGS);
                 else corr_bwd_query_f16x3_body<CVB, STORE_DS, STORE_P, RAGGED, false, BLK, true>(COCOS_BQ_ARGS);
             }
         } else

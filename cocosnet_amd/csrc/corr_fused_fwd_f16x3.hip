@@ -116,7 +116,7 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
     float* __restrict__ mtile = nullptr /* RAWM + STORE_S: [B][Nk/32 tiles][2][Nq] = (m_hi, m_lo) when the tile's logits were stored */) {
     // KST (RAWM): 16-channel steps that hold non-zero channels — the Attention block's K = C/8 = 32 or 64 channels sit zero-padded
     // in 256-channel planes; the QK MFMAs, fragment reads and key-tile fetches of the all-padding steps do not exist in the
-    // KST = 2 / 4 instantiations.  (A run-time step count was tried first: 48 scalar branches per tile cost more than the MFMAs
+    // KST = 2 / 4 / 8 instantiations (K <= 32 / 64 / 128).  (A run-time step count was tried first: 48 scalar branches per tile cost more than the MFMAs
     // they skipped — QK phase 3250 cycles per tile against 2320 without them, tools/phase_timing_attention.py.)
     static_assert(KST >= 1 && KST <= SP_KD / 16 && (RAWM || KST == SP_KD / 16), "KST < 16 belongs to the magnitude-free flavour");
     constexpr int CVP = CVB * 32;
@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256, 1) void corr_fwd_f16x3_kernel(
             } else {
                 if (ksteps <= 2) COCOS_RAWM_BODY(2);
                 else if (ksteps <= 4) COCOS_RAWM_BODY(4);
+                else if (ksteps <= 8) COCOS_RAWM_BODY(8);
                 else COCOS_RAWM_BODY(SP_KD / 16);
             }
 #undef COCOS_RAWM_BODY

@@ -1185,7 +1185,7 @@ def conv_nhwc_prep(x: torch.Tensor, pad: int, reflect: bool = False) -> torch.Te
 #: cost what the second round costs (407 -> 407 input gradient 0.191 vs 0.192 ms, 512 -> 512 0.224 vs 0.239).
 CONV_NHWC_STREAMK = False
 #: the three-term flavour (K16c) is the other way round: a tile takes 3x as long, the parked partials cost the same — stream-K on
-#: unless COCOS_CONV_STREAMK=0 (407 -> 407 input gradient on 66 x 66: two rounds of 0.3 ms against 1.07 rounds + 0.04 ms)
+#: (407 -> 407 input gradient on 66 x 66: two rounds of 0.3 ms against 1.07 rounds + 0.04 ms)
 CONV_NHWC_STREAMK_SPLIT = True
 
 

@@ -151,7 +151,7 @@ int cocos_corr_softmax_warp_fwd_f16x3_ex(const void* qh, const void* ql, const v
                                          float inv_temperature, float operand_scale, const float* q_scale_dev,
                                          const float* k_scale_dev, float* rowstat_out /* nullable */, float* mtile_out /* nullable */,
                                          int k_active /* 0 = K; else: channels >= k_active of q and k are zero padding (the Attention
-                                         block's C/8 channels in 256-channel planes): k_active <= 32 / <= 64 run instantiations without
+                                         block's C/8 channels in 256-channel planes): k_active <= 32 / <= 64 / <= 128 run instantiations without
                                          the QK steps, fragment reads and key fetches of the padding */,
                                          cocos_stream_t stream);
 /* bit (c >> 5) of *mask_inout_dev |= (channel c of the channel-major f16 plane [B,C,N] has a non-zero element); the
@@ -211,8 +211,8 @@ int cocos_corr_softmax_warp_bwd_query_f16x3_ex(
     float inv_temperature, float k_scale, const float* q_scale_dev, const float* k_scale_dev, int planes_blocked,
     const float* rowstat /* nullable */, const float* mtile /* nullable */,
     const float* d_pre /* nullable: D[b][i] = sum_c dout * out from cocos_rowdot_f64 — the kernel then skips its own serial fp64 loop */,
-    int k_active /* 0 = K; as in the forward call: the dqn MFMAs of all-padding channel blocks do not exist in the K <= 32 / K <= 64
-    instantiations, and the dqn rows of those blocks (channels >= 32 resp. 64) are NOT written */,
+    int k_active /* 0 = K; as in the forward call: the dqn MFMAs of all-padding channel blocks do not exist in the K <= 32 / 64 / 128
+    instantiations, and the dqn rows of those blocks (channels >= 32 / 64 / 128) are NOT written */,
     cocos_stream_t stream);
 /* d[b][i] = sum_c a[b][c][i] * b[b][c][i], fp64 accumulation, fp32 result: D of the softmax backward (autograd of
  * correspondence.py:307/:318: dS = P * (dP - D)) as a streaming kernel. */
