@@ -126,6 +126,25 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     return LIB_PATH
 
 
+def compile_check(sources=("upsample_nearest.hip", "wta_scale.hip"), verbose: bool = True) -> None:
+    """Compile a couple of small translation units from scratch with the product flags into a temporary directory and check
+    that the objects carry gfx950 code — `build_hip()` is a no-op when the shipped library's stamp matches the sources
+    (the driver's build() then did not exercise the compiler at all).  ~10 s; `python -m cocosnet_amd.build
+    --force` rebuilds everything."""
+    import tempfile
+    hipcc = _hipcc()
+    with tempfile.TemporaryDirectory(prefix="cocos_cc_") as tmp:
+        for name in sources:
+            src, obj = os.path.join(CSRC_DIR, name), os.path.join(tmp, name + ".o")
+            cmd = [hipcc, *_flags(), *FILE_FLAGS.get(name, []), "-c", src, "-o", obj]
+            if verbose:
+                print("[build] compile check:", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            blob = open(obj, "rb").read()
+            if b"gfx950" not in blob or len(blob) < 4096:
+                raise RuntimeError(f"compile check: {obj} holds no gfx950 code object")
+
+
 def build_oracle(verbose: bool = True) -> None:
     """Nothing to compile: the oracle under oracle/ is numpy / torch, and the reference it is pinned against is pure
     Python (no oracle/_ref build).  Kept because __graft_entry__.build() calls it as the "build the checker" step; it
