@@ -9,6 +9,7 @@ R=$PWD; O=$R/gpurun_out/final_$TAG; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 (rocm-smi --showproductname; rocm-smi --showclocks; uname -a) > $O/${TAG}_box_info.txt 2>&1
 timeout 900 python bench.py > $O/${TAG}_bench_final.json 2> $O/bench_default.err; echo "bench rc=$?"; cut -c1-400 $O/${TAG}_bench_final.json
 timeout 1500 python -m pytest tests -q -m gpu > $O/${TAG}_pytest_gpu_final.log 2>&1; echo "pytest rc=$?"; tail -3 $O/${TAG}_pytest_gpu_final.log
+timeout 600 python -m pytest tests/test_gpu_conv.py -q -s -m gpu -k "end_to_end or config3" 2>&1 | grep "E2E_FP64\|CFG3_FP64\|passed\|failed" > $O/${TAG}_e2e_fp64_errors.txt
 timeout 600 python tools/configs_bench.py > $O/configs_bench.log 2>&1; cp gpurun_out/configs_bench.json $O/${TAG}_configs_bench.json 2>/dev/null
 timeout 300 python tools/attention_bench.py > $O/${TAG}_attention_bench.txt 2>&1; tail -3 $O/${TAG}_attention_bench.txt | cut -c1-300
 cd /tmp
