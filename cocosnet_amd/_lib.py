@@ -119,11 +119,11 @@ _SIGNATURES = {
                                    + [_c_float_p, _c_float_p, _stream_t]),
     "cocos_box3_softmax_warp_fwd_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_void_p] * 2 + [_c_float_p] * 3
                                           + [ctypes.c_void_p] + [ctypes.c_int] * 6
-                                          + [ctypes.c_float, ctypes.c_float, _stream_t]),
+                                          + [ctypes.c_float, ctypes.c_float, ctypes.c_int, _stream_t]),
     "cocos_box3_softmax_warp_bwd_colpart_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
     "cocos_box3_softmax_warp_bwd_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_void_p] * 4 + [_c_float_p] * 10
                                           + [ctypes.c_void_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-                                          + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, _c_float_p, _stream_t]),
+                                          + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_float, _c_float_p, ctypes.c_int, _stream_t]),
     "cocos_box3_adjoint_planes_f16x3": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p]
                                         + [ctypes.c_int] * 5 + [_stream_t]),
     "cocos_warp_values_amax": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 6 + [_c_float_p, _stream_t]),

@@ -59,7 +59,31 @@ struct BxGeom {
     unsigned lane_off;      // lane * 16
     const float* kstat;     // LDS: [b_q (nk floats) | kc * nu_q * b_q (nk floats)] of this sample's keys (x 2 buffers when chunked)
     int nk;                 // keys per LDS buffer: Nk, or BX_KCH when chunked
+    float* xt;              // TRANSPOSED T (see below): this wave's [32][BX_XT_ROW] floats of LDS; nullptr = T as stored
 };
+
+// Round 4: T = xbox(C) of the OTHER orientation is T transposed (the diagonal filter moves both indices alike), so the column
+// pass of the cycle terms (correspondence.py:338,:351: softmax over the content positions) reads the row pass's T instead of
+// running a second correlation GEMM: block (key tile kt, query block qb) of the transposed problem is block (qb, kt) of the
+// stored tensor, transposed inside — the three y-box blocks are summed as stored and the 32 x 32 sum goes once through a
+// per-wave LDS image (4 x ds_write_b128, 16 x ds_read_b32 per tile).  The backward writes its G the same way back, into the
+// layout of the stored T, and ADDS it to what another pass has already written there (flags bit 1): one G, one box adjoint
+// (K20) and one pair of GEMMs for both orientations.
+constexpr int BX_XT_ROW = 36, BX_XT_FLOATS = 32 * BX_XT_ROW;
+constexpr int BX_FLAG_TRANSPOSED = 1, BX_FLAG_ACCUMULATE = 2;
+
+// x[4g + e] of lane (h, c) = element (8g + 4h + e, c) of a 32 x 32 matrix  ->  the same registers of the TRANSPOSED matrix
+__device__ __forceinline__ void bx_transpose32(float (&x)[16], float* xt, int h, int c) {
+    float* row = xt + c * BX_XT_ROW + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(row + 8 * g) = f32x4{x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+    __builtin_amdgcn_wave_barrier();      // one wave's LDS instructions execute in order: no workgroup barrier
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[4 * g + e] = xt[(8 * g + 4 * h + e) * BX_XT_ROW + c];
+    __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ void bx_fetch(BxTile& tl, const BxGeom& gm, int t, int ntiles) {
     const int tc = min(t, ntiles - 1);                  // look-ahead past the end re-reads the last tile
@@ -69,7 +93,8 @@ __device__ __forceinline__ void bx_fetch(BxTile& tl, const BxGeom& gm, int t, in
         const int dy = d - 1;
         if ((BX_ABLATE & 4) && d != 1) continue;
         const bool ok = (unsigned)(gm.py + dy) < (unsigned)gm.himg && (unsigned)(ky + dy) < (unsigned)gm.himg;
-        const int blk = ok ? (tc + dy * gm.tpr) * gm.nqblk + gm.qblk + dy * gm.tpr : 0;
+        const int kb = tc + dy * gm.tpr, qb = gm.qblk + dy * gm.tpr;
+        const int blk = ok ? (gm.xt ? qb * gm.nqblk + kb : kb * gm.nqblk + qb) : 0;
         const unsigned voff = ok ? gm.lane_off : kBufOob;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -105,8 +130,15 @@ __device__ __forceinline__ void bx_stage_next_chunk(float* kstat, const float* _
 // b_q and kn_q per register for the backward.
 template <bool CHUNKED>
 __device__ __forceinline__ void bx_logits(const BxTile& tl, const BxGeom& gm, int t, int h, float mu_p, float (&tt)[16],
-                                          float (&bq)[16], float (&kn)[16]) {
+                                          float (&bq)[16], float (&kn)[16], int lane_c) {
     const float* ks = gm.kstat + (CHUNKED ? ((t / BX_TCH) & 1) * 2 * BX_KCH + (t & (BX_TCH - 1)) * 32 : t * 32);
+    float ts[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            ts[4 * g + e] = (BX_ABLATE & 4) ? tl.s[1][g][e] : (tl.s[0][g][e] + tl.s[2][g][e]) + tl.s[1][g][e];
+    if (gm.xt) bx_transpose32(ts, gm.xt, h, lane_c);      // (workgroup-uniform: one branch per tile)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(ks + 8 * g + 4 * h);
@@ -114,10 +146,9 @@ __device__ __forceinline__ void bx_logits(const BxTile& tl, const BxGeom& gm, in
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
-            const float ts = (BX_ABLATE & 4) ? tl.s[1][g][e] : (tl.s[0][g][e] + tl.s[2][g][e]) + tl.s[1][g][e];
             bq[r] = b4[e];
             kn[r] = k4[e];
-            tt[r] = __builtin_fmaf(bq[r], ts, -(mu_p * kn[r]));
+            tt[r] = __builtin_fmaf(bq[r], ts[r], -(mu_p * kn[r]));
         }
     }
 }
@@ -132,7 +163,7 @@ __device__ __forceinline__ void box3_sw_fwd_body(
     const float* __restrict__ T, const float* __restrict__ mu_q, const float* __restrict__ a_q,
     const float* __restrict__ nu_k, const float* __restrict__ b_k, const _Float16* __restrict__ vh,
     const _Float16* __restrict__ vl, float* __restrict__ out, float* __restrict__ lse,
-    const float* __restrict__ v_scale, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale) {
+    const float* __restrict__ v_scale, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale, int flags) {
     constexpr int CVP = CVB * 32, VPLANE = CVP * BX_VROW;
     extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
     _Float16* const vt = reinterpret_cast<_Float16*>(bx_smem);      // [2 buf][hi|lo|hi*2^-11][CVP][VROW]
@@ -161,6 +192,7 @@ __device__ __forceinline__ void box3_sw_fwd_body(
     gm.himg = himg;
     gm.nqblk = Nq >> 5;
     gm.lane_off = (unsigned)lane * 16u;
+    gm.xt = (flags & BX_FLAG_TRANSPOSED) ? kstat + (CHUNKED ? 4 * BX_KCH : 2 * Nk) + wave * BX_XT_FLOATS : nullptr;
 
     const float mu_p = mu_q[(size_t)b * Nq + i_lane];
     const float a2 = a_q[(size_t)b * Nq + i_lane] * scale * kLog2e;      // log2-domain factor of this query's logits (> 0)
@@ -207,7 +239,7 @@ __device__ __forceinline__ void box3_sw_fwd_body(
         const int j0 = t * 32, buf = t & 1;
         bx_stage_next_chunk<CHUNKED>(kstat, bk_b, nu_b, t, ntiles, kc, tid);
         float tt[16], bq[16], kn[16];
-        bx_logits<CHUNKED>(tl, gm, t, h, mu_p, tt, bq, kn);
+        bx_logits<CHUNKED>(tl, gm, t, h, mu_p, tt, bq, kn, c);
         bx_fetch(tl, gm, t + 1, ntiles);                  // the next tile's blocks have the whole MFMA loop to arrive
         float tmax = tt[0];
 #pragma unroll
@@ -301,11 +333,11 @@ __global__ __launch_bounds__(256, 1) void box3_sw_fwd_kernel(
     const float* __restrict__ nu_k, const float* __restrict__ b_k, const _Float16* __restrict__ vh,
     const _Float16* __restrict__ vl, float* __restrict__ out, float* __restrict__ lse,
     const float* __restrict__ v_scale, const unsigned* __restrict__ v_lo_mask, int B, int Nq, int Nk, int Cv, int himg,
-    int wimg, float kc, float scale) {
+    int wimg, float kc, float scale, int flags) {
     if (DUAL && (__builtin_amdgcn_readfirstlane(*v_lo_mask) & ~1u) == 0u)
-        box3_sw_fwd_body<CVB, DUAL, CHUNKED>(T, mu_q, a_q, nu_k, b_k, vh, vl, out, lse, v_scale, B, Nq, Nk, Cv, himg, wimg, kc, scale);
+        box3_sw_fwd_body<CVB, DUAL, CHUNKED>(T, mu_q, a_q, nu_k, b_k, vh, vl, out, lse, v_scale, B, Nq, Nk, Cv, himg, wimg, kc, scale, flags);
     else
-        box3_sw_fwd_body<CVB, false, CHUNKED>(T, mu_q, a_q, nu_k, b_k, vh, vl, out, lse, v_scale, B, Nq, Nk, Cv, himg, wimg, kc, scale);
+        box3_sw_fwd_body<CVB, false, CHUNKED>(T, mu_q, a_q, nu_k, b_k, vh, vl, out, lse, v_scale, B, Nq, Nk, Cv, himg, wimg, kc, scale, flags);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -350,10 +382,10 @@ __device__ __forceinline__ float bx_colsum4(const float (&x)[4], int c) {
     const float* __restrict__ dout, const float* __restrict__ lse, float* __restrict__ G, float* __restrict__ dmu,     \
     float* __restrict__ da, float* __restrict__ colpart, float* __restrict__ gmax, _Float16* __restrict__ psh,         \
     _Float16* __restrict__ psl, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale,              \
-    const float* __restrict__ d_pre
+    const float* __restrict__ d_pre, int flags
 #define COCOS_BXB_ARGS \
     T, mu_q, a_q, nu_k, b_k, vph, vpl, gph, gpl, g_scale, v_scale, outp, dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, \
-    Nk, Cv, himg, wimg, kc, scale, d_pre
+    Nk, Cv, himg, wimg, kc, scale, d_pre, flags
 
 template <int CVB, bool STORE_P, bool VLO0, bool CHUNKED>
 __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
@@ -393,6 +425,8 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     gm.himg = himg;
     gm.nqblk = Nq >> 5;
     gm.lane_off = (unsigned)lane * 16u;
+    gm.xt = (flags & BX_FLAG_TRANSPOSED) ? kstat + (CHUNKED ? 4 * BX_KCH : 2 * Nk) + wave * BX_XT_FLOATS : nullptr;
+    const bool accumulate = (flags & BX_FLAG_ACCUMULATE) != 0;
 
     const float mu_p = mu_q[(size_t)b * Nq + i_lane];
     const float a_p = a_q[(size_t)b * Nq + i_lane];
@@ -478,7 +512,7 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
         if (t > 0) reduce_cols(t - 1);
         bx_stage_next_chunk<CHUNKED>(kstat, bk_b, nu_b, t, ntiles, kc, tid);
         float tt[16], bq[16], kn[16];
-        bx_logits<CHUNKED>(tl, gm, t, h, mu_p, tt, bq, kn);
+        bx_logits<CHUNKED>(tl, gm, t, h, mu_p, tt, bq, kn, c);
         bx_fetch(tl, gm, t + 1, ntiles);
         float p[16];
 #pragma unroll
@@ -515,22 +549,37 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
         static_assert(2 * VPT <= CVS, "staging pieces must fit the dP steps");
 
         // ---- L = P (dP - D); G = L * a_n * b_q; row sums in registers, column sums through the butterfly -----------------
-        float x1[16], x2[16];
+        float x1[16], x2[16], gv[16];
         f32x4 gout[4];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float L = p[r] * ((dp0[r] + dp1[r]) - d_lane) * undo;
             const float z = tt[r] * a_n;
-            const float gv = L * a_n * bq[r];
-            gout[r >> 2][r & 3] = gv;
-            gabs = fmaxf(gabs, fabsf(gv));
+            gv[r] = L * a_n * bq[r];
             x1[r] = L * z;
             x2[r] = L * am;
             r2 += x1[r];
             rm = __builtin_fmaf(L, kn[r], rm);
         }
+        // G leaves in the layout of the STORED T: transposed back when T was read transposed, and added to what another pass
+        // has already written (one G for all passes over this T: one box adjoint + one pair of GEMMs)
+        if (gm.xt) bx_transpose32(gv, gm.xt, h, c);
+        const unsigned blk = (unsigned)((gm.xt ? gm.qblk * gm.nqblk + t : t * gm.nqblk + gm.qblk) * 4096);
+        if (accumulate && !(BX_ABLATE & 2)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 old = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(G_rs, (int)gm.lane_off,
+                                                                                                 (int)(blk + (unsigned)g * 1024u), 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gv[4 * g + e] += old[e];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            gout[r >> 2][r & 3] = gv[r];
+            gabs = fmaxf(gabs, fabsf(gv[r]));
+        }
         if (!(BX_ABLATE & 2)) {
-            const unsigned blk = (unsigned)((t * gm.nqblk + gm.qblk) * 4096);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gout[g]), G_rs, (int)gm.lane_off,
@@ -818,14 +867,15 @@ template <int CVB>
 static int bx_fwd_launch(const float* T, const float* mu, const float* a, const float* nu, const float* bk,
                          const _Float16* vh, const _Float16* vl, float* out, float* lse, const float* vs,
                          const unsigned* mask, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale,
-                         hipStream_t s) {
+                         int flags, hipStream_t s) {
     const bool chunked = Nk > 2 * BX_KCH;
-    const size_t smem = (size_t)2 * 3 * CVB * 32 * BX_VROW * sizeof(_Float16) + (size_t)(chunked ? 4 * BX_KCH : 2 * Nk) * sizeof(float);
+    const size_t smem = (size_t)2 * 3 * CVB * 32 * BX_VROW * sizeof(_Float16) + (size_t)(chunked ? 4 * BX_KCH : 2 * Nk) * sizeof(float) +
+                        ((flags & BX_FLAG_TRANSPOSED) ? (size_t)4 * BX_XT_FLOATS * sizeof(float) : 0);
     auto kern = chunked ? ((CVB > 1 && mask) ? box3_sw_fwd_kernel<CVB, (CVB > 1), true> : box3_sw_fwd_kernel<CVB, false, true>)
                         : ((CVB > 1 && mask) ? box3_sw_fwd_kernel<CVB, (CVB > 1), false> : box3_sw_fwd_kernel<CVB, false, false>);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3(B * (Nq / 128)), dim3(256), smem, s, T, mu, a, nu, bk, vh, vl, out, lse, vs, mask, B, Nq, Nk,
-                       Cv, himg, wimg, kc, scale);
+                       Cv, himg, wimg, kc, scale, flags);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -836,16 +886,17 @@ static int bx_bwd_launch(const float* T, const float* mu, const float* a, const 
                          const float* gs, const float* vs, const float* outp, const float* dout, const float* lse, float* G,
                          float* dmu, float* da, float* colpart, float* gmax, _Float16* psh, _Float16* psl,
                          const unsigned* mask, int B, int Nq, int Nk, int Cv, int himg, int wimg, float kc, float scale,
-                         const float* d_pre, hipStream_t s) {
+                         const float* d_pre, int flags, hipStream_t s) {
     const bool chunked = Nk > 2 * BX_KCH;
     const size_t smem = (size_t)2 * 2 * 32 * (CVB * 32 + 8) * sizeof(_Float16) +
-                        (size_t)(2 * 4 * 2048 + (chunked ? 4 * BX_KCH : 2 * Nk)) * sizeof(float);
+                        (size_t)(2 * 4 * 2048 + (chunked ? 4 * BX_KCH : 2 * Nk)) * sizeof(float) +
+                        ((flags & BX_FLAG_TRANSPOSED) ? (size_t)4 * BX_XT_FLOATS * sizeof(float) : 0);
 #define COCOS_BX_GO(SP, CH)                                                                                              \
     do {                                                                                                                 \
         auto kern = (CVB > 1 && mask) ? box3_sw_bwd_kernel<CVB, SP, (CVB > 1), CH> : box3_sw_bwd_kernel<CVB, SP, false, CH>; \
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         hipLaunchKernelGGL(kern, dim3(B * (Nq / 128)), dim3(256), smem, s, T, mu, a, nu, bk, vph, vpl, gph, gpl, gs, vs, outp, \
-                           dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, Nk, Cv, himg, wimg, kc, scale, d_pre, mask); \
+                           dout, lse, G, dmu, da, colpart, gmax, psh, psl, B, Nq, Nk, Cv, himg, wimg, kc, scale, d_pre, flags, mask); \
     } while (0)
     if (chunked) { if (psh) COCOS_BX_GO(true, true); else COCOS_BX_GO(false, true); }
     else { if (psh) COCOS_BX_GO(true, false); else COCOS_BX_GO(false, false); }
@@ -870,11 +921,12 @@ extern "C" int cocos_box3_softmax_warp_fwd_f16x3(const float* t_blocked, const f
                                                  const float* nu_k, const float* b_k, const void* vh, const void* vl,
                                                  float* out, float* lse, const float* v_scale_dev,
                                                  const unsigned* v_lo_mask_dev, int B, int Nq, int Nk,
-                                                 int Cv, int grid_h, int grid_w, float k_unfolded, float scale,
+                                                 int Cv, int grid_h, int grid_w, float k_unfolded, float scale, int flags,
                                                  cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(t_blocked && mu_q && a_q && nu_k && b_k && vh && vl && out && lse, COCOS_ERR_INVALID,
                   "box3_softmax_warp_fwd_f16x3: null pointer");
+    COCOS_REQUIRE((flags & ~BX_FLAG_TRANSPOSED) == 0, COCOS_ERR_INVALID, "box3_softmax_warp_fwd_f16x3: flags=%d (bit 0: T transposed)", flags);
     COCOS_REQUIRE(B >= 1 && scale > 0.f, COCOS_ERR_INVALID, "box3_softmax_warp_fwd_f16x3: bad B=%d / scale", B);
     COCOS_REQUIRE(bx_shape_ok(Nq, Nk, Cv, grid_h, grid_w), COCOS_ERR_UNSUPPORTED,
                   "box3_softmax_warp_fwd_f16x3: needs a 64- or 128-wide grid with Nq == Nk == h*w, Nq %% 256 == 0, Cv <= 160 "
@@ -886,7 +938,7 @@ extern "C" int cocos_box3_softmax_warp_fwd_f16x3(const float* t_blocked, const f
                       "box3_softmax_warp_fwd_f16x3: v planes must be 8-byte aligned");
     const _Float16 *a = static_cast<const _Float16*>(vh), *b2 = static_cast<const _Float16*>(vl);
     hipStream_t s = as_stream(stream);
-#define COCOS_ARGS t_blocked, mu_q, a_q, nu_k, b_k, a, b2, out, lse, v_scale_dev, v_lo_mask_dev, B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, s
+#define COCOS_ARGS t_blocked, mu_q, a_q, nu_k, b_k, a, b2, out, lse, v_scale_dev, v_lo_mask_dev, B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, flags, s
     switch ((Cv + 31) / 32) {
         case 1: return bx_fwd_launch<1>(COCOS_ARGS);
         case 2: return bx_fwd_launch<2>(COCOS_ARGS);
@@ -907,8 +959,10 @@ extern "C" int cocos_box3_softmax_warp_bwd_f16x3(
     const void* vpl, const void* gph, const void* gpl, const float* g_scale_dev, const float* v_scale_dev, const float* out,
     const float* dout, const float* lse, float* g_blocked, float* dmu, float* da, float* dnu, float* db, void* colpart,
     float* gmax_dev, void* psh, void* psl, const unsigned* v_lo_mask_dev, int B, int Nq, int Nk, int Cv, int CvPad, int grid_h,
-    int grid_w, float k_unfolded, float scale, const float* d_pre, cocos_stream_t stream) {
+    int grid_w, float k_unfolded, float scale, const float* d_pre, int flags, cocos_stream_t stream) {
     using namespace cocos;
+    COCOS_REQUIRE((flags & ~(BX_FLAG_TRANSPOSED | BX_FLAG_ACCUMULATE)) == 0, COCOS_ERR_INVALID,
+                  "box3_softmax_warp_bwd_f16x3: flags=%d (bit 0: T transposed, bit 1: add G to g_blocked)", flags);
     COCOS_REQUIRE(t_blocked && mu_q && a_q && nu_k && b_k && vph && vpl && gph && gpl && g_scale_dev && out && dout && lse &&
                       g_blocked && dmu && da && dnu && db && colpart && gmax_dev,
                   COCOS_ERR_INVALID, "box3_softmax_warp_bwd_f16x3: null pointer");
@@ -927,7 +981,7 @@ extern "C" int cocos_box3_softmax_warp_bwd_f16x3(
     t_blocked, mu_q, a_q, nu_k, b_k, static_cast<const _Float16*>(vph), static_cast<const _Float16*>(vpl),               \
         static_cast<const _Float16*>(gph), static_cast<const _Float16*>(gpl), g_scale_dev, v_scale_dev, out, dout, lse,   \
         g_blocked, dmu, da, static_cast<float*>(colpart), gmax_dev, static_cast<_Float16*>(psh),                         \
-        static_cast<_Float16*>(psl), v_lo_mask_dev, B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, d_pre, s
+        static_cast<_Float16*>(psl), v_lo_mask_dev, B, Nq, Nk, Cv, grid_h, grid_w, k_unfolded, scale, d_pre, flags, s
     int rc;
     switch (cvb) {
         case 1: rc = bx_bwd_launch<1>(COCOS_ARGS); break;

@@ -153,6 +153,9 @@ class _BoxedCorr:
         _, C, self.fh, self.fw = theta_raw.shape
         self.kc = float(C * 9)
         self._cache = {}
+        # round 4: ONE T for both orientations (xbox(C)^T = xbox(C^T): the column pass reads it transposed) and one gradient
+        # buffer for all passes over it — no second correlation GEMM, one box adjoint and one pair of GEMMs in the backward
+        self._sink = ops.Box3GradSink() if ops.BOX3_SHARE_T else None
 
     def _get(self, name, fn):
         if name not in self._cache:
@@ -162,12 +165,15 @@ class _BoxedCorr:
     def rows(self, v):
         mu, a = self._get("q", lambda: _unfold3_stats(self.th, self.kc))
         nu, b = self._get("k", lambda: _unfold3_stats(self.ph, self.kc))
-        t = self._get("t_rows", lambda: ops.box3_corr_xbox(self.th, self.ph))
-        return ops.box3_softmax_warp(t, mu, a, nu, b, v, self.fh, self.fw, self.kc, self.inv_t)
+        t = self._get("t_rows", lambda: ops.box3_corr_xbox(self.th, self.ph, self._sink))
+        return ops.box3_softmax_warp(t, mu, a, nu, b, v, self.fh, self.fw, self.kc, self.inv_t, sink=self._sink)
 
     def cols(self, v):   # the same operator with the roles of theta and phi exchanged
         mu, a = self._get("q", lambda: _unfold3_stats(self.th, self.kc))
         nu, b = self._get("k", lambda: _unfold3_stats(self.ph, self.kc))
+        if self._sink is not None:
+            t = self._get("t_rows", lambda: ops.box3_corr_xbox(self.th, self.ph, self._sink))
+            return ops.box3_softmax_warp(t, nu, b, mu, a, v, self.fh, self.fw, self.kc, self.inv_t, transposed=True, sink=self._sink)
         t = self._get("t_cols", lambda: ops.box3_corr_xbox(self.ph, self.th))
         return ops.box3_softmax_warp(t, nu, b, mu, a, v, self.fh, self.fw, self.kc, self.inv_t)
 

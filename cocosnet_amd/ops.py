@@ -1449,6 +1449,8 @@ def box3_logits(c_raw, mu, nu, a, b, h, w, k_unfolded, scale):
 # ------------------------------------------------------------------------------------------
 #: "0": match_kernel 3 keeps the round-2 chain (K3 -> K6 -> K7) everywhere (A/B runs, tests of that chain)
 BOX3_FUSED = True
+#: the column pass of the cycle terms reads the row pass's T transposed and all passes share one gradient buffer (round 4)
+BOX3_SHARE_T = True
 
 
 def box3_fused_ok(B, C, h, w, Cv=1):
@@ -1463,7 +1465,8 @@ class _Box3CorrXbox(torch.autograd.Function):
     y box of the adjoint is applied here, together with the x box, by K20."""
 
     @staticmethod
-    def forward(ctx, q_raw, k_raw):
+    def forward(ctx, q_raw, k_raw, sink=None):
+        ctx.sink = sink
         q_raw, k_raw = _chk(q_raw, "box3_corr_xbox: q"), _chk(k_raw, "box3_corr_xbox: k")
         B, K, h, w = q_raw.shape
         N = h * w
@@ -1506,18 +1509,38 @@ class _Box3CorrXbox(torch.autograd.Function):
             dk = torch.empty_like(k_raw)
             _call("box3_corr_grad", "cocos_hgemm_f16x3", ch.data_ptr(), cl.data_ptr(), dch.data_ptr(), dcl.data_ptr(),
                   dk.data_ptr(), B, K, N, N, 1.0, cs.data_ptr(), sc.data_ptr(), 2, _stream())
-        return dq, dk
+        if ctx.sink is not None:
+            ctx.sink.reset()      # (a second backward through the same graph starts a new G)
+        return dq, dk, None
 
 
-def box3_corr_xbox(q_raw, k_raw):
+class Box3GradSink:
+    """The ONE gradient buffer G of a T = box3_corr_xbox(...) that several box3_softmax_warp passes read (row pass, the column
+    pass on the transposed T, a second row pass): the first pass's backward allocates G, writes it and hands it to autograd as
+    d loss / d T; every later pass ADDS its G into the same buffer inside its kernel (COCOS_BOX3_G_ACCUMULATE) and returns no
+    gradient for T — autograd never sums HWxHW tensors, and T's node runs ONE box adjoint + ONE pair of GEMMs for all passes.
+    (T's node runs after all of its consumers, so the buffer is complete by then.)"""
+
+    def __init__(self):
+        self.buf = None
+        self.gmax = None
+
+    def reset(self):
+        self.buf = None
+        self.gmax = None
+
+
+def box3_corr_xbox(q_raw, k_raw, sink: Box3GradSink | None = None):
     """x-direction diagonal box filter of the K = 256 correlation of two raw [B,256,h,w] feature maps (64- or 128-wide grid),
-    keys in the rows, in the tile-blocked layout of K19 (an opaque 1-D tensor of B*N*N floats)."""
-    return _Box3CorrXbox.apply(q_raw, k_raw)
+    keys in the rows, in the tile-blocked layout of K19 (an opaque 1-D tensor of B*N*N floats).  `sink`: the gradient sink the
+    box3_softmax_warp passes over this T share (see Box3GradSink)."""
+    return _Box3CorrXbox.apply(q_raw, k_raw, sink)
 
 
 class _Box3SoftmaxWarp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, t, mu, a, nu, b, v, h: int, w: int, kc: float, scale: float):
+    def forward(ctx, t, mu, a, nu, b, v, h: int, w: int, kc: float, scale: float, transposed: bool = False, sink=None):
+        ctx.transposed, ctx.sink = bool(transposed), sink
         t, v = _chk(t, "box3_softmax_warp: t"), _chk(v, "box3_softmax_warp: v")
         mu, a, nu, b = (_chk(x, n) for x, n in ((mu, "mu"), (a, "a"), (nu, "nu"), (b, "b")))
         B, N = mu.shape
@@ -1532,7 +1555,7 @@ class _Box3SoftmaxWarp(torch.autograd.Function):
         lse = torch.empty((B, N), device=v.device, dtype=torch.float32)
         _call("box3_softmax_warp_fwd", "cocos_box3_softmax_warp_fwd_f16x3", t.data_ptr(), mu.data_ptr(), a.data_ptr(),
               nu.data_ptr(), b.data_ptr(), vh.data_ptr(), vl.data_ptr(), out.data_ptr(), lse.data_ptr(), v_scale.data_ptr(),
-              _ptr(v_lomask), B, N, N, Cv, h, w, float(kc), float(scale), _stream())
+              _ptr(v_lomask), B, N, N, Cv, h, w, float(kc), float(scale), 1 if transposed else 0, _stream())
         ctx.v_lomask = v_lomask
         ctx.save_for_backward(t, mu, a, nu, b, v, out, lse)
         ctx.cfg = (int(h), int(w), float(kc), float(scale))
@@ -1551,10 +1574,18 @@ class _Box3SoftmaxWarp(torch.autograd.Function):
         gph, gpl, gs = split_f16(dout, True, cpad=cvp, amax=g_amax)
         vph, vpl, v_scale = split_f16(v, True, cpad=cvp, amax=ctx.v_amax)
         f32 = dict(device=v.device, dtype=torch.float32)
-        g = torch.empty(B * N * N, **f32)
+        sink, flags = ctx.sink, (1 if ctx.transposed else 0)
+        if sink is not None and sink.buf is not None:      # another pass over this T has written its G: add ours to it
+            g, g_ret = sink.buf, None
+            gmax = sink.gmax = _zero_cell(v.device)        # ... and max|G| becomes that of the sum (a fresh zero cell)
+            flags |= 2
+        else:
+            g = g_ret = torch.empty(B * N * N, **f32)
+            gmax = _zero_cell(v.device)
+            if sink is not None:
+                sink.buf, sink.gmax = g, gmax
         dmu, da, dnu, db = (torch.empty((B, N), **f32) for _ in range(4))
         colpart = torch.empty(_lib.load().cocos_box3_softmax_warp_bwd_colpart_bytes(B, N, N) // 4, **f32)
-        gmax = _zero_cell(v.device)
         need_v = ctx.needs_input_grad[5]
         psh = psl = None
         if need_v:        # cycle terms: V itself is differentiated -> the planes of 2^14 P for dv = dout . P
@@ -1564,24 +1595,27 @@ class _Box3SoftmaxWarp(torch.autograd.Function):
               nu.data_ptr(), b.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(), gs.data_ptr(),
               v_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), g.data_ptr(), dmu.data_ptr(),
               da.data_ptr(), dnu.data_ptr(), db.data_ptr(), colpart.data_ptr(), gmax.data_ptr(), _ptr(psh), _ptr(psl),
-              _ptr(ctx.v_lomask), B, N, N, Cv, cvp, h, w, kc, scale, _ptr(_rowdot(dout, out) if BWD_D_PRECOMPUTED else None), _stream())
-        _remember_amax(g, gmax)
+              _ptr(ctx.v_lomask), B, N, N, Cv, cvp, h, w, kc, scale, _ptr(_rowdot(dout, out) if BWD_D_PRECOMPUTED else None), flags,
+              _stream())
+        _remember_amax(g, gmax)      # (an accumulating pass replaces the cell remembered for the shared buffer)
         dv = None
         if need_v:
             gch, gcl, _ = split_f16(dout, False, amax=g_amax)
             dv = torch.empty_like(v)
             _call("box3_softmax_warp_bwd_dv", "cocos_hgemm_f16x3", gch.data_ptr(), gcl.data_ptr(), psh.data_ptr(),
                   psl.data_ptr(), dv.data_ptr(), B, Cv, N, N, 1.0 / 16384.0, gs.data_ptr(), None, 2, _stream())
-        return g, dmu, da, dnu, db, dv, None, None, None, None
+        return g_ret, dmu, da, dnu, db, dv, None, None, None, None, None, None
 
 
-def box3_softmax_warp(t, mu, a, nu, b, v, h, w, k_unfolded, scale):
+def box3_softmax_warp(t, mu, a, nu, b, v, h, w, k_unfolded, scale, transposed: bool = False, sink: Box3GradSink | None = None):
     """out[b,c,p] = sum_q softmax_q(scale * a_p b_q (ybox(T)[p,q] - k mu_p nu_q)) v[b,c,q] with T from box3_corr_xbox —
-    the whole match_kernel-3 attention of one orientation; v [B,Cv,N] in chunks of 160 channels."""
+    the whole match_kernel-3 attention of one orientation; v [B,Cv,N] in chunks of 160 channels.  `transposed`: T is the
+    OTHER orientation's (mu / a then belong to T's keys, nu / b to its queries): the column pass on the row pass's T.
+    `sink`: the Box3GradSink given to box3_corr_xbox — the passes then accumulate ONE gradient of T inside their kernels."""
     Cv = v.shape[1]
     if Cv <= MAX_FUSED_CV:
-        return _Box3SoftmaxWarp.apply(t, mu, a, nu, b, v, h, w, k_unfolded, scale)
-    return torch.cat([_Box3SoftmaxWarp.apply(t, mu, a, nu, b, v[:, c0:c0 + MAX_FUSED_CV], h, w, k_unfolded, scale)
+        return _Box3SoftmaxWarp.apply(t, mu, a, nu, b, v, h, w, k_unfolded, scale, transposed, sink)
+    return torch.cat([_Box3SoftmaxWarp.apply(t, mu, a, nu, b, v[:, c0:c0 + MAX_FUSED_CV], h, w, k_unfolded, scale, transposed, sink)
                       for c0 in range(0, Cv, MAX_FUSED_CV)], dim=1)
 
 

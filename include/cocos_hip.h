@@ -604,7 +604,15 @@ int cocos_conv2d_wgrad_bf16(const float* x, const float* dy, float* partials, in
  *       T below 2 GiB); every other match_kernel-3 shape keeps the K3 -> K6 -> K7 chain.  Round 4: on 128-wide grids the x box
  *       exchanges its halo between the two 64-position chunks of an image row (GEMM epilogue: within a wave for the keys,
  *       between neighbouring waves for the queries; K20: four waves per row pair), the y box spans grid_w / 32 tiles, and the
- *       per-key statistics of samples with more than 4096 keys pass through LDS in a ring of 2048-key chunks. */
+ *       per-key statistics of samples with more than 4096 keys pass through LDS in a ring of 2048-key chunks.
+ *   `flags` (round 4): bit 0 (COCOS_BOX3_T_TRANSPOSED) — t_blocked holds T of the OTHER orientation (keys and queries exchanged:
+ *       xbox(C)^T = xbox(C^T)); the kernels read block (qb, kt) for (kt, qb) and transpose it in LDS, so the column pass of
+ *       the cycle terms (correspondence.py:338,:351) shares the row pass's T — no second correlation GEMM — and the backward
+ *       writes g_blocked in the layout of that stored T.  Bit 1 (COCOS_BOX3_G_ACCUMULATE, backward) — g_blocked already holds
+ *       another pass's G over the same T: this pass's G is ADDED to it and *gmax_dev (zeroed on entry) receives max|sum|: one
+ *       g tensor, one cocos_box3_adjoint_planes_f16x3 and one pair of GEMMs for all passes over a T. */
+#define COCOS_BOX3_T_TRANSPOSED 1
+#define COCOS_BOX3_G_ACCUMULATE 2
 int cocos_box3_fused_supported(int Nq, int Nk, int Cv, int grid_h, int grid_w);
 int cocos_box3_corr_xbox_f16x3(const void* k_hi, const void* k_lo, const void* q_hi, const void* q_lo, float* t_blocked,
                                int batch, int Nk, int Nq, int K, int grid_w, const float* k_scale_dev /* nullable */,
@@ -614,7 +622,7 @@ int cocos_box3_softmax_warp_fwd_f16x3(const float* t_blocked, const float* mu_q,
                                       const float* v_scale_dev /* nullable */,
                                       const unsigned* v_lo_mask_dev /* nullable: as for cocos_corr_softmax_warp_fwd_f16x3 */,
                                       int B, int Nq, int Nk, int Cv, int grid_h, int grid_w, float k_unfolded, float scale,
-                                      cocos_stream_t stream);
+                                      int flags, cocos_stream_t stream);
 size_t cocos_box3_softmax_warp_bwd_colpart_bytes(int B, int Nq, int Nk);
 int cocos_box3_softmax_warp_bwd_f16x3(const float* t_blocked, const float* mu_q, const float* a_q, const float* nu_k,
                                       const float* b_k, const void* vph, const void* vpl, const void* gph, const void* gpl,
@@ -624,7 +632,7 @@ int cocos_box3_softmax_warp_bwd_f16x3(const float* t_blocked, const float* mu_q,
                                       void* psl /* nullable */, const unsigned* v_lo_mask_dev /* nullable */, int B, int Nq,
                                       int Nk, int Cv, int CvPad, int grid_h, int grid_w, float k_unfolded, float scale,
                                       const float* d_pre /* nullable: D = sum_c dout * out [B][Nq] (cocos_rowdot_f64) */,
-                                      cocos_stream_t stream);
+                                      int flags, cocos_stream_t stream);
 int cocos_box3_adjoint_planes_f16x3(const float* g_blocked, const float* gmax_dev, void* dc_hi, void* dc_lo,
                                     float* scale_out_dev, int B, int Nq, int Nk, int grid_h, int grid_w,
                                     cocos_stream_t stream);

@@ -307,6 +307,55 @@ def test_box3_fused_family_on_128_wide_grids_vs_fp64_and_vs_the_materialised_cha
         assert max(v for k, v in errs[fused].items() if k.startswith("d ")) < 5e-4, (fused, errs)
 
 
+@pytest.mark.parametrize("fh,fw,flags", [
+    (8, 64, dict(warp_mask_losstype="cycle", warp_cycle_w=1.0, two_cycle=True)),       # rows x 3 (two of them via the sink), columns x 2
+    (12, 64, dict(warp_mask_losstype="none", warp_cycle_w=1.0, warp_bilinear=True)),   # README.md:106 (CelebA-HQ edge) flags
+    (4, 128, dict(warp_patch=True, warp_cycle_w=1.0, warp_mask_losstype="none")),      # 128-wide, Cv = 48
+])
+def test_column_pass_on_the_row_pass_T_and_one_shared_gradient(fh, fw, flags, monkeypatch):
+    """Round 4: xbox(C)^T = xbox(C^T), so the column pass of the cycle terms reads the row pass's T transposed
+    (COCOS_BOX3_T_TRANSPOSED) and every pass adds its G into one buffer (COCOS_BOX3_G_ACCUMULATE): ONE correlation GEMM, ONE box
+    adjoint and ONE pair of GEMMs per step whatever the number of passes.  Same outputs and gradients as with a T per orientation
+    and autograd's sum of the G's (the round-3 arrangement, ops.BOX3_SHARE_T = False) — to fp32 summation order."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    B, d, nc = 2, 4, 9
+    g = torch.Generator(device=DEV).manual_seed(700 + fh)
+    th = torch.randn(B, 256, fh, fw, device=DEV, generator=g) + 0.15
+    ph = 0.4 * th.roll((1, 5), (2, 3)) + torch.randn(B, 256, fh, fw, device=DEV, generator=g) - 0.1
+    H, W = fh * d, fw * d
+    ref_img = torch.rand(B, 3, H, W, device=DEV, generator=g) * 2 - 1
+    real_img = torch.rand(B, 3, H, W, device=DEV, generator=g) * 2 - 1
+    seg = torch.rand(B, nc, H, W, device=DEV, generator=g)
+    ref_seg = torch.rand(B, nc, H, W, device=DEV, generator=g)
+    cfg = dict(match_kernel=3, PONO_C=True, down=d, isTrain=True, **flags)
+    res = {}
+    for share in (True, False):
+        monkeypatch.setattr(ops, "BOX3_SHARE_T", share)
+        t, p = th.clone().requires_grad_(True), ph.clone().requires_grad_(True)
+        with ops.KernelTimer() as kt:
+            out = correspondence_hot_path(t, p, ref_img, real_img, seg, ref_seg, HotPathConfig(**cfg))
+            if share:
+                G = {k: torch.randn(v.shape, device=DEV, generator=g) for k, v in sorted(out.items())}
+            torch.autograd.backward([out[k] for k in sorted(out)], [G[k] for k in sorted(out)])
+        res[share] = (out, t.grad, p.grad, {k: v["calls"] for k, v in kt.summary().items()})
+    calls = {s_: res[s_][3] for s_ in res}
+    assert calls[True]["box3_corr_xbox"] == 1 and calls[False]["box3_corr_xbox"] == 2, calls
+    assert calls[True]["box3_adjoint_planes"] == 1 and calls[False]["box3_adjoint_planes"] == 2, calls
+    assert calls[True]["box3_corr_grad"] == 2 and calls[False]["box3_corr_grad"] == 4, calls
+    assert calls[True]["box3_softmax_warp_fwd"] == calls[False]["box3_softmax_warp_fwd"] >= 2
+    for k in res[True][0]:
+        assert rel(res[True][0][k], f64(res[False][0][k])) < 1e-5, k
+    # (gradients: both arrangements carry the fp32 noise of the statistics' gradients — sums of L * z that cancel to first
+    #  order, 1e-4 of the gradient's range against fp64 in either — so they agree with each other to that, not to an ulp)
+    assert rel(res[True][1], f64(res[False][1])) < 2e-4 and rel(res[True][2], f64(res[False][2])) < 2e-4
+    outs, dth, dph = tr.forward_backward(th, ph, ref_img, real_img, seg, ref_seg, co.default_opt(**cfg), G, device=DEV)
+    for k in outs:
+        assert rel(res[True][0][k], outs[k]) < TOL, k
+    assert rel(res[True][1], dth) < 5e-4 and rel(res[True][2], dph) < 5e-4
+
+
 @pytest.mark.parametrize("route", ["512_patch48", "256_stride2_patch12"])
 def test_config5_match_kernel3_hw16384_vs_fp64(route, monkeypatch):
     """BASELINE config 5 AS THE REFERENCE RUNS IT: DeepFashion flags (README.md:69,115: --warp_patch --warp_bilinear, no mask

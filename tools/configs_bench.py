@@ -46,10 +46,15 @@ out.append(run("cfg2 ADE20k 256^2 B=8 mk1 direct mask (headline)", 8, 256, 151, 
                C(match_kernel=1, PONO_C=True, warp_mask_losstype="direct", isTrain=True)))
 out.append(run("cfg2' same, match_kernel 3 (reference default)", 8, 256, 151, False,
                C(match_kernel=3, PONO_C=True, warp_mask_losstype="direct", isTrain=True)))
-out.append(run("cfg3 CelebA-HQ edge 256^2 B=16 mk1 warp_cycle+two_cycle bilinear", 16, 256, 15, True,
+out.append(run("cfg3+ CelebA-HQ edge 256^2 B=16 mk1 warp_cycle + two_cycle (superset of the README flags: three passes) bilinear", 16, 256, 15, True,
                C(match_kernel=1, PONO_C=True, warp_bilinear=True, warp_cycle_w=1.0, two_cycle=True, isTrain=True)))
 out.append(run("cfg3' same, match_kernel 3", 16, 256, 15, True,
                C(match_kernel=3, PONO_C=True, warp_bilinear=True, warp_cycle_w=1.0, two_cycle=True, isTrain=True)))
+# config 3 AS THE README RUNS IT (README.md:106): --warp_cycle_w 1 without --two_cycle (two passes: rows, columns), match_kernel 3
+out.append(run("cfg3 as written: CelebA-HQ edge 256^2 B=16, warp_cycle_w 1 (no two_cycle), match_kernel 3", 16, 256, 15, True,
+               C(match_kernel=3, PONO_C=True, warp_bilinear=True, warp_cycle_w=1.0, isTrain=True)))
+out.append(run("cfg3 as written, match_kernel 1", 16, 256, 15, True,
+               C(match_kernel=1, PONO_C=True, warp_bilinear=True, warp_cycle_w=1.0, isTrain=True)))
 out.append(run("cfg5 DeepFashion 512^2 warp_patch, 128x128 grid, B=2 mk1", 2, 512, 20, True,
                C(match_kernel=1, PONO_C=True, warp_bilinear=True, warp_patch=True, isTrain=True)))
 out.append(run("cfg5' 256^2 warp_stride 2 warp_patch, 128x128 grid, B=2 mk1", 2, 256, 20, True,
@@ -69,6 +74,7 @@ def ab(name, *a, **k):
     try:
         for route, lim in (("saved logits", 64 << 30), ("chunked recompute (512 MiB per matrix)", 0)):
             ops.MAX_SAVED_LOGITS_BYTES = lim
+            ops.RECOMPUTE_CHUNK_BYTES = 512 << 20
             out.append(run(f"A/B {name}: {route}", *a, **k))
     finally:
         ops.MAX_SAVED_LOGITS_BYTES, ops.RECOMPUTE_CHUNK_BYTES = saved
