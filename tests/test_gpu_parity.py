@@ -443,7 +443,7 @@ def test_module_return_corr_and_wta_and_detach():
     seg = torch.zeros(1, 3, 32, 32, device=DEV); seg[:, 1] = 1
     corr = net(img, img, seg, seg, return_corr=True)
     assert torch.is_tensor(corr) and corr.shape == (1, 64, 64)
-    assert float(corr.abs().max()) <= 100.0 * (1 + 1e-5)        # cosine / 0.01
+    assert float(corr.detach().abs().max()) <= 100.0 * (1 + 1e-5)        # cosine / 0.01
     o = net(img, img, seg, seg, WTA_scale_weight=0.5)
     assert set(o) == {"warp_out"}
     o = net(img, img, seg, seg, detach_flag=True)
