@@ -22,6 +22,9 @@ namespace cocos {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef HG_ABLATE
+#define HG_ABLATE 0    // debug builds only (tools/xbox_ablate.sh): 1 no T stores, 2 no x box, 4 no MFMAs, 8 no loads inside the k loop
+#endif
 constexpr int HG_BM = 256, HG_BN = 128, HG_BK = 32;
 constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row
 
@@ -36,8 +39,13 @@ constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row
 // EPI 2 (round 4): the same on a 128-wide grid — the sub-tile is ONE image row of keys x HALF an image row of queries;
 // the halo between the two key chunks comes from the wave's own registers, the halo between the query halves from the
 // neighbouring wave (wave ^ 1) through the LDS images, with workgroup barriers around the exchange.
-template <bool EXACT, int BMODE, int EPI = 0>
-__global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __restrict__ ah,
+// DUO (round 4, with EPI 1 / 2): TWO workgroups per CU.  The x-box GEMM has K = 256 — 8 k-steps — and a 128 KB tile to store:
+// with one workgroup per CU the matrix pipe idles through every epilogue (the store of 537 MB per 8 samples is 0.13 ms of the
+// 0.29 ms launch) and every prologue.  LDS is what held the occupancy at one: this flavour stages ONE k-block (61 KB; the four
+// x-box images, 80 KB, lie over it) with a single register stage, commit -> barrier -> multiply -> barrier per step — the bubbles
+// a single workgroup would see are the other workgroup's MFMA time, and one workgroup's epilogue drains while the other multiplies.
+template <bool EXACT, int BMODE, int EPI = 0, bool DUO = false>
+__global__ __launch_bounds__(256, DUO ? 2 : 1) void hgemm_f16x3_kernel(const _Float16* __restrict__ ah,
                                                              const _Float16* __restrict__ al,
                                                              const _Float16* __restrict__ bh,
                                                              const _Float16* __restrict__ bl,
@@ -57,8 +65,9 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
     constexpr int APLANE = HG_BM * HG_ROW, BPLANE = HG_BN * HG_ROW;     // (= 32 * HG_GROW: both images are 5120 halfs)
     static_assert(32 * HG_GROW == HG_BN * HG_ROW, "B plane size");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // [2 buf][hi|lo][256][ROW]
-    _Float16* const bt = at + 2 * 2 * APLANE;                      // [2 buf][hi|lo][128][ROW]
+    constexpr int NBUF = DUO ? 1 : 2;
+    _Float16* const at = reinterpret_cast<_Float16*>(smem_raw);   // [NBUF][hi|lo][256][ROW]
+    _Float16* const bt = at + NBUF * 2 * APLANE;                   // [NBUF][hi|lo][128][ROW]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -146,10 +155,12 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
 
     const int nsteps = (K + HG_BK - 1) / HG_BK;
     fetch(st0, 0);
-    fetch(st1, HG_BK);
-    commit(st0, 0);
-    fetch(st0, 2 * HG_BK);
-    __syncthreads();
+    if (!DUO) {
+        fetch(st1, HG_BK);
+        commit(st0, 0);
+        fetch(st0, 2 * HG_BK);
+        __syncthreads();
+    }
     // at the top of step t: LDS[t&1] = k-block t; st1 (t even) / st0 (t odd) holds t+1, the other stage t+2
     // one staged 16-byte piece (plane pl, chunk u of operand A or B) -> the other LDS buffer, and its register
     // takes the load for k-block t+3: issued ONE piece at a time between MFMAs (12 pieces per step, one per
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
     // mode 2: transpose-read addressing (lane i of a 16-lane group supplies row i>>2, columns 4(i&3)..+3 of its 4 x 16 block)
     const int tr_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * HG_GROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     auto step = [&](int t, Stage& st) {
-        const int buf = t & 1;
+        const int buf = DUO ? 0 : (t & 1);
         const _Float16* ab = at + buf * 2 * APLANE + (wm * 128 + c) * HG_ROW + h * 8;
         const _Float16* bb = bt + buf * 2 * BPLANE + (BMODE == 2 ? wn * 64 + tr_off : (wn * 64 + c) * HG_ROW + h * 8);
 #pragma unroll
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                 const f16x8 avl = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * HG_ROW + s * 16);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    if (EXACT || i < rows_live) {     // (ragged M: a wave-uniform branch around the MFMAs of all-padding row tiles)
+                    if (!(HG_ABLATE & 4) && (EXACT || i < rows_live)) {     // (ragged M: a wave-uniform branch around the MFMAs of all-padding row tiles)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avh, bvl[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(avl, bvh[j], acc[i][j], 0, 0, 0);
@@ -214,19 +225,28 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                     // 16 (s, i, j) slots per step, 12 pieces: k-block t+1 -> LDS[buf ^ 1] (released by the barrier
                     // that ended step t-1), k-block t+3 -> the freed registers
                     const int slot = (s * 4 + i) * 2 + j;
-                    if (slot < 12) piece(st, slot, buf ^ 1, (t + 3) * HG_BK);
+                    if (!DUO && slot < 12) piece(st, slot, buf ^ 1, (t + 3) * HG_BK);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
         __syncthreads();
     };
-    int t = 0;
-    for (; t + 1 < nsteps; t += 2) {      // (no branch inside the pair: it would cost the exact vmcnt waits)
-        step(t, st1);
-        step(t + 1, st0);
+    if (DUO) {
+        for (int t = 0; t < nsteps; ++t) {
+            commit(st0, 0);                                   // (every wave passed the barrier that ended step t - 1)
+            if (!(HG_ABLATE & 8) && t + 1 < nsteps) fetch(st0, (t + 1) * HG_BK);  // in flight while this k-block multiplies
+            __syncthreads();
+            step(t, st0);                                     // (ends with a barrier)
+        }
+    } else {
+        int t = 0;
+        for (; t + 1 < nsteps; t += 2) {      // (no branch inside the pair: it would cost the exact vmcnt waits)
+            step(t, st1);
+            step(t + 1, st0);
+        }
+        if (t < nsteps) step(t, st1);
     }
-    if (t < nsteps) step(t, st1);
 
     const float scale = host_scale / ((dev_scale ? *dev_scale : 1.0f) * (dev_scale2 ? *dev_scale2 : 1.0f));
     if (EPI == 1 || EPI == 2) {
@@ -242,7 +262,8 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             f32x16 (&t)[2][2] = *reinterpret_cast<f32x16 (*)[2][2]>(&acc[2 * hh]);
-            if (EPI == 1) {
+            if (HG_ABLATE & 2) {
+            } else if (EPI == 1) {
                 xbox_64x64(t, img, lane);
             } else {
                 // 128-wide grid (box3_common.h): the wave's 128 keys are ONE image row (two chunks hh = 0, 1, handled one after
@@ -275,6 +296,7 @@ __global__ __launch_bounds__(256, 1) void hgemm_f16x3_kernel(const _Float16* __r
                     const unsigned blk = (unsigned)((((m0 + wm * 128 + (2 * hh + kt) * 32) >> 5) * nqblk + ((n0 + wn * 64 + qt * 32) >> 5)) * 4096);
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
+                        if (!(HG_ABLATE & 1) || t[kt][qt][4 * g] == 1234.5f)
                         __builtin_amdgcn_raw_buffer_store_b128(
                             __builtin_bit_cast(u32x4, f32x4{t[kt][qt][4 * g] * scale, t[kt][qt][4 * g + 1] * scale,
                                                             t[kt][qt][4 * g + 2] * scale, t[kt][qt][4 * g + 3] * scale}),
@@ -352,10 +374,11 @@ extern "C" int cocos_box3_corr_xbox_f16x3(const void* k_hi, const void* k_lo, co
         COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "box3_corr_xbox_f16x3: pointers must be 16-byte aligned");
     const long long blocks = (long long)batch * (Nq / HG_BN) * (Nk / HG_BM);
     COCOS_REQUIRE(blocks <= 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "box3_corr_xbox_f16x3: grid too large");
-    const size_t smem = (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16);
-    static_assert((size_t)4 * kXbFloats * sizeof(float) <= (size_t)2 * 2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16),
-                  "the four x-box images must fit the staging buffers");
-    auto kern = grid_w == 64 ? hgemm_f16x3_kernel<true, 0, 1> : hgemm_f16x3_kernel<true, 0, 2>;
+    // two workgroups per CU (DUO): one staging buffer (61 KB) under the four x-box images (80 KB)
+    constexpr size_t kStage1 = (size_t)2 * (HG_BM + HG_BN) * HG_ROW * sizeof(_Float16), kImages = (size_t)4 * kXbFloats * sizeof(float);
+    const size_t smem = kStage1 > kImages ? kStage1 : kImages;
+    static_assert(2 * (kStage1 > kImages ? kStage1 : kImages) <= 160 * 1024, "two workgroups of the x-box GEMM must fit one CU's LDS");
+    auto kern = grid_w == 64 ? hgemm_f16x3_kernel<true, 0, 1, true> : hgemm_f16x3_kernel<true, 0, 2, true>;
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, as_stream(stream),
