@@ -148,6 +148,46 @@ def config5_context(device, steps=5, warmup=3):
     return out
 
 
+def config3_hot_path_context(device, steps=8, warmup=3):
+    """The correspondence hot path of BASELINE config 3 as the README runs it (README.md:106: CelebA-HQ edge->face, --warp_bilinear
+    --warp_cycle_w 1, float edge maps, no mask loss, the DEFAULT match_kernel 3), B = 16, 256^2 at down 4 = 64 x 64 grid: a row pass
+    and a column pass over the same correlation (round 4: ONE T read transposed by the column pass, ONE gradient buffer, one box
+    adjoint + one GEMM pair).  Forward + backward from theta / phi on; match_kernel 1 beside it.  Context, never part of `value`."""
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    B, S, fh = 16, 256, 64
+    g = torch.Generator(device=device).manual_seed(333)
+    th = torch.randn(B, KDIM, fh, fh, device=device, generator=g).requires_grad_(True)
+    ph = (0.3 * th.detach().roll((2, 7), (2, 3)) + torch.randn(B, KDIM, fh, fh, device=device, generator=g)).requires_grad_(True)
+    img = torch.rand(B, 3, S, S, device=device, generator=g) * 2 - 1
+    seg = torch.rand(B, 15, S, S, device=device, generator=g)
+    out = {}
+    for mk in (3, 1):
+        cfg = HotPathConfig(match_kernel=mk, PONO_C=True, down=4, warp_bilinear=True, warp_cycle_w=1.0, isTrain=True)
+        cot = {}
+
+        def step():
+            th.grad = ph.grad = None
+            o = correspondence_hot_path(th, ph, img, img, seg, seg, cfg)
+            if not cot:
+                cot.update({k: torch.randn(v.shape, device=device, generator=g) for k, v in o.items()})
+            torch.autograd.backward([o[k] for k in sorted(o)], [cot[k] for k in sorted(o)])
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        out[f"match_kernel_{mk}"] = {"ms_per_step": round(ms, 3), "images_per_s": round(B / ms * 1e3, 1), "steps": steps,
+                                     "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    out["note"] = ("CelebA-HQ edge training flags (--warp_cycle_w 1: row pass + column pass), B = 16, 64x64 grid, hot path fwd+bwd; "
+                   "match_kernel 3 is what the README command runs")
+    return out
+
+
 def config3_context(device, steps=4, warmup=3):
     """BASELINE config 3 as written — "CelebA-HQ edge->face 256x256 batch 16, + HIP SPADE generator / PatchGAN conv kernels, bf16
     MFMA" — for the two networks behind the correspondence: cocosnet_amd.translation.SPADEGenerator (generator.py:17-89) and
@@ -679,6 +719,7 @@ def main():
                 context["config5"] = {"error": repr(e)}
             try:
                 context["config3"] = config3_context(device)
+                context["config3"]["hot_path"] = config3_hot_path_context(device)
             except Exception as e:       # noqa: BLE001
                 context["config3"] = {"error": repr(e)}
             torch.cuda.empty_cache()

@@ -225,22 +225,23 @@ __device__ __forceinline__ void box3_sw_fwd_body(
     };
 
     const int ntiles = Nk / 32;
-    BxTile tl;
+    BxTile tl0, tl1;        // tiles t and t + 1 in flight: one tile of look-ahead did not cover the HBM latency of the T blocks
 #pragma unroll
     for (int i = 0; i < 2 * CVB; ++i) fetch_v_piece(i, 0);
-    bx_fetch(tl, gm, 0, ntiles);
+    bx_fetch(tl0, gm, 0, ntiles);
+    bx_fetch(tl1, gm, 1, ntiles);
 #pragma unroll
     for (int i = 0; i < 2 * CVB; ++i) commit_v_piece(i, 0);
 #pragma unroll
     for (int i = 0; i < 2 * CVB; ++i) fetch_v_piece(i, 32);
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    auto do_tile = [&](int t, BxTile& tl) __attribute__((always_inline)) {
         const int j0 = t * 32, buf = t & 1;
         bx_stage_next_chunk<CHUNKED>(kstat, bk_b, nu_b, t, ntiles, kc, tid);
         float tt[16], bq[16], kn[16];
         bx_logits<CHUNKED>(tl, gm, t, h, mu_p, tt, bq, kn, c);
-        bx_fetch(tl, gm, t + 1, ntiles);                  // the next tile's blocks have the whole MFMA loop to arrive
+        bx_fetch(tl, gm, t + 2, ntiles);                  // two tiles ahead (round 4)
         float tmax = tt[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, tt[r]);
@@ -310,6 +311,14 @@ __device__ __forceinline__ void box3_sw_fwd_body(
 #pragma unroll
         for (int cb = 0; cb < CVB; ++cb) asm volatile("" : "+a"(o[cb]));
         __syncthreads();
+    };
+    {
+        int t = 0;
+        for (; t + 1 < ntiles; t += 2) {
+            do_tile(t, tl0);
+            do_tile(t + 1, tl1);
+        }
+        if (t < ntiles) do_tile(t, tl0);
     }
 
     const float l_tot = l_run + swap_half(l_run);
@@ -496,10 +505,11 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     };
 
     const int ntiles = Nk / 32;
-    BxTile tl;
+    BxTile tl0, tl1;        // (two tiles of look-ahead, as in the forward)
 #pragma unroll
     for (int i = 0; i < 2 * VPT; ++i) fetch_v_piece(i, 0);
-    bx_fetch(tl, gm, 0, ntiles);
+    bx_fetch(tl0, gm, 0, ntiles);
+    bx_fetch(tl1, gm, 1, ntiles);
 #pragma unroll
     for (int i = 0; i < 2 * VPT; ++i) commit_v_piece(i, 0);
 #pragma unroll
@@ -507,13 +517,13 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     __syncthreads();
 
     float r2 = 0.f, rm = 0.f, gabs = 0.f;
-    for (int t = 0; t < ntiles; ++t) {
+    auto do_tile = [&](int t, BxTile& tl) __attribute__((always_inline)) {
         const int j0 = t * 32, buf = t & 1;
         if (t > 0) reduce_cols(t - 1);
         bx_stage_next_chunk<CHUNKED>(kstat, bk_b, nu_b, t, ntiles, kc, tid);
         float tt[16], bq[16], kn[16];
         bx_logits<CHUNKED>(tl, gm, t, h, mu_p, tt, bq, kn, c);
-        bx_fetch(tl, gm, t + 1, ntiles);
+        bx_fetch(tl, gm, t + 2, ntiles);
         float p[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) p[r] = (BX_ABLATE & 32) ? tt[r] * 1e-3f : fast_exp2(__builtin_fmaf(tt[r], a2, -lse2));
@@ -622,6 +632,14 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
             }
         }
         __syncthreads();
+    };
+    {
+        int t = 0;
+        for (; t + 1 < ntiles; t += 2) {
+            do_tile(t, tl0);
+            do_tile(t + 1, tl1);
+        }
+        if (t < ntiles) do_tile(t, tl0);
     }
     reduce_cols(ntiles - 1);
 
