@@ -520,9 +520,9 @@ def test_contextual_loss_forward_matches_the_reference_formula(B, C, h, w, pono)
     xr, yr = X.double().cpu().requires_grad_(True), Y.double().cpu().requires_grad_(True)
     lr = mod(xr, yr, h=0.1)               # CPU tensors: the reference's formulation (torch), here in fp64
     lr.sum().backward()
-    assert rel(loss, lr.detach().numpy()) < 1e-3
-    assert rel(xa.grad, xr.grad.numpy()) < 2e-3
-    assert rel(ya.grad, yr.grad.numpy()) < 2e-3
+    errs = (rel(loss, lr.detach().numpy()), rel(xa.grad, xr.grad.numpy()), rel(ya.grad, yr.grad.numpy()))
+    print("CTX_FP64", (B, C, h, w, pono), errs)
+    assert errs[0] < 2e-5 and errs[1] < 5e-5 and errs[2] < 5e-5, errs      # (measured 1e-8 .. 4e-6; VERDICT r3 weak 1c: was 1e-3 / 2e-3)
 
 
 # ------------------------------------------------------------------ RCCL is at least initialised on the box
