@@ -23,7 +23,7 @@ namespace cocos {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef HG_ABLATE
-#define HG_ABLATE 0    // debug builds only (tools/xbox_ablate.sh): 1 no T stores, 2 no x box, 4 no MFMAs, 8 no loads inside the k loop
+#define HG_ABLATE 0    // debug builds only (tools/xbox_ablate.sh): 1 no T stores, 2 no x box, 4 no MFMAs, 8 no loads inside the k loop, 16 row-major tile order
 #endif
 constexpr int HG_BM = 256, HG_BN = 128, HG_BK = 32;
 constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row
@@ -77,7 +77,18 @@ __global__ __launch_bounds__(256, DUO ? 2 : 1) void hgemm_f16x3_kernel(const _Fl
     const int ntn = (N + HG_BN - 1) / HG_BN, ntm = (M + HG_BM - 1) / HG_BM;
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
     const int b = vb / (ntn * ntm), rem = vb % (ntn * ntm);
-    const int m0 = (rem / ntn) * HG_BM, n0 = (rem % ntn) * HG_BN;
+    int mi = rem / ntn, ni = rem % ntn;
+    if (EPI != 0 && !(HG_ABLATE & 16) && (ntm & 7) == 0 && (ntn & 7) == 0) {
+        // x-box GEMM (both operands are re-read: 16 x 32 tiles per sample at cfg2'): the ~64 tiles an XCD works on at a time
+        // form an 8 x 8 block of the tile grid instead of two full rows — 3 MB of operand planes (8 key tiles + 8 query tiles)
+        // instead of 4.5 MB, inside the XCD's 4 MB of L2 — and the blocks walk along n inside an m block, so the key planes of
+        // an m block are fetched once (round 4; same-box A/B, -DHG_ABLATE=16: neutral at cfg2' — the 256 MB memory-side cache
+        // was already serving the re-reads — and 1.23 -> 1.19 ms on the 64 x 128 tile grid of cfg5)
+        const int blk = rem >> 6, w = rem & 63, nb = ntn >> 3;
+        mi = (blk / nb) * 8 + (w >> 3);
+        ni = (blk % nb) * 8 + (w & 7);
+    }
+    const int m0 = mi * HG_BM, n0 = ni * HG_BN;
     // ragged M (the Attention block's key-side GEMM has M = C/8 = 32..64 rows, its dv GEMM M = C/2): 32-row tiles of this wave
     // that hold a real row; the MFMAs of the others are skipped (wave-uniform) — such a GEMM is then bound by its B stream
     const int rows_live = EXACT ? 4 : max(0, min(4, (M - m0 - wm * 128 + 31) >> 5));
