@@ -446,11 +446,12 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     // group m0 and lane h = 1 with those of m1 (probed: tools/probes/permlane_probe.hip) — 16 bytes per lane, the wave's
     // tile is 2 KB contiguous and leaves as two stores per plane.  No LDS round trip; the key-side GEMM reads its B
     // fragments from this layout with ds_read_b64_tr_b16 (hgemm_f16x3.hip, b_blocked = 2).
-    auto store_regs_blk = [&](int t, const DsRegs& d, __amdgpu_buffer_rsrc_t h_rs, __amdgpu_buffer_rsrc_t l_rs) {
+    auto store_regs_blk = [&](int t, const DsRegs& d, __amdgpu_buffer_rsrc_t h_rs, __amdgpu_buffer_rsrc_t l_rs, int pp_lo = 0,
+                              int pp_hi = 2) {
         if (COCOS_ABLATE & 8) return;
         const unsigned blk = (unsigned)((((q0 >> 5) + wave) * (Nk >> 5) + t) * 2048);     // bytes: block (q-block, key tile t)
 #pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {                 // group pairs (0,1) and (2,3)
+        for (int pp = pp_lo; pp < pp_hi; ++pp) {         // group pairs (0,1) and (2,3)
             const int m0 = 2 * pp, m1 = 2 * pp + 1;         // lane h = 0 ends up with group m0, h = 1 with m1
             u32x4 xh, xl;
 #pragma unroll
@@ -501,6 +502,10 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     //      logit registers are consumed, the loads of tile t + 2's logits ride in the MFMA gaps.  STAGE_K: the key-tile
     //      pieces of tile t go to LDS (read from the next iteration on), one every other step ----------------------------
     constexpr int LEAD = 3;
+#ifndef BQ_STORE_I0
+#define BQ_STORE_I0 7        // dqn steps at which the two halves of the tile's planes are stored: slices 0..7 are done by step 4,
+#define BQ_STORE_I1 15       // slices 8..15 by step 12 (tuned: see DESIGN 5.0)
+#endif
     auto phase_dqn = [&](int t, const DsRegs& prev, auto with_valu, auto stage_k, f32x4 (&s)[4], float& dm, const f32x16& dp0,
                          DsRegs& cur, DsRegs& pcur) {
         constexpr bool WITH_VALU = decltype(with_valu)::value;
@@ -541,6 +546,14 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
                 dx[kb] = bq_mfma(a_l[cur_], sh[tt], dx[kb]);
             }
             if (WITH_VALU && i + LEAD < 16) slice(i + LEAD);
+            // blocked planes leave from registers (no LDS round trip): each half of the tile as soon as its slices are done,
+            // BETWEEN the MFMAs — at the end of the iteration the four 1 KB stores cost 0.04 ms of the 0.33 ms kernel even
+            // with an L2-resident target (round-4 ablation), i.e. their issue, not HBM
+            if (WITH_VALU && BLK && (i == BQ_STORE_I0 || i == BQ_STORE_I1)) {
+                const int pp = i == BQ_STORE_I1 ? 1 : 0;
+                if (STORE_DS) store_regs_blk(t, cur, dh_rs, dl_rs, pp, pp + 1);
+                if (STORE_P) store_regs_blk(t, pcur, ph_rs, pl_rs, pp, pp + 1);
+            }
             if (STAGE_K && (i & 1) == 0) stage_piece(2 * VPT + (i >> 1), t + 1, t, false_type{});
             if (WITH_VALU && i == 2 * KB - 1) prefetch_v(t + 1);         // first fragments of the next iteration's dP'
             __builtin_amdgcn_sched_barrier(0);
@@ -620,8 +633,10 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
         BPH_T(tp2);
         phase_dqn(t, prev, true_type{}, true_type{}, s, dm, dp0, cur, pcur);
         BPH_T(tp3);
-        if (STORE_DS) store_planes(t, cur, dh_rs, dl_rs);
-        if (STORE_P) store_p_tile(t, pcur);
+        if (!BLK || BQ_STORE_I0 > 15) {                 // (blocked planes were stored inside phase_dqn)
+            if (STORE_DS) store_planes(t, cur, dh_rs, dl_rs);
+            if (STORE_P) store_p_tile(t, pcur);
+        }
         BPH_T(tp4);
         BPH_ADD(0, tp0, tp1); BPH_ADD(3, tp1, tp2); BPH_ADD(1, tp2, tp3); BPH_ADD(2, tp3, tp4);
     };
