@@ -549,10 +549,11 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
             // blocked planes leave from registers (no LDS round trip): each half of the tile as soon as its slices are done,
             // BETWEEN the MFMAs — at the end of the iteration the four 1 KB stores cost 0.04 ms of the 0.33 ms kernel even
             // with an L2-resident target (round-4 ablation), i.e. their issue, not HBM
-            if (WITH_VALU && BLK && (i == BQ_STORE_I0 || i == BQ_STORE_I1)) {
+            // (only when dS'' is the one plane set: with the P planes as well — cycle terms, the Attention block — four stores per
+            //  position measured 1-2 % SLOWER than all eight at the end, same box, tools/bq_ab.py)
+            if (WITH_VALU && BLK && !STORE_P && (i == BQ_STORE_I0 || i == BQ_STORE_I1)) {
                 const int pp = i == BQ_STORE_I1 ? 1 : 0;
                 if (STORE_DS) store_regs_blk(t, cur, dh_rs, dl_rs, pp, pp + 1);
-                if (STORE_P) store_regs_blk(t, pcur, ph_rs, pl_rs, pp, pp + 1);
             }
             if (STAGE_K && (i & 1) == 0) stage_piece(2 * VPT + (i >> 1), t + 1, t, false_type{});
             if (WITH_VALU && i == 2 * KB - 1) prefetch_v(t + 1);         // first fragments of the next iteration's dP'
@@ -633,7 +634,7 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
         BPH_T(tp2);
         phase_dqn(t, prev, true_type{}, true_type{}, s, dm, dp0, cur, pcur);
         BPH_T(tp3);
-        if (!BLK || BQ_STORE_I0 > 15) {                 // (blocked planes were stored inside phase_dqn)
+        if (!BLK || STORE_P || BQ_STORE_I0 > 15) {      // (else: the blocked dS'' planes were stored inside phase_dqn)
             if (STORE_DS) store_planes(t, cur, dh_rs, dl_rs);
             if (STORE_P) store_p_tile(t, pcur);
         }
