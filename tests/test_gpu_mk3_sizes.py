@@ -307,12 +307,13 @@ def test_box3_fused_family_on_128_wide_grids_vs_fp64_and_vs_the_materialised_cha
         assert max(v for k, v in errs[fused].items() if k.startswith("d ")) < 5e-4, (fused, errs)
 
 
-@pytest.mark.parametrize("fh,fw,flags", [
-    (8, 64, dict(warp_mask_losstype="cycle", warp_cycle_w=1.0, two_cycle=True)),       # rows x 3 (two of them via the sink), columns x 2
-    (12, 64, dict(warp_mask_losstype="none", warp_cycle_w=1.0, warp_bilinear=True)),   # README.md:106 (CelebA-HQ edge) flags
-    (4, 128, dict(warp_patch=True, warp_cycle_w=1.0, warp_mask_losstype="none")),      # 128-wide, Cv = 48
+@pytest.mark.parametrize("fh,fw,flags,nc", [
+    (8, 64, dict(warp_mask_losstype="cycle", warp_cycle_w=1.0, two_cycle=True), 9),     # rows x 3 (two of them via the sink), columns x 2
+    (12, 64, dict(warp_mask_losstype="none", warp_cycle_w=1.0, warp_bilinear=True), 9), # README.md:106 (CelebA-HQ edge) flags
+    (4, 128, dict(warp_patch=True, warp_cycle_w=1.0, warp_mask_losstype="none"), 9),    # 128-wide, Cv = 48
+    (4, 64, dict(warp_mask_losstype="cycle"), 170),     # 170 label channels: every pass runs in two value chunks on the same sink
 ])
-def test_column_pass_on_the_row_pass_T_and_one_shared_gradient(fh, fw, flags, monkeypatch):
+def test_column_pass_on_the_row_pass_T_and_one_shared_gradient(fh, fw, flags, nc, monkeypatch):
     """Round 4: xbox(C)^T = xbox(C^T), so the column pass of the cycle terms reads the row pass's T transposed
     (COCOS_BOX3_T_TRANSPOSED) and every pass adds its G into one buffer (COCOS_BOX3_G_ACCUMULATE): ONE correlation GEMM, ONE box
     adjoint and ONE pair of GEMMs per step whatever the number of passes.  Same outputs and gradients as with a T per orientation
@@ -320,7 +321,7 @@ def test_column_pass_on_the_row_pass_T_and_one_shared_gradient(fh, fw, flags, mo
     from cocosnet_amd import ops
     from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
     monkeypatch.setattr(ops, "PRECISION", "f16x3")
-    B, d, nc = 2, 4, 9
+    B, d = 2, 4
     g = torch.Generator(device=DEV).manual_seed(700 + fh)
     th = torch.randn(B, 256, fh, fw, device=DEV, generator=g) + 0.15
     ph = 0.4 * th.roll((1, 5), (2, 3)) + torch.randn(B, 256, fh, fw, device=DEV, generator=g) - 0.1
@@ -344,7 +345,7 @@ def test_column_pass_on_the_row_pass_T_and_one_shared_gradient(fh, fw, flags, mo
     assert calls[True]["box3_corr_xbox"] == 1 and calls[False]["box3_corr_xbox"] == 2, calls
     assert calls[True]["box3_adjoint_planes"] == 1 and calls[False]["box3_adjoint_planes"] == 2, calls
     assert calls[True]["box3_corr_grad"] == 2 and calls[False]["box3_corr_grad"] == 4, calls
-    assert calls[True]["box3_softmax_warp_fwd"] == calls[False]["box3_softmax_warp_fwd"] >= 2
+    assert calls[True]["box3_softmax_warp_fwd"] == calls[False]["box3_softmax_warp_fwd"] >= (4 if nc > 160 else 2)
     for k in res[True][0]:
         assert rel(res[True][0][k], f64(res[False][0][k])) < 1e-5, k
     # (gradients: both arrangements carry the fp32 noise of the statistics' gradients — sums of L * z that cancel to first
