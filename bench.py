@@ -521,7 +521,7 @@ def roofline_of(kernels, precision):
                "frac_algorithmic": round(alg_gbs / HBM_PEAK_GBS, 4), "moved_over_algorithmic": round(traffic / alg_bytes, 2),
                "note": "moved bytes per launch (PMC, profiles/) / the launch time measured in this run; the kernel streams the "
                        "saved logits in and the dS'' planes out (2 x HW^2 x 4 B per sample) next to its MFMA work — a measured "
-                       "design choice (saved logits beat recompute by 24-68 % at every BASELINE shape: config.context / "
+                       "design choice (saved logits beat the chunked recompute by 22-40 % at every BASELINE shape: config.context / "
                        "profiles/r04_configs_bench.json); a linear read reaches 4.7-4.9 TB/s on this chip "
                        "(tools/probes/strided_rows.hip)"}
     if split and dom in SPLIT_TAGS:
