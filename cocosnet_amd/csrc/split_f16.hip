@@ -73,12 +73,20 @@ __global__ __launch_bounds__(256) void split_f16_transpose_kernel(const float* _
     }
     {
         const int q = tid & 15, r = tid >> 4;   // 16 position quads x 16 rows, 4 sweeps
+        const bool vec = (N & 3) == 0 && n0 + 64 <= N && (reinterpret_cast<uintptr_t>(xb) & 15) == 0;    // (workgroup-uniform)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int ch = c0 + r + 16 * u, n = n0 + 4 * q;
+            if (vec) {          // whole, aligned quads: one 16-byte load per thread and sweep (round 4: was four scalar loads)
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ch < C) v = *reinterpret_cast<const f32x4*>(xb + (size_t)ch * N + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                tile[r + 16 * u][4 * q + e] = (ch < C && n + e < N) ? xb[(size_t)ch * N + n + e] * scale : 0.f;
+                for (int e = 0; e < 4; ++e) tile[r + 16 * u][4 * q + e] = v[e] * scale;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    tile[r + 16 * u][4 * q + e] = (ch < C && n + e < N) ? xb[(size_t)ch * N + n + e] * scale : 0.f;
+            }
         }
     }
     __syncthreads();
