@@ -119,11 +119,11 @@ __device__ __forceinline__ f32x16 cv_mfma_bf16(f16x8 a, f16x8 b, f32x16 c) {    
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// x*s -> f16 hi (round toward zero) + f16 lo, four values
+// x*s -> f16 hi (round to nearest) + f16 lo, four values
 __device__ __forceinline__ void cv_split4(const float (&x)[4], float s, u32x2& hi, u32x2& lo) {
     unsigned h0, l0, h1, l1;
-    split_pair_rtz(x[0] * s, x[1] * s, h0, l0);
-    split_pair_rtz(x[2] * s, x[3] * s, h1, l1);
+    split_pair_rn(x[0] * s, x[1] * s, h0, l0);
+    split_pair_rn(x[2] * s, x[3] * s, h1, l1);
     hi = u32x2{h0, h1};
     lo = u32x2{l0, l1};
 }
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256) void conv_weight_planes_kernel(const float* __
             continue;
         }
         unsigned h2, l2;
-        split_pair_rtz(v[0], v[1], h2, l2);
+        split_pair_rn(v[0], v[1], h2, l2);
         reinterpret_cast<unsigned*>(hi)[i] = h2;
         reinterpret_cast<unsigned*>(lo)[i] = l2;
     }

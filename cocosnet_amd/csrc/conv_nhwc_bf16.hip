@@ -78,7 +78,7 @@ __device__ __forceinline__ int nb_reflect(int i, int n) {                  // to
 // of the chunk for its lane's position (each load 256 bytes coalesced across the wave), the packed pairs cross through LDS
 // ([position][64 channels], 144-byte rows: conflict-free 16-byte writes), and go out as 128 contiguous bytes per position.
 // ---------------------------------------------------------------------------------------------------------------------
-// SPLIT (K16c, the fp32-accurate flavour): x * s as f16 hi (round toward zero) + f16 lo, s the power of two from *amax
+// SPLIT (K16c, the fp32-accurate flavour): x * s as f16 hi (round to nearest: common.h split_pair_rn) + f16 lo, s the power of two from *amax
 // (cv's convention: |x s| < 2^10); two planes, the lo plane `plane_bytes` behind the hi plane.
 __device__ __forceinline__ float nb_scale_from_amax(const float* amax) {
     if (!amax) return 1.0f;
@@ -124,9 +124,9 @@ __global__ __launch_bounds__(256) void conv_nhwc_prep_kernel(const float* __rest
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 unsigned h, l;
-                split_pair_rtz(v[2 * i] * sc, v[2 * i + 1] * sc, h, l);
+                split_pair_rn(v[2 * i] * sc, v[2 * i + 1] * sc, h, l);
                 o0[i] = h; l0[i] = l;
-                split_pair_rtz(v[8 + 2 * i] * sc, v[9 + 2 * i] * sc, h, l);
+                split_pair_rn(v[8 + 2 * i] * sc, v[9 + 2 * i] * sc, h, l);
                 o1[i] = h; l1[i] = l;
             }
         } else {

@@ -660,6 +660,10 @@ def corr_softmax_warp(qn, kn, v, inv_temperature: float, planes: OperandPlanes |
     B, K, Nq = qn.shape
     Nk, Cv = kn.shape[2], v.shape[1]
     keep = _wants_logits(qn, kn)
+    if operand_amax and not keep and torch.is_grad_enabled() and v.requires_grad:
+        # only V is differentiated (frozen / detached theta, phi of an Attention block): the backward still needs P, and for K < 256
+        # only the split chain (saved logits -> P planes -> the dv GEMM) exists — the exact-fp32 kernels are K = 256 only
+        keep = True
     prec = PRECISION if precision is None else precision
     if prec not in ("fp32", "f16x3"):
         raise ValueError(f"cocosnet_amd.ops.PRECISION = {prec!r}: expected 'fp32' or 'f16x3'")
@@ -1575,6 +1579,9 @@ class _Box3SoftmaxWarp(torch.autograd.Function):
         vph, vpl, v_scale = split_f16(v, True, cpad=cvp, amax=ctx.v_amax)
         f32 = dict(device=v.device, dtype=torch.float32)
         sink, flags = ctx.sink, (1 if ctx.transposed else 0)
+        if not ctx.needs_input_grad[0]:
+            sink = None          # nobody differentiates T through this pass (autograd.grad(..., inputs=[v])): its G is scratch and must
+                                 # not become — or be added into — the shared buffer
         if sink is not None and sink.buf is not None:      # another pass over this T has written its G: add ours to it
             g, g_ret = sink.buf, None
             gmax = sink.gmax = _zero_cell(v.device)        # ... and max|G| becomes that of the sum (a fresh zero cell)
@@ -1584,6 +1591,9 @@ class _Box3SoftmaxWarp(torch.autograd.Function):
             gmax = _zero_cell(v.device)
             if sink is not None:
                 sink.buf, sink.gmax = g, gmax
+                # the buffer belongs to THIS backward: whatever happens to T's node (not reached, an exception on the way), the
+                # engine drops it when the pass ends, so a later backward over a retained graph starts a new G
+                torch.autograd.Variable._execution_engine.queue_callback(sink.reset)
         dmu, da, dnu, db = (torch.empty((B, N), **f32) for _ in range(4))
         colpart = torch.empty(_lib.load().cocos_box3_softmax_warp_bwd_colpart_bytes(B, N, N) // 4, **f32)
         need_v = ctx.needs_input_grad[5]
@@ -2045,7 +2055,7 @@ def softmax_attention(q, k, v, scale: float = 1.0):
     tools/attention_bench.py).  Everything else: the materialised family on the same MFMA GEMMs (K3 -> K4 -> K5)."""
     B, K, Nq = q.shape
     Nk = k.shape[2]
-    keep = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad)
+    keep = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
     if (ATTENTION_FUSED and K <= FUSED_K and q.is_cuda and q.dtype == torch.float32
             and corr_split_ok(B, FUSED_K, Nq, Nk, v.shape[1], keep)):
         return corr_softmax_warp(q, k, v, scale, operand_amax=True)

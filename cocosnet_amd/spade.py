@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import _kinks, ops
 
 LEAKY_SLOPE = 2e-1      # SPADEResnetBlock.actvn (architecture.py:107-108)
 
@@ -48,7 +48,13 @@ def spade_forward(self, x, segmap, similarity_map=None, slope: float = 1.0):
     module instances (attributes param_free_norm, mlp_shared, pad, mlp_gamma, mlp_beta, pad_type).  `slope`: negative
     slope of the LeakyReLU the caller would apply next (1.0 = none)."""
     segmap = F.interpolate(segmap, size=x.size()[2:], mode="nearest")
-    actv = self.mlp_shared(segmap)
+    if _kinks.TAPE is not None and isinstance(self.mlp_shared, torch.nn.Sequential) and isinstance(self.mlp_shared[-1], torch.nn.ReLU):
+        actv = segmap                        # tests only (see _kinks.py): the ReLU's recorded branches
+        for m in list(self.mlp_shared)[:-1]:
+            actv = m(actv)
+        actv = _kinks.TAPE.act(actv, 0.0)
+    else:
+        actv = self.mlp_shared(segmap)
     if getattr(self, "pad_type", "nozero") != "zero":
         actv = self.pad(actv)
     gamma, beta = self.mlp_gamma(actv), self.mlp_beta(actv)

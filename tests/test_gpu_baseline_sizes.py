@@ -696,6 +696,62 @@ def test_softmax_attention_channel_counts_and_split_reductions(K, Nq, Nk, monkey
     assert rel(qd.grad, dq_ref) < TOL and rel(kd.grad, dk_ref) < TOL and rel(vd.grad, dv_ref) < TOL
 
 
+@pytest.mark.parametrize("K", [32, 128, 256])
+def test_softmax_attention_with_only_v_differentiated(K, monkeypatch):
+    """an Attention block whose theta / phi are frozen or detached differentiates V alone.  With K < 256 the
+    forward used to run without saved logits and the backward fell through to the exact-fp32 kernels, which are K = 256 only
+    ('fused path needs K == 256').  Now V's requires_grad keeps the logits: d v comes from the split chain's P planes; vs fp64."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    rs = np.random.RandomState(K)
+    B, Nq, Nk, Cv = 2, 512, 256, 40
+    q, k = rs.standard_normal((B, K, Nq)), rs.standard_normal((B, K, Nk))
+    v, g = rs.uniform(-1, 1, (B, Cv, Nk)), rs.standard_normal((B, Cv, Nq))
+    sc = 1.0 / np.sqrt(K)
+    p = co.softmax(np.einsum("bci,bcj->bij", q, k) * sc)
+    o_ref, dv_ref = np.einsum("bij,bcj->bci", p, v), np.einsum("bci,bij->bcj", g, p)
+    qd, kd, vd = dev(q), dev(k), dev(v, True)
+    o = ops.softmax_attention(qd, kd, vd, float(sc))
+    o.backward(dev(g))
+    assert rel(o, o_ref) < TOL and rel(vd.grad, dv_ref) < TOL
+    assert qd.grad is None and kd.grad is None
+
+
+@pytest.mark.parametrize("K", [32, 256])
+def test_softmax_attention_chunked_recompute_backward_of_the_magnitude_free_flavour(K, monkeypatch):
+    """the chunked RECOMPUTE backward (no saved logits: ops._corr_bwd_recompute) was only tested for unit-norm
+    operands.  An Attention block whose logits exceed MAX_SAVED_LOGITS_BYTES takes it in the magnitude-free flavour: per-chunk
+    reference maxima rebuilt by a chunk-local forward, combined with the full forward's row statistics, K-active rows of d q
+    sliced.  MAX_SAVED_LOGITS_BYTES = 0 and 128-key chunks: against the saved-logits chain on the same inputs and against fp64."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    rs = np.random.RandomState(100 + K)
+    B, Nq, Nk, Cv = 2, 512, 384, 40
+    q, k = rs.standard_normal((B, K, Nq)) * 3.0, rs.standard_normal((B, K, Nk)) * 2.0
+    v, g = rs.uniform(-1, 1, (B, Cv, Nk)), rs.standard_normal((B, Cv, Nq))
+    sc = 1.0 / np.sqrt(K)
+    p = co.softmax(np.einsum("bci,bcj->bij", q, k) * sc)
+    dp = np.einsum("bci,bcj->bij", g, v)
+    ds = p * (dp - (p * dp).sum(-1, keepdims=True)) * sc
+    refs = (np.einsum("bij,bcj->bci", p, v), np.einsum("bij,bcj->bci", ds, k), np.einsum("bij,bci->bcj", ds, q), np.einsum("bci,bij->bcj", g, p))
+
+    def run():
+        qd, kd, vd = dev(q, True), dev(k, True), dev(v, True)
+        with ops.KernelTimer() as kt:
+            o = ops.softmax_attention(qd, kd, vd, float(sc))
+            o.backward(dev(g))
+        return (o.detach(), qd.grad, kd.grad, vd.grad), set(kt.summary())
+    saved, tags = run()
+    assert "corr_softmax_warp_recompute" not in tags
+    monkeypatch.setattr(ops, "MAX_SAVED_LOGITS_BYTES", 0)
+    monkeypatch.setattr(ops, "RECOMPUTE_CHUNK_BYTES", B * Nq * 128 * 4)
+    chunked, tags = run()
+    assert "corr_softmax_warp_recompute" in tags
+    for a, b, r, what in zip(chunked, saved, refs, ("out", "dq", "dk", "dv")):
+        assert rel(a, r) < TOL, what
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), what
+
+
 @pytest.mark.parametrize("qmag,kmag,vmag", [(4e5, 1.5e4, 1e4), (3e3, 2e3, 1.0), (40.0, 30.0, 5.0)])
 def test_softmax_attention_is_finite_and_exact_at_any_logit_magnitude(qmag, kmag, vmag, monkeypatch):
     """Round 4 (found by the BASELINE config 3 generator, cocosnet_amd/translation.py): a randomly initialised SPADEGenerator feeds

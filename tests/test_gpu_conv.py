@@ -167,13 +167,17 @@ def test_patchgan_stack_on_hip_convs_matches_the_framework():
         assert (a - r).abs().max().item() <= 2e-4 * max(r.abs().max().item(), 1e-6), (a.shape, (a - r).abs().max().item())
 
 
-def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False):     # smooth_adaptors: ALL kinks
+def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False, forced=False):     # smooth_adaptors: ALL kinks
     """The whole drop-in module — adaptors with SPADE blocks, feature_normalize, four ResidualBlocks, theta / phi, AND the hot
     path behind them — in one graph: ours (every convolution / norm / correlation kernel on HIP, `arm` = f16x3 | bf16 | torch)
     against a torch-FP64 copy of the same module (same parameters and buffers; framework ops in double up to theta / phi, the
     oracle's restatement of correspondence.py:272-372 in double from there on).  Returns {arm: {name: relative error}} for
-    features, outputs and parameter gradients of loss = sum_k <out_k, G_k>."""
+    features, outputs and parameter gradients of loss = sum_k <out_k, G_k>.
+    forced: the fp64 copy RECORDS the branch of every LeakyReLU / PReLU / ReLU / max-pool element (cocosnet_amd/_kinks.py) and the
+    fp32 arms are evaluated ON THAT PATTERN (their kernels run with the slope at 1, the recorded pattern is the multiplier);
+    errs[arm]["#flips"] = [elements whose own branch differed, elements]."""
     import copy
+    from cocosnet_amd import _kinks
     from cocosnet_amd import correspondence as cc
     from cocosnet_amd import ops
     from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
@@ -213,6 +217,8 @@ def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False):     # 
     # ---- the fp64 arbiter -------------------------------------------------------------------------------------------------
     net64 = copy.deepcopy(net).double()
     d = lambda t: t.double()
+    tape = _kinks.KinkTape() if forced else None
+    monkeypatch.setattr(_kinks, "TAPE", tape)
     th64, ph64 = net64.project(d(img), d(real), d(seg), d(ref_seg))
     out64 = tr.hot_path(th64, ph64, d(img), d(real), d(seg), d(ref_seg), cfg)
     keys = sorted(out64)
@@ -225,6 +231,8 @@ def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False):     # 
     def arm(backend):
         monkeypatch.setattr(ops, "CONV_PRECISION", backend)
         net.zero_grad()
+        if tape is not None:
+            tape.rewind("replay")
         th, ph = net.project(img, real, seg, ref_seg)
         out = correspondence_hot_path(th, ph, img, real, seg, ref_seg, cfg)
         assert sorted(out) == keys
@@ -232,8 +240,15 @@ def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False):     # 
         got = {"theta_raw": th.detach(), "phi_raw": ph.detach()}
         got.update({k: out[k].detach() for k in keys})
         got.update({"d " + n: f(net).grad.clone() for n, f in probes.items()})
-        return {k: float((got[k].double() - want[k]).abs().max() / (want[k].abs().max() + 1e-300)) for k in want}
-    return {b: arm(b) for b in ("f16x3", "torch", "bf16")}
+        e = {k: float((got[k].double() - want[k]).abs().max() / (want[k].abs().max() + 1e-300)) for k in want}
+        if tape is not None:
+            assert tape.pos == len(tape.masks), (tape.pos, len(tape.masks))
+            e["#flips"] = [sum(tape.flips), tape.elements]
+        return e
+    try:
+        return {b: arm(b) for b in ("f16x3", "torch", "bf16")}
+    finally:
+        _kinks.TAPE = None
 
 
 E2E_FLAGS = {
@@ -246,35 +261,49 @@ E2E_FLAGS = {
 }
 
 
-#: gradients of the adaptors' strided layers 1-4: each sits UPSTREAM of InstanceNorm -> LeakyReLU(0.2) kinks whose branch an fp32
-#: evaluation and an fp64 evaluation can take differently (see the test below)
-_KINK_PROBES = ("d adaptive_model_img.layer1.0.weight_orig", "d adaptive_model_img.layer4.0.weight_orig",
-                "d adaptive_model_seg.layer2.0.weight_orig")
+def _is_kinked(probe: str) -> bool:
+    """Parameter gradients that sit UPSTREAM of an InstanceNorm / PONO -> LeakyReLU / PReLU / ReLU site are discontinuous functions
+    of the features: every probed `d ...` except theta's and phi's own (everything between those and the loss is smooth)."""
+    return probe.startswith("d ") and probe not in ("d theta.weight", "d phi.bias")
 
 
 @pytest.mark.parametrize("name", sorted(E2E_FLAGS))
 def test_module_end_to_end_against_an_fp64_copy_of_itself(name, monkeypatch):
-    """VERDICT r3 weak 1a / 1b.  project() + the hot path in ONE graph against torch-fp64: features, outputs AND parameter
-    gradients within north_star's 1e-3 for the default flavour (f16x3 convolutions); the framework-fp32 arm (`torch`: MIOpen
-    convolutions, framework norms, our hot path) is the yardstick of what fp32 arithmetic itself loses; the bf16 arm's figures are
-    REPORTED (printed here, collected into profiles/ by tools/final_artifacts.sh) — they are what bench.py's `module_scope.bf16`
-    number has to be read with.
+    """VERDICT r3 weak 1a / 1b.  project() + the hot path in ONE graph against torch-fp64, as the PRODUCT runs it (every site its
+    fused kernel): features, outputs and the gradients of theta / phi within north_star's 1e-3 for the default flavour (f16x3
+    convolutions); the framework-fp32 arm (`torch`: MIOpen convolutions, our norms and hot path) is the yardstick of what fp32
+    arithmetic itself loses; the bf16 arm's figures are REPORTED (printed here, collected into profiles/ by tools/final_artifacts.sh).
 
-    One class of probes cannot be held to 1e-3 against fp64 by ANY fp32 implementation, the reference's own included: the
-    gradients of the adaptors' strided layers.  Behind each of them sits InstanceNorm -> LeakyReLU(0.2); a normalised value
-    within fp32 rounding of zero takes the other branch than in fp64, and ONE such element changes d weight by up to 2e-2 of
-    its range (measured: tools/adaptor_grad_bisect.py — the identical 1.9e-2 with every convolution, norm and activation on the
-    framework's own kernels, 2e-6 everywhere once the slope is 1; tools/k13_check.py — planes with |mean| >> std: 0.15 for
-    K13 AND for F.instance_norm + F.leaky_relu).  Those probes are therefore (i) reported and sanity-bounded here and (ii)
-    held to 1e-3 in the twin test below, where the kinks are taken out of the adaptors."""
+    Every OTHER parameter gradient sits upstream of InstanceNorm -> LeakyReLU(0.2) / PReLU kinks: a normalised value within fp32
+    rounding of zero takes the other branch than in fp64, and ONE such element (the twin test below counts 0-3 of 9.1 M per arm) moves
+    d weight by 1e-3 .. 6e-2 of its range — for any fp32 implementation, the framework's included (round 5: with the operand split
+    rounding to nearest instead of truncating, OTHER elements flip than in round 4 and probes that had passed at 1e-3 by luck no longer
+    did, on the framework arm just as on ours).  Those gradients are therefore reported and sanity-bounded here, and HELD to 1e-3 in
+    test_module_end_to_end_every_gradient_on_the_fp64_branch_pattern, where both evaluations take the same branches."""
     errs = _module_e2e(monkeypatch, E2E_FLAGS[name])
     import json
     print("E2E_FP64", name, json.dumps(errs))
-    bad = {k: v for k, v in errs["f16x3"].items() if k not in _KINK_PROBES and not v < 1e-3}
+    bad = {k: v for k, v in errs["f16x3"].items() if not _is_kinked(k) and not v < 1e-3}
     assert not bad, (bad, {k: errs["torch"][k] for k in bad})
-    assert all(errs["f16x3"][k] < 0.1 for k in _KINK_PROBES), {k: errs["f16x3"][k] for k in _KINK_PROBES}
+    assert all(v < 0.1 for k, v in errs["f16x3"].items() if _is_kinked(k)), errs["f16x3"]
     # the one-term flavour is not held to 1e-3 (it is not parity-qualified: DESIGN.md §3.6); it must be finite and sane
     assert all(v < 0.6 for v in errs["bf16"].values()), errs["bf16"]
+
+
+@pytest.mark.parametrize("name", sorted(E2E_FLAGS))
+def test_module_end_to_end_every_gradient_on_the_fp64_branch_pattern(name, monkeypatch):
+    """the kink probes MEASURED instead of bounded at 0.1.  The fp64 copy records which branch every
+    LeakyReLU / PReLU / ReLU element (and every 2x2 max-pool window) takes; the fp32 arms run their production kernels with the
+    activation's slope at 1 and apply the recorded pattern (cocosnet_amd/_kinks.py), so that the comparison is between two evaluations
+    of the SAME piecewise-linear function.  On that footing EVERY probed gradient of the default flavour is within north_star's 1e-3
+    — the adaptors' strided layers included, and celebaedge_mk1's layer1.0 (4.5e-3 on this arm, 9e-6 on the framework arm in round 4:
+    ONE element of the f16x3 arm's own flips, see the printed counts).  The counts say how many elements each fp32 arm would have
+    put on the other branch than fp64."""
+    errs = _module_e2e(monkeypatch, E2E_FLAGS[name], forced=True)
+    import json
+    print("E2E_FP64_FORCED", name, json.dumps(errs))
+    bad = {k: v for k, v in errs["f16x3"].items() if k != "#flips" and not v < 1e-3}
+    assert not bad, (bad, {k: errs["torch"][k] for k in bad}, errs["f16x3"]["#flips"])
 
 
 def test_module_end_to_end_against_fp64_every_gradient_without_the_adaptor_kinks(monkeypatch):
@@ -559,15 +588,14 @@ def test_conv2d_nhwc_shape_sweep_vs_fp64(case, prec, tol, monkeypatch):
 
 
 # ------------------------------------------------------------------ BASELINE config 3: SPADE generator + PatchGAN on the HIP kernels
-def test_config3_generator_and_patchgan_against_fp64_copies(monkeypatch):
+def _config3_vs_fp64(monkeypatch, forced, arms=("f16x3", "torch", "bf16")):
     """cocosnet_amd.translation.{SPADEGenerator, MultiscaleDiscriminator} with the CelebA-HQ edge training flags (README.md:106)
-    at 256x256: forward AND parameter gradients of both networks, every convolution / SPADE / InstanceNorm / attention kernel on
-    HIP, against fp64 copies of the same modules evaluated by the framework.  Default flavour (f16x3): outputs within north_star's
-    1e-3; gradients reported and bounded (they sit behind LeakyReLU kinks after InstanceNorm / PONO: see
-    test_module_end_to_end_against_an_fp64_copy_of_itself).  bf16 (the precision BASELINE config 3 names): reported."""
+    at 256x256: forward AND parameter gradients of both networks against fp64 copies of the same modules evaluated by the framework.
+    Arms: f16x3 (default: every convolution / SPADE / InstanceNorm / attention kernel on HIP), torch (the framework's fp32
+    convolutions under the same norms — the yardstick of what fp32 arithmetic itself loses), bf16 (reported).  forced: every arm on
+    the fp64 copy's branch pattern (cocosnet_amd/_kinks.py); errs[arm]["#flips"] = [own branches that differed, elements]."""
     import copy
-    import json
-    from cocosnet_amd import ops, translation as tl
+    from cocosnet_amd import _kinks, ops, translation as tl
     opt = tl.celebahq_edge_train_options()
     torch.manual_seed(0)
     G = tl.SPADEGenerator(opt).cuda(); G.init_weights(opt.init_type, opt.init_variance); G.eval()
@@ -595,15 +623,45 @@ def test_config3_generator_and_patchgan_against_fp64_copies(monkeypatch):
         out.update({"d G." + k: f(Gm).grad.clone() for k, f in gprobes.items()})
         out.update({"d D." + k: f(Dm).grad.clone() for k, f in dprobes.items()})
         return out
-    want = run(copy.deepcopy(G).double(), copy.deepcopy(D).double(), torch.float64)
-    errs = {}
-    for flavour in ("f16x3", "bf16"):
-        monkeypatch.setattr(ops, "CONV_PRECISION", flavour)
-        got = run(G, D, torch.float32)
-        errs[flavour] = {k: float((got[k].double() - want[k]).abs().max() / (want[k].abs().max() + 1e-300)) for k in want}
+    tape = _kinks.KinkTape() if forced else None
+    monkeypatch.setattr(_kinks, "TAPE", tape)
+    try:
+        want = run(copy.deepcopy(G).double(), copy.deepcopy(D).double(), torch.float64)
+        errs = {}
+        for flavour in arms:
+            monkeypatch.setattr(ops, "CONV_PRECISION", flavour)
+            if tape is not None:
+                tape.rewind("replay")
+            got = run(G, D, torch.float32)
+            errs[flavour] = {k: float((got[k].double() - want[k]).abs().max() / (want[k].abs().max() + 1e-300)) for k in want}
+            if tape is not None:
+                assert tape.pos == len(tape.masks), (tape.pos, len(tape.masks))
+                errs[flavour]["#flips"] = [sum(tape.flips), tape.elements]
+    finally:
+        _kinks.TAPE = None
+    return errs
+
+
+def test_config3_generator_and_patchgan_against_fp64_copies(monkeypatch):
+    """Config 3 as the product runs it.  Default flavour (f16x3): outputs within north_star's 1e-3; the gradients sit behind
+    LeakyReLU / ReLU kinks after InstanceNorm / PONO, so they are printed next to the framework-fp32 arm's here and HELD to 1e-3
+    in the twin test below, where both evaluations are on the fp64 copy's branch pattern.  bf16: reported."""
+    import json
+    errs = _config3_vs_fp64(monkeypatch, forced=False)
     print("CFG3_FP64", json.dumps(errs))
     e = errs["f16x3"]
     assert all(e[k] < 1e-3 for k in ("fake_image", "D0_logits", "D1_logits", "D0_feat2")), e
     grads = sorted(v for k, v in e.items() if k.startswith("d "))
-    assert grads[-1] < 0.05, e            # (behind LeakyReLU / ReLU kinks: 1e-6 .. 3e-3 measured, see the docstring)
+    assert grads[-1] < 0.05, e            # (kinks: a sanity bound; the measured comparison is the twin test)
     assert all(v < 1.0 for v in errs["bf16"].values()), errs["bf16"]
+
+
+def test_config3_every_gradient_on_the_fp64_branch_pattern(monkeypatch):
+    """the same comparison with every fp32 arm evaluated on the fp64 copy's branch pattern (LeakyReLU after
+    InstanceNorm / PONO-SPADE, SPADE's ReLU, the Attention blocks' max-pools): every probed gradient of the default flavour within
+    1e-3, with the framework-fp32 arm beside it."""
+    import json
+    errs = _config3_vs_fp64(monkeypatch, forced=True, arms=("f16x3", "torch"))
+    print("CFG3_FP64_FORCED", json.dumps(errs))
+    bad = {k: v for k, v in errs["f16x3"].items() if k != "#flips" and not v < 1e-3}
+    assert not bad, (bad, {k: errs["torch"][k] for k in bad}, errs["f16x3"]["#flips"])
