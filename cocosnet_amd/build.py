@@ -49,6 +49,7 @@ HIP_SOURCES = [
     "upsample_nearest.hip",
     "warp_values.hip",
     "contextual_rows.hip",
+    "contextual_fused_f16x3.hip",
     "conv_f16x3.hip",
     "conv_nhwc_bf16.hip",
     "spade_modulate.hip",

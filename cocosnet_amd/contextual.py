@@ -5,10 +5,12 @@ path (pix2pix_model.py get_ctx_loss: VGG relu features of the generated image ag
 constructor and `forward(X_features, Y_features, h=0.1, feature_centering=True)` signature; returns the per-sample loss.
 
     centring + x / (||x||_2 + eps)       K1 (`ops.center_l2norm`, mode 2 after the reference's own centring)   :108-116
-    cos = X^T Y                          K3 (`ops.corr_materialize`, split-precision GEMM)                     :121
-    d, d_norm, w, A, max_j A             K15 (`ops.contextual_rows`: one pass over the [N, N] matrix)          :121-132
+    cos = X^T Y, d, d_norm, w, A, max_j A   K22 (`ops.contextual_cx`: the cosine tiles stay in the accumulators — a row-maximum sweep,
+                                         then a sum sweep at the row's own temperature; its backward recomputes them)  :121-132
     CX = mean_i, loss = -log CX          host (B numbers)                                                      :132-133
-CPU tensors take the reference's formulation in torch (used by the CPU parity test only).
+Round 2's route (K3 `ops.corr_materialize` -> K15 `ops.contextual_rows` on the [B, N, N] cosine matrix, <= 4096 keys) is still
+exported for callers that hold a cosine matrix; this class no longer uses it and has no size limit and no framework fallback on a
+GPU.  CPU tensors take the reference's formulation in torch (used by the CPU parity test only).
 """
 from __future__ import annotations
 
@@ -43,10 +45,11 @@ class ContextualLoss_forward(nn.Module):
             X_features, Y_features = X_features - mu, Y_features - mu
         Xn = _feature_normalize(X_features).reshape(B, C, -1)                                  # :115-116
         Yn = _feature_normalize(Y_features).reshape(B, C, -1)
-        if Xn.is_cuda and Xn.dtype == torch.float32 and Yn.shape[2] <= 4096:
-            cos = ops.corr_materialize(Xn.contiguous(), Yn.contiguous(), 1.0)                  # :121 (K3)
-            cx = ops.contextual_rows(cos, h, 1e-3)                                             # :121-132 (K15)
+        if Xn.is_cuda and Xn.dtype == torch.float32:
+            # K22: cosine tiles -> row maximum -> per-row temperature -> sums, all in registers; any N, any C, nothing [N, N] in HBM
+            cx = ops.contextual_cx(Xn.contiguous(), Yn.contiguous(), h, 1e-3)                  # :121-132
             return -torch.log(cx.mean(dim=1))                                                  # :132-133
+        # CPU / non-fp32 tensors: the reference's formulation in torch (the CPU parity test and the fp64 arbiter of the GPU tests)
         d = 1 - torch.matmul(Xn.permute(0, 2, 1), Yn)
         d_norm = d / (torch.min(d, dim=-1, keepdim=True)[0] + 1e-3)
         w = torch.exp((1 - d_norm) / h)

@@ -2100,6 +2100,91 @@ def contextual_rows(cosm, h: float = 0.1, eps: float = 1e-3):
     return _ContextualRows.apply(cosm, h, eps)
 
 
+# ------------------------------------------------------------------------------------------
+# K22 the contextual loss without its [N, N] matrices   (ContextualLoss.py:121-133; contextual_fused_f16x3.hip)
+# ------------------------------------------------------------------------------------------
+CX_TILE = 128     # positions per workgroup / inner tile of K22: the planes are padded to whole tiles
+
+
+def _cx_pad_positions(x: torch.Tensor) -> torch.Tensor:
+    n = x.shape[2]
+    npad = (n + CX_TILE - 1) // CX_TILE * CX_TILE
+    return x if npad == n else torch.nn.functional.pad(x, (0, npad - n))
+
+
+class _ContextualCx(torch.autograd.Function):
+    """cx[b,i] = max_j A_ij of the contextual affinity of two sets of normalised features xn [B,C,Nq], yn [B,C,Nk]:
+    1 / sum_j exp((cos_ij - m_i) tau_i).  Forward: one launch of K22 (two sweeps over the keys).  Backward: one launch per side
+    (the cosine tiles are recomputed) + the argmax column's term as a gather (d xn) / scatter-add (d yn).  Nothing [Nq, Nk]
+    exists at any point; saved for the backward: the operand planes (the size of the features) and four numbers per query."""
+
+    @staticmethod
+    def forward(ctx, xn, yn, h: float, eps: float):
+        xn, yn = _chk(xn, "contextual_cx: xn"), _chk(yn, "contextual_cx: yn")
+        B, C, Nq = xn.shape
+        if yn.dim() != 3 or yn.shape[:2] != (B, C):
+            raise ValueError(f"contextual_cx: shape mismatch xn{tuple(xn.shape)} yn{tuple(yn.shape)}")
+        Nk = yn.shape[2]
+        kp = (C + 31) // 32 * 32
+        xp, yp = _cx_pad_positions(xn), _cx_pad_positions(yn)
+        xa, ya = absmax(xn), absmax(yn)
+        xh, xl, xs = split_f16(xp, True, cpad=kp, amax=xa)          # [B, Nqp, Kp]
+        yh, yl, ys = split_f16(yp, True, cpad=kp, amax=ya)
+        f32 = dict(device=xn.device, dtype=torch.float32)
+        m, S, U = (torch.empty((B, Nq), **f32) for _ in range(3))
+        jstar = torch.empty((B, Nq), device=xn.device, dtype=torch.int32)
+        _call("contextual_cx_fwd", "cocos_contextual_cx_fwd_f16x3", xh.data_ptr(), xl.data_ptr(), yh.data_ptr(), yl.data_ptr(),
+              xs.data_ptr(), ys.data_ptr(), m.data_ptr(), S.data_ptr(), U.data_ptr(), jstar.data_ptr(), B, Nq, Nk, xp.shape[2],
+              yp.shape[2], kp, float(h), float(eps), _stream())
+        ctx.save_for_backward(xn, yn, m, S, U, jstar)
+        ctx.planes = (xh, xl, xs, xa, yh, yl, ys, ya)
+        ctx.cfg = (float(h), float(eps))
+        return 1.0 / S
+
+    @staticmethod
+    def backward(ctx, dcx):
+        xn, yn, m, S, U, jstar = ctx.saved_tensors
+        xh, xl, xs, xa, yh, yl, ys, ya = ctx.planes
+        h, eps = ctx.cfg
+        dcx = _chk(dcx, "contextual_cx: dcx")
+        B, C, Nq = xn.shape
+        Nk = yn.shape[2]
+        kp, nqp, nkp = xh.shape[2], xh.shape[1], yh.shape[1]
+        need_x, need_y = ctx.needs_input_grad[:2]
+        # per query (tiny [B, Nq] tensors): d loss / d S, the temperature, the coefficient of e_ij and the argmax column's extra term
+        dS = -dcx / (S * S)
+        tau = 1.0 / (h * (1.0 - m + eps))
+        a = (dS * tau).contiguous()
+        extra = dS * (h * tau * tau * U - tau * S)        # through m_i and tau(m_i): lands on column j*_i only
+        t2 = (tau * 1.4426950408889634).contiguous()
+        jl = jstar.long().unsqueeze(1).expand(B, C, Nq)
+        st = _stream()
+        dx = dy = None
+        if need_x:     # rows = queries, inner = keys, values = yn (channel-major), (m, t) and beta = a per row
+            vh, vl, vs = split_f16(_cx_pad_positions(yn), False, amax=ya)
+            dx = torch.empty_like(xn)
+            _call("contextual_cx_bwd", "cocos_contextual_cx_bwd_f16x3", xh.data_ptr(), xl.data_ptr(), yh.data_ptr(), yl.data_ptr(),
+                  vh.data_ptr(), vl.data_ptr(), xs.data_ptr(), ys.data_ptr(), vs.data_ptr(), None, m.data_ptr(), t2.data_ptr(), None,
+                  a.data_ptr(), dx.data_ptr(), B, Nq, Nk, nqp, nkp, kp, C, 1, 1.0, st)
+            dx.add_(extra.unsqueeze(1) * yn.gather(2, jl))
+        if need_y:     # rows = keys, inner = queries, values = xn, (m, t) and alpha = a / max|a| per inner position
+            amax_a = a.abs().amax().clamp_min(1e-30).reshape(1)
+            alpha = (a / amax_a).contiguous()
+            vh, vl, vs = split_f16(_cx_pad_positions(xn), False, amax=xa)
+            dy = torch.empty_like(yn)
+            _call("contextual_cx_bwd", "cocos_contextual_cx_bwd_f16x3", yh.data_ptr(), yl.data_ptr(), xh.data_ptr(), xl.data_ptr(),
+                  vh.data_ptr(), vl.data_ptr(), ys.data_ptr(), xs.data_ptr(), vs.data_ptr(), amax_a.data_ptr(), m.data_ptr(),
+                  t2.data_ptr(), alpha.data_ptr(), None, dy.data_ptr(), B, Nk, Nq, nkp, nqp, kp, C, 0, 1.0, st)
+            dy.scatter_add_(2, jl, extra.unsqueeze(1) * xn)
+        return dx, dy, None, None
+
+
+def contextual_cx(xn, yn, h: float = 0.1, eps: float = 1e-3):
+    """cx [B,Nq] = max_j A_ij of the contextual affinity (ContextualLoss.py:121-132) of normalised features xn [B,C,Nq],
+    yn [B,C,Nk] — any Nq, Nk, C; no [Nq, Nk] tensor in HBM, forward or backward (K22)."""
+    return _ContextualCx.apply(xn, yn, float(h), float(eps))
+
+
 def mfma_probe() -> torch.Tensor:
     """Debug: the 64x16 accumulator image of one v_mfma_f32_32x32x2_f32 (see api_common.hip)."""
     out = torch.empty((64, 16), device="cuda", dtype=torch.float32)

@@ -494,6 +494,34 @@ int cocos_contextual_rows_bwd(const float* cosm, const float* dcx, float* dcos, 
                               float eps, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * K22 the contextual loss WITHOUT its [N, N] matrices (round 5; replaces cocos_corr_materialize + K15 inside
+ *     ContextualLoss_forward.forward, models/networks/ContextualLoss.py:93-137, for any N and C):
+ *       cx[i] = 1 / S_i,  S_i = sum_j exp((cos_ij - m_i) tau_i),  m_i = max_j cos_ij,  tau_i = 1 / (h (1 - m_i + eps))
+ *     forward: one launch, a workgroup owns 128 queries and sweeps the keys twice (maximum, then sums); each sweep is a K = C
+ *     GEMM on the f16 MFMA with split operands (three terms, fp32 accumulate), the cosine tile never leaves the registers.
+ *     backward: G_ij = a_i e_ij (+ a term on column argmax_j only, which the caller applies as a gather / scatter-add):
+ *       d Xn[:, i] = sum_j G_ij Yn[:, j],   d Yn[:, j] = sum_i G_ij Xn[:, i]
+ *     — one launch per side; per 128 x 128 tile the cosines are recomputed, exponentiated, written to LDS as f16 hi / lo planes
+ *     and multiplied with the other side's channel-major planes (256 output channels per workgroup).
+ *   Planes: position-major [B][Np][Kp] f16 hi / lo of the normalised features times a power-of-two device scale
+ *   (cocos_split_f16_ex), Np % 128 == 0, Kp % 32 == 0, zero beyond the real positions / channels; channel-major value planes
+ *   [B][Cv][Nip].  All statistics fp32 [B][N].
+ * ------------------------------------------------------------------------------------- */
+int cocos_contextual_cx_fwd_f16x3(const void* xh, const void* xl, const void* yh, const void* yl, const float* x_scale_dev,
+                                  const float* y_scale_dev, float* m_out /* max_j cos */, float* s_out /* S */,
+                                  float* u_out /* sum_j e_ij (cos_ij - m_i) */, int* j_out /* argmax_j, first */, int B, int Nq,
+                                  int Nk, int Nqp, int Nkp, int Kp, float h, float eps, cocos_stream_t stream);
+/* out[b][ch][r] = host_scale * (*mul_dev) * beta[r] * sum_c alpha[c] exp2((cos_rc - m) t) V[ch][c];  (m, t = tau log2 e) per QUERY:
+ * indexed by r when stats_on_rows (rows = queries, inner = keys: d Xn), by c otherwise (rows = keys, inner = queries: d Yn).
+ * |alpha| <= 1 (the caller normalises and passes the factor in mul_dev); alpha, beta, mul_dev nullable = 1. */
+int cocos_contextual_cx_bwd_f16x3(const void* rh, const void* rl, const void* ih, const void* il, const void* vh, const void* vl,
+                                  const float* r_scale_dev, const float* i_scale_dev, const float* v_scale_dev,
+                                  const float* mul_dev /* nullable */, const float* m, const float* t,
+                                  const float* alpha /* nullable */, const float* beta /* nullable */, float* out, int B, int Nr,
+                                  int Ni, int Nrp, int Nip, int Kp, int Cv, int stats_on_rows, float host_scale,
+                                  cocos_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * K18 nn.ReflectionPad2d(pad) and its backward: the pad in front of the 3x3 convolutions of ResidualBlock
  *     (correspondence.py:19,:23), SPADE (normalization.py:118,:146) and SPADEResnetBlock (architecture.py:30).
  *   fwd: x [planes,H,W] -> y [planes,H+2pad,W+2pad];  bwd: dy -> dx as a gather (no atomics).  pad < H, W.

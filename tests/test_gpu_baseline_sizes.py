@@ -519,11 +519,14 @@ def test_attention_block_on_hip_matches_torch_fp64(B, ch, H, W):
         assert rel(p.grad, q.grad.numpy()) < TOL, n
 
 
-@pytest.mark.parametrize("B,C,h,w,pono", [(2, 512, 32, 32, True), (2, 256, 16, 16, False), (1, 64, 64, 64, True), (1, 48, 9, 7, False)])
+@pytest.mark.parametrize("B,C,h,w,pono", [(2, 512, 32, 32, True), (2, 256, 16, 16, False), (1, 64, 64, 64, True), (1, 48, 9, 7, False),
+                                          (2, 128, 32, 32, True), (1, 300, 20, 13, False), (3, 512, 16, 16, True)])
 def test_contextual_loss_forward_matches_the_reference_formula(B, C, h, w, pono):
-    """`ContextualLoss_forward.forward` (ContextualLoss.py:93-137) on K1 + K3 + K15 against the reference's formulation
+    """`ContextualLoss_forward.forward` (ContextualLoss.py:93-137) on K1 + K22 against the reference's formulation
     in torch fp64: per-sample loss and the gradient w.r.t. the generated features X (the exemplar side Y is detached in
-    the caller, pix2pix_model.py get_ctx_loss; checked here too)."""
+    the caller, pix2pix_model.py get_ctx_loss; checked here too).  The shapes of get_ctx_loss at 256^2 (relu5_1 16x16x512,
+    relu4_1 32x32x512, pooled relu3_1 32x32x256, pooled relu2_1 32x32x128) and ragged ones (positions and channels padded to the
+    kernel's 128 / 32 inside the op)."""
     from types import SimpleNamespace
     from cocosnet_amd.contextual import ContextualLoss_forward
     g = torch.Generator(device=DEV).manual_seed(C + h)
@@ -541,6 +544,90 @@ def test_contextual_loss_forward_matches_the_reference_formula(B, C, h, w, pono)
     errs = (rel(loss, lr.detach().numpy()), rel(xa.grad, xr.grad.numpy()), rel(ya.grad, yr.grad.numpy()))
     print("CTX_FP64", (B, C, h, w, pono), errs)
     assert errs[0] < 2e-5 and errs[1] < 5e-5 and errs[2] < 5e-5, errs      # (measured 1e-8 .. 4e-6; VERDICT r3 weak 1c: was 1e-3 / 2e-3)
+
+
+def _ctx_case(B, C, N, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    Y = torch.randn(B, C, N, device=DEV, generator=g) + 0.3
+    perm = torch.randperm(N, device=DEV, generator=g)
+    X = 0.6 * Y[:, :, perm] + torch.randn(B, C, N, device=DEV, generator=g)
+    return X, Y
+
+
+def test_contextual_loss_at_4096_positions_and_512_channels(monkeypatch):
+    """VERDICT r4 item 4 ("done when"): N = 4096, C = 512 (relu4_1 at 512^2) — the per-sample loss and BOTH gradients against the
+    reference's formulation in fp64 (on the device), with the framework's matmul and the round-2 materialised route (K3 + K15)
+    poisoned: K22 is the only thing that may run.  Peak memory of the whole forward + backward (centring, normalisation, operand
+    planes, both gradients) is a fixed number of FEATURE-sized tensors — measured 7.6, bounded at 10 — with no term in N^2 (at this
+    shape a feature tensor is C / N = 1/8 of an [N, N] matrix; the round-2 route held two such matrices on top, the reference's
+    formulation five; test_contextual_cx_beyond_the_old_4096_key_cap shows the same at N = 12288, where [N, N] is 576 MiB)."""
+    from types import SimpleNamespace
+    from cocosnet_amd import ops
+    from cocosnet_amd.contextual import ContextualLoss_forward
+
+    def poisoned(*a, **k):
+        raise AssertionError("the contextual loss must not materialise a cosine matrix")
+    monkeypatch.setattr(ops, "corr_materialize", poisoned)
+    monkeypatch.setattr(ops, "contextual_rows", poisoned)
+    B, C, N = 2, 512, 4096
+    X, Y = _ctx_case(B, C, N, 77)
+    X, Y = X.reshape(B, C, 64, 64), Y.reshape(B, C, 64, 64)
+    mod = ContextualLoss_forward(SimpleNamespace(PONO=True))
+    xr, yr = X.double().requires_grad_(True), Y.double().requires_grad_(True)
+    lr = mod(xr, yr, h=0.1)                   # fp64 tensors: the reference's formulation in torch, on the device
+    lr.sum().backward()
+    want = (lr.detach().cpu().numpy(), xr.grad.cpu().numpy(), yr.grad.cpu().numpy())
+    del xr, yr, lr
+    torch.cuda.empty_cache()
+    xa, ya = X.clone().requires_grad_(True), Y.clone().requires_grad_(True)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with ops.KernelTimer() as kt:
+        loss = mod(xa, ya, h=0.1)
+        loss.sum().backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert {"contextual_cx_fwd", "contextual_cx_bwd"} <= set(kt.summary())
+    errs = (rel(loss, want[0]), rel(xa.grad, want[1]), rel(ya.grad, want[2]))
+    feat = B * C * N * 4
+    print("CTX_FP64_4096", errs, "peak MiB", peak >> 20, "= %.1f feature tensors;" % (peak / feat), "[B,N,N] fp32 MiB", (B * N * N * 4) >> 20,
+          {k: round(v["total_ms"], 3) for k, v in kt.summary().items()})
+    assert errs[0] < 2e-5 and errs[1] < 5e-5 and errs[2] < 5e-5, errs
+    assert peak < 10 * feat, (peak, feat)
+
+
+def test_contextual_cx_beyond_the_old_4096_key_cap():
+    """Round 2's K15 stopped at 4096 keys and the class fell through to framework ops above.  N = 12288
+    positions (a 96 x 128 feature map), C = 64: cx and the gradient w.r.t. X against fp64; extra memory of the op (planes,
+    statistics, the gradient) stays three orders of magnitude below the 576 MiB of ONE [N, N] fp32 matrix."""
+    from cocosnet_amd import ops
+    B, C, N = 1, 64, 12288
+    X, Y = _ctx_case(B, C, N, 5)
+    nrm = lambda t: t / (t.norm(dim=1, keepdim=True) + 2.2e-16)
+    Xn, Yn = nrm(X - Y.mean(1, keepdim=True)), nrm(Y - Y.mean(1, keepdim=True))
+    xr = Xn.double().requires_grad_(True)
+    d = 1 - torch.matmul(xr.transpose(1, 2), Yn.double())
+    dn = d / (d.min(-1, keepdim=True)[0] + 1e-3)
+    w_ = torch.exp((1 - dn) / 0.1)
+    cx_ref = (w_ / w_.sum(-1, keepdim=True)).max(-1)[0]
+    G = torch.randn(B, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+    (cx_ref * G.double()).sum().backward()
+    want = (cx_ref.detach().cpu().numpy(), xr.grad.cpu().numpy())
+    del d, dn, w_, cx_ref
+    torch.cuda.empty_cache()
+    xa = Xn.clone().requires_grad_(True)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    cx = ops.contextual_cx(xa, Yn, 0.1, 1e-3)
+    (cx * G).sum().backward()
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    errs = (rel(cx, want[0]), rel(xa.grad, want[1]))
+    print("CTX_FP64_12288", errs, "peak MiB", peak >> 20)
+    assert errs[0] < 2e-5 and errs[1] < 5e-5, errs
+    assert peak < 64 << 20, peak
 
 
 # ------------------------------------------------------------------ RCCL is at least initialised on the box
