@@ -105,6 +105,8 @@ def module_scope_context(device, d, steps=8, warmup=6):
                        "three-term f16 hi/lo on the NHWC / LDS-DMA kernels (K16c, default), bf16 = one term (K16b, COCOS_CONV=bf16); "
                        "err_vs_f16x3 = end-to-end max-norm deviation of warp_out / warp_mask on identical parameters: bf16 convolutions "
                        "upstream of the T = 0.01 softmax are a timing reference, not a parity-qualified result, unless it is < 1e-3")
+        if not out["bf16"].get("parity_qualified", False):      # no bf16 timing beside the qualified ones
+            out["unqualified"] = {"bf16": out.pop("bf16")}
     finally:
         ops.CONV_PRECISION = saved
     return out
@@ -255,7 +257,14 @@ def config3_context(device, steps=4, warmup=3):
         out["note"] = ("cocosnet_amd.translation.SPADEGenerator / MultiscaleDiscriminator, CelebA-HQ edge training flags, B = 16, 256x256, "
                        "forward + backward each; err_vs_fp64 = max-norm error of the generated image / the PatchGAN logits against an "
                        "fp64 copy of the same module (eval mode, 2 samples): bf16 is the precision BASELINE config 3 names for these two "
-                       "networks (behind InstanceNorm / SPADE, NOT upstream of the correlation)")
+                       "networks (behind InstanceNorm / SPADE, NOT upstream of the correlation).  Round 5: the only flavour within "
+                       "north_star's 1e-3 of fp64 is f16x3 — one f16 term is at 2.2e-3 on fake_image, two terms (activations split, weights "
+                       "one plane) at 1.4e-3 (generator) / 6e-4 (PatchGAN), bf16 at 1.6e-2: profiles/r05_conv_flavour_table.txt, all arms on "
+                       "the fp64 copy's branch pattern — so bf16 is listed under `unqualified`")
+        out["bf16"]["parity_qualified"] = bool(max(out["bf16"]["err_vs_fp64"].values()) < 1e-3)
+        out["f16x3"]["parity_qualified"] = bool(max(out["f16x3"]["err_vs_fp64"].values()) < 1e-3)
+        if not out["bf16"]["parity_qualified"]:
+            out["unqualified"] = {"bf16": out.pop("bf16")}
     finally:
         ops.CONV_PRECISION = saved
     return out

@@ -63,9 +63,11 @@ struct CfArgs {
 };
 
 // MODE 0: forward (rows = queries, two sweeps).  MODE 1: backward; STAT_ROWS: (m, t) belong to the rows (d Xn) or to the inner
-// index (d Yn).
-template <int MODE, bool STAT_ROWS>
+// index (d Yn).  NJ: 32-row tiles per wave — a workgroup owns BR = 64 NJ rows (128, or 64 when 128-row blocks would leave most of
+// the 256 CUs without a workgroup: get_ctx_loss's shapes are 8 samples x 256 .. 1024 positions).
+template <int MODE, bool STAT_ROWS, int NJ>
 __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
+    constexpr int BR = 64 * NJ, WR = 32 * NJ;       // rows per workgroup / per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
     _Float16* const stage = reinterpret_cast<_Float16*>(cf_smem);                     // [2][CF_G1]
     _Float16* const pimg = stage + 2 * CF_G1;                                         // [hi | lo][128 r][CF_PROW]
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, c = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;          // GEMM 1: inner half (M), row half (N)
-    const int b = blockIdx.y, r0 = blockIdx.x * CF_B;
+    const int b = blockIdx.y, r0 = blockIdx.x * BR;
     const int ch0 = MODE == 1 ? blockIdx.z * CF_CW : 0;
 
     const size_t rbytes = (size_t)a.Nrp * a.Kp * 2, ibytes = (size_t)a.Nip * a.Kp * 2;
@@ -90,16 +92,20 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
     const float sscale = 1.0f / (*a.s_r * *a.s_i);
     const int nk = a.Kp / CF_BK, ntile = a.Nip / CF_B;
 
-    // ---- GEMM 1 staging: 128 inner rows + 128 rows, 4 chunks of 16 B each and plane: 2 x 2 chunks per thread and plane ----
-    struct G1Regs { u32x4 ih[2], il[2], rh[2], rl[2]; };
+    // ---- GEMM 1 staging: 128 inner rows + BR rows, 4 chunks of 16 B each and plane: 2 resp. NJ chunks per thread and plane ----
+    struct G1Regs { u32x4 ih[2], il[2], rh[NJ], rl[NJ]; };
     auto g1_fetch = [&](G1Regs& g, int c0, int k0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int q = u * 256 + tid, row = q >> 2, kc = q & 3;
             const unsigned io = (unsigned)((c0 + row) * a.Kp + k0 + kc * 8) * 2u;
-            const unsigned ro = (unsigned)((r0 + row) * a.Kp + k0 + kc * 8) * 2u;
             g.ih[u] = __builtin_amdgcn_raw_buffer_load_b128(ih_rs, (int)io, 0, 0);
             g.il[u] = __builtin_amdgcn_raw_buffer_load_b128(il_rs, (int)io, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NJ; ++u) {
+            const int q = u * 256 + tid, row = q >> 2, kc = q & 3;
+            const unsigned ro = (unsigned)((r0 + row) * a.Kp + k0 + kc * 8) * 2u;
             g.rh[u] = __builtin_amdgcn_raw_buffer_load_b128(rh_rs, (int)ro, 0, 0);
             g.rl[u] = __builtin_amdgcn_raw_buffer_load_b128(rl_rs, (int)ro, 0, 0);
         }
@@ -112,17 +118,22 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
             const int o = row * CF_ROW + kc * 8;
             *reinterpret_cast<u32x4*>(s + o) = g.ih[u];
             *reinterpret_cast<u32x4*>(s + CF_PLANE + o) = g.il[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NJ; ++u) {
+            const int q = u * 256 + tid, row = q >> 2, kc = q & 3;
+            const int o = row * CF_ROW + kc * 8;
             *reinterpret_cast<u32x4*>(s + 2 * CF_PLANE + o) = g.rh[u];
             *reinterpret_cast<u32x4*>(s + 3 * CF_PLANE + o) = g.rl[u];
         }
     };
     // the cosine tile of inner positions c0 .. c0 + 127: acc[i][j][g] = raw accumulator of
-    //     inner  c0 + wm * 64 + i * 32 + acc_row_base(g) + 4 hh     x     row  r0 + wn * 64 + j * 32 + c
-    auto gemm1 = [&](f32x16 (&acc)[2][2], int c0) {
+    //     inner  c0 + wm * 64 + i * 32 + acc_row_base(g) + 4 hh     x     row  r0 + wn * WR + j * 32 + c
+    auto gemm1 = [&](f32x16 (&acc)[2][NJ], int c0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
         G1Regs g;
@@ -133,12 +144,12 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
             const int buf = kb & 1;
             if (kb + 1 < nk) g1_fetch(g, c0, (kb + 1) * CF_BK);
             const _Float16* ap = stage + buf * CF_G1 + (wm * 64 + c) * CF_ROW + hh * 8;
-            const _Float16* bp = stage + buf * CF_G1 + 2 * CF_PLANE + (wn * 64 + c) * CF_ROW + hh * 8;
+            const _Float16* bp = stage + buf * CF_G1 + 2 * CF_PLANE + (wn * WR + c) * CF_ROW + hh * 8;
 #pragma unroll
             for (int s = 0; s < CF_BK / 16; ++s) {
-                cf_f16x8 bh[2], bl[2];
+                cf_f16x8 bh[NJ], bl[NJ];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     bh[j] = *reinterpret_cast<const cf_f16x8*>(bp + j * 32 * CF_ROW + s * 16);
                     bl[j] = *reinterpret_cast<const cf_f16x8*>(bp + CF_PLANE + j * 32 * CF_ROW + s * 16);
                 }
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
                     const cf_f16x8 ah = *reinterpret_cast<const cf_f16x8*>(ap + i * 32 * CF_ROW + s * 16);
                     const cf_f16x8 al = *reinterpret_cast<const cf_f16x8*>(ap + CF_PLANE + i * 32 * CF_ROW + s * 16);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc[i][j], 0, 0, 0);
@@ -160,15 +171,17 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
     };
     auto inner_of = [&](int c0, int i, int g) { return c0 + wm * 64 + i * 32 + acc_row_base(g) + 4 * hh; };
 
-    if (MODE == 0) {
+    if constexpr (MODE == 0) {
         // ---------------- forward: sweep 1 (max, argmax), sweep 2 (S, U) ------------------------------------------------
-        float best[2] = {-INFINITY, -INFINITY};
-        int arg[2] = {0x7fffffff, 0x7fffffff};
-        f32x16 acc[2][2];
+        float best[NJ];
+        int arg[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { best[j] = -INFINITY; arg[j] = 0x7fffffff; }
+        f32x16 acc[2][NJ];
         for (int tI = 0; tI < ntile; ++tI) {
             gemm1(acc, tI * CF_B);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -182,32 +195,32 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
         auto pick = [](float& v, int& x, float ov, int ox) {
             if (ov > v || (ov == v && ox < x)) { v = ov; x = ox; }
         };
-        float m[2];
-        int jst[2];
+        float m[NJ];
+        int jst[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             pick(best[j], arg[j], __shfl_xor(best[j], 32, 64), __shfl_xor(arg[j], 32, 64));
             if (hh == 0) {
-                red[(wm * 2 + 0) * CF_B + wn * 64 + j * 32 + c] = best[j];
-                red[(wm * 2 + 1) * CF_B + wn * 64 + j * 32 + c] = __builtin_bit_cast(float, arg[j]);
+                red[(wm * 2 + 0) * CF_B + wn * WR + j * 32 + c] = best[j];
+                red[(wm * 2 + 1) * CF_B + wn * WR + j * 32 + c] = __builtin_bit_cast(float, arg[j]);
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int rr = wn * 64 + j * 32 + c;
+        for (int j = 0; j < NJ; ++j) {
+            const int rr = wn * WR + j * 32 + c;
             m[j] = red[0 * CF_B + rr];
             jst[j] = __builtin_bit_cast(int, red[1 * CF_B + rr]);
             pick(m[j], jst[j], red[2 * CF_B + rr], __builtin_bit_cast(int, red[3 * CF_B + rr]));
         }
         __syncthreads();
-        float t2[2], z[2] = {0.f, 0.f}, uu[2] = {0.f, 0.f};
+        float t2[NJ], z[NJ], uu[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) t2[j] = kLog2e / (a.h * (1.0f - m[j] + a.eps));
+        for (int j = 0; j < NJ; ++j) { t2[j] = kLog2e / (a.h * (1.0f - m[j] + a.eps)); z[j] = 0.f; uu[j] = 0.f; }
         for (int tI = 0; tI < ntile; ++tI) {
             gemm1(acc, tI * CF_B);          // (the same instruction sequence as sweep 1: bit-identical cosines, e = 1 at the argmax)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -220,19 +233,19 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
                     }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             z[j] += __shfl_xor(z[j], 32, 64);
             uu[j] += __shfl_xor(uu[j], 32, 64);
             if (hh == 0) {
-                red[(wm * 2 + 0) * CF_B + wn * 64 + j * 32 + c] = z[j];
-                red[(wm * 2 + 1) * CF_B + wn * 64 + j * 32 + c] = uu[j];
+                red[(wm * 2 + 0) * CF_B + wn * WR + j * 32 + c] = z[j];
+                red[(wm * 2 + 1) * CF_B + wn * WR + j * 32 + c] = uu[j];
             }
         }
         __syncthreads();
         if (wm == 0 && hh == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int rr = wn * 64 + j * 32 + c, r = r0 + rr;
+            for (int j = 0; j < NJ; ++j) {
+                const int rr = wn * WR + j * 32 + c, r = r0 + rr;
                 if (r < a.Nr) {
                     const size_t o = (size_t)b * a.Nr + r;
                     a.m_out[o] = m[j];
@@ -245,21 +258,20 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
         return;
     } else {
         // ---------------- backward ---------------------------------------------------------------------------------------
-        const int vm = wave >> 1, vn = wave & 1;     // GEMM 2: channel half (M, 128), row half (N, 64)
-        f32x16 acc2[4][2];
+        const int vm = wave >> 1, vn = wave & 1;     // GEMM 2: channel half (M, 128), row half (N, WR)
+        f32x16 acc2[4][NJ];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) acc2[i][j][g] = 0.f;
-        float mr[2] = {0.f, 0.f}, tr[2] = {0.f, 0.f};
-        if (STAT_ROWS) {
+        float mr[NJ], tr[NJ];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = r0 + wn * 64 + j * 32 + c;
-                if (r < a.Nr) { mr[j] = a.m[(size_t)b * a.Nr + r]; tr[j] = a.t[(size_t)b * a.Nr + r]; }
-            }
+        for (int j = 0; j < NJ; ++j) {
+            mr[j] = tr[j] = 0.f;
+            const int r = r0 + wn * WR + j * 32 + c;
+            if (STAT_ROWS && r < a.Nr) { mr[j] = a.m[(size_t)b * a.Nr + r]; tr[j] = a.t[(size_t)b * a.Nr + r]; }
         }
         struct G2Regs { u32x4 vh[4], vl[4]; };
         auto g2_fetch = [&](G2Regs& g, int c0, int kb) {
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
                 *reinterpret_cast<u32x4*>(s + CF_VPLANE + row * CF_ROW + kc * 8) = g.vl[u];
             }
         };
-        f32x16 acc[2][2];
+        f32x16 acc[2][NJ];
         for (int tI = 0; tI < ntile; ++tI) {
             const int c0 = tI * CF_B;
             // the inner tile's per-position numbers (read after the barriers inside gemm1)
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
             g2_fetch(g2, c0, 0);              // in flight under the exponentials
             // ---- P = 2^10 alpha_c exp2((S - m) t) as f16 hi / lo planes, [row][inner], inner contiguous ----
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
                         unsigned h0, l0, h1, l1;
                         split_pair_rn(p[0], p[1], h0, l0);
                         split_pair_rn(p[2], p[3], h1, l1);
-                        _Float16* dst = pimg + (wn * 64 + j * 32 + c) * CF_PROW + cl;
+                        _Float16* dst = pimg + (wn * WR + j * 32 + c) * CF_PROW + cl;
                         *reinterpret_cast<cf_u32x2*>(dst) = cf_u32x2{h0, h1};
                         *reinterpret_cast<cf_u32x2*>(dst + CF_PIMG) = cf_u32x2{l0, l1};
                     }
@@ -332,12 +344,12 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
                 const int buf = kb & 1;
                 if (kb + 1 < CF_B / CF_BK) g2_fetch(g2, c0, kb + 1);
                 const _Float16* ap = stage + buf * CF_G2 + (vm * 128 + c) * CF_ROW + hh * 8;
-                const _Float16* bp = pimg + (vn * 64 + c) * CF_PROW + kb * CF_BK + hh * 8;
+                const _Float16* bp = pimg + (vn * WR + c) * CF_PROW + kb * CF_BK + hh * 8;
 #pragma unroll
                 for (int s = 0; s < CF_BK / 16; ++s) {
-                    cf_f16x8 bh[2], bl[2];
+                    cf_f16x8 bh[NJ], bl[NJ];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         bh[j] = *reinterpret_cast<const cf_f16x8*>(bp + j * 32 * CF_PROW + s * 16);
                         bl[j] = *reinterpret_cast<const cf_f16x8*>(bp + CF_PIMG + j * 32 * CF_PROW + s * 16);
                     }
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
                         const cf_f16x8 ah = *reinterpret_cast<const cf_f16x8*>(ap + i * 32 * CF_ROW + s * 16);
                         const cf_f16x8 al = *reinterpret_cast<const cf_f16x8*>(ap + CF_VPLANE + i * 32 * CF_ROW + s * 16);
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
+                        for (int j = 0; j < NJ; ++j) {
                             acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc2[i][j], 0, 0, 0);
                             acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc2[i][j], 0, 0, 0);
                             acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc2[i][j], 0, 0, 0);
@@ -359,8 +371,8 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
         }
         const float gscale = a.host_scale * (a.mul ? *a.mul : 1.0f) / (*a.s_v * CF_PSCALE);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int r = r0 + vn * 64 + j * 32 + c;
+        for (int j = 0; j < NJ; ++j) {
+            const int r = r0 + vn * WR + j * 32 + c;
             const float bsc = (r < a.Nr && a.beta) ? a.beta[(size_t)b * a.Nr + r] * gscale : gscale;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -405,9 +417,11 @@ extern "C" int cocos_contextual_cx_fwd_f16x3(const void* xh, const void* xl, con
     a.s_r = x_scale_dev; a.s_i = y_scale_dev;
     a.m_out = m_out; a.s_out = s_out; a.u_out = u_out; a.j_out = j_out;
     a.Nr = Nq; a.Ni = Nk; a.Nrp = Nqp; a.Nip = Nkp; a.Kp = Kp; a.h = h; a.eps = eps;
-    auto kern = cf_kernel<0, true>;
+    // 128-row blocks when they fill the chip, else 64-row blocks (twice the workgroups, half the reuse of a staged key block)
+    const bool small = (long long)(Nqp / CF_B) * B < 256;
+    auto kern = small ? cf_kernel<0, true, 1> : cf_kernel<0, true, 2>;
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_SMEM));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(Nqp / CF_B), (unsigned)B, 1), dim3(256), CF_SMEM, as_stream(stream), a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(Nqp / (small ? 64 : 128)), (unsigned)B, 1), dim3(256), CF_SMEM, as_stream(stream), a);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -435,9 +449,12 @@ extern "C" int cocos_contextual_cx_bwd_f16x3(const void* rh, const void* rl, con
     a.s_r = r_scale_dev; a.s_i = i_scale_dev; a.s_v = v_scale_dev; a.mul = mul_dev;
     a.m = m; a.t = t; a.alpha = alpha; a.beta = beta; a.out = out;
     a.Nr = Nr; a.Ni = Ni; a.Nrp = Nrp; a.Nip = Nip; a.Kp = Kp; a.Cv = Cv; a.host_scale = host_scale;
-    auto kern = stats_on_rows ? cf_kernel<1, true> : cf_kernel<1, false>;
+    const int nz = (Cv + CF_CW - 1) / CF_CW;
+    const bool small = (long long)(Nrp / CF_B) * B * nz < 256;
+    auto kern = small ? (stats_on_rows ? cf_kernel<1, true, 1> : cf_kernel<1, false, 1>)
+                      : (stats_on_rows ? cf_kernel<1, true, 2> : cf_kernel<1, false, 2>);
     COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_SMEM));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(Nrp / CF_B), (unsigned)B, (unsigned)((Cv + CF_CW - 1) / CF_CW)), dim3(256), CF_SMEM,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(Nrp / (small ? 64 : 128)), (unsigned)B, (unsigned)nz), dim3(256), CF_SMEM,
                        as_stream(stream), a);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
