@@ -1457,6 +1457,11 @@ BOX3_FUSED = True
 BOX3_SHARE_T = True
 
 
+#: T tensors of at least this many bytes lend their storage to the dC planes in the backward (see _Box3CorrXbox.backward): the
+#: BASELINE config 5 class (128 x 128 grid: 1 GiB per sample).  Smaller ones keep a T that a retained graph may read again.
+BOX3_ALIAS_T_BYTES = int(os.environ.get("COCOS_BOX3_ALIAS_T_BYTES", 2 << 30))
+
+
 def box3_fused_ok(B, C, h, w, Cv=1):
     """Shapes the fused match_kernel-3 family takes (64- or 128-wide grid, whole 256-position tiles) on the split flavour."""
     return (BOX3_FUSED and PRECISION == "f16x3" and C == FUSED_K
@@ -1498,7 +1503,17 @@ class _Box3CorrXbox(torch.autograd.Function):
         if gmax is None:
             gmax = absmax(g)
         half = dict(device=g.device, dtype=torch.float16)
-        dch, dcl = torch.empty(B * N * N, **half), torch.empty(B * N * N, **half)
+        t_dead = getattr(ctx.sink, "t_dead", None) if ctx.sink is not None else None
+        if (t_dead is not None and t_dead.numel() == B * N * N and t_dead.dtype == torch.float32
+                and B * N * N * 4 >= BOX3_ALIAS_T_BYTES):
+            # round 5: T's last reader was the last pass's backward, which ran before this node — the dC planes
+            # (two f16 planes = T's bytes) take T's storage instead of another B N^2 x 4 bytes (cfg5, B = 2: 5.1 -> 4.1 GiB peak).
+            # Through a VIEW, so that autograd's version counter sees it: a second backward over a retained graph raises
+            # ("modified by an inplace operation") instead of reading planes as T.  Only for the large shapes (BOX3_ALIAS_T_BYTES).
+            planes = t_dead.view(torch.float16)
+            dch, dcl = planes[:B * N * N], planes[B * N * N:]
+        else:
+            dch, dcl = torch.empty(B * N * N, **half), torch.empty(B * N * N, **half)
         sc = torch.empty(1, device=g.device, dtype=torch.float32)
         _call("box3_adjoint_planes", "cocos_box3_adjoint_planes_f16x3", g.data_ptr(), gmax.data_ptr(), dch.data_ptr(),
               dcl.data_ptr(), sc.data_ptr(), B, N, N, h, w, _stream())
@@ -1528,10 +1543,12 @@ class Box3GradSink:
     def __init__(self):
         self.buf = None
         self.gmax = None
+        self.t_dead = None      # T as the LAST pass's backward saw it: nothing reads it after that (see _Box3CorrXbox.backward)
 
     def reset(self):
         self.buf = None
         self.gmax = None
+        self.t_dead = None
 
 
 def box3_corr_xbox(q_raw, k_raw, sink: Box3GradSink | None = None):
@@ -1608,6 +1625,8 @@ class _Box3SoftmaxWarp(torch.autograd.Function):
               _ptr(ctx.v_lomask), B, N, N, Cv, cvp, h, w, kc, scale, _ptr(_rowdot(dout, out) if BWD_D_PRECOMPUTED else None), flags,
               _stream())
         _remember_amax(g, gmax)      # (an accumulating pass replaces the cell remembered for the shared buffer)
+        if sink is not None and t.numel() * 4 >= BOX3_ALIAS_T_BYTES:
+            sink.t_dead = t          # (only when T's node will take the storage over: the reference keeps T alive until then)
         dv = None
         if need_v:
             gch, gcl, _ = split_f16(dout, False, amax=g_amax)

@@ -383,18 +383,21 @@ def test_config5_match_kernel3_hw16384_vs_fp64(route, monkeypatch):
     seg = torch.rand(B, 20, S, S, device=DEV, generator=g)
     flags = dict(match_kernel=3, PONO_C=True, down=d, warp_patch=True, warp_bilinear=True, isTrain=True, warp_mask_losstype="none")
     tq, pq = th.clone().requires_grad_(True), ph.clone().requires_grad_(True)
+    torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()             # (other tests' module fixtures live on the device: the step's own peak)
     with ops.KernelTimer() as kt:
         out = correspondence_hot_path(tq, pq, ref_img, ref_img, seg, seg, HotPathConfig(**flags))
         G = {"warp_out": torch.randn(out["warp_out"].shape, device=DEV, generator=g)}
         out["warp_out"].backward(G["warp_out"])
     tags = set(kt.summary())
-    peak_gib = torch.cuda.max_memory_allocated() / 2 ** 30
+    peak_gib = (torch.cuda.max_memory_allocated() - base) / 2 ** 30
     assert set(out) == {"warp_out"} and out["warp_out"].shape == (B, 3, S, S)
     assert {"box3_corr_xbox", "box3_softmax_warp_fwd", "box3_softmax_warp_bwd", "box3_adjoint_planes"} <= tags, tags
     assert not ({"box3_logits_fwd", "corr_materialize", "logits_softmax_warp_fwd"} & tags), tags
     print("CFG5_MK3", route, "peak GiB", round(peak_gib, 2))
-    assert peak_gib < 12.0, peak_gib          # T + G + the dC planes: 3 x 1 GiB per sample, + operands (the chain: > 20 GiB)
+    assert peak_gib < 4.6, peak_gib           # T + G: 2 x 1 GiB per sample + operands — the dC planes live in T's storage (round 5:
+                                              # 5.1 -> 4.1 GiB measured; the materialised chain: > 20 GiB)
     for b in range(B):
         sl = slice(b, b + 1)
         outs, dth, dph = tr.forward_backward(th[sl], ph[sl], ref_img[sl], ref_img[sl], seg[sl], seg[sl], co.default_opt(**flags),
