@@ -189,8 +189,9 @@ _SIGNATURES = {
                                                                    ctypes.c_float, _stream_t]),
     "cocos_contextual_cx_fwd_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 4 + [_c_float_p] * 5 + [ctypes.c_void_p] + [ctypes.c_int] * 6
                                       + [ctypes.c_float, ctypes.c_float, _stream_t]),
-    "cocos_contextual_cx_bwd_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 6 + [_c_float_p] * 9 + [ctypes.c_int] * 8
+    "cocos_contextual_cx_bwd_f16x3": (ctypes.c_int, [ctypes.c_void_p] * 6 + [_c_float_p] * 13 + [ctypes.c_int] * 8
                                       + [ctypes.c_float, _stream_t]),
+    "cocos_contextual_cx_coeffs": (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_longlong, ctypes.c_float, ctypes.c_float, _stream_t]),
     "cocos_reflect_pad2d_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong] + [ctypes.c_int] * 3 + [_stream_t]),
     "cocos_reflect_pad2d_bwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong] + [ctypes.c_int] * 3 + [_stream_t]),
     "cocos_spade_modulate_fwd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_longlong, ctypes.c_float, _stream_t]),

@@ -21,6 +21,13 @@ from . import ops
 
 _EPS = __import__("sys").float_info.epsilon      # util.feature_normalize (util/util.py:31-34)
 
+#: "fused" (default): K22, nothing [N, N] in HBM, any N.  "materialised": round 2's K3 + K15 on the [B, N, N] cosine matrix (<= 4096
+#: keys) — kept as the A/B arm of tools/contextual_bench.py, where it is the FASTER one while the matrix is small (0.25 vs 0.42 ms at
+#: get_ctx_loss's B = 8, N = 1024, C = 512; 1.5 vs 2.8 ms at N = 4096) and the hungrier one throughout (1088 vs 321 MiB at N = 4096):
+#: the default follows the memory, the difference is 0.2 ms of a > 100 ms generator step.  A module attribute, not an environment
+#: switch; an explicit "materialised" beyond its 4096 keys raises (no framework fallback on a GPU).
+ROUTE = "fused"
+
 
 def _feature_normalize(x):
     if x.is_cuda and x.dtype == torch.float32:
@@ -45,6 +52,11 @@ class ContextualLoss_forward(nn.Module):
             X_features, Y_features = X_features - mu, Y_features - mu
         Xn = _feature_normalize(X_features).reshape(B, C, -1)                                  # :115-116
         Yn = _feature_normalize(Y_features).reshape(B, C, -1)
+        if Xn.is_cuda and Xn.dtype == torch.float32 and ROUTE == "materialised":
+            if Yn.shape[2] > 4096:
+                raise ValueError(f"contextual.ROUTE = 'materialised' supports at most 4096 key positions (got {Yn.shape[2]})")
+            cx = ops.contextual_rows(ops.corr_materialize(Xn.contiguous(), Yn.contiguous(), 1.0), h, 1e-3)
+            return -torch.log(cx.mean(dim=1))
         if Xn.is_cuda and Xn.dtype == torch.float32:
             # K22: cosine tiles -> row maximum -> per-row temperature -> sums, all in registers; any N, any C, nothing [N, N] in HBM
             cx = ops.contextual_cx(Xn.contiguous(), Yn.contiguous(), h, 1e-3)                  # :121-132

@@ -54,7 +54,11 @@ struct CfArgs {
     const float* mul;             // device cell multiplied into the result (nullable)      (backward)
     const float *m, *t;           // per QUERY: max cos and tau * log2(e)                   (backward; [B][Nq])
     const float* alpha;           // per inner position (nullable = 1)                      (backward; [B][Ni])
+    const float* alpha_div;       // device cell: alpha is divided by it (nullable = 1)     (backward)
     const float* beta;            // per row (nullable = 1)                                 (backward; [B][Nr])
+    const float* gat_src;         // [B][Cv][Ni] fp32 (nullable): out[ch][r] += gat_coef[r] * gat_src[ch][gat_idx[r]]   (backward)
+    const int* gat_idx;           // [B][Nr]
+    const float* gat_coef;        // [B][Nr]
     float* out;                   // backward: [B][Cv][Nr]
     float *m_out, *s_out, *u_out; // forward: [B][Nr]
     int* j_out;                   // forward: [B][Nr]
@@ -129,20 +133,23 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
     };
     // the cosine tile of inner positions c0 .. c0 + 127: acc[i][j][g] = raw accumulator of
     //     inner  c0 + wm * 64 + i * 32 + acc_row_base(g) + 4 hh     x     row  r0 + wn * WR + j * 32 + c
-    auto gemm1 = [&](f32x16 (&acc)[2][NJ], int c0) {
+    // `g` carries k-block 0 of this tile when `have0` (requested during the previous tile: its HBM / L2 latency is behind the
+    // previous tile's epilogue instead of in front of this tile's first MFMA); `c0_next` >= 0: request the NEXT tile's k-block 0
+    // during this tile's last k-step (forward; the backward does that inside GEMM 2, whose staging shares these buffers).
+    auto gemm1 = [&](f32x16 (&acc)[2][NJ], int c0, G1Regs& g, bool have0, int c0_next) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
-        G1Regs g;
-        g1_fetch(g, c0, 0);
+        if (!have0) g1_fetch(g, c0, 0);
         g1_commit(g, 0);
         __syncthreads();
         for (int kb = 0; kb < nk; ++kb) {
             const int buf = kb & 1;
             if (kb + 1 < nk) g1_fetch(g, c0, (kb + 1) * CF_BK);
+            else if (c0_next >= 0) g1_fetch(g, c0_next, 0);
             const _Float16* ap = stage + buf * CF_G1 + (wm * 64 + c) * CF_ROW + hh * 8;
             const _Float16* bp = stage + buf * CF_G1 + 2 * CF_PLANE + (wn * WR + c) * CF_ROW + hh * 8;
 #pragma unroll
@@ -178,8 +185,9 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { best[j] = -INFINITY; arg[j] = 0x7fffffff; }
         f32x16 acc[2][NJ];
+        G1Regs gr;
         for (int tI = 0; tI < ntile; ++tI) {
-            gemm1(acc, tI * CF_B);
+            gemm1(acc, tI * CF_B, gr, tI > 0, tI + 1 < ntile ? (tI + 1) * CF_B : 0);     // (the last tile requests tile 0 again: sweep 2)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -218,7 +226,8 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { t2[j] = kLog2e / (a.h * (1.0f - m[j] + a.eps)); z[j] = 0.f; uu[j] = 0.f; }
         for (int tI = 0; tI < ntile; ++tI) {
-            gemm1(acc, tI * CF_B);          // (the same instruction sequence as sweep 1: bit-identical cosines, e = 1 at the argmax)
+            // (the same instruction sequence as sweep 1: bit-identical cosines, e = 1 at the argmax)
+            gemm1(acc, tI * CF_B, gr, true, tI + 1 < ntile ? (tI + 1) * CF_B : -1);
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -294,6 +303,8 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
             }
         };
         f32x16 acc[2][NJ];
+        G1Regs gr;
+        const float adiv = a.alpha_div ? (*a.alpha_div > 0.f ? 1.0f / *a.alpha_div : 0.f) : 1.0f;      // (all-zero d cx: nothing to scale)
         for (int tI = 0; tI < ntile; ++tI) {
             const int c0 = tI * CF_B;
             // the inner tile's per-position numbers (read after the barriers inside gemm1)
@@ -305,9 +316,9 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
                     istat[tid] = ok ? a.m[o] : 0.f;
                     istat[CF_B + tid] = ok ? a.t[o] : 0.f;
                 }
-                istat[2 * CF_B + tid] = ok ? (a.alpha ? a.alpha[o] : 1.0f) : 0.f;      // padding positions contribute nothing
+                istat[2 * CF_B + tid] = ok ? (a.alpha ? a.alpha[o] * adiv : 1.0f) : 0.f;      // padding positions contribute nothing
             }
-            gemm1(acc, c0);
+            gemm1(acc, c0, gr, tI > 0, -1);
             G2Regs g2;
             g2_fetch(g2, c0, 0);              // in flight under the exponentials
             // ---- P = 2^10 alpha_c exp2((S - m) t) as f16 hi / lo planes, [row][inner], inner contiguous ----
@@ -343,6 +354,7 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
             for (int kb = 0; kb < CF_B / CF_BK; ++kb) {
                 const int buf = kb & 1;
                 if (kb + 1 < CF_B / CF_BK) g2_fetch(g2, c0, kb + 1);
+                else if (tI + 1 < ntile) g1_fetch(gr, c0 + CF_B, 0);      // the next tile's first GEMM-1 block (see gemm1)
                 const _Float16* ap = stage + buf * CF_G2 + (vm * 128 + c) * CF_ROW + hh * 8;
                 const _Float16* bp = pimg + (vn * WR + c) * CF_PROW + kb * CF_BK + hh * 8;
 #pragma unroll
@@ -374,15 +386,47 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
         for (int j = 0; j < NJ; ++j) {
             const int r = r0 + vn * WR + j * 32 + c;
             const float bsc = (r < a.Nr && a.beta) ? a.beta[(size_t)b * a.Nr + r] * gscale : gscale;
+            // the argmax column's extra term (through m_i and tau(m_i)): a gather from the inner side's fp32 values
+            const bool gat = a.gat_src != nullptr && r < a.Nr;
+            const float gco = gat ? a.gat_coef[(size_t)b * a.Nr + r] : 0.f;
+            const float* gsrc = gat ? a.gat_src + (size_t)b * a.Cv * a.Ni + a.gat_idx[(size_t)b * a.Nr + r] : nullptr;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int ch = ch0 + vm * 128 + i * 32 + acc_row_base(g) + 4 * hh;
-                    if (ch < a.Cv && r < a.Nr) a.out[((size_t)b * a.Cv + ch) * a.Nr + r] = acc2[i][j][g] * bsc;
+                    if (ch < a.Cv && r < a.Nr) {
+                        float v = acc2[i][j][g] * bsc;
+                        if (gat) v += gco * gsrc[(size_t)ch * a.Ni];
+                        a.out[((size_t)b * a.Cv + ch) * a.Nr + r] = v;
+                    }
                 }
         }
     }
+}
+
+// The backward's per-query coefficients from the forward's statistics and d loss / d cx (one launch instead of ~10 framework
+// element-wise ones):  dS = -dcx / S^2,  tau = 1 / (h (1 - m + eps)),  a = dS tau (coefficient of e_ij),  t2 = tau log2 e,
+// extra = dS (h tau^2 U - tau S) (the argmax column's term),  *amax |= max |a| (cell zero on entry: non-negative floats order as integers).
+__global__ __launch_bounds__(256) void cf_coeffs_kernel(const float* __restrict__ dcx, const float* __restrict__ S,
+                                                        const float* __restrict__ U, const float* __restrict__ m, float* __restrict__ a_out,
+                                                        float* __restrict__ t2_out, float* __restrict__ extra_out,
+                                                        unsigned* __restrict__ amax, long long n, float h, float eps) {
+    __shared__ float red[4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float av = 0.f;
+    if (i < n) {
+        const float s = S[i], dS = -dcx[i] / (s * s), tau = 1.0f / (h * (1.0f - m[i] + eps));
+        const float aa = dS * tau;
+        a_out[i] = aa;
+        t2_out[i] = tau * kLog2e;
+        extra_out[i] = dS * (h * tau * tau * U[i] - tau * s);
+        av = fabsf(aa);
+    }
+    av = wave_max_dpp(av);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = av;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
 static int cf_check_planes(const char* what, int B, int Nr, int Ni, int Nrp, int Nip, int Kp) {
@@ -426,15 +470,30 @@ extern "C" int cocos_contextual_cx_fwd_f16x3(const void* xh, const void* xl, con
     return COCOS_OK;
 }
 
-// One side of the backward:  out[b][ch][r] = host_scale * mul * beta_r * sum_c alpha_c exp2((cos_rc - m) t) V[ch][c]  for r < Nr,
+// a, t2, extra [n] from dcx, S, U, m [n] (see cf_coeffs_kernel); *a_amax_dev (zero on entry) = max |a|.
+extern "C" int cocos_contextual_cx_coeffs(const float* dcx, const float* S, const float* U, const float* m, float* a_out, float* t2_out,
+                                          float* extra_out, float* a_amax_dev, long long n, float h, float eps, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(dcx && S && U && m && a_out && t2_out && extra_out && a_amax_dev, COCOS_ERR_INVALID, "contextual_cx_coeffs: null pointer");
+    COCOS_REQUIRE(n >= 1 && (n + 255) / 256 <= 0x7fffffffLL && h > 0.f && eps > 0.f, COCOS_ERR_INVALID, "contextual_cx_coeffs: n=%lld", n);
+    hipLaunchKernelGGL(cf_coeffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), dcx, S, U, m, a_out, t2_out,
+                       extra_out, reinterpret_cast<unsigned*>(a_amax_dev), n, h, eps);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+// One side of the backward:  out[b][ch][r] = host_scale * mul * beta_r * sum_c (alpha_c / alpha_div) exp2((cos_rc - m) t) V[ch][c]
+//                                            (+ gather_coef[r] * gather_src[ch][gather_idx[r]] when gather_src is given)  for r < Nr,
 // ch < Cv, with (m, t) per QUERY — indexed by r when stats_on_rows (rows = queries: d Xn, V = Yn) and by c otherwise (rows = keys:
 // d Yn, V = Xn).  rh, rl / ih, il: position-major planes of the rows / inner side (as above), vh, vl [B][Cv][Nip]: channel-major
 // planes of the inner side's values times *v_scale_dev; alpha [B][Ni] (|alpha| <= 1), beta [B][Nr], mul: nullable = 1.
 extern "C" int cocos_contextual_cx_bwd_f16x3(const void* rh, const void* rl, const void* ih, const void* il, const void* vh,
                                              const void* vl, const float* r_scale_dev, const float* i_scale_dev,
                                              const float* v_scale_dev, const float* mul_dev, const float* m, const float* t,
-                                             const float* alpha, const float* beta, float* out, int B, int Nr, int Ni, int Nrp,
-                                             int Nip, int Kp, int Cv, int stats_on_rows, float host_scale, cocos_stream_t stream) {
+                                             const float* alpha, const float* alpha_div_dev, const float* beta,
+                                             const float* gather_src, const int* gather_idx, const float* gather_coef, float* out,
+                                             int B, int Nr, int Ni, int Nrp, int Nip, int Kp, int Cv, int stats_on_rows,
+                                             float host_scale, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(rh && rl && ih && il && vh && vl && r_scale_dev && i_scale_dev && v_scale_dev && m && t && out, COCOS_ERR_INVALID,
                   "contextual_cx_bwd_f16x3: null pointer");
@@ -447,7 +506,9 @@ extern "C" int cocos_contextual_cx_bwd_f16x3(const void* rh, const void* rl, con
     a.ih = static_cast<const _Float16*>(ih); a.il = static_cast<const _Float16*>(il);
     a.vh = static_cast<const _Float16*>(vh); a.vl = static_cast<const _Float16*>(vl);
     a.s_r = r_scale_dev; a.s_i = i_scale_dev; a.s_v = v_scale_dev; a.mul = mul_dev;
-    a.m = m; a.t = t; a.alpha = alpha; a.beta = beta; a.out = out;
+    COCOS_REQUIRE(!gather_src || (gather_idx && gather_coef), COCOS_ERR_INVALID, "contextual_cx_bwd_f16x3: gather needs its index and coefficient");
+    a.m = m; a.t = t; a.alpha = alpha; a.alpha_div = alpha_div_dev; a.beta = beta; a.out = out;
+    a.gat_src = gather_src; a.gat_idx = gather_idx; a.gat_coef = gather_coef;
     a.Nr = Nr; a.Ni = Ni; a.Nrp = Nrp; a.Nip = Nip; a.Kp = Kp; a.Cv = Cv; a.host_scale = host_scale;
     const int nz = (Cv + CF_CW - 1) / CF_CW;
     const bool small = (long long)(Nrp / CF_B) * B * nz < 256;

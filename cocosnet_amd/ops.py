@@ -2170,31 +2170,29 @@ class _ContextualCx(torch.autograd.Function):
         Nk = yn.shape[2]
         kp, nqp, nkp = xh.shape[2], xh.shape[1], yh.shape[1]
         need_x, need_y = ctx.needs_input_grad[:2]
-        # per query (tiny [B, Nq] tensors): d loss / d S, the temperature, the coefficient of e_ij and the argmax column's extra term
-        dS = -dcx / (S * S)
-        tau = 1.0 / (h * (1.0 - m + eps))
-        a = (dS * tau).contiguous()
-        extra = dS * (h * tau * tau * U - tau * S)        # through m_i and tau(m_i): lands on column j*_i only
-        t2 = (tau * 1.4426950408889634).contiguous()
-        jl = jstar.long().unsqueeze(1).expand(B, C, Nq)
+        # per query: the coefficient of e_ij, the temperature and the argmax column's extra term — one small launch
+        f32 = dict(device=xn.device, dtype=torch.float32)
+        a, t2, extra = (torch.empty((B, Nq), **f32) for _ in range(3))
+        a_amax = _zero_cell(xn.device)
         st = _stream()
+        _call("contextual_cx_coeffs", "cocos_contextual_cx_coeffs", dcx.data_ptr(), S.data_ptr(), U.data_ptr(), m.data_ptr(), a.data_ptr(),
+              t2.data_ptr(), extra.data_ptr(), a_amax.data_ptr(), B * Nq, h, eps, st)
         dx = dy = None
-        if need_x:     # rows = queries, inner = keys, values = yn (channel-major), (m, t) and beta = a per row
-            vh, vl, vs = split_f16(_cx_pad_positions(yn), False, amax=ya)
+        if need_x:     # rows = queries, inner = keys, values = yn (channel-major), (m, t) and beta = a per row; the argmax column's
+            vh, vl, vs = split_f16(_cx_pad_positions(yn), False, amax=ya)          # term is gathered from yn in the epilogue
             dx = torch.empty_like(xn)
             _call("contextual_cx_bwd", "cocos_contextual_cx_bwd_f16x3", xh.data_ptr(), xl.data_ptr(), yh.data_ptr(), yl.data_ptr(),
-                  vh.data_ptr(), vl.data_ptr(), xs.data_ptr(), ys.data_ptr(), vs.data_ptr(), None, m.data_ptr(), t2.data_ptr(), None,
-                  a.data_ptr(), dx.data_ptr(), B, Nq, Nk, nqp, nkp, kp, C, 1, 1.0, st)
-            dx.add_(extra.unsqueeze(1) * yn.gather(2, jl))
+                  vh.data_ptr(), vl.data_ptr(), xs.data_ptr(), ys.data_ptr(), vs.data_ptr(), None, m.data_ptr(), t2.data_ptr(), None, None,
+                  a.data_ptr(), yn.data_ptr(), jstar.data_ptr(), extra.data_ptr(), dx.data_ptr(), B, Nq, Nk, nqp, nkp, kp, C, 1, 1.0, st)
         if need_y:     # rows = keys, inner = queries, values = xn, (m, t) and alpha = a / max|a| per inner position
-            amax_a = a.abs().amax().clamp_min(1e-30).reshape(1)
-            alpha = (a / amax_a).contiguous()
             vh, vl, vs = split_f16(_cx_pad_positions(xn), False, amax=xa)
             dy = torch.empty_like(yn)
             _call("contextual_cx_bwd", "cocos_contextual_cx_bwd_f16x3", yh.data_ptr(), yl.data_ptr(), xh.data_ptr(), xl.data_ptr(),
-                  vh.data_ptr(), vl.data_ptr(), ys.data_ptr(), xs.data_ptr(), vs.data_ptr(), amax_a.data_ptr(), m.data_ptr(),
-                  t2.data_ptr(), alpha.data_ptr(), None, dy.data_ptr(), B, Nk, Nq, nkp, nqp, kp, C, 0, 1.0, st)
-            dy.scatter_add_(2, jl, extra.unsqueeze(1) * xn)
+                  vh.data_ptr(), vl.data_ptr(), ys.data_ptr(), xs.data_ptr(), vs.data_ptr(), a_amax.data_ptr(), m.data_ptr(),
+                  t2.data_ptr(), a.data_ptr(), a_amax.data_ptr(), None, None, None, None, dy.data_ptr(), B, Nk, Nq, nkp, nqp, kp, C, 0, 1.0, st)
+            # the argmax column's term lands on key j*_i: a scatter-add over the queries (the exemplar side is detached by the
+            # reference's caller, pix2pix_model.py:197-201: this branch is for completeness)
+            dy.scatter_add_(2, jstar.long().unsqueeze(1).expand(B, C, Nq), extra.unsqueeze(1) * xn)
         return dx, dy, None, None
 
 

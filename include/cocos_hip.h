@@ -511,15 +511,21 @@ int cocos_contextual_cx_fwd_f16x3(const void* xh, const void* xl, const void* yh
                                   const float* y_scale_dev, float* m_out /* max_j cos */, float* s_out /* S */,
                                   float* u_out /* sum_j e_ij (cos_ij - m_i) */, int* j_out /* argmax_j, first */, int B, int Nq,
                                   int Nk, int Nqp, int Nkp, int Kp, float h, float eps, cocos_stream_t stream);
-/* out[b][ch][r] = host_scale * (*mul_dev) * beta[r] * sum_c alpha[c] exp2((cos_rc - m) t) V[ch][c];  (m, t = tau log2 e) per QUERY:
- * indexed by r when stats_on_rows (rows = queries, inner = keys: d Xn), by c otherwise (rows = keys, inner = queries: d Yn).
- * |alpha| <= 1 (the caller normalises and passes the factor in mul_dev); alpha, beta, mul_dev nullable = 1. */
+/* out[b][ch][r] = host_scale * (*mul_dev) * beta[r] * sum_c (alpha[c] / *alpha_div_dev) exp2((cos_rc - m) t) V[ch][c]
+ *                 (+ gather_coef[r] * gather_src[b][ch][gather_idx[r]]: the argmax column's term of d Xn, from the fp32 values);
+ * (m, t = tau log2 e) per QUERY: indexed by r when stats_on_rows (rows = queries, inner = keys: d Xn), by c otherwise (rows = keys,
+ * inner = queries: d Yn).  |alpha / alpha_div| <= 1.  alpha, alpha_div_dev, beta, mul_dev, gather_* nullable. */
 int cocos_contextual_cx_bwd_f16x3(const void* rh, const void* rl, const void* ih, const void* il, const void* vh, const void* vl,
                                   const float* r_scale_dev, const float* i_scale_dev, const float* v_scale_dev,
                                   const float* mul_dev /* nullable */, const float* m, const float* t,
-                                  const float* alpha /* nullable */, const float* beta /* nullable */, float* out, int B, int Nr,
-                                  int Ni, int Nrp, int Nip, int Kp, int Cv, int stats_on_rows, float host_scale,
-                                  cocos_stream_t stream);
+                                  const float* alpha /* nullable */, const float* alpha_div_dev /* nullable */,
+                                  const float* beta /* nullable */, const float* gather_src /* nullable: [B][Cv][Ni] */,
+                                  const int* gather_idx, const float* gather_coef, float* out, int B, int Nr, int Ni, int Nrp,
+                                  int Nip, int Kp, int Cv, int stats_on_rows, float host_scale, cocos_stream_t stream);
+/* The backward's per-query coefficients (n = B * Nq) from the forward's statistics and d loss / d cx:  a = dS tau with
+ * dS = -dcx / S^2, tau = 1 / (h (1 - m + eps));  t2 = tau log2 e;  extra = dS (h tau^2 U - tau S);  *a_amax_dev = max |a| (zero on entry). */
+int cocos_contextual_cx_coeffs(const float* dcx, const float* S, const float* U, const float* m, float* a_out, float* t2_out,
+                               float* extra_out, float* a_amax_dev, long long n, float h, float eps, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K18 nn.ReflectionPad2d(pad) and its backward: the pad in front of the 3x3 convolutions of ResidualBlock

@@ -544,6 +544,16 @@ def test_contextual_loss_forward_matches_the_reference_formula(B, C, h, w, pono)
     errs = (rel(loss, lr.detach().numpy()), rel(xa.grad, xr.grad.numpy()), rel(ya.grad, yr.grad.numpy()))
     print("CTX_FP64", (B, C, h, w, pono), errs)
     assert errs[0] < 2e-5 and errs[1] < 5e-5 and errs[2] < 5e-5, errs      # (measured 1e-8 .. 4e-6; VERDICT r3 weak 1c: was 1e-3 / 2e-3)
+    # the A/B arm (round 2's K3 + K15 on the materialised cosine matrix) stays a tested route: same contract
+    from cocosnet_amd import contextual
+    contextual.ROUTE = "materialised"
+    try:
+        xm = X.clone().requires_grad_(True)
+        lm = mod(xm, Y, h=0.1)
+        lm.sum().backward()
+    finally:
+        contextual.ROUTE = "fused"
+    assert rel(lm, lr.detach().numpy()) < 2e-5 and rel(xm.grad, xr.grad.numpy()) < 5e-5
 
 
 def _ctx_case(B, C, N, seed):
