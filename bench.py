@@ -786,6 +786,12 @@ def main():
                                       "whole NoVGGCorrespondence module fwd+bwd (convolutions K16, norms K9/K13/K17, theta/phi K0); "
                                       f"convolutions={_conv_flavour()}"),
                        "untimed_steps_before_window": SETUP_STEPS + args.warmup,
+                       # hygiene: `value` is measured on ADE20k's one-hot label map, whose V_lo MFMA term is
+                       # skipped; the same step with every term issued (what configs 3 and 5, with float label maps, get):
+                       "value_with_general_v": (flavours.get("general_v") or {}).get("images_per_s"),
+                       "step_definition": "bench step = theta/phi 1x1 projections (K0) + centre/L2-norm (K1) + the correspondence "
+                                          "kernels, forward and backward; tools/configs_bench.py's step starts at theta/phi (no K0): "
+                                          "its match_kernel-3 figure is ~0.2 ms below context.match_kernel_3.ms_per_step",
                        "context": context,
                        "global_batch": BATCH_PER_GPU * world, "parallelism": f"dp{world}",
                        "grad_payload": args.grad_payload,

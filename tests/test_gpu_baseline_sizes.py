@@ -556,6 +556,25 @@ def test_contextual_loss_forward_matches_the_reference_formula(B, C, h, w, pono)
     assert rel(lm, lr.detach().numpy()) < 2e-5 and rel(xm.grad, xr.grad.numpy()) < 5e-5
 
 
+@pytest.mark.parametrize("name", ["contextual_pono", "contextual_nopono", "contextual_h05"])
+def test_contextual_loss_matches_the_reference_generated_fixtures(name):
+    """tests/golden/contextual_*.npz: per-sample loss and d loss / d X of the REFERENCE's own ContextualLoss_forward (fp32 on CPU,
+    oracle/make_contextual_golden.py) — the drop-in class on the GPU (K1 + K22) against them.  The fixtures are fp32 evaluations of a
+    formulation whose exponent is (1 - d / (d_min + 1e-3)) / h: their own rounding is ~1e-5, which is the tolerance."""
+    import os
+    from types import SimpleNamespace
+    from cocosnet_amd.contextual import ContextualLoss_forward
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    x = torch.from_numpy(f["X"]).to(DEV).requires_grad_(True)
+    with_ops = __import__("cocosnet_amd.ops", fromlist=["ops"])
+    with with_ops.KernelTimer() as kt:
+        loss = ContextualLoss_forward(SimpleNamespace(PONO=bool(f["pono"])))(x, torch.from_numpy(f["Y"]).to(DEV), h=float(f["h"]))
+        loss.sum().backward()
+    assert "contextual_cx_fwd" in kt.summary() and "contextual_cx_bwd" in kt.summary()
+    assert rel(loss, f["loss"].astype(np.float64)) < 3e-5, name
+    assert rel(x.grad, f["dX"].astype(np.float64)) < 5e-5, name
+
+
 def _ctx_case(B, C, N, seed):
     g = torch.Generator(device=DEV).manual_seed(seed)
     Y = torch.randn(B, C, N, device=DEV, generator=g) + 0.3

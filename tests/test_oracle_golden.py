@@ -153,3 +153,40 @@ def test_torch_oracle_agrees_with_numpy_oracle_fp64():
     assert set(outs) == set(ref)
     for k in ref:
         assert np.abs(outs[k] - ref[k]).max() < 1e-11, k
+
+
+# ------------------------------------------------------------------ contextual loss: reference-generated fixtures
+CTX_GOLDEN = ("contextual_pono", "contextual_nopono", "contextual_h05")
+
+
+@pytest.mark.parametrize("name", CTX_GOLDEN)
+def test_contextual_class_matches_the_reference_fixture_on_cpu(name):
+    """tests/golden/contextual_*.npz are outputs and autograd gradients of the reference's own ContextualLoss_forward
+    (oracle/make_contextual_golden.py).  The drop-in class on CPU tensors (the reference's formulation in torch: the fp64 arbiter
+    of the GPU tests is this code path in double) reproduces them."""
+    import os
+    from types import SimpleNamespace
+    import numpy as np
+    import torch
+    from cocosnet_amd.contextual import ContextualLoss_forward
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    x = torch.from_numpy(f["X"]).requires_grad_(True)
+    loss = ContextualLoss_forward(SimpleNamespace(PONO=bool(f["pono"])))(x, torch.from_numpy(f["Y"]), h=float(f["h"]))
+    loss.sum().backward()
+    assert np.allclose(loss.detach().numpy(), f["loss"], rtol=2e-5, atol=1e-6)
+    assert np.abs(x.grad.numpy() - f["dX"]).max() <= 2e-5 * np.abs(f["dX"]).max()
+
+
+def test_contextual_fixtures_regenerate_from_the_reference():
+    """With /root/reference present (build container): running the reference again reproduces the committed fixtures bit for bit."""
+    import os
+    import numpy as np
+    from oracle import ref_harness as rh
+    if not rh.reference_available():
+        pytest.skip("reference tree not present (GPU box)")
+    from oracle import make_contextual_golden as mk
+    for name in CTX_GOLDEN:
+        got = mk.run_reference_case(name)
+        f = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+        for k in ("X", "Y", "loss", "dX"):
+            assert np.array_equal(got[k], f[k]), (name, k)
