@@ -4,12 +4,14 @@
 #   the mk-3 profile, the BASELINE-config table, the attention bench, the full GPU test log.
 # Output: gpurun_out/final_<tag>/ (merged back by gpurun; copied into profiles/ by hand).
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$PWD; O=$R/gpurun_out/final_$TAG; rm -rf $O; mkdir -p $O; export TMPDIR=/tmp
 (rocm-smi --showproductname; rocm-smi --showclocks; uname -a) > $O/${TAG}_box_info.txt 2>&1
 timeout 900 python bench.py > $O/${TAG}_bench_final.json 2> $O/bench_default.err; echo "bench rc=$?"; cut -c1-400 $O/${TAG}_bench_final.json
 timeout 1500 python -m pytest tests -q -m gpu > $O/${TAG}_pytest_gpu_final.log 2>&1; echo "pytest rc=$?"; tail -3 $O/${TAG}_pytest_gpu_final.log
 timeout 600 python -m pytest tests/test_gpu_conv.py -q -s -m gpu -k "end_to_end or config3" 2>&1 | grep "E2E_FP64\|CFG3_FP64\|passed\|failed" > $O/${TAG}_e2e_fp64_errors.txt
+timeout 300 python -m pytest tests/test_gpu_baseline_sizes.py -q -s -m gpu -k "contextual" 2>&1 | grep "CTX_FP64\|passed\|failed" | cut -c1-600 > $O/${TAG}_contextual_fp64_errors.txt
+timeout 300 python tools/contextual_bench.py 2>/dev/null | grep "^{" > $O/${TAG}_contextual_bench.txt
 timeout 600 python tools/configs_bench.py > $O/configs_bench.log 2>&1; cp gpurun_out/configs_bench.json $O/${TAG}_configs_bench.json 2>/dev/null
 timeout 300 python tools/attention_bench.py > $O/${TAG}_attention_bench.txt 2>&1; tail -3 $O/${TAG}_attention_bench.txt | cut -c1-300
 cd /tmp
