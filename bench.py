@@ -435,7 +435,7 @@ SPLIT_TAGS = ("corr_softmax_warp_fwd", "corr_softmax_warp_bwd_query", "corr_soft
 #: parameter counts of BASELINE config 4's exchange: theta/phi only (what the hot path owns),
 #: netCorr (59 M), netG + netCorr (156 M)
 PAYLOAD_PARAMS = {"path": 0, "netcorr": 59_000_000, "full": 156_000_000}
-PMC_FILE = {"f16x3": next((f for f in ("r04_pmc_f16x3.json", "r03_pmc_f16x3.json", "r02_pmc_f16x3.json")
+PMC_FILE = {"f16x3": next((f for f in ("r05_pmc_f16x3.json", "r04_pmc_f16x3.json", "r03_pmc_f16x3.json", "r02_pmc_f16x3.json")
                            if os.path.exists(os.path.join(REPO, "profiles", f))), "r02_pmc_f16x3.json"),
             "fp32": "r01_pmc_final.json"}
 # (the counters were taken on the general instantiations <..., 0>; the one that skips exact value blocks moves 8 MB less)
@@ -531,7 +531,7 @@ def roofline_of(kernels, precision):
                "note": "moved bytes per launch (PMC, profiles/) / the launch time measured in this run; the kernel streams the "
                        "saved logits in and the dS'' planes out (2 x HW^2 x 4 B per sample) next to its MFMA work — a measured "
                        "design choice (saved logits beat the chunked recompute by 22-40 % at every BASELINE shape: config.context / "
-                       "profiles/r04_configs_bench.json); a linear read reaches 4.7-4.9 TB/s on this chip "
+                       "profiles/r05_configs_bench.json); a linear read reaches 4.7-4.9 TB/s on this chip "
                        "(tools/probes/strided_rows.hip)"}
     if split and dom in SPLIT_TAGS:
         peak = F16_MFMA_PEAK_TFLOPS / 3.0
@@ -667,10 +667,21 @@ def main():
     for _ in range(SETUP_STEPS):
         step()
     sync()
-    dt, kern = window(args.steps, args.warmup)
+    # Round 5: the timed window carries HIP events around the DOMINANT kernel only (the one `roofline` is about: ④ asks for
+    # its launch time measured live over the timed region) — every bracketed call costs two marker packets that serialise
+    # dispatch, and six per step were 2-3 % of `value`.  Which kernel that is comes from one fully-bracketed, untimed step;
+    # the other hot kernels' live averages come from a second window of the same length right after the headline one.
+    with ops.KernelTimer(tags=HOT_TAGS) as kt_probe:
+        step()
+    probe = kt_probe.summary()
+    dom_tag = max(probe, key=lambda t: probe[t]["total_ms"]) if probe else None
+    dt, kern = window(args.steps, args.warmup, tags=(dom_tag,) if dom_tag else HOT_TAGS)
     with ops.KernelTimer() as kt_all:
         step()
     kern_all = kt_all.summary()
+    _, kern_hot = window(args.steps, 0)              # all hot kernels bracketed: the `kernels` table (never part of `value`)
+    for tag, rec in kern_hot.items():
+        kern.setdefault(tag, rec)                    # (the dominant kernel keeps its figure from the headline window)
 
     # ---- extras, same process / same box, after the headline window (N = 1 only) --------------------------------
     flavours, stability, context = {}, None, None
@@ -785,7 +796,8 @@ def main():
                                       if args.scope == "hotpath" else
                                       "whole NoVGGCorrespondence module fwd+bwd (convolutions K16, norms K9/K13/K17, theta/phi K0); "
                                       f"convolutions={_conv_flavour()}"),
-                       "untimed_steps_before_window": SETUP_STEPS + args.warmup,
+                       "untimed_steps_before_window": SETUP_STEPS + 1 + args.warmup,
+                       "hip_events_in_timed_window": [dom_tag] if dom_tag else list(HOT_TAGS),
                        # hygiene: `value` is measured on ADE20k's one-hot label map, whose V_lo MFMA term is
                        # skipped; the same step with every term issued (what configs 3 and 5, with float label maps, get):
                        "value_with_general_v": (flavours.get("general_v") or {}).get("images_per_s"),
