@@ -41,10 +41,10 @@ constexpr int CF_PLANE = CF_B * CF_ROW;   // one staged 128-row plane (halfs)
 constexpr int CF_G1 = 4 * CF_PLANE;       // GEMM 1 stage: inner hi, inner lo, rows hi, rows lo  (40 KB)
 constexpr int CF_VPLANE = CF_CW * CF_ROW;
 constexpr int CF_G2 = 2 * CF_VPLANE;      // GEMM 2 stage: value hi, value lo  (40 KB)
-static_assert(CF_G1 == CF_G2, "the two GEMMs share their staging buffers");
 constexpr int CF_PIMG = CF_B * CF_PROW;   // one P plane (halfs)
+constexpr int CF_RED = 256;               // rows of the forward's exchange arrays (the widest workgroup: NJ = 4)
 constexpr float CF_PSCALE = 1024.0f;      // P planes hold 2^10 alpha e (|alpha e| <= 1)
-constexpr size_t CF_SMEM = (size_t)2 * CF_G1 * 2 + (size_t)2 * CF_PIMG * 2 + (size_t)(3 * CF_B + 4 * 2 * CF_B) * 4;
+constexpr size_t CF_SMEM = (size_t)2 * CF_G1 * 2 + (size_t)2 * CF_PIMG * 2 + (size_t)(3 * CF_B + 4 * CF_RED) * 4;
 
 struct CfArgs {
     const _Float16 *rh, *rl;      // rows side, position-major [B][Nrp][Kp]
@@ -72,11 +72,15 @@ struct CfArgs {
 template <int MODE, bool STAT_ROWS, int NJ>
 __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
     constexpr int BR = 64 * NJ, WR = 32 * NJ;       // rows per workgroup / per wave
+    constexpr int RPLANE = BR * CF_ROW;             // one staged plane of the rows side (halfs)
+    constexpr int G1 = 2 * CF_PLANE + 2 * RPLANE;   // GEMM 1 stage: inner hi, inner lo, rows hi, rows lo
+    constexpr int STG = MODE == 0 ? G1 : (G1 > CF_G2 ? G1 : CF_G2);      // one staging buffer (the backward's two GEMMs share them)
+    static_assert(MODE == 0 || NJ <= 2, "the backward's P image and second accumulator are sized for 128-row workgroups");
     extern __shared__ __attribute__((aligned(16))) unsigned char cf_smem[];
-    _Float16* const stage = reinterpret_cast<_Float16*>(cf_smem);                     // [2][CF_G1]
-    _Float16* const pimg = stage + 2 * CF_G1;                                         // [hi | lo][128 r][CF_PROW]
-    float* const istat = reinterpret_cast<float*>(pimg + 2 * CF_PIMG);                // [m | t | alpha][128] of the inner tile
-    float* const red = istat + 3 * CF_B;                                              // forward: [4][2][128] exchange between the waves
+    _Float16* const stage = reinterpret_cast<_Float16*>(cf_smem);                     // [2][STG]
+    _Float16* const pimg = stage + 2 * STG;                                           // backward: [hi | lo][128 r][CF_PROW]
+    float* const istat = reinterpret_cast<float*>(pimg + 2 * CF_PIMG);                // backward: [m | t | alpha][128] of the inner tile
+    float* const red = MODE == 0 ? reinterpret_cast<float*>(stage + 2 * STG) : istat + 3 * CF_B;      // forward: [4][CF_RED] exchange between the waves
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, c = lane & 31;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
         }
     };
     auto g1_commit = [&](const G1Regs& g, int buf) {
-        _Float16* s = stage + buf * CF_G1;
+        _Float16* s = stage + buf * STG;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int q = u * 256 + tid, row = q >> 2, kc = q & 3;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
             const int q = u * 256 + tid, row = q >> 2, kc = q & 3;
             const int o = row * CF_ROW + kc * 8;
             *reinterpret_cast<u32x4*>(s + 2 * CF_PLANE + o) = g.rh[u];
-            *reinterpret_cast<u32x4*>(s + 3 * CF_PLANE + o) = g.rl[u];
+            *reinterpret_cast<u32x4*>(s + 2 * CF_PLANE + RPLANE + o) = g.rl[u];
         }
     };
     // the cosine tile of inner positions c0 .. c0 + 127: acc[i][j][g] = raw accumulator of
@@ -150,15 +154,15 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
             const int buf = kb & 1;
             if (kb + 1 < nk) g1_fetch(g, c0, (kb + 1) * CF_BK);
             else if (c0_next >= 0) g1_fetch(g, c0_next, 0);
-            const _Float16* ap = stage + buf * CF_G1 + (wm * 64 + c) * CF_ROW + hh * 8;
-            const _Float16* bp = stage + buf * CF_G1 + 2 * CF_PLANE + (wn * WR + c) * CF_ROW + hh * 8;
+            const _Float16* ap = stage + buf * STG + (wm * 64 + c) * CF_ROW + hh * 8;
+            const _Float16* bp = stage + buf * STG + 2 * CF_PLANE + (wn * WR + c) * CF_ROW + hh * 8;
 #pragma unroll
             for (int s = 0; s < CF_BK / 16; ++s) {
                 cf_f16x8 bh[NJ], bl[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     bh[j] = *reinterpret_cast<const cf_f16x8*>(bp + j * 32 * CF_ROW + s * 16);
-                    bl[j] = *reinterpret_cast<const cf_f16x8*>(bp + CF_PLANE + j * 32 * CF_ROW + s * 16);
+                    bl[j] = *reinterpret_cast<const cf_f16x8*>(bp + RPLANE + j * 32 * CF_ROW + s * 16);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -209,17 +213,17 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
         for (int j = 0; j < NJ; ++j) {
             pick(best[j], arg[j], __shfl_xor(best[j], 32, 64), __shfl_xor(arg[j], 32, 64));
             if (hh == 0) {
-                red[(wm * 2 + 0) * CF_B + wn * WR + j * 32 + c] = best[j];
-                red[(wm * 2 + 1) * CF_B + wn * WR + j * 32 + c] = __builtin_bit_cast(float, arg[j]);
+                red[(wm * 2 + 0) * CF_RED + wn * WR + j * 32 + c] = best[j];
+                red[(wm * 2 + 1) * CF_RED + wn * WR + j * 32 + c] = __builtin_bit_cast(float, arg[j]);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int rr = wn * WR + j * 32 + c;
-            m[j] = red[0 * CF_B + rr];
-            jst[j] = __builtin_bit_cast(int, red[1 * CF_B + rr]);
-            pick(m[j], jst[j], red[2 * CF_B + rr], __builtin_bit_cast(int, red[3 * CF_B + rr]));
+            m[j] = red[0 * CF_RED + rr];
+            jst[j] = __builtin_bit_cast(int, red[1 * CF_RED + rr]);
+            pick(m[j], jst[j], red[2 * CF_RED + rr], __builtin_bit_cast(int, red[3 * CF_RED + rr]));
         }
         __syncthreads();
         float t2[NJ], z[NJ], uu[NJ];
@@ -246,8 +250,8 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
             z[j] += __shfl_xor(z[j], 32, 64);
             uu[j] += __shfl_xor(uu[j], 32, 64);
             if (hh == 0) {
-                red[(wm * 2 + 0) * CF_B + wn * WR + j * 32 + c] = z[j];
-                red[(wm * 2 + 1) * CF_B + wn * WR + j * 32 + c] = uu[j];
+                red[(wm * 2 + 0) * CF_RED + wn * WR + j * 32 + c] = z[j];
+                red[(wm * 2 + 1) * CF_RED + wn * WR + j * 32 + c] = uu[j];
             }
         }
         __syncthreads();
@@ -258,8 +262,8 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
                 if (r < a.Nr) {
                     const size_t o = (size_t)b * a.Nr + r;
                     a.m_out[o] = m[j];
-                    a.s_out[o] = red[0 * CF_B + rr] + red[2 * CF_B + rr];
-                    a.u_out[o] = red[1 * CF_B + rr] + red[3 * CF_B + rr];
+                    a.s_out[o] = red[0 * CF_RED + rr] + red[2 * CF_RED + rr];
+                    a.u_out[o] = red[1 * CF_RED + rr] + red[3 * CF_RED + rr];
                     a.j_out[o] = jst[j];
                 }
             }
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
             }
         };
         auto g2_commit = [&](const G2Regs& g, int buf) {
-            _Float16* s = stage + buf * CF_G2;
+            _Float16* s = stage + buf * STG;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int q = u * 256 + tid, row = q >> 2, kc = q & 3;
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
                 const int buf = kb & 1;
                 if (kb + 1 < CF_B / CF_BK) g2_fetch(g2, c0, kb + 1);
                 else if (tI + 1 < ntile) g1_fetch(gr, c0 + CF_B, 0);      // the next tile's first GEMM-1 block (see gemm1)
-                const _Float16* ap = stage + buf * CF_G2 + (vm * 128 + c) * CF_ROW + hh * 8;
+                const _Float16* ap = stage + buf * STG + (vm * 128 + c) * CF_ROW + hh * 8;
                 const _Float16* bp = pimg + (vn * WR + c) * CF_PROW + kb * CF_BK + hh * 8;
 #pragma unroll
                 for (int s = 0; s < CF_BK / 16; ++s) {
@@ -461,11 +465,15 @@ extern "C" int cocos_contextual_cx_fwd_f16x3(const void* xh, const void* xl, con
     a.s_r = x_scale_dev; a.s_i = y_scale_dev;
     a.m_out = m_out; a.s_out = s_out; a.u_out = u_out; a.j_out = j_out;
     a.Nr = Nq; a.Ni = Nk; a.Nrp = Nqp; a.Nip = Nkp; a.Kp = Kp; a.h = h; a.eps = eps;
-    // 128-row blocks when they fill the chip, else 64-row blocks (twice the workgroups, half the reuse of a staged key block)
-    const bool small = (long long)(Nqp / CF_B) * B < 256;
-    auto kern = small ? cf_kernel<0, true, 1> : cf_kernel<0, true, 2>;
-    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CF_SMEM));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(Nqp / (small ? 64 : 128)), (unsigned)B, 1), dim3(256), CF_SMEM, as_stream(stream), a);
+    // rows per workgroup: 256 when that still gives every CU a workgroup (the staged key block is re-used by twice the rows: the
+    // kernel streams (128 + rows) x C operand elements per 128 x rows cosines from L2), 128, or 64 when 128-row blocks would leave
+    // most of the chip without one
+    const long long blocks128 = (long long)(Nqp / CF_B) * B;
+    const int nj = blocks128 >= 512 ? 4 : blocks128 >= 256 ? 2 : 1;
+    auto kern = nj == 4 ? cf_kernel<0, true, 4> : nj == 2 ? cf_kernel<0, true, 2> : cf_kernel<0, true, 1>;
+    const size_t smem = (size_t)2 * (2 * CF_PLANE + 2 * 64 * nj * CF_ROW) * 2 + (size_t)4 * CF_RED * 4;
+    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(kern, dim3((unsigned)((Nqp + 64 * nj - 1) / (64 * nj)), (unsigned)B, 1), dim3(256), smem, as_stream(stream), a);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

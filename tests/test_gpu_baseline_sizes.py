@@ -626,6 +626,31 @@ def test_contextual_loss_at_4096_positions_and_512_channels(monkeypatch):
     assert peak < 10 * feat, (peak, feat)
 
 
+def test_contextual_cx_with_256_row_workgroups():
+    """K22's forward takes 256-row workgroups when 128-row blocks would be two rounds of the chip (B N / 128 >= 512): B = 16,
+    N = 4096, C = 32 — cx and d X against the reference's formulation in fp64 on the device."""
+    from cocosnet_amd import ops
+    B, C, N = 16, 32, 4096
+    X, Y = _ctx_case(B, C, N, 15)
+    nrm = lambda t: t / (t.norm(dim=1, keepdim=True) + 2.2e-16)
+    Xn, Yn = nrm(X), nrm(Y)
+    G = torch.randn(B, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    want = []
+    for b in range(0, B, 4):        # (four samples at a time: [4, N, N] fp64 matrices)
+        xr = Xn[b:b + 4].double().requires_grad_(True)
+        d = 1 - torch.matmul(xr.transpose(1, 2), Yn[b:b + 4].double())
+        w_ = torch.exp((1 - d / (d.min(-1, keepdim=True)[0] + 1e-3)) / 0.1)
+        cx_ref = (w_ / w_.sum(-1, keepdim=True)).max(-1)[0]
+        (cx_ref * G[b:b + 4].double()).sum().backward()
+        want.append((cx_ref.detach().cpu().numpy(), xr.grad.cpu().numpy()))
+        del d, w_, cx_ref
+    xa = Xn.clone().requires_grad_(True)
+    cx = ops.contextual_cx(xa, Yn, 0.1, 1e-3)
+    (cx * G).sum().backward()
+    cx_w, dx_w = np.concatenate([w[0] for w in want]), np.concatenate([w[1] for w in want])
+    assert rel(cx, cx_w) < 2e-5 and rel(xa.grad, dx_w) < 5e-5, (rel(cx, cx_w), rel(xa.grad, dx_w))
+
+
 def test_contextual_cx_beyond_the_old_4096_key_cap():
     """Round 2's K15 stopped at 4096 keys and the class fell through to framework ops above.  N = 12288
     positions (a 96 x 128 feature map), C = 64: cx and the gradient w.r.t. X against fp64; extra memory of the op (planes,
