@@ -520,7 +520,8 @@ def test_attention_block_on_hip_matches_torch_fp64(B, ch, H, W):
 
 
 @pytest.mark.parametrize("B,C,h,w,pono", [(2, 512, 32, 32, True), (2, 256, 16, 16, False), (1, 64, 64, 64, True), (1, 48, 9, 7, False),
-                                          (2, 128, 32, 32, True), (1, 300, 20, 13, False), (3, 512, 16, 16, True)])
+                                          (2, 128, 32, 32, True), (1, 300, 20, 13, False), (3, 512, 16, 16, True),
+                                          (2, 3, 2, 3, False), (5, 33, 1, 130, True)])
 def test_contextual_loss_forward_matches_the_reference_formula(B, C, h, w, pono):
     """`ContextualLoss_forward.forward` (ContextualLoss.py:93-137) on K1 + K22 against the reference's formulation
     in torch fp64: per-sample loss and the gradient w.r.t. the generated features X (the exemplar side Y is detached in
