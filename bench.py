@@ -676,8 +676,12 @@ def main():
     with ops.KernelTimer(tags=HOT_TAGS) as kt_probe:
         step()
     probe = kt_probe.summary()
-    dom_tag = max(probe, key=lambda t: probe[t]["total_ms"]) if probe else None
-    dt, kern = window(args.steps, args.warmup, tags=(dom_tag,) if dom_tag else HOT_TAGS)
+    # (one step is a noisy ranking: the forward and the query backward are within 2 % of each other — every kernel within 5 % of
+    #  the longest stays bracketed, and `roofline` ranks them by their average over the window)
+    top = max((r["total_ms"] for r in probe.values()), default=0.0)
+    dom_tags = tuple(t for t, r in probe.items() if r["total_ms"] >= 0.95 * top)
+    dom_tag = dom_tags[0] if dom_tags else None
+    dt, kern = window(args.steps, args.warmup, tags=dom_tags if dom_tags else HOT_TAGS)
     with ops.KernelTimer() as kt_all:
         step()
     kern_all = kt_all.summary()
@@ -799,7 +803,7 @@ def main():
                                       "whole NoVGGCorrespondence module fwd+bwd (convolutions K16, norms K9/K13/K17, theta/phi K0); "
                                       f"convolutions={_conv_flavour()}"),
                        "untimed_steps_before_window": SETUP_STEPS + 1 + args.warmup,
-                       "hip_events_in_timed_window": [dom_tag] if dom_tag else list(HOT_TAGS),
+                       "hip_events_in_timed_window": list(dom_tags) if dom_tags else list(HOT_TAGS),
                        # hygiene: `value` is measured on ADE20k's one-hot label map, whose V_lo MFMA term is
                        # skipped; the same step with every term issued (what configs 3 and 5, with float label maps, get):
                        "value_with_general_v": (flavours.get("general_v") or {}).get("images_per_s"),
