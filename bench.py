@@ -676,18 +676,18 @@ def main():
     with ops.KernelTimer(tags=HOT_TAGS) as kt_probe:
         step()
     probe = kt_probe.summary()
-    # (one step is a noisy ranking: the forward and the query backward are within 2 % of each other — every kernel within 5 % of
-    #  the longest stays bracketed, and `roofline` ranks them by their average over the window)
-    top = max((r["total_ms"] for r in probe.values()), default=0.0)
-    dom_tags = tuple(t for t, r in probe.items() if r["total_ms"] >= 0.95 * top)
+    # (one step is a noisy ranking and the forward and the query backward are within a few per cent of each other: the TWO longest
+    #  kernels of the probe step stay bracketed, `roofline` ranks them by their average over the timed window)
+    dom_tags = tuple(sorted(probe, key=lambda t: -probe[t]["total_ms"])[:2])
     dom_tag = dom_tags[0] if dom_tags else None
     dt, kern = window(args.steps, args.warmup, tags=dom_tags if dom_tags else HOT_TAGS)
     with ops.KernelTimer() as kt_all:
         step()
     kern_all = kt_all.summary()
     _, kern_hot = window(args.steps, 0)              # all hot kernels bracketed: the `kernels` table (never part of `value`)
+    kern_timed = dict(kern)                          # what the timed window itself measured: `roofline` is computed from these
     for tag, rec in kern_hot.items():
-        kern.setdefault(tag, rec)                    # (the dominant kernel keeps its figure from the headline window)
+        kern.setdefault(tag, rec)                    # (the bracketed kernels keep their figures from the headline window)
 
     # ---- extras, same process / same box, after the headline window (N = 1 only) --------------------------------
     flavours, stability, context = {}, None, None
@@ -780,7 +780,7 @@ def main():
     if rank == 0:
         split = headline_precision == "f16x3"
         kernels = kernel_table(kern, headline_precision)
-        roofline = roofline_of(kernels, headline_precision)
+        roofline = roofline_of(kernel_table(kern_timed, headline_precision) or kernels, headline_precision)
         # device time of EVERY C-ABI call per step (ms), so the part of the step outside the three big kernels is visible
         per_step = {tag: round(rec["total_ms"], 4) for tag, rec in sorted(kern_all.items())}
         cpu = None
