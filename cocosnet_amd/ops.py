@@ -1270,9 +1270,10 @@ class _Conv2d(torch.autograd.Function):
         if _conv_bf16():          # one-term flavour: no max|x| passes at all
             xa = wa = None
         else:
-            xa = _recall_amax(x)
+            xa = _recall_amax(x, consume=False)      # (not consumed: SPADE's gamma and beta convolutions read the SAME activation)
             if xa is None:
                 xa = absmax(x)
+                _remember_amax(x, xa)                # ... and the second one finds what the first one measured
             wa = _recall_amax(weight)          # K21 leaves it for spectral-normed layers
             if wa is None:
                 wa = absmax(weight)
