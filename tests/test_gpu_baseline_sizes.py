@@ -627,6 +627,27 @@ def test_contextual_loss_at_4096_positions_and_512_channels(monkeypatch):
     assert peak < 10 * feat, (peak, feat)
 
 
+@pytest.mark.parametrize("B,C,Nq,Nk,h", [(2, 40, 200, 330, 0.1), (1, 64, 513, 129, 0.5), (3, 16, 64, 1000, 0.05)])
+def test_contextual_cx_rectangular_and_other_bandwidths(B, C, Nq, Nk, h):
+    """ops.contextual_cx on its own: Nq != Nk (the class always passes equal sizes), ragged against the 128-position tiles on
+    either side, other bandwidths h; cx and BOTH gradients against the reference's formulation in fp64."""
+    from cocosnet_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + Nq)
+    nrm = lambda t: t / (t.norm(dim=1, keepdim=True) + 2.2e-16)
+    Xn, Yn = nrm(torch.randn(B, C, Nq, device=DEV, generator=g)), nrm(torch.randn(B, C, Nk, device=DEV, generator=g))
+    G = torch.randn(B, Nq, device=DEV, generator=g)
+    xr, yr = Xn.double().requires_grad_(True), Yn.double().requires_grad_(True)
+    d = 1 - torch.matmul(xr.transpose(1, 2), yr)
+    w_ = torch.exp((1 - d / (d.min(-1, keepdim=True)[0] + 1e-3)) / h)
+    cx_ref = (w_ / w_.sum(-1, keepdim=True)).max(-1)[0]
+    (cx_ref * G.double()).sum().backward()
+    xa, ya = Xn.clone().requires_grad_(True), Yn.clone().requires_grad_(True)
+    cx = ops.contextual_cx(xa, ya, h, 1e-3)
+    (cx * G).sum().backward()
+    assert rel(cx, cx_ref.detach().cpu().numpy()) < 2e-5
+    assert rel(xa.grad, xr.grad.cpu().numpy()) < 5e-5 and rel(ya.grad, yr.grad.cpu().numpy()) < 5e-5
+
+
 def test_contextual_cx_with_256_row_workgroups():
     """K22's forward takes 256-row workgroups when 128-row blocks would be two rounds of the chip (B N / 128 >= 512): B = 16,
     N = 4096, C = 32 — cx and d X against the reference's formulation in fp64 on the device."""
