@@ -39,6 +39,7 @@ if REPO not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16: 32 cycles), no sparsity
+F16_MFMA_SUSTAINED_FRAC = 0.655     # measured: tools/mfma_ceiling.sh -> profiles/r06_mfma_ceiling.txt (random operands; zeros reach 0.991)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 BATCH_PER_GPU = 8
 IMG = 256
@@ -546,6 +547,11 @@ def roofline_of(kernels, precision):
                 "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                 "avg_launch_ms": kernels[dom]["avg_ms"], "issued_tflops": kernels[dom]["issued_tflops"],
                 "frac_issued": kernels[dom]["frac_f16_mfma_peak"],
+                # round 6: on random operands a pure f16 MFMA stream sustains 0.655 of the nominal rate on this
+                # chip — the clock drops from 2.39 to ~1.8 GHz at the 1.3 kW it then draws (zeros: 0.991) — profiles/r06_mfma_ceiling.txt
+                "frac_of_sustained": round(mfma_frac / F16_MFMA_SUSTAINED_FRAC, 4),
+                "sustained_note": f"peak x {F16_MFMA_SUSTAINED_FRAC} = what a pure v_mfma_f32_32x32x16_f16 stream sustains on uniform "
+                                  "random operands (DVFS / power: profiles/r06_mfma_ceiling.txt); `frac` stays against the nominal peak",
                 "vs_fp32_mfma_peak": kernels[dom]["frac_fp32_mfma_peak"],
                 "note": "achieved = ALGORITHMIC fp32 FLOPs per launch / HIP-event time on torch's current stream. Each "
                         "fp32-accurate product is 3 v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi of f16 hi/lo "

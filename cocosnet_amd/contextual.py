@@ -8,9 +8,9 @@ constructor and `forward(X_features, Y_features, h=0.1, feature_centering=True)`
     cos = X^T Y, d, d_norm, w, A, max_j A   K22 (`ops.contextual_cx`: the cosine tiles stay in the accumulators — a row-maximum sweep,
                                          then a sum sweep at the row's own temperature; its backward recomputes them)  :121-132
     CX = mean_i, loss = -log CX          host (B numbers)                                                      :132-133
-Round 2's route (K3 `ops.corr_materialize` -> K15 `ops.contextual_rows` on the [B, N, N] cosine matrix, <= 4096 keys) is still
-exported for callers that hold a cosine matrix; this class no longer uses it and has no size limit and no framework fallback on a
-GPU.  CPU tensors take the reference's formulation in torch (used by the CPU parity test only).
+Round 2's route (K3 `ops.corr_materialize` -> K15 `ops.contextual_rows` on the [B, N, N] cosine matrix, <= 4096 keys) is the
+faster one while that matrix is small: `ROUTE = "auto"` picks per call (see below); no size limit and no framework fallback on a
+GPU either way.  CPU tensors take the reference's formulation in torch (used by the CPU parity test only).
 """
 from __future__ import annotations
 
@@ -21,12 +21,21 @@ from . import ops
 
 _EPS = __import__("sys").float_info.epsilon      # util.feature_normalize (util/util.py:31-34)
 
-#: "fused" (default): K22, nothing [N, N] in HBM, any N.  "materialised": round 2's K3 + K15 on the [B, N, N] cosine matrix (<= 4096
-#: keys) — kept as the A/B arm of tools/contextual_bench.py, where it is the FASTER one while the matrix is small (0.25 vs 0.42 ms at
-#: get_ctx_loss's B = 8, N = 1024, C = 512; 1.5 vs 2.8 ms at N = 4096) and the hungrier one throughout (1088 vs 321 MiB at N = 4096):
-#: the default follows the memory, the difference is 0.2 ms of a > 100 ms generator step.  A module attribute, not an environment
-#: switch; an explicit "materialised" beyond its 4096 keys raises (no framework fallback on a GPU).
-ROUTE = "fused"
+#: "auto" (default, round 6): per call — the materialised route (round 2's K3 + K15 on the [B, N, N] cosine matrix) while that matrix is
+#: small (B N^2 x 4 bytes <= MATERIALISED_MAX_BYTES and N <= 4096, K15's key limit), K22 above: `tools/contextual_bench.py` has the
+#: materialised route FASTER wherever it applies (0.26 vs 0.39 ms at get_ctx_loss's B = 8, N = 1024, C = 512; 1.48 vs 2.79 ms at
+#: N = 4096) and hungrier only where the matrix is large (1088 vs 321 MiB at N = 4096, B = 8 — 0.4 % of the 288 GB of one MI355X).
+#: "fused": K22 always (nothing [N, N] in HBM, any N); "materialised": K3 + K15 always (raises beyond 4096 keys: no framework
+#: fallback on a GPU).  A module attribute, not an environment switch.
+ROUTE = "auto"
+#: "auto" takes the materialised route up to this many bytes of cosine matrix (B = 8, N = 4096: 512 MiB)
+MATERIALISED_MAX_BYTES = 1 << 30
+
+
+def _route(B: int, N: int) -> str:
+    if ROUTE != "auto":
+        return ROUTE
+    return "materialised" if (N <= 4096 and B * N * N * 4 <= MATERIALISED_MAX_BYTES) else "fused"
 
 
 def _feature_normalize(x):
@@ -52,7 +61,7 @@ class ContextualLoss_forward(nn.Module):
             X_features, Y_features = X_features - mu, Y_features - mu
         Xn = _feature_normalize(X_features).reshape(B, C, -1)                                  # :115-116
         Yn = _feature_normalize(Y_features).reshape(B, C, -1)
-        if Xn.is_cuda and Xn.dtype == torch.float32 and ROUTE == "materialised":
+        if Xn.is_cuda and Xn.dtype == torch.float32 and _route(B, Yn.shape[2]) == "materialised":
             if Yn.shape[2] > 4096:
                 raise ValueError(f"contextual.ROUTE = 'materialised' supports at most 4096 key positions (got {Yn.shape[2]})")
             cx = ops.contextual_rows(ops.corr_materialize(Xn.contiguous(), Yn.contiguous(), 1.0), h, 1e-3)

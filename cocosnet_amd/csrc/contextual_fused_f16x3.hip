@@ -270,7 +270,9 @@ __global__ __launch_bounds__(256, 1) void cf_kernel(const CfArgs a) {
                     a.m_out[o] = m[j];
                     a.s_out[o] = red[0 * CF_RED + rr] + red[2 * CF_RED + rr];
                     a.u_out[o] = red[1 * CF_RED + rr] + red[3 * CF_RED + rr];
-                    a.j_out[o] = jst[j];
+                    // (a row of NaN cosines never replaces the sentinel: a valid index keeps the backward's gather in bounds and lets
+                    //  the NaNs propagate as NaNs, as the reference does — ADVICE r5)
+                    a.j_out[o] = (unsigned)jst[j] < (unsigned)a.Ni ? jst[j] : 0;
                 }
             }
         }

@@ -1509,8 +1509,10 @@ class _Box3CorrXbox(torch.autograd.Function):
                 and B * N * N * 4 >= BOX3_ALIAS_T_BYTES):
             # round 5: T's last reader was the last pass's backward, which ran before this node — the dC planes
             # (two f16 planes = T's bytes) take T's storage instead of another B N^2 x 4 bytes (cfg5, B = 2: 5.1 -> 4.1 GiB peak).
-            # Through a VIEW, so that autograd's version counter sees it: a second backward over a retained graph raises
-            # ("modified by an inplace operation") instead of reading planes as T.  Only for the large shapes (BOX3_ALIAS_T_BYTES).
+            # The kernel writes through raw pointers, which autograd cannot see: the version counter of T is bumped by hand, so that
+            # a second backward over a retained graph — T is a saved input of every pass — raises ("modified by an inplace
+            # operation") instead of reading planes as logits.  Only for the large shapes (BOX3_ALIAS_T_BYTES).
+            torch.autograd.graph.increment_version(t_dead)
             planes = t_dead.view(torch.float16)
             dch, dcl = planes[:B * N * N], planes[B * N * N:]
         else:

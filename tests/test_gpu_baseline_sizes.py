@@ -534,44 +534,52 @@ def test_contextual_loss_forward_matches_the_reference_formula(B, C, h, w, pono)
     Y = torch.randn(B, C, h, w, device=DEV, generator=g) + 0.3
     perm = torch.randperm(h * w, device=DEV, generator=g)
     X = (0.6 * Y.reshape(B, C, -1)[:, :, perm].reshape(B, C, h, w) + torch.randn(B, C, h, w, device=DEV, generator=g))
+    from cocosnet_amd import contextual
     mod = ContextualLoss_forward(SimpleNamespace(PONO=pono))
     xa, ya = X.clone().requires_grad_(True), Y.clone().requires_grad_(True)
-    loss = mod(xa, ya, h=0.1)
-    assert loss.shape == (B,)
-    loss.sum().backward()
+    contextual.ROUTE = "fused"            # K22 itself (the "auto" default would take K3 + K15 at these sizes)
+    try:
+        loss = mod(xa, ya, h=0.1)
+        assert loss.shape == (B,)
+        loss.sum().backward()
+    finally:
+        contextual.ROUTE = "auto"
     xr, yr = X.double().cpu().requires_grad_(True), Y.double().cpu().requires_grad_(True)
     lr = mod(xr, yr, h=0.1)               # CPU tensors: the reference's formulation (torch), here in fp64
     lr.sum().backward()
     errs = (rel(loss, lr.detach().numpy()), rel(xa.grad, xr.grad.numpy()), rel(ya.grad, yr.grad.numpy()))
     print("CTX_FP64", (B, C, h, w, pono), errs)
     assert errs[0] < 2e-5 and errs[1] < 5e-5 and errs[2] < 5e-5, errs      # (measured 1e-8 .. 4e-6; VERDICT r3 weak 1c: was 1e-3 / 2e-3)
-    # the A/B arm (round 2's K3 + K15 on the materialised cosine matrix) stays a tested route: same contract
-    from cocosnet_amd import contextual
-    contextual.ROUTE = "materialised"
-    try:
-        xm = X.clone().requires_grad_(True)
+    # round 2's K3 + K15 on the materialised cosine matrix — what ROUTE = "auto" (the default) takes at these sizes: same contract
+    from cocosnet_amd import ops
+    assert contextual.ROUTE == "auto" and contextual._route(B, h * w) == "materialised"
+    xm = X.clone().requires_grad_(True)
+    with ops.KernelTimer() as kt:
         lm = mod(xm, Y, h=0.1)
         lm.sum().backward()
-    finally:
-        contextual.ROUTE = "fused"
+    assert "contextual_cx_fwd" not in kt.summary() and "contextual_rows_fwd" in kt.summary(), sorted(kt.summary())
     assert rel(lm, lr.detach().numpy()) < 2e-5 and rel(xm.grad, xr.grad.numpy()) < 5e-5
 
 
 @pytest.mark.parametrize("name", ["contextual_pono", "contextual_nopono", "contextual_h05"])
-def test_contextual_loss_matches_the_reference_generated_fixtures(name):
+@pytest.mark.parametrize("route", ["fused", "auto"])
+def test_contextual_loss_matches_the_reference_generated_fixtures(name, route, monkeypatch):
     """tests/golden/contextual_*.npz: per-sample loss and d loss / d X of the REFERENCE's own ContextualLoss_forward (fp32 on CPU,
     oracle/make_contextual_golden.py) — the drop-in class on the GPU (K1 + K22) against them.  The fixtures are fp32 evaluations of a
     formulation whose exponent is (1 - d / (d_min + 1e-3)) / h: their own rounding is ~1e-5, which is the tolerance."""
     import os
     from types import SimpleNamespace
+    from cocosnet_amd import contextual
     from cocosnet_amd.contextual import ContextualLoss_forward
+    monkeypatch.setattr(contextual, "ROUTE", route)          # K22 itself, and whatever the default picks for the fixture's size
     f = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
     x = torch.from_numpy(f["X"]).to(DEV).requires_grad_(True)
     with_ops = __import__("cocosnet_amd.ops", fromlist=["ops"])
     with with_ops.KernelTimer() as kt:
         loss = ContextualLoss_forward(SimpleNamespace(PONO=bool(f["pono"])))(x, torch.from_numpy(f["Y"]).to(DEV), h=float(f["h"]))
         loss.sum().backward()
-    assert "contextual_cx_fwd" in kt.summary() and "contextual_cx_bwd" in kt.summary()
+    if route == "fused":
+        assert "contextual_cx_fwd" in kt.summary() and "contextual_cx_bwd" in kt.summary()
     assert rel(loss, f["loss"].astype(np.float64)) < 3e-5, name
     assert rel(x.grad, f["dX"].astype(np.float64)) < 5e-5, name
 
@@ -599,6 +607,8 @@ def test_contextual_loss_at_4096_positions_and_512_channels(monkeypatch):
         raise AssertionError("the contextual loss must not materialise a cosine matrix")
     monkeypatch.setattr(ops, "corr_materialize", poisoned)
     monkeypatch.setattr(ops, "contextual_rows", poisoned)
+    from cocosnet_amd import contextual
+    monkeypatch.setattr(contextual, "ROUTE", "fused")        # ("auto" takes K3 + K15 while the matrix is <= 1 GiB: 128 MiB here)
     B, C, N = 2, 512, 4096
     X, Y = _ctx_case(B, C, N, 77)
     X, Y = X.reshape(B, C, 64, 64), Y.reshape(B, C, 64, 64)
