@@ -311,8 +311,10 @@ class HotPathStep(torch.nn.Module):
     def forward(self, d):
         from cocosnet_amd import ops
         from cocosnet_amd.hot_path import correspondence_hot_path
-        theta = ops.proj1x1(d["cont_features"], self.theta.weight, self.theta.bias)   # :272
-        phi = ops.proj1x1(d["ref_features"], self.phi.weight, self.phi.bias)          # :282
+        # :272 / :282 as lazy projections: the match_kernel-1 path fuses them with the centring / normalisation (K23), match_kernel 3
+        # asks for the fp32 projections (K0) — exactly what NoVGGCorrespondence.forward hands to the hot path
+        theta = ops.LazyProj1x1(d["cont_features"], self.theta.weight, self.theta.bias)
+        phi = ops.LazyProj1x1(d["ref_features"], self.phi.weight, self.phi.bias)
         return correspondence_hot_path(theta, phi,
                                        d["ref_img"], d["real_img"], d["seg"], d["ref_seg"], self.cfg)
 

@@ -165,6 +165,13 @@ _SIGNATURES = {
     "cocos_proj1x1_dw_f16x3": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 4 + [_c_float_p] * 2 + [_stream_t]),
     "cocos_proj1x1_stream_f16x3": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p,
                                                   _c_float_p] + [ctypes.c_int] * 4 + [_c_float_p, _stream_t]),
+    "cocos_proj_weight_frag_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "cocos_proj_weight_frag_planes": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                     ctypes.c_int, ctypes.c_int, _stream_t]),
+    "cocos_proj_center_l2norm_planes_f16x3": (ctypes.c_int, [ctypes.c_int]
+                                              + ([_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p]
+                                                 + [ctypes.c_void_p] * 4) * 2
+                                              + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_float, _stream_t]),
     "cocos_proj1x1_bwd_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [_stream_t]),
     "cocos_upsample_nearest_fwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),
     "cocos_upsample_nearest_bwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),

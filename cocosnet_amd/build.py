@@ -37,6 +37,7 @@ HIP_SOURCES = [
     "sgemm_f16x3.hip",
     "proj_stream_f16x3.hip",
     "proj_dw_f16x3.hip",
+    "proj_norm_f16x3.hip",
     "box3_unfold.hip",
     "box3_fused_f16x3.hip",
     "unfold3_stats.hip",

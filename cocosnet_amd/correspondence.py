@@ -126,7 +126,7 @@ class NoVGGCorrespondence(NetworkBase):
         yy = ys.view(1, 1, h, 1).expand(B, 1, h, w)
         return torch.cat((x, xx, yy, torch.sqrt(xx ** 2 + yy ** 2)), dim=1)
 
-    def project(self, ref_img, real_img, seg_map, ref_seg_map, coor_out=None):
+    def project(self, ref_img, real_img, seg_map, ref_seg_map, coor_out=None, lazy=False):
         """Everything BEFORE the hot path (:239-272, :282): returns (theta_raw, phi_raw)."""
         opt = self.opt
         if opt.mask_noise:
@@ -163,6 +163,9 @@ class NoVGGCorrespondence(NetworkBase):
         else:
             cont, ref = self.layer(cont_in), self.layer(ref_in)
         if cont.is_cuda and cont.dtype == torch.float32:   # :272 / :282 on K0 (same parameters: checkpoints are unaffected)
+            if lazy:      # forward(): the hot path decides — K23 (projection + K1 fused, no fp32 theta / phi) or K0 (ops.LazyProj1x1)
+                return (ops.LazyProj1x1(cont, self.theta.weight, self.theta.bias),
+                        ops.LazyProj1x1(ref, self.phi.weight, self.phi.bias))
             return (ops.proj1x1(cont, self.theta.weight, self.theta.bias),
                     ops.proj1x1(ref, self.phi.weight, self.phi.bias))
         return self.theta(cont), self.phi(ref)   # CPU / fp64: producer parity tests only; the hot path needs a GPU and fp32
@@ -170,7 +173,7 @@ class NoVGGCorrespondence(NetworkBase):
     def forward(self, ref_img, real_img, seg_map, ref_seg_map, temperature=0.01, detach_flag=False,
                 WTA_scale_weight=1, alpha=1, return_corr=False):
         coor_out = {}
-        theta_raw, phi_raw = self.project(ref_img, real_img, seg_map, ref_seg_map, coor_out)
+        theta_raw, phi_raw = self.project(ref_img, real_img, seg_map, ref_seg_map, coor_out, lazy=True)
         cfg = HotPathConfig.from_opt(self.opt, down=self.opt.down)
         res = correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_seg_map, cfg,
                                       temperature=temperature, detach_flag=detach_flag,

@@ -248,7 +248,26 @@ def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_
 
     inv_t = 1.0 / temperature
     fused = (mk == 1) and (C == ops.FUSED_K) and WTA_scale_weight == 1 and not return_corr
-    if fused:
+    # round 6: theta / phi may arrive as LAZY projections (ops.LazyProj1x1: the 1x1 convolutions of :272 / :282 not run yet).  On the
+    # fused match_kernel-1 / PONO_C path K23 then goes from the features straight to the correlation kernels' operand planes
+    # (projection + centring + normalisation in one launch for both tensors: the fp32 projections never exist); every other
+    # back end asks for the projections (K0) and continues as before.
+    lazy = isinstance(theta_raw, ops.LazyProj1x1) and isinstance(phi_raw, ops.LazyProj1x1)
+    if lazy != (isinstance(theta_raw, ops.LazyProj1x1) or isinstance(phi_raw, ops.LazyProj1x1)):
+        raise TypeError("correspondence_hot_path: theta and phi must both be tensors or both be ops.LazyProj1x1")
+    k23 = False
+    if lazy:
+        keep = torch.is_grad_enabled() and not detach_flag and (theta_raw.requires_grad or phi_raw.requires_grad)
+        k23 = (fused and cfg.PONO_C and theta_raw.x.shape == phi_raw.x.shape and ops.proj_norm_fused_ok(theta_raw)
+               and ops.proj_norm_fused_ok(phi_raw) and ops.corr_split_ok(B, C, fh * fw, fh * fw, 1, keep))
+        if not k23:
+            theta_raw, phi_raw = theta_raw.raw(), phi_raw.raw()
+    if k23:
+        th_l, ph_l = (theta_raw.detach(), phi_raw.detach()) if detach_flag else (theta_raw, phi_raw)   # :292-293 `f = f.detach()`
+        planes = ops.OperandPlanes()
+        qn, kn = ops.proj_center_l2norm_planes_pair(th_l, ph_l, 1, planes, want_chan=keep)
+        attn = _Attention(qn=qn, kn=kn, inv_t=inv_t, planes=planes)
+    elif fused:
         # :272-289 — flatten, centre, L2-normalise; the rest happens inside the fused kernels
         th_f, ph_f = _flat(theta_raw), _flat(phi_raw)
         if detach_flag:   # :292-293 `f = f.detach()`: nothing upstream of f receives a gradient

@@ -1009,69 +1009,221 @@ class _Proj1x1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w2 = ctx.saved_tensors
-        dy = _chk(dy, "proj1x1: dy")
-        B, Cin, h, w = x.shape
-        Cout = w2.shape[0]
-        N = h * w
         need_x, need_w, need_b = ctx.needs_input_grad
-        need_b = need_b and ctx.has_bias
-        lib = _lib.load()
-        dx = torch.empty_like(x) if need_x else None
-        dw = db = None
-        if ctx.split:
-            xa, wa = ctx.amax
-            ga = _recall_amax(dy)            # left by the kernel that wrote dy (K1's backward), else one pass
-            if ga is None:
-                ga = absmax(dy)
-            dx_gemm, dw_gemm = need_x, need_w
-            if ctx.stream and need_x:     # dx = W^T dy, same streaming kernel with the transposed weight planes
-                if getattr(ctx, "t_planes", None) is not None:
-                    th, tl, ts = ctx.t_planes
-                else:
-                    th, tl, ts = split_f16(w2.unsqueeze(0), transpose=True, cpad=lib.cocos_proj1x1_stream_kpad(Cout),
-                                           amax=wa)
-                _call("proj1x1_bwd", "cocos_proj1x1_stream_f16x3", dy.data_ptr(), th.data_ptr(), tl.data_ptr(),
-                      ts.data_ptr(), None, dx.data_ptr(), B, Cout, Cin, N, ga.data_ptr(), _stream())
-                dx_gemm = False
-            parts = lib.cocos_proj1x1_dw_partials_f16x3(B, Cin, Cout, N) if (need_w and PROJ_STREAM) else 0
-            if parts:                     # dw (and db) in one pass over dy and x (proj_dw_f16x3.hip)
-                ws = torch.empty((parts, Cout, (Cin + 31) // 32 * 32), device=x.device, dtype=torch.float32)
-                wsb = torch.empty((parts, Cout), device=x.device, dtype=torch.float32) if need_b else None
-                dw = torch.empty((Cout, Cin), device=x.device, dtype=torch.float32)
-                db = torch.empty(Cout, device=x.device, dtype=torch.float32) if need_b else None
-                _call("proj1x1_bwd", "cocos_proj1x1_dw_f16x3", dy.data_ptr(), x.data_ptr(), ws.data_ptr(), _ptr(wsb),
-                      dw.data_ptr(), _ptr(db), B, Cin, Cout, N, ga.data_ptr(), xa.data_ptr(), _stream())
-                dw_gemm = False
-            if dx_gemm or dw_gemm:
-                dwb = None
-                if dw_gemm:
-                    dwb = torch.empty((lib.cocos_proj1x1_bwd_partials_f16x3(B, Cin, Cout, N), Cout, Cin),
-                                      device=x.device, dtype=torch.float32)
-                _call("proj1x1_bwd", "cocos_proj1x1_bwd_f16x3", x.data_ptr(), w2.data_ptr(), dy.data_ptr(),
-                      dx.data_ptr() if dx_gemm else None, _ptr(dwb), B, Cin, Cout, N, xa.data_ptr(), wa.data_ptr(),
-                      ga.data_ptr(), _stream())
-                if dw_gemm:
-                    dw = sum_leading(dwb)                                   # [P,256,Cl] partials, small
-        else:
+        return _proj1x1_backward(x, w2, dy, ctx.amax if ctx.split else None, getattr(ctx, "t_planes", None), ctx.split, ctx.stream,
+                                 need_x, need_w, need_b and ctx.has_bias, ctx.wshape)
+
+
+def _proj1x1_backward(x, w2, dy, amax, t_planes, split, stream, need_x, need_w, need_b, wshape):
+    """Backward of y = conv1x1(x, w2) given dy: (dx, dw, db) — shared by _Proj1x1 and the fused projection + normalisation
+    (_ProjCenterL2NormPlanesPair).  `amax` = (max|x|, max|w|) device cells of the split flavour; `t_planes` = the transposed weight
+    planes (hi, lo, scale) when the forward already made them."""
+    dy = _chk(dy, "proj1x1: dy")
+    B, Cin, h, w = x.shape
+    Cout = w2.shape[0]
+    N = h * w
+    lib = _lib.load()
+    dx = torch.empty_like(x) if need_x else None
+    dw = db = None
+    if split:
+        xa, wa = amax
+        ga = _recall_amax(dy)            # left by the kernel that wrote dy (K1's backward), else one pass
+        if ga is None:
+            ga = absmax(dy)
+        dx_gemm, dw_gemm = need_x, need_w
+        if stream and need_x:     # dx = W^T dy, same streaming kernel with the transposed weight planes
+            if t_planes is not None:
+                th, tl, ts = t_planes
+            else:
+                th, tl, ts = split_f16(w2.unsqueeze(0), transpose=True, cpad=lib.cocos_proj1x1_stream_kpad(Cout),
+                                       amax=wa)
+            _call("proj1x1_bwd", "cocos_proj1x1_stream_f16x3", dy.data_ptr(), th.data_ptr(), tl.data_ptr(),
+                  ts.data_ptr(), None, dx.data_ptr(), B, Cout, Cin, N, ga.data_ptr(), _stream())
+            dx_gemm = False
+        parts = lib.cocos_proj1x1_dw_partials_f16x3(B, Cin, Cout, N) if (need_w and PROJ_STREAM) else 0
+        if parts:                     # dw (and db) in one pass over dy and x (proj_dw_f16x3.hip)
+            ws = torch.empty((parts, Cout, (Cin + 31) // 32 * 32), device=x.device, dtype=torch.float32)
+            wsb = torch.empty((parts, Cout), device=x.device, dtype=torch.float32) if need_b else None
+            dw = torch.empty((Cout, Cin), device=x.device, dtype=torch.float32)
+            db = torch.empty(Cout, device=x.device, dtype=torch.float32) if need_b else None
+            _call("proj1x1_bwd", "cocos_proj1x1_dw_f16x3", dy.data_ptr(), x.data_ptr(), ws.data_ptr(), _ptr(wsb),
+                  dw.data_ptr(), _ptr(db), B, Cin, Cout, N, ga.data_ptr(), xa.data_ptr(), _stream())
+            dw_gemm = False
+        if dx_gemm or dw_gemm:
             dwb = None
-            if need_w:
-                dwb = torch.empty((lib.cocos_proj1x1_bwd_partials(B, Cin, Cout, N), Cout, Cin), device=x.device,
-                                  dtype=torch.float32)
-            _call("proj1x1_bwd", "cocos_proj1x1_bwd", x.data_ptr(), w2.data_ptr(), dy.data_ptr(), _ptr(dx),
-                  _ptr(dwb), B, Cin, Cout, N, _stream())
-            if need_w:
-                dw = sum_leading(dwb)
+            if dw_gemm:
+                dwb = torch.empty((lib.cocos_proj1x1_bwd_partials_f16x3(B, Cin, Cout, N), Cout, Cin),
+                                  device=x.device, dtype=torch.float32)
+            _call("proj1x1_bwd", "cocos_proj1x1_bwd_f16x3", x.data_ptr(), w2.data_ptr(), dy.data_ptr(),
+                  dx.data_ptr() if dx_gemm else None, _ptr(dwb), B, Cin, Cout, N, xa.data_ptr(), wa.data_ptr(),
+                  ga.data_ptr(), _stream())
+            if dw_gemm:
+                dw = sum_leading(dwb)                                   # [P,256,Cl] partials, small
+    else:
+        dwb = None
         if need_w:
-            dw = dw.reshape(ctx.wshape)
-        if need_b and db is None:
-            db = channel_sum(dy)
-        return dx, dw, db
+            dwb = torch.empty((lib.cocos_proj1x1_bwd_partials(B, Cin, Cout, N), Cout, Cin), device=x.device,
+                              dtype=torch.float32)
+        _call("proj1x1_bwd", "cocos_proj1x1_bwd", x.data_ptr(), w2.data_ptr(), dy.data_ptr(), _ptr(dx),
+              _ptr(dwb), B, Cin, Cout, N, _stream())
+        if need_w:
+            dw = sum_leading(dwb)
+    if need_w:
+        dw = dw.reshape(wshape)
+    if need_b and db is None:
+        db = channel_sum(dy)
+    return dx, dw, db
 
 
 def proj1x1(x, weight, bias=None):
     """nn.Conv2d(Cin, Cout, kernel_size=1): x [B,Cin,h,w], weight [Cout,Cin,1,1].  PROJ_PRECISION "f16x3" (default):
     the streaming split-precision kernels at the reference's shapes, else the split GEMM; "fp32": the fp32-MFMA GEMM."""
     return _Proj1x1.apply(x, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------
+# K23  K0 fused with K1: projection -> centre -> L2-normalise -> operand planes   (correspondence.py:272-289; proj_norm_f16x3.hip)
+# ------------------------------------------------------------------------------------------
+#: False: the fused match_kernel-1 path projects with K0 and normalises with K1 in separate launches (the round-5 chain; A/B runs)
+PROJ_NORM_FUSED = os.environ.get("COCOS_PROJ_NORM_FUSED", "1") != "0"
+
+
+class LazyProj1x1:
+    """`conv1x1(x, weight, bias)` of the theta / phi projections (correspondence.py:272,:282), not computed yet.  The hot path asks
+    for what its back end needs: `raw()` — the fp32 projection through K0 (computed once, cached) — or, on the fused
+    match_kernel-1 / PONO_C path, nothing at all: `proj_center_l2norm_planes_pair` then produces the correlation kernels' operand
+    planes straight from `x` (K23) and the projection never exists in HBM.  Quacks like the tensor it stands for where
+    `correspondence_hot_path` looks (shape, is_cuda, dtype, requires_grad, detach)."""
+
+    def __init__(self, x, weight, bias=None):
+        if x.dim() != 4 or weight.shape[1] != x.shape[1]:
+            raise ValueError(f"LazyProj1x1: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}")
+        self.x, self.weight, self.bias = x, weight, bias
+        self._raw = None
+
+    @property
+    def shape(self):
+        return torch.Size((self.x.shape[0], self.weight.shape[0], self.x.shape[2], self.x.shape[3]))
+
+    is_cuda = property(lambda self: self.x.is_cuda)
+    dtype = property(lambda self: self.x.dtype)
+    device = property(lambda self: self.x.device)
+
+    @property
+    def requires_grad(self):
+        return any(t is not None and t.requires_grad for t in (self.x, self.weight, self.bias))
+
+    def detach(self):
+        return LazyProj1x1(self.x.detach(), self.weight.detach(), None if self.bias is None else self.bias.detach())
+
+    def raw(self):
+        if self._raw is None:
+            self._raw = proj1x1(self.x, self.weight, self.bias)
+        return self._raw
+
+
+def proj_norm_fused_ok(p: LazyProj1x1) -> bool:
+    """Shapes K23 takes: 256 output channels, whole 128-position tiles, fp32 on the GPU, the split flavour."""
+    B, Cout, h, w = p.shape
+    return (PROJ_NORM_FUSED and PROJ_PRECISION == "f16x3" and PRECISION == "f16x3" and p.is_cuda and p.dtype == torch.float32
+            and Cout == FUSED_K and (h * w) % 128 == 0 and p.x.shape[1] <= 4096 and p.x.shape[1] * h * w * 4 < 2 ** 31 - 1)
+
+
+class _ProjCenterL2NormPlanesPair(torch.autograd.Function):
+    """K23 for the two projections of a forward call (theta, phi): ONE launch -> operand planes (handed to the caller's
+    OperandPlanes) + row norms.  Outputs are HANDLES as in _CenterL2NormPlanes: [B,256,N] tensors whose memory is never written
+    or read (the split correlation kernels read the planes); their gradients (d qn / d kn from K2's backward) come back here and
+    go through K1's backward (cocos_center_l2norm_bwd_planes) and K0's (_proj1x1_backward)."""
+
+    @staticmethod
+    def forward(ctx, x1, w1, b1, x2, w2, b2, center_over_channels: int, eps: float, planes, want_chan: bool):
+        lib = _lib.load()
+        xs = [_chk(x1, "proj_center_l2norm_planes: x (theta)"), _chk(x2, "proj_center_l2norm_planes: x (phi)")]
+        ws = [_chk(w1.reshape(w1.shape[0], -1), "proj_center_l2norm_planes: weight"),
+              _chk(w2.reshape(w2.shape[0], -1), "proj_center_l2norm_planes: weight")]
+        bs = [None if b is None else _chk(b, "proj_center_l2norm_planes: bias") for b in (b1, b2)]
+        B, Cin, h, w = xs[0].shape
+        N = h * w
+        if xs[1].shape != xs[0].shape or ws[0].shape != (FUSED_K, Cin) or ws[1].shape != (FUSED_K, Cin):
+            raise ValueError("proj_center_l2norm_planes_pair: the two projections must have the same shapes "
+                             f"(x {tuple(xs[0].shape)} / {tuple(xs[1].shape)}, weights {tuple(ws[0].shape)} / {tuple(ws[1].shape)})")
+        dev = xs[0].device
+        half = dict(device=dev, dtype=torch.float16)
+        args, keep, tplanes = [], [], []
+        for x, w2d, bb in zip(xs, ws, bs):
+            xa = _recall_amax(x, consume=False)
+            xa = absmax(x) if xa is None else xa
+            wa = _recall_amax(w2d)          # left by K21 when the layer is spectral-normed, else one small pass
+            wa = absmax(w2d) if wa is None else wa
+            wfrag = torch.empty(lib.cocos_proj_weight_frag_bytes(Cin), device=dev, dtype=torch.uint8)
+            wsc = torch.empty(1, device=dev, dtype=torch.float32)
+            # ... and, when the input gradient will be wanted, the transposed planes [Cin][256] of dx = W^T dy in the same launch
+            th = tl = None
+            if ctx.needs_input_grad[3 * len(keep)]:
+                th, tl = torch.empty((Cin, FUSED_K), **half), torch.empty((Cin, FUSED_K), **half)
+            _call("split_f16", "cocos_proj_weight_frag_planes", w2d.data_ptr(), wa.data_ptr(), wfrag.data_ptr(), wsc.data_ptr(),
+                  _ptr(th), _ptr(tl), FUSED_K, Cin, _stream())
+            tplanes.append((th, tl, wsc) if th is not None else None)
+            norm = torch.empty((B, N), device=dev, dtype=torch.float32)
+            ph, pl = torch.empty((B, N, FUSED_K), **half), torch.empty((B, N, FUSED_K), **half)
+            ch = cl = None
+            if want_chan:
+                ch, cl = torch.empty((B, FUSED_K, N), **half), torch.empty((B, FUSED_K, N), **half)
+            args += [x.data_ptr(), wfrag.data_ptr(), wsc.data_ptr(), _ptr(bb), xa.data_ptr(), norm.data_ptr(), ph.data_ptr(),
+                     pl.data_ptr(), _ptr(ch), _ptr(cl)]
+            keep.append((xa, wa, wfrag, wsc, norm, ph, pl, ch, cl))
+        _call("proj_center_l2norm_fwd", "cocos_proj_center_l2norm_planes_f16x3", 2, *args, B, Cin, N, int(center_over_channels),
+              float(eps), SPLIT_OPERAND_SCALE, _stream())
+        handles = []
+        for (_xa, _wa, _wf, _ws, norm, ph, pl, ch, cl) in keep:
+            hd = torch.empty((B, FUSED_K, N), device=dev, dtype=torch.float32)      # never written, never read: an autograd handle
+            planes.put(hd, True, SPLIT_OPERAND_SCALE, ph, pl)
+            if want_chan:
+                planes.put(hd, False, SPLIT_OPERAND_SCALE, ch, cl)
+            handles.append(hd)
+        ctx.save_for_backward(xs[0], ws[0], xs[1], ws[1], keep[0][4], keep[1][4])
+        ctx.chan = [(k[7], k[8]) for k in keep]
+        ctx.amax = [(k[0], k[1]) for k in keep]
+        ctx.t_planes = tplanes
+        ctx.cfg = (int(center_over_channels), float(eps))
+        ctx.wshapes = (tuple(w1.shape), tuple(w2.shape))
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        return handles[0], handles[1]
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        x1, w1, x2, w2, n1, n2 = ctx.saved_tensors
+        mode, eps = ctx.cfg
+        out = []
+        for i, (x, w2d, norm, dy) in enumerate(((x1, w1, n1, d1), (x2, w2, n2, d2))):
+            need_x, need_w, need_b = ctx.needs_input_grad[3 * i:3 * i + 3]
+            if dy is None or not (need_x or need_w or need_b):
+                out += [None, None, None]
+                continue
+            ch, cl = ctx.chan[i]
+            if ch is None:
+                raise _lib.CocosHipError("proj_center_l2norm_planes: backward without the channel-major planes (forward ran without grad)")
+            dy = _chk(dy, "proj_center_l2norm_planes: d qn")
+            B, K, N = dy.shape
+            dth = torch.empty((B, K, x.shape[2], x.shape[3]), device=dy.device, dtype=torch.float32)
+            cell = _zero_cell(dy.device)
+            _call("center_l2norm_bwd", "cocos_center_l2norm_bwd_planes", ch.data_ptr(), cl.data_ptr(), norm.data_ptr(),
+                  dy.data_ptr(), dth.data_ptr(), B, K, N, mode, eps, SPLIT_OPERAND_SCALE, cell.data_ptr(), _stream())
+            _remember_amax(dth, cell)
+            lib = _lib.load()
+            Cin = x.shape[1]
+            stream = PROJ_STREAM and N % 64 == 0 and lib.cocos_proj1x1_stream_kpad(Cin) != 0 and lib.cocos_proj1x1_stream_kpad(K) != 0
+            out += list(_proj1x1_backward(x, w2d, dth, ctx.amax[i], ctx.t_planes[i], True, stream, need_x, need_w,
+                                          need_b and ctx.has_bias[i], ctx.wshapes[i]))
+        return (*out, None, None, None, None)
+
+
+def proj_center_l2norm_planes_pair(theta: LazyProj1x1, phi: LazyProj1x1, center_over_channels, planes: OperandPlanes,
+                                   eps: float = NORM_EPS, want_chan: bool = True):
+    """(qn handle, kn handle) of the two lazy projections through K23: see _ProjCenterL2NormPlanesPair.  Pass the handles to
+    corr_softmax_warp(..., planes=planes).  Only for proj_norm_fused_ok() shapes on the split path (corr_split_ok)."""
+    return _ProjCenterL2NormPlanesPair.apply(theta.x, theta.weight, theta.bias, phi.x, phi.weight, phi.bias,
+                                             int(center_over_channels), eps, planes, bool(want_chan))
 
 
 # ------------------------------------------------------------------------------------------

@@ -340,6 +340,30 @@ int cocos_proj1x1_stream_kpad(int K);
 int cocos_proj1x1_stream_f16x3(const float* x, const void* a_hi, const void* a_lo, const float* a_scale_dev,
                                const float* bias, float* y, int B, int K, int M, int N, const float* x_amax,
                                cocos_stream_t stream);
+/* K23 (round 6): K0 FUSED with K1 — the theta / phi 1x1 projection, centring over the channels and the L2 normalisation in one
+ * kernel whose only products are the operand planes of the split correlation kernels (correspondence.py:272 + :277-280,
+ * :282 + :287-289; csrc/proj_norm_f16x3.hip).  The fp32 projection never reaches HBM.
+ *   cocos_proj_weight_frag_planes: w [256][K] fp32 (+ device cell max|w|) -> the weight's f16 hi / lo planes in the kernel's
+ *       fragment order (cocos_proj_weight_frag_bytes(K) bytes: one 16 KB stage per 16 input channels, zero beyond K) and
+ *       *w_scale = the power of two they were multiplied with; t_hi / t_lo (nullable pair): the same scaled numbers as transposed
+ *       row-major planes [K][256] = the A operand of dx = W^T dy in cocos_proj1x1_stream_f16x3 (scale: *w_scale).  Once per step
+ *       and projection.
+ *   cocos_proj_center_l2norm_planes_f16x3: up to two projections of the same shape in one launch (theta and phi of a
+ *       forward call fill the chip together: two workgroups per CU).  Per projection: x [B,K,N] fp32 (N % 128 == 0),
+ *       x_amax (device cell max|x|, NULL = 1), bias [256] (nullable) -> norm [B,N] (the L2 norm of the centred column) and the
+ *       planes of plane_scale * y, y = (W x + bias - mean) / (norm + eps): position-major [B,N,256] (always) and
+ *       channel-major [B,256,N] (chan_hi / chan_lo, nullable pair — the backward's operands), same layouts and rounding
+ *       as cocos_center_l2norm_fwd_planes.  center_over_channels: 1 (PONO_C) or 2 (no centring).
+ *       The backward is cocos_center_l2norm_bwd_planes followed by K0's (cocos_proj1x1_stream_f16x3 with the transposed
+ *       planes, cocos_proj1x1_dw_f16x3). */
+size_t cocos_proj_weight_frag_bytes(int K);
+int cocos_proj_weight_frag_planes(const float* w, const float* w_amax_dev, void* wfrag, float* w_scale_dev,
+                                  void* t_hi /* nullable */, void* t_lo /* nullable */, int M, int K, cocos_stream_t stream);
+int cocos_proj_center_l2norm_planes_f16x3(
+    int nprob, const float* x0, const void* wfrag0, const float* w_scale0, const float* bias0, const float* x_amax0, float* norm0,
+    void* pos_hi0, void* pos_lo0, void* chan_hi0, void* chan_lo0, const float* x1, const void* wfrag1, const float* w_scale1,
+    const float* bias1, const float* x_amax1, float* norm1, void* pos_hi1, void* pos_lo1, void* chan_hi1, void* chan_lo1, int B,
+    int K, int N, int center_over_channels, float eps, float plane_scale, cocos_stream_t stream);
 /* K0 weight and bias gradient as one streaming reduction (autograd of correspondence.py:272,:282):
  *     dw[m,c] = sum_{b,n} dy[b,m,n] x[b,c,n]      db[m] = sum_{b,n} dy[b,m,n]   (db, ws_db: both or neither NULL)
  * dy [B,M,N], x [B,C,N] fp32, read once; f16x3 products with the power-of-two scales from dy_amax / x_amax.

@@ -106,7 +106,24 @@ def bench_oracle():
 def test_bench_configuration_forward_and_all_gradients_vs_fp64(bench_oracle, precision):
     """B=8, HW=4096, Cl=407, Cv=154: the step bench.py times, output for output and gradient for gradient (the
     theta/phi-only backward: saved logits -> query kernel in the blocked layout -> planes GEMM over all 8 samples,
-    then K1 and K0 backward)."""
+    then K1 and K0 backward).  Round 6: the f16x3 flavour's forward goes through K23 (projection + K1 fused, lazy projections)."""
+    from cocosnet_amd import ops
+    with ops.KernelTimer() as kt:
+        _bench_configuration_vs_fp64(bench_oracle, precision)
+    assert ("proj_center_l2norm_fwd" in kt.summary()) == (precision == "f16x3"), sorted(kt.summary())
+
+
+def test_bench_configuration_unfused_projection_chain_vs_fp64(bench_oracle, monkeypatch):
+    """The same step with ops.PROJ_NORM_FUSED = False: K0 (`proj1x1`) -> K1 (`center_l2norm_planes`) in separate launches — the
+    round-5 chain stays a tested route (it is what every non-fused back end and the match_kernel-3 path project with)."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PROJ_NORM_FUSED", False)
+    with ops.KernelTimer() as kt:
+        _bench_configuration_vs_fp64(bench_oracle, "f16x3")
+    assert "proj_center_l2norm_fwd" not in kt.summary() and "proj1x1_fwd" in kt.summary(), sorted(kt.summary())
+
+
+def _bench_configuration_vs_fp64(bench_oracle, precision):
     model, d, ref = bench_oracle
     for p in model.parameters():
         p.grad = None

@@ -1,0 +1,167 @@
+"""K23 — the theta / phi projection fused with centre + L2-normalise (proj_norm_f16x3.hip, correspondence.py:272-289) on the GPU
+(`-m gpu`), against fp64 restatements:
+
+  * the operand planes it writes (both orientations, both projections of the pair launch) against fp64 conv1x1 -> centre ->
+    normalise (oracle.corr_oracle.center_l2norm), for the reference's channel counts (256, 256 + 151 labels), ragged ones
+    (K not a multiple of the 16-wide k-step, K < 16) and 1 .. 32 position tiles per sample;
+  * the same planes against the ones the unfused chain (K0 `proj1x1` -> K1 `center_l2norm_planes`) writes;
+  * through `correspondence_hot_path`: lazy projections (K23) and eager ones (K0 + K1) give the same outputs and the same
+    gradients w.r.t. features, weights and biases (the bench configuration's fp64 test runs both: test_gpu_baseline_sizes.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import corr_oracle as co
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu(hip_lib):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (the HIP path has no fallback)")
+
+
+def _planes_to_f64(hi, lo, scale):
+    return (hi.double() + lo.double()).cpu().numpy() / scale
+
+
+def _case(B, Cin, h, w, seed, bias=True, x_scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x1 = torch.randn(B, Cin, h, w, device=DEV, generator=g) * x_scale
+    x2 = (0.3 * x1 + torch.randn(B, Cin, h, w, device=DEV, generator=g)) * x_scale
+    w1 = torch.randn(256, Cin, 1, 1, device=DEV, generator=g) / Cin ** 0.5
+    w2 = torch.randn(256, Cin, 1, 1, device=DEV, generator=g) / Cin ** 0.5
+    b1 = torch.randn(256, device=DEV, generator=g) * 0.1 if bias else None
+    b2 = torch.randn(256, device=DEV, generator=g) * 0.1 if bias else None
+    return x1, w1, b1, x2, w2, b2
+
+
+def _ref_qn(x, w, b, center=True):
+    x64, w64 = x.double().cpu().numpy(), w.double().cpu().numpy().reshape(w.shape[0], -1)
+    B, Cin = x64.shape[:2]
+    th = np.einsum("mk,bkn->bmn", w64, x64.reshape(B, Cin, -1))
+    if b is not None:
+        th = th + b.double().cpu().numpy()[None, :, None]
+    if not center:
+        return th / (np.linalg.norm(th, axis=1, keepdims=True) + co.EPS)
+    return co.center_l2norm(th, True)
+
+
+@pytest.mark.parametrize("B,Cin,h,w,bias", [(2, 407, 16, 16, True), (1, 256, 8, 16, True), (3, 19, 8, 16, False), (1, 3, 16, 8, True),
+                                            (2, 64, 64, 64, True), (1, 417, 4, 32, True)])
+def test_k23_planes_match_fp64_projection_centring_normalisation(B, Cin, h, w, bias):
+    from cocosnet_amd import ops
+    x1, w1, b1, x2, w2, b2 = _case(B, Cin, h, w, seed=Cin + h)
+    N = h * w
+    planes = ops.OperandPlanes()
+    with torch.no_grad():
+        qn, kn = ops.proj_center_l2norm_planes_pair(ops.LazyProj1x1(x1, w1, b1), ops.LazyProj1x1(x2, w2, b2), 1, planes, want_chan=True)
+    assert qn.shape == (B, 256, N) and kn.shape == (B, 256, N)
+    S = ops.SPLIT_OPERAND_SCALE
+    for hd, (x, wt, bb) in ((qn, (x1, w1, b1)), (kn, (x2, w2, b2))):
+        ref = _ref_qn(x, wt, bb)                                            # [B,256,N], unit columns
+        ph, pl = planes.get(hd, True, S)
+        ch, cl = planes.get(hd, False, S)
+        assert ph.shape == (B, N, 256) and ch.shape == (B, 256, N)
+        got_pos = _planes_to_f64(ph, pl, S).transpose(0, 2, 1)
+        got_chan = _planes_to_f64(ch, cl, S)
+        # entries of unit-norm columns: |.| <= 1; hi + lo carries 22 bits, the projection's own fp32-class rounding ~1e-6
+        assert np.abs(got_pos - ref).max() < 4e-6, np.abs(got_pos - ref).max()
+        assert np.abs(got_chan - ref).max() < 4e-6, np.abs(got_chan - ref).max()
+        assert np.array_equal(got_pos, got_chan)                            # the two orientations hold the same numbers
+        # hi is the nearest f16 of the scaled value (|lo| <= half an ulp of hi)
+        assert (np.abs(pl.float().cpu().numpy()) <= np.abs(ph.float().cpu().numpy()) * 2.0 ** -10 + 2.0 ** -24).all()
+
+
+def test_k23_without_channel_planes_and_without_centring():
+    """Inference (no channel-major planes) and center_over_channels = 2 (util.feature_normalize semantics)."""
+    from cocosnet_amd import ops
+    x1, w1, b1, x2, w2, b2 = _case(2, 407, 16, 16, seed=5)
+    S = ops.SPLIT_OPERAND_SCALE
+    for mode in (1, 2):
+        planes = ops.OperandPlanes()
+        with torch.no_grad():
+            qn, kn = ops.proj_center_l2norm_planes_pair(ops.LazyProj1x1(x1, w1, b1), ops.LazyProj1x1(x2, w2, b2), mode, planes, want_chan=False)
+        for hd, (x, wt, bb) in ((qn, (x1, w1, b1)), (kn, (x2, w2, b2))):
+            ph, pl = planes.get(hd, True, S)
+            ref = _ref_qn(x, wt, bb, center=(mode == 1))
+            assert np.abs(_planes_to_f64(ph, pl, S).transpose(0, 2, 1) - ref).max() < 4e-6
+            with pytest.raises(Exception):
+                planes.get(hd, False, S)                                     # not written: asking for them is an error, not a re-split
+
+
+@pytest.mark.parametrize("x_scale", [1.0, 3e4, 1e-5])
+def test_k23_equals_the_unfused_chain_and_survives_operand_ranges(x_scale):
+    """Same planes (to fp32 rounding of the projection) as K0 -> K1, also for features near f16's overflow / far below its normal
+    range (the device-side power-of-two scale from max|x|)."""
+    from cocosnet_amd import ops
+    x1, w1, b1, x2, w2, b2 = _case(2, 407, 32, 32, seed=11, x_scale=x_scale)
+    b1, b2 = b1 * x_scale, b2 * x_scale
+    S = ops.SPLIT_OPERAND_SCALE
+    planes = ops.OperandPlanes()
+    with torch.no_grad():
+        qn, kn = ops.proj_center_l2norm_planes_pair(ops.LazyProj1x1(x1, w1, b1), ops.LazyProj1x1(x2, w2, b2), 1, planes, want_chan=True)
+        planes_u = ops.OperandPlanes()
+        qu = ops.center_l2norm_planes(ops.proj1x1(x1, w1, b1).reshape(2, 256, -1), 1, planes_u, want_chan=True)
+    a = _planes_to_f64(*planes.get(qn, True, S), S)
+    u = _planes_to_f64(*planes_u.get(qu, True, S), S)
+    ref = _ref_qn(x1, w1, b1).transpose(0, 2, 1)
+    print("K23_VS_CHAIN", x_scale, "fused", np.abs(a - ref).max(), "chain", np.abs(u - ref).max(), "fused vs chain", np.abs(a - u).max())
+    assert np.abs(a - ref).max() < 4e-6 and np.abs(a - u).max() < 6e-6
+
+
+@pytest.mark.parametrize("mk", [1, 3])
+def test_hot_path_with_lazy_projections_equals_eager_ones(mk):
+    """correspondence_hot_path(LazyProj1x1, LazyProj1x1, ...) == correspondence_hot_path(proj1x1(...), proj1x1(...), ...): outputs and
+    the gradients w.r.t. features, weights, biases.  match_kernel 1 takes K23, match_kernel 3 asks for the projections (K0)."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    B, Cin, fh, down, nc = 2, 64 + 7, 16, 4, 7
+    fw = 64 if mk == 3 else 16
+    x1, w1, b1, x2, w2, b2 = _case(B, Cin, fh, fw, seed=21 + mk)
+    g = torch.Generator(device=DEV).manual_seed(99)
+    H, W = fh * down, fw * down
+    ref_img = torch.rand(B, 3, H, W, device=DEV, generator=g) * 2 - 1
+    lab = torch.randint(0, nc, (B, 1, H, W), device=DEV, generator=g)
+    seg = torch.zeros(B, nc, H, W, device=DEV).scatter_(1, lab, 1.0)
+    cfg = HotPathConfig(match_kernel=mk, PONO_C=True, down=down, warp_mask_losstype="direct", isTrain=True)
+    g_out = torch.randn(B, 3, H, W, device=DEV, generator=g)
+    g_mask = torch.randn(B, nc, fh, fw, device=DEV, generator=g)
+    res = {}
+    for name in ("lazy", "eager"):
+        leaves = [t.clone().requires_grad_(True) for t in (x1, w1, b1, x2, w2, b2)]
+        if name == "lazy":
+            th, ph = ops.LazyProj1x1(*leaves[:3]), ops.LazyProj1x1(*leaves[3:])
+        else:
+            th, ph = ops.proj1x1(*leaves[:3]), ops.proj1x1(*leaves[3:])
+        with ops.KernelTimer() as kt:
+            out = correspondence_hot_path(th, ph, ref_img, ref_img, seg, seg, cfg)
+            torch.autograd.backward([out["warp_out"], out["warp_mask"]], [g_out, g_mask])
+        tags = set(kt.summary())
+        assert ("proj_center_l2norm_fwd" in tags) == (name == "lazy" and mk == 1), (name, mk, sorted(tags))
+        res[name] = ([out["warp_out"].detach(), out["warp_mask"].detach()], [t.grad for t in leaves])
+    relerr = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    for a, b in zip(res["lazy"][0] + res["lazy"][1], res["eager"][0] + res["eager"][1]):
+        assert a.shape == b.shape and relerr(a, b) < 1e-4, relerr(a, b)
+
+
+def test_hot_path_lazy_detach_flag_and_inference():
+    """detach_flag (correspondence.py:292-293): nothing upstream of f receives a gradient, the lazy route included; no-grad
+    inference writes no channel-major planes."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    x1, w1, b1, x2, w2, b2 = _case(1, 32, 16, 16, seed=31)
+    ref_img = torch.rand(1, 3, 64, 64, device=DEV) * 2 - 1
+    seg = torch.zeros(1, 5, 64, 64, device=DEV); seg[:, 2] = 1
+    cfg = HotPathConfig(match_kernel=1, PONO_C=True, down=4, warp_mask_losstype="direct")
+    leaves = [t.clone().requires_grad_(True) for t in (x1, w1, b1, x2, w2, b2)]
+    out = correspondence_hot_path(ops.LazyProj1x1(*leaves[:3]), ops.LazyProj1x1(*leaves[3:]), ref_img, ref_img, seg, seg, cfg, detach_flag=True)
+    assert not out["warp_out"].requires_grad
+    with torch.no_grad():
+        out2 = correspondence_hot_path(ops.LazyProj1x1(*leaves[:3]), ops.LazyProj1x1(*leaves[3:]), ref_img, ref_img, seg, seg, cfg)
+    assert torch.equal(out["warp_out"], out2["warp_out"])
+    with pytest.raises(TypeError):
+        correspondence_hot_path(ops.LazyProj1x1(*leaves[:3]), ops.proj1x1(*leaves[3:]), ref_img, ref_img, seg, seg, cfg)

@@ -37,6 +37,13 @@ for name, d in agg.items():
         rec["MfmaUtil"] = rec["mfma_busy_cycles_per_simd"] / rec["gui_active_cycles_per_xcd"]
     if "SQ_WAIT_ANY" in avg and "SQ_WAVE_CYCLES" in avg and avg["SQ_WAVE_CYCLES"]:
         rec["wait_any_frac"] = avg["SQ_WAIT_ANY"] / avg["SQ_WAVE_CYCLES"]
+    if "SQ_WAVE_CYCLES" in avg and avg["SQ_WAVE_CYCLES"]:
+        for c, k in (("SQ_WAIT_INST_ANY", "wait_inst_frac"), ("SQ_ACTIVE_INST_ANY", "active_inst_frac"), ("SQ_ACTIVE_INST_VALU", "active_valu_frac"),
+                     ("SQ_ACTIVE_INST_LDS", "active_lds_frac"), ("SQ_ACTIVE_INST_VMEM", "active_vmem_frac"), ("SQ_WAIT_INST_LDS", "wait_inst_lds_frac")):
+            if c in avg:
+                rec[k] = avg[c] / avg["SQ_WAVE_CYCLES"]
+    if "SQ_WAVES" in avg:
+        rec["waves"] = avg["SQ_WAVES"]
     if "SQ_LDS_BANK_CONFLICT" in avg:
         rec["lds_bank_conflict_cycles"] = avg["SQ_LDS_BANK_CONFLICT"]
     for c in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_F16"):
