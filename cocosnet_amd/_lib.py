@@ -172,6 +172,17 @@ _SIGNATURES = {
                                               + ([_c_float_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p]
                                                  + [ctypes.c_void_p] * 4) * 2
                                               + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_float, _stream_t]),
+    "cocos_proj_weight_tfrag_bytes": (ctypes.c_size_t, []),
+    "cocos_proj_weight_tfrag_planes": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, ctypes.c_int, ctypes.c_int,
+                                                      _stream_t]),
+    "cocos_proj_bwd_input_supported": (ctypes.c_int, [ctypes.c_int] * 3),
+    "cocos_proj_bwd_input_f16x3": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]
+                                   + ([_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p,
+                                       _c_float_p, _c_float_p, _c_float_p]) * 2
+                                   + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_float, _stream_t]),
+    "cocos_proj1x1_dw_affine_f16x3": (ctypes.c_int, [ctypes.c_int, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, ctypes.c_float,
+                                                     _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p] + [ctypes.c_int] * 4
+                                      + [_c_float_p, _c_float_p, _stream_t]),
     "cocos_proj1x1_bwd_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [_stream_t]),
     "cocos_upsample_nearest_fwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),
     "cocos_upsample_nearest_bwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),
@@ -188,6 +199,7 @@ _SIGNATURES = {
     "cocos_unfold3_stats_fwd_amax": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4
                                      + [ctypes.c_float, ctypes.c_float, _c_float_p, _stream_t]),
     "cocos_unfold3_stats_bwd": (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_int] * 4 + [ctypes.c_float, _stream_t]),
+    "cocos_unfold3_stats_bwd_maps": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_float, _stream_t]),
     "cocos_instnorm_prelu_fwd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float, _stream_t]),
     "cocos_instnorm_prelu_bwd": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 2 + [ctypes.c_float, _stream_t]),
     "cocos_contextual_rows_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_float,

@@ -38,6 +38,7 @@ HIP_SOURCES = [
     "proj_stream_f16x3.hip",
     "proj_dw_f16x3.hip",
     "proj_norm_f16x3.hip",
+    "proj_bwd_f16x3.hip",
     "box3_unfold.hip",
     "box3_fused_f16x3.hip",
     "unfold3_stats.hip",

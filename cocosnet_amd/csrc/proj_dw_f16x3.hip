@@ -50,11 +50,23 @@ __device__ __forceinline__ void dw_split4(const f32x4& x, float s, u32x2& hi, u3
 }
 
 // CBW = 32-column blocks (rows of x) per wave: the workgroup covers 2 * CBW * 32 rows of x
-template <int CBW>
+// DMODE (round 6, K24's companion): 0 — dy is the gradient itself; 1 / 2 — dy is REBUILT while it is staged,
+//     dy[m, n] = alpha_n * in1[m, n] + beta_n * in2[m, n] + gamma_n        (coef [B][3][N] from cocos_proj_bwd_input_f16x3)
+// with in1 = the `dy` argument and in2 = the fp32 projection [B,M,N] (1: match_kernel 3, K12's backward folded in) or the
+// channel-major f16 hi / lo planes [B,M,N] of plane_scale * y (2: match_kernel 1, K1's backward folded in).  The fp32 gradient
+// w.r.t. the projection is then neither written nor read anywhere.
+struct DwAffine {
+    const float* coef;        // [B][3][N]
+    const void* in2a;         // DMODE 1: fp32 [B][M][N];  DMODE 2: hi plane [B][M][N] f16
+    const void* in2b;         // DMODE 2: lo plane
+    float inv_plane_scale;
+};
+
+template <int CBW, int DMODE>
 __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ ws_dw, float* __restrict__ ws_db,
     int M, int C, int N, int chunks_per_img, int chunk_len, const float* __restrict__ dy_amax,
-    const float* __restrict__ x_amax) {
+    const float* __restrict__ x_amax, const DwAffine af) {
     constexpr int XROWS = 2 * CBW * 32;                           // x rows staged per k-step
     constexpr int APLANE = DW_MROWS * DW_ROW, BPLANE = XROWS * DW_ROW;
     constexpr int BUF = 2 * (APLANE + BPLANE);                    // halfs per LDS buffer: A hi, A lo, B hi, B lo
@@ -78,6 +90,10 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(
 
     const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(dy + (size_t)b * M * N, (size_t)M * N * 4);
     const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(x + (size_t)b * C * N, (size_t)C * N * 4);
+    const __amdgpu_buffer_rsrc_t a2_rs = DMODE == 1 ? make_rsrc(static_cast<const float*>(af.in2a) + (size_t)b * M * N, (size_t)M * N * 4)
+                                       : DMODE == 2 ? make_rsrc(static_cast<const _Float16*>(af.in2a) + (size_t)b * M * N, (size_t)M * N * 2) : a_rs;
+    const __amdgpu_buffer_rsrc_t a3_rs = DMODE == 2 ? make_rsrc(static_cast<const _Float16*>(af.in2b) + (size_t)b * M * N, (size_t)M * N * 2) : a_rs;
+    const __amdgpu_buffer_rsrc_t cf_rs = make_rsrc(DMODE ? af.coef + (size_t)b * 3 * N : nullptr, DMODE ? (size_t)3 * N * 4 : 0);
     const float sa = dw_scale_from_amax(dy_amax), sb = dw_scale_from_amax(x_amax);
 
     // ---- staging: piece p of this thread = 4 consecutive positions (kq) of one row -----------------------------
@@ -94,17 +110,48 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(
     }
     _Float16* const lds_t = lds + prow * DW_ROW + kq * 4;         // + buffer, operand, plane, p*64 rows: constants
     f32x4 st[2][NP];
+    // DMODE != 0: the second operand of the affine rebuild of dy (fp32 piece, or hi | lo halves of a plane piece) and the three
+    // coefficient quads of this thread's positions (the same for all of its pieces: kq is fixed), per register stage
+    f32x4 st2[2][DMODE ? NPA : 1], cf[2][DMODE ? 3 : 1];
     float dbsum[NPA];
 #pragma unroll
     for (int p = 0; p < NPA; ++p) dbsum[p] = 0.f;
 
-    auto fetch_piece = [&](f32x4 (&sg)[NP], int p, int t) {       // k-step t (beyond the chunk: zeros)
+    auto fetch_piece = [&](f32x4 (&sg)[NP], int p, int t, int stg = 0) {       // k-step t (beyond the chunk: zeros)
         const int n = n_beg + t * DW_BK;                          // uniform; + kq*4 per lane
         const bool ok = (t < nsteps) && (n + kq * 4 < n_end);
         sg[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
             p < NPA ? a_rs : b_rs, (int)(ok ? voff[p] : kBufOob), n * 4, 0));
+        if (DMODE && p < NPA) {
+            if (DMODE == 1) {
+                st2[stg][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a2_rs, (int)(ok ? voff[p] : kBufOob), n * 4, 0));
+            } else {
+                const u32x2 hw = __builtin_amdgcn_raw_buffer_load_b64(a2_rs, (int)(ok && voff[p] != kBufOob ? voff[p] / 2 : kBufOob), n * 2, 0);
+                const u32x2 lw = __builtin_amdgcn_raw_buffer_load_b64(a3_rs, (int)(ok && voff[p] != kBufOob ? voff[p] / 2 : kBufOob), n * 2, 0);
+                st2[stg][p] = __builtin_bit_cast(f32x4, u32x4{hw.x, hw.y, lw.x, lw.y});
+            }
+            if (p == NPA - 1) {      // (with the LAST dy piece: the earlier pieces of this stage are committed with the old quads first)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)      // (beyond the chunk: zero coefficients -> the rebuilt dy is zero there, gamma included)
+                    cf[stg][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        cf_rs, (int)(ok ? (unsigned)(q * N + kq * 4) * 4u : kBufOob), n * 4, 0));
+            }
+        }
     };
-    auto commit_piece = [&](const f32x4 (&sg)[NP], int p, int buf) {
+    auto commit_piece = [&](f32x4 (&sg)[NP], int p, int buf, int stg = 0) {
+        if (DMODE && p < NPA) {
+            f32x4 v2;
+            if (DMODE == 1) v2 = st2[stg][p];
+            else {
+                typedef _Float16 dw_f16x4 __attribute__((ext_vector_type(4)));
+                const u32x4 w = __builtin_bit_cast(u32x4, st2[stg][p]);
+                const dw_f16x4 h4 = __builtin_bit_cast(dw_f16x4, u32x2{w.x, w.y}), l4 = __builtin_bit_cast(dw_f16x4, u32x2{w.z, w.w});
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v2[e] = ((float)h4[e] + (float)l4[e]) * af.inv_plane_scale;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sg[p][e] = __builtin_fmaf(cf[stg][0][e], sg[p][e], __builtin_fmaf(cf[stg][1][e], v2[e], cf[stg][2][e]));
+        }
         u32x2 hi, lo;
         dw_split4(sg[p], p < NPA ? sa : sb, hi, lo);
         if (p < NPA) dbsum[p] += (sg[p][0] + sg[p][1]) + (sg[p][2] + sg[p][3]);
@@ -159,28 +206,28 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(
 
     // prologue (loads in the order in which the loop consumes them: stage 0 = k-step 0, stage 1 = 1, stage 0 = 2)
 #pragma unroll
-    for (int p = 0; p < NP; ++p) fetch_piece(st[0], p, 0);
+    for (int p = 0; p < NP; ++p) fetch_piece(st[0], p, 0, 0);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) fetch_piece(st[1], p, 1);
+    for (int p = 0; p < NP; ++p) fetch_piece(st[1], p, 1, 1);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) commit_piece(st[0], p, 0);
+    for (int p = 0; p < NP; ++p) commit_piece(st[0], p, 0, 0);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) fetch_piece(st[0], p, 2);
+    for (int p = 0; p < NP; ++p) fetch_piece(st[0], p, 2, 0);
     __syncthreads();
 
     // k-step t: multiply LDS[t&1]; commit stage (t+1)&1 (= k-step t+1) to the other buffer, refill it with t+3
     for (int t = 0; t < nsteps; t += 2) {
         kstep(0, [&](int slot) {
             if (slot < NP) {
-                commit_piece(st[1], slot, 1);
-                fetch_piece(st[1], slot, t + 3);
+                commit_piece(st[1], slot, 1, 1);
+                fetch_piece(st[1], slot, t + 3, 1);
             }
         });
         if (t + 1 < nsteps)
             kstep(1, [&](int slot) {
                 if (slot < NP) {
-                    commit_piece(st[0], slot, 0);
-                    fetch_piece(st[0], slot, t + 4);
+                    commit_piece(st[0], slot, 0, 0);
+                    fetch_piece(st[0], slot, t + 4, 0);
                 }
             });
     }
@@ -292,9 +339,8 @@ extern "C" int cocos_proj1x1_dw_partials_f16x3(int B, int C, int M, int N) {
     return B * cpi;
 }
 
-extern "C" int cocos_proj1x1_dw_f16x3(const float* dy, const float* x, float* ws_dw, float* ws_db, float* dw,
-                                      float* db, int B, int C, int M, int N, const float* dy_amax,
-                                      const float* x_amax, cocos_stream_t stream) {
+static int proj_dw_launch(int dmode, const float* dy, const float* x, float* ws_dw, float* ws_db, float* dw, float* db, int B, int C,
+                          int M, int N, const float* dy_amax, const float* x_amax, const cocos::DwAffine& af, cocos_stream_t stream) {
     using namespace cocos;
     COCOS_REQUIRE(dy && x && ws_dw && dw, COCOS_ERR_INVALID, "proj1x1_dw_f16x3: null pointer");
     COCOS_REQUIRE((db == nullptr) == (ws_db == nullptr), COCOS_ERR_INVALID,
@@ -314,10 +360,14 @@ extern "C" int cocos_proj1x1_dw_f16x3(const float* dy, const float* x, float* ws
         const size_t smem = (size_t)2 * 2 * (DW_MROWS + xrows) * DW_ROW * sizeof(_Float16);
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, dy, x, ws_dw, ws_db, M, C, N, cpi, len, dy_amax, x_amax);
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, dy, x, ws_dw, ws_db, M, C, N, cpi, len, dy_amax, x_amax, af);
         return COCOS_OK;
     };
-    const int rc = cbw == 4 ? launch(proj_dw_f16x3_kernel<4>, 256) : launch(proj_dw_f16x3_kernel<7>, 448);
+    int rc;
+    if (cbw == 4) rc = dmode == 0 ? launch(proj_dw_f16x3_kernel<4, 0>, 256) : dmode == 1 ? launch(proj_dw_f16x3_kernel<4, 1>, 256)
+                                                                                         : launch(proj_dw_f16x3_kernel<4, 2>, 256);
+    else rc = dmode == 0 ? launch(proj_dw_f16x3_kernel<7, 0>, 448) : dmode == 1 ? launch(proj_dw_f16x3_kernel<7, 1>, 448)
+                                                                                : launch(proj_dw_f16x3_kernel<7, 2>, 448);
     if (rc != COCOS_OK) return rc;
     COCOS_HIP_CHECK(hipGetLastError());
     const int CP = (C + 31) / 32 * 32;
@@ -326,4 +376,25 @@ extern "C" int cocos_proj1x1_dw_f16x3(const float* dy, const float* x, float* ws
                        ws_db, db);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+extern "C" int cocos_proj1x1_dw_f16x3(const float* dy, const float* x, float* ws_dw, float* ws_db, float* dw,
+                                      float* db, int B, int C, int M, int N, const float* dy_amax,
+                                      const float* x_amax, cocos_stream_t stream) {
+    return proj_dw_launch(0, dy, x, ws_dw, ws_db, dw, db, B, C, M, N, dy_amax, x_amax, cocos::DwAffine{nullptr, nullptr, nullptr, 1.0f}, stream);
+}
+
+// The same reduction with dy REBUILT on the fly (round 6, the companion of cocos_proj_bwd_input_f16x3):
+//     dy[b,m,n] = coef[b,0,n] * in1[b,m,n] + coef[b,1,n] * in2[b,m,n] + coef[b,2,n]
+// mode 1: in2a = fp32 [B,M,N] (in2b unused);  mode 2: in2a / in2b = channel-major f16 hi / lo planes [B,M,N] of plane_scale * in2.
+// dy_amax: device cell with max|dy| (or an upper bound) — the scale source of the f16 split, as for cocos_proj1x1_dw_f16x3.
+extern "C" int cocos_proj1x1_dw_affine_f16x3(int mode, const float* in1, const void* in2a, const void* in2b, const float* coef,
+                                             float plane_scale, const float* x, float* ws_dw, float* ws_db, float* dw, float* db, int B,
+                                             int C, int M, int N, const float* dy_amax, const float* x_amax, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(mode == 1 || mode == 2, COCOS_ERR_INVALID, "proj1x1_dw_affine_f16x3: mode %d", mode);
+    COCOS_REQUIRE(in2a && coef && (mode == 1 || in2b) && plane_scale > 0.f && dy_amax, COCOS_ERR_INVALID, "proj1x1_dw_affine_f16x3: null pointer");
+    COCOS_REQUIRE(aligned16(in2a) && aligned16(coef) && (mode == 1 || (reinterpret_cast<uintptr_t>(in2b) & 7u) == 0), COCOS_ERR_INVALID,
+                  "proj1x1_dw_affine_f16x3: in2 / coef must be 16-byte aligned");
+    return proj_dw_launch(mode, in1, x, ws_dw, ws_db, dw, db, B, C, M, N, dy_amax, x_amax, DwAffine{coef, in2a, in2b, 1.0f / plane_scale}, stream);
 }

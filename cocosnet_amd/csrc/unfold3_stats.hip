@@ -203,3 +203,19 @@ extern "C" int cocos_unfold3_stats_bwd(const float* x, const float* mu, const fl
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
+
+// Only the two per-position maps of the backward (ws = [g1 | g2], B*h*w floats each): dx[c,p] = g1[p] + 2 x[c,p] g2[p] is then
+// applied by the consumer — round 6: K24 (cocos_proj_bwd_input_f16x3, mode 1) folds it into the projection's backward.
+extern "C" int cocos_unfold3_stats_bwd_maps(const float* mu, const float* a, const float* nrm, const float* dmu /* nullable */,
+                                            const float* da /* nullable */, float* ws /* 2*B*h*w */, int B, int h, int w,
+                                            float k_unfolded, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(mu && a && nrm && ws, COCOS_ERR_INVALID, "unfold3_stats_bwd_maps: null pointer");
+    COCOS_REQUIRE(B >= 1 && B <= 65535 && h >= 1 && w >= 1 && k_unfolded > 0.f, COCOS_ERR_INVALID,
+                  "unfold3_stats_bwd_maps: bad dims B=%d h=%d w=%d", B, h, w);
+    const int N = h * w;
+    hipLaunchKernelGGL(unfold3_bwd_maps_kernel, dim3((N + 255) / 256, B), dim3(256), 0, as_stream(stream), mu, a, nrm, dmu, da, ws,
+                       ws + (size_t)B * N, h, w, k_unfolded);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}

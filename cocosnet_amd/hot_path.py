@@ -149,10 +149,16 @@ class _BoxedCorr:
     blocks at a time (K19).  Nothing box-filtered and no logits matrix reaches HBM."""
 
     def __init__(self, theta_raw, phi_raw, inv_t):
-        self.th, self.ph, self.inv_t = theta_raw, phi_raw, inv_t
         _, C, self.fh, self.fw = theta_raw.shape
         self.kc = float(C * 9)
         self._cache = {}
+        if isinstance(theta_raw, ops.LazyProj1x1):
+            # round 6: projection + K12 statistics as ONE autograd node per tensor (ops.proj_unfold3_stats): its backward folds K12's
+            # backward and the sum of theta_raw's two gradients into the projection's input gradient (K24)
+            theta_raw, mu, a = ops.proj_unfold3_stats(theta_raw, self.kc)
+            phi_raw, nu, b = ops.proj_unfold3_stats(phi_raw, self.kc)
+            self._cache["q"], self._cache["k"] = (mu, a), (nu, b)
+        self.th, self.ph, self.inv_t = theta_raw, phi_raw, inv_t
         # round 4: ONE T for both orientations (xbox(C)^T = xbox(C^T): the column pass reads it transposed) and one gradient
         # buffer for all passes over it — no second correlation GEMM, one box adjoint and one pair of GEMMs in the backward
         self._sink = ops.Box3GradSink() if ops.BOX3_SHARE_T else None
@@ -255,12 +261,15 @@ def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_
     lazy = isinstance(theta_raw, ops.LazyProj1x1) and isinstance(phi_raw, ops.LazyProj1x1)
     if lazy != (isinstance(theta_raw, ops.LazyProj1x1) or isinstance(phi_raw, ops.LazyProj1x1)):
         raise TypeError("correspondence_hot_path: theta and phi must both be tensors or both be ops.LazyProj1x1")
-    k23 = False
+    k23 = boxed_lazy = False
     if lazy:
         keep = torch.is_grad_enabled() and not detach_flag and (theta_raw.requires_grad or phi_raw.requires_grad)
         k23 = (fused and cfg.PONO_C and theta_raw.x.shape == phi_raw.x.shape and ops.proj_norm_fused_ok(theta_raw)
                and ops.proj_norm_fused_ok(phi_raw) and ops.corr_split_ok(B, C, fh * fw, fh * fw, 1, keep))
-        if not k23:
+        # match_kernel 3, fused family: the projections stay lazy up to _BoxedCorr, which makes (theta_raw, mu, a) in one autograd node
+        boxed_lazy = (mk == 3 and cfg.PONO_C and WTA_scale_weight == 1 and not return_corr and _hip_fp32(theta_raw)
+                      and ops.PROJ_BWD_FUSED and ops.box3_fused_ok(B, C, fh, fw))
+        if not (k23 or boxed_lazy):
             theta_raw, phi_raw = theta_raw.raw(), phi_raw.raw()
     if k23:
         th_l, ph_l = (theta_raw.detach(), phi_raw.detach()) if detach_flag else (theta_raw, phi_raw)   # :292-293 `f = f.detach()`

@@ -954,56 +954,62 @@ def channel_sum(dy: torch.Tensor) -> torch.Tensor:
     return db
 
 
+def _proj1x1_forward(x, weight, bias, need_t: bool):
+    """y = conv1x1(x, weight, bias) on K0 -> (y, x, w2, state): `state` = what the backward needs (split / stream flags, the max|.|
+    cells, the transposed weight planes when `need_t`).  Shared by _Proj1x1 and _ProjUnfoldStats."""
+    x = _chk(x, "proj1x1: x")
+    w2 = _chk(weight.reshape(weight.shape[0], -1), "proj1x1: weight")
+    B, Cin, h, w = x.shape
+    Cout = w2.shape[0]
+    if w2.shape[1] != Cin:
+        raise ValueError(f"proj1x1: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}")
+    bb = None if bias is None else _chk(bias, "proj1x1: bias")
+    y = torch.empty((B, Cout, h, w), device=x.device, dtype=torch.float32)
+    split = PROJ_PRECISION == "f16x3" and min(Cin * Cout, Cin * h * w, Cout * h * w) >= 4
+    # the reference's shapes (<= 416 input channels, grid a multiple of 64 positions): weight planes resident in
+    # the accumulator file, x and y streamed once (proj_stream_f16x3.hip)
+    lib = _lib.load()
+    stream = (split and PROJ_STREAM and (h * w) % 64 == 0 and lib.cocos_proj1x1_stream_kpad(Cin) != 0
+              and lib.cocos_proj1x1_stream_kpad(Cout) != 0)
+    st = dict(split=split, stream=stream, amax=None, t_planes=None, wshape=tuple(weight.shape), has_bias=bias is not None)
+    if split:      # products on the f16 MFMA, operands split on the fly (sgemm_f16x3.hip)
+        wa = _recall_amax(w2)      # left by K21 when the layer is spectral-normed (W / sigma), else one small pass
+        xa, wa = absmax(x), (absmax(w2) if wa is None else wa)
+        if stream:
+            # A = W as planes [Cout][Kpad], rows zero-padded to whole MFMA k-steps
+            kp = lib.cocos_proj1x1_stream_kpad(Cin)
+            wh = torch.empty((Cout, kp), device=x.device, dtype=torch.float16)
+            wl = torch.empty((Cout, kp), device=x.device, dtype=torch.float16)
+            ws = torch.empty(1, device=x.device, dtype=torch.float32)
+            # ... and, when the input gradient will be wanted, the transposed planes [Cin][Kpad(Cout)] of dx = W^T dy
+            # in the same launch (they used to be a second split in the backward)
+            th = tl = None
+            if need_t:
+                kpo = lib.cocos_proj1x1_stream_kpad(Cout)
+                th = torch.empty((Cin, kpo), device=x.device, dtype=torch.float16)
+                tl = torch.empty((Cin, kpo), device=x.device, dtype=torch.float16)
+            _call("split_f16", "cocos_proj_weight_planes", w2.data_ptr(), wh.data_ptr(), wl.data_ptr(), _ptr(th), _ptr(tl),
+                  Cout, Cin, kp, lib.cocos_proj1x1_stream_kpad(Cout), wa.data_ptr(), ws.data_ptr(), _stream())
+            st["t_planes"] = (th, tl, ws) if th is not None else None
+            _call("proj1x1_fwd", "cocos_proj1x1_stream_f16x3", x.data_ptr(), wh.data_ptr(), wl.data_ptr(),
+                  ws.data_ptr(), _ptr(bb), y.data_ptr(), B, Cin, Cout, h * w, xa.data_ptr(), _stream())
+        else:
+            _call("proj1x1_fwd", "cocos_proj1x1_fwd_f16x3", x.data_ptr(), w2.data_ptr(), _ptr(bb), y.data_ptr(),
+                  B, Cin, Cout, h * w, xa.data_ptr(), wa.data_ptr(), _stream())
+        st["amax"] = (xa, wa)
+    else:
+        _call("proj1x1_fwd", "cocos_proj1x1_fwd", x.data_ptr(), w2.data_ptr(), _ptr(bb), y.data_ptr(), B, Cin,
+              Cout, h * w, _stream())
+    return y, x, w2, st
+
+
 class _Proj1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
-        x = _chk(x, "proj1x1: x")
-        w2 = _chk(weight.reshape(weight.shape[0], -1), "proj1x1: weight")
-        B, Cin, h, w = x.shape
-        Cout = w2.shape[0]
-        if w2.shape[1] != Cin:
-            raise ValueError(f"proj1x1: weight {tuple(weight.shape)} does not match input {tuple(x.shape)}")
-        bb = None if bias is None else _chk(bias, "proj1x1: bias")
-        y = torch.empty((B, Cout, h, w), device=x.device, dtype=torch.float32)
-        split = PROJ_PRECISION == "f16x3" and min(Cin * Cout, Cin * h * w, Cout * h * w) >= 4
-        # the reference's shapes (<= 416 input channels, grid a multiple of 64 positions): weight planes resident in
-        # the accumulator file, x and y streamed once (proj_stream_f16x3.hip)
-        lib = _lib.load()
-        stream = (split and PROJ_STREAM and (h * w) % 64 == 0 and lib.cocos_proj1x1_stream_kpad(Cin) != 0
-                  and lib.cocos_proj1x1_stream_kpad(Cout) != 0)
-        if split:      # products on the f16 MFMA, operands split on the fly (sgemm_f16x3.hip)
-            wa = _recall_amax(w2)      # left by K21 when the layer is spectral-normed (W / sigma), else one small pass
-            xa, wa = absmax(x), (absmax(w2) if wa is None else wa)
-            if stream:
-                # A = W as planes [Cout][Kpad], rows zero-padded to whole MFMA k-steps
-                kp = lib.cocos_proj1x1_stream_kpad(Cin)
-                wh = torch.empty((Cout, kp), device=x.device, dtype=torch.float16)
-                wl = torch.empty((Cout, kp), device=x.device, dtype=torch.float16)
-                ws = torch.empty(1, device=x.device, dtype=torch.float32)
-                # ... and, when the input gradient will be wanted, the transposed planes [Cin][Kpad(Cout)] of dx = W^T dy
-                # in the same launch (they used to be a second split in the backward)
-                th = tl = None
-                if ctx.needs_input_grad[0]:
-                    kpo = lib.cocos_proj1x1_stream_kpad(Cout)
-                    th = torch.empty((Cin, kpo), device=x.device, dtype=torch.float16)
-                    tl = torch.empty((Cin, kpo), device=x.device, dtype=torch.float16)
-                _call("split_f16", "cocos_proj_weight_planes", w2.data_ptr(), wh.data_ptr(), wl.data_ptr(), _ptr(th), _ptr(tl),
-                      Cout, Cin, kp, lib.cocos_proj1x1_stream_kpad(Cout), wa.data_ptr(), ws.data_ptr(), _stream())
-                ctx.t_planes = (th, tl, ws) if th is not None else None
-                _call("proj1x1_fwd", "cocos_proj1x1_stream_f16x3", x.data_ptr(), wh.data_ptr(), wl.data_ptr(),
-                      ws.data_ptr(), _ptr(bb), y.data_ptr(), B, Cin, Cout, h * w, xa.data_ptr(), _stream())
-            else:
-                _call("proj1x1_fwd", "cocos_proj1x1_fwd_f16x3", x.data_ptr(), w2.data_ptr(), _ptr(bb), y.data_ptr(),
-                      B, Cin, Cout, h * w, xa.data_ptr(), wa.data_ptr(), _stream())
-            ctx.amax = (xa, wa)
-        else:
-            _call("proj1x1_fwd", "cocos_proj1x1_fwd", x.data_ptr(), w2.data_ptr(), _ptr(bb), y.data_ptr(), B, Cin,
-                  Cout, h * w, _stream())
-        ctx.split = split
-        ctx.stream = stream
+        y, x, w2, st = _proj1x1_forward(x, weight, bias, ctx.needs_input_grad[0])
+        ctx.split, ctx.stream, ctx.amax, ctx.t_planes = st["split"], st["stream"], st["amax"], st["t_planes"]
         ctx.save_for_backward(x, w2)
-        ctx.wshape = tuple(weight.shape)
-        ctx.has_bias = bias is not None
+        ctx.wshape, ctx.has_bias = st["wshape"], st["has_bias"]
         return y
 
     @staticmethod
@@ -1086,6 +1092,10 @@ def proj1x1(x, weight, bias=None):
 # ------------------------------------------------------------------------------------------
 #: False: the fused match_kernel-1 path projects with K0 and normalises with K1 in separate launches (the round-5 chain; A/B runs)
 PROJ_NORM_FUSED = os.environ.get("COCOS_PROJ_NORM_FUSED", "1") != "0"
+#: False: the projections' backward runs as round 5's chain (K1 backward / K12 backward + autograd's add -> max|.| -> input gradient ->
+#: weight gradient); True: K24 (cocos_proj_bwd_input_f16x3) folds everything in front of the input gradient into it and the weight
+#: gradient rebuilds its dy on the fly (A/B runs)
+PROJ_BWD_FUSED = os.environ.get("COCOS_PROJ_BWD_FUSED", "1") != "0"
 
 
 class LazyProj1x1:
@@ -1149,7 +1159,7 @@ class _ProjCenterL2NormPlanesPair(torch.autograd.Function):
                              f"(x {tuple(xs[0].shape)} / {tuple(xs[1].shape)}, weights {tuple(ws[0].shape)} / {tuple(ws[1].shape)})")
         dev = xs[0].device
         half = dict(device=dev, dtype=torch.float16)
-        args, keep, tplanes = [], [], []
+        args, keep, tplanes, tfrags = [], [], [], []
         for x, w2d, bb in zip(xs, ws, bs):
             xa = _recall_amax(x, consume=False)
             xa = absmax(x) if xa is None else xa
@@ -1164,6 +1174,13 @@ class _ProjCenterL2NormPlanesPair(torch.autograd.Function):
             _call("split_f16", "cocos_proj_weight_frag_planes", w2d.data_ptr(), wa.data_ptr(), wfrag.data_ptr(), wsc.data_ptr(),
                   _ptr(th), _ptr(tl), FUSED_K, Cin, _stream())
             tplanes.append((th, tl, wsc) if th is not None else None)
+            # ... and W^T in K24's fragment order when the fused backward will run (its own tiny launch: a different grid)
+            wtf = None
+            if th is not None and PROJ_BWD_FUSED and lib.cocos_proj_bwd_input_supported(Cin, FUSED_K, N):
+                wtf = torch.empty(lib.cocos_proj_weight_tfrag_bytes(), device=dev, dtype=torch.uint8)
+                _call("split_f16", "cocos_proj_weight_tfrag_planes", w2d.data_ptr(), wa.data_ptr(), wtf.data_ptr(), None, FUSED_K, Cin,
+                      _stream())
+            tfrags.append(wtf)
             norm = torch.empty((B, N), device=dev, dtype=torch.float32)
             ph, pl = torch.empty((B, N, FUSED_K), **half), torch.empty((B, N, FUSED_K), **half)
             ch = cl = None
@@ -1185,6 +1202,9 @@ class _ProjCenterL2NormPlanesPair(torch.autograd.Function):
         ctx.chan = [(k[7], k[8]) for k in keep]
         ctx.amax = [(k[0], k[1]) for k in keep]
         ctx.t_planes = tplanes
+        ctx.tfrags = tfrags
+        ctx.pos = [(k[5], k[6]) for k in keep]          # position-major planes: K24 reads y back from them
+        ctx.wsc = [k[3] for k in keep]
         ctx.cfg = (int(center_over_channels), float(eps))
         ctx.wshapes = (tuple(w1.shape), tuple(w2.shape))
         ctx.has_bias = (b1 is not None, b2 is not None)
@@ -1194,6 +1214,34 @@ class _ProjCenterL2NormPlanesPair(torch.autograd.Function):
     def backward(ctx, d1, d2):
         x1, w1, x2, w2, n1, n2 = ctx.saved_tensors
         mode, eps = ctx.cfg
+        needs = ctx.needs_input_grad
+        if (d1 is not None and d2 is not None and needs[0] and needs[3] and all(t is not None for t in ctx.tfrags)
+                and (needs[1] or not needs[2]) and (needs[4] or not needs[5])):
+            # K24: K1's backward + the input gradient of BOTH projections in one launch; the weight gradients rebuild d on the fly
+            d = [_chk(d1, "proj_center_l2norm_planes: d qn"), _chk(d2, "proj_center_l2norm_planes: d kn")]
+            xs, w2s, norms = (x1, x2), (w1, w2), (n1, n2)
+            B, K, N = d[0].shape
+            Cin = x1.shape[1]
+            dev = d[0].device
+            dxs = [torch.empty_like(x1), torch.empty_like(x2)]
+            coefs = [torch.empty((B, 3, N), device=dev, dtype=torch.float32) for _ in range(2)]
+            cells = [_zero_cell(dev), _zero_cell(dev)]
+            args = []
+            for i in range(2):
+                ph, pl = ctx.pos[i]
+                args += [d[i].data_ptr(), ph.data_ptr(), pl.data_ptr(), norms[i].data_ptr(), None, ctx.tfrags[i].data_ptr(),
+                         ctx.wsc[i].data_ptr(), dxs[i].data_ptr(), coefs[i].data_ptr(), cells[i].data_ptr()]
+            _call("proj_bwd_input", "cocos_proj_bwd_input_f16x3", 0, 2, *args, B, Cin, N, mode, eps, SPLIT_OPERAND_SCALE, _stream())
+            out = []
+            for i in range(2):
+                need_w, need_b = needs[3 * i + 1], needs[3 * i + 2] and ctx.has_bias[i]
+                dw = db = None
+                if need_w:
+                    ch, cl = ctx.chan[i]
+                    dw, db = _proj1x1_dw_affine(2, d[i], ch, cl, coefs[i], SPLIT_OPERAND_SCALE, xs[i], cells[i], ctx.amax[i][0], need_b)
+                    dw = dw.reshape(ctx.wshapes[i])
+                out += [dxs[i], dw, db]
+            return (*out, None, None, None, None)
         out = []
         for i, (x, w2d, norm, dy) in enumerate(((x1, w1, n1, d1), (x2, w2, n2, d2))):
             need_x, need_w, need_b = ctx.needs_input_grad[3 * i:3 * i + 3]
@@ -1216,6 +1264,102 @@ class _ProjCenterL2NormPlanesPair(torch.autograd.Function):
             out += list(_proj1x1_backward(x, w2d, dth, ctx.amax[i], ctx.t_planes[i], True, stream, need_x, need_w,
                                           need_b and ctx.has_bias[i], ctx.wshapes[i]))
         return (*out, None, None, None, None)
+
+
+def _proj1x1_dw_affine(mode, in1, in2a, in2b, coef, plane_scale, x, d_amax, x_amax, need_b):
+    """(dw [Cout,Cin], db | None) of a 1x1 projection whose output gradient is alpha in1 + beta in2 + gamma (coef [B,3,N] from K24),
+    rebuilt inside the weight-gradient kernel (cocos_proj1x1_dw_affine_f16x3).  in1 [B,Cout,N] fp32; mode 1: in2a fp32 [B,Cout,N];
+    mode 2: in2a / in2b channel-major f16 planes."""
+    lib = _lib.load()
+    B, Cin = x.shape[:2]
+    Cout, N = in1.shape[1], in1.shape[2]
+    parts = lib.cocos_proj1x1_dw_partials_f16x3(B, Cin, Cout, N)
+    if not parts:
+        raise _lib.CocosHipError(f"proj1x1_dw_affine: shape not supported (Cin={Cin} Cout={Cout} N={N})")
+    ws = torch.empty((parts, Cout, (Cin + 31) // 32 * 32), device=x.device, dtype=torch.float32)
+    wsb = torch.empty((parts, Cout), device=x.device, dtype=torch.float32) if need_b else None
+    dw = torch.empty((Cout, Cin), device=x.device, dtype=torch.float32)
+    db = torch.empty(Cout, device=x.device, dtype=torch.float32) if need_b else None
+    _call("proj1x1_bwd", "cocos_proj1x1_dw_affine_f16x3", mode, in1.data_ptr(), in2a.data_ptr(), _ptr(in2b), coef.data_ptr(),
+          float(plane_scale), x.data_ptr(), ws.data_ptr(), _ptr(wsb), dw.data_ptr(), _ptr(db), B, Cin, Cout, N, d_amax.data_ptr(),
+          x_amax.data_ptr(), _stream())
+    return dw, db
+
+
+class _ProjUnfoldStats(torch.autograd.Function):
+    """match_kernel 3 (round 6): theta_raw = conv1x1(x, w, b) AND the statistics (mu, a) of its 3x3-unfolded vectors (K0 + K12) as ONE
+    autograd node, so that its backward sees both gradients of theta_raw at once — the one through the statistics (K12's
+    backward: g1 + 2 theta_raw g2 per position) and the one from the correlation GEMMs — and folds K12's apply pass, autograd's
+    addition and the max|.| pass into the projection's input gradient (K24 mode 1); the weight gradient rebuilds d on the fly."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, k_unfolded: float, eps: float):
+        lib = _lib.load()
+        y, x, w2, st = _proj1x1_forward(x, weight, bias, ctx.needs_input_grad[0])
+        B, C, h, w = y.shape
+        N = h * w
+        mk = lambda: torch.empty((B, N), device=y.device, dtype=torch.float32)
+        mu, a, nrm = mk(), mk(), mk()
+        ws = torch.empty(2 * B * N, device=y.device, dtype=torch.float32)
+        cell = _zero_cell(y.device)          # max|theta_raw| as a by-product: the correlation GEMM of the fused family splits it next
+        _call("unfold3_stats_fwd", "cocos_unfold3_stats_fwd_amax", y.data_ptr(), mu.data_ptr(), a.data_ptr(), nrm.data_ptr(),
+              ws.data_ptr(), B, C, h, w, float(k_unfolded), float(eps), cell.data_ptr(), _stream())
+        _remember_amax(y, cell)
+        ctx.wtf = None
+        if (ctx.needs_input_grad[0] and st["split"] and PROJ_BWD_FUSED and C == FUSED_K
+                and lib.cocos_proj_bwd_input_supported(x.shape[1], C, N)):
+            ctx.wtf = torch.empty(lib.cocos_proj_weight_tfrag_bytes(), device=y.device, dtype=torch.uint8)
+            ctx.wtf_scale = torch.empty(1, device=y.device, dtype=torch.float32)
+            _call("split_f16", "cocos_proj_weight_tfrag_planes", w2.data_ptr(), st["amax"][1].data_ptr(), ctx.wtf.data_ptr(),
+                  ctx.wtf_scale.data_ptr(), C, x.shape[1], _stream())
+        ctx.st = st
+        ctx.kc = float(k_unfolded)
+        ctx.save_for_backward(x, w2, y, mu, a, nrm)
+        ctx.mark_non_differentiable(nrm)
+        return y, mu, a, nrm
+
+    @staticmethod
+    def backward(ctx, dy, dmu, da, _dnrm):
+        x, w2, y, mu, a, nrm = ctx.saved_tensors
+        st = ctx.st
+        B, C, h, w = y.shape
+        N = h * w
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        need_b = need_b and st["has_bias"]
+        dmu = None if dmu is None else _chk(dmu, "proj_unfold3_stats: dmu")
+        da = None if da is None else _chk(da, "proj_unfold3_stats: da")
+        if dy is not None and ctx.wtf is not None and need_x and (need_w or not need_b):
+            dy = _chk(dy, "proj_unfold3_stats: d theta")
+            maps = torch.empty(2 * B * N, device=y.device, dtype=torch.float32)
+            _call("unfold3_stats_bwd", "cocos_unfold3_stats_bwd_maps", mu.data_ptr(), a.data_ptr(), nrm.data_ptr(), _ptr(dmu), _ptr(da),
+                  maps.data_ptr(), B, h, w, ctx.kc, _stream())
+            g1, g2 = maps[:B * N], maps[B * N:]
+            dx = torch.empty_like(x)
+            coef = torch.empty((B, 3, N), device=y.device, dtype=torch.float32)
+            cell = _zero_cell(y.device)
+            _call("proj_bwd_input", "cocos_proj_bwd_input_f16x3", 1, 1, dy.data_ptr(), y.data_ptr(), None, g1.data_ptr(), g2.data_ptr(),
+                  ctx.wtf.data_ptr(), ctx.wtf_scale.data_ptr(), dx.data_ptr(), coef.data_ptr(), cell.data_ptr(),
+                  None, None, None, None, None, None, None, None, None, None, B, x.shape[1], N, 1, 0.0, 1.0, _stream())
+            dw = db = None
+            if need_w:
+                dw, db = _proj1x1_dw_affine(1, dy.reshape(B, C, N), y, None, coef, 1.0, x, cell, st["amax"][0], need_b)
+                dw = dw.reshape(st["wshape"])
+            return dx, dw, db, None, None
+        # round 5's chain: K12's backward as a tensor, autograd-style addition, then the projection's backward
+        dth = torch.empty_like(y)
+        ws = torch.empty(2 * B * N, device=y.device, dtype=torch.float32)
+        _call("unfold3_stats_bwd", "cocos_unfold3_stats_bwd", y.data_ptr(), mu.data_ptr(), a.data_ptr(), nrm.data_ptr(),
+              _ptr(dmu), _ptr(da), dth.data_ptr(), ws.data_ptr(), B, C, h, w, ctx.kc, _stream())
+        if dy is not None:
+            dth = dth + dy
+        return (*_proj1x1_backward(x, w2, dth, st["amax"], st["t_planes"], st["split"], st["stream"], need_x, need_w, need_b,
+                                   st["wshape"]), None, None)
+
+
+def proj_unfold3_stats(p: LazyProj1x1, k_unfolded: float, eps: float = NORM_EPS):
+    """(theta_raw [B,C,h,w], mu, a [B,h*w]) of a lazy projection: K0 + K12 as one autograd node (see _ProjUnfoldStats)."""
+    y, mu, a, _ = _ProjUnfoldStats.apply(p.x, p.weight, p.bias, float(k_unfolded), eps)
+    return y, mu, a
 
 
 def proj_center_l2norm_planes_pair(theta: LazyProj1x1, phi: LazyProj1x1, center_over_channels, planes: OperandPlanes,

@@ -364,6 +364,32 @@ int cocos_proj_center_l2norm_planes_f16x3(
     void* pos_hi0, void* pos_lo0, void* chan_hi0, void* chan_lo0, const float* x1, const void* wfrag1, const float* w_scale1,
     const float* bias1, const float* x_amax1, float* norm1, void* pos_hi1, void* pos_lo1, void* chan_hi1, void* chan_lo1, int B,
     int K, int N, int center_over_channels, float eps, float plane_scale, cocos_stream_t stream);
+/* K24 (round 6): the projection's INPUT gradient fused with what autograd puts between it and the correlation's gradient
+ * (csrc/proj_bwd_f16x3.hip; autograd of correspondence.py:272-289 / :272 + :276-280):
+ *     d[b,ch,n] = alpha[b,n] in1[b,ch,n] + beta[b,n] in2[b,ch,n] + gamma[b,n],      dx[b,ci,n] = sum_ch W[ch,ci] d[b,ch,n]
+ *   mode 0 (match_kernel 1, K1's backward folded in): in1 = d qn [B,256,N], in2a / in2b = the position-major f16 hi / lo planes
+ *       [B,N,256] of plane_scale * y (K23's / K1's), c1 = nrm [B,N]; alpha, beta, gamma are computed by a first sweep over the
+ *       channels exactly as cocos_center_l2norm_bwd_planes does (center_over_channels 1 or 2);
+ *   mode 1 (match_kernel 3, K12's backward and autograd's sum folded in): in1 = d theta from the correlation GEMMs, in2a = the
+ *       fp32 projection [B,256,N], c1 = g1, c2 = g2 [B,N] (cocos_unfold3_stats_bwd's maps): alpha = 1, beta = 2 g2, gamma = g1.
+ * Outputs per projection: dx [B,Cin,N] fp32; coef [B,3,N] = (alpha, beta, gamma); *amax = max(*amax, max|d|) (mode 0: an upper
+ * bound; the cell must hold a finite value >= 0) — the inputs of cocos_proj1x1_dw_affine_f16x3, which rebuilds d while it
+ * stages in1 / in2: the fp32 d is neither written nor read.  Up to two projections of one shape per launch; N % 128 == 0,
+ * Cin <= 448 (cocos_proj_bwd_input_supported).  wtfrag: cocos_proj_weight_tfrag_planes (cocos_proj_weight_tfrag_bytes() bytes). */
+size_t cocos_proj_weight_tfrag_bytes(void);
+int cocos_proj_weight_tfrag_planes(const float* w, const float* w_amax_dev, void* wtfrag, float* w_scale_dev /* nullable */, int M,
+                                   int Cin, cocos_stream_t stream);
+int cocos_proj_bwd_input_supported(int Cin, int M, int N);
+int cocos_proj_bwd_input_f16x3(
+    int mode, int nprob, const float* in1_0, const void* in2a_0, const void* in2b_0, const float* c1_0, const float* c2_0,
+    const void* wtfrag0, const float* w_scale0, float* dx0, float* coef0, float* amax0, const float* in1_1, const void* in2a_1,
+    const void* in2b_1, const float* c1_1, const float* c2_1, const void* wtfrag1, const float* w_scale1, float* dx1, float* coef1,
+    float* amax1, int B, int Cin, int N, int center_over_channels, float eps, float plane_scale, cocos_stream_t stream);
+/* cocos_proj1x1_dw_f16x3 (below) with dy rebuilt on the fly: dy = coef[:,0] in1 + coef[:,1] in2 + coef[:,2].  mode 1: in2a = fp32
+ * [B,M,N]; mode 2: in2a / in2b = CHANNEL-major f16 hi / lo planes [B,M,N] of plane_scale * in2.  dy_amax: max|dy| or a bound. */
+int cocos_proj1x1_dw_affine_f16x3(int mode, const float* in1, const void* in2a, const void* in2b, const float* coef,
+                                  float plane_scale, const float* x, float* ws_dw, float* ws_db, float* dw, float* db, int B,
+                                  int C, int M, int N, const float* dy_amax, const float* x_amax, cocos_stream_t stream);
 /* K0 weight and bias gradient as one streaming reduction (autograd of correspondence.py:272,:282):
  *     dw[m,c] = sum_{b,n} dy[b,m,n] x[b,c,n]      db[m] = sum_{b,n} dy[b,m,n]   (db, ws_db: both or neither NULL)
  * dy [B,M,N], x [B,C,N] fp32, read once; f16x3 products with the power-of-two scales from dy_amax / x_amax.
@@ -710,6 +736,11 @@ int cocos_unfold3_stats_fwd_amax(const float* x, float* mu, float* a, float* nrm
 int cocos_unfold3_stats_bwd(const float* x, const float* mu, const float* a, const float* nrm,
                             const float* dmu, const float* da, float* dx, float* ws,
                             int B, int C, int h, int w, float k_unfolded, cocos_stream_t stream);
+/* ... only its two per-position maps (ws = [g1 | g2]): the consumer applies dx[c,p] = g1[p] + 2 x[c,p] g2[p]
+ * (cocos_proj_bwd_input_f16x3 mode 1). */
+int cocos_unfold3_stats_bwd_maps(const float* mu, const float* a, const float* nrm, const float* dmu /* nullable */,
+                                 const float* da /* nullable */, float* ws /* 2*B*h*w */, int B, int h, int w, float k_unfolded,
+                                 cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K13 InstanceNorm2d(affine=False) (+ residual) + PReLU of the ResidualBlocks in front of theta/phi

@@ -165,3 +165,96 @@ def test_hot_path_lazy_detach_flag_and_inference():
     assert torch.equal(out["warp_out"], out2["warp_out"])
     with pytest.raises(TypeError):
         correspondence_hot_path(ops.LazyProj1x1(*leaves[:3]), ops.proj1x1(*leaves[3:]), ref_img, ref_img, seg, seg, cfg)
+
+
+# ------------------------------------------------------------------ K24: the projections' backward (proj_bwd_f16x3.hip)
+def _f64(t):
+    return None if t is None else t.detach().double().cpu()
+
+
+@pytest.mark.parametrize("B,Cin,h,w,bias", [(2, 407, 16, 16, True), (1, 256, 8, 16, True), (2, 19, 8, 16, False), (1, 448, 16, 8, True),
+                                            (2, 64, 32, 32, True)])
+@pytest.mark.parametrize("fused_bwd", [True, False])
+def test_k24_mode0_gradients_of_the_fused_projection_match_fp64(B, Cin, h, w, bias, fused_bwd, monkeypatch):
+    """d loss / d (x, weight, bias) through K23's handles — K1's backward + dx = W^T d in K24, d W / d b in the affine weight-gradient
+    kernel — against torch fp64 autograd of conv1x1 -> centre -> normalise; `fused_bwd = False`: round 5's chain on the same handles."""
+    from cocosnet_amd import ops
+    monkeypatch.setattr(ops, "PROJ_BWD_FUSED", fused_bwd)
+    x1, w1, b1, x2, w2, b2 = _case(B, Cin, h, w, seed=3 * Cin + h)
+    N = h * w
+    g = torch.Generator(device=DEV).manual_seed(7)
+    G1, G2 = torch.randn(B, 256, N, device=DEV, generator=g), torch.randn(B, 256, N, device=DEV, generator=g) * 1e-3
+    leaves = [None if t is None else t.clone().requires_grad_(True) for t in (x1, w1, b1, x2, w2, b2)]
+    planes = ops.OperandPlanes()
+    with ops.KernelTimer() as kt:
+        qn, kn = ops.proj_center_l2norm_planes_pair(ops.LazyProj1x1(*leaves[:3]), ops.LazyProj1x1(*leaves[3:]), 1, planes, want_chan=True)
+        torch.autograd.backward([qn, kn], [G1, G2])
+    assert ("proj_bwd_input" in kt.summary()) == fused_bwd, sorted(kt.summary())
+    for i, (x, wt, bb, G) in enumerate(((x1, w1, b1, G1), (x2, w2, b2, G2))):
+        xr, wr = _f64(x).requires_grad_(True), _f64(wt).requires_grad_(True)
+        br = None if bb is None else _f64(bb).requires_grad_(True)
+        th = torch.einsum("mk,bkn->bmn", wr.reshape(256, Cin), xr.reshape(B, Cin, N))
+        if br is not None:
+            th = th + br[None, :, None]
+        thc = th - th.mean(dim=1, keepdim=True)
+        y = thc / (thc.norm(dim=1, keepdim=True) + co.EPS)
+        (y * _f64(G)).sum().backward()
+        got = leaves[3 * i:3 * i + 3]
+        rel = lambda a, r: float((a.detach().double().cpu() - r).abs().max() / (r.abs().max() + 1e-300))
+        errs = (rel(got[0].grad, xr.grad), rel(got[1].grad, wr.grad), None if br is None else rel(got[2].grad, br.grad))
+        print("K24_MODE0", (B, Cin, h, w), "fused" if fused_bwd else "chain", i, errs)
+        assert errs[0] < 2e-5 and errs[1] < 2e-5 and (errs[2] is None or errs[2] < 2e-5), errs
+
+
+@pytest.mark.parametrize("B,Cin,h,w", [(2, 407, 4, 64), (1, 256, 8, 64), (2, 33, 2, 64)])
+@pytest.mark.parametrize("fused_bwd", [True, False])
+def test_k24_mode1_projection_plus_unfold_statistics_gradients_match_fp64(B, Cin, h, w, fused_bwd, monkeypatch):
+    """ops.proj_unfold3_stats (match_kernel 3): theta_raw, mu, a of a lazy projection as one autograd node; gradients of
+    <theta_raw, G> + <mu, gm> + <a, ga> w.r.t. x, weight, bias against torch fp64 (hot_path's torch formulation of K12)."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import _unfold3_stats
+    monkeypatch.setattr(ops, "PROJ_BWD_FUSED", fused_bwd)
+    x1, w1, b1, _, _, _ = _case(B, Cin, h, w, seed=Cin)
+    N, kc = h * w, 256.0 * 9
+    g = torch.Generator(device=DEV).manual_seed(17)
+    G = torch.randn(B, 256, h, w, device=DEV, generator=g)
+    gm, ga = torch.randn(B, N, device=DEV, generator=g), torch.randn(B, N, device=DEV, generator=g) * 0.1
+    leaves = [t.clone().requires_grad_(True) for t in (x1, w1, b1)]
+    with ops.KernelTimer() as kt:
+        th, mu, a = ops.proj_unfold3_stats(ops.LazyProj1x1(*leaves), kc)
+        torch.autograd.backward([th, mu, a], [G, gm, ga])
+    assert ("proj_bwd_input" in kt.summary()) == fused_bwd, sorted(kt.summary())
+    xr, wr, br = _f64(x1).requires_grad_(True), _f64(w1).requires_grad_(True), _f64(b1).requires_grad_(True)
+    thr = torch.einsum("mk,bkn->bmn", wr.reshape(256, Cin), xr.reshape(B, Cin, N)).reshape(B, 256, h, w) + br[None, :, None, None]
+    mur, ar = _unfold3_stats(thr, kc)
+    ((thr * _f64(G)).sum() + (mur * _f64(gm)).sum() + (ar * _f64(ga)).sum()).backward()
+    rel = lambda t, r: float((t.detach().double().cpu() - r).abs().max() / (r.abs().max() + 1e-300))
+    errs = (rel(th, thr.detach()), rel(mu, mur.detach()), rel(a, ar.detach()), rel(leaves[0].grad, xr.grad), rel(leaves[1].grad, wr.grad),
+            rel(leaves[2].grad, br.grad))
+    print("K24_MODE1", (B, Cin, h, w), "fused" if fused_bwd else "chain", errs)
+    assert max(errs[:3]) < 5e-6 and max(errs[3:]) < 2e-5, errs
+
+
+def test_k24_tiny_and_huge_gradients_keep_their_precision():
+    """The per-position power-of-two scale of K24's f16 split: gradients of 1e-9 and of 1e+6 magnitude (no global max|.| pass)."""
+    from cocosnet_amd import ops
+    B, Cin, h, w = 1, 407, 8, 16
+    x1, w1, b1, x2, w2, b2 = _case(B, Cin, h, w, seed=41)
+    N = h * w
+    g = torch.Generator(device=DEV).manual_seed(3)
+    base = torch.randn(B, 256, N, device=DEV, generator=g)
+    scale_p = torch.logspace(-9, 6, N, device=DEV).reshape(1, 1, N)          # every position its own magnitude
+    for G in (base * 1e-9, base * 1e6, base * scale_p):
+        leaves = [t.clone().requires_grad_(True) for t in (x1, w1, b1, x2, w2, b2)]
+        planes = ops.OperandPlanes()
+        qn, kn = ops.proj_center_l2norm_planes_pair(ops.LazyProj1x1(*leaves[:3]), ops.LazyProj1x1(*leaves[3:]), 1, planes, want_chan=True)
+        torch.autograd.backward([qn, kn], [G, G])
+        xr, wr, br = _f64(x1).requires_grad_(True), _f64(w1).requires_grad_(True), _f64(b1).requires_grad_(True)
+        th = torch.einsum("mk,bkn->bmn", wr.reshape(256, Cin), xr.reshape(B, Cin, N)) + br[None, :, None]
+        thc = th - th.mean(dim=1, keepdim=True)
+        (thc / (thc.norm(dim=1, keepdim=True) + co.EPS) * _f64(G)).sum().backward()
+        # d x column by column (each position has its own magnitude): relative to the column's own maximum
+        got, ref = leaves[0].grad.double().cpu().reshape(B, Cin, N), xr.grad.reshape(B, Cin, N)
+        col = ((got - ref).abs().amax(dim=1) / (ref.abs().amax(dim=1) + 1e-300)).max()
+        assert float(col) < 3e-5, float(col)
+        assert float((leaves[1].grad.double().cpu() - wr.grad).abs().max() / wr.grad.abs().max()) < 3e-5
