@@ -158,6 +158,7 @@ _SIGNATURES = {
                           + [ctypes.c_float, _c_float_p, _c_float_p, ctypes.c_int, _stream_t]),
     "cocos_absmax": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, _c_float_p, _stream_t]),
     "cocos_absmax_accumulate": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, _c_float_p, _stream_t]),
+    "cocos_absmax4": (ctypes.c_int, [_c_float_p, ctypes.c_longlong, _c_float_p] * 4 + [_stream_t]),
     "cocos_proj1x1_fwd_f16x3": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 4 + [_c_float_p] * 2 + [_stream_t]),
     "cocos_proj1x1_bwd_partials_f16x3": (ctypes.c_int, [ctypes.c_int] * 4),
     "cocos_proj1x1_stream_kpad": (ctypes.c_int, [ctypes.c_int]),
@@ -175,6 +176,9 @@ _SIGNATURES = {
     "cocos_proj_weight_tfrag_bytes": (ctypes.c_size_t, []),
     "cocos_proj_weight_tfrag_planes": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, ctypes.c_int, ctypes.c_int,
                                                       _stream_t]),
+    "cocos_proj_weight_prep_pair": (ctypes.c_int, [ctypes.c_int]
+                                    + [_c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p] * 2 + [ctypes.c_int, ctypes.c_int, _stream_t]),
     "cocos_proj_bwd_input_supported": (ctypes.c_int, [ctypes.c_int] * 3),
     "cocos_proj_bwd_input_f16x3": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]
                                    + ([_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.c_void_p, _c_float_p,

@@ -94,7 +94,7 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP translation unit for gfx950 and link libcocos_hip.so. Returns its path."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     srcs = [os.path.join(CSRC_DIR, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC_DIR, "common.h"), os.path.join(CSRC_DIR, "box3_common.h"),
+    deps = srcs + [os.path.join(CSRC_DIR, "common.h"), os.path.join(CSRC_DIR, "box3_common.h"), os.path.join(CSRC_DIR, "proj_frag.h"),
                    os.path.join(REPO_DIR, "include", "cocos_hip.h")]
     stamp = LIB_PATH + ".sha256"      # next to the library: it travels with it (obj/ does not have to)
     want = _digest(deps)

@@ -25,17 +25,13 @@
 // a.b ~= ah.bh + ah.bl + al.bh on v_mfma_f32_32x32x16_f16, fp32 accumulate.
 #include <algorithm>
 
-#include "common.h"
+#include "proj_frag.h"
 
 namespace cocos {
 
 typedef _Float16 pb_f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* pb_lds_ptr;
 
-constexpr int PB_K = 256;                       // channels of the projection's output = the contraction of dx
-constexpr int PB_NST = PB_K / 16;               // 16-channel stages
-constexpr int PB_HB = 7;                        // accumulator tiles (32 rows of dx) per workgroup: two halves cover 14 x 32 = 448 rows
-constexpr int PB_WSTAGE_ALL = 2 * PB_HB * 2 * 1024;      // bytes of one stage of the transposed weight planes: [row block 14][plane 2][1 KB]
 constexpr int PB_WSTAGE = PB_HB * 2 * 1024;     // ... of which a workgroup stages its half: 14 KB
 constexpr int PB_SLOT = 2048;                   // one operand slot of a wave: in1 [16 ch][32 pos] fp32, or in2 (fp32 the same; planes: hi | lo, [32 pos][16 ch] f16 each)
 constexpr int PB_SLOTS = 3;
@@ -67,25 +63,13 @@ struct PbArgs {
     float eps, inv_plane_scale;
 };
 
-// w [256][Cin] fp32 -> fragment-ordered planes of W^T for the kernel below: lane l of (stage s, row block blk) owns
-// W[16 s + 8 (l >> 5) .. + 7][blk * 32 + (l & 31)] (A[i = input channel][k = output channel]), zero beyond Cin.
+// w [256][Cin] fp32 -> fragment-ordered planes of W^T for the kernel below (proj_frag.h).  grid (PB_NST, 2 * PB_HB), 64 threads.
 __global__ __launch_bounds__(64) void proj_weight_tfrag_kernel(const float* __restrict__ w, const float* __restrict__ w_amax,
                                                                unsigned char* __restrict__ out, float* __restrict__ w_scale, int Cin) {
     const int s = blockIdx.x, blk = blockIdx.y, l = threadIdx.x;
-    const float a = *w_amax;
-    const float sc = pb_pow2_scale(a);
+    const float sc = pb_pow2_scale(*w_amax);
     if (s == 0 && blk == 0 && l == 0 && w_scale) *w_scale = sc;
-    const int ci = blk * 32 + (l & 31), k0 = 16 * s + 8 * (l >> 5);
-    unsigned hw[4], lw[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float v0 = ci < Cin ? w[(size_t)(k0 + 2 * q) * Cin + ci] * sc : 0.f;
-        const float v1 = ci < Cin ? w[(size_t)(k0 + 2 * q + 1) * Cin + ci] * sc : 0.f;
-        split_pair_rn(v0, v1, hw[q], lw[q]);
-    }
-    unsigned char* d = out + (size_t)s * PB_WSTAGE_ALL + (size_t)(blk * 2) * 1024 + l * 16;
-    *reinterpret_cast<u32x4*>(d) = u32x4{hw[0], hw[1], hw[2], hw[3]};
-    *reinterpret_cast<u32x4*>(d + 1024) = u32x4{lw[0], lw[1], lw[2], lw[3]};
+    pf_weight_tfrag_item(w, sc, out, Cin, s, blk, l);
 }
 
 template <int MODE>

@@ -26,7 +26,7 @@
 //     (v_permlane32_swap pairs the half-waves' 4-channel groups), channel-major rows as 4-byte stores of two neighbouring
 //     positions (one DPP exchange per 4 channels).
 // Arithmetic identical to proj_stream_f16x3.hip: a.b ~= ah.bh + ah.bl + al.bh on v_mfma_f32_32x32x16_f16, fp32 accumulate.
-#include "common.h"
+#include "proj_frag.h"
 
 namespace cocos {
 
@@ -34,8 +34,6 @@ typedef _Float16 pn_f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* pn_lds_ptr;
 typedef unsigned int pn_u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int PN_M = 256;                      // output channels (= the correlation kernels' K)
-constexpr int PN_WSTAGE = 8 * 2 * 1024;        // bytes of one weight stage: [row block 8][plane 2][lane 64][16 B], k-step of 16
 constexpr int PN_XSLOT = 16 * 32 * 4;          // bytes of one x slot of a wave: [16 k][32 positions] fp32
 constexpr int PN_XSLOTS = 3;                   // x stages in flight / being read, per wave
 constexpr int PN_SMEM = 2 * PN_WSTAGE + 4 * PN_XSLOTS * PN_XSLOT;     // 32 + 24 KB
@@ -66,33 +64,47 @@ struct PnArgs {
     float eps, plane_scale;
 };
 
-// weight [256][K] fp32 -> fragment-ordered f16 hi / lo planes.  grid (nst, 8), 64 threads: lane l of (stage s, row block blk)
-// owns W[blk*32 + (l & 31)][16 s + 8 (l >> 5) .. + 7].  t_hi / t_lo (nullable): the same numbers as TRANSPOSED row-major planes
-// [K][256] — the A operand of dx = W^T dy in cocos_proj1x1_stream_f16x3 (one launch instead of a second split in the backward).
+// weight [256][K] fp32 -> fragment-ordered f16 hi / lo planes (proj_frag.h).  grid (nst, 8), 64 threads.
 __global__ __launch_bounds__(64) void proj_weight_frag_kernel(const float* __restrict__ w, const float* __restrict__ w_amax,
                                                               unsigned char* __restrict__ out, float* __restrict__ w_scale, int K,
                                                               _Float16* __restrict__ t_hi, _Float16* __restrict__ t_lo) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const int s = blockIdx.x, blk = blockIdx.y, l = threadIdx.x;
     const float sc = pn_scale_from_amax(w_amax);
     if (s == 0 && blk == 0 && l == 0) *w_scale = sc;
-    const int row = blk * 32 + (l & 31), k0 = 16 * s + 8 * (l >> 5);
-    unsigned hw[4], lw[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = k0 + 2 * q;
-        const float a = k < K ? w[(size_t)row * K + k] * sc : 0.f;
-        const float b = k + 1 < K ? w[(size_t)row * K + k + 1] * sc : 0.f;
-        split_pair_rn(a, b, hw[q], lw[q]);
-        if (t_hi) {
-            const h2 hh = __builtin_bit_cast(h2, hw[q]), ll = __builtin_bit_cast(h2, lw[q]);
-            if (k < K) { t_hi[(size_t)k * PN_M + row] = hh[0]; t_lo[(size_t)k * PN_M + row] = ll[0]; }
-            if (k + 1 < K) { t_hi[(size_t)(k + 1) * PN_M + row] = hh[1]; t_lo[(size_t)(k + 1) * PN_M + row] = ll[1]; }
-        }
+    pf_weight_frag_item(w, sc, out, K, t_hi, t_lo, s, blk, l);
+}
+
+// Both fragment layouts (W for K23, W^T for K24) of up to two projections in ONE launch: the benchmark step ran four 5 us
+// launches for them.  256 threads = 4 items of 64 lanes; items [0, nst * 8) of a problem are (stage, row block) pairs of W,
+// the next PB_NST * 2 * PB_HB are those of W^T (absent when wtfrag is null).
+struct PwProb {
+    const float* w;
+    const float* w_amax;
+    unsigned char* wfrag;
+    float* w_scale;
+    _Float16 *t_hi, *t_lo;
+    unsigned char* wtfrag;
+};
+struct PwArgs {
+    PwProb p[2];
+    int nprob, K, nst, items_per_prob;
+};
+__global__ __launch_bounds__(256) void proj_weight_prep_kernel(const PwArgs a) {
+    const int l = threadIdx.x & 63;
+    int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int pi = item >= a.items_per_prob ? 1 : 0;
+    item -= pi * a.items_per_prob;
+    if (pi >= a.nprob || item >= a.items_per_prob) return;
+    const PwProb P = pi ? a.p[1] : a.p[0];
+    const float sc = pn_scale_from_amax(P.w_amax);
+    if (item == 0 && l == 0) *P.w_scale = sc;
+    const int nfrag = a.nst * 8;
+    if (item < nfrag) {
+        pf_weight_frag_item(P.w, sc, P.wfrag, a.K, P.t_hi, P.t_lo, item >> 3, item & 7, l);
+    } else if (P.wtfrag) {
+        const int j = item - nfrag;
+        pf_weight_tfrag_item(P.w, sc, P.wtfrag, a.K, j / (2 * PB_HB), j % (2 * PB_HB), l);
     }
-    unsigned char* d = out + (size_t)s * PN_WSTAGE + (size_t)(blk * 2) * 1024 + l * 16;
-    *reinterpret_cast<u32x4*>(d) = u32x4{hw[0], hw[1], hw[2], hw[3]};
-    *reinterpret_cast<u32x4*>(d + 1024) = u32x4{lw[0], lw[1], lw[2], lw[3]};
 }
 
 template <bool WANT_CHAN>
@@ -299,6 +311,37 @@ extern "C" int cocos_proj_weight_frag_planes(const float* w, const float* w_amax
     COCOS_REQUIRE(aligned16(wfrag), COCOS_ERR_INVALID, "proj_weight_frag_planes: planes must be 16-byte aligned");
     hipLaunchKernelGGL(proj_weight_frag_kernel, dim3((K + 15) / 16, 8), dim3(64), 0, as_stream(stream), w, w_amax,
                        static_cast<unsigned char*>(wfrag), w_scale, K, static_cast<_Float16*>(t_hi), static_cast<_Float16*>(t_lo));
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+// Both layouts for up to two projections of the same shape in one launch (see proj_weight_prep_kernel): per projection the weight
+// [256][K], its max|w| cell, the K23 planes (cocos_proj_weight_frag_bytes(K)) + the scale cell, optionally the transposed
+// row-major planes [K][256] (t_hi / t_lo) and optionally the K24 planes of W^T (cocos_proj_weight_tfrag_bytes(); needs K <= 448).
+extern "C" int cocos_proj_weight_prep_pair(int nprob, const float* w0, const float* w_amax0, void* wfrag0, float* w_scale0, void* t_hi0,
+                                           void* t_lo0, void* wtfrag0, const float* w1, const float* w_amax1, void* wfrag1,
+                                           float* w_scale1, void* t_hi1, void* t_lo1, void* wtfrag1, int M, int K,
+                                           cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(nprob == 1 || nprob == 2, COCOS_ERR_INVALID, "proj_weight_prep_pair: nprob = %d", nprob);
+    COCOS_REQUIRE(w0 && w_amax0 && wfrag0 && w_scale0 && (nprob == 1 || (w1 && w_amax1 && wfrag1 && w_scale1)), COCOS_ERR_INVALID,
+                  "proj_weight_prep_pair: null pointer");
+    COCOS_REQUIRE((t_hi0 == nullptr) == (t_lo0 == nullptr) && (t_hi1 == nullptr) == (t_lo1 == nullptr), COCOS_ERR_INVALID,
+                  "proj_weight_prep_pair: the transposed planes come as a hi/lo pair");
+    COCOS_REQUIRE(M == PN_M && K >= 1 && K <= 4096, COCOS_ERR_UNSUPPORTED, "proj_weight_prep_pair: needs M == 256, K <= 4096 (M=%d K=%d)", M, K);
+    const bool any_t = wtfrag0 || (nprob == 2 && wtfrag1);
+    COCOS_REQUIRE(!any_t || K <= 2 * PB_HB * 32, COCOS_ERR_UNSUPPORTED, "proj_weight_prep_pair: the W^T planes need K <= 448 (K=%d)", K);
+    for (const void* p : {(const void*)wfrag0, (const void*)wfrag1, (const void*)wtfrag0, (const void*)wtfrag1})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "proj_weight_prep_pair: planes must be 16-byte aligned");
+    PwArgs a;
+    a.p[0] = PwProb{w0, w_amax0, static_cast<unsigned char*>(wfrag0), w_scale0, static_cast<_Float16*>(t_hi0), static_cast<_Float16*>(t_lo0),
+                    static_cast<unsigned char*>(wtfrag0)};
+    a.p[1] = nprob == 2 ? PwProb{w1, w_amax1, static_cast<unsigned char*>(wfrag1), w_scale1, static_cast<_Float16*>(t_hi1),
+                                 static_cast<_Float16*>(t_lo1), static_cast<unsigned char*>(wtfrag1)} : a.p[0];
+    a.nprob = nprob; a.K = K; a.nst = (K + 15) / 16;
+    a.items_per_prob = a.nst * 8 + (any_t ? PB_NST * 2 * PB_HB : 0);
+    const int items = nprob * a.items_per_prob;
+    hipLaunchKernelGGL(proj_weight_prep_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, as_stream(stream), a);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

@@ -354,6 +354,47 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
         atomicMax(out, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
+// max|x| of up to four tensors in ONE launch (round 6: the benchmark step took four of these passes in a row — the two feature
+// tensors and the two projection weights — 5 + 14 us each with nothing to overlap).  Block ranges per segment; within a segment
+// the same 8-loads-in-flight loop as above; each cell must hold a finite value >= 0 on entry (accumulate semantics).
+struct AbsmaxSegs {
+    const float* x[4];
+    size_t n4[4], n[4];
+    unsigned* out[4];
+    int first_block[5];        // segment i owns blocks [first_block[i], first_block[i + 1])
+};
+__global__ __launch_bounds__(256) void absmax_multi_kernel(const AbsmaxSegs sg) {
+    int seg = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) seg += (int)blockIdx.x >= sg.first_block[i] ? 1 : 0;
+    const float* __restrict__ x = sg.x[seg];
+    const size_t n4 = sg.n4[seg], n = sg.n[seg];
+    const int bid = blockIdx.x - sg.first_block[seg], nb = sg.first_block[seg + 1] - sg.first_block[seg];
+    float m = 0.f;
+    constexpr int U = 8;
+    const size_t stride = (size_t)nb * 256;
+    for (size_t i = (size_t)bid * 256 + threadIdx.x; i < n4; i += stride * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t idx = i + (size_t)u * stride;
+            v[u] = idx < n4 ? *reinterpret_cast<const f32x4*>(x + idx * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
+    if (bid == 0)
+        for (size_t j = n4 * 4 + threadIdx.x; j < n; j += 256) m = fmaxf(m, fabsf(x[j]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(sg.out[seg], __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
 }  // namespace cocos
 
 #ifdef COCOS_DEBUG_TIMING
@@ -390,6 +431,33 @@ extern "C" int cocos_absmax(const float* x, long long n, float* out_dev, cocos_s
 // e.g. one of a pre-zeroed pool, or the maximum of another part of the same virtual tensor
 extern "C" int cocos_absmax_accumulate(const float* x, long long n, float* inout_dev, cocos_stream_t stream) {
     return absmax_launch(x, n, inout_dev, false, cocos::as_stream(stream));
+}
+
+// *c_i = max(*c_i, max|x_i[0..n_i)|) for up to four tensors in one launch (x_i == NULL: slot unused).  Cells as for
+// cocos_absmax_accumulate: finite, >= 0 on entry.
+extern "C" int cocos_absmax4(const float* x0, long long n0, float* c0, const float* x1, long long n1, float* c1, const float* x2,
+                             long long n2, float* c2, const float* x3, long long n3, float* c3, cocos_stream_t stream) {
+    using namespace cocos;
+    const float* xs[4] = {x0, x1, x2, x3};
+    const long long ns[4] = {n0, n1, n2, n3};
+    float* cs[4] = {c0, c1, c2, c3};
+    AbsmaxSegs sg;
+    int nseg = 0, blocks = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (!xs[i]) continue;
+        COCOS_REQUIRE(cs[i] && ns[i] >= 1, COCOS_ERR_INVALID, "absmax4: bad arguments for tensor %d", i);
+        const size_t n4 = aligned16(xs[i]) ? (size_t)ns[i] / 4 : 0;
+        sg.x[nseg] = xs[i]; sg.n4[nseg] = n4; sg.n[nseg] = (size_t)ns[i]; sg.out[nseg] = reinterpret_cast<unsigned*>(cs[i]);
+        sg.first_block[nseg] = blocks;
+        blocks += (int)std::min<size_t>(512, (n4 + 256 * 8 - 1) / (256 * 8) + 1);
+        ++nseg;
+    }
+    COCOS_REQUIRE(nseg >= 1, COCOS_ERR_INVALID, "absmax4: no tensor");
+    for (int i = nseg; i < 4; ++i) { sg.x[i] = sg.x[0]; sg.n4[i] = 0; sg.n[i] = 0; sg.out[i] = sg.out[0]; }
+    for (int i = nseg; i <= 4; ++i) sg.first_block[i] = i == nseg ? blocks : 0x7fffffff;
+    hipLaunchKernelGGL(absmax_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), sg);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
 }
 
 // ---- K0 on the split-precision GEMM (same contract as cocos_proj1x1_fwd / _bwd in sgemm_mfma.hip) -------------

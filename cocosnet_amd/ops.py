@@ -934,6 +934,20 @@ def absmax(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def absmax_many(xs):
+    """[max|x| cell for x in xs] with ONE launch per four tensors (cocos_absmax4) — the max|.| passes a step takes in a row (the two
+    feature tensors and the two projection weights in front of K23 / K0) used to be a 5-14 us launch each."""
+    xs = [_chk(x, "absmax_many: x") for x in xs]
+    cells = [_zero_cell(x.device) for x in xs]
+    for i in range(0, len(xs), 4):
+        args = []
+        for x, c in zip(xs[i:i + 4], cells[i:i + 4]):
+            args += [x.data_ptr(), x.numel(), c.data_ptr()]
+        args += [None, 0, None] * (4 - len(xs[i:i + 4]))
+        _call("absmax", "cocos_absmax4", *args, _stream())
+    return cells
+
+
 def sum_leading(x: torch.Tensor) -> torch.Tensor:
     """x.sum(0) for contiguous fp32 partial tiles [S, ...] (cocos_sum_leading)."""
     x = _chk(x, "sum_leading: x")
@@ -1160,27 +1174,29 @@ class _ProjCenterL2NormPlanesPair(torch.autograd.Function):
         dev = xs[0].device
         half = dict(device=dev, dtype=torch.float16)
         args, keep, tplanes, tfrags = [], [], [], []
-        for x, w2d, bb in zip(xs, ws, bs):
-            xa = _recall_amax(x, consume=False)
-            xa = absmax(x) if xa is None else xa
-            wa = _recall_amax(w2d)          # left by K21 when the layer is spectral-normed, else one small pass
-            wa = absmax(w2d) if wa is None else wa
+        # max|.| of the two feature tensors and the two weights: the ones no producer left behind (K21 leaves a spectral-normed
+        # weight's, K13 / K9 epilogues the features') share ONE launch
+        amax = [_recall_amax(xs[0], consume=False), _recall_amax(ws[0]), _recall_amax(xs[1], consume=False), _recall_amax(ws[1])]
+        missing = [i for i, c in enumerate(amax) if c is None]
+        if missing:
+            for i, c in zip(missing, absmax_many([(xs[0], ws[0], xs[1], ws[1])[i] for i in missing])):
+                amax[i] = c
+        wprep = []
+        for pi, (x, w2d, bb) in enumerate(zip(xs, ws, bs)):
+            xa, wa = amax[2 * pi], amax[2 * pi + 1]
             wfrag = torch.empty(lib.cocos_proj_weight_frag_bytes(Cin), device=dev, dtype=torch.uint8)
             wsc = torch.empty(1, device=dev, dtype=torch.float32)
             # ... and, when the input gradient will be wanted, the transposed planes [Cin][256] of dx = W^T dy in the same launch
             th = tl = None
             if ctx.needs_input_grad[3 * len(keep)]:
                 th, tl = torch.empty((Cin, FUSED_K), **half), torch.empty((Cin, FUSED_K), **half)
-            _call("split_f16", "cocos_proj_weight_frag_planes", w2d.data_ptr(), wa.data_ptr(), wfrag.data_ptr(), wsc.data_ptr(),
-                  _ptr(th), _ptr(tl), FUSED_K, Cin, _stream())
             tplanes.append((th, tl, wsc) if th is not None else None)
-            # ... and W^T in K24's fragment order when the fused backward will run (its own tiny launch: a different grid)
+            # ... and W^T in K24's fragment order when the fused backward will run
             wtf = None
             if th is not None and PROJ_BWD_FUSED and lib.cocos_proj_bwd_input_supported(Cin, FUSED_K, N):
                 wtf = torch.empty(lib.cocos_proj_weight_tfrag_bytes(), device=dev, dtype=torch.uint8)
-                _call("split_f16", "cocos_proj_weight_tfrag_planes", w2d.data_ptr(), wa.data_ptr(), wtf.data_ptr(), None, FUSED_K, Cin,
-                      _stream())
             tfrags.append(wtf)
+            wprep += [w2d.data_ptr(), wa.data_ptr(), wfrag.data_ptr(), wsc.data_ptr(), _ptr(th), _ptr(tl), _ptr(wtf)]
             norm = torch.empty((B, N), device=dev, dtype=torch.float32)
             ph, pl = torch.empty((B, N, FUSED_K), **half), torch.empty((B, N, FUSED_K), **half)
             ch = cl = None
@@ -1189,6 +1205,8 @@ class _ProjCenterL2NormPlanesPair(torch.autograd.Function):
             args += [x.data_ptr(), wfrag.data_ptr(), wsc.data_ptr(), _ptr(bb), xa.data_ptr(), norm.data_ptr(), ph.data_ptr(),
                      pl.data_ptr(), _ptr(ch), _ptr(cl)]
             keep.append((xa, wa, wfrag, wsc, norm, ph, pl, ch, cl))
+        # every weight layout of both projections in one launch (they were four)
+        _call("split_f16", "cocos_proj_weight_prep_pair", 2, *wprep, FUSED_K, Cin, _stream())
         _call("proj_center_l2norm_fwd", "cocos_proj_center_l2norm_planes_f16x3", 2, *args, B, Cin, N, int(center_over_channels),
               float(eps), SPLIT_OPERAND_SCALE, _stream())
         handles = []

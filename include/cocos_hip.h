@@ -315,6 +315,10 @@ int cocos_absmax(const float* x, long long n, float* out_dev, cocos_stream_t str
 /* *inout_dev = max(*inout_dev, max|x|) without the memset cocos_absmax puts in front: the cell must hold a finite
  * value >= 0 (pre-zeroed pool; or the running maximum over the parts of a virtually concatenated tensor). */
 int cocos_absmax_accumulate(const float* x, long long n, float* inout_dev, cocos_stream_t stream);
+/* The same for up to four tensors in ONE launch (x_i == NULL: slot unused): the max|.| passes a step takes in a row — the two
+ * feature tensors and the two projection weights in front of K23 / K0 — share a launch (csrc/sgemm_f16x3.hip). */
+int cocos_absmax4(const float* x0, long long n0, float* c0, const float* x1, long long n1, float* c1, const float* x2,
+                  long long n2, float* c2, const float* x3, long long n3, float* c3, cocos_stream_t stream);
 int cocos_proj1x1_fwd_f16x3(const float* x, const float* w, const float* bias, float* y,
                             int B, int Cin, int Cout, int N, const float* x_amax, const float* w_amax,
                             cocos_stream_t stream);
@@ -379,6 +383,12 @@ int cocos_proj_center_l2norm_planes_f16x3(
 size_t cocos_proj_weight_tfrag_bytes(void);
 int cocos_proj_weight_tfrag_planes(const float* w, const float* w_amax_dev, void* wtfrag, float* w_scale_dev /* nullable */, int M,
                                    int Cin, cocos_stream_t stream);
+/* cocos_proj_weight_frag_planes + cocos_proj_weight_tfrag_planes for up to two projections of one shape (theta and phi of a
+ * forward call) in ONE launch: per projection w [256][K], its max|w| cell, wfrag + w_scale, t_hi / t_lo (nullable pair) and
+ * wtfrag (nullable; needs K <= 448).  Same bytes as the single entry points write. */
+int cocos_proj_weight_prep_pair(int nprob, const float* w0, const float* w_amax0, void* wfrag0, float* w_scale0, void* t_hi0,
+                                void* t_lo0, void* wtfrag0, const float* w1, const float* w_amax1, void* wfrag1, float* w_scale1,
+                                void* t_hi1, void* t_lo1, void* wtfrag1, int M, int K, cocos_stream_t stream);
 int cocos_proj_bwd_input_supported(int Cin, int M, int N);
 int cocos_proj_bwd_input_f16x3(
     int mode, int nprob, const float* in1_0, const void* in2a_0, const void* in2b_0, const float* c1_0, const float* c2_0,
