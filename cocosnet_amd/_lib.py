@@ -187,9 +187,18 @@ _SIGNATURES = {
     "cocos_proj1x1_dw_affine_f16x3": (ctypes.c_int, [ctypes.c_int, _c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, ctypes.c_float,
                                                      _c_float_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p] + [ctypes.c_int] * 4
                                       + [_c_float_p, _c_float_p, _stream_t]),
+    "cocos_proj1x1_dw_partials_pair_f16x3": (ctypes.c_int, [ctypes.c_int] * 4),
+    "cocos_proj1x1_dw_affine_pair_f16x3": (ctypes.c_int, [ctypes.c_int, ctypes.c_float]
+                                           + [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [_c_float_p] * 8
+                                           + [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [_c_float_p] * 8
+                                           + [ctypes.c_int] * 4 + [_stream_t]),
     "cocos_proj1x1_bwd_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [_stream_t]),
     "cocos_upsample_nearest_fwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),
     "cocos_upsample_nearest_bwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),
+    "cocos_warp_head_fwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 6 + [_stream_t]),
+    "cocos_warp_head_bwd": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 6 + [_stream_t]),
+    "cocos_split_f16_transpose_pair": (ctypes.c_int, ([_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p]) * 2
+                                       + [ctypes.c_int] * 4 + [_stream_t]),
     "cocos_warp_values": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 6 + [_stream_t]),
     "cocos_corr_materialize_f16x3": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_float]
                                      + [_c_float_p] * 2 + [_stream_t]),

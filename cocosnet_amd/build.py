@@ -50,6 +50,7 @@ HIP_SOURCES = [
     "instnorm_prelu.hip",
     "upsample_nearest.hip",
     "warp_values.hip",
+    "warp_head.hip",
     "contextual_rows.hip",
     "contextual_fused_f16x3.hip",
     "conv_f16x3.hip",

@@ -62,11 +62,31 @@ struct DwAffine {
     float inv_plane_scale;
 };
 
+// One problem of a launch (blockIdx.z picks it: theta's and phi's weight gradients share a launch — 2 x 128 workgroups with
+// chunks twice as long instead of two launches of 256, i.e. half the partial tiles to write and to sum).
+struct DwProb {
+    const float* dy;
+    const float* x;
+    float* ws_dw;
+    float* ws_db;
+    const float* dy_amax;
+    const float* x_amax;
+    DwAffine af;
+};
+struct DwProbs {
+    DwProb p[2];
+};
+
 template <int CBW, int DMODE>
-__global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(
-    const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ ws_dw, float* __restrict__ ws_db,
-    int M, int C, int N, int chunks_per_img, int chunk_len, const float* __restrict__ dy_amax,
-    const float* __restrict__ x_amax, const DwAffine af) {
+__global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(const DwProbs pr, int M, int C, int N, int chunks_per_img, int chunk_len) {
+    const bool second = blockIdx.z != 0;                         // (workgroup-uniform)
+    const float* __restrict__ const dy = second ? pr.p[1].dy : pr.p[0].dy;
+    const float* __restrict__ const x = second ? pr.p[1].x : pr.p[0].x;
+    float* __restrict__ const ws_dw = second ? pr.p[1].ws_dw : pr.p[0].ws_dw;
+    float* __restrict__ const ws_db = second ? pr.p[1].ws_db : pr.p[0].ws_db;
+    const float* __restrict__ const dy_amax = second ? pr.p[1].dy_amax : pr.p[0].dy_amax;
+    const float* __restrict__ const x_amax = second ? pr.p[1].x_amax : pr.p[0].x_amax;
+    const DwAffine af = second ? pr.p[1].af : pr.p[0].af;
     constexpr int XROWS = 2 * CBW * 32;                           // x rows staged per k-step
     constexpr int APLANE = DW_MROWS * DW_ROW, BPLANE = XROWS * DW_ROW;
     constexpr int BUF = 2 * (APLANE + BPLANE);                    // halfs per LDS buffer: A hi, A lo, B hi, B lo
@@ -265,9 +285,18 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(
 // dw[m][c] = sum_s ws[s][m][c]  (partial tiles of the kernel above, rows padded to CP floats); db likewise.
 // Bandwidth-bound: a block takes 64 float4 columns, its four 64-thread groups each sum a quarter of the S partials
 // (8 loads in flight), the quarters meet in LDS.
-__global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
-                                                             int S, int M, int C, int CP,
-                                                             const float* __restrict__ ws_db, float* __restrict__ db) {
+struct DwReduceProbs {
+    const float* ws[2];
+    float* out[2];
+    const float* ws_db[2];
+    float* db[2];
+};
+__global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const DwReduceProbs rp, int S, int M, int C, int CP) {
+    const bool second = blockIdx.y != 0;
+    const float* __restrict__ const ws = second ? rp.ws[1] : rp.ws[0];
+    float* __restrict__ const out = second ? rp.out[1] : rp.out[0];
+    const float* __restrict__ const ws_db = second ? rp.ws_db[1] : rp.ws_db[0];
+    float* __restrict__ const db = second ? rp.db[1] : rp.db[0];
     __shared__ __attribute__((aligned(16))) float red[3 * 64 * 4];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const size_t n = (size_t)M * CP;                               // floats per partial tile
@@ -314,12 +343,12 @@ __global__ __launch_bounds__(256) void proj_dw_reduce_kernel(const float* __rest
     }
 }
 
-static bool dw_plan(int B, int C, int M, int N, int* chunks_per_img, int* chunk_len, int* cbw) {
+static bool dw_plan(int B, int C, int M, int N, int* chunks_per_img, int* chunk_len, int* cbw, int nprob = 1) {
     if (M < 1 || M > 2 * DW_MROWS || C < 1 || C > 448 || N % 4 != 0 || B < 1) return false;
     *cbw = C <= 256 ? 4 : 7;
     const int mhalves = (M + DW_MROWS - 1) / DW_MROWS;
     // ~256 workgroups, a multiple of 8 chunks so that the row halves of a chunk share an XCD; >= 4 k-steps each
-    int want = std::max(1, (256 / mhalves) / B);
+    int want = std::max(1, (256 / mhalves) / (B * nprob));
     const int max_chunks = std::max(1, N / (4 * DW_BK));
     want = std::min(want, max_chunks);
     int len = (N + want - 1) / want;
@@ -339,28 +368,44 @@ extern "C" int cocos_proj1x1_dw_partials_f16x3(int B, int C, int M, int N) {
     return B * cpi;
 }
 
-static int proj_dw_launch(int dmode, const float* dy, const float* x, float* ws_dw, float* ws_db, float* dw, float* db, int B, int C,
-                          int M, int N, const float* dy_amax, const float* x_amax, const cocos::DwAffine& af, cocos_stream_t stream) {
+struct DwHostProb {
+    const float *dy, *x;
+    float *ws_dw, *ws_db, *dw, *db;
+    const float *dy_amax, *x_amax;
+    cocos::DwAffine af;
+};
+
+static int proj_dw_launch(int dmode, int nprob, const DwHostProb* hp, int B, int C, int M, int N, cocos_stream_t stream) {
     using namespace cocos;
-    COCOS_REQUIRE(dy && x && ws_dw && dw, COCOS_ERR_INVALID, "proj1x1_dw_f16x3: null pointer");
-    COCOS_REQUIRE((db == nullptr) == (ws_db == nullptr), COCOS_ERR_INVALID,
-                  "proj1x1_dw_f16x3: db and ws_db go together");
+    for (int i = 0; i < nprob; ++i) {
+        COCOS_REQUIRE(hp[i].dy && hp[i].x && hp[i].ws_dw && hp[i].dw, COCOS_ERR_INVALID, "proj1x1_dw_f16x3: null pointer");
+        COCOS_REQUIRE((hp[i].db == nullptr) == (hp[i].ws_db == nullptr), COCOS_ERR_INVALID, "proj1x1_dw_f16x3: db and ws_db go together");
+        COCOS_REQUIRE(aligned16(hp[i].dy) && aligned16(hp[i].x) && aligned16(hp[i].ws_dw) && aligned16(hp[i].dw), COCOS_ERR_INVALID,
+                      "proj1x1_dw_f16x3: pointers must be 16-byte aligned");
+    }
+    COCOS_REQUIRE(nprob == 1 || (hp[0].db == nullptr) == (hp[1].db == nullptr), COCOS_ERR_INVALID,
+                  "proj1x1_dw_f16x3: the bias gradient for both projections of a pair or for neither");
     int cpi, len, cbw;
-    COCOS_REQUIRE(dw_plan(B, C, M, N, &cpi, &len, &cbw), COCOS_ERR_UNSUPPORTED,
+    COCOS_REQUIRE(dw_plan(B, C, M, N, &cpi, &len, &cbw, nprob), COCOS_ERR_UNSUPPORTED,
                   "proj1x1_dw_f16x3: needs M <= 256, C <= 448, N %% 4 == 0 (got M=%d C=%d N=%d): use "
                   "cocos_proj1x1_bwd_f16x3", M, C, N);
-    COCOS_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(ws_dw) && aligned16(dw), COCOS_ERR_INVALID,
-                  "proj1x1_dw_f16x3: pointers must be 16-byte aligned");
     COCOS_REQUIRE((size_t)M * N * 4 < 0x7fffffffull && (size_t)C * N * 4 < 0x7fffffffull, COCOS_ERR_UNSUPPORTED,
                   "proj1x1_dw_f16x3: one sample exceeds 2 GiB");
     hipStream_t s = as_stream(stream);
     const int S = B * cpi, mhalves = (M + DW_MROWS - 1) / DW_MROWS;
-    const dim3 grid(S, mhalves);
+    const dim3 grid(S, mhalves, nprob);
+    DwProbs pr;
+    DwReduceProbs rp;
+    for (int i = 0; i < 2; ++i) {
+        const DwHostProb& h = hp[i < nprob ? i : 0];
+        pr.p[i] = DwProb{h.dy, h.x, h.ws_dw, h.ws_db, h.dy_amax, h.x_amax, h.af};
+        rp.ws[i] = h.ws_dw; rp.out[i] = h.dw; rp.ws_db[i] = h.ws_db; rp.db[i] = h.db;
+    }
     auto launch = [&](auto kern, int xrows) -> int {
         const size_t smem = (size_t)2 * 2 * (DW_MROWS + xrows) * DW_ROW * sizeof(_Float16);
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, dy, x, ws_dw, ws_db, M, C, N, cpi, len, dy_amax, x_amax, af);
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, pr, M, C, N, cpi, len);
         return COCOS_OK;
     };
     int rc;
@@ -372,8 +417,7 @@ static int proj_dw_launch(int dmode, const float* dy, const float* x, float* ws_
     COCOS_HIP_CHECK(hipGetLastError());
     const int CP = (C + 31) / 32 * 32;
     const size_t n = (size_t)M * CP;
-    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws_dw, dw, S, M, C, CP,
-                       ws_db, db);
+    hipLaunchKernelGGL(proj_dw_reduce_kernel, dim3((unsigned)((n + 255) / 256), nprob), dim3(256), 0, s, rp, S, M, C, CP);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }
@@ -381,20 +425,54 @@ static int proj_dw_launch(int dmode, const float* dy, const float* x, float* ws_
 extern "C" int cocos_proj1x1_dw_f16x3(const float* dy, const float* x, float* ws_dw, float* ws_db, float* dw,
                                       float* db, int B, int C, int M, int N, const float* dy_amax,
                                       const float* x_amax, cocos_stream_t stream) {
-    return proj_dw_launch(0, dy, x, ws_dw, ws_db, dw, db, B, C, M, N, dy_amax, x_amax, cocos::DwAffine{nullptr, nullptr, nullptr, 1.0f}, stream);
+    const DwHostProb hp{dy, x, ws_dw, ws_db, dw, db, dy_amax, x_amax, cocos::DwAffine{nullptr, nullptr, nullptr, 1.0f}};
+    return proj_dw_launch(0, 1, &hp, B, C, M, N, stream);
 }
 
 // The same reduction with dy REBUILT on the fly (round 6, the companion of cocos_proj_bwd_input_f16x3):
 //     dy[b,m,n] = coef[b,0,n] * in1[b,m,n] + coef[b,1,n] * in2[b,m,n] + coef[b,2,n]
 // mode 1: in2a = fp32 [B,M,N] (in2b unused);  mode 2: in2a / in2b = channel-major f16 hi / lo planes [B,M,N] of plane_scale * in2.
 // dy_amax: device cell with max|dy| (or an upper bound) — the scale source of the f16 split, as for cocos_proj1x1_dw_f16x3.
-extern "C" int cocos_proj1x1_dw_affine_f16x3(int mode, const float* in1, const void* in2a, const void* in2b, const float* coef,
-                                             float plane_scale, const float* x, float* ws_dw, float* ws_db, float* dw, float* db, int B,
-                                             int C, int M, int N, const float* dy_amax, const float* x_amax, cocos_stream_t stream) {
+static int dw_affine_check(int mode, const void* in2a, const void* in2b, const float* coef, float plane_scale, const float* dy_amax) {
     using namespace cocos;
     COCOS_REQUIRE(mode == 1 || mode == 2, COCOS_ERR_INVALID, "proj1x1_dw_affine_f16x3: mode %d", mode);
     COCOS_REQUIRE(in2a && coef && (mode == 1 || in2b) && plane_scale > 0.f && dy_amax, COCOS_ERR_INVALID, "proj1x1_dw_affine_f16x3: null pointer");
     COCOS_REQUIRE(aligned16(in2a) && aligned16(coef) && (mode == 1 || (reinterpret_cast<uintptr_t>(in2b) & 7u) == 0), COCOS_ERR_INVALID,
                   "proj1x1_dw_affine_f16x3: in2 / coef must be 16-byte aligned");
-    return proj_dw_launch(mode, in1, x, ws_dw, ws_db, dw, db, B, C, M, N, dy_amax, x_amax, DwAffine{coef, in2a, in2b, 1.0f / plane_scale}, stream);
+    return COCOS_OK;
+}
+
+extern "C" int cocos_proj1x1_dw_affine_f16x3(int mode, const float* in1, const void* in2a, const void* in2b, const float* coef,
+                                             float plane_scale, const float* x, float* ws_dw, float* ws_db, float* dw, float* db, int B,
+                                             int C, int M, int N, const float* dy_amax, const float* x_amax, cocos_stream_t stream) {
+    using namespace cocos;
+    const int rc = dw_affine_check(mode, in2a, in2b, coef, plane_scale, dy_amax);
+    if (rc != COCOS_OK) return rc;
+    const DwHostProb hp{in1, x, ws_dw, ws_db, dw, db, dy_amax, x_amax, DwAffine{coef, in2a, in2b, 1.0f / plane_scale}};
+    return proj_dw_launch(mode, 1, &hp, B, C, M, N, stream);
+}
+
+// Workspace sizing of the PAIR form below: partial tiles per projection.
+extern "C" int cocos_proj1x1_dw_partials_pair_f16x3(int B, int C, int M, int N) {
+    int cpi, len, cbw;
+    if (!cocos::dw_plan(B, C, M, N, &cpi, &len, &cbw, 2)) return 0;
+    return B * cpi;
+}
+
+// cocos_proj1x1_dw_affine_f16x3 for TWO projections of one shape (theta and phi) in one launch: half as many, twice as long
+// position chunks per projection — the chip is filled by the pair, and half the partial tiles are written and summed.
+extern "C" int cocos_proj1x1_dw_affine_pair_f16x3(
+    int mode, float plane_scale, const float* in1_0, const void* in2a_0, const void* in2b_0, const float* coef0, const float* x0,
+    float* ws_dw0, float* ws_db0, float* dw0, float* db0, const float* dy_amax0, const float* x_amax0, const float* in1_1,
+    const void* in2a_1, const void* in2b_1, const float* coef1, const float* x1, float* ws_dw1, float* ws_db1, float* dw1, float* db1,
+    const float* dy_amax1, const float* x_amax1, int B, int C, int M, int N, cocos_stream_t stream) {
+    using namespace cocos;
+    int rc = dw_affine_check(mode, in2a_0, in2b_0, coef0, plane_scale, dy_amax0);
+    if (rc != COCOS_OK) return rc;
+    rc = dw_affine_check(mode, in2a_1, in2b_1, coef1, plane_scale, dy_amax1);
+    if (rc != COCOS_OK) return rc;
+    const DwHostProb hp[2] = {
+        {in1_0, x0, ws_dw0, ws_db0, dw0, db0, dy_amax0, x_amax0, DwAffine{coef0, in2a_0, in2b_0, 1.0f / plane_scale}},
+        {in1_1, x1, ws_dw1, ws_db1, dw1, db1, dy_amax1, x_amax1, DwAffine{coef1, in2a_1, in2b_1, 1.0f / plane_scale}}};
+    return proj_dw_launch(mode, 2, hp, B, C, M, N, stream);
 }

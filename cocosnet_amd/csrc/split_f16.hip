@@ -57,19 +57,16 @@ __device__ __forceinline__ float scale_from_amax(float amax) {
 
 // 64 channels x 64 positions per workgroup through an LDS transpose; rows of the output are Cpad halfs
 // (channels C..Cpad-1 zero) so that a consumer can read whole 16-channel MFMA k-steps
-__global__ __launch_bounds__(256) void split_f16_transpose_kernel(const float* __restrict__ x,
-                                                                  _Float16* __restrict__ hi,
-                                                                  _Float16* __restrict__ lo, int C, int N,
-                                                                  int Cpad, float scale,
-                                                                  const float* __restrict__ amax_dev,
-                                                                  float* __restrict__ scale_out) {
+__device__ __forceinline__ void split_f16_transpose_tile(const float* __restrict__ x, _Float16* __restrict__ hi,
+                                                         _Float16* __restrict__ lo, int C, int N, int Cpad, float scale,
+                                                         const float* __restrict__ amax_dev, float* __restrict__ scale_out, int b) {
     __shared__ float tile[64][65];
     const int tid = threadIdx.x;
-    const int b = blockIdx.z, c0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
     const float* xb = x + (size_t)b * C * N;
     if (amax_dev) {
         scale = scale_from_amax(*amax_dev);
-        if (scale_out && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *scale_out = scale;
+        if (scale_out && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && b == 0) *scale_out = scale;
     }
     {
         const int q = tid & 15, r = tid >> 4;   // 16 position quads x 16 rows, 4 sweeps
@@ -111,6 +108,27 @@ __global__ __launch_bounds__(256) void split_f16_transpose_kernel(const float* _
                 if (c0 + cbase + e < Cpad) { hrow[c0 + cbase + e] = h[e]; lrow[c0 + cbase + e] = l[e]; }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void split_f16_transpose_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
+                                                                  _Float16* __restrict__ lo, int C, int N, int Cpad, float scale,
+                                                                  const float* __restrict__ amax_dev,
+                                                                  float* __restrict__ scale_out) {
+    split_f16_transpose_tile(x, hi, lo, C, N, Cpad, scale, amax_dev, scale_out, blockIdx.z);
+}
+
+// Two tensors of one shape in one launch (grid z = 2 B): the K2 / K19 backward splits d out and v back to back.
+struct SplitPair {
+    const float* x[2];
+    _Float16 *hi[2], *lo[2];
+    const float* amax[2];
+    float* scale_out[2];
+};
+__global__ __launch_bounds__(256) void split_f16_transpose_pair_kernel(const SplitPair sp, int B, int C, int N, int Cpad) {
+    const bool second = (int)blockIdx.z >= B;          // (workgroup-uniform)
+    split_f16_transpose_tile(second ? sp.x[1] : sp.x[0], second ? sp.hi[1] : sp.hi[0], second ? sp.lo[1] : sp.lo[0], C, N, Cpad, 1.0f,
+                             second ? sp.amax[1] : sp.amax[0], second ? sp.scale_out[1] : sp.scale_out[0],
+                             (int)blockIdx.z - (second ? B : 0));
 }
 
 }  // namespace cocos
@@ -201,6 +219,29 @@ extern "C" int cocos_split_f16_ex(const float* x, void* hi, void* lo, int B, int
                   "split_f16_ex: bad dims B=%d C=%d N=%d Cpad=%d", B, C, N, Cpad);
     COCOS_REQUIRE(transpose || Cpad == C, COCOS_ERR_INVALID, "split_f16_ex: padding only with transpose");
     return split_f16_launch(x, hi, lo, B, C, N, Cpad, transpose, scale, amax_dev, scale_out_dev, as_stream(stream));
+}
+
+// cocos_split_f16_ex(transpose = 1, device-side scales) for TWO tensors of one shape [B,C,N] in one launch.
+extern "C" int cocos_split_f16_transpose_pair(const float* x0, void* hi0, void* lo0, const float* amax0_dev, float* scale0_out_dev,
+                                              const float* x1, void* hi1, void* lo1, const float* amax1_dev, float* scale1_out_dev,
+                                              int B, int C, int N, int Cpad, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x0 && hi0 && lo0 && amax0_dev && scale0_out_dev && x1 && hi1 && lo1 && amax1_dev && scale1_out_dev, COCOS_ERR_INVALID,
+                  "split_f16_transpose_pair: null pointer");
+    COCOS_REQUIRE(B >= 1 && C >= 1 && N >= 1 && 2 * B <= 65535 && Cpad >= C && (Cpad + 63) / 64 <= 65535, COCOS_ERR_INVALID,
+                  "split_f16_transpose_pair: bad dims B=%d C=%d N=%d Cpad=%d", B, C, N, Cpad);
+    for (const void* p : {(const void*)hi0, (const void*)lo0, (const void*)hi1, (const void*)lo1})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "split_f16_transpose_pair: planes must be 16-byte aligned");
+    SplitPair sp;
+    sp.x[0] = x0; sp.x[1] = x1;
+    sp.hi[0] = static_cast<_Float16*>(hi0); sp.hi[1] = static_cast<_Float16*>(hi1);
+    sp.lo[0] = static_cast<_Float16*>(lo0); sp.lo[1] = static_cast<_Float16*>(lo1);
+    sp.amax[0] = amax0_dev; sp.amax[1] = amax1_dev;
+    sp.scale_out[0] = scale0_out_dev; sp.scale_out[1] = scale1_out_dev;
+    hipLaunchKernelGGL(split_f16_transpose_pair_kernel, dim3((N + 63) / 64, (Cpad + 63) / 64, 2 * B), dim3(256), 0, as_stream(stream), sp,
+                       B, C, N, Cpad);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
 }
 
 // 2-D form with padded rows: x [rows][cols] -> hi, lo [rows][cols_pad] (zero beyond cols), x*scale ~= hi + lo with

@@ -155,6 +155,8 @@ class _BoxedCorr:
         if isinstance(theta_raw, ops.LazyProj1x1):
             # round 6: projection + K12 statistics as ONE autograd node per tensor (ops.proj_unfold3_stats): its backward folds K12's
             # backward and the sum of theta_raw's two gradients into the projection's input gradient (K24)
+            if ops.PROJ_PRECISION == "f16x3":      # max|.| of both feature tensors and both weights in one launch
+                ops.prefetch_amax([theta_raw.x, theta_raw.weight.reshape(C, -1), phi_raw.x, phi_raw.weight.reshape(C, -1)])
             theta_raw, mu, a = ops.proj_unfold3_stats(theta_raw, self.kc)
             phi_raw, nu, b = ops.proj_unfold3_stats(phi_raw, self.kc)
             self._cache["q"], self._cache["k"] = (mu, a), (nu, b)
@@ -331,16 +333,24 @@ def correspondence_hot_path(theta_raw, phi_raw, ref_img, real_img, seg_map, ref_
             v_r1.append(_flat(ref_seg))
         v1 = torch.cat(v_r1, dim=1) if len(v_r1) > 1 else ref
     o_r1 = attn.rows(v1)
-    y, o_mask = _split_channels(o_r1, n_ref) if direct_mask else (o_r1, None)   # [B, ch, HW], [B, nc, HW]
-    if cfg.warp_patch:
-        y_img = F.fold(y, (H, W), down, stride=down)                  # reference hard-codes 256 (:321)
+    # round 6: when the row pass's output goes to the up-sampling and the direct mask and nowhere else, both come from one op whose
+    # backward hands the K2 / K19 backward its d out, max|d out| and D in ONE kernel (ops.warp_head)
+    head = (direct_mask and not cfg.warp_patch and not cfg.warp_bilinear and not (cfg.warp_cycle_w > 0)
+            and not ((not cfg.isTrain) and cfg.show_corr) and ops.warp_head_ok(o_r1, n_ref, fh, fw, down))
+    if head:
+        out["warp_out"], out["warp_mask"] = ops.warp_head(o_r1, n_ref, fh, fw, down)
+        y = y_img = None          # (only the cycle terms read them: excluded above)
     else:
-        y_img = y.reshape(B, n_ref, fh, fw)
-    if (not cfg.isTrain) and cfg.show_corr:
-        out["warp_out_bi"] = y_img if cfg.warp_patch else _upsample(y_img, down, True)
-    out["warp_out"] = y_img if cfg.warp_patch else _upsample(y_img, down, cfg.warp_bilinear)
-    if direct_mask:
-        out["warp_mask"] = o_mask.reshape(B, -1, fh, fw)
+        y, o_mask = _split_channels(o_r1, n_ref) if direct_mask else (o_r1, None)   # [B, ch, HW], [B, nc, HW]
+        if cfg.warp_patch:
+            y_img = F.fold(y, (H, W), down, stride=down)                  # reference hard-codes 256 (:321)
+        else:
+            y_img = y.reshape(B, n_ref, fh, fw)
+        if (not cfg.isTrain) and cfg.show_corr:
+            out["warp_out_bi"] = y_img if cfg.warp_patch else _upsample(y_img, down, True)
+        out["warp_out"] = y_img if cfg.warp_patch else _upsample(y_img, down, cfg.warp_bilinear)
+        if direct_mask:
+            out["warp_mask"] = o_mask.reshape(B, -1, fh, fw)
 
     # ---- C1: everything that goes through the column softmax  (:337-343, :350-367) ---------------
     cycle_mask = (not direct_mask) and cfg.warp_mask_losstype == "cycle"

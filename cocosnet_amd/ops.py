@@ -488,8 +488,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
             g_amax, v_amax = _recall_amax(dout), ctx.v_amax   # max|v| was taken once, by the forward; max|dout| comes
             if g_amax is None:                                # with dout when concat_channels_amax produced it
                 g_amax = absmax(dout)
-            gph, gpl, g_scale = split_f16(dout, True, cpad=cvp, amax=g_amax)
-            vph, vpl, v_scale = split_f16(v, True, cpad=cvp, amax=v_amax)
+            (gph, gpl, g_scale), (vph, vpl, v_scale) = _split_pair_transposed(dout, g_amax, v, v_amax, cvp)
             half = dict(device=qn.device, dtype=torch.float16)
             want_k = dkn is not None
             dsh = dsl = psh = psl = None
@@ -509,7 +508,7 @@ class _CorrSoftmaxWarp(torch.autograd.Function):
                 dqn_buf = torch.empty_like(qn)
             else:
                 dqn_buf = dqn
-            d_pre = _rowdot(dout, out) if BWD_D_PRECOMPUTED else None
+            d_pre = _rowdot_cached(dout, out) if BWD_D_PRECOMPUTED else None
             _call("corr_softmax_warp_bwd_query", "cocos_corr_softmax_warp_bwd_query_f16x3_ex", kch.data_ptr(),
                   kcl.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(),
                   g_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), logits_t.data_ptr(),
@@ -637,6 +636,36 @@ def _rowdot(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     d = torch.empty((B, N), device=a.device, dtype=torch.float32)
     _call("rowdot", "cocos_rowdot_f64", a.data_ptr(), b.data_ptr(), d.data_ptr(), B, C, N, _stream())
     return d
+
+
+def _rowdot_cached(dout: torch.Tensor, out: torch.Tensor):
+    """D of the softmax backward: the one the producer of `dout` left behind (warp_head's backward computes it in the pass that
+    writes dout), else one cocos_rowdot_f64 pass."""
+    ent, _tls.known_rowdot = _tls.known_rowdot, None
+    if ent is not None:
+        ref, version, out_ptr, d = ent
+        src = ref()
+        if (src is not None and src.data_ptr() == dout.data_ptr() and src.shape == dout.shape and dout._version == version
+                and out.data_ptr() == out_ptr and dout.is_contiguous()):
+            return d
+    return _rowdot(dout, out)
+
+
+def _split_pair_transposed(x0, amax0, x1, amax1, cpad):
+    """split_f16(x0, True, cpad=cpad, amax=amax0) and the same of x1 (same shape) in ONE launch: ((hi, lo, scale), (hi, lo, scale))."""
+    x0, x1 = _chk(x0, "split_f16: x"), _chk(x1, "split_f16: x")
+    B, C, N = x0.shape
+    if x1.shape != x0.shape or 2 * B > 65535:
+        return split_f16(x0, True, cpad=cpad, amax=amax0), split_f16(x1, True, cpad=cpad, amax=amax1)
+    half = dict(device=x0.device, dtype=torch.float16)
+    res, args = [], []
+    for x, am in ((x0, amax0), (x1, amax1)):
+        hi, lo = torch.empty((B, N, cpad), **half), torch.empty((B, N, cpad), **half)
+        sc = torch.empty(1, device=x0.device, dtype=torch.float32)
+        res.append((hi, lo, sc))
+        args += [x.data_ptr(), hi.data_ptr(), lo.data_ptr(), am.data_ptr(), sc.data_ptr()]
+    _call("split_f16", "cocos_split_f16_transpose_pair", *args, B, C, N, int(cpad), _stream())
+    return res[0], res[1]
 
 
 def _wants_logits(qn, kn):
@@ -869,10 +898,11 @@ class _ThreadState(threading.local):
     def __init__(self):
         self.zero_pool = {}      # (device, stream) -> [zeros tensor, next free cell]
         self.known_amax = {}     # (device, storage pointer) -> (the tensor, its version, amax cell)
+        self.known_rowdot = None  # (weakref of dout, its version, data_ptr of out, D [B,N]) left by warp_head's backward
 
 
 _tls = _ThreadState()
-_KNOWN_AMAX_MAX = 4      # entries per thread
+_KNOWN_AMAX_MAX = 8      # entries per thread
 
 
 #: tensors at least this large are remembered through a weak reference only (see _remember_amax)
@@ -948,6 +978,16 @@ def absmax_many(xs):
     return cells
 
 
+def prefetch_amax(xs):
+    """max|x| of the tensors in `xs` that no producer has left a value for, in ONE launch, remembered for their consumers (the two
+    feature tensors and the two weights of a pair of projections: match_kernel 3's K0 calls picked them up one 5-14 us pass each)."""
+    todo = [x for x in xs if x is not None and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+            and _recall_amax(x, consume=False) is None]
+    if todo:
+        for x, c in zip(todo, absmax_many(todo)):
+            _remember_amax(x, c)
+
+
 def sum_leading(x: torch.Tensor) -> torch.Tensor:
     """x.sum(0) for contiguous fp32 partial tiles [S, ...] (cocos_sum_leading)."""
     x = _chk(x, "sum_leading: x")
@@ -987,8 +1027,9 @@ def _proj1x1_forward(x, weight, bias, need_t: bool):
               and lib.cocos_proj1x1_stream_kpad(Cout) != 0)
     st = dict(split=split, stream=stream, amax=None, t_planes=None, wshape=tuple(weight.shape), has_bias=bias is not None)
     if split:      # products on the f16 MFMA, operands split on the fly (sgemm_f16x3.hip)
-        wa = _recall_amax(w2)      # left by K21 when the layer is spectral-normed (W / sigma), else one small pass
-        xa, wa = absmax(x), (absmax(w2) if wa is None else wa)
+        wa = _recall_amax(w2)      # left by K21 when the layer is spectral-normed (W / sigma) or by prefetch_amax, else one small pass
+        xa = _recall_amax(x)
+        xa, wa = (absmax(x) if xa is None else xa), (absmax(w2) if wa is None else wa)
         if stream:
             # A = W as planes [Cout][Kpad], rows zero-padded to whole MFMA k-steps
             kp = lib.cocos_proj1x1_stream_kpad(Cin)
@@ -1110,6 +1151,8 @@ PROJ_NORM_FUSED = os.environ.get("COCOS_PROJ_NORM_FUSED", "1") != "0"
 #: weight gradient); True: K24 (cocos_proj_bwd_input_f16x3) folds everything in front of the input gradient into it and the weight
 #: gradient rebuilds its dy on the fly (A/B runs)
 PROJ_BWD_FUSED = os.environ.get("COCOS_PROJ_BWD_FUSED", "1") != "0"
+#: False: theta's and phi's weight gradients run as two launches of cocos_proj1x1_dw_affine_f16x3 (A/B runs); True: one pair launch
+PROJ_DW_PAIR = os.environ.get("COCOS_PROJ_DW_PAIR", "1") != "0"
 
 
 class LazyProj1x1:
@@ -1251,8 +1294,16 @@ class _ProjCenterL2NormPlanesPair(torch.autograd.Function):
                          ctx.wsc[i].data_ptr(), dxs[i].data_ptr(), coefs[i].data_ptr(), cells[i].data_ptr()]
             _call("proj_bwd_input", "cocos_proj_bwd_input_f16x3", 0, 2, *args, B, Cin, N, mode, eps, SPLIT_OPERAND_SCALE, _stream())
             out = []
+            nb = [needs[3 * i + 2] and ctx.has_bias[i] for i in range(2)]
+            if needs[1] and needs[4] and nb[0] == nb[1] and PROJ_DW_PAIR:
+                # both weight gradients in ONE launch (+ one reduction): half the partial tiles, the chip filled by the pair
+                res = _proj1x1_dw_affine_pair(2, [(d[i], ctx.chan[i][0], ctx.chan[i][1], coefs[i], xs[i], cells[i], ctx.amax[i][0])
+                                                  for i in range(2)], SPLIT_OPERAND_SCALE, nb[0])
+                for i in range(2):
+                    out += [dxs[i], res[i][0].reshape(ctx.wshapes[i]), res[i][1]]
+                return (*out, None, None, None, None)
             for i in range(2):
-                need_w, need_b = needs[3 * i + 1], needs[3 * i + 2] and ctx.has_bias[i]
+                need_w, need_b = needs[3 * i + 1], nb[i]
                 dw = db = None
                 if need_w:
                     ch, cl = ctx.chan[i]
@@ -1304,6 +1355,30 @@ def _proj1x1_dw_affine(mode, in1, in2a, in2b, coef, plane_scale, x, d_amax, x_am
     return dw, db
 
 
+def _proj1x1_dw_affine_pair(mode, probs, plane_scale, need_b):
+    """_proj1x1_dw_affine for two projections of one shape in one launch: probs = [(in1, in2a, in2b, coef, x, d_amax, x_amax)] * 2
+    -> [(dw, db | None)] * 2 (cocos_proj1x1_dw_affine_pair_f16x3)."""
+    lib = _lib.load()
+    x0 = probs[0][4]
+    B, Cin = x0.shape[:2]
+    Cout, N = probs[0][0].shape[1], probs[0][0].shape[2]
+    parts = lib.cocos_proj1x1_dw_partials_pair_f16x3(B, Cin, Cout, N)
+    if not parts or probs[1][4].shape != x0.shape:
+        return [_proj1x1_dw_affine(mode, in1, a, b, coef, plane_scale, x, da, xa, need_b) for (in1, a, b, coef, x, da, xa) in probs]
+    res, args = [], []
+    f32 = dict(device=x0.device, dtype=torch.float32)
+    for (in1, in2a, in2b, coef, x, d_amax, x_amax) in probs:
+        ws = torch.empty((parts, Cout, (Cin + 31) // 32 * 32), **f32)
+        wsb = torch.empty((parts, Cout), **f32) if need_b else None
+        dw = torch.empty((Cout, Cin), **f32)
+        db = torch.empty(Cout, **f32) if need_b else None
+        res.append((dw, db))
+        args += [in1.data_ptr(), in2a.data_ptr(), _ptr(in2b), coef.data_ptr(), x.data_ptr(), ws.data_ptr(), _ptr(wsb), dw.data_ptr(),
+                 _ptr(db), d_amax.data_ptr(), x_amax.data_ptr()]
+    _call("proj1x1_bwd", "cocos_proj1x1_dw_affine_pair_f16x3", mode, float(plane_scale), *args, B, Cin, Cout, N, _stream())
+    return res
+
+
 class _ProjUnfoldStats(torch.autograd.Function):
     """match_kernel 3 (round 6): theta_raw = conv1x1(x, w, b) AND the statistics (mu, a) of its 3x3-unfolded vectors (K0 + K12) as ONE
     autograd node, so that its backward sees both gradients of theta_raw at once — the one through the statistics (K12's
@@ -1313,6 +1388,7 @@ class _ProjUnfoldStats(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, k_unfolded: float, eps: float):
         lib = _lib.load()
+        ctx.set_materialize_grads(False)      # (nrm is not differentiable: autograd would hand its backward a zero-filled [B,N] tensor per call)
         y, x, w2, st = _proj1x1_forward(x, weight, bias, ctx.needs_input_grad[0])
         B, C, h, w = y.shape
         N = h * w
@@ -1908,9 +1984,11 @@ class _Box3SoftmaxWarp(torch.autograd.Function):
         B, N = mu.shape
         Cv = v.shape[1]
         cvp = (Cv + 31) // 32 * 32
-        g_amax = absmax(dout)
-        gph, gpl, gs = split_f16(dout, True, cpad=cvp, amax=g_amax)
-        vph, vpl, v_scale = split_f16(v, True, cpad=cvp, amax=ctx.v_amax)
+        g_amax = _recall_amax(dout)          # left by the kernel that wrote dout (warp_head's backward, concat_channels_amax), else one pass
+        if g_amax is None:
+            g_amax = absmax(dout)
+        d_pre = _rowdot_cached(dout, out) if BWD_D_PRECOMPUTED else None
+        (gph, gpl, gs), (vph, vpl, v_scale) = _split_pair_transposed(dout, g_amax, v, ctx.v_amax, cvp)
         f32 = dict(device=v.device, dtype=torch.float32)
         sink, flags = ctx.sink, (1 if ctx.transposed else 0)
         if not ctx.needs_input_grad[0]:
@@ -1939,8 +2017,7 @@ class _Box3SoftmaxWarp(torch.autograd.Function):
               nu.data_ptr(), b.data_ptr(), vph.data_ptr(), vpl.data_ptr(), gph.data_ptr(), gpl.data_ptr(), gs.data_ptr(),
               v_scale.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), g.data_ptr(), dmu.data_ptr(),
               da.data_ptr(), dnu.data_ptr(), db.data_ptr(), colpart.data_ptr(), gmax.data_ptr(), _ptr(psh), _ptr(psl),
-              _ptr(ctx.v_lomask), B, N, N, Cv, cvp, h, w, kc, scale, _ptr(_rowdot(dout, out) if BWD_D_PRECOMPUTED else None), flags,
-              _stream())
+              _ptr(ctx.v_lomask), B, N, N, Cv, cvp, h, w, kc, scale, _ptr(d_pre), flags, _stream())
         _remember_amax(g, gmax)      # (an accumulating pass replaces the cell remembered for the shared buffer)
         if sink is not None and t.numel() * 4 >= BOX3_ALIAS_T_BYTES:
             sink.t_dead = t          # (only when T's node will take the storage over: the reference keeps T alive until then)
@@ -2240,6 +2317,54 @@ def upsample_nearest(x, scale: int):
     return _UpsampleNearest.apply(x, scale)
 
 
+
+
+class _WarpHead(torch.autograd.Function):
+    """(warp_out, warp_mask) from the first row pass's output o [B,Ci+Cs,h*w] (correspondence.py:327, :334): nearest up-sampling
+    of the Ci image channels and a VIEW of the Cs mask channels.  Backward: ONE kernel (cocos_warp_head_bwd) writes d o from
+    the two loss gradients and leaves max|d o| and D = sum_c d o * o (fp64) for the K2 / K19 backward that consumes d o next —
+    round 5 ran cocos_upsample_nearest_bwd, cocos_concat2_amax and cocos_rowdot_f64 for these."""
+
+    @staticmethod
+    def forward(ctx, o, n_img: int, h: int, w: int, down: int):
+        o = _chk(o, "warp_head: o")
+        B, C, N = o.shape
+        y = torch.empty((B, n_img, h * down, w * down), device=o.device, dtype=torch.float32)
+        _call("upsample_nearest_fwd", "cocos_warp_head_fwd", o.data_ptr(), y.data_ptr(), B, n_img, C, h, w, down, _stream())
+        ctx.save_for_backward(o)
+        ctx.cfg = (int(n_img), int(h), int(w), int(down))
+        return y, o[:, n_img:].view(B, C - n_img, h, w)
+
+    @staticmethod
+    def backward(ctx, g_img, g_mask):
+        o, = ctx.saved_tensors
+        n_img, h, w, down = ctx.cfg
+        B, C, N = o.shape
+        if g_img is None:
+            g_img = torch.zeros((B, n_img, h * down, w * down), device=o.device, dtype=torch.float32)
+        if g_mask is None:
+            g_mask = torch.zeros((B, C - n_img, h, w), device=o.device, dtype=torch.float32)
+        g_img, g_mask = _chk(g_img, "warp_head: d warp_out"), _chk(g_mask, "warp_head: d warp_mask")
+        dout = torch.empty_like(o)
+        drow = torch.empty((B, N), device=o.device, dtype=torch.float32)
+        cell = _zero_cell(o.device)
+        _call("warp_head_bwd", "cocos_warp_head_bwd", g_img.data_ptr(), g_mask.data_ptr(), o.data_ptr(), dout.data_ptr(), drow.data_ptr(),
+              cell.data_ptr(), B, n_img, C - n_img, h, w, down, _stream())
+        if PRECISION == "f16x3":
+            _remember_amax(dout, cell)
+        _tls.known_rowdot = (weakref.ref(dout), dout._version, o.data_ptr(), drow)
+        return dout, None, None, None, None
+
+
+def warp_head_ok(o: torch.Tensor, n_img: int, h: int, w: int, down: int) -> bool:
+    """Shapes cocos_warp_head_fwd / _bwd take: fp32 on the GPU, some image and some mask channels, grid width a multiple of 4."""
+    return (o.is_cuda and o.dtype == torch.float32 and o.dim() == 3 and 0 < n_img < o.shape[1] and w % 4 == 0
+            and o.shape[2] == h * w and o.shape[0] <= 65535)
+
+
+def warp_head(o, n_img: int, h: int, w: int, down: int):
+    """(warp_out [B,n_img,h*down,w*down], warp_mask [B,C-n_img,h,w]) of the row pass's output o [B,C,h*w]: see _WarpHead."""
+    return _WarpHead.apply(o, int(n_img), int(h), int(w), int(down))
 
 
 def warp_values(img, seg_map, down: int):

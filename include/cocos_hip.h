@@ -192,6 +192,11 @@ int cocos_split_f16_ex(const float* x, void* hi, void* lo, int B, int C, int N, 
  * weight planes [M][Kpad] of cocos_proj1x1_stream_f16x3 straight from the weight matrix. */
 int cocos_split_f16_rows(const float* x, void* hi, void* lo, int rows, int cols, int cols_pad, float scale,
                          const float* amax_dev, float* scale_out_dev, cocos_stream_t stream);
+/* cocos_split_f16_ex(transpose = 1, device-side scales) for two tensors of one shape [B,C,N] in one launch (the K2 / K19 backward
+ * splits d out and v back to back). */
+int cocos_split_f16_transpose_pair(const float* x0, void* hi0, void* lo0, const float* amax0_dev, float* scale0_out_dev,
+                                   const float* x1, void* hi1, void* lo1, const float* amax1_dev, float* scale1_out_dev, int B, int C,
+                                   int N, int Cpad, cocos_stream_t stream);
 int cocos_corr_softmax_warp_bwd_query_f16x3(
     const void* kch, const void* kcl, const void* vph, const void* vpl, const void* gph, const void* gpl,
     const float* g_scale_dev, const float* out, const float* dout, const float* lse, const void* saved_logits,
@@ -400,6 +405,14 @@ int cocos_proj_bwd_input_f16x3(
 int cocos_proj1x1_dw_affine_f16x3(int mode, const float* in1, const void* in2a, const void* in2b, const float* coef,
                                   float plane_scale, const float* x, float* ws_dw, float* ws_db, float* dw, float* db, int B,
                                   int C, int M, int N, const float* dy_amax, const float* x_amax, cocos_stream_t stream);
+/* The same for TWO projections of one shape (theta and phi of a step) in one launch: half as many, twice as long position chunks
+ * per projection (cocos_proj1x1_dw_partials_pair_f16x3 partial tiles each), one reduction launch for both. */
+int cocos_proj1x1_dw_partials_pair_f16x3(int B, int C, int M, int N);   /* 0 on bad dims */
+int cocos_proj1x1_dw_affine_pair_f16x3(
+    int mode, float plane_scale, const float* in1_0, const void* in2a_0, const void* in2b_0, const float* coef0, const float* x0,
+    float* ws_dw0, float* ws_db0, float* dw0, float* db0, const float* dy_amax0, const float* x_amax0, const float* in1_1,
+    const void* in2a_1, const void* in2b_1, const float* coef1, const float* x1, float* ws_dw1, float* ws_db1, float* dw1, float* db1,
+    const float* dy_amax1, const float* x_amax1, int B, int C, int M, int N, cocos_stream_t stream);
 /* K0 weight and bias gradient as one streaming reduction (autograd of correspondence.py:272,:282):
  *     dw[m,c] = sum_{b,n} dy[b,m,n] x[b,c,n]      db[m] = sum_{b,n} dy[b,m,n]   (db, ws_db: both or neither NULL)
  * dy [B,M,N], x [B,C,N] fp32, read once; f16x3 products with the power-of-two scales from dy_amax / x_amax.
@@ -485,6 +498,15 @@ int cocos_pono_spade_bwd(const float* x, const float* gamma, const float* beta, 
  * ------------------------------------------------------------------------------------- */
 int cocos_upsample_nearest_fwd(const float* x, float* y, int planes, int h, int w, int scale, cocos_stream_t stream);
 int cocos_upsample_nearest_bwd(const float* dy, float* dx, int planes, int h, int w, int scale, cocos_stream_t stream);
+/* The head of the first row pass (csrc/warp_head.hip; correspondence.py:327, :334 and their autograd).
+ *   cocos_warp_head_fwd: y [B,Ci,h*down,w*down] = nearest up-sampling of channels [0,Ci) of o [B,C,h,w] ((w*down) % 4 == 0).
+ *   cocos_warp_head_bwd: g_img [B,Ci,h*down,w*down] = d loss / d warp_out, g_mask [B,Cs,h,w] = d loss / d warp_mask,
+ *       o [B,Ci+Cs,h,w] -> dout [B,Ci+Cs,h,w] (window sums | copy), drow [B,h*w] = sum_c dout * o accumulated in fp64 (the D of
+ *       the softmax backward), *amax_inout = max(*amax_inout, max|dout|) — one pass instead of cocos_upsample_nearest_bwd +
+ *       cocos_concat2_amax + cocos_rowdot_f64.  w % 4 == 0, tensors 16-byte aligned. */
+int cocos_warp_head_fwd(const float* o, float* y, int B, int Ci, int C, int h, int w, int down, cocos_stream_t stream);
+int cocos_warp_head_bwd(const float* g_img, const float* g_mask, const float* o, float* dout, float* drow, float* amax_inout_dev,
+                        int B, int Ci, int Cs, int h, int w, int down, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K14  value tensor of the first row pass in one kernel (correspondence.py:314, :318-319, :331-334):

@@ -141,3 +141,87 @@ def test_sum_leading_sums_partial_slices():
     for S, n in ((7, 4096), (3, 1001), (1, 8)):
         x = torch.randn(S, n, device=DEV, generator=g)
         assert torch.allclose(ops.sum_leading(x), x.sum(0), rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,Ci,Cs,h,w,down", [(8, 3, 151, 64, 64, 4), (2, 3, 7, 4, 64, 4), (1, 2, 5, 6, 8, 2), (3, 1, 1, 5, 12, 3)])
+def test_warp_head_is_upsample_plus_view_and_its_backward_is_the_three_launch_chain(B, Ci, Cs, h, w, down, monkeypatch):
+    """ops.warp_head (round 6): forward = nearest up-sampling of the image channels + a view of the mask channels; backward = the
+    window sums | copy that autograd's upsample backward + concatenation gave (bit for bit: same additions in the same order for
+    down = 4), with max|d o| and D = sum_c d o * o (fp64) left for the consumer exactly as absmax / cocos_rowdot_f64 give them."""
+    import torch.nn.functional as F
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    N = h * w
+    seen = {}
+
+    class Tap(torch.autograd.Function):          # stands where the K2 / K19 backward stands: it receives d o itself
+        @staticmethod
+        def forward(ctx, x):
+            ctx.save_for_backward(x)
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            x, = ctx.saved_tensors
+            cell = ops._recall_amax(g)
+            seen["amax"] = None if cell is None else float(cell)
+            seen["d"] = ops._rowdot_cached(g, x)
+            seen["left"] = ops._tls.known_rowdot
+            return g
+
+    leaf = _rand(B, Ci + Cs, N, seed=h).requires_grad_(True)
+    o = Tap.apply(leaf)
+    assert ops.warp_head_ok(o, Ci, h, w, down)
+    y, m = ops.warp_head(o, Ci, h, w, down)
+    assert torch.equal(y, F.interpolate(o[:, :Ci].reshape(B, Ci, h, w), scale_factor=down, mode="nearest"))
+    assert m.data_ptr() == o[:, Ci:].data_ptr() and torch.equal(m, o[:, Ci:].reshape(B, Cs, h, w))
+    gy, gm = _rand(*y.shape, seed=1, scale=0.3), _rand(*m.shape, seed=2, scale=2.0)
+    torch.autograd.backward([y, m], [gy, gm])
+    o2 = leaf.detach().clone().requires_grad_(True)
+    y2 = F.interpolate(o2[:, :Ci].reshape(B, Ci, h, w), scale_factor=down, mode="nearest")
+    torch.autograd.backward([y2, o2[:, Ci:].reshape(B, Cs, h, w)], [gy, gm])
+    err = float((leaf.grad - o2.grad).abs().max() / o2.grad.abs().max())
+    assert err < 1e-6, err
+    assert torch.equal(leaf.grad[:, Ci:], gm.reshape(B, Cs, N))
+    assert seen["amax"] == float(leaf.grad.abs().max())
+    want = (leaf.grad.double() * leaf.detach().double()).sum(1)
+    assert float((seen["d"].double() - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-30
+    assert seen["left"] is None          # consumed
+
+
+def test_split_pair_transposed_equals_two_single_splits():
+    a, b = _rand(3, 154, 320, seed=5, scale=7.0), _rand(3, 154, 320, seed=6, scale=1e-3)
+    aa, ba = ops.absmax(a), ops.absmax(b)
+    (h0, l0, s0), (h1, l1, s1) = ops._split_pair_transposed(a, aa, b, ba, 160)
+    for x, am, (h, l, s) in ((a, aa, (h0, l0, s0)), (b, ba, (h1, l1, s1))):
+        rh, rl, rs = ops.split_f16(x, True, cpad=160, amax=am)
+        assert torch.equal(h, rh) and torch.equal(l, rl) and float(s) == float(rs)
+
+
+def test_absmax_many_and_weight_prep_pair_equal_the_single_launches():
+    from cocosnet_amd import _lib
+    lib = _lib.load()
+    xs = [_rand(8, 407, 64, 64, seed=1, scale=3.0), _rand(256, 407, seed=2, scale=0.05), _rand(5, 7, seed=3), _rand(2, 407, 16, 16, seed=4),
+          _rand(1, 3, seed=5, scale=100.0)]
+    cells = ops.absmax_many(xs)
+    for x, c in zip(xs, cells):
+        assert float(c) == float(x.abs().max())
+    Cin = 407
+    ws = [xs[1], _rand(256, Cin, seed=9, scale=2.0)]
+    was = ops.absmax_many(ws)
+    single, pair, args = [], [], []
+    u8 = dict(device=DEV, dtype=torch.uint8)
+    for w2d, wa in zip(ws, was):
+        f, t = torch.zeros(lib.cocos_proj_weight_frag_bytes(Cin), **u8), torch.zeros(lib.cocos_proj_weight_tfrag_bytes(), **u8)
+        th, tl = torch.zeros((Cin, 256), device=DEV, dtype=torch.float16), torch.zeros((Cin, 256), device=DEV, dtype=torch.float16)
+        sc = torch.zeros(1, device=DEV)
+        ops._call("split_f16", "cocos_proj_weight_frag_planes", w2d.data_ptr(), wa.data_ptr(), f.data_ptr(), sc.data_ptr(), th.data_ptr(),
+                  tl.data_ptr(), 256, Cin, ops._stream())
+        ops._call("split_f16", "cocos_proj_weight_tfrag_planes", w2d.data_ptr(), wa.data_ptr(), t.data_ptr(), None, 256, Cin, ops._stream())
+        single.append((f, t, th, tl, sc))
+        f2, t2, th2, tl2, sc2 = torch.zeros_like(f), torch.zeros_like(t), torch.zeros_like(th), torch.zeros_like(tl), torch.zeros_like(sc)
+        pair.append((f2, t2, th2, tl2, sc2))
+        args += [w2d.data_ptr(), wa.data_ptr(), f2.data_ptr(), sc2.data_ptr(), th2.data_ptr(), tl2.data_ptr(), t2.data_ptr()]
+    ops._call("split_f16", "cocos_proj_weight_prep_pair", 2, *args, 256, Cin, ops._stream())
+    for a, b in zip(single, pair):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
