@@ -191,7 +191,16 @@ _SIGNATURES = {
     "cocos_proj1x1_dw_affine_pair_f16x3": (ctypes.c_int, [ctypes.c_int, ctypes.c_float]
                                            + [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [_c_float_p] * 8
                                            + [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [_c_float_p] * 8
-                                           + [ctypes.c_int] * 4 + [_stream_t]),
+                                           + [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),
+    "cocos_proj_raw_planes_stats_f16x3": (ctypes.c_int, [ctypes.c_int]
+                                          + ([_c_float_p, ctypes.c_void_p] + [_c_float_p] * 6 + [ctypes.c_void_p] * 4) * 2
+                                          + [ctypes.c_int] * 3 + [_stream_t]),
+    "cocos_unfold3_stats_finish_pair": (ctypes.c_int, [_c_float_p] * 10 + [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_float, _stream_t]),
+    "cocos_unfold3_stats_bwd_maps_pair": (ctypes.c_int, [_c_float_p] * 12 + [ctypes.c_int] * 3 + [ctypes.c_float, _stream_t]),
+    "cocos_proj_bwd_input_planes_f16x3": (ctypes.c_int, [ctypes.c_int]
+                                          + ([_c_float_p, ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, ctypes.c_void_p,
+                                              _c_float_p, _c_float_p, _c_float_p, _c_float_p]) * 2
+                                          + [ctypes.c_int] * 3 + [_stream_t]),
     "cocos_proj1x1_bwd_f16x3": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [_c_float_p] * 3 + [_stream_t]),
     "cocos_upsample_nearest_fwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),
     "cocos_upsample_nearest_bwd": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [_stream_t]),

@@ -55,6 +55,7 @@ struct PbProb {
     float* dx;              // [B][Cin][N]
     float* coef;            // [B][3][N]: alpha, beta, gamma
     unsigned* amax;         // device cell: atomicMax of max|d| (as bits of a non-negative float)
+    const float* in2_scale; // mode C: device cell with the power of two the in2 planes were multiplied with (null: a.inv_plane_scale)
 };
 struct PbArgs {
     PbProb p[2];
@@ -94,11 +95,14 @@ __global__ __launch_bounds__(256, 2) void proj_bwd_kernel(const PbArgs a) {
     unsigned char* const s1w = pb_smem + 2 * PB_WSTAGE + wave * (2 * PB_SLOTS * PB_SLOT);  // this wave's in1 slots
     unsigned char* const s2w = s1w + PB_SLOTS * PB_SLOT;                                   // ... and in2 slots
 
+    // MODE 0 (A): planes + K1's coefficients; 1 (B): fp32 in2 + K12's coefficients; 2 (C, round 6 / K25): planes + K12's coefficients
+    constexpr bool PLANES = MODE != 1;
+    const float inv_plane_scale = (MODE == 2 && P.in2_scale) ? 1.0f / *P.in2_scale : a.inv_plane_scale;
     const size_t chan_bytes = (size_t)PB_K * N * 4;
     const __amdgpu_buffer_rsrc_t i1_rs = make_rsrc(P.in1 + (size_t)b * PB_K * N, chan_bytes);
-    const __amdgpu_buffer_rsrc_t i2a_rs = MODE == 0 ? make_rsrc(static_cast<const _Float16*>(P.in2a) + (size_t)b * N * PB_K, (size_t)N * PB_K * 2)
+    const __amdgpu_buffer_rsrc_t i2a_rs = PLANES ? make_rsrc(static_cast<const _Float16*>(P.in2a) + (size_t)b * N * PB_K, (size_t)N * PB_K * 2)
                                                     : make_rsrc(static_cast<const float*>(P.in2a) + (size_t)b * PB_K * N, chan_bytes);
-    const __amdgpu_buffer_rsrc_t i2b_rs = MODE == 0 ? make_rsrc(static_cast<const _Float16*>(P.in2b) + (size_t)b * N * PB_K, (size_t)N * PB_K * 2)
+    const __amdgpu_buffer_rsrc_t i2b_rs = PLANES ? make_rsrc(static_cast<const _Float16*>(P.in2b) + (size_t)b * N * PB_K, (size_t)N * PB_K * 2)
                                                     : i2a_rs;
     const __amdgpu_buffer_rsrc_t w_rs = make_rsrc(P.wtfrag, (size_t)PB_NST * PB_WSTAGE_ALL);
     const __amdgpu_buffer_rsrc_t none_rs = make_rsrc(P.wtfrag, 0);
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void proj_bwd_kernel(const PbArgs a) {
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ok ? i1_rs : none_rs, (pb_lds_ptr)(s1w + slot * PB_SLOT + i * 1024), 16, (int)f_voff,
                                                      (int)((unsigned)(16 * s + 8 * i) * N * 4u), 0, 0);
-        if (MODE == 0) {
+        if (PLANES) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ok ? i2a_rs : none_rs, (pb_lds_ptr)(s2w + slot * PB_SLOT), 16, (int)p_voff, (int)(32 * s), 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ok ? i2b_rs : none_rs, (pb_lds_ptr)(s2w + slot * PB_SLOT + 1024), 16, (int)p_voff, (int)(32 * s), 0, 0);
         } else {
@@ -139,11 +143,11 @@ __global__ __launch_bounds__(256, 2) void proj_bwd_kernel(const PbArgs a) {
         const float* q1 = reinterpret_cast<const float*>(s1w + slot * PB_SLOT) + (8 * h) * 32 + c;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v1[j] = q1[j * 32];
-        if (MODE == 0) {
+        if (PLANES) {
             const pb_f16x8 yh = *reinterpret_cast<const pb_f16x8*>(s2w + slot * PB_SLOT + c * 32 + h * 16);
             const pb_f16x8 yl = *reinterpret_cast<const pb_f16x8*>(s2w + slot * PB_SLOT + 1024 + c * 32 + h * 16);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v2[j] = ((float)yh[j] + (float)yl[j]) * a.inv_plane_scale;
+            for (int j = 0; j < 8; ++j) v2[j] = ((float)yh[j] + (float)yl[j]) * inv_plane_scale;
         } else {
             const float* q2 = reinterpret_cast<const float*>(s2w + slot * PB_SLOT) + (8 * h) * 32 + c;
 #pragma unroll
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void proj_bwd_kernel(const PbArgs a) {
 
     const size_t pos = (size_t)b * N + n0 + c;
     float alpha = 1.0f, beta = 0.f, gamma = 0.f;
-    if (MODE == 1) { beta = 2.0f * P.c2[pos]; gamma = P.c1[pos]; }
+    if (MODE != 0) { beta = 2.0f * P.c2[pos]; gamma = P.c1[pos]; }
 
     // ---------------- sweep 1: per-position sums / maximum over the 256 channels ----------------
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, mx = 0.f;
@@ -319,8 +323,9 @@ extern "C" int cocos_proj_bwd_input_f16x3(
     for (const void* p : {(const void*)in1_0, in2a_0, in2b_0, wtfrag0, (const void*)in1_1, in2a_1, in2b_1, wtfrag1})
         COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "proj_bwd_input: pointers must be 16-byte aligned");
     PbArgs a;
-    a.p[0] = PbProb{in1_0, in2a_0, in2b_0, c1_0, c2_0, wtfrag0, w_scale0, dx0, coef0, reinterpret_cast<unsigned*>(amax0)};
-    a.p[1] = nprob == 2 ? PbProb{in1_1, in2a_1, in2b_1, c1_1, c2_1, wtfrag1, w_scale1, dx1, coef1, reinterpret_cast<unsigned*>(amax1)} : a.p[0];
+    a.p[0] = PbProb{in1_0, in2a_0, in2b_0, c1_0, c2_0, wtfrag0, w_scale0, dx0, coef0, reinterpret_cast<unsigned*>(amax0), nullptr};
+    a.p[1] = nprob == 2 ? PbProb{in1_1, in2a_1, in2b_1, c1_1, c2_1, wtfrag1, w_scale1, dx1, coef1, reinterpret_cast<unsigned*>(amax1), nullptr}
+                        : a.p[0];
     a.nprob = nprob; a.B = B; a.Cin = Cin; a.N = N;
     a.center = center_over_channels == 1;
     a.eps = eps; a.inv_plane_scale = 1.0f / plane_scale;
@@ -332,6 +337,39 @@ extern "C" int cocos_proj_bwd_input_f16x3(
     };
     const int rc = mode == 0 ? launch(proj_bwd_kernel<0>) : launch(proj_bwd_kernel<1>);
     if (rc != COCOS_OK) return rc;
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+// Mode C (round 6, K25's backward): as mode 1 — d = in1 + 2 g2 y + g1 — with y read back from the position-major f16 hi / lo
+// planes [B,N,256] of s * y that cocos_proj_raw_planes_stats_f16x3 wrote (in2_scale = its *y_scale cell): the fp32 projection
+// does not exist on this path.  Up to two projections of one shape per launch; outputs as for cocos_proj_bwd_input_f16x3.
+extern "C" int cocos_proj_bwd_input_planes_f16x3(
+    int nprob, const float* in1_0, const void* y_hi0, const void* y_lo0, const float* y_scale0, const float* g1_0, const float* g2_0,
+    const void* wtfrag0, const float* w_scale0, float* dx0, float* coef0, float* amax0, const float* in1_1, const void* y_hi1,
+    const void* y_lo1, const float* y_scale1, const float* g1_1, const float* g2_1, const void* wtfrag1, const float* w_scale1, float* dx1,
+    float* coef1, float* amax1, int B, int Cin, int N, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(nprob == 1 || nprob == 2, COCOS_ERR_INVALID, "proj_bwd_input_planes: nprob = %d", nprob);
+    COCOS_REQUIRE(in1_0 && y_hi0 && y_lo0 && y_scale0 && g1_0 && g2_0 && wtfrag0 && w_scale0 && dx0 && coef0 && amax0, COCOS_ERR_INVALID,
+                  "proj_bwd_input_planes: null pointer");
+    COCOS_REQUIRE(nprob == 1 || (in1_1 && y_hi1 && y_lo1 && y_scale1 && g1_1 && g2_1 && wtfrag1 && w_scale1 && dx1 && coef1 && amax1),
+                  COCOS_ERR_INVALID, "proj_bwd_input_planes: null pointer (second projection)");
+    COCOS_REQUIRE(B >= 1 && cocos_proj_bwd_input_supported(Cin, PB_K, N), COCOS_ERR_UNSUPPORTED,
+                  "proj_bwd_input_planes: needs Cin <= 448, N %% 128 == 0 (B=%d Cin=%d N=%d)", B, Cin, N);
+    COCOS_REQUIRE((long long)nprob * B * (N / 128) * 2 < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED, "proj_bwd_input_planes: grid too large");
+    for (const void* p : {(const void*)in1_0, y_hi0, y_lo0, wtfrag0, (const void*)in1_1, y_hi1, y_lo1, wtfrag1})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "proj_bwd_input_planes: pointers must be 16-byte aligned");
+    PbArgs a;
+    a.p[0] = PbProb{in1_0, y_hi0, y_lo0, g1_0, g2_0, wtfrag0, w_scale0, dx0, coef0, reinterpret_cast<unsigned*>(amax0), y_scale0};
+    a.p[1] = nprob == 2 ? PbProb{in1_1, y_hi1, y_lo1, g1_1, g2_1, wtfrag1, w_scale1, dx1, coef1, reinterpret_cast<unsigned*>(amax1), y_scale1}
+                        : a.p[0];
+    a.nprob = nprob; a.B = B; a.Cin = Cin; a.N = N;
+    a.center = 0;
+    a.eps = 0.f; a.inv_plane_scale = 1.0f;
+    const dim3 grid((unsigned)(nprob * B * (N / 128) * 2));
+    COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(proj_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PB_SMEM));
+    hipLaunchKernelGGL(proj_bwd_kernel<2>, grid, dim3(256), PB_SMEM, as_stream(stream), a);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

@@ -60,6 +60,7 @@ struct DwAffine {
     const void* in2a;         // DMODE 1: fp32 [B][M][N];  DMODE 2: hi plane [B][M][N] f16
     const void* in2b;         // DMODE 2: lo plane
     float inv_plane_scale;
+    const float* plane_scale_dev;     // DMODE 2 (nullable): device cell with the planes' scale; overrides inv_plane_scale
 };
 
 // One problem of a launch (blockIdx.z picks it: theta's and phi's weight gradients share a launch — 2 x 128 workgroups with
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(const DwProbs pr,
     const __amdgpu_buffer_rsrc_t a3_rs = DMODE == 2 ? make_rsrc(static_cast<const _Float16*>(af.in2b) + (size_t)b * M * N, (size_t)M * N * 2) : a_rs;
     const __amdgpu_buffer_rsrc_t cf_rs = make_rsrc(DMODE ? af.coef + (size_t)b * 3 * N : nullptr, DMODE ? (size_t)3 * N * 4 : 0);
     const float sa = dw_scale_from_amax(dy_amax), sb = dw_scale_from_amax(x_amax);
+    const float inv_plane_scale = (DMODE == 2 && af.plane_scale_dev) ? 1.0f / *af.plane_scale_dev : af.inv_plane_scale;
 
     // ---- staging: piece p of this thread = 4 consecutive positions (kq) of one row -----------------------------
     // piece p covers row p*64 + (tid >> 2) of its operand (dy rows first, then x rows), positions kq*4 .. +3 of the
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(const DwProbs pr,
                 const u32x4 w = __builtin_bit_cast(u32x4, st2[stg][p]);
                 const dw_f16x4 h4 = __builtin_bit_cast(dw_f16x4, u32x2{w.x, w.y}), l4 = __builtin_bit_cast(dw_f16x4, u32x2{w.z, w.w});
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v2[e] = ((float)h4[e] + (float)l4[e]) * af.inv_plane_scale;
+                for (int e = 0; e < 4; ++e) v2[e] = ((float)h4[e] + (float)l4[e]) * inv_plane_scale;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) sg[p][e] = __builtin_fmaf(cf[stg][0][e], sg[p][e], __builtin_fmaf(cf[stg][1][e], v2[e], cf[stg][2][e]));
@@ -425,7 +427,7 @@ static int proj_dw_launch(int dmode, int nprob, const DwHostProb* hp, int B, int
 extern "C" int cocos_proj1x1_dw_f16x3(const float* dy, const float* x, float* ws_dw, float* ws_db, float* dw,
                                       float* db, int B, int C, int M, int N, const float* dy_amax,
                                       const float* x_amax, cocos_stream_t stream) {
-    const DwHostProb hp{dy, x, ws_dw, ws_db, dw, db, dy_amax, x_amax, cocos::DwAffine{nullptr, nullptr, nullptr, 1.0f}};
+    const DwHostProb hp{dy, x, ws_dw, ws_db, dw, db, dy_amax, x_amax, cocos::DwAffine{nullptr, nullptr, nullptr, 1.0f, nullptr}};
     return proj_dw_launch(0, 1, &hp, B, C, M, N, stream);
 }
 
@@ -448,7 +450,7 @@ extern "C" int cocos_proj1x1_dw_affine_f16x3(int mode, const float* in1, const v
     using namespace cocos;
     const int rc = dw_affine_check(mode, in2a, in2b, coef, plane_scale, dy_amax);
     if (rc != COCOS_OK) return rc;
-    const DwHostProb hp{in1, x, ws_dw, ws_db, dw, db, dy_amax, x_amax, DwAffine{coef, in2a, in2b, 1.0f / plane_scale}};
+    const DwHostProb hp{in1, x, ws_dw, ws_db, dw, db, dy_amax, x_amax, DwAffine{coef, in2a, in2b, 1.0f / plane_scale, nullptr}};
     return proj_dw_launch(mode, 1, &hp, B, C, M, N, stream);
 }
 
@@ -461,18 +463,20 @@ extern "C" int cocos_proj1x1_dw_partials_pair_f16x3(int B, int C, int M, int N) 
 
 // cocos_proj1x1_dw_affine_f16x3 for TWO projections of one shape (theta and phi) in one launch: half as many, twice as long
 // position chunks per projection — the chip is filled by the pair, and half the partial tiles are written and summed.
+// plane_scale_dev_i (mode 2, nullable): device cell holding the scale of projection i's planes (K25's *y_scale) instead of plane_scale.
 extern "C" int cocos_proj1x1_dw_affine_pair_f16x3(
     int mode, float plane_scale, const float* in1_0, const void* in2a_0, const void* in2b_0, const float* coef0, const float* x0,
     float* ws_dw0, float* ws_db0, float* dw0, float* db0, const float* dy_amax0, const float* x_amax0, const float* in1_1,
     const void* in2a_1, const void* in2b_1, const float* coef1, const float* x1, float* ws_dw1, float* ws_db1, float* dw1, float* db1,
-    const float* dy_amax1, const float* x_amax1, int B, int C, int M, int N, cocos_stream_t stream) {
+    const float* dy_amax1, const float* x_amax1, const float* plane_scale_dev0, const float* plane_scale_dev1, int B, int C, int M, int N,
+    cocos_stream_t stream) {
     using namespace cocos;
     int rc = dw_affine_check(mode, in2a_0, in2b_0, coef0, plane_scale, dy_amax0);
     if (rc != COCOS_OK) return rc;
     rc = dw_affine_check(mode, in2a_1, in2b_1, coef1, plane_scale, dy_amax1);
     if (rc != COCOS_OK) return rc;
     const DwHostProb hp[2] = {
-        {in1_0, x0, ws_dw0, ws_db0, dw0, db0, dy_amax0, x_amax0, DwAffine{coef0, in2a_0, in2b_0, 1.0f / plane_scale}},
-        {in1_1, x1, ws_dw1, ws_db1, dw1, db1, dy_amax1, x_amax1, DwAffine{coef1, in2a_1, in2b_1, 1.0f / plane_scale}}};
+        {in1_0, x0, ws_dw0, ws_db0, dw0, db0, dy_amax0, x_amax0, DwAffine{coef0, in2a_0, in2b_0, 1.0f / plane_scale, plane_scale_dev0}},
+        {in1_1, x1, ws_dw1, ws_db1, dw1, db1, dy_amax1, x_amax1, DwAffine{coef1, in2a_1, in2b_1, 1.0f / plane_scale, plane_scale_dev1}}};
     return proj_dw_launch(mode, 2, hp, B, C, M, N, stream);
 }

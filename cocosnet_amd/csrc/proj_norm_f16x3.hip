@@ -56,6 +56,8 @@ struct PnProb {
     float* norm;             // [B][N]
     _Float16 *ph, *pl;       // position-major planes [B][N][256]
     _Float16 *ch, *cl;       // channel-major planes [B][256][N] (null: not written)
+    float* sum2;             // RAW flavour: sum_c y^2 [B][N] (norm then holds sum_c y)
+    float* y_scale;          // RAW flavour: device cell that receives the power of two the planes were multiplied with
 };
 struct PnArgs {
     PnProb p[2];
@@ -107,7 +109,11 @@ __global__ __launch_bounds__(256) void proj_weight_prep_kernel(const PwArgs a) {
     }
 }
 
-template <bool WANT_CHAN>
+// RAW (K25, match_kernel 3): no centring / normalisation — the planes hold s * (W x + bias) itself, with the power of two s chosen
+// from an a-priori bound on |y| (K max|w| max|x| + max|bias|: known before the first product, so planes and sums leave in the
+// same pass; the bound is loose by a few binades, which a hi/lo pair of f16 absorbs — see the epilogue), and the per-position
+// sums sum_c y, sum_c y^2 that K12's statistics are box sums of (unfold3_stats.hip) replace the norm.
+template <bool WANT_CHAN, bool RAW = false>
 __global__ __launch_bounds__(256, 2) void proj_norm_fwd_kernel(const PnArgs a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char pn_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void proj_norm_fwd_kernel(const PnArgs a) {
     // ---- epilogue: bias, centre, norm (this lane's position: 128 of the 256 channels here, 128 in lane ^ 32) ----
     const float oscale = 1.0f / (sa * sb);
     const __amdgpu_buffer_rsrc_t bias_rs = make_rsrc(P.bias, P.bias ? (size_t)PN_M * 4 : 0);
-    float sum = 0.f;
+    float sum = 0.f, bmax = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -223,9 +229,10 @@ __global__ __launch_bounds__(256, 2) void proj_norm_fwd_kernel(const PnArgs a) {
                 const float t = __builtin_fmaf(acc[i][4 * g + e], oscale, b4[e]);
                 acc[i][4 * g + e] = t;
                 sum += t;
+                if (RAW) bmax = fmaxf(bmax, fabsf(b4[e]));
             }
         }
-    const float mean = a.center ? (sum + swap_half(sum)) * (1.0f / (float)PN_M) : 0.f;
+    const float mean = (!RAW && a.center) ? (sum + swap_half(sum)) * (1.0f / (float)PN_M) : 0.f;
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -236,9 +243,30 @@ __global__ __launch_bounds__(256, 2) void proj_norm_fwd_kernel(const PnArgs a) {
             ss = __builtin_fmaf(d, d, ss);
         }
     ss += swap_half(ss);
-    const float nrm = sqrtf(ss);
-    const float u = 1.0f / (nrm + a.eps);
-    if (h == 0) P.norm[(size_t)b * N + n0 + c] = nrm;
+    float u, pscale;
+    if (RAW) {
+        // |y| <= K max|w| max|x| + max|bias|, with max|w| < 2^10 / sa and max|x| < 2^10 / sb (the scales put the maxima into
+        // [2^9, 2^10)): every lane of every workgroup computes the same bound, hence the same power of two — no pass over y.
+        // The bound lands in [2^13, 2^14); the real maximum sits a few binades below (random weights: ~2^5), where hi keeps its 11
+        // bits and lo = the next 11 down to 2^-24: values 2^12 below the maximum still carry 22 bits.
+        bmax = fmaxf(bmax, swap_half(bmax));
+        const float bound = (1024.0f / sa) * (1024.0f / sb) * (float)K + bmax;
+        int e = 0;
+        if (bound > 0.f && bound < INFINITY) frexpf(bound, &e); else e = 14;
+        pscale = ldexpf(1.0f, 14 - e);
+        u = 1.0f;
+        const float sum_t = sum + swap_half(sum);          // (the exchange is executed by all lanes, before the select)
+        if (h == 0) {
+            P.norm[(size_t)b * N + n0 + c] = sum_t;
+            P.sum2[(size_t)b * N + n0 + c] = ss;
+        }
+        if (rem == 0 && tid == 0) *P.y_scale = pscale;
+    } else {
+        const float nrm = sqrtf(ss);
+        u = 1.0f / (nrm + a.eps);
+        pscale = a.plane_scale;
+        if (h == 0) P.norm[(size_t)b * N + n0 + c] = nrm;
+    }
 
     // ---- planes of plane_scale * y ----
     const size_t plane_b = (size_t)b * N * PN_M;
@@ -256,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void proj_norm_fwd_kernel(const PnArgs a) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const float y0 = (acc[i][4 * g + 2 * q] * u) * a.plane_scale, y1 = (acc[i][4 * g + 2 * q + 1] * u) * a.plane_scale;
+                const float y0 = (acc[i][4 * g + 2 * q] * u) * pscale, y1 = (acc[i][4 * g + 2 * q + 1] * u) * pscale;
                 split_pair_rn(y0, y1, hw[g][q], lw[g][q]);
             }
         if (WANT_CHAN) {
@@ -373,9 +401,10 @@ extern "C" int cocos_proj_center_l2norm_planes_f16x3(
         COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "proj_center_l2norm_planes: pointers must be 16-byte aligned");
     PnArgs a;
     a.p[0] = PnProb{x0, wfrag0, w_scale0, bias0, x_amax0, norm0, static_cast<_Float16*>(pos_hi0), static_cast<_Float16*>(pos_lo0),
-                    static_cast<_Float16*>(chan_hi0), static_cast<_Float16*>(chan_lo0)};
+                    static_cast<_Float16*>(chan_hi0), static_cast<_Float16*>(chan_lo0), nullptr, nullptr};
     a.p[1] = nprob == 2 ? PnProb{x1, wfrag1, w_scale1, bias1, x_amax1, norm1, static_cast<_Float16*>(pos_hi1),
-                                 static_cast<_Float16*>(pos_lo1), static_cast<_Float16*>(chan_hi1), static_cast<_Float16*>(chan_lo1)}
+                                 static_cast<_Float16*>(pos_lo1), static_cast<_Float16*>(chan_hi1), static_cast<_Float16*>(chan_lo1),
+                                 nullptr, nullptr}
                         : a.p[0];
     a.nprob = nprob; a.B = B; a.K = K; a.N = N; a.nst = (K + 15) / 16;
     a.center = center_over_channels == 1;
@@ -387,6 +416,54 @@ extern "C" int cocos_proj_center_l2norm_planes_f16x3(
         return COCOS_OK;
     };
     const int rc = chan_hi0 ? launch(proj_norm_fwd_kernel<true>) : launch(proj_norm_fwd_kernel<false>);
+    if (rc != COCOS_OK) return rc;
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+// K25 (round 6, match_kernel 3): the projection with NO normalisation — up to two projections of one shape per launch.  Per
+// projection: x [B,K,N] fp32, wfrag / w_scale (cocos_proj_weight_frag_planes), bias [256] (nullable), x_amax (device cell) ->
+//   sum1 [B,N] = sum_c y,  sum2 [B,N] = sum_c y^2   (y = W x + bias; cocos_unfold3_stats_finish_pair turns them into mu / a / nrm),
+//   the planes of s * y, position-major [B,N,256] and (chan_hi / chan_lo, nullable pair) channel-major [B,256,N], and *y_scale = s,
+//   the power of two chosen from the a-priori bound K max|w| max|x| + max|bias| (see the kernel).  The fp32 projection is not written.
+extern "C" int cocos_proj_raw_planes_stats_f16x3(
+    int nprob, const float* x0, const void* wfrag0, const float* w_scale0, const float* bias0, const float* x_amax0, float* sum1_0,
+    float* sum2_0, float* y_scale0, void* pos_hi0, void* pos_lo0, void* chan_hi0, void* chan_lo0, const float* x1, const void* wfrag1,
+    const float* w_scale1, const float* bias1, const float* x_amax1, float* sum1_1, float* sum2_1, float* y_scale1, void* pos_hi1,
+    void* pos_lo1, void* chan_hi1, void* chan_lo1, int B, int K, int N, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(nprob == 1 || nprob == 2, COCOS_ERR_INVALID, "proj_raw_planes_stats: nprob = %d", nprob);
+    COCOS_REQUIRE(x0 && wfrag0 && w_scale0 && x_amax0 && sum1_0 && sum2_0 && y_scale0 && pos_hi0 && pos_lo0, COCOS_ERR_INVALID,
+                  "proj_raw_planes_stats: null pointer");
+    COCOS_REQUIRE(nprob == 1 || (x1 && wfrag1 && w_scale1 && x_amax1 && sum1_1 && sum2_1 && y_scale1 && pos_hi1 && pos_lo1), COCOS_ERR_INVALID,
+                  "proj_raw_planes_stats: null pointer (second projection)");
+    COCOS_REQUIRE((chan_hi0 == nullptr) == (chan_lo0 == nullptr) && (nprob == 1 || ((chan_hi1 == nullptr) == (chan_hi0 == nullptr) &&
+                  (chan_lo1 == nullptr) == (chan_lo0 == nullptr))), COCOS_ERR_INVALID,
+                  "proj_raw_planes_stats: channel-major planes come as hi/lo pairs, for both projections or neither");
+    COCOS_REQUIRE(B >= 1 && K >= 1 && K <= 4096 && N >= 128 && N % 128 == 0, COCOS_ERR_UNSUPPORTED,
+                  "proj_raw_planes_stats: needs N %% 128 == 0, K <= 4096 (B=%d K=%d N=%d)", B, K, N);
+    COCOS_REQUIRE((size_t)K * N * 4 < 0x7fffffffull && (long long)nprob * B * (N / 128) < 0x7fffffffLL, COCOS_ERR_UNSUPPORTED,
+                  "proj_raw_planes_stats: one sample exceeds 2 GiB");
+    for (const void* p : {(const void*)x0, wfrag0, (const void*)pos_hi0, (const void*)pos_lo0, (const void*)x1, wfrag1,
+                          (const void*)pos_hi1, (const void*)pos_lo1, (const void*)bias0, (const void*)bias1})
+        COCOS_REQUIRE(aligned16(p), COCOS_ERR_INVALID, "proj_raw_planes_stats: pointers must be 16-byte aligned");
+    PnArgs a;
+    a.p[0] = PnProb{x0, wfrag0, w_scale0, bias0, x_amax0, sum1_0, static_cast<_Float16*>(pos_hi0), static_cast<_Float16*>(pos_lo0),
+                    static_cast<_Float16*>(chan_hi0), static_cast<_Float16*>(chan_lo0), sum2_0, y_scale0};
+    a.p[1] = nprob == 2 ? PnProb{x1, wfrag1, w_scale1, bias1, x_amax1, sum1_1, static_cast<_Float16*>(pos_hi1),
+                                 static_cast<_Float16*>(pos_lo1), static_cast<_Float16*>(chan_hi1), static_cast<_Float16*>(chan_lo1),
+                                 sum2_1, y_scale1}
+                        : a.p[0];
+    a.nprob = nprob; a.B = B; a.K = K; a.N = N; a.nst = (K + 15) / 16;
+    a.center = 0;
+    a.eps = 0.f; a.plane_scale = 1.0f;
+    const dim3 grid((unsigned)(nprob * B * (N / 128)));
+    auto launch = [&](auto kern) -> int {
+        COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PN_SMEM));
+        hipLaunchKernelGGL(kern, grid, dim3(256), PN_SMEM, as_stream(stream), a);
+        return COCOS_OK;
+    };
+    const int rc = chan_hi0 ? launch(proj_norm_fwd_kernel<true, true>) : launch(proj_norm_fwd_kernel<false, true>);
     if (rc != COCOS_OK) return rc;
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;

@@ -84,6 +84,66 @@ __global__ __launch_bounds__(256) void unfold3_finish_kernel(const float* __rest
     a[(size_t)b * N + p] = 1.0f / (r + eps);
 }
 
+// the same for two tensors of one shape in one launch (grid z): K25 leaves the sums of theta and phi together
+struct Unfold3FinishPair {
+    const float *s1[2], *s2[2];
+    float *mu[2], *a[2], *nrm[2];
+};
+__global__ __launch_bounds__(256) void unfold3_finish_pair_kernel(const Unfold3FinishPair fp, int h, int w, float kc, float eps) {
+    const bool second = blockIdx.z != 0;
+    const float* __restrict__ s1 = second ? fp.s1[1] : fp.s1[0];
+    const float* __restrict__ s2 = second ? fp.s2[1] : fp.s2[0];
+    float* __restrict__ mu = second ? fp.mu[1] : fp.mu[0];
+    float* __restrict__ a = second ? fp.a[1] : fp.a[0];
+    float* __restrict__ nrm = second ? fp.nrm[1] : fp.nrm[0];
+    const int N = h * w, p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (p >= N) return;
+    const int y = p / w, x = p % w;
+    const float m = box3_at(s1 + (size_t)b * N, y, x, h, w) / kc;
+    const float v = fmaxf(box3_at(s2 + (size_t)b * N, y, x, h, w) - kc * m * m, 0.f);
+    const float r = sqrtf(v);
+    mu[(size_t)b * N + p] = m;
+    nrm[(size_t)b * N + p] = r;
+    a[(size_t)b * N + p] = 1.0f / (r + eps);
+}
+
+// the backward's two maps for two tensors of one shape in one launch
+struct Unfold3MapsPair {
+    const float *mu[2], *a[2], *nrm[2], *dmu[2], *da[2];
+    float *g1[2], *g2[2];
+};
+__device__ __forceinline__ void unfold3_t(const float* mu, const float* a, const float* nrm, const float* dmu, const float* da, int q,
+                                          float kc, float& t1, float& t2);
+__global__ __launch_bounds__(256) void unfold3_bwd_maps_pair_kernel(const Unfold3MapsPair mp, int h, int w, float kc) {
+    const int z = blockIdx.z != 0 ? 1 : 0;
+    const float* mu = z ? mp.mu[1] : mp.mu[0];
+    const float* a = z ? mp.a[1] : mp.a[0];
+    const float* nrm = z ? mp.nrm[1] : mp.nrm[0];
+    const float* dmu = z ? mp.dmu[1] : mp.dmu[0];
+    const float* da = z ? mp.da[1] : mp.da[0];
+    float* g1 = z ? mp.g1[1] : mp.g1[0];
+    float* g2 = z ? mp.g2[1] : mp.g2[0];
+    const int N = h * w, p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (p >= N) return;
+    const size_t o = (size_t)b * N;
+    const int y = p / w, x = p % w;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+                float t1, t2;
+                unfold3_t(mu + o, a + o, nrm + o, dmu ? dmu + o : nullptr, da ? da + o : nullptr, yy * w + xx, kc, t1, t2);
+                s1 += t1;
+                s2 += t2;
+            }
+        }
+    g1[o + p] = s1;
+    g2[o + p] = s2;
+}
+
 // t1, t2 of one position (see header)
 __device__ __forceinline__ void unfold3_t(const float* mu, const float* a, const float* nrm, const float* dmu,
                                           const float* da, int q, float kc, float& t1, float& t2) {
@@ -216,6 +276,44 @@ extern "C" int cocos_unfold3_stats_bwd_maps(const float* mu, const float* a, con
     const int N = h * w;
     hipLaunchKernelGGL(unfold3_bwd_maps_kernel, dim3((N + 255) / 256, B), dim3(256), 0, as_stream(stream), mu, a, nrm, dmu, da, ws,
                        ws + (size_t)B * N, h, w, k_unfolded);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+// mu, a, nrm [B,h*w] of two tensors from their per-position channel sums s1 = sum_c x, s2 = sum_c x^2 [B,h*w] (K25 computes
+// them in the projection's epilogue) — cocos_unfold3_stats_fwd's second half, for a pair, in one launch.
+extern "C" int cocos_unfold3_stats_finish_pair(const float* s1_0, const float* s2_0, float* mu0, float* a0, float* nrm0,
+                                               const float* s1_1, const float* s2_1, float* mu1, float* a1, float* nrm1, int B, int h,
+                                               int w, float k_unfolded, float eps, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(s1_0 && s2_0 && mu0 && a0 && nrm0 && s1_1 && s2_1 && mu1 && a1 && nrm1, COCOS_ERR_INVALID,
+                  "unfold3_stats_finish_pair: null pointer");
+    COCOS_REQUIRE(B >= 1 && B <= 65535 && h >= 1 && w >= 1 && k_unfolded > 0.f, COCOS_ERR_INVALID,
+                  "unfold3_stats_finish_pair: bad dims B=%d h=%d w=%d", B, h, w);
+    Unfold3FinishPair fp;
+    fp.s1[0] = s1_0; fp.s1[1] = s1_1; fp.s2[0] = s2_0; fp.s2[1] = s2_1;
+    fp.mu[0] = mu0; fp.mu[1] = mu1; fp.a[0] = a0; fp.a[1] = a1; fp.nrm[0] = nrm0; fp.nrm[1] = nrm1;
+    hipLaunchKernelGGL(unfold3_finish_pair_kernel, dim3((h * w + 255) / 256, B, 2), dim3(256), 0, as_stream(stream), fp, h, w, k_unfolded,
+                       eps);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+// cocos_unfold3_stats_bwd_maps for two tensors of one shape in one launch: ws_i = [g1 | g2] (B*h*w floats each).
+extern "C" int cocos_unfold3_stats_bwd_maps_pair(const float* mu0, const float* a0, const float* nrm0, const float* dmu0, const float* da0,
+                                                 float* ws0, const float* mu1, const float* a1, const float* nrm1, const float* dmu1,
+                                                 const float* da1, float* ws1, int B, int h, int w, float k_unfolded,
+                                                 cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(mu0 && a0 && nrm0 && ws0 && mu1 && a1 && nrm1 && ws1, COCOS_ERR_INVALID, "unfold3_stats_bwd_maps_pair: null pointer");
+    COCOS_REQUIRE(B >= 1 && B <= 65535 && h >= 1 && w >= 1 && k_unfolded > 0.f, COCOS_ERR_INVALID,
+                  "unfold3_stats_bwd_maps_pair: bad dims B=%d h=%d w=%d", B, h, w);
+    const size_t BN = (size_t)B * h * w;
+    Unfold3MapsPair mp;
+    mp.mu[0] = mu0; mp.mu[1] = mu1; mp.a[0] = a0; mp.a[1] = a1; mp.nrm[0] = nrm0; mp.nrm[1] = nrm1;
+    mp.dmu[0] = dmu0; mp.dmu[1] = dmu1; mp.da[0] = da0; mp.da[1] = da1;
+    mp.g1[0] = ws0; mp.g1[1] = ws1; mp.g2[0] = ws0 + BN; mp.g2[1] = ws1 + BN;
+    hipLaunchKernelGGL(unfold3_bwd_maps_pair_kernel, dim3((h * w + 255) / 256, B, 2), dim3(256), 0, as_stream(stream), mp, h, w, k_unfolded);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

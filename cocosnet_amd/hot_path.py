@@ -152,7 +152,14 @@ class _BoxedCorr:
         _, C, self.fh, self.fw = theta_raw.shape
         self.kc = float(C * 9)
         self._cache = {}
-        if isinstance(theta_raw, ops.LazyProj1x1):
+        self._raw_planes = None
+        if isinstance(theta_raw, ops.LazyProj1x1) and ops.proj_raw_fused_ok(theta_raw, phi_raw):
+            # round 6, K25: ONE launch from the features of both tensors to the operand planes of the raw projections and the sums
+            # behind K12's statistics — the fp32 projections never exist; theta_raw / phi_raw are autograd handles from here on
+            self._raw_planes = ops.Box3RawPlanes()
+            (theta_raw, mu, a), (phi_raw, nu, b) = ops.proj_raw_planes_stats_pair(theta_raw, phi_raw, self.kc, self._raw_planes)
+            self._cache["q"], self._cache["k"] = (mu, a), (nu, b)
+        elif isinstance(theta_raw, ops.LazyProj1x1):
             # round 6: projection + K12 statistics as ONE autograd node per tensor (ops.proj_unfold3_stats): its backward folds K12's
             # backward and the sum of theta_raw's two gradients into the projection's input gradient (K24)
             if ops.PROJ_PRECISION == "f16x3":      # max|.| of both feature tensors and both weights in one launch
@@ -173,16 +180,16 @@ class _BoxedCorr:
     def rows(self, v):
         mu, a = self._get("q", lambda: _unfold3_stats(self.th, self.kc))
         nu, b = self._get("k", lambda: _unfold3_stats(self.ph, self.kc))
-        t = self._get("t_rows", lambda: ops.box3_corr_xbox(self.th, self.ph, self._sink))
+        t = self._get("t_rows", lambda: ops.box3_corr_xbox(self.th, self.ph, self._sink, self._raw_planes))
         return ops.box3_softmax_warp(t, mu, a, nu, b, v, self.fh, self.fw, self.kc, self.inv_t, sink=self._sink)
 
     def cols(self, v):   # the same operator with the roles of theta and phi exchanged
         mu, a = self._get("q", lambda: _unfold3_stats(self.th, self.kc))
         nu, b = self._get("k", lambda: _unfold3_stats(self.ph, self.kc))
         if self._sink is not None:
-            t = self._get("t_rows", lambda: ops.box3_corr_xbox(self.th, self.ph, self._sink))
+            t = self._get("t_rows", lambda: ops.box3_corr_xbox(self.th, self.ph, self._sink, self._raw_planes))
             return ops.box3_softmax_warp(t, nu, b, mu, a, v, self.fh, self.fw, self.kc, self.inv_t, transposed=True, sink=self._sink)
-        t = self._get("t_cols", lambda: ops.box3_corr_xbox(self.ph, self.th))
+        t = self._get("t_cols", lambda: ops.box3_corr_xbox(self.ph, self.th, None, self._raw_planes))
         return ops.box3_softmax_warp(t, nu, b, mu, a, v, self.fh, self.fw, self.kc, self.inv_t)
 
 

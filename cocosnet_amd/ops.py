@@ -1355,7 +1355,7 @@ def _proj1x1_dw_affine(mode, in1, in2a, in2b, coef, plane_scale, x, d_amax, x_am
     return dw, db
 
 
-def _proj1x1_dw_affine_pair(mode, probs, plane_scale, need_b):
+def _proj1x1_dw_affine_pair(mode, probs, plane_scale, need_b, scale_cells=(None, None)):
     """_proj1x1_dw_affine for two projections of one shape in one launch: probs = [(in1, in2a, in2b, coef, x, d_amax, x_amax)] * 2
     -> [(dw, db | None)] * 2 (cocos_proj1x1_dw_affine_pair_f16x3)."""
     lib = _lib.load()
@@ -1364,6 +1364,8 @@ def _proj1x1_dw_affine_pair(mode, probs, plane_scale, need_b):
     Cout, N = probs[0][0].shape[1], probs[0][0].shape[2]
     parts = lib.cocos_proj1x1_dw_partials_pair_f16x3(B, Cin, Cout, N)
     if not parts or probs[1][4].shape != x0.shape:
+        if any(c is not None for c in scale_cells):
+            raise _lib.CocosHipError(f"proj1x1_dw_affine_pair: shape not supported (Cin={Cin} Cout={Cout} N={N})")
         return [_proj1x1_dw_affine(mode, in1, a, b, coef, plane_scale, x, da, xa, need_b) for (in1, a, b, coef, x, da, xa) in probs]
     res, args = [], []
     f32 = dict(device=x0.device, dtype=torch.float32)
@@ -1375,7 +1377,8 @@ def _proj1x1_dw_affine_pair(mode, probs, plane_scale, need_b):
         res.append((dw, db))
         args += [in1.data_ptr(), in2a.data_ptr(), _ptr(in2b), coef.data_ptr(), x.data_ptr(), ws.data_ptr(), _ptr(wsb), dw.data_ptr(),
                  _ptr(db), d_amax.data_ptr(), x_amax.data_ptr()]
-    _call("proj1x1_bwd", "cocos_proj1x1_dw_affine_pair_f16x3", mode, float(plane_scale), *args, B, Cin, Cout, N, _stream())
+    _call("proj1x1_bwd", "cocos_proj1x1_dw_affine_pair_f16x3", mode, float(plane_scale), *args, _ptr(scale_cells[0]), _ptr(scale_cells[1]),
+          B, Cin, Cout, N, _stream())
     return res
 
 
@@ -1448,6 +1451,162 @@ class _ProjUnfoldStats(torch.autograd.Function):
             dth = dth + dy
         return (*_proj1x1_backward(x, w2, dth, st["amax"], st["t_planes"], st["split"], st["stream"], need_x, need_w, need_b,
                                    st["wshape"]), None, None)
+
+
+#: False: match_kernel 3 projects with K0 and takes the statistics / operand planes in separate launches (A/B runs)
+PROJ_RAW_FUSED = os.environ.get("COCOS_PROJ_RAW_FUSED", "1") != "0"
+
+
+class Box3RawPlanes:
+    """What K25 leaves for the match_kernel-3 family about theta and phi, keyed by the autograd HANDLE that stands for each raw
+    projection: (position-major hi, lo, channel-major hi | None, lo | None, scale cell).  Owned by hot_path's _BoxedCorr: one
+    forward call, one thread."""
+
+    def __init__(self):
+        self._ent = {}
+
+    def put(self, handle, ph, pl, ch, cl, scale):
+        self._ent[id(handle)] = (handle, handle._version, ph, pl, ch, cl, scale)
+
+    def get(self, handle):
+        ent = self._ent.get(id(handle))
+        if ent is None or ent[0] is not handle:
+            return None
+        if ent[1] != handle._version:
+            raise _lib.CocosHipError("Box3RawPlanes: the tensor behind producer-made operand planes was modified in place")
+        return ent[2:]
+
+
+def proj_raw_fused_ok(theta: LazyProj1x1, phi: LazyProj1x1) -> bool:
+    """Shapes / gradient patterns K25 and its backward take: both projections 256 channels from <= 448 of one shape, whole
+    128-position tiles, and either nothing or everything (features, weights) differentiated."""
+    if not (PROJ_RAW_FUSED and PROJ_BWD_FUSED and PROJ_PRECISION == "f16x3" and PRECISION == "f16x3"):
+        return False
+    B, Cout, h, w = theta.shape
+    N = h * w
+    if not (theta.is_cuda and theta.dtype == torch.float32 and theta.x.shape == phi.x.shape and phi.shape == theta.shape
+            and Cout == FUSED_K and N % 128 == 0 and _lib.load().cocos_proj_bwd_input_supported(theta.x.shape[1], FUSED_K, N)
+            and theta.x.shape[1] * N * 4 < 2 ** 31 - 1 and phi.is_cuda and phi.dtype == torch.float32):
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    req = [t.requires_grad for t in (theta.x, theta.weight, phi.x, phi.weight)]
+    return all(req) or not (any(req) or any(b is not None and b.requires_grad for b in (theta.bias, phi.bias)))
+
+
+class _ProjRawPlanesStatsPair(torch.autograd.Function):
+    """K25 for the two projections of a match_kernel-3 forward call: ONE launch from the features to the operand planes of the raw
+    theta / phi (position-major for the x-box GEMM, channel-major for the backward GEMMs and the weight gradient) and to the
+    per-position sums K12's statistics are box sums of; one more launch finishes (mu, a) / (nu, b).  Outputs: two HANDLES
+    [B,256,h,w] (never written, never read: _Box3CorrXbox takes the planes from `holder`) and the statistics.  Backward: the
+    handles' gradients (the correlation GEMMs') and the statistics' (K19's) meet here — K12's maps for both tensors (one launch),
+    K24 mode C for both input gradients (one launch), both weight gradients (one launch + one reduction)."""
+
+    @staticmethod
+    def forward(ctx, x1, w1, b1, x2, w2, b2, k_unfolded: float, eps: float, holder):
+        lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        xs = [_chk(x1, "proj_raw_planes_stats: x (theta)"), _chk(x2, "proj_raw_planes_stats: x (phi)")]
+        ws = [_chk(w1.reshape(w1.shape[0], -1), "proj_raw_planes_stats: weight"), _chk(w2.reshape(w2.shape[0], -1), "proj_raw_planes_stats: weight")]
+        bs = [None if b is None else _chk(b, "proj_raw_planes_stats: bias") for b in (b1, b2)]
+        B, Cin, h, w = xs[0].shape
+        N = h * w
+        dev = xs[0].device
+        half, f32 = dict(device=dev, dtype=torch.float16), dict(device=dev, dtype=torch.float32)
+        want_grad = any(ctx.needs_input_grad[:6])
+        amax = [_recall_amax(xs[0], consume=False), _recall_amax(ws[0]), _recall_amax(xs[1], consume=False), _recall_amax(ws[1])]
+        missing = [i for i, c in enumerate(amax) if c is None]
+        if missing:
+            for i, c in zip(missing, absmax_many([(xs[0], ws[0], xs[1], ws[1])[i] for i in missing])):
+                amax[i] = c
+        wprep, args, keep = [], [], []
+        for pi in range(2):
+            wfrag = torch.empty(lib.cocos_proj_weight_frag_bytes(Cin), device=dev, dtype=torch.uint8)
+            wsc = torch.empty(1, **f32)
+            wtf = torch.empty(lib.cocos_proj_weight_tfrag_bytes(), device=dev, dtype=torch.uint8) if want_grad else None
+            wprep += [ws[pi].data_ptr(), amax[2 * pi + 1].data_ptr(), wfrag.data_ptr(), wsc.data_ptr(), None, None, _ptr(wtf)]
+            sums = torch.empty((2, B, N), **f32)
+            ysc = torch.empty(1, **f32)
+            ph, pl = torch.empty((B, N, FUSED_K), **half), torch.empty((B, N, FUSED_K), **half)
+            ch = cl = None
+            if want_grad:
+                ch, cl = torch.empty((B, FUSED_K, N), **half), torch.empty((B, FUSED_K, N), **half)
+            args += [xs[pi].data_ptr(), wfrag.data_ptr(), wsc.data_ptr(), _ptr(bs[pi]), amax[2 * pi].data_ptr(), sums[0].data_ptr(),
+                     sums[1].data_ptr(), ysc.data_ptr(), ph.data_ptr(), pl.data_ptr(), _ptr(ch), _ptr(cl)]
+            keep.append((wfrag, wsc, wtf, sums, ysc, ph, pl, ch, cl))
+        _call("split_f16", "cocos_proj_weight_prep_pair", 2, *wprep, FUSED_K, Cin, _stream())
+        _call("proj1x1_fwd", "cocos_proj_raw_planes_stats_f16x3", 2, *args, B, Cin, N, _stream())
+        stats = [tuple(torch.empty((B, N), **f32) for _ in range(3)) for _ in range(2)]      # (mu, a, nrm) per tensor
+        fa = []
+        for pi in range(2):
+            fa += [keep[pi][3][0].data_ptr(), keep[pi][3][1].data_ptr()] + [t.data_ptr() for t in stats[pi]]
+        _call("unfold3_stats_fwd", "cocos_unfold3_stats_finish_pair", *fa, B, h, w, float(k_unfolded), float(eps), _stream())
+        handles = []
+        for pi in range(2):
+            hd = torch.empty((B, FUSED_K, h, w), **f32)      # never written, never read: an autograd handle
+            (_wf, _ws, _wt, _s, ysc, ph, pl, ch, cl) = keep[pi]
+            holder.put(hd, ph, pl, ch, cl, ysc)
+            handles.append(hd)
+        ctx.save_for_backward(xs[0], ws[0], xs[1], ws[1], *stats[0], *stats[1])
+        ctx.keep = keep
+        ctx.x_amax = (amax[0], amax[2])
+        ctx.kc = float(k_unfolded)
+        ctx.dims = (B, Cin, h, w)
+        ctx.wshapes = (tuple(w1.shape), tuple(w2.shape))
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.mark_non_differentiable(stats[0][2], stats[1][2])
+        return handles[0], stats[0][0], stats[0][1], handles[1], stats[1][0], stats[1][1], stats[0][2], stats[1][2]
+
+    @staticmethod
+    def backward(ctx, d1, dmu1, da1, d2, dmu2, da2, _n1, _n2):
+        x1, w1, x2, w2, mu1, a1, nrm1, mu2, a2, nrm2 = ctx.saved_tensors
+        B, Cin, h, w = ctx.dims
+        N = h * w
+        dev = x1.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        needs = ctx.needs_input_grad
+        if not (needs[0] and needs[1] and needs[3] and needs[4]):
+            raise _lib.CocosHipError("proj_raw_planes_stats: backward needs the gradients of both feature tensors and both weights "
+                                     "(proj_raw_fused_ok gates the forward)")
+        ds = []
+        for d in (d1, d2):      # (a projection whose correlation gradient is absent: only the statistics' path contributes)
+            ds.append(torch.zeros((B, FUSED_K, N), **f32) if d is None else _chk(d, "proj_raw_planes_stats: d theta").reshape(B, FUSED_K, N))
+        stats = ((mu1, a1, nrm1, dmu1, da1), (mu2, a2, nrm2, dmu2, da2))
+        maps = [torch.empty(2 * B * N, **f32) for _ in range(2)]
+        ma = []
+        for pi in range(2):
+            mu, a, nrm, dmu, da = stats[pi]
+            ma += [mu.data_ptr(), a.data_ptr(), nrm.data_ptr(), _ptr(None if dmu is None else _chk(dmu, "dmu")),
+                   _ptr(None if da is None else _chk(da, "da")), maps[pi].data_ptr()]
+        _call("unfold3_stats_bwd", "cocos_unfold3_stats_bwd_maps_pair", *ma, B, h, w, ctx.kc, _stream())
+        xs, dxs = (x1, x2), [torch.empty_like(x1), torch.empty_like(x2)]
+        coefs = [torch.empty((B, 3, N), **f32) for _ in range(2)]
+        cells = [_zero_cell(dev), _zero_cell(dev)]
+        args = []
+        for pi in range(2):
+            (_wf, wsc, wtf, _s, ysc, ph, pl, _ch, _cl) = ctx.keep[pi]
+            g1, g2 = maps[pi][:B * N], maps[pi][B * N:]
+            args += [ds[pi].data_ptr(), ph.data_ptr(), pl.data_ptr(), ysc.data_ptr(), g1.data_ptr(), g2.data_ptr(), wtf.data_ptr(),
+                     wsc.data_ptr(), dxs[pi].data_ptr(), coefs[pi].data_ptr(), cells[pi].data_ptr()]
+        _call("proj_bwd_input", "cocos_proj_bwd_input_planes_f16x3", 2, *args, B, Cin, N, _stream())
+        nb = [needs[2] and ctx.has_bias[0], needs[5] and ctx.has_bias[1]]
+        probs = [(ds[pi], ctx.keep[pi][7], ctx.keep[pi][8], coefs[pi], xs[pi], cells[pi], ctx.x_amax[pi]) for pi in range(2)]
+        scale_cells = (ctx.keep[0][4], ctx.keep[1][4])
+        if nb[0] == nb[1]:
+            res = _proj1x1_dw_affine_pair(2, probs, 1.0, nb[0], scale_cells)
+        else:       # (a bias on one projection only: two pair-API launches of one problem each would need another entry point — both
+            #  biases' gradients are computed and the unwanted one dropped)
+            res = _proj1x1_dw_affine_pair(2, probs, 1.0, True, scale_cells)
+            res = [(res[pi][0], res[pi][1] if nb[pi] else None) for pi in range(2)]
+        return (dxs[0], res[0][0].reshape(ctx.wshapes[0]), res[0][1], dxs[1], res[1][0].reshape(ctx.wshapes[1]), res[1][1], None, None, None)
+
+
+def proj_raw_planes_stats_pair(theta: LazyProj1x1, phi: LazyProj1x1, k_unfolded: float, holder: Box3RawPlanes, eps: float = NORM_EPS):
+    """((theta handle, mu, a), (phi handle, nu, b)) of two lazy projections through K25: see _ProjRawPlanesStatsPair.  The handles go
+    to box3_corr_xbox(..., raw_planes=holder).  Only for proj_raw_fused_ok() pairs."""
+    th, mu, a, ph, nu, b, _, _ = _ProjRawPlanesStatsPair.apply(theta.x, theta.weight, theta.bias, phi.x, phi.weight, phi.bias,
+                                                               float(k_unfolded), eps, holder)
+    return (th, mu, a), (ph, nu, b)
 
 
 def proj_unfold3_stats(p: LazyProj1x1, k_unfolded: float, eps: float = NORM_EPS):
@@ -1865,17 +2024,28 @@ class _Box3CorrXbox(torch.autograd.Function):
     y box of the adjoint is applied here, together with the x box, by K20."""
 
     @staticmethod
-    def forward(ctx, q_raw, k_raw, sink=None):
+    def forward(ctx, q_raw, k_raw, sink=None, raw_planes=None):
         ctx.sink = sink
         q_raw, k_raw = _chk(q_raw, "box3_corr_xbox: q"), _chk(k_raw, "box3_corr_xbox: k")
         B, K, h, w = q_raw.shape
         N = h * w
-        qf, kf = q_raw.reshape(B, K, N), k_raw.reshape(B, K, N)
-        qa, ka = _recall_amax(qf, consume=False), _recall_amax(kf, consume=False)   # left by K12 (both orientations read them)
-        qa = absmax(qf) if qa is None else qa
-        ka = absmax(kf) if ka is None else ka
-        qh, ql, qs = split_f16(qf, True, amax=qa)            # position-major planes [B,N,K]
-        kh, kl, ks = split_f16(kf, True, amax=ka)
+        qp = kp = None
+        if raw_planes is not None:        # K25 wrote the planes itself: q_raw / k_raw are handles (their memory is never read)
+            qp, kp = raw_planes.get(q_raw), raw_planes.get(k_raw)
+        ctx.chan = None
+        if qp is not None and kp is not None:
+            (qh, ql, qch, qcl, qs), (kh, kl, kch, kcl, ks) = qp, kp
+            ctx.chan = ((qch, qcl, qs), (kch, kcl, ks))
+            qa = ka = None
+        else:
+            if qp is not None or kp is not None:
+                raise _lib.CocosHipError("box3_corr_xbox: producer-made planes for one operand only")
+            qf, kf = q_raw.reshape(B, K, N), k_raw.reshape(B, K, N)
+            qa, ka = _recall_amax(qf, consume=False), _recall_amax(kf, consume=False)   # left by K12 (both orientations read them)
+            qa = absmax(qf) if qa is None else qa
+            ka = absmax(kf) if ka is None else ka
+            qh, ql, qs = split_f16(qf, True, amax=qa)            # position-major planes [B,N,K]
+            kh, kl, ks = split_f16(kf, True, amax=ka)
         t = torch.empty(B * N * N, device=q_raw.device, dtype=torch.float32)
         _call("box3_corr_xbox", "cocos_box3_corr_xbox_f16x3", kh.data_ptr(), kl.data_ptr(), qh.data_ptr(), ql.data_ptr(),
               t.data_ptr(), B, N, N, K, w, ks.data_ptr(), qs.data_ptr(), _stream())
@@ -1911,19 +2081,22 @@ class _Box3CorrXbox(torch.autograd.Function):
         _call("box3_adjoint_planes", "cocos_box3_adjoint_planes_f16x3", g.data_ptr(), gmax.data_ptr(), dch.data_ptr(),
               dcl.data_ptr(), sc.data_ptr(), B, N, N, h, w, _stream())
         dq = dk = None
+        chan = ctx.chan
+        if chan is not None and any(p is None for p in (chan[0][0], chan[1][0])):
+            raise _lib.CocosHipError("box3_corr_xbox: backward without the channel-major planes (forward ran without grad)")
         if ctx.needs_input_grad[0]:         # d q_raw[c,P] = sum_Q dC[P,Q] k_raw[c,Q]
-            ch, cl, cs = split_f16(k_raw.reshape(B, K, N), False, amax=ka)
+            ch, cl, cs = chan[1] if chan is not None else split_f16(k_raw.reshape(B, K, N), False, amax=ka)
             dq = torch.empty_like(q_raw)
             _call("box3_corr_grad", "cocos_hgemm_f16x3", ch.data_ptr(), cl.data_ptr(), dch.data_ptr(), dcl.data_ptr(),
                   dq.data_ptr(), B, K, N, N, 1.0, cs.data_ptr(), sc.data_ptr(), 3, _stream())
         if ctx.needs_input_grad[1]:         # d k_raw[c,Q] = sum_P dC[P,Q] q_raw[c,P]
-            ch, cl, cs = split_f16(q_raw.reshape(B, K, N), False, amax=qa)
+            ch, cl, cs = chan[0] if chan is not None else split_f16(q_raw.reshape(B, K, N), False, amax=qa)
             dk = torch.empty_like(k_raw)
             _call("box3_corr_grad", "cocos_hgemm_f16x3", ch.data_ptr(), cl.data_ptr(), dch.data_ptr(), dcl.data_ptr(),
                   dk.data_ptr(), B, K, N, N, 1.0, cs.data_ptr(), sc.data_ptr(), 2, _stream())
         if ctx.sink is not None:
             ctx.sink.reset()      # (a second backward through the same graph starts a new G)
-        return dq, dk, None
+        return dq, dk, None, None
 
 
 class Box3GradSink:
@@ -1944,11 +2117,11 @@ class Box3GradSink:
         self.t_dead = None
 
 
-def box3_corr_xbox(q_raw, k_raw, sink: Box3GradSink | None = None):
+def box3_corr_xbox(q_raw, k_raw, sink: Box3GradSink | None = None, raw_planes: Box3RawPlanes | None = None):
     """x-direction diagonal box filter of the K = 256 correlation of two raw [B,256,h,w] feature maps (64- or 128-wide grid),
     keys in the rows, in the tile-blocked layout of K19 (an opaque 1-D tensor of B*N*N floats).  `sink`: the gradient sink the
     box3_softmax_warp passes over this T share (see Box3GradSink)."""
-    return _Box3CorrXbox.apply(q_raw, k_raw, sink)
+    return _Box3CorrXbox.apply(q_raw, k_raw, sink, raw_planes)
 
 
 class _Box3SoftmaxWarp(torch.autograd.Function):

@@ -412,7 +412,34 @@ int cocos_proj1x1_dw_affine_pair_f16x3(
     int mode, float plane_scale, const float* in1_0, const void* in2a_0, const void* in2b_0, const float* coef0, const float* x0,
     float* ws_dw0, float* ws_db0, float* dw0, float* db0, const float* dy_amax0, const float* x_amax0, const float* in1_1,
     const void* in2a_1, const void* in2b_1, const float* coef1, const float* x1, float* ws_dw1, float* ws_db1, float* dw1, float* db1,
-    const float* dy_amax1, const float* x_amax1, int B, int C, int M, int N, cocos_stream_t stream);
+    const float* dy_amax1, const float* x_amax1, const float* plane_scale_dev0 /* nullable */, const float* plane_scale_dev1 /* nullable */,
+    int B, int C, int M, int N, cocos_stream_t stream);   /* plane_scale_dev_i (mode 2): device cell with the planes' scale, overrides plane_scale */
+/* K25 (round 6, match_kernel 3; csrc/proj_norm_f16x3.hip): the theta / phi projection with NO normalisation, straight to what the
+ * match_kernel-3 family reads (correspondence.py:272, :282 + :276-280 / :286-289 without the unfold): per projection x [B,K,N] ->
+ *   sum1 = sum_c y, sum2 = sum_c y^2 [B,N] (y = W x + bias) — cocos_unfold3_stats_finish_pair makes mu / a / nrm of both tensors from
+ *       them in one launch (cocos_unfold3_stats_fwd's second half);
+ *   the f16 hi / lo planes of s * y, position-major [B,N,256] (the x-box GEMM's operands) and channel-major [B,256,N] (nullable pair:
+ *       the backward GEMMs' and the weight gradient's operands), *y_scale = s: a power of two from the a-priori bound
+ *       K max|w| max|x| + max|bias| (no pass over y; the bound lands in [2^13, 2^14)).  The fp32 projection is never written.
+ * Backward: cocos_unfold3_stats_bwd_maps_pair (g1, g2 of both tensors), cocos_proj_bwd_input_planes_f16x3 (K24 mode C: d = in1 +
+ * 2 g2 y + g1 with y read back from the position-major planes, dx = W^T d), cocos_proj1x1_dw_affine_pair_f16x3 (mode 2, plane_scale_dev). */
+int cocos_proj_raw_planes_stats_f16x3(
+    int nprob, const float* x0, const void* wfrag0, const float* w_scale0, const float* bias0, const float* x_amax0, float* sum1_0,
+    float* sum2_0, float* y_scale0, void* pos_hi0, void* pos_lo0, void* chan_hi0, void* chan_lo0, const float* x1, const void* wfrag1,
+    const float* w_scale1, const float* bias1, const float* x_amax1, float* sum1_1, float* sum2_1, float* y_scale1, void* pos_hi1,
+    void* pos_lo1, void* chan_hi1, void* chan_lo1, int B, int K, int N, cocos_stream_t stream);
+int cocos_unfold3_stats_finish_pair(const float* s1_0, const float* s2_0, float* mu0, float* a0, float* nrm0, const float* s1_1,
+                                    const float* s2_1, float* mu1, float* a1, float* nrm1, int B, int h, int w, float k_unfolded,
+                                    float eps, cocos_stream_t stream);
+int cocos_unfold3_stats_bwd_maps_pair(const float* mu0, const float* a0, const float* nrm0, const float* dmu0 /* nullable */,
+                                      const float* da0 /* nullable */, float* ws0 /* 2*B*h*w */, const float* mu1, const float* a1,
+                                      const float* nrm1, const float* dmu1 /* nullable */, const float* da1 /* nullable */,
+                                      float* ws1, int B, int h, int w, float k_unfolded, cocos_stream_t stream);
+int cocos_proj_bwd_input_planes_f16x3(
+    int nprob, const float* in1_0, const void* y_hi0, const void* y_lo0, const float* y_scale0, const float* g1_0, const float* g2_0,
+    const void* wtfrag0, const float* w_scale0, float* dx0, float* coef0, float* amax0, const float* in1_1, const void* y_hi1,
+    const void* y_lo1, const float* y_scale1, const float* g1_1, const float* g2_1, const void* wtfrag1, const float* w_scale1, float* dx1,
+    float* coef1, float* amax1, int B, int Cin, int N, cocos_stream_t stream);
 /* K0 weight and bias gradient as one streaming reduction (autograd of correspondence.py:272,:282):
  *     dw[m,c] = sum_{b,n} dy[b,m,n] x[b,c,n]      db[m] = sum_{b,n} dy[b,m,n]   (db, ws_db: both or neither NULL)
  * dy [B,M,N], x [B,C,N] fp32, read once; f16x3 products with the power-of-two scales from dy_amax / x_amax.

@@ -258,3 +258,96 @@ def test_k24_tiny_and_huge_gradients_keep_their_precision():
         col = ((got - ref).abs().amax(dim=1) / (ref.abs().amax(dim=1) + 1e-300)).max()
         assert float(col) < 3e-5, float(col)
         assert float((leaves[1].grad.double().cpu() - wr.grad).abs().max() / wr.grad.abs().max()) < 3e-5
+
+
+# ------------------------------------------------------------------ K25: match_kernel 3's projections without normalisation
+@pytest.mark.parametrize("B,Cin,h,w,bias,x_scale", [(2, 407, 4, 64, True, 1.0), (1, 256, 8, 64, True, 3e4), (2, 33, 2, 64, False, 1e-5),
+                                                    (1, 448, 16, 8, True, 1.0)])
+def test_k25_planes_sums_and_statistics_match_fp64(B, Cin, h, w, bias, x_scale):
+    """ops.proj_raw_planes_stats_pair: the planes of s * (W x + b) in both orientations (s = the device-side power of two from the
+    a-priori bound), and (mu, a) / (nu, b) from the sums of its epilogue, against fp64 — for both projections of the pair launch."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import _unfold3_stats
+    x1, w1, b1, x2, w2, b2 = _case(B, Cin, h, w, seed=5 * Cin + w, bias=bias, x_scale=x_scale)
+    N, kc = h * w, 256.0 * 9
+    leaves = [None if t is None else t.clone().requires_grad_(True) for t in (x1, w1, b1, x2, w2, b2)]
+    holder = ops.Box3RawPlanes()
+    assert ops.proj_raw_fused_ok(ops.LazyProj1x1(*leaves[:3]), ops.LazyProj1x1(*leaves[3:]))
+    (th, mu, a), (ph, nu, b) = ops.proj_raw_planes_stats_pair(ops.LazyProj1x1(*leaves[:3]), ops.LazyProj1x1(*leaves[3:]), kc, holder)
+    for hd, st, (x, wt, bb) in ((th, (mu, a), (x1, w1, b1)), (ph, (nu, b), (x2, w2, b2))):
+        y = torch.einsum("mk,bkn->bmn", _f64(wt).reshape(256, Cin), _f64(x).reshape(B, Cin, N))
+        if bb is not None:
+            y = y + _f64(bb)[None, :, None]
+        phh, pll, chh, cll, sc = holder.get(hd)
+        s = float(sc)
+        assert s > 0 and np.log2(s) == round(np.log2(s))                         # a power of two
+        ymax = float(y.abs().max())
+        assert 2.0 ** 4 <= ymax * s < 2.0 ** 14, (ymax, s)                        # below the bound, not absurdly far below it
+        pos = (phh.double() + pll.double()).cpu() / s
+        chan = (chh.double() + cll.double()).cpu() / s
+        assert float((pos - y.transpose(1, 2)).abs().max()) < 2.0 ** -20 * ymax
+        assert float((chan - y).abs().max()) < 2.0 ** -20 * ymax
+        mur, ar = _unfold3_stats(y.reshape(B, 256, h, w), kc)
+        rel = lambda t, r: float((t.detach().double().cpu() - r).abs().max() / (r.abs().max() + 1e-300))
+        assert rel(st[0], mur) < 5e-6 and rel(st[1], ar) < 5e-6, (rel(st[0], mur), rel(st[1], ar))
+
+
+@pytest.mark.parametrize("B,Cin,h,w,bias", [(2, 407, 4, 64, True), (1, 256, 8, 64, True), (2, 33, 2, 64, False)])
+def test_k25_gradients_match_fp64(B, Cin, h, w, bias):
+    """Gradients of <theta_raw, G> + <mu, gm> + <a, ga> (and the same for phi) through the K25 pair node — K12's maps, K24 mode C
+    (y read back from the planes), the pair weight gradient with the device-side plane scale — against torch fp64."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import _unfold3_stats
+    x1, w1, b1, x2, w2, b2 = _case(B, Cin, h, w, seed=Cin + 1, bias=bias)
+    N, kc = h * w, 256.0 * 9
+    g = torch.Generator(device=DEV).manual_seed(19)
+    Gs = [torch.randn(B, 256, h, w, device=DEV, generator=g), torch.randn(B, 256, h, w, device=DEV, generator=g) * 1e-3]
+    gms = [torch.randn(B, N, device=DEV, generator=g) for _ in range(2)]
+    gas = [torch.randn(B, N, device=DEV, generator=g) * 0.1 for _ in range(2)]
+    leaves = [None if t is None else t.clone().requires_grad_(True) for t in (x1, w1, b1, x2, w2, b2)]
+    holder = ops.Box3RawPlanes()
+    with ops.KernelTimer() as kt:
+        (th, mu, a), (ph, nu, b) = ops.proj_raw_planes_stats_pair(ops.LazyProj1x1(*leaves[:3]), ops.LazyProj1x1(*leaves[3:]), kc, holder)
+        torch.autograd.backward([th, mu, a, ph, nu, b], [Gs[0], gms[0], gas[0], Gs[1], gms[1], gas[1]])
+    assert "proj_bwd_input" in kt.summary(), sorted(kt.summary())
+    for i, (x, wt, bb) in enumerate(((x1, w1, b1), (x2, w2, b2))):
+        xr, wr = _f64(x).requires_grad_(True), _f64(wt).requires_grad_(True)
+        br = None if bb is None else _f64(bb).requires_grad_(True)
+        thr = torch.einsum("mk,bkn->bmn", wr.reshape(256, Cin), xr.reshape(B, Cin, N)).reshape(B, 256, h, w)
+        if br is not None:
+            thr = thr + br[None, :, None, None]
+        mur, ar = _unfold3_stats(thr, kc)
+        ((thr * _f64(Gs[i])).sum() + (mur * _f64(gms[i])).sum() + (ar * _f64(gas[i])).sum()).backward()
+        got = leaves[3 * i:3 * i + 3]
+        rel = lambda t, r: float((t.detach().double().cpu() - r).abs().max() / (r.abs().max() + 1e-300))
+        errs = (rel(got[0].grad, xr.grad), rel(got[1].grad, wr.grad), None if br is None else rel(got[2].grad, br.grad))
+        print("K25_GRAD", (B, Cin, h, w), i, errs)
+        assert errs[0] < 2e-5 and errs[1] < 2e-5 and (errs[2] is None or errs[2] < 2e-5), errs
+
+
+def test_k25_hot_path_equals_the_unfused_chain(monkeypatch):
+    """match_kernel 3 through correspondence_hot_path with lazy projections: K25 (planes + sums in one launch, no fp32 projection)
+    against COCOS_PROJ_RAW_FUSED=0 (K0 + K12 + separate splits) — outputs and all six gradients."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    B, Cin, fh, fw, down, nc = 2, 256 + 7, 4, 64, 4, 7
+    x1, w1, b1, x2, w2, b2 = _case(B, Cin, fh, fw, seed=77)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    H, W = fh * down, fw * down
+    ref_img = torch.rand(B, 3, H, W, device=DEV, generator=g) * 2 - 1
+    lab = torch.randint(0, nc, (B, 1, H, W), device=DEV, generator=g)
+    seg = torch.zeros(B, nc, H, W, device=DEV).scatter_(1, lab, 1.0)
+    cfg = HotPathConfig(match_kernel=3, PONO_C=True, down=down, warp_mask_losstype="direct", isTrain=True)
+    g_out, g_mask = torch.randn(B, 3, H, W, device=DEV, generator=g), torch.randn(B, nc, fh, fw, device=DEV, generator=g)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "PROJ_RAW_FUSED", fused)
+        leaves = [t.clone().requires_grad_(True) for t in (x1, w1, b1, x2, w2, b2)]
+        with ops.KernelTimer() as kt:
+            out = correspondence_hot_path(ops.LazyProj1x1(*leaves[:3]), ops.LazyProj1x1(*leaves[3:]), ref_img, ref_img, seg, seg, cfg)
+            torch.autograd.backward([out["warp_out"], out["warp_mask"]], [g_out, g_mask])
+        assert ("unfold3_stats_fwd" in kt.summary()) and (("proj1x1_fwd" in kt.summary())), sorted(kt.summary())
+        res[fused] = [out["warp_out"].detach(), out["warp_mask"].detach()] + [t.grad for t in leaves]
+    relerr = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    for a, b in zip(res[True], res[False]):
+        assert a.shape == b.shape and relerr(a, b) < 1e-4, relerr(a, b)
