@@ -224,6 +224,8 @@ _SIGNATURES = {
     "cocos_unfold3_stats_bwd_maps": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_float, _stream_t]),
     "cocos_instnorm_prelu_fwd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float, _stream_t]),
     "cocos_instnorm_prelu_bwd": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 2 + [ctypes.c_float, _stream_t]),
+    "cocos_instnorm_prelu_bwd_f64": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 2
+                                     + [ctypes.c_float, _stream_t]),
     "cocos_contextual_rows_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_float,
                                                  ctypes.c_float, _stream_t]),
     "cocos_contextual_rows_bwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_float,

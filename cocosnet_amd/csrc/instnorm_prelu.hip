@@ -10,6 +10,8 @@
 //   fwd: xn = (x - mean) / sqrt(var + eps);  z = xn (+ res);  y = z > 0 ? z : a*z          (a = the PReLU weight)
 //   bwd: dz = dy * (z > 0 ? 1 : a);  dres = dz;  dx = r*(dz - mean(dz) - xn*mean(dz*xn));  da = sum_{z<0} dy*z
 // Planes of up to 16384 positions take the register path (64 floats per thread); larger ones the streaming path.
+#include <type_traits>
+
 #include "common.h"
 
 namespace cocos {
@@ -27,13 +29,27 @@ __device__ __forceinline__ float inp_block_sum(float v, float* red, int tid) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-template <bool BWD, bool REG, int VPT = INP_VPT>
+__device__ __forceinline__ double inp_block_sum_f64(double v, double* red, int tid) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// DA64 (round 6): the PReLU weight's gradient da = sum_{z <= 0} dy z — ONE number summed over every element of the layer, whose
+// terms cancel (|sum| ~ sqrt(n) of sum |term| at n = 1.3e7) — is accumulated in fp64 from the products on: per element, per plane
+// and (cocos_instnorm_prelu_bwd_f64) over the planes.  In fp32 it was 90x further from fp64 than the framework's on one probe.
+template <bool BWD, bool REG, int VPT = INP_VPT, bool DA64 = false>
 __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                              const float* __restrict__ dy, const float* __restrict__ aw,
                                                              float* __restrict__ out0 /* y | dx */,
-                                                             float* __restrict__ dres, float* __restrict__ da_part,
+                                                             float* __restrict__ dres, void* __restrict__ da_part,
                                                              int N, float eps) {
     __shared__ float red[4];
+    __shared__ double red64[4];
+    typedef typename std::conditional<DA64, double, float>::type da_t;
     const int tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * N;
     const float a = *aw;
@@ -104,12 +120,22 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
     }
 
     // ---- backward: pass 1 = sums of dz and dz*xn (+ da), pass 2 = dx --------------------------------------
-    float s1 = 0.f, s2 = 0.f, sa = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    da_t sa = 0;
+    auto put_da = [&]() {
+        if (DA64) {
+            const double t = inp_block_sum_f64((double)sa, red64, tid);
+            if (tid == 0 && da_part) static_cast<double*>(da_part)[blockIdx.x] = t;
+        } else {
+            const float t = inp_block_sum((float)sa, red, tid);
+            if (tid == 0 && da_part) static_cast<float*>(da_part)[blockIdx.x] = t;
+        }
+    };
     auto dz_at = [&](int u, int e, int i, float& xn) {
         xn = xn_at(u, e, i);
         const float z = xn + (res ? res[base + i] : 0.f);
         const float g = dy[base + i];
-        if (z <= 0.f) sa += g * z;
+        if (z <= 0.f) sa += (da_t)g * (da_t)z;
         return z > 0.f ? g : g * a;
     };
     if (REG && vec) {
@@ -128,7 +154,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xn = v[u][e] * r, z = xn + r4[e], g = g4[e];
-                    if (z <= 0.f) sa += g * z;
+                    if (z <= 0.f) sa += (da_t)g * (da_t)z;
                     const float dz = z > 0.f ? g : g * a;
                     d[u][e] = dz;
                     s1 += dz;
@@ -138,8 +164,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
         }
         const float m1 = inp_block_sum(s1, red, tid) * invn;
         const float m2 = inp_block_sum(s2, red, tid) * invn;
-        const float sat = inp_block_sum(sa, red, tid);
-        if (tid == 0 && da_part) da_part[blockIdx.x] = sat;
+        put_da();
 #pragma unroll
         for (int u = 0; u < VPT; ++u) {
             const int q = u * 256 + tid;
@@ -169,12 +194,11 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
     }
     const float m1 = inp_block_sum(s1, red, tid) * invn;
     const float m2 = inp_block_sum(s2, red, tid) * invn;
-    const float sat = inp_block_sum(sa, red, tid);
-    if (tid == 0 && da_part) da_part[blockIdx.x] = sat;
+    put_da();
     float dummy = 0.f;
     auto fin = [&](int u, int e, int i) {
         float xn;
-        const float sa_keep = sa;
+        const da_t sa_keep = sa;
         const float dz = dz_at(u, e, i, xn);
         sa = sa_keep;
         if (dres) dres[base + i] = dz;
@@ -192,6 +216,15 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
         for (int i = tid; i < N; i += 256) fin(0, 0, i);
     }
     (void)dummy;
+}
+
+// *out = (float) sum of n doubles: one workgroup (n = planes of a layer: a few thousand)
+__global__ __launch_bounds__(256) void sum_f64_to_f32_kernel(const double* __restrict__ p, int n, float* __restrict__ out) {
+    __shared__ double red64[4];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += p[i];
+    const double t = inp_block_sum_f64(v, red64, threadIdx.x);
+    if (threadIdx.x == 0) *out = (float)t;
 }
 
 }  // namespace cocos
@@ -223,6 +256,29 @@ extern "C" int cocos_instnorm_prelu_bwd(const float* x, const float* residual, c
     if (reg && N <= 256 * 4 * 4) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true, 4>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, da_partials, N, eps);
     else if (reg) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, da_partials, N, eps);
     else     hipLaunchKernelGGL((instnorm_prelu_kernel<true, false>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, da_partials, N, eps);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+// The same backward with the PReLU weight's gradient accumulated in fp64 end to end: da_partials_f64 = workspace of `planes`
+// doubles, *da_out = sum over every element of the layer with z <= 0 of dy * z (rounded to fp32 once, at the end).
+extern "C" int cocos_instnorm_prelu_bwd_f64(const float* x, const float* residual, const float* prelu_weight, const float* dy,
+                                            float* dx, float* dresidual, double* da_partials_f64, float* da_out, int planes, int N,
+                                            float eps, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && prelu_weight && dy && da_partials_f64 && da_out, COCOS_ERR_INVALID, "instnorm_prelu_bwd_f64: null pointer");
+    COCOS_REQUIRE(planes >= 1 && N >= 1, COCOS_ERR_INVALID, "instnorm_prelu_bwd_f64: bad dims planes=%d N=%d", planes, N);
+    COCOS_REQUIRE((reinterpret_cast<uintptr_t>(da_partials_f64) & 7u) == 0, COCOS_ERR_INVALID, "instnorm_prelu_bwd_f64: workspace must be 8-byte aligned");
+    hipStream_t s = as_stream(stream);
+    const bool reg = N <= 256 * 4 * INP_VPT &&
+                     (N % 4 != 0 || (aligned16(x) && aligned16(dy) && (!residual || aligned16(residual)) && (!dx || aligned16(dx)) &&
+                                     (!dresidual || aligned16(dresidual))));
+    void* dap = da_partials_f64;
+    if (reg && N <= 256 * 4 * 4) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true, 4, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps);
+    else if (reg) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true, INP_VPT, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps);
+    else     hipLaunchKernelGGL((instnorm_prelu_kernel<true, false, INP_VPT, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps);
+    COCOS_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(sum_f64_to_f32_kernel, dim3(1), dim3(256), 0, s, da_partials_f64, planes, da_out);
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
 }

@@ -909,7 +909,7 @@ _KNOWN_AMAX_MAX = 8      # entries per thread
 _AMAX_WEAK_BYTES = 32 << 20
 
 
-def _remember_amax(t: torch.Tensor, cell: torch.Tensor):
+def _remember_amax(t: torch.Tensor, cell: torch.Tensor, weak: bool = False):
     """A producer kernel computed max|t| while writing t: keep it for the consumer (autograd hands the gradient on
     as a view of the same storage; producer and consumer of one device's backward run in the same thread).  Small
     tensors are held by the entry itself, so their address cannot be recycled for other data while the entry exists;
@@ -921,7 +921,9 @@ def _remember_amax(t: torch.Tensor, cell: torch.Tensor):
     table = _tls.known_amax
     while len(table) >= _KNOWN_AMAX_MAX:
         table.pop(next(iter(table)), None)
-    big = t.numel() * t.element_size() >= _AMAX_WEAK_BYTES
+    # (weak = True: the entry must not keep `t` alive whatever its size — a convolution's INPUT remembered for a sibling convolution
+    #  (ADVICE r5): a strong reference kept up to four dead activations alive across steps)
+    big = weak or t.numel() * t.element_size() >= _AMAX_WEAK_BYTES
     table[(t.device, t.untyped_storage().data_ptr())] = (weakref.ref(t) if big else t, t._version, cell)
 
 
@@ -1822,7 +1824,7 @@ class _Conv2d(torch.autograd.Function):
             xa = _recall_amax(x, consume=False)      # (not consumed: SPADE's gamma and beta convolutions read the SAME activation)
             if xa is None:
                 xa = absmax(x)
-                _remember_amax(x, xa)                # ... and the second one finds what the first one measured
+                _remember_amax(x, xa, weak=True)     # ... and the second one finds what the first one measured
             wa = _recall_amax(weight)          # K21 leaves it for spectral-normed layers
             if wa is None:
                 wa = absmax(weight)
@@ -2612,11 +2614,17 @@ class _InstNormPReLU(torch.autograd.Function):
         need_x, need_r, need_w = ctx.needs_input_grad[:3]
         dx = torch.empty_like(x) if need_x else None
         dr = torch.empty_like(x) if (need_r and res is not None) else None
-        dap = torch.empty(B * C, device=x.device, dtype=torch.float32) if need_w else None
+        if need_w:
+            # the weight's gradient is ONE number summed over every element of the layer, with cancelling terms: fp64 from the
+            # products to the last addition (cocos_instnorm_prelu_bwd_f64; in fp32 it was up to 90x further from fp64 than the framework's)
+            dap = torch.empty(B * C, device=x.device, dtype=torch.float64)
+            dw = torch.empty(1, device=x.device, dtype=torch.float32)
+            _call("instnorm_prelu_bwd", "cocos_instnorm_prelu_bwd_f64", x.data_ptr(), _ptr(res), w.data_ptr(), dy.data_ptr(),
+                  _ptr(dx), _ptr(dr), dap.data_ptr(), dw.data_ptr(), B * C, N, ctx.eps, _stream())
+            return dx, dr, dw.reshape(w.shape), None
         _call("instnorm_prelu_bwd", "cocos_instnorm_prelu_bwd", x.data_ptr(), _ptr(res), w.data_ptr(), dy.data_ptr(),
-              _ptr(dx), _ptr(dr), _ptr(dap), B * C, N, ctx.eps, _stream())
-        dw = channel_sum(dap.reshape(1, 1, -1)).reshape(w.shape) if need_w else None   # one workgroup sums the B*C partials
-        return dx, dr, dw, None
+              _ptr(dx), _ptr(dr), None, B * C, N, ctx.eps, _stream())
+        return dx, dr, None, None
 
 
 def instnorm_prelu(x, residual, weight, eps: float = INSTNORM_EPS):

@@ -21,7 +21,6 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
-from . import _kinks
 
 
 _HIP_BACKENDS = ("f16x3", "bf16")
@@ -227,12 +226,15 @@ class Attention(nn.Module):
         self.o = wrap(Conv2d(ch // 2, ch, 1, bias=False))
         self.gamma = nn.Parameter(torch.tensor(0.0), requires_grad=True)
 
+    @staticmethod
+    def _pool(t):
+        return F.max_pool2d(t, [2, 2])
+
     def forward(self, x, y=None):
         B, _, H, W = x.shape
         theta = self.theta(x).view(B, self.ch // 8, H * W)
-        pool = (lambda t: F.max_pool2d(t, [2, 2])) if _kinks.TAPE is None else _kinks.TAPE.pool2    # (tests: recorded argmax)
-        phi = pool(self.phi(x)).view(B, self.ch // 8, H * W // 4)
-        g = pool(self.g(x)).view(B, self.ch // 2, H * W // 4)
+        phi = self._pool(self.phi(x)).view(B, self.ch // 8, H * W // 4)
+        g = self._pool(self.g(x)).view(B, self.ch // 2, H * W // 4)
         if x.is_cuda and x.dtype == torch.float32:
             from . import ops            # QK^T -> softmax -> PV on the HIP kernels of the path (§8f rank 3)
             att = ops.softmax_attention(theta.contiguous(), phi.contiguous(), g.contiguous(), 1.0)
@@ -280,8 +282,6 @@ class SPADEResnetBlock(nn.Module):
             self.se_layar = SELayer(fout)   # (sic) the reference's attribute name, kept for checkpoints
 
     def _norm_act(self, norm, x, seg):
-        if _kinks.TAPE is not None and self.slope != 1.0:          # tests only: the fused kernel at slope 1, the recorded branches on top
-            return _kinks.TAPE.act(norm(x, seg, slope=1.0), self.slope)
         return norm(x, seg, slope=self.slope)
 
     def forward(self, x, seg):
@@ -365,8 +365,6 @@ class AdaptiveFeatureGenerator(nn.Module):
         """`layer` = conv [+ InstanceNorm2d] (nonspade_norm_layer), followed by LeakyReLU(slope) (slope 1.0: none).  The parameter-free
         InstanceNorm and the activation are K13 — one HBM pass forward, one backward — instead of the framework's batch-norm
         kernels + leaky_relu (generator.py:133-138 calls them as `layerK(self.actvn(x))`: same values, other grouping)."""
-        if _kinks.TAPE is not None and slope != 1.0:               # tests only (see _kinks.py)
-            return _kinks.TAPE.act(self._conv_norm_act(layer, x, 1.0), slope)
         if (isinstance(layer, nn.Sequential) and len(layer) == 2 and type(layer[1]) is nn.InstanceNorm2d and not layer[1].affine
                 and not layer[1].track_running_stats and x.is_cuda and x.dtype == torch.float32 and conv_backend() in _HIP_BACKENDS):
             from . import ops
@@ -415,18 +413,10 @@ class ResidualBlock(nn.Module):
         self.bn2 = nn.InstanceNorm2d(out_channels)
 
     def forward(self, x):
-        tape = _kinks.TAPE
         if x.is_cuda and x.dtype == torch.float32:
             from . import ops            # K13: InstanceNorm (+ skip) + PReLU in one HBM pass each
-            if tape is not None:         # tests only: K13 with a = 1 (its linear part), the recorded branches on top
-                one = torch.ones_like(self.prelu.weight)
-                y = tape.act(ops.instnorm_prelu(reflect_conv(self.padding1, self.conv1, x), None, one, self.bn1.eps), self.prelu.weight)
-                return tape.act(ops.instnorm_prelu(reflect_conv(self.padding2, self.conv2, y), x, one, self.bn2.eps), self.prelu.weight)
             y = ops.instnorm_prelu(reflect_conv(self.padding1, self.conv1, x), None, self.prelu.weight, self.bn1.eps)
             return ops.instnorm_prelu(reflect_conv(self.padding2, self.conv2, y), x, self.prelu.weight, self.bn2.eps)
-        if tape is not None:
-            y = tape.act(self.bn1(self.conv1(self.padding1(x))), self.prelu.weight)
-            return tape.act(self.bn2(self.conv2(self.padding2(y))) + x, self.prelu.weight)
         y = self.prelu(self.bn1(self.conv1(self.padding1(x))))
         y = self.bn2(self.conv2(self.padding2(y)))
         return self.prelu(y + x)

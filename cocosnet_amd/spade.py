@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from . import _kinks, ops
+from . import ops
 
 LEAKY_SLOPE = 2e-1      # SPADEResnetBlock.actvn (architecture.py:107-108)
 
@@ -43,18 +43,18 @@ def modulate(x, gamma, beta, pono: bool, param_free_norm=None, slope: float = 1.
     return y if slope == 1.0 else F.leaky_relu(y, slope)
 
 
+def shared_activation(self, segmap):
+    """`self.mlp_shared(segmap)` (normalization.py:139): conv + ReLU of the label map.  Its own function so that a caller can put
+    another evaluation of the same piecewise-linear map in its place."""
+    return self.mlp_shared(segmap)
+
+
 def spade_forward(self, x, segmap, similarity_map=None, slope: float = 1.0):
     """Drop-in for `SPADE.forward(x, segmap, similarity_map=None)` (normalization.py:129-151); works on the reference's
     module instances (attributes param_free_norm, mlp_shared, pad, mlp_gamma, mlp_beta, pad_type).  `slope`: negative
     slope of the LeakyReLU the caller would apply next (1.0 = none)."""
     segmap = F.interpolate(segmap, size=x.size()[2:], mode="nearest")
-    if _kinks.TAPE is not None and isinstance(self.mlp_shared, torch.nn.Sequential) and isinstance(self.mlp_shared[-1], torch.nn.ReLU):
-        actv = segmap                        # tests only (see _kinks.py): the ReLU's recorded branches
-        for m in list(self.mlp_shared)[:-1]:
-            actv = m(actv)
-        actv = _kinks.TAPE.act(actv, 0.0)
-    else:
-        actv = self.mlp_shared(segmap)
+    actv = shared_activation(self, segmap)
     if getattr(self, "pad_type", "nozero") != "zero":
         actv = self.pad(actv)
     gamma, beta = self.mlp_gamma(actv), self.mlp_beta(actv)

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _kinks, ops
+from . import ops
 from .correspondence import NetworkBase
 from .producers import Attention, Conv2d, SPADEResnetBlock, hip_spectral_norm, nonspade_norm_layer
 
@@ -58,6 +58,10 @@ class SPADEGenerator(NetworkBase):
         self.conv_img = Conv2d(nf, 3, 3, padding=1)
         self.up = nn.Upsample(scale_factor=2)               # parameter-free; kept because the reference has it
 
+    @staticmethod
+    def _final_act(x):
+        return F.leaky_relu(x, 2e-1)          # generator.py:99
+
     def forward(self, input, warp_out=None):
         seg = input if warp_out is None else warp_out
         x = self.fc(F.interpolate(seg, size=(self.sh, self.sw)))
@@ -71,8 +75,7 @@ class SPADEGenerator(NetworkBase):
             x = self.attn(x)
         x = self.up_2(x, seg)
         x = self.up_3(_up2(x), seg)
-        x = F.leaky_relu(x, 2e-1) if _kinks.TAPE is None else _kinks.TAPE.act(x, 2e-1)
-        return torch.tanh(self.conv_img(x))
+        return torch.tanh(self.conv_img(self._final_act(x)))
 
 
 class _ConvNormAct(nn.Sequential):
@@ -82,21 +85,16 @@ class _ConvNormAct(nn.Sequential):
 
     def forward(self, x):
         first = self[0]
-        tape = _kinks.TAPE if len(self) == 2 and isinstance(self[1], nn.LeakyReLU) else None      # tests only (see _kinks.py)
         if (isinstance(first, nn.Sequential) and len(first) == 2 and type(first[1]) is nn.InstanceNorm2d and not first[1].affine
                 and x.is_cuda and x.dtype == torch.float32 and ops.CONV_PRECISION != "torch" and len(self) == 2):
             y = first[0](x)
             if y.shape[2] * y.shape[3] <= 16384:
-                if tape is not None:         # K13 at slope 1 (its linear part), the recorded branches on top
-                    return tape.act(ops.instnorm_prelu(y, None, torch.ones(1, device=y.device), first[1].eps), self[1].negative_slope)
                 slope = getattr(self, "_slope", None)
                 if slope is None or slope.device != y.device:
                     slope = self._slope = torch.full((1,), float(self[1].negative_slope), device=y.device)
                 return ops.instnorm_prelu(y, None, slope, first[1].eps)
             y = first[1](y)
-            return self[1](y) if tape is None else tape.act(y, self[1].negative_slope)
-        if tape is not None:
-            return tape.act(first(x), self[1].negative_slope)
+            return self[1](y)
         return super().forward(x)
 
 

@@ -813,6 +813,11 @@ int cocos_instnorm_prelu_fwd(const float* x, const float* residual, const float*
 int cocos_instnorm_prelu_bwd(const float* x, const float* residual, const float* prelu_weight, const float* dy,
                              float* dx, float* dresidual, float* da_partials, int planes, int N, float eps,
                              cocos_stream_t stream);
+/* The same with the PReLU weight's gradient accumulated in fp64 from the products to the last addition (round 6: da is one number
+ * summed over every element of the layer with cancelling terms): da_partials_f64 = workspace of `planes` doubles, *da_out = the sum. */
+int cocos_instnorm_prelu_bwd_f64(const float* x, const float* residual, const float* prelu_weight, const float* dy, float* dx,
+                                 float* dresidual, double* da_partials_f64, float* da_out, int planes, int N, float eps,
+                                 cocos_stream_t stream);
 
 /* Debug: runs one v_mfma_f32_32x32x2_f32 with known operands and dumps the 64x16 accumulator
  * registers to out[64*16] so the host can verify the lane/register -> (row, col) map. */

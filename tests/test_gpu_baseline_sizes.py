@@ -561,8 +561,9 @@ def test_contextual_loss_forward_matches_the_reference_formula(B, C, h, w, pono)
         loss.sum().backward()
     finally:
         contextual.ROUTE = "auto"
+    from oracle import contextual_ref as cr         # the arbiter: oracle/contextual_ref.py (ContextualLoss.py:93-137 in fp64), not the product
     xr, yr = X.double().cpu().requires_grad_(True), Y.double().cpu().requires_grad_(True)
-    lr = mod(xr, yr, h=0.1)               # CPU tensors: the reference's formulation (torch), here in fp64
+    lr = cr.contextual_loss(xr, yr, h=0.1, pono=pono)
     lr.sum().backward()
     errs = (rel(loss, lr.detach().numpy()), rel(xa.grad, xr.grad.numpy()), rel(ya.grad, yr.grad.numpy()))
     print("CTX_FP64", (B, C, h, w, pono), errs)
@@ -630,8 +631,9 @@ def test_contextual_loss_at_4096_positions_and_512_channels(monkeypatch):
     X, Y = _ctx_case(B, C, N, 77)
     X, Y = X.reshape(B, C, 64, 64), Y.reshape(B, C, 64, 64)
     mod = ContextualLoss_forward(SimpleNamespace(PONO=True))
+    from oracle import contextual_ref as cr
     xr, yr = X.double().requires_grad_(True), Y.double().requires_grad_(True)
-    lr = mod(xr, yr, h=0.1)                   # fp64 tensors: the reference's formulation in torch, on the device
+    lr = cr.contextual_loss(xr, yr, h=0.1, pono=True)      # oracle/contextual_ref.py in fp64, on the device (the checker, not the product)
     lr.sum().backward()
     want = (lr.detach().cpu().numpy(), xr.grad.cpu().numpy(), yr.grad.cpu().numpy())
     del xr, yr, lr
@@ -663,10 +665,9 @@ def test_contextual_cx_rectangular_and_other_bandwidths(B, C, Nq, Nk, h):
     nrm = lambda t: t / (t.norm(dim=1, keepdim=True) + 2.2e-16)
     Xn, Yn = nrm(torch.randn(B, C, Nq, device=DEV, generator=g)), nrm(torch.randn(B, C, Nk, device=DEV, generator=g))
     G = torch.randn(B, Nq, device=DEV, generator=g)
+    from oracle import contextual_ref as cr
     xr, yr = Xn.double().requires_grad_(True), Yn.double().requires_grad_(True)
-    d = 1 - torch.matmul(xr.transpose(1, 2), yr)
-    w_ = torch.exp((1 - d / (d.min(-1, keepdim=True)[0] + 1e-3)) / h)
-    cx_ref = (w_ / w_.sum(-1, keepdim=True)).max(-1)[0]
+    cx_ref = cr.cx_rows(xr, yr, h, 1e-3)
     (cx_ref * G.double()).sum().backward()
     xa, ya = Xn.clone().requires_grad_(True), Yn.clone().requires_grad_(True)
     cx = ops.contextual_cx(xa, ya, h, 1e-3)
@@ -686,13 +687,12 @@ def test_contextual_cx_with_256_row_workgroups():
     G = torch.randn(B, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
     want = []
     for b in range(0, B, 4):        # (four samples at a time: [4, N, N] fp64 matrices)
+        from oracle import contextual_ref as cr
         xr = Xn[b:b + 4].double().requires_grad_(True)
-        d = 1 - torch.matmul(xr.transpose(1, 2), Yn[b:b + 4].double())
-        w_ = torch.exp((1 - d / (d.min(-1, keepdim=True)[0] + 1e-3)) / 0.1)
-        cx_ref = (w_ / w_.sum(-1, keepdim=True)).max(-1)[0]
+        cx_ref = cr.cx_rows(xr, Yn[b:b + 4].double(), 0.1, 1e-3)
         (cx_ref * G[b:b + 4].double()).sum().backward()
         want.append((cx_ref.detach().cpu().numpy(), xr.grad.cpu().numpy()))
-        del d, w_, cx_ref
+        del cx_ref
     xa = Xn.clone().requires_grad_(True)
     cx = ops.contextual_cx(xa, Yn, 0.1, 1e-3)
     (cx * G).sum().backward()
@@ -709,15 +709,13 @@ def test_contextual_cx_beyond_the_old_4096_key_cap():
     X, Y = _ctx_case(B, C, N, 5)
     nrm = lambda t: t / (t.norm(dim=1, keepdim=True) + 2.2e-16)
     Xn, Yn = nrm(X - Y.mean(1, keepdim=True)), nrm(Y - Y.mean(1, keepdim=True))
+    from oracle import contextual_ref as cr
     xr = Xn.double().requires_grad_(True)
-    d = 1 - torch.matmul(xr.transpose(1, 2), Yn.double())
-    dn = d / (d.min(-1, keepdim=True)[0] + 1e-3)
-    w_ = torch.exp((1 - dn) / 0.1)
-    cx_ref = (w_ / w_.sum(-1, keepdim=True)).max(-1)[0]
+    cx_ref = cr.cx_rows(xr, Yn.double(), 0.1, 1e-3)
     G = torch.randn(B, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
     (cx_ref * G.double()).sum().backward()
     want = (cx_ref.detach().cpu().numpy(), xr.grad.cpu().numpy())
-    del d, dn, w_, cx_ref
+    del cx_ref
     torch.cuda.empty_cache()
     xa = Xn.clone().requires_grad_(True)
     torch.cuda.synchronize()

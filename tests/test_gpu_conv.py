@@ -167,17 +167,18 @@ def test_patchgan_stack_on_hip_convs_matches_the_framework():
         assert (a - r).abs().max().item() <= 2e-4 * max(r.abs().max().item(), 1e-6), (a.shape, (a - r).abs().max().item())
 
 
-def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False, forced=False):     # smooth_adaptors: ALL kinks
+def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False, forced=False, seed=2):     # smooth_adaptors: ALL kinks
     """The whole drop-in module — adaptors with SPADE blocks, feature_normalize, four ResidualBlocks, theta / phi, AND the hot
     path behind them — in one graph: ours (every convolution / norm / correlation kernel on HIP, `arm` = f16x3 | bf16 | torch)
     against a torch-FP64 copy of the same module (same parameters and buffers; framework ops in double up to theta / phi, the
     oracle's restatement of correspondence.py:272-372 in double from there on).  Returns {arm: {name: relative error}} for
     features, outputs and parameter gradients of loss = sum_k <out_k, G_k>.
-    forced: the fp64 copy RECORDS the branch of every LeakyReLU / PReLU / ReLU / max-pool element (cocosnet_amd/_kinks.py) and the
+    forced: the fp64 copy RECORDS the branch of every LeakyReLU / PReLU / ReLU / max-pool element (tests/kink_tape.py) and the
     fp32 arms are evaluated ON THAT PATTERN (their kernels run with the slope at 1, the recorded pattern is the multiplier);
     errs[arm]["#flips"] = [elements whose own branch differed, elements]."""
+    import contextlib
     import copy
-    from cocosnet_amd import _kinks
+    import kink_tape
     from cocosnet_amd import correspondence as cc
     from cocosnet_amd import ops
     from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
@@ -197,7 +198,7 @@ def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False, forced=
                 m.slope = 1.0
             elif isinstance(m, producers.SPADE):
                 m.mlp_shared[2] = torch.nn.Identity()
-    g = torch.Generator(device="cuda").manual_seed(2)
+    g = torch.Generator(device="cuda").manual_seed(seed)
     nc = flags["semantic_nc"]
     img = torch.rand(B, 3, size, size, device="cuda", generator=g) * 2 - 1
     real = torch.rand(B, 3, size, size, device="cuda", generator=g) * 2 - 1
@@ -217,8 +218,9 @@ def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False, forced=
     # ---- the fp64 arbiter -------------------------------------------------------------------------------------------------
     net64 = copy.deepcopy(net).double()
     d = lambda t: t.double()
-    tape = _kinks.KinkTape() if forced else None
-    monkeypatch.setattr(_kinks, "TAPE", tape)
+    tape = kink_tape.KinkTape() if forced else None
+    stack = contextlib.ExitStack()
+    stack.enter_context(kink_tape.install(tape))       # (None: the product's own forward everywhere)
     th64, ph64 = net64.project(d(img), d(real), d(seg), d(ref_seg))
     out64 = tr.hot_path(th64, ph64, d(img), d(real), d(seg), d(ref_seg), cfg)
     keys = sorted(out64)
@@ -248,7 +250,7 @@ def _module_e2e(monkeypatch, flags, size=64, B=2, smooth_adaptors=False, forced=
     try:
         return {b: arm(b) for b in ("f16x3", "torch", "bf16")}
     finally:
-        _kinks.TAPE = None
+        stack.close()
 
 
 E2E_FLAGS = {
@@ -285,8 +287,11 @@ def test_module_end_to_end_against_an_fp64_copy_of_itself(name, monkeypatch):
     print("E2E_FP64", name, json.dumps(errs))
     bad = {k: v for k, v in errs["f16x3"].items() if not _is_kinked(k) and not v < 1e-3}
     assert not bad, (bad, {k: errs["torch"][k] for k in bad})
-    # (a SANITY bound only — one flipped element moved a probe by 6.3e-2 this round; the measured comparison is the twin test)
-    assert all(v < 0.25 for k, v in errs["f16x3"].items() if _is_kinked(k)), errs["f16x3"]
+    # the kinked probes are only required to be finite here: a magnitude bound cannot tell one unlucky element (6.3e-2 in round 5)
+    # from a kernel that flips systematically more — that is asserted on the flip COUNTS per arm
+    # (test_flip_counts_of_the_split_arm_stay_within_the_framework_arms) and on the fp64 branch pattern (the twin test below)
+    import math
+    assert all(math.isfinite(v) for k, v in errs["f16x3"].items() if _is_kinked(k)), errs["f16x3"]
     # the one-term flavour is not held to 1e-3 (it is not parity-qualified: DESIGN.md §3.6); it must be finite and sane
     assert all(v < 0.6 for v in errs["bf16"].values()), errs["bf16"]
 
@@ -295,7 +300,7 @@ def test_module_end_to_end_against_an_fp64_copy_of_itself(name, monkeypatch):
 def test_module_end_to_end_every_gradient_on_the_fp64_branch_pattern(name, monkeypatch):
     """the kink probes MEASURED instead of bounded at 0.1.  The fp64 copy records which branch every
     LeakyReLU / PReLU / ReLU element (and every 2x2 max-pool window) takes; the fp32 arms run their production kernels with the
-    activation's slope at 1 and apply the recorded pattern (cocosnet_amd/_kinks.py), so that the comparison is between two evaluations
+    activation's slope at 1 and apply the recorded pattern (tests/kink_tape.py), so that the comparison is between two evaluations
     of the SAME piecewise-linear function.  On that footing EVERY probed gradient of the default flavour is within north_star's 1e-3
     — the adaptors' strided layers included, and celebaedge_mk1's layer1.0 (4.5e-3 on this arm, 9e-6 on the framework arm in round 4:
     ONE element of the f16x3 arm's own flips, see the printed counts).  The counts say how many elements each fp32 arm would have
@@ -305,6 +310,20 @@ def test_module_end_to_end_every_gradient_on_the_fp64_branch_pattern(name, monke
     print("E2E_FP64_FORCED", name, json.dumps(errs))
     bad = {k: v for k, v in errs["f16x3"].items() if k != "#flips" and not v < 1e-3}
     assert not bad, (bad, {k: errs["torch"][k] for k in bad}, errs["f16x3"]["#flips"])
+
+
+def test_flip_counts_of_the_split_arm_stay_within_the_framework_arms(monkeypatch):
+    """over three input seeds, the number of piecewise-linear elements that the f16x3 arm puts on the other branch
+    than fp64 must stay within what fp32 arithmetic itself does — f16x3 flips <= 2 x framework-fp32 flips + 4 per seed (1-3 of 9.1 M
+    on both arms when this was written).  A kernel that flipped systematically more would pass any magnitude bound on the probes;
+    it cannot pass this."""
+    import json
+    for seed in (2, 11, 23):
+        errs = _module_e2e(monkeypatch, E2E_FLAGS["ade20k_mk1"], forced=True, seed=seed)
+        ours, elements = errs["f16x3"]["#flips"]
+        theirs, _ = errs["torch"]["#flips"]
+        print("E2E_FLIPS", seed, json.dumps({"f16x3": ours, "torch": theirs, "bf16": errs["bf16"]["#flips"][0], "elements": elements}))
+        assert ours <= 2 * theirs + 4, (seed, ours, theirs, elements)
 
 
 def test_module_end_to_end_against_fp64_every_gradient_without_the_adaptor_kinks(monkeypatch):
@@ -594,9 +613,10 @@ def _config3_vs_fp64(monkeypatch, forced, arms=("f16x3", "torch", "bf16")):
     at 256x256: forward AND parameter gradients of both networks against fp64 copies of the same modules evaluated by the framework.
     Arms: f16x3 (default: every convolution / SPADE / InstanceNorm / attention kernel on HIP), torch (the framework's fp32
     convolutions under the same norms — the yardstick of what fp32 arithmetic itself loses), bf16 (reported).  forced: every arm on
-    the fp64 copy's branch pattern (cocosnet_amd/_kinks.py); errs[arm]["#flips"] = [own branches that differed, elements]."""
+    the fp64 copy's branch pattern (tests/kink_tape.py); errs[arm]["#flips"] = [own branches that differed, elements]."""
     import copy
-    from cocosnet_amd import _kinks, ops, translation as tl
+    import kink_tape
+    from cocosnet_amd import ops, translation as tl
     opt = tl.celebahq_edge_train_options()
     torch.manual_seed(0)
     G = tl.SPADEGenerator(opt).cuda(); G.init_weights(opt.init_type, opt.init_variance); G.eval()
@@ -624,9 +644,8 @@ def _config3_vs_fp64(monkeypatch, forced, arms=("f16x3", "torch", "bf16")):
         out.update({"d G." + k: f(Gm).grad.clone() for k, f in gprobes.items()})
         out.update({"d D." + k: f(Dm).grad.clone() for k, f in dprobes.items()})
         return out
-    tape = _kinks.KinkTape() if forced else None
-    monkeypatch.setattr(_kinks, "TAPE", tape)
-    try:
+    tape = kink_tape.KinkTape() if forced else None
+    with kink_tape.install(tape):
         want = run(copy.deepcopy(G).double(), copy.deepcopy(D).double(), torch.float64)
         errs = {}
         for flavour in arms:
@@ -638,8 +657,6 @@ def _config3_vs_fp64(monkeypatch, forced, arms=("f16x3", "torch", "bf16")):
             if tape is not None:
                 assert tape.pos == len(tape.masks), (tape.pos, len(tape.masks))
                 errs[flavour]["#flips"] = [sum(tape.flips), tape.elements]
-    finally:
-        _kinks.TAPE = None
     return errs
 
 

@@ -177,6 +177,22 @@ def test_contextual_class_matches_the_reference_fixture_on_cpu(name):
     assert np.abs(x.grad.numpy() - f["dX"]).max() <= 2e-5 * np.abs(f["dX"]).max()
 
 
+@pytest.mark.parametrize("name", CTX_GOLDEN)
+def test_contextual_oracle_is_pinned_to_the_reference_fixtures(name):
+    """oracle/contextual_ref.py (the fp64 arbiter of the at-size GPU tests of K22) against the reference-generated fixtures: the
+    per-sample loss and d loss / d X — in fp64 on the fixtures' fp32 inputs, so the tolerance is the FIXTURES' own fp32 rounding."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import contextual_ref as cr
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    x = torch.from_numpy(f["X"]).double().requires_grad_(True)
+    loss = cr.contextual_loss(x, torch.from_numpy(f["Y"]).double(), h=float(f["h"]), pono=bool(f["pono"]))
+    loss.sum().backward()
+    assert np.allclose(loss.detach().numpy(), f["loss"], rtol=2e-5, atol=1e-6)
+    assert np.abs(x.grad.numpy() - f["dX"]).max() <= 2e-5 * np.abs(f["dX"]).max()
+
+
 def test_contextual_fixtures_regenerate_from_the_reference():
     """With /root/reference present (build container): running the reference again reproduces the committed fixtures bit for bit."""
     import os

@@ -5,7 +5,7 @@ Measured WITHOUT writing the kernels first: the candidate arithmetic is EMULATED
 the operands the way the candidate kernel's operand preparation would (per-tensor power-of-two scale, max|x| -> [2^9, 2^10), round to
 nearest) — forward, input gradient and weight gradient alike (a custom autograd Function around F.conv2d / torch.nn.grad).  fp32
 accumulation of exact products of rounded operands is what the MFMA does, so the emulation's error is the candidate's error up to
-the accumulation order.  All arms are evaluated on the fp64 copy's branch pattern (cocosnet_amd/_kinks.py), so that the figures
+the accumulation order.  All arms are evaluated on the fp64 copy's branch pattern (tests/kink_tape.py), so that the figures
 are rounding, not LeakyReLU flips.  The real kernels' arms (f16x3, bf16) run beside the emulated ones as the calibration.
 
     arms:   f16x3 (real)   bf16 (real)   emu:bf16 (calibration of the emulation against the real bf16 arm)
@@ -24,7 +24,9 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, ".")
-from cocosnet_amd import _kinks, ops, producers, translation as tl  # noqa: E402
+sys.path.insert(0, "tests")
+import kink_tape  # noqa: E402  (test infrastructure: tests/kink_tape.py)
+from cocosnet_amd import ops, producers, translation as tl  # noqa: E402
 
 
 def _scale(x):
@@ -117,8 +119,9 @@ def main():
                 out["dD " + n] = p.grad.clone()
         return out
 
-    tape = _kinks.KinkTape()
-    _kinks.TAPE = tape
+    tape = kink_tape.KinkTape()
+    tape_ctx = kink_tape.install(tape)
+    tape_ctx.__enter__()
     want = run(copy.deepcopy(G).double(), copy.deepcopy(D).double(), torch.float64)
     table = {}
 
@@ -150,7 +153,7 @@ def main():
     arm("bf16 (real)", "bf16")
     for fl in FLAVOURS:
         arm(fl + " G+D", "f16x3", fl, "GD")
-    _kinks.TAPE = None
+    tape_ctx.__exit__(None, None, None)
     ops.CONV_PRECISION = "f16x3"
     if len(sys.argv) > 1:
         json.dump(table, open(sys.argv[1], "w"), indent=1)
