@@ -440,7 +440,7 @@ SPLIT_TAGS = ("corr_softmax_warp_fwd", "corr_softmax_warp_bwd_query", "corr_soft
 #: parameter counts of BASELINE config 4's exchange: theta/phi only (what the hot path owns),
 #: netCorr (59 M), netG + netCorr (156 M)
 PAYLOAD_PARAMS = {"path": 0, "netcorr": 59_000_000, "full": 156_000_000}
-PMC_FILE = {"f16x3": next((f for f in ("r05_pmc_f16x3.json", "r04_pmc_f16x3.json", "r03_pmc_f16x3.json", "r02_pmc_f16x3.json")
+PMC_FILE = {"f16x3": next((f for f in ("r06_pmc_f16x3.json", "r05_pmc_f16x3.json", "r04_pmc_f16x3.json", "r03_pmc_f16x3.json", "r02_pmc_f16x3.json")
                            if os.path.exists(os.path.join(REPO, "profiles", f))), "r02_pmc_f16x3.json"),
             "fp32": "r01_pmc_final.json"}
 # (the counters were taken on the general instantiations <..., 0>; the one that skips exact value blocks moves 8 MB less)

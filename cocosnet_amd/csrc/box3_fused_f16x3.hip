@@ -169,7 +169,11 @@ __device__ __forceinline__ void box3_sw_fwd_body(
     _Float16* const vt = reinterpret_cast<_Float16*>(bx_smem);      // [2 buf][hi|lo|hi*2^-11][CVP][VROW]
     float* const kstat = reinterpret_cast<float*>(vt + 2 * 3 * VPLANE);   // [b | kn][Nk]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform BY CONSTRUCTION for the compiler too (round 6): derived from threadIdx it lived in a VGPR, every T / G block offset
+    // that depends on it (qblk, py, blk) was VGPR arithmetic, and every block load / store sat in a waterfall loop (readfirstlane /
+    // compare / saveexec / branch: 12 loops per tile in K19, 56 in K20)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     const int nqb = Nq / 128;
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
@@ -205,23 +209,30 @@ __device__ __forceinline__ void box3_sw_fwd_body(
     float m_run = -INFINITY, l_run = 0.f;
 
     u32x2 vst[2][CVB];
+    // staging addresses: the tile-invariant part per lane once (round 6: `row >= Cv || j0 + 4 kq >= Nk` inside the loop compiled to two
+    // EXEC-masked regions per piece — 20 s_and_saveexec / 30 s_or per tile), the tile as the buffer instruction's scalar offset.
+    // Nk % 32 == 0 (whole tiles): a look-ahead tile past the end is the last tile again instead of an out-of-range test per lane.
+    unsigned v_voff[CVB];
+    int v_lds[CVB];
+#pragma unroll
+    for (int u = 0; u < CVB; ++u) {
+        const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
+        v_voff[u] = row < Cv ? (unsigned)(row * Nk + 4 * kq) * 2u : kBufOob;
+        v_lds[u] = row * BX_VROW + 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);   // permuted k-slots: see corr_fused_fwd_f16x3.hip
+    }
     auto fetch_v_piece = [&](int i, int j0) {          // plane i & 1, chunk i >> 1 (= value block)
         const int pl = i & 1, u = i >> 1;
         if (VLO0 && pl == 1 && u >= 1) return;
-        const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
-        unsigned off = (unsigned)(row * Nk + j0 + 4 * kq) * 2u;
-        if (row >= Cv || j0 + 4 * kq >= Nk) off = kBufOob;
-        vst[pl][u] = __builtin_amdgcn_raw_buffer_load_b64(pl ? vl_rs : vh_rs, (int)off, 0, 0);
+        const int jc = min(j0, Nk - 32);
+        vst[pl][u] = __builtin_amdgcn_raw_buffer_load_b64(pl ? vl_rs : vh_rs, (int)v_voff[u], (int)((unsigned)jc * 2u), 0);
     };
     auto commit_v_piece = [&](int i, int buf) {
         const int pl = i & 1, u = i >> 1;
         if (VLO0 && pl == 1 && u >= 1) return;
-        const int g = u * 256 + tid, row = g >> 3, kq = g & 7;
-        const int slot = 16 * (kq >> 2) + 8 * (kq & 1) + 4 * ((kq >> 1) & 1);   // see corr_fused_fwd_f16x3.hip
-        *reinterpret_cast<u32x2*>(vt + (buf * 3 + pl) * VPLANE + row * BX_VROW + slot) = vst[pl][u];
+        _Float16* const d = vt + buf * 3 * VPLANE + v_lds[u];
+        *reinterpret_cast<u32x2*>(d + pl * VPLANE) = vst[pl][u];
         if (pl == 0)
-            *reinterpret_cast<u32x2*>(vt + (buf * 3 + 2) * VPLANE + row * BX_VROW + slot) =
-                u32x2{pk_unshift_f16(vst[0][u].x), pk_unshift_f16(vst[0][u].y)};
+            *reinterpret_cast<u32x2*>(d + 2 * VPLANE) = u32x2{pk_unshift_f16(vst[0][u].x), pk_unshift_f16(vst[0][u].y)};
     };
 
     const int ntiles = Nk / 32;
@@ -404,7 +415,11 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     float* const colacc = reinterpret_cast<float*>(vt + 2 * 2 * VPLANE);   // [2 buf][4 waves][2 quantities][4 groups][64 lanes][4]
     float* const kstat = colacc + 2 * 4 * 2048;                            // [b | kn][Nk]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform BY CONSTRUCTION for the compiler too (round 6): derived from threadIdx it lived in a VGPR, every T / G block offset
+    // that depends on it (qblk, py, blk) was VGPR arithmetic, and every block load / store sat in a waterfall loop (readfirstlane /
+    // compare / saveexec / branch: 12 loops per tile in K19, 56 in K20)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     const int nqb = Nq / 128;
     const int vb = xcd_remap(blockIdx.x, gridDim.x);
@@ -476,17 +491,27 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
 
     constexpr int VCH = 32 * CVP / 8, VPT = (VCH + 255) / 256;
     u32x4 vst[2][VPT];
+    // staging addresses: per lane once, the tile in the scalar offset (see the forward); Nk % 32 == 0, look-ahead clamped to the last tile
+    unsigned v_voff[2][VPT];
+    int v_lds[VPT];
+    bool v_ok[VPT];
+#pragma unroll
+    for (int u = 0; u < VPT; ++u) {
+        const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
+        v_ok[u] = g < VCH;
+        v_voff[0][u] = v_ok[u] ? (unsigned)(key * CVP + cc * 8) * 2u : kBufOob;
+        // (VLO0: the lo plane of channels >= 32 is all zero and never read: not fetched — its LDS image stays whatever it was)
+        v_voff[1][u] = (v_ok[u] && !(VLO0 && cc >= 4)) ? v_voff[0][u] : kBufOob;
+        v_lds[u] = key * VROW + cc * 8;
+    }
     auto fetch_v_piece = [&](int i, int j0) {
         const int pl = i & 1, u = i >> 1;
-        const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
-        // (VLO0: the lo plane of channels >= 32 is all zero and never read: not fetched — its LDS image stays whatever it was)
-        vst[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(
-            pl ? vl_rs : vh_rs, (int)((g < VCH && !(VLO0 && pl == 1 && cc >= 4)) ? (unsigned)((j0 + key) * CVP + cc * 8) * 2u : kBufOob), 0, 0);
+        const int jc = min(j0, Nk - 32);
+        vst[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(pl ? vl_rs : vh_rs, (int)v_voff[pl][u], (int)((unsigned)(jc * CVP) * 2u), 0);
     };
     auto commit_v_piece = [&](int i, int buf) {
         const int pl = i & 1, u = i >> 1;
-        const int g = u * 256 + tid, key = g / (CVP / 8), cc = g % (CVP / 8);
-        if (g < VCH) *reinterpret_cast<u32x4*>(vt + (buf * 2 + pl) * VPLANE + key * VROW + cc * 8) = vst[pl][u];
+        if (v_ok[u]) *reinterpret_cast<u32x4*>(vt + (buf * 2 + pl) * VPLANE + v_lds[u]) = vst[pl][u];
     };
     // behind the barrier that ended tile t: register group `wave` of the four waves' images, summed -> column sums -> colpart
     float* const cp_b = colpart + ((size_t)b * nqb + wg) * 2 * Nk;
@@ -688,7 +713,11 @@ __global__ __launch_bounds__(256, 1) void box3_adjoint_planes_kernel(const float
                                                                      float* __restrict__ scale_out, int B, int Nq, int Nk,
                                                                      int himg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform BY CONSTRUCTION for the compiler too (round 6): derived from threadIdx it lived in a VGPR, every T / G block offset
+    // that depends on it (qblk, py, blk) was VGPR arithmetic, and every block load / store sat in a waterfall loop (readfirstlane /
+    // compare / saveexec / branch: 12 loops per tile in K19, 56 in K20)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     float* const img = reinterpret_cast<float*>(bx_smem) + wave * kXbFloats;
     xbox_zero_border(img, lane);
@@ -783,7 +812,11 @@ __global__ __launch_bounds__(256, 2) void box3_adjoint_planes_w128_kernel(const 
                                                                           float* __restrict__ scale_out, int B, int Nq, int Nk,
                                                                           int himg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char bx_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform BY CONSTRUCTION for the compiler too (round 6): derived from threadIdx it lived in a VGPR, every T / G block offset
+    // that depends on it (qblk, py, blk) was VGPR arithmetic, and every block load / store sat in a waterfall loop (readfirstlane /
+    // compare / saveexec / branch: 12 loops per tile in K19, 56 in K20)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     float* const img0 = reinterpret_cast<float*>(bx_smem);
     float* const img = img0 + wave * kXbFloats;
