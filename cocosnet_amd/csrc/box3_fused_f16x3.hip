@@ -55,7 +55,7 @@ struct BxTile {
 // Geometry of a wave's query block, fixed for the kernel.
 struct BxGeom {
     __amdgpu_buffer_rsrc_t t_rs;
-    int qblk, py, tpr, himg, nqblk;
+    int qblk, py, tpr, tpr_log2, himg, nqblk;
     unsigned lane_off;      // lane * 16
     const float* kstat;     // LDS: [b_q (nk floats) | kc * nu_q * b_q (nk floats)] of this sample's keys (x 2 buffers when chunked)
     int nk;                 // keys per LDS buffer: Nk, or BX_KCH when chunked
@@ -87,7 +87,7 @@ __device__ __forceinline__ void bx_transpose32(float (&x)[16], float* xt, int h,
 
 __device__ __forceinline__ void bx_fetch(BxTile& tl, const BxGeom& gm, int t, int ntiles) {
     const int tc = min(t, ntiles - 1);                  // look-ahead past the end re-reads the last tile
-    const int ky = tc / gm.tpr;
+    const int ky = tc >> gm.tpr_log2;                   // (tpr = 2 or 4: a runtime division per tile was ~20 scalar instructions)
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const int dy = d - 1;
@@ -191,8 +191,9 @@ __device__ __forceinline__ void box3_sw_fwd_body(
     gm.kstat = kstat;
     gm.nk = CHUNKED ? BX_KCH : Nk;
     gm.tpr = wimg / 32;
+    gm.tpr_log2 = gm.tpr == 4 ? 2 : 1;          // (64- or 128-wide grids: cocos_box3_fused_supported)
     gm.qblk = (q0 >> 5) + wave;
-    gm.py = gm.qblk / gm.tpr;
+    gm.py = gm.qblk >> gm.tpr_log2;
     gm.himg = himg;
     gm.nqblk = Nq >> 5;
     gm.lane_off = (unsigned)lane * 16u;
@@ -444,8 +445,9 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     gm.kstat = kstat;
     gm.nk = CHUNKED ? BX_KCH : Nk;
     gm.tpr = wimg / 32;
+    gm.tpr_log2 = gm.tpr == 4 ? 2 : 1;          // (64- or 128-wide grids: cocos_box3_fused_supported)
     gm.qblk = (q0 >> 5) + wave;
-    gm.py = gm.qblk / gm.tpr;
+    gm.py = gm.qblk >> gm.tpr_log2;
     gm.himg = himg;
     gm.nqblk = Nq >> 5;
     gm.lane_off = (unsigned)lane * 16u;
@@ -456,7 +458,6 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     const float a_p = a_q[(size_t)b * Nq + i_lane];
     const float a_n = a_p * scale;                     // natural-domain factor: z = tt * a_n
     const float a2 = a_n * kLog2e;
-    const float am = a_n * mu_p;
 
     const float s_o = *g_scale * (v_scale ? *v_scale : 1.0f);      // scale of dP' = V' . dO'
     f16x8 goh[CVS], gol[CVS];
@@ -486,8 +487,10 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
         const int hi = __shfl_xor((int)__double2hiint(dacc), 32, 64);
         d_lane = (float)((dacc + __hiloint2double(hi, lo)) * (double)s_o);
     }
-    const float lse2 = lse[(size_t)b * Nq + i_lane] * kLog2e;
     const float undo = 1.0f / s_o;
+    // (round 6: s_o is a power of two — the two operand scales are — so the 1 / s_o of L = P (dP' - D') / s_o rides in the exponent of
+    //  P instead of a multiply per element; only the flavour that also stores the planes of P keeps the plain P)
+    const float lse2 = lse[(size_t)b * Nq + i_lane] * kLog2e + (STORE_P ? 0.f : log2f(s_o));
 
     constexpr int VCH = 32 * CVP / 8, VPT = (VCH + 255) / 256;
     u32x4 vst[2][VPT];
@@ -588,13 +591,14 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
         f32x4 gout[4];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float L = p[r] * ((dp0[r] + dp1[r]) - d_lane) * undo;
-            const float z = tt[r] * a_n;
-            gv[r] = L * a_n * bq[r];
-            x1[r] = L * z;
-            x2[r] = L * am;
+            // La = L a_n (a_n = scale a_p > 0 folded once): G = La b_q, L z = La tt, L a_n mu_p = La mu_p, sum_q L kn_q = (sum_q La kn_q) / a_n
+            const float dd = (dp0[r] + dp1[r]) - d_lane;
+            const float La = (STORE_P ? p[r] * undo : p[r]) * dd * a_n;
+            gv[r] = La * bq[r];
+            x1[r] = La * tt[r];
+            x2[r] = La * mu_p;
             r2 += x1[r];
-            rm = __builtin_fmaf(L, kn[r], rm);
+            rm = __builtin_fmaf(La, kn[r], rm);
         }
         // G leaves in the layout of the STORED T: transposed back when T was read transposed, and added to what another pass
         // has already written (one G for all passes over this T: one box adjoint + one pair of GEMMs)
@@ -672,7 +676,7 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
     rm += swap_half(rm);
     if (h == 0) {
         da[(size_t)b * Nq + i_lane] = r2 / a_p;
-        dmu[(size_t)b * Nq + i_lane] = -a_n * rm;
+        dmu[(size_t)b * Nq + i_lane] = -rm;          // (rm carries the factor a_n already)
     }
     gabs = wave_max_dpp(gabs);
     if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(gmax), __builtin_bit_cast(unsigned, gabs));   // >= 0: ordered as integers
