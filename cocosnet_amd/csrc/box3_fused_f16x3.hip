@@ -557,9 +557,9 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
         for (int r = 0; r < 16; ++r) p[r] = (BX_ABLATE & 32) ? tt[r] * 1e-3f : fast_exp2(__builtin_fmaf(tt[r], a2, -lse2));
 
         // ---- dP' = V(t) . dO' ---------------------------------------------------------------------------------------
-        f32x16 dp0, dp1;
+        f32x16 dp0;          // ONE accumulator for the three terms (round 6, as corr_fused_fwd_f16x3.hip's QK1: the kernel is VALU-bound)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dp0[r] = 0.f; dp1[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) dp0[r] = 0.f;
         {
             const _Float16* vb0 = vt + buf * 2 * VPLANE + c * VROW + h * 8;
             f16x8 ah[2], al[2];
@@ -574,8 +574,8 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
                 }
                 if (!(BX_ABLATE & 8)) {
                     dp0 = bx_mfma(ah[cur], goh[u], dp0);
-                    dp1 = bx_mfma(ah[cur], gol[u], dp1);
-                    if (!VLO0 || u < 2) dp1 = bx_mfma(al[cur], goh[u], dp1);
+                    dp0 = bx_mfma(ah[cur], gol[u], dp0);
+                    if (!VLO0 || u < 2) dp0 = bx_mfma(al[cur], goh[u], dp0);
                 }
                 if (u < 2 * VPT) {
                     commit_v_piece(u, buf ^ 1);
@@ -592,7 +592,7 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             // La = L a_n (a_n = scale a_p > 0 folded once): G = La b_q, L z = La tt, L a_n mu_p = La mu_p, sum_q L kn_q = (sum_q La kn_q) / a_n
-            const float dd = (dp0[r] + dp1[r]) - d_lane;
+            const float dd = dp0[r] - d_lane;
             const float La = (STORE_P ? p[r] * undo : p[r]) * dd * a_n;
             gv[r] = La * bq[r];
             x1[r] = La * tt[r];

@@ -353,6 +353,15 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
         // ---- S^T = K_tile . Q : 16 k-steps x 3 terms; three accumulators (one per product term) used round-robin, so
         //      that consecutive MFMAs never depend on each other and every gap can carry a filler; the key-tile pieces of
         //      tile t+1 ride in the gaps ------------------------------------------------------------------------------
+        // QK1 (round 6): the three product terms accumulate into ONE register set — a dependent chain of v_mfma_f32_32x32x16_f16 issues at
+        // the full rate on gfx950 (tools/probes/mfma_operand_rate.hip), and the kernel is bound by its VALU instructions, not by MFMA
+        // dependencies: 32 accumulator reads and 16 packed adds fewer per tile, forward 0.311 -> 0.293 ms same box (tools/ab_libs.sh;
+        // -DCOCOS_QK_THREE_ACC restores the round-2 form).  The magnitude-free flavour keeps its two chains (they START at -m_hi / -m_lo).
+#ifdef COCOS_QK_THREE_ACC
+        constexpr bool QK1 = false;
+#else
+        constexpr bool QK1 = !RAWM;
+#endif
         f32x16 sa, sb, sc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sa[r] = RAWM ? -m_run : 0.f; sb[r] = RAWM ? -m_lo : 0.f; sc[r] = 0.f; }
@@ -365,10 +374,10 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
                 if (live) sa = mfma16h(ah[cur], qhr[s], sa);
                 if (!(COCOS_ABLATE & 2) && s + RA - 1 < KST) ah[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + (s + RA - 1) * 16);
                 __builtin_amdgcn_sched_barrier(0);
-                if (live) sb = mfma16h(ah[cur], qlr[s], sb);
+                if (live) { if (QK1) sa = mfma16h(ah[cur], qlr[s], sa); else sb = mfma16h(ah[cur], qlr[s], sb); }
                 if (!(COCOS_ABLATE & 2) && s + RA - 1 < KST) al[(s + RA - 1) % RA] = *reinterpret_cast<const f16x8*>(kb + KPLANE + (s + RA - 1) * 16);
                 __builtin_amdgcn_sched_barrier(0);
-                if (live) sc = mfma16h(al[cur], qhr[s], sc);
+                if (live) { if (QK1) sa = mfma16h(al[cur], qhr[s], sa); else sc = mfma16h(al[cur], qhr[s], sc); }
                 if ((s & 1) == 0) piece(s >> 1, std::false_type{});   // the 8 key-tile pieces, every other step
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -391,7 +400,7 @@ __device__ __forceinline__ void corr_fwd_f16x3_body(
         // fma per element: p = 2^(s * scale_log2 - (m - kPBias)).
         f32x16 s0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s0[r] = (sa[r] + sb[r]) + sc[r];
+        for (int r = 0; r < 16; ++r) s0[r] = QK1 ? sa[r] : (sa[r] + sb[r]) + sc[r];
         if (ragged) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
