@@ -78,8 +78,13 @@ struct DwProbs {
     DwProb p[2];
 };
 
-template <int CBW, int DMODE>
-__global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(const DwProbs pr, int M, int C, int N, int chunks_per_img, int chunk_len) {
+// NW (round 6) = waves per workgroup.  With 4 a wave owns 64 x 224 of the tile = 224 accumulator registers, and the ~112 staging
+// registers beside them do not fit the other half of the file: the allocator parked them in AGPRs and the loop carried 281
+// v_accvgpr_read / _write / _mov per two k-steps next to its 84 MFMAs (a third of its instructions; SQ_INSTS_VALU 13.5 k per
+// wave for 1.3 k MFMAs).  With 8 (two per SIMD) a wave owns 32 x 224 = 112 registers, everything else lives in VGPRs, and one
+// wave's staging arithmetic runs under the other's MFMAs.
+template <int CBW, int DMODE, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 1) void proj_dw_f16x3_kernel(const DwProbs pr, int M, int C, int N, int chunks_per_img, int chunk_len) {
     const bool second = blockIdx.z != 0;                         // (workgroup-uniform)
     const float* __restrict__ const dy = second ? pr.p[1].dy : pr.p[0].dy;
     const float* __restrict__ const x = second ? pr.p[1].x : pr.p[0].x;
@@ -88,20 +93,24 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(const DwProbs pr,
     const float* __restrict__ const dy_amax = second ? pr.p[1].dy_amax : pr.p[0].dy_amax;
     const float* __restrict__ const x_amax = second ? pr.p[1].x_amax : pr.p[0].x_amax;
     const DwAffine af = second ? pr.p[1].af : pr.p[0].af;
+    constexpr int NT = NW * 64, PR = NT / 4;                      // threads; rows one piece index covers (a piece = 4 positions of a row)
+    constexpr int RB = 8 / NW;                                    // 32-row blocks of dy per wave: 2 (four waves) or 1 (eight)
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
     constexpr int XROWS = 2 * CBW * 32;                           // x rows staged per k-step
-    constexpr int APLANE = DW_MROWS * DW_ROW, BPLANE = XROWS * DW_ROW;
+    constexpr int NPA = DW_MROWS / PR;                            // float4 pieces per thread and k-step: dy
+    constexpr int NPB = (XROWS + PR - 1) / PR;                    //                                      x
+    constexpr int XPAD = NPB * PR;                                // x rows of the LDS image (448 -> 512 with eight waves: the pad rows get zeros)
+    constexpr int APLANE = DW_MROWS * DW_ROW, BPLANE = XPAD * DW_ROW;
     constexpr int BUF = 2 * (APLANE + BPLANE);                    // halfs per LDS buffer: A hi, A lo, B hi, B lo
-    constexpr int NPA = DW_MROWS * 4 / 256;                       // float4 pieces per thread and k-step: dy
-    constexpr int NPB = (XROWS * 4 + 255) / 256;                  //                                      x
     constexpr int NP = NPA + NPB;
-    constexpr int SLOTS = 2 * CBW;                                // MFMA triples per k-step and wave
+    constexpr int SLOTS = RB * CBW;                               // MFMA triples per k-step and wave
     static_assert(NP <= SLOTS, "more staging pieces than MFMA steps to carry them");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16* const lds = reinterpret_cast<_Float16*>(smem_raw);  // [2 buf][A hi | A lo | B hi | B lo]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;                      // RB x 32 rows of dy, CBW x 32 rows of x
     // chunk (blockIdx.x) x row half (blockIdx.y); the halves of one chunk are 8k blocks apart = same XCD
     const int s_idx = blockIdx.x, mh = blockIdx.y;
     const int b = s_idx / chunks_per_img;
@@ -121,13 +130,13 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(const DwProbs pr,
     // ---- staging: piece p of this thread = 4 consecutive positions (kq) of one row -----------------------------
     // piece p covers row p*64 + (tid >> 2) of its operand (dy rows first, then x rows), positions kq*4 .. +3 of the
     // k-step with kq = tid & 3 for every piece: one LDS address register + immediates, one position test per step
-    static_assert((XROWS * 4) % 256 == 0 && (DW_MROWS * 4) % 256 == 0, "whole pieces only");
+    static_assert(DW_MROWS % PR == 0, "whole dy pieces only");
     const int kq = tid & 3, prow = tid >> 2;
     unsigned voff[NP];                       // per-lane byte offset of (row, kq*4) in its image; kBufOob: row absent
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         const bool isA = p < NPA;
-        const int grow = isA ? m0 + p * 64 + prow : (p - NPA) * 64 + prow;
+        const int grow = isA ? m0 + p * PR + prow : (p - NPA) * PR + prow;
         voff[p] = (grow < (isA ? M : C)) ? (unsigned)(grow * N + kq * 4) * 4u : kBufOob;
     }
     _Float16* const lds_t = lds + prow * DW_ROW + kq * 4;         // + buffer, operand, plane, p*64 rows: constants
@@ -177,14 +186,14 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(const DwProbs pr,
         u32x2 hi, lo;
         dw_split4(sg[p], p < NPA ? sa : sb, hi, lo);
         if (p < NPA) dbsum[p] += (sg[p][0] + sg[p][1]) + (sg[p][2] + sg[p][3]);
-        _Float16* d = lds_t + buf * BUF + (p < NPA ? p * 64 * DW_ROW : 2 * APLANE + (p - NPA) * 64 * DW_ROW);
+        _Float16* d = lds_t + buf * BUF + (p < NPA ? p * PR * DW_ROW : 2 * APLANE + (p - NPA) * PR * DW_ROW);
         *reinterpret_cast<u32x2*>(d) = hi;
         *reinterpret_cast<u32x2*>(d + (p < NPA ? APLANE : BPLANE)) = lo;
     };
 
-    f32x16 acc[2][CBW];
+    f32x16 acc[RB][CBW];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < CBW; ++cb)
 #pragma unroll
@@ -192,11 +201,11 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(const DwProbs pr,
 
     // one k-step: this wave's 64 x (CBW*32) block += A(64 x 16) . B(16 x CBW*32); hook(slot) after every MFMA triple
     auto kstep = [&](int buf, auto&& hook) {
-        const _Float16* ab = lds + buf * BUF + (wm * 64 + c) * DW_ROW + h * 8;
+        const _Float16* ab = lds + buf * BUF + (wm * RB * 32 + c) * DW_ROW + h * 8;
         const _Float16* bb = lds + buf * BUF + 2 * APLANE + (wn * CBW * 32 + c) * DW_ROW + h * 8;
-        f16x8 ah[2], al[2];
+        f16x8 ah[RB], al[RB];
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
+        for (int rb = 0; rb < RB; ++rb) {
             ah[rb] = *reinterpret_cast<const f16x8*>(ab + rb * 32 * DW_ROW);
             al[rb] = *reinterpret_cast<const f16x8*>(ab + APLANE + rb * 32 * DW_ROW);
         }
@@ -215,11 +224,11 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(const DwProbs pr,
                 bl[nx % RA] = *reinterpret_cast<const f16x8*>(bb + BPLANE + nx * 32 * DW_ROW);
             }
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
+            for (int rb = 0; rb < RB; ++rb) {
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], bh[cur], acc[rb][cb], 0, 0, 0);
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], bl[cur], acc[rb][cb], 0, 0, 0);
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rb], bh[cur], acc[rb][cb], 0, 0, 0);
-                hook(cb * 2 + rb);
+                hook(cb * RB + rb);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -261,13 +270,13 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(const DwProbs pr,
     const int CP = (C + 31) / 32 * 32;
     float* wsb = ws_dw + (size_t)s_idx * M * CP;
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < CBW; ++cb) {
             const int ci = (wn * CBW + cb) * 32 + c;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + rb * 32 + acc_row_base(r) + 4 * h;
+                const int m = m0 + wm * RB * 32 + rb * 32 + acc_row_base(r) + 4 * h;
                 if (m < M && ci < CP) wsb[(size_t)m * CP + ci] = acc[rb][cb][r] * oscale;
             }
         }
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void proj_dw_f16x3_kernel(const DwProbs pr,
             float v = dbsum[p];
             v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
             v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
-            const int row = m0 + p * 64 + prow;
+            const int row = m0 + p * PR + prow;
             if ((tid & 3) == 0 && row < M) ws_db[(size_t)s_idx * M + row] = v;
         }
     }
@@ -403,11 +412,13 @@ static int proj_dw_launch(int dmode, int nprob, const DwHostProb* hp, int B, int
         pr.p[i] = DwProb{h.dy, h.x, h.ws_dw, h.ws_db, h.dy_amax, h.x_amax, h.af};
         rp.ws[i] = h.ws_dw; rp.out[i] = h.dw; rp.ws_db[i] = h.ws_db; rp.db[i] = h.db;
     }
+    constexpr int NW = 8, PRH = NW * 64 / 4;                  // (the kernel's NW / PR)
     auto launch = [&](auto kern, int xrows) -> int {
-        const size_t smem = (size_t)2 * 2 * (DW_MROWS + xrows) * DW_ROW * sizeof(_Float16);
+        const int xpad = (xrows + PRH - 1) / PRH * PRH;
+        const size_t smem = (size_t)2 * 2 * (DW_MROWS + xpad) * DW_ROW * sizeof(_Float16);
         COCOS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, pr, M, C, N, cpi, len);
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, pr, M, C, N, cpi, len);
         return COCOS_OK;
     };
     int rc;
