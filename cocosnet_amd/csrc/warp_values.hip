@@ -20,34 +20,56 @@ __global__ __launch_bounds__(256) void warp_values_kernel(const float* __restric
                                                           size_t n, bool vec4, unsigned* __restrict__ amax) {
   float vmax = 0.f;
   const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const int x = (int)(i % w);
-    size_t r = i / w;
-    const int y = (int)(r % h);
-    r /= h;
-    const int c = (int)(r % (Ci + Cs));
-    const size_t b = r / (Ci + Cs);
-    const int W = w * d, H = h * d;
-    float v;
-    if (c >= Ci) {                                        // nearest: source pixel (y*d, x*d)
-        v = seg[((b * Cs + (c - Ci)) * H + (size_t)y * d) * W + (size_t)x * d];
-    } else {                                              // mean of the d x d window
-        const float* p = img + ((b * Ci + c) * H + (size_t)y * d) * W + (size_t)x * d;
-        float acc = 0.f;
-        if (vec4) {                                       // d == 4, rows 16-byte aligned
+  const int W = w * d, H = h * d;
+  // four output elements per thread and iteration, their loads issued before any is used (round 6: with one strided 4-byte load in
+  // flight per thread the kernel was latency-bound — 2.1 TB/s of 64-byte bursts over every d-th row of the label map)
+  constexpr int U = 4;
+  for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += stride * U) {
+    float v[U];
+    const float* pimg[U];
+    bool is_img[U], live[U];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(p + (size_t)a * W);
-                acc += (q[0] + q[1]) + (q[2] + q[3]);
-            }
-        } else {
-            for (int a = 0; a < d; ++a)
-                for (int e = 0; e < d; ++e) acc += p[(size_t)a * W + e];
-        }
-        v = acc / (float)(d * d);
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + (size_t)u * stride;
+      live[u] = i < n;
+      const size_t ii = live[u] ? i : 0;
+      const int x = (int)(ii % w);
+      size_t r = ii / w;
+      const int y = (int)(r % h);
+      r /= h;
+      const int c = (int)(r % (Ci + Cs));
+      const size_t b = r / (Ci + Cs);
+      is_img[u] = c < Ci;
+      pimg[u] = nullptr;
+      v[u] = 0.f;
+      if (!is_img[u]) {                                     // nearest: source pixel (y*d, x*d)
+        v[u] = seg[((b * Cs + (c - Ci)) * H + (size_t)y * d) * W + (size_t)x * d];
+      } else {
+        pimg[u] = img + ((b * Ci + c) * H + (size_t)y * d) * W + (size_t)x * d;
+      }
     }
-    out[i] = v;
-    vmax = fmaxf(vmax, fabsf(v));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (is_img[u]) {                                      // mean of the d x d window
+        const float* p = pimg[u];
+        float acc = 0.f;
+        if (vec4) {                                         // d == 4, rows 16-byte aligned
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(p + (size_t)a * W);
+            acc += (q[0] + q[1]) + (q[2] + q[3]);
+          }
+        } else {
+          for (int a = 0; a < d; ++a)
+            for (int e = 0; e < d; ++e) acc += p[(size_t)a * W + e];
+        }
+        v[u] = acc / (float)(d * d);
+      }
+      if (live[u]) {
+        out[i0 + (size_t)u * stride] = v[u];
+        vmax = fmaxf(vmax, fabsf(v[u]));
+      }
+    }
   }
   // max|V| as a by-product (the K2 forward's f16 split of V wants it): one same-address atomic per workgroup, the
   // grid of the _amax entry point is capped accordingly
@@ -75,7 +97,8 @@ static int warp_values_impl(const float* img, const float* seg, float* out, int 
     const size_t n = (size_t)B * (Ci + Cs) * (H / down) * (W / down);
     COCOS_REQUIRE((n + 255) / 256 <= 0x7fffffffull, COCOS_ERR_UNSUPPORTED, "warp_values: tensor too large");
     const bool vec4 = down == 4 && W % 4 == 0 && img && aligned16(img);
-    const size_t blocks = amax_inout_dev ? std::min<size_t>(1024, (n + 255) / 256) : (n + 255) / 256;
+    // (4 elements per thread and trip; more than ~1000 workgroups of strided streams at once was SLOWER: 61 us at 4096 against 35)
+    const size_t blocks = std::min<size_t>(1024, (n + 1023) / 1024);
     hipLaunchKernelGGL(warp_values_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), img, seg,
                        out, Ci, Cs, H / down, W / down, down, n, vec4, reinterpret_cast<unsigned*>(amax_inout_dev));
     COCOS_HIP_CHECK(hipGetLastError());
