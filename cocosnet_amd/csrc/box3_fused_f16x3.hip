@@ -559,7 +559,7 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
         // ---- dP' = V(t) . dO' ---------------------------------------------------------------------------------------
         f32x16 dp0;          // ONE accumulator for the three terms (round 6, as corr_fused_fwd_f16x3.hip's QK1: the kernel is VALU-bound)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dp0[r] = 0.f;
+        for (int r = 0; r < 16; ++r) dp0[r] = -d_lane;       // ... which starts at -D': L = P (dP' - D') without a subtraction per element
         {
             const _Float16* vb0 = vt + buf * 2 * VPLANE + c * VROW + h * 8;
             f16x8 ah[2], al[2];
@@ -592,7 +592,7 @@ __device__ __forceinline__ void box3_sw_bwd_body(COCOS_BXB_PARAMS) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             // La = L a_n (a_n = scale a_p > 0 folded once): G = La b_q, L z = La tt, L a_n mu_p = La mu_p, sum_q L kn_q = (sum_q La kn_q) / a_n
-            const float dd = dp0[r] - d_lane;
+            const float dd = dp0[r];
             const float La = (STORE_P ? p[r] * undo : p[r]) * dd * a_n;
             gv[r] = La * bq[r];
             x1[r] = La * tt[r];

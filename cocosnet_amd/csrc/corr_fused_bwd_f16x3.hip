@@ -385,8 +385,10 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
     // fragment reads and the fetch of those lo channels are skipped for the other blocks (8 of 30 MFMAs, same result)
     auto phase_dp = [&](f32x16& dp0, int t) __attribute__((always_inline)) {
         constexpr bool SKIPLO = VLO0 || (COCOS_ABLATE & 512);
+        // (round 6: the accumulator STARTS at -D' — the subtraction of dS'' = P (dP' - D') rides in the initialisation the chain needs
+        //  anyway: 16 VALU instructions per tile fewer in a kernel that is bound by them)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dp0[r] = 0.f;
+        for (int r = 0; r < 16; ++r) dp0[r] = -d_lane;
         const _Float16* vb0 = vt + (t & 1) * 2 * VPLANE + c * VROW + h * 8;
         f16x8 ah[2], al[2];
         ah[0] = vf_h;
@@ -432,7 +434,7 @@ __device__ __forceinline__ void corr_bwd_query_f16x3_body(
         float pc = (COCOS_ABLATE & 4) ? s[r >> 2][r & 3] * 1e-9f
                                       : fast_exp2(__builtin_fmaf(RAWM ? s[r >> 2][r & 3] + dm : s[r >> 2][r & 3], scale_log2, nlse2c));
         if (RAGGED && (t * 32 + acc_row_base(r) + 4 * h >= Nk)) pc = 0.f;
-        dsv[r & 1] = pc * (dp0[r] - d_lane);
+        dsv[r & 1] = pc * dp0[r];
         if (STORE_P) pv[r & 1] = pc * p_from_pc;
         if (r & 1) {
             split_pair_rtz(dsv[0], dsv[1], out.hw[r >> 1], out.lw[r >> 1]);
