@@ -92,7 +92,7 @@ class KernelTimer:
         out = {}
         for tag, evs in self.events.items():
             ms = [a.elapsed_time(b) for a, b in evs]
-            out[tag] = {"calls": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms)}
+            out[tag] = {"calls": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "min_ms": min(ms)}
         return out
 
 

@@ -406,3 +406,36 @@ def test_config5_match_kernel3_hw16384_vs_fp64(route, monkeypatch):
         assert rel(tq.grad[sl], dth) < TOL, b
         assert rel(pq.grad[sl], dph) < TOL, b
         torch.cuda.empty_cache()
+
+
+def test_t_storage_taken_over_by_the_planes_is_visible_to_autograd(monkeypatch):
+    """when the dC planes take T's storage (ops.BOX3_ALIAS_T_BYTES; here forced for a small T), the kernels write
+    through raw pointers — T's version counter is bumped by hand, so a SECOND backward over a retained graph (T is a saved input of
+    every pass) raises instead of reading f16 planes as fp32 logits.  The first backward's gradients equal the un-aliased ones."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    monkeypatch.setattr(ops, "PRECISION", "f16x3")
+    monkeypatch.setattr(ops, "PROJ_PRECISION", "f16x3")
+    B, S, d, nc = 1, 256, 4, 5
+    fh = S // d
+    g = torch.Generator(device=DEV).manual_seed(7)
+    th0, ph0 = _features(B, fh, g, corr=0.5)
+    ref_img = torch.rand(B, 3, S, S, device=DEV, generator=g) * 2 - 1
+    lab = torch.randint(0, nc, (B, 1, S // 8, S // 8), device=DEV, generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    seg = torch.zeros(B, nc, S, S, device=DEV).scatter_(1, lab, 1.0)
+    cfg = HotPathConfig(match_kernel=3, PONO_C=True, down=d, isTrain=True, warp_mask_losstype="direct")
+    go, gm = torch.randn(B, 3, S, S, device=DEV, generator=g), torch.randn(B, nc, fh, fh, device=DEV, generator=g)
+    grads = {}
+    for alias in (False, True):
+        monkeypatch.setattr(ops, "BOX3_ALIAS_T_BYTES", 0 if alias else 1 << 62)
+        th, ph = th0.clone().requires_grad_(True), ph0.clone().requires_grad_(True)
+        out = correspondence_hot_path(th, ph, ref_img, None, seg, seg, cfg)
+        torch.autograd.backward([out["warp_out"], out["warp_mask"]], [go, gm], retain_graph=True)
+        grads[alias] = (th.grad.clone(), ph.grad.clone())
+        if alias:
+            with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+                torch.autograd.backward([out["warp_out"], out["warp_mask"]], [go, gm])
+        else:
+            torch.autograd.backward([out["warp_out"], out["warp_mask"]], [go, gm])       # un-aliased: a retained graph runs again
+    for a, b in zip(grads[True], grads[False]):
+        assert torch.equal(a, b)
