@@ -1369,7 +1369,7 @@ def _proj1x1_dw_affine_pair(mode, probs, plane_scale, need_b, scale_cells=(None,
         if any(c is not None for c in scale_cells):
             raise _lib.CocosHipError(f"proj1x1_dw_affine_pair: shape not supported (Cin={Cin} Cout={Cout} N={N})")
         return [_proj1x1_dw_affine(mode, in1, a, b, coef, plane_scale, x, da, xa, need_b) for (in1, a, b, coef, x, da, xa) in probs]
-    res, args = [], []
+    res, args, hold = [], [], []
     f32 = dict(device=x0.device, dtype=torch.float32)
     for (in1, in2a, in2b, coef, x, d_amax, x_amax) in probs:
         ws = torch.empty((parts, Cout, (Cin + 31) // 32 * 32), **f32)
@@ -1377,10 +1377,16 @@ def _proj1x1_dw_affine_pair(mode, probs, plane_scale, need_b, scale_cells=(None,
         dw = torch.empty((Cout, Cin), **f32)
         db = torch.empty(Cout, **f32) if need_b else None
         res.append((dw, db))
+        # the FIRST problem's partial tiles must outlive the loop: rebinding `ws` / `wsb` for the second problem handed their blocks back
+        # to the allocator before the launch, and the second problem's 1 KB `db` was carved out of the first one's bias partials — the
+        # reduction then read a partial row that the other half of the same launch was overwriting (caught by the full GPU suite only:
+        # it takes an allocator state in which that block is the best fit)
+        hold.append((ws, wsb))
         args += [in1.data_ptr(), in2a.data_ptr(), _ptr(in2b), coef.data_ptr(), x.data_ptr(), ws.data_ptr(), _ptr(wsb), dw.data_ptr(),
                  _ptr(db), d_amax.data_ptr(), x_amax.data_ptr()]
     _call("proj1x1_bwd", "cocos_proj1x1_dw_affine_pair_f16x3", mode, float(plane_scale), *args, _ptr(scale_cells[0]), _ptr(scale_cells[1]),
           B, Cin, Cout, N, _stream())
+    del hold          # (released after the launch: stream order makes the reuse safe)
     return res
 
 

@@ -1,0 +1,118 @@
+"""Every device pointer handed to the C-ABI must lie inside a LIVE allocation at the moment of the call.
+
+The binding passes raw addresses (`tensor.data_ptr()`); a tensor that Python has already dropped by the time the entry point is
+invoked is a block the caching allocator may hand to the next `torch.empty` — round 6's pair launch of the two projections' weight
+gradients rebound its loop variables and thereby freed the FIRST problem's partial tiles before the launch; the second problem's
+bias gradient was then carved out of them and one launch read what its other half was overwriting (only in allocator states where
+that block was the best fit: the full GPU suite, not the file on its own).  This test wraps `_lib.call` for one differentiated
+step of the hot path (both match kernels, lazy projections = the bench's configuration) and checks each pointer argument against
+`torch.cuda.memory_snapshot()`."""
+import bisect
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _live_blocks():
+    """sorted [(address, size, live)] of every block of the caching allocator's segments"""
+    blocks = []
+    for seg in torch.cuda.memory_snapshot():
+        addr = seg["address"]
+        for b in seg["blocks"]:
+            blocks.append((addr, b["size"], b["state"] == "active_allocated"))
+            addr += b["size"]
+    blocks.sort()
+    return blocks
+
+
+class _Guard:
+    """`_lib.call` wrapped: every c_void_p argument that is an address inside one of the allocator's segments must be inside an
+    ACTIVE block.  (The stream handle and NULL are skipped: not allocator memory.)"""
+
+    def __init__(self, monkeypatch):
+        from cocosnet_amd import _lib
+        self.calls, self.pointers, self.dead = 0, 0, []
+        real_call, sigs = _lib.call, _lib._SIGNATURES
+
+        def checked_call(name, *args):
+            blocks = _live_blocks()
+            starts = [b[0] for b in blocks]
+            for i, (a, ty) in enumerate(zip(args, sigs[name][1])):
+                if ty is not ctypes.c_void_p or not isinstance(a, int) or a == 0:
+                    continue
+                j = bisect.bisect_right(starts, a) - 1
+                if j < 0 or a >= blocks[j][0] + blocks[j][1]:
+                    continue
+                self.pointers += 1
+                if not blocks[j][2]:
+                    self.dead.append((name, i, hex(a), blocks[j][1]))
+            self.calls += 1
+            return real_call(name, *args)
+
+        monkeypatch.setattr(_lib, "call", checked_call)
+
+    def check(self, min_calls, min_pointers):
+        torch.cuda.synchronize()
+        assert self.calls >= min_calls and self.pointers >= min_pointers, (self.calls, self.pointers)
+        assert not self.dead, f"pointers into freed blocks at call time (entry point, argument index, address, block size): {self.dead[:8]}"
+
+
+@pytest.mark.parametrize("mk", [1, 3])
+def test_every_pointer_argument_is_a_live_allocation(mk, hip_lib, monkeypatch):
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    B, Cin, fh, fw, down, nc = 2, 64 + 7, 16, 64, 4, 7
+    g = torch.Generator(device=DEV).manual_seed(5 + mk)
+    mkp = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    H, W = fh * down, fw * down
+    leaves = [mkp(B, Cin, fh, fw), mkp(256, Cin, 1, 1) / Cin ** 0.5, mkp(256) * 0.1,
+              mkp(B, Cin, fh, fw), mkp(256, Cin, 1, 1) / Cin ** 0.5, mkp(256) * 0.1]
+    leaves = [t.requires_grad_(True) for t in leaves]
+    ref_img = torch.rand(B, 3, H, W, device=DEV, generator=g) * 2 - 1
+    lab = torch.randint(0, nc, (B, 1, H, W), device=DEV, generator=g)
+    seg = torch.zeros(B, nc, H, W, device=DEV).scatter_(1, lab, 1.0)
+    cfg = HotPathConfig(match_kernel=mk, PONO_C=True, down=down, warp_mask_losstype="direct", isTrain=True)
+    g_out, g_mask = mkp(B, 3, H, W), mkp(B, nc, fh, fw)
+    guard = _Guard(monkeypatch)
+    th, ph = ops.LazyProj1x1(*leaves[:3]), ops.LazyProj1x1(*leaves[3:])
+    out = correspondence_hot_path(th, ph, ref_img, ref_img, seg, seg, cfg)
+    torch.autograd.backward([out["warp_out"], out["warp_mask"]], [g_out, g_mask])
+    guard.check(8, 40)
+
+
+@pytest.mark.parametrize("mk", [1, 3])
+def test_whole_module_step_hands_over_live_buffers_only(mk, hip_lib, monkeypatch):
+    """NoVGGCorrespondence forward + backward (adaptors, ResidualBlocks, SPADE blocks, projections, the path): ~10^3 entry-point calls."""
+    from cocosnet_amd import correspondence as cc
+    opt = cc.ade20k_options(semantic_nc=7, match_kernel=mk, isTrain=True)
+    torch.manual_seed(0)
+    net = cc.NoVGGCorrespondence(opt).to(DEV)
+    net.init_weights(opt.init_type, opt.init_variance)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    S = 256 if mk == 3 else 64                    # (the fused match_kernel-3 family takes 64-wide grids)
+    img = torch.rand(2, 3, S, S, device=DEV, generator=g) * 2 - 1
+    real = torch.rand(2, 3, S, S, device=DEV, generator=g) * 2 - 1
+    lab = torch.randint(0, 7, (2, 1, S, S), device=DEV, generator=g)
+    seg = torch.zeros(2, 7, S, S, device=DEV).scatter_(1, lab, 1.0)
+    guard = _Guard(monkeypatch)
+    out = net(img, real, seg, seg.flip(0), alpha=1.0)
+    loss = out["warp_out"].pow(2).sum() + torch.log(out["warp_mask"] + 1e-10).mul(seg[:, :, ::4, ::4]).sum()
+    loss.backward()
+    guard.check(300, 1500)
+
+
+def test_contextual_loss_hands_over_live_buffers_only(hip_lib, monkeypatch):
+    from types import SimpleNamespace
+    from cocosnet_amd.contextual import ContextualLoss_forward
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(2, 64, 32, 32, device=DEV, generator=g).requires_grad_(True)
+    y = torch.randn(2, 64, 32, 32, device=DEV, generator=g).requires_grad_(True)
+    guard = _Guard(monkeypatch)
+    for route in ("fused", "materialised"):
+        monkeypatch.setattr("cocosnet_amd.contextual.ROUTE", route, raising=False)
+        ContextualLoss_forward(SimpleNamespace(PONO=True))(x, y).sum().backward()
+    guard.check(4, 20)
