@@ -27,7 +27,30 @@
 
 #include "proj_frag.h"
 
+// Debug builds (results of the ablations are WRONG; tools/proj_pair_bench.py, tools/k24_timeline.py):
+//   -DCOCOS_K24_ABLATE=<bits>  1: no first sweep, 2: the weight stages are fetched once, 4: no dx stores, 8: no MFMAs
+//   -DCOCOS_K24_TIMING         wall-clock stamps (100 MHz) of every workgroup at its start, after each sweep and at its end,
+//                              read back with cocos_debug_k24_timing()
+// What they showed at the bench shape (B = 8, Cin = 407, 64 x 64, both projections; 112 us on that box): sweep 1 ~21 us and sweep 2
+// ~20 us per workgroup (1.3 us per 16-channel stage: the latency of a DMA two stages ahead), the store tail 4-9 us, two rounds of
+// 512 resident workgroups; without the first sweep 89 us, without the weight stages 111 (they are L2 hits), without MFMAs 104.
+// An eight-wave form (both row halves in one workgroup, operand slots shared and fetched once, three stages ahead, weight and
+// operand DMAs issued by different waves so that each has its own vmcnt queue) was built and measured: the SAME 115 us — the
+// duplicate fetches of the two halves were L2 hits all along; what the kernel waits for is the memory side: the operands of a
+// round (67 MB) do not fit the 32 MB of L2, so BOTH sweeps stream them from HBM / Infinity Cache (268 MB read + 107 MB written in
+// ~110 us).  Removing the first sweep needs its per-position sums from the kernels that produce d qn / d kn — not built.
+#ifndef COCOS_K24_ABLATE
+#define COCOS_K24_ABLATE 0
+#endif
+
 namespace cocos {
+
+#ifdef COCOS_K24_TIMING
+__device__ long long g_k24_t[2048][4];
+#define K24_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_k24_t[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define K24_STAMP(i) do {} while (0)
+#endif
 
 typedef _Float16 pb_f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* pb_lds_ptr;
@@ -80,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void proj_bwd_kernel(const PbArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     const int N = a.N, Cin = a.Cin;
+    K24_STAMP(0);
     const int tiles = N / 128, per_prob = a.B * tiles, total = a.nprob * per_prob;
     // the two row halves of a position tile: 8 workgroups apart in dispatch order = the same XCD, resident together
     const int vb = blockIdx.x;
@@ -116,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void proj_bwd_kernel(const PbArgs a) {
     for (int i = 0; i < 4; ++i) w_soff[i] = (unsigned)(min(wave * 4 + i, 2 * PB_HB - 1) * 1024 + half * PB_WSTAGE);
 
     auto issue_w = [&](int s) {
-        const bool ok = s < PB_NST;
+        const bool ok = s < PB_NST && !((COCOS_K24_ABLATE & 2) && s > 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ok ? w_rs : none_rs, (pb_lds_ptr)(wbuf + (s & 1) * PB_WSTAGE + (w_soff[i] - half * PB_WSTAGE)), 16,
@@ -165,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void proj_bwd_kernel(const PbArgs a) {
     issue_in(1, 1);
     int slot = 0;
 #pragma unroll 1
-    for (int s = 0; s < PB_NST; ++s) {
+    for (int s = 0; s < ((COCOS_K24_ABLATE & 1) ? 0 : PB_NST); ++s) {
         asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");      // in(s) landed; in(s + 1) may be in flight
         int slot2 = slot + 2;
         if (slot2 >= PB_SLOTS) slot2 -= PB_SLOTS;
@@ -198,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void proj_bwd_kernel(const PbArgs a) {
         dmax = u * mx + fabsf(g) + fabsf(m);      // |y| <= 1: unit columns
     }
     const float sp = pb_pow2_scale(dmax);
+    K24_STAMP(1);
     if (half == 0 && h == 0) {
         float* cf = P.coef + (size_t)b * 3 * N + n0 + c;
         cf[0] = alpha; cf[N] = beta; cf[2 * (size_t)N] = gamma;
@@ -238,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void proj_bwd_kernel(const PbArgs a) {
         const pb_f16x8 bl = __builtin_bit_cast(pb_f16x8, u32x4{blw[0], blw[1], blw[2], blw[3]});
         const unsigned char* wb = wbuf + (s & 1) * PB_WSTAGE + lane * 16;
 #pragma unroll
-        for (int i = 0; i < PB_HB; i += 2) {
+        for (int i = 0; i < ((COCOS_K24_ABLATE & 8) ? 0 : PB_HB); i += 2) {
             const pb_f16x8 ah0 = *reinterpret_cast<const pb_f16x8*>(wb + (i * 2 + 0) * 1024);
             const pb_f16x8 al0 = *reinterpret_cast<const pb_f16x8*>(wb + (i * 2 + 1) * 1024);
             if (i + 1 < PB_HB) {
@@ -259,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void proj_bwd_kernel(const PbArgs a) {
         slot = slot + 1 == PB_SLOTS ? 0 : slot + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    K24_STAMP(2);
 
     // ---------------- dx rows of this half: lane = position, register = row; 128-byte row segments ----------------
     const float oscale = 1.0f / (*P.w_scale * sp);
@@ -270,11 +296,24 @@ __global__ __launch_bounds__(256, 2) void proj_bwd_kernel(const PbArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + i * 32 + acc_row_base(r);
-            buf_store1s(dx_rs, acc[i][r] * oscale, row < Cin ? dx_voff : kBufOob, (unsigned)((i * 32 + acc_row_base(r)) * N) * 4u);
+            buf_store1s(dx_rs, acc[i][r] * oscale, (row < Cin && !(COCOS_K24_ABLATE & 4)) ? dx_voff : kBufOob, (unsigned)((i * 32 + acc_row_base(r)) * N) * 4u);
         }
+#ifdef COCOS_K24_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    K24_STAMP(3);
 }
 
 }  // namespace cocos
+
+#ifdef COCOS_K24_TIMING
+extern "C" int cocos_debug_k24_timing(long long* host, int nblocks) {
+    using namespace cocos;
+    COCOS_HIP_CHECK(hipDeviceSynchronize());
+    COCOS_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k24_t), (size_t)std::min(nblocks, 2048) * 4 * sizeof(long long)));
+    return COCOS_OK;
+}
+#endif
 
 extern "C" size_t cocos_proj_weight_tfrag_bytes(void) { return (size_t)cocos::PB_NST * cocos::PB_WSTAGE_ALL; }
 
