@@ -85,6 +85,9 @@ _SIGNATURES = {
                                            ctypes.c_float, _stream_t]),
     "cocos_pono_spade_fwd": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [_stream_t]),
     "cocos_pono_spade_bwd": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [_stream_t]),
+    "cocos_pono_spade_amax_partials": (ctypes.c_int, [ctypes.c_int] * 3),
+    "cocos_pono_spade_fwd_amax": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [_stream_t]),
+    "cocos_pono_spade_bwd_amax": (ctypes.c_int, [_c_float_p] * 9 + [ctypes.c_int] * 3 + [ctypes.c_float] * 2 + [_stream_t]),
     "cocos_split_f16": (ctypes.c_int, [_c_float_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 4
                         + [ctypes.c_float, _stream_t]),
     "cocos_corr_softmax_warp_saved_logits_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
@@ -226,6 +229,9 @@ _SIGNATURES = {
     "cocos_instnorm_prelu_bwd": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 2 + [ctypes.c_float, _stream_t]),
     "cocos_instnorm_prelu_bwd_f64": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 2
                                      + [ctypes.c_float, _stream_t]),
+    "cocos_instnorm_prelu_fwd_amax": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_int] * 2 + [ctypes.c_float, _stream_t]),
+    "cocos_instnorm_prelu_bwd_amax": (ctypes.c_int, [_c_float_p] * 6 + [ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p]
+                                      + [ctypes.c_int] * 2 + [ctypes.c_float, _stream_t]),
     "cocos_contextual_rows_fwd": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_float,
                                                  ctypes.c_float, _stream_t]),
     "cocos_contextual_rows_bwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_float,

@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
                                                              const float* __restrict__ dy, const float* __restrict__ aw,
                                                              float* __restrict__ out0 /* y | dx */,
                                                              float* __restrict__ dres, void* __restrict__ da_part,
-                                                             int N, float eps) {
+                                                             int N, float eps, float* __restrict__ amax_part /* nullable: [planes] max|out0| of this plane */) {
     __shared__ float red[4];
+    __shared__ float redm[4];
     __shared__ double red64[4];
     typedef typename std::conditional<DA64, double, float>::type da_t;
     const int tid = threadIdx.x;
@@ -92,11 +93,25 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
 
     auto xn_at = [&](int u, int e, int i) { return REG ? v[u][e] * r : (x[base + i] - mean) * r; };
 
+    // max|out0| as a by-product (round 6): the convolution / projection that reads this tensor next splits it into f16 planes scaled by
+    // it.  One value per plane, reduced by amax_finish_kernel in the same entry point: a same-address atomicMax per wave (13 k of them
+    // at 8 x 407 planes) serialises at ~10 ns each on the memory side — it made the forward 5x slower (0.033 -> 0.165 ms).
+    float vmax = 0.f;
+    auto put_amax = [&]() {
+        if (amax_part) {
+            vmax = wave_max_dpp(vmax);
+            if ((tid & 63) == 0) redm[tid >> 6] = vmax;
+            __syncthreads();
+            if (tid == 0) amax_part[blockIdx.x] = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        }
+    };
     if (!BWD) {
         auto emit = [&](int u, int e, int i) {
             float z = xn_at(u, e, i);
             if (res) z += res[base + i];
-            out0[base + i] = z > 0.f ? z : a * z;
+            z = z > 0.f ? z : a * z;
+            vmax = fmaxf(vmax, fabsf(z));
+            out0[base + i] = z;
         };
         if (REG) {
 #pragma unroll
@@ -106,7 +121,10 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
                     f32x4 z = v[u] * r;
                     if (res) z += *reinterpret_cast<const f32x4*>(res + base + (size_t)q * 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) z[e] = z[e] > 0.f ? z[e] : a * z[e];
+                    for (int e = 0; e < 4; ++e) {
+                        z[e] = z[e] > 0.f ? z[e] : a * z[e];
+                        vmax = fmaxf(vmax, fabsf(z[e]));
+                    }
                     *reinterpret_cast<f32x4*>(out0 + base + (size_t)q * 4) = z;
                 } else if (!vec) {
 #pragma unroll
@@ -116,6 +134,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
         } else {
             for (int i = tid; i < N; i += 256) emit(0, 0, i);
         }
+        put_amax();
         return;
     }
 
@@ -173,11 +192,15 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
                 if (out0) {
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = r * (d[u][e] - m1 - (v[u][e] * r) * m2);
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = r * (d[u][e] - m1 - (v[u][e] * r) * m2);
+                        vmax = fmaxf(vmax, fabsf(o[e]));
+                    }
                     *reinterpret_cast<f32x4*>(out0 + base + (size_t)q * 4) = o;
                 }
             }
         }
+        put_amax();
         return;
     }
     // (the element-wise register path recomputes dz in pass 2 from dy — an L2 hit — instead of holding a second plane)
@@ -202,7 +225,11 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
         const float dz = dz_at(u, e, i, xn);
         sa = sa_keep;
         if (dres) dres[base + i] = dz;
-        if (out0) out0[base + i] = r * (dz - m1 - xn * m2);
+        if (out0) {
+            const float o = r * (dz - m1 - xn * m2);
+            vmax = fmaxf(vmax, fabsf(o));
+            out0[base + i] = o;
+        }
     };
     if (REG) {
 #pragma unroll
@@ -215,6 +242,7 @@ __global__ __launch_bounds__(256) void instnorm_prelu_kernel(const float* __rest
     } else {
         for (int i = tid; i < N; i += 256) fin(0, 0, i);
     }
+    put_amax();
     (void)dummy;
 }
 
@@ -227,37 +255,97 @@ __global__ __launch_bounds__(256) void sum_f64_to_f32_kernel(const double* __res
     if (threadIdx.x == 0) *out = (float)t;
 }
 
+// cells[j] = max(cells[j], max part[j][0..n)) for j = blockIdx.x: the per-workgroup maxima of a producer kernel -> the caller's cell
+__global__ __launch_bounds__(256) void amax_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ cells) {
+    __shared__ float redm[4];
+    const float* p = part + (size_t)blockIdx.x * n;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, p[i]);
+    m = wave_max_dpp(m);
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        if (m > cells[blockIdx.x] && m < INFINITY) cells[blockIdx.x] = m;
+    }
+}
+
 }  // namespace cocos
+
+static int inp_fwd_impl(const float* x, const float* residual, const float* prelu_weight, float* y, float* y_amax_dev, float* part, int planes, int N,
+                        float eps, cocos_stream_t stream, const char* who) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && prelu_weight && y, COCOS_ERR_INVALID, "%s: null pointer", who);
+    COCOS_REQUIRE(planes >= 1 && N >= 1, COCOS_ERR_INVALID, "%s: bad dims planes=%d N=%d", who, planes, N);
+    hipStream_t s = as_stream(stream);
+    float* cell = part;
+    const bool reg = N <= 256 * 4 * INP_VPT && (N % 4 != 0 || (aligned16(x) && aligned16(y) && (!residual || aligned16(residual))));
+    if (reg && N <= 256 * 4 * 4) hipLaunchKernelGGL((instnorm_prelu_kernel<false, true, 4>), dim3(planes), dim3(256), 0, s, x, residual, nullptr, prelu_weight, y, nullptr, nullptr, N, eps, cell);
+    else if (reg) hipLaunchKernelGGL((instnorm_prelu_kernel<false, true>), dim3(planes), dim3(256), 0, s, x, residual, nullptr, prelu_weight, y, nullptr, nullptr, N, eps, cell);
+    else     hipLaunchKernelGGL((instnorm_prelu_kernel<false, false>), dim3(planes), dim3(256), 0, s, x, residual, nullptr, prelu_weight, y, nullptr, nullptr, N, eps, cell);
+    COCOS_HIP_CHECK(hipGetLastError());
+    if (part) {
+        hipLaunchKernelGGL(amax_finish_kernel, dim3(1), dim3(256), 0, s, part, planes, y_amax_dev);
+        COCOS_HIP_CHECK(hipGetLastError());
+    }
+    return COCOS_OK;
+}
 
 extern "C" int cocos_instnorm_prelu_fwd(const float* x, const float* residual, const float* prelu_weight, float* y,
                                         int planes, int N, float eps, cocos_stream_t stream) {
+    return inp_fwd_impl(x, residual, prelu_weight, y, nullptr, nullptr, planes, N, eps, stream, "instnorm_prelu_fwd");
+}
+
+// ... also leaving max|y| in the caller's cell: *y_amax_inout = max(*y_amax_inout, max|y|) (a cell holding a finite value >= 0) — the
+// scale source of the f16 split of the convolution / projection that reads y next (correspondence.py:21,:25, :272, :282).
+extern "C" int cocos_instnorm_prelu_fwd_amax(const float* x, const float* residual, const float* prelu_weight, float* y,
+                                             float* y_amax_inout_dev, float* amax_partials /* [planes] workspace */, int planes, int N,
+                                             float eps, cocos_stream_t stream) {
+    COCOS_REQUIRE(y_amax_inout_dev && amax_partials, COCOS_ERR_INVALID, "instnorm_prelu_fwd_amax: null pointer");
+    return inp_fwd_impl(x, residual, prelu_weight, y, y_amax_inout_dev, amax_partials, planes, N, eps, stream, "instnorm_prelu_fwd_amax");
+}
+
+static int inp_bwd_impl(const float* x, const float* residual, const float* prelu_weight, const float* dy, float* dx, float* dresidual,
+                        float* da_partials_f32, double* da_partials_f64, float* da_out, float* dx_amax_dev, float* part, int planes, int N,
+                        float eps, cocos_stream_t stream, const char* who) {
     using namespace cocos;
-    COCOS_REQUIRE(x && prelu_weight && y, COCOS_ERR_INVALID, "instnorm_prelu_fwd: null pointer");
-    COCOS_REQUIRE(planes >= 1 && N >= 1, COCOS_ERR_INVALID, "instnorm_prelu_fwd: bad dims planes=%d N=%d", planes, N);
+    COCOS_REQUIRE(x && prelu_weight && dy, COCOS_ERR_INVALID, "%s: null pointer", who);
+    COCOS_REQUIRE(planes >= 1 && N >= 1, COCOS_ERR_INVALID, "%s: bad dims planes=%d N=%d", who, planes, N);
+    COCOS_REQUIRE((da_partials_f64 == nullptr) == (da_out == nullptr) && !(da_partials_f64 && da_partials_f32), COCOS_ERR_INVALID,
+                  "%s: the fp64 partials and their sum go together (and exclude the fp32 partials)", who);
+    COCOS_REQUIRE((reinterpret_cast<uintptr_t>(da_partials_f64) & 7u) == 0, COCOS_ERR_INVALID, "%s: workspace must be 8-byte aligned", who);
+    COCOS_REQUIRE(!dx_amax_dev || dx, COCOS_ERR_INVALID, "%s: max|dx| without dx", who);
     hipStream_t s = as_stream(stream);
-    const bool reg = N <= 256 * 4 * INP_VPT && (N % 4 != 0 || (aligned16(x) && aligned16(y) && (!residual || aligned16(residual))));
-    if (reg && N <= 256 * 4 * 4) hipLaunchKernelGGL((instnorm_prelu_kernel<false, true, 4>), dim3(planes), dim3(256), 0, s, x, residual, nullptr, prelu_weight, y, nullptr, nullptr, N, eps);
-    else if (reg) hipLaunchKernelGGL((instnorm_prelu_kernel<false, true>), dim3(planes), dim3(256), 0, s, x, residual, nullptr, prelu_weight, y, nullptr, nullptr, N, eps);
-    else     hipLaunchKernelGGL((instnorm_prelu_kernel<false, false>), dim3(planes), dim3(256), 0, s, x, residual, nullptr, prelu_weight, y, nullptr, nullptr, N, eps);
+    float* cell = part;
+    const bool reg = N <= 256 * 4 * INP_VPT &&
+                     (N % 4 != 0 || (aligned16(x) && aligned16(dy) && (!residual || aligned16(residual)) && (!dx || aligned16(dx)) &&
+                                     (!dresidual || aligned16(dresidual))));
+    if (da_partials_f64) {
+        void* dap = da_partials_f64;
+        if (reg && N <= 256 * 4 * 4) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true, 4, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps, cell);
+        else if (reg) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true, INP_VPT, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps, cell);
+        else     hipLaunchKernelGGL((instnorm_prelu_kernel<true, false, INP_VPT, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps, cell);
+        COCOS_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(sum_f64_to_f32_kernel, dim3(1), dim3(256), 0, s, da_partials_f64, planes, da_out);
+    } else {
+        void* dap = da_partials_f32;
+        if (reg && N <= 256 * 4 * 4) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true, 4>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps, cell);
+        else if (reg) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps, cell);
+        else     hipLaunchKernelGGL((instnorm_prelu_kernel<true, false>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps, cell);
+    }
     COCOS_HIP_CHECK(hipGetLastError());
+    if (part) {
+        hipLaunchKernelGGL(amax_finish_kernel, dim3(1), dim3(256), 0, s, part, planes, dx_amax_dev);
+        COCOS_HIP_CHECK(hipGetLastError());
+    }
     return COCOS_OK;
 }
 
 extern "C" int cocos_instnorm_prelu_bwd(const float* x, const float* residual, const float* prelu_weight, const float* dy,
                                         float* dx, float* dresidual, float* da_partials /* [planes] */, int planes,
                                         int N, float eps, cocos_stream_t stream) {
-    using namespace cocos;
-    COCOS_REQUIRE(x && prelu_weight && dy, COCOS_ERR_INVALID, "instnorm_prelu_bwd: null pointer");
-    COCOS_REQUIRE(planes >= 1 && N >= 1, COCOS_ERR_INVALID, "instnorm_prelu_bwd: bad dims planes=%d N=%d", planes, N);
-    hipStream_t s = as_stream(stream);
-    const bool reg = N <= 256 * 4 * INP_VPT &&
-                     (N % 4 != 0 || (aligned16(x) && aligned16(dy) && (!residual || aligned16(residual)) && (!dx || aligned16(dx)) &&
-                                     (!dresidual || aligned16(dresidual))));
-    if (reg && N <= 256 * 4 * 4) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true, 4>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, da_partials, N, eps);
-    else if (reg) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, da_partials, N, eps);
-    else     hipLaunchKernelGGL((instnorm_prelu_kernel<true, false>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, da_partials, N, eps);
-    COCOS_HIP_CHECK(hipGetLastError());
-    return COCOS_OK;
+    return inp_bwd_impl(x, residual, prelu_weight, dy, dx, dresidual, da_partials, nullptr, nullptr, nullptr, nullptr, planes, N, eps, stream,
+                        "instnorm_prelu_bwd");
 }
 
 // The same backward with the PReLU weight's gradient accumulated in fp64 end to end: da_partials_f64 = workspace of `planes`
@@ -265,20 +353,18 @@ extern "C" int cocos_instnorm_prelu_bwd(const float* x, const float* residual, c
 extern "C" int cocos_instnorm_prelu_bwd_f64(const float* x, const float* residual, const float* prelu_weight, const float* dy,
                                             float* dx, float* dresidual, double* da_partials_f64, float* da_out, int planes, int N,
                                             float eps, cocos_stream_t stream) {
-    using namespace cocos;
-    COCOS_REQUIRE(x && prelu_weight && dy && da_partials_f64 && da_out, COCOS_ERR_INVALID, "instnorm_prelu_bwd_f64: null pointer");
-    COCOS_REQUIRE(planes >= 1 && N >= 1, COCOS_ERR_INVALID, "instnorm_prelu_bwd_f64: bad dims planes=%d N=%d", planes, N);
-    COCOS_REQUIRE((reinterpret_cast<uintptr_t>(da_partials_f64) & 7u) == 0, COCOS_ERR_INVALID, "instnorm_prelu_bwd_f64: workspace must be 8-byte aligned");
-    hipStream_t s = as_stream(stream);
-    const bool reg = N <= 256 * 4 * INP_VPT &&
-                     (N % 4 != 0 || (aligned16(x) && aligned16(dy) && (!residual || aligned16(residual)) && (!dx || aligned16(dx)) &&
-                                     (!dresidual || aligned16(dresidual))));
-    void* dap = da_partials_f64;
-    if (reg && N <= 256 * 4 * 4) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true, 4, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps);
-    else if (reg) hipLaunchKernelGGL((instnorm_prelu_kernel<true, true, INP_VPT, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps);
-    else     hipLaunchKernelGGL((instnorm_prelu_kernel<true, false, INP_VPT, true>), dim3(planes), dim3(256), 0, s, x, residual, dy, prelu_weight, dx, dresidual, dap, N, eps);
-    COCOS_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(sum_f64_to_f32_kernel, dim3(1), dim3(256), 0, s, da_partials_f64, planes, da_out);
-    COCOS_HIP_CHECK(hipGetLastError());
-    return COCOS_OK;
+    COCOS_REQUIRE(da_partials_f64 && da_out, COCOS_ERR_INVALID, "instnorm_prelu_bwd_f64: null pointer");
+    return inp_bwd_impl(x, residual, prelu_weight, dy, dx, dresidual, nullptr, da_partials_f64, da_out, nullptr, nullptr, planes, N, eps, stream,
+                        "instnorm_prelu_bwd_f64");
+}
+
+// Either backward (da_partials_f64 / da_out both null: no weight gradient) also leaving max|dx| in the caller's cell — dx is the output
+// gradient of the convolution in front of the norm (correspondence.py:20-21, :24-25), whose backward splits it next.
+extern "C" int cocos_instnorm_prelu_bwd_amax(const float* x, const float* residual, const float* prelu_weight, const float* dy,
+                                             float* dx, float* dresidual, double* da_partials_f64, float* da_out, float* dx_amax_inout_dev,
+                                             float* amax_partials /* [planes] workspace */, int planes, int N, float eps,
+                                             cocos_stream_t stream) {
+    COCOS_REQUIRE(dx && dx_amax_inout_dev && amax_partials, COCOS_ERR_INVALID, "instnorm_prelu_bwd_amax: null pointer");
+    return inp_bwd_impl(x, residual, prelu_weight, dy, dx, dresidual, nullptr, da_partials_f64, da_out, dx_amax_inout_dev, amax_partials, planes,
+                        N, eps, stream, "instnorm_prelu_bwd_amax");
 }

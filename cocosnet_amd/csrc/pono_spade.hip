@@ -73,8 +73,10 @@ __global__ __launch_bounds__(256) void pono_spade_reg_kernel(const float* __rest
                                                              float* __restrict__ out0,    // y | dx
                                                              float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, int C, int N,
-                                                             float eps, float slope) {
+                                                             float eps, float slope,
+                                                             float* __restrict__ amax /* nullable: per-workgroup maxima: forward [nwg] max|y|; backward [2][nwg] max|dgamma|, max|dbeta| */) {
     __shared__ __attribute__((aligned(16))) float red[2 * PS_CG * PS_POS + PS_POS];
+    __shared__ float redm[2][4];
     const int tid = threadIdx.x, pq = tid & 7, cg = tid >> 3;
     const int b = blockIdx.y, n = blockIdx.x * PS_POS + pq * 4;
     const size_t sample = (size_t)b * C * N;
@@ -91,22 +93,39 @@ __global__ __launch_bounds__(256) void pono_spade_reg_kernel(const float* __rest
         xn[i] = buf_load4(x_rs, ok ? (unsigned)((cg + PS_CG * i) * N + n) * 4u : kBufOob);
     ps_normalise<NI>(xn, red, cg, pq, C, eps);
 
+    // max|.| of the tensors the next convolutions split (round 6): one value per workgroup (reduced by amax_finish_kernel in the same
+    // entry point — same-address atomics from every wave serialise on the memory side); every lane stays to the end
+    const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+    auto put_amax = [&](int idx, float v) {
+        v = wave_max_dpp(v);
+        if ((tid & 63) == 0) redm[idx][tid >> 6] = v;
+    };
+    auto flush_amax = [&](int n) {      // after the put_amax calls of this workgroup (uniform)
+        __syncthreads();
+        if (tid < n) amax[(size_t)tid * nwg + wg] = fmaxf(fmaxf(redm[tid][0], redm[tid][1]), fmaxf(redm[tid][2], redm[tid][3]));
+    };
     if (!BWD) {
-        if (!ok) return;
         float* yb = out0 + sample;
+        float vm = 0.f;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const unsigned off = (unsigned)((cg + PS_CG * i) * N + n) * 4u;
+            const unsigned off = ok ? (unsigned)((cg + PS_CG * i) * N + n) * 4u : kBufOob;
             const f32x4 g = buf_load4(g_rs, off), bt = buf_load4(b_rs, off);
             f32x4 z = xn[i] * (1.0f + g) + bt;
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[e] = z[e] > 0.f ? z[e] : z[e] * slope;
-            *reinterpret_cast<f32x4*>(yb + (size_t)(cg + PS_CG * i) * N + n) = z;
+            if (ok) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vm = fmaxf(vm, fabsf(z[e]));
+                *reinterpret_cast<f32x4*>(yb + (size_t)(cg + PS_CG * i) * N + n) = z;
+            }
         }
+        if (amax) { put_amax(0, vm); flush_amax(1); }
     } else {
         const f32x4 r = *reinterpret_cast<const f32x4*>(red + 2 * PS_CG * PS_POS + pq * 4);
         f32x4 dxn[NI];
         f32x4 s[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // sum dxn, sum dxn*xn
+        float vmg = 0.f, vmb = 0.f;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const unsigned off = ok ? (unsigned)((cg + PS_CG * i) * N + n) * 4u : kBufOob;
@@ -117,12 +136,23 @@ __global__ __launch_bounds__(256) void pono_spade_reg_kernel(const float* __rest
             for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.f ? dy[e] : dy[e] * slope;
             if (ok) {
                 const size_t o = sample + (size_t)(cg + PS_CG * i) * N + n;
-                if (dgamma) *reinterpret_cast<f32x4*>(dgamma + o) = dz * xn[i];
+                const f32x4 dgv = dz * xn[i];
+                if (dgamma) *reinterpret_cast<f32x4*>(dgamma + o) = dgv;
                 if (dbeta) *reinterpret_cast<f32x4*>(dbeta + o) = dz;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vmg = fmaxf(vmg, fabsf(dgv[e]));
+                    vmb = fmaxf(vmb, fabsf(dz[e]));
+                }
             }
             dxn[i] = dz * (1.0f + g);
             s[0] += dxn[i];
             s[1] += dxn[i] * xn[i];
+        }
+        if (amax) {
+            put_amax(0, dgamma ? vmg : 0.f);
+            put_amax(1, dbeta ? vmb : 0.f);
+            flush_amax(2);
         }
         if (!out0) return;                       // uniform: kernel argument
         ps_reduce<2>(s, red, cg, pq);
@@ -187,19 +217,30 @@ __global__ __launch_bounds__(256) void pono_spade_generic_kernel(const float* __
     }
 }
 
+static bool pono_spade_reg_ok(int C, int N) {
+    if (!(C % PS_CG == 0 && C / PS_CG <= 32 && N % 4 == 0 && (size_t)C * N * 4 < 0x7fffffffull)) return false;
+    switch (C / PS_CG) {
+        case 1: case 2: case 3: case 4: case 6: case 8: case 12: case 16: case 24: case 32: return true;
+        default: return false;
+    }
+}
+
+// amax_part (nullable): the register kernel leaves its per-workgroup maxima there and *wrote_part = true
 template <bool BWD>
 static int pono_spade_launch(const float* x, const float* gamma, const float* beta, const float* dout,
                              float* out0, float* dgamma, float* dbeta, int B, int C, int N, float eps,
-                             float slope, hipStream_t s) {
-    const bool reg = C % PS_CG == 0 && C / PS_CG <= 32 && N % 4 == 0 && (size_t)C * N * 4 < 0x7fffffffull &&
+                             float slope, hipStream_t s, float* amax = nullptr, bool* wrote_part = nullptr) {
+    if (wrote_part) *wrote_part = false;
+    const bool reg = pono_spade_reg_ok(C, N) &&
                      aligned16(x) && aligned16(gamma) && aligned16(beta) && (!BWD || aligned16(dout)) &&
                      (!out0 || aligned16(out0)) && (!dgamma || aligned16(dgamma)) && (!dbeta || aligned16(dbeta));
     if (reg) {
+        if (wrote_part) *wrote_part = amax != nullptr;
         const dim3 grid((N + PS_POS - 1) / PS_POS, B);
 #define COCOS_PS(NI)                                                                                      \
     case NI:                                                                                              \
         hipLaunchKernelGGL((pono_spade_reg_kernel<NI, BWD>), grid, dim3(256), 0, s, x, gamma, beta, dout, \
-                           out0, dgamma, dbeta, C, N, eps, slope);                                        \
+                           out0, dgamma, dbeta, C, N, eps, slope, amax);                                  \
         break;
         switch (C / PS_CG) {
             COCOS_PS(1) COCOS_PS(2) COCOS_PS(3) COCOS_PS(4) COCOS_PS(6) COCOS_PS(8) COCOS_PS(12) COCOS_PS(16)
@@ -215,6 +256,21 @@ static int pono_spade_launch(const float* x, const float* gamma, const float* be
     }
     COCOS_HIP_CHECK(hipGetLastError());
     return COCOS_OK;
+}
+
+// cells[j] = max(cells[j], max part[j][0..n)), j = blockIdx.x
+__global__ __launch_bounds__(256) void pono_amax_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ cells) {
+    __shared__ float redm[4];
+    const float* p = part + (size_t)blockIdx.x * n;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, p[i]);
+    m = wave_max_dpp(m);
+    if ((threadIdx.x & 63) == 0) redm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        if (m > cells[blockIdx.x] && m < INFINITY) cells[blockIdx.x] = m;
+    }
 }
 
 }  // namespace cocos
@@ -238,4 +294,54 @@ extern "C" int cocos_pono_spade_bwd(const float* x, const float* gamma, const fl
                   "pono_spade_bwd: bad dims B=%d C=%d N=%d (unbiased variance needs C >= 2)", B, C, N);
     return pono_spade_launch<true>(x, gamma, beta, dy, dx, dgamma, dbeta, B, C, N, eps, slope,
                                    as_stream(stream));
+}
+
+// Round 6: the same passes also leaving max|.| of what the next convolutions split into f16 planes (*cell = max(*cell, max|.|); cells
+// holding finite values >= 0): the forward's y (the input of conv_0 / conv_1 / conv_s, architecture.py:88-95), the backward's
+// dgamma and dbeta (the output gradients of SPADE's mlp_gamma / mlp_beta, normalization.py:121-127): amax2 = [max|dgamma|, max|dbeta|].
+// amax_partials: cocos_pono_spade_amax_partials() floats (forward), twice that (backward) — one maximum per workgroup, reduced by a
+// small kernel of the same call; shapes on the generic kernel take cocos_absmax_accumulate passes instead (same result).
+extern "C" int cocos_pono_spade_amax_partials(int B, int C, int N) {
+    if (B < 1 || C < 2 || N < 1) return 0;
+    return ((N + cocos::PS_POS - 1) / cocos::PS_POS) * B;
+}
+
+extern "C" int cocos_pono_spade_fwd_amax(const float* x, const float* gamma, const float* beta, float* y, float* y_amax_inout_dev,
+                                         float* amax_partials, int B, int C, int N, float eps, float slope, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && gamma && beta && y && y_amax_inout_dev && amax_partials, COCOS_ERR_INVALID, "pono_spade_fwd_amax: null pointer");
+    COCOS_REQUIRE(B >= 1 && B <= 65535 && C >= 2 && N >= 1, COCOS_ERR_INVALID,
+                  "pono_spade_fwd_amax: bad dims B=%d C=%d N=%d (unbiased variance needs C >= 2)", B, C, N);
+    bool wrote = false;
+    const int rc = pono_spade_launch<false>(x, gamma, beta, nullptr, y, nullptr, nullptr, B, C, N, eps, slope, as_stream(stream),
+                                            amax_partials, &wrote);
+    if (rc != COCOS_OK) return rc;
+    if (!wrote) return cocos_absmax_accumulate(y, (long long)B * C * N, y_amax_inout_dev, stream);
+    hipLaunchKernelGGL(pono_amax_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), amax_partials,
+                       cocos_pono_spade_amax_partials(B, C, N), y_amax_inout_dev);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
+}
+
+extern "C" int cocos_pono_spade_bwd_amax(const float* x, const float* gamma, const float* beta, const float* dy, float* dx, float* dgamma,
+                                         float* dbeta, float* amax2_inout_dev, float* amax_partials, int B, int C, int N, float eps,
+                                         float slope, cocos_stream_t stream) {
+    using namespace cocos;
+    COCOS_REQUIRE(x && gamma && beta && dy && amax2_inout_dev && amax_partials, COCOS_ERR_INVALID, "pono_spade_bwd_amax: null pointer");
+    COCOS_REQUIRE(B >= 1 && B <= 65535 && C >= 2 && N >= 1, COCOS_ERR_INVALID,
+                  "pono_spade_bwd_amax: bad dims B=%d C=%d N=%d (unbiased variance needs C >= 2)", B, C, N);
+    bool wrote = false;
+    const int rc = pono_spade_launch<true>(x, gamma, beta, dy, dx, dgamma, dbeta, B, C, N, eps, slope, as_stream(stream), amax_partials,
+                                           &wrote);
+    if (rc != COCOS_OK) return rc;
+    if (!wrote) {
+        const long long n = (long long)B * C * N;
+        int r2 = dgamma ? cocos_absmax_accumulate(dgamma, n, amax2_inout_dev, stream) : COCOS_OK;
+        if (r2 == COCOS_OK && dbeta) r2 = cocos_absmax_accumulate(dbeta, n, amax2_inout_dev + 1, stream);
+        return r2;
+    }
+    hipLaunchKernelGGL(pono_amax_finish_kernel, dim3(2), dim3(256), 0, as_stream(stream), amax_partials,
+                       cocos_pono_spade_amax_partials(B, C, N), amax2_inout_dev);
+    COCOS_HIP_CHECK(hipGetLastError());
+    return COCOS_OK;
 }

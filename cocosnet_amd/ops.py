@@ -958,6 +958,18 @@ def _zero_cell(device) -> torch.Tensor:
     return cell
 
 
+def _zero_cells(device, n: int) -> torch.Tensor:
+    """n CONSECUTIVE cells of the pool above (a kernel that leaves several maxima takes one pointer)."""
+    pool = _tls.zero_pool
+    key = (device, _stream())
+    ent = pool.get(key)
+    if ent is None or ent[1] + n > ent[0].numel():
+        ent = pool[key] = [torch.zeros(4096, device=device, dtype=torch.float32), 0]
+    cells = ent[0][ent[1]:ent[1] + n]
+    ent[1] += n
+    return cells
+
+
 def absmax(x: torch.Tensor) -> torch.Tensor:
     """max|x| as a 1-element CUDA tensor (one pass, no host sync) — the scale source of the f16 splits."""
     x = _chk(x, "absmax: x")
@@ -2386,8 +2398,15 @@ class _PonoSpade(torch.autograd.Function):
         B, C = x.shape[:2]
         N = x.numel() // (B * C)
         y = torch.empty_like(x)
-        _call("pono_spade_fwd", "cocos_pono_spade_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-              y.data_ptr(), B, C, N, float(eps), float(slope), _stream())
+        if CONV_PRECISION == "f16x3":         # max|y| as a by-product: y is the input of the block's next convolution
+            cell = _zero_cell(x.device)
+            part = torch.empty(_lib.load().cocos_pono_spade_amax_partials(B, C, N), device=x.device, dtype=torch.float32)
+            _call("pono_spade_fwd", "cocos_pono_spade_fwd_amax", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                  cell.data_ptr(), part.data_ptr(), B, C, N, float(eps), float(slope), _stream())
+            _remember_amax(y, cell, weak=True)
+        else:
+            _call("pono_spade_fwd", "cocos_pono_spade_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                  y.data_ptr(), B, C, N, float(eps), float(slope), _stream())
         ctx.save_for_backward(x, gamma, beta)
         ctx.cfg = (float(slope), float(eps))
         return y
@@ -2403,8 +2422,19 @@ class _PonoSpade(torch.autograd.Function):
         dx = torch.empty_like(x) if need_x else None
         dg = torch.empty_like(x) if need_g else None
         db = torch.empty_like(x) if need_b else None
-        _call("pono_spade_bwd", "cocos_pono_spade_bwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-              dy.data_ptr(), _ptr(dx), _ptr(dg), _ptr(db), B, C, N, eps, slope, _stream())
+        if (dg is not None or db is not None) and CONV_PRECISION == "f16x3":
+            # max|dgamma| / max|dbeta| as by-products: the output gradients of SPADE's mlp_gamma / mlp_beta convolutions
+            cells = _zero_cells(x.device, 2)
+            part = torch.empty(2 * _lib.load().cocos_pono_spade_amax_partials(B, C, N), device=x.device, dtype=torch.float32)
+            _call("pono_spade_bwd", "cocos_pono_spade_bwd_amax", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dy.data_ptr(), _ptr(dx),
+                  _ptr(dg), _ptr(db), cells.data_ptr(), part.data_ptr(), B, C, N, eps, slope, _stream())
+            if dg is not None:
+                _remember_amax(dg, cells[0:1], weak=True)
+            if db is not None:
+                _remember_amax(db, cells[1:2], weak=True)
+        else:
+            _call("pono_spade_bwd", "cocos_pono_spade_bwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                  dy.data_ptr(), _ptr(dx), _ptr(dg), _ptr(db), B, C, N, eps, slope, _stream())
         return dx, dg, db, None, None
 
 
@@ -2605,8 +2635,16 @@ class _InstNormPReLU(torch.autograd.Function):
         B, C = x.shape[:2]
         N = x.numel() // (B * C)
         y = torch.empty_like(x)
-        _call("instnorm_prelu_fwd", "cocos_instnorm_prelu_fwd", x.data_ptr(), _ptr(res), w.data_ptr(), y.data_ptr(),
-              B * C, N, float(eps), _stream())
+        if CONV_PRECISION == "f16x3":
+            # max|y| as a by-product: y is the next convolution's (or the projections') input, split with that scale
+            cell = _zero_cell(x.device)
+            part = torch.empty(B * C, device=x.device, dtype=torch.float32)       # one maximum per plane, reduced by the same call
+            _call("instnorm_prelu_fwd", "cocos_instnorm_prelu_fwd_amax", x.data_ptr(), _ptr(res), w.data_ptr(), y.data_ptr(), cell.data_ptr(),
+                  part.data_ptr(), B * C, N, float(eps), _stream())
+            _remember_amax(y, cell, weak=True)
+        else:
+            _call("instnorm_prelu_fwd", "cocos_instnorm_prelu_fwd", x.data_ptr(), _ptr(res), w.data_ptr(), y.data_ptr(),
+                  B * C, N, float(eps), _stream())
         ctx.save_for_backward(x, res, w)
         ctx.eps = float(eps)
         return y
@@ -2620,17 +2658,26 @@ class _InstNormPReLU(torch.autograd.Function):
         need_x, need_r, need_w = ctx.needs_input_grad[:3]
         dx = torch.empty_like(x) if need_x else None
         dr = torch.empty_like(x) if (need_r and res is not None) else None
+        dap = dw = None
         if need_w:
             # the weight's gradient is ONE number summed over every element of the layer, with cancelling terms: fp64 from the
             # products to the last addition (cocos_instnorm_prelu_bwd_f64; in fp32 it was up to 90x further from fp64 than the framework's)
             dap = torch.empty(B * C, device=x.device, dtype=torch.float64)
             dw = torch.empty(1, device=x.device, dtype=torch.float32)
+        if dx is not None and CONV_PRECISION == "f16x3":
+            # max|dx| as a by-product: dx is the output gradient of the convolution in front of the norm, whose backward splits it next
+            cell = _zero_cell(x.device)
+            part = torch.empty(B * C, device=x.device, dtype=torch.float32)
+            _call("instnorm_prelu_bwd", "cocos_instnorm_prelu_bwd_amax", x.data_ptr(), _ptr(res), w.data_ptr(), dy.data_ptr(), dx.data_ptr(),
+                  _ptr(dr), _ptr(dap), _ptr(dw), cell.data_ptr(), part.data_ptr(), B * C, N, ctx.eps, _stream())
+            _remember_amax(dx, cell, weak=True)
+        elif need_w:
             _call("instnorm_prelu_bwd", "cocos_instnorm_prelu_bwd_f64", x.data_ptr(), _ptr(res), w.data_ptr(), dy.data_ptr(),
                   _ptr(dx), _ptr(dr), dap.data_ptr(), dw.data_ptr(), B * C, N, ctx.eps, _stream())
-            return dx, dr, dw.reshape(w.shape), None
-        _call("instnorm_prelu_bwd", "cocos_instnorm_prelu_bwd", x.data_ptr(), _ptr(res), w.data_ptr(), dy.data_ptr(),
-              _ptr(dx), _ptr(dr), None, B * C, N, ctx.eps, _stream())
-        return dx, dr, None, None
+        else:
+            _call("instnorm_prelu_bwd", "cocos_instnorm_prelu_bwd", x.data_ptr(), _ptr(res), w.data_ptr(), dy.data_ptr(),
+                  _ptr(dx), _ptr(dr), None, B * C, N, ctx.eps, _stream())
+        return dx, dr, (dw.reshape(w.shape) if need_w else None), None
 
 
 def instnorm_prelu(x, residual, weight, eps: float = INSTNORM_EPS):

@@ -517,6 +517,16 @@ int cocos_pono_spade_fwd(const float* x, const float* gamma, const float* beta, 
 int cocos_pono_spade_bwd(const float* x, const float* gamma, const float* beta, const float* dy,
                          float* dx, float* dgamma, float* dbeta,
                          int B, int C, int N, float eps, float slope, cocos_stream_t stream);
+/* Round 6: the same passes also leaving max|.| of the tensors the next convolutions split (*cell = max(*cell, max|.|); cells holding
+ * finite values >= 0): the forward's y — the input of conv_0 / conv_1 / conv_s (architecture.py:88-95) — and the backward's dgamma /
+ * dbeta — the output gradients of SPADE's mlp_gamma / mlp_beta (normalization.py:121-127): amax2 = [max|dgamma|, max|dbeta|].
+ * amax_partials = workspace of cocos_pono_spade_amax_partials(B, C, N) floats (forward) resp. twice that (backward). */
+int cocos_pono_spade_amax_partials(int B, int C, int N);
+int cocos_pono_spade_fwd_amax(const float* x, const float* gamma, const float* beta, float* y, float* y_amax_inout_dev,
+                              float* amax_partials, int B, int C, int N, float eps, float slope, cocos_stream_t stream);
+int cocos_pono_spade_bwd_amax(const float* x, const float* gamma, const float* beta, const float* dy,
+                              float* dx, float* dgamma, float* dbeta, float* amax2_inout_dev, float* amax_partials,
+                              int B, int C, int N, float eps, float slope, cocos_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K11 nearest-neighbour up-sampling of the warped image (self.upsampling = nn.Upsample(scale_factor=down),
@@ -818,6 +828,17 @@ int cocos_instnorm_prelu_bwd(const float* x, const float* residual, const float*
 int cocos_instnorm_prelu_bwd_f64(const float* x, const float* residual, const float* prelu_weight, const float* dy, float* dx,
                                  float* dresidual, double* da_partials_f64, float* da_out, int planes, int N, float eps,
                                  cocos_stream_t stream);
+/* Round 6: the same two passes also leaving max|out| in a device cell (*cell = max(*cell, max|.|); the cell must hold a finite value
+ * >= 0) — y is the input of the next convolution / projection (correspondence.py:21, :25, :272, :282) and dx the output gradient of the
+ * convolution in front of the norm (:20, :24): both are split into f16 hi / lo planes scaled by that maximum, which used to cost a
+ * pass over the tensor each (cocos_absmax).  amax_partials = workspace of `planes` floats: one maximum per plane, reduced into the cell
+ * by a one-workgroup kernel of the same call (same-address atomics from 13 k waves serialise at ~10 ns each: measured 5x slower).
+ * _bwd_amax: da_partials_f64 / da_out both NULL = no PReLU-weight gradient. */
+int cocos_instnorm_prelu_fwd_amax(const float* x, const float* residual, const float* prelu_weight, float* y, float* y_amax_inout_dev,
+                                  float* amax_partials, int planes, int N, float eps, cocos_stream_t stream);
+int cocos_instnorm_prelu_bwd_amax(const float* x, const float* residual, const float* prelu_weight, const float* dy, float* dx,
+                                  float* dresidual, double* da_partials_f64, float* da_out, float* dx_amax_inout_dev, float* amax_partials,
+                                  int planes, int N, float eps, cocos_stream_t stream);
 
 /* Debug: runs one v_mfma_f32_32x32x2_f32 with known operands and dumps the 64x16 accumulator
  * registers to out[64*16] so the host can verify the lane/register -> (row, col) map. */
