@@ -683,15 +683,12 @@ def main():
     # its launch time measured live over the timed region) — every bracketed call costs two marker packets that serialise
     # dispatch, and six per step were 2-3 % of `value`.  Which kernel that is comes from one fully-bracketed, untimed step;
     # the other hot kernels' live averages come from a second window of the same length right after the headline one.
-    with ops.KernelTimer(tags=HOT_TAGS) as kt_probe:
-        for _ in range(5):       # (five steps: one step's ranking of two kernels 10 % apart flipped on a box whose clocks were still ramping)
-            step()
-    probe = kt_probe.summary()
-    # (round 6: ONE kernel stays bracketed — since the forward's QK loop accumulates in one chain the query backward is the longest
-    #  by > 10 %, a ranking a single probe step gets right; the second bracket cost another 1.4 % of `value`)
-    # ranked by the SHORTEST bracket of each kernel over the probe steps: an event pair also spans the host's launch latency whenever the
-    # queue runs dry in front of it (the forward sits where the step's Python work is), which inflated the forward's average past the
-    # query backward's on some boxes; the minimum is the kernel itself
+    # the probe is a steady-state window of its own (30 steps after 5 unbracketed ones, all three MFMA kernels bracketed): on an idle
+    # queue an event pair also spans the host's launch latency, and a five-step probe right after a synchronisation ranked the forward
+    # above the query backward on some boxes
+    _, probe = window(30, 5, tags=HOT_TAGS)
+    # (round 6: ONE kernel stays bracketed in the timed window — since the forward's QK loop accumulates in one chain the query backward is
+    #  the longest by > 10 %; the second bracket cost another 1.4 % of `value`).  Ranked by the SHORTEST bracket: the kernel itself
     dom_tags = tuple(sorted(probe, key=lambda t: -probe[t].get("min_ms", probe[t]["avg_ms"]))[:1])
     dom_tag = dom_tags[0] if dom_tags else None
     dt, kern = window(args.steps, args.warmup, tags=dom_tags if dom_tags else HOT_TAGS)
