@@ -36,7 +36,7 @@ __global__ void mfma_probe_kernel(float* out) {
 
 }  // namespace cocos
 
-extern "C" int cocos_version(void) { return 610; /* 0.6.1 (round 6): K24 / K25 — cocos_proj_bwd_input_f16x3 / _planes_f16x3, cocos_proj_raw_planes_stats_f16x3, cocos_proj1x1_dw_affine(_pair)_f16x3, pair / multi launches (cocos_absmax4, cocos_proj_weight_prep_pair, cocos_split_f16_transpose_pair, cocos_unfold3_stats_finish_pair / _bwd_maps_pair), cocos_warp_head_fwd / _bwd, cocos_instnorm_prelu_bwd_f64; 0.6.0: K23 — cocos_proj_center_l2norm_planes_f16x3 / cocos_proj_weight_frag_planes (K0 fused with K1); 0.5.2 (round 5): K22 — cocos_contextual_cx_fwd_f16x3 / _bwd_f16x3 / cocos_contextual_cx_coeffs (the contextual loss without its [N, N] matrices); the convolutions' operand planes are split round-to-nearest; 0.5.1 (round 4): `flags` on the K19 entry points (transposed T, accumulated G), `_ex` K2 entry points (magnitude-free flavour, k_active, d_pre), cocos_rowdot_f64, 128-wide box3 grids; 0.5.0 (round 3): K19/K20 box3 fused family, K1 planes, plane preparation, device-side operand scales, K16b NHWC bf16 convolution, cocos_channel_sum takes a partials buffer; 0.4.0 (round 2): K2 split kernels take a device-side V scale and a private saved-logits layout (signatures changed); K15 contextual rows; K16 convolution */ }
+extern "C" int cocos_version(void) { return 620; /* 0.6.2 (round 6): cocos_instnorm_prelu_fwd_amax / _bwd_amax, cocos_pono_spade_fwd_amax / _bwd_amax / _amax_partials (K13 / K9 leave max|.| for the next convolution); 0.6.1: K24 / K25 — cocos_proj_bwd_input_f16x3 / _planes_f16x3, cocos_proj_raw_planes_stats_f16x3, cocos_proj1x1_dw_affine(_pair)_f16x3, pair / multi launches (cocos_absmax4, cocos_proj_weight_prep_pair, cocos_split_f16_transpose_pair, cocos_unfold3_stats_finish_pair / _bwd_maps_pair), cocos_warp_head_fwd / _bwd, cocos_instnorm_prelu_bwd_f64; 0.6.0: K23 — cocos_proj_center_l2norm_planes_f16x3 / cocos_proj_weight_frag_planes (K0 fused with K1); 0.5.2 (round 5): K22 — cocos_contextual_cx_fwd_f16x3 / _bwd_f16x3 / cocos_contextual_cx_coeffs (the contextual loss without its [N, N] matrices); the convolutions' operand planes are split round-to-nearest; 0.5.1 (round 4): `flags` on the K19 entry points (transposed T, accumulated G), `_ex` K2 entry points (magnitude-free flavour, k_active, d_pre), cocos_rowdot_f64, 128-wide box3 grids; 0.5.0 (round 3): K19/K20 box3 fused family, K1 planes, plane preparation, device-side operand scales, K16b NHWC bf16 convolution, cocos_channel_sum takes a partials buffer; 0.4.0 (round 2): K2 split kernels take a device-side V scale and a private saved-logits layout (signatures changed); K15 contextual rows; K16 convolution */ }
 
 extern "C" const char* cocos_last_error_string(void) { return cocos::last_error().c_str(); }
 
