@@ -27,6 +27,18 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #endif
 constexpr int HG_BM = 256, HG_BN = 128, HG_BK = 32;
 constexpr int HG_ROW = HG_BK + 8;   // halfs per LDS row
+// A tile (round 6): 64-byte rows, the 16-byte chunk of a row XOR-swizzled by (row >> 2) & 3.  With the padded 80-byte rows the staging
+// writes (four lanes per row: 16 lanes = rows r .. r + 3) put rows r and r + 3 onto 12 common banks — PMC: 8.4 M LDS conflict cycles per
+// launch, 9 % of its time; here a 16-lane group writes 256 contiguous bytes and the fragment reads of 16 consecutive rows still fall
+// into 16 distinct 4-bank groups.  (Re-mapping the lanes instead — one chunk of 16 rows per 16 lanes — made the GLOBAL loads of the tile
+// 16-byte pieces of 16 different rows: 0.175 -> 0.200 ms.)  -DHG_A_PADDED keeps the old rows.  The tile's LDS region keeps its size.
+#ifdef HG_A_PADDED
+constexpr int HG_AROW = HG_ROW;
+__device__ __forceinline__ int hg_a_chunk(int row, int kc) { return kc; }
+#else
+constexpr int HG_AROW = HG_BK;
+__device__ __forceinline__ int hg_a_chunk(int row, int kc) { return kc ^ ((row >> 2) & 3); }
+#endif
 
 // EXACT: M % 256 == 0, N % 128 == 0, K % 32 == 0 — no bounds tests at all.  With them hipcc wraps every staged load in
 // an exec-mask region (s_and_saveexec / s_or per load: ~120 scalar instructions per k-step of 96 MFMAs).
@@ -153,8 +165,8 @@ __global__ __launch_bounds__(256, DUO ? 2 : 1) void hgemm_f16x3_kernel(const _Fl
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
-            *reinterpret_cast<u32x4*>(ab + row * HG_ROW + kc * 8) = st.a[0][u];
-            *reinterpret_cast<u32x4*>(ab + APLANE + row * HG_ROW + kc * 8) = st.a[1][u];
+            *reinterpret_cast<u32x4*>(ab + row * HG_AROW + hg_a_chunk(row, kc) * 8) = st.a[0][u];
+            *reinterpret_cast<u32x4*>(ab + APLANE + row * HG_AROW + hg_a_chunk(row, kc) * 8) = st.a[1][u];
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256, DUO ? 2 : 1) void hgemm_f16x3_kernel(const _Fl
         if (idx < 8) {                                   // A: plane idx & 1, chunk idx >> 1
             const int pl = idx & 1, u = idx >> 1;
             const int g = u * 256 + tid, row = g >> 2, kc = g & 3;
-            *reinterpret_cast<u32x4*>(ab + pl * APLANE + row * HG_ROW + kc * 8) = st.a[pl][u];
+            *reinterpret_cast<u32x4*>(ab + pl * APLANE + row * HG_AROW + hg_a_chunk(row, kc) * 8) = st.a[pl][u];
             unsigned off = (unsigned)((m0 + row) * K + k0 + kc * 8) * 2u;
             if (!EXACT && (m0 + row >= M || k0 + kc * 8 >= K)) off = kBufOob;
             st.a[pl][u] = __builtin_amdgcn_raw_buffer_load_b128(pl ? al_rs : ah_rs, (int)off, 0, 0);
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(256, DUO ? 2 : 1) void hgemm_f16x3_kernel(const _Fl
     const int tr_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * HG_GROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     auto step = [&](int t, Stage& st) {
         const int buf = DUO ? 0 : (t & 1);
-        const _Float16* ab = at + buf * 2 * APLANE + (wm * 128 + c) * HG_ROW + h * 8;
+        const _Float16* ab = at + buf * 2 * APLANE + (wm * 128 + c) * HG_AROW;      // (+ the swizzled chunk 2 s + h of the step)
         const _Float16* bb = bt + buf * 2 * BPLANE + (BMODE == 2 ? wn * 64 + tr_off : (wn * 64 + c) * HG_ROW + h * 8);
 #pragma unroll
         for (int s = 0; s < HG_BK / 16; ++s) {
@@ -224,8 +236,9 @@ __global__ __launch_bounds__(256, DUO ? 2 : 1) void hgemm_f16x3_kernel(const _Fl
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const f16x8 avh = *reinterpret_cast<const f16x8*>(ab + i * 32 * HG_ROW + s * 16);
-                const f16x8 avl = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * HG_ROW + s * 16);
+                const int ach = hg_a_chunk(c, 2 * s + h) * 8;          // ((row >> 2) & 3 of row = wm*128 + c + 32 i is that of c)
+                const f16x8 avh = *reinterpret_cast<const f16x8*>(ab + i * 32 * HG_AROW + ach);
+                const f16x8 avl = *reinterpret_cast<const f16x8*>(ab + APLANE + i * 32 * HG_AROW + ach);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (!(HG_ABLATE & 4) && (EXACT || i < rows_live)) {     // (ragged M: a wave-uniform branch around the MFMAs of all-padding row tiles)
