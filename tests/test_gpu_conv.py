@@ -350,8 +350,11 @@ def test_reflect_pad2d_matches_torch(shape, pad):
     assert torch.equal(y, yr)
     go = torch.randn(y.shape, device="cuda", generator=g)
     y.backward(go)
-    yr.backward(go)
-    assert (x.grad - xr.grad).abs().max().item() <= 1e-6 * max(xr.grad.abs().max().item(), 1.0)
+    # arbiter of the backward: the framework's CPU kernel in fp64 (its GPU kernel under torch.use_deterministic_algorithms — the
+    # COCOS_POISON_EMPTY=1 run of this suite — returns wrong sums where several mirrored pixels fold onto one: (4, 4) pad 3 off by 2.8)
+    xc = x.detach().cpu().double().requires_grad_(True)
+    (F.pad(xc, (pad,) * 4, mode="reflect") if pad else xc * 1.0).backward(go.cpu().double())
+    assert (x.grad.cpu().double() - xc.grad).abs().max().item() <= 1e-6 * max(xc.grad.abs().max().item(), 1.0)
     with pytest.raises(ValueError):
         ops.reflect_pad2d(x.detach(), min(shape[2:]))
 
