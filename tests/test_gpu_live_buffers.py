@@ -116,3 +116,72 @@ def test_contextual_loss_hands_over_live_buffers_only(hip_lib, monkeypatch):
         monkeypatch.setattr("cocosnet_amd.contextual.ROUTE", route, raising=False)
         ContextualLoss_forward(SimpleNamespace(PONO=True))(x, y).sum().backward()
     guard.check(4, 20)
+
+
+@pytest.mark.parametrize("flavour", ["cycle_mk3", "cycle_mk1", "two_cycle_mk3", "warp_patch_mk3", "eager_mk3", "eager_mk1", "novgg_mask_mk1"])
+def test_other_configurations_of_the_path_hand_over_live_buffers_only(flavour, hip_lib, monkeypatch):
+    """The branches the BASELINE configurations take besides the bench's: cycle passes (CelebA-HQ: --warp_cycle_w, --two_cycle), --warp_patch
+    (DeepFashion), projections computed eagerly (K0 + K1 / K12 instead of K23 / K25), and a second step on the same tensors (the
+    operand-plane and max|x| caches carry entries from the first)."""
+    from cocosnet_amd import ops
+    from cocosnet_amd.hot_path import HotPathConfig, correspondence_hot_path
+    mk = 1 if flavour.endswith("mk1") else 3
+    B, Cin, fh, fw, down, nc = 2, 64 + 7, 16, 64, 4, 7
+    g = torch.Generator(device=DEV).manual_seed(11)
+    mkp = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    H, W = fh * down, fw * down
+    leaves = [mkp(B, Cin, fh, fw), mkp(256, Cin, 1, 1) / Cin ** 0.5, mkp(256) * 0.1,
+              mkp(B, Cin, fh, fw), mkp(256, Cin, 1, 1) / Cin ** 0.5, mkp(256) * 0.1]
+    leaves = [t.requires_grad_(True) for t in leaves]
+    ref_img = torch.rand(B, 3, H, W, device=DEV, generator=g) * 2 - 1
+    real_img = torch.rand(B, 3, H, W, device=DEV, generator=g) * 2 - 1
+    lab = torch.randint(0, nc, (B, 1, H, W), device=DEV, generator=g)
+    seg = torch.zeros(B, nc, H, W, device=DEV).scatter_(1, lab, 1.0)
+    kw = dict(match_kernel=mk, PONO_C=True, down=down, isTrain=True)
+    if flavour.startswith("cycle"):
+        kw.update(warp_cycle_w=1.0)
+    elif flavour.startswith("two_cycle"):
+        kw.update(warp_cycle_w=1.0, two_cycle=True)
+    elif flavour.startswith("warp_patch"):
+        kw.update(warp_patch=True)
+    elif flavour.startswith("novgg_mask"):
+        kw.update(warp_mask_losstype="direct")
+    else:
+        kw.update(warp_mask_losstype="direct")
+    cfg = HotPathConfig(**kw)
+    guard = _Guard(monkeypatch)
+    for _ in range(2):
+        for t in leaves:
+            t.grad = None
+        if flavour.startswith("eager"):
+            th, ph = ops.proj1x1(*leaves[:3]), ops.proj1x1(*leaves[3:])
+        else:
+            th, ph = ops.LazyProj1x1(*leaves[:3]), ops.LazyProj1x1(*leaves[3:])
+        out = correspondence_hot_path(th, ph, ref_img, real_img, seg, seg, cfg)
+        roots = [v for k, v in sorted(out.items()) if torch.is_tensor(v) and v.requires_grad and v.dtype == torch.float32]
+        assert roots, sorted(out)
+        torch.autograd.backward(roots, [torch.ones_like(r) for r in roots])
+    guard.check(16, 80)
+
+
+def test_config3_networks_hand_over_live_buffers_only(hip_lib, monkeypatch):
+    """The SPADE generator and the PatchGAN of BASELINE config 3 (translation.py: convolutions, SPADE / PONO norms, Attention, spectral
+    norm) — a training step each."""
+    from cocosnet_amd import translation as tl
+    opt = tl.celebahq_edge_train_options()
+    B, IMG = 2, 256
+    g = torch.Generator(device=DEV).manual_seed(77)
+    seg = torch.rand(B, 15, IMG, IMG, device=DEV, generator=g)
+    cbn = torch.cat((torch.rand(B, 3, IMG, IMG, device=DEV, generator=g) * 2 - 1, seg), 1)
+    real = torch.rand(B, 3, IMG, IMG, device=DEV, generator=g) * 2 - 1
+    torch.manual_seed(0)
+    G = tl.SPADEGenerator(opt).to(DEV)
+    G.init_weights(opt.init_type, opt.init_variance)
+    D = tl.MultiscaleDiscriminator(opt).to(DEV)
+    D.init_weights(opt.init_type, opt.init_variance)
+    G.train(); D.train()
+    guard = _Guard(monkeypatch)
+    G(seg, warp_out=cbn).sum().backward()
+    res = D(torch.cat((seg, real), 1))[0]
+    torch.autograd.backward([r[-1] for r in res], [torch.ones_like(r[-1]) for r in res])
+    guard.check(200, 1000)
