@@ -285,6 +285,10 @@ class SPADEResnetBlock(nn.Module):
         return norm(x, seg, slope=self.slope)
 
     def forward(self, x, seg):
+        # ONE nearest resize of the label map for the block's two or three SPADEs (the reference resizes inside each,
+        # normalization.py:133: same values; spade.spade_forward skips it when the grids already agree)
+        if seg.shape[2:] != x.shape[2:]:
+            seg = nn.functional.interpolate(seg, size=x.size()[2:], mode="nearest")
         x_s = self.conv_s(self.norm_s(x, seg)) if self.learned_shortcut else x
         dx = reflect_conv(self.pad, self.conv_0, self._norm_act(self.norm_0, x, seg))         # norm -> LeakyReLU(0.2) -> pad -> conv
         dx = reflect_conv(self.pad, self.conv_1, self._norm_act(self.norm_1, dx, seg))

@@ -53,7 +53,8 @@ def spade_forward(self, x, segmap, similarity_map=None, slope: float = 1.0):
     """Drop-in for `SPADE.forward(x, segmap, similarity_map=None)` (normalization.py:129-151); works on the reference's
     module instances (attributes param_free_norm, mlp_shared, pad, mlp_gamma, mlp_beta, pad_type).  `slope`: negative
     slope of the LeakyReLU the caller would apply next (1.0 = none)."""
-    segmap = F.interpolate(segmap, size=x.size()[2:], mode="nearest")
+    if segmap.shape[2:] != x.shape[2:]:      # (spade_resnet_block_forward resizes once for the block's two or three SPADEs)
+        segmap = F.interpolate(segmap, size=x.size()[2:], mode="nearest")
     actv = shared_activation(self, segmap)
     if getattr(self, "pad_type", "nozero") != "zero":
         actv = self.pad(actv)
@@ -71,6 +72,11 @@ def spade_forward(self, x, segmap, similarity_map=None, slope: float = 1.0):
 def spade_resnet_block_forward(self, x, seg1):
     """Drop-in for `SPADEResnetBlock.forward` (architecture.py:70-95): same sub-module calls in the same order, with
     the two `actvn(norm_k(...))` pairs as one fused call each."""
+    # the reference resizes the label map inside every SPADE (normalization.py:133): the block's SPADEs all see x's grid (its
+    # convolutions keep the size), so ONE nearest resize serves them — and the convolutions that read it find its max|.| from the
+    # first one (per module step: 24 resize kernels and as many max|.| passes less)
+    if seg1.shape[2:] != x.shape[2:]:
+        seg1 = F.interpolate(seg1, size=x.size()[2:], mode="nearest")
     x_s = self.conv_s(self.norm_s(x, seg1)) if self.learned_shortcut else x            # :97-102
     pad = self.pad if getattr(self, "pad_type", "nozero") != "zero" else (lambda t: t)
     dx = self.conv_0(pad(self.norm_0(x, seg1, slope=LEAKY_SLOPE)))
