@@ -902,7 +902,8 @@ class _ThreadState(threading.local):
 
 
 _tls = _ThreadState()
-_KNOWN_AMAX_MAX = 8      # entries per thread
+_KNOWN_AMAX_MAX = 8      # entries per thread that hold their tensor
+_KNOWN_AMAX_WEAK_MAX = 48      # ... and entries that only watch theirs (see _remember_amax)
 
 
 #: tensors at least this large are remembered through a weak reference only (see _remember_amax)
@@ -919,11 +920,22 @@ def _remember_amax(t: torch.Tensor, cell: torch.Tensor, weak: bool = False):
     several passes' gradients out of place.  A dead weak reference means the tensor was summed into another one or
     freed: the entry is void and the consumer takes its own max|.| pass — never a stale value."""
     table = _tls.known_amax
-    while len(table) >= _KNOWN_AMAX_MAX:
-        table.pop(next(iter(table)), None)
     # (weak = True: the entry must not keep `t` alive whatever its size — a convolution's INPUT remembered for a sibling convolution
     #  (ADVICE r5): a strong reference kept up to four dead activations alive across steps)
     big = weak or t.numel() * t.element_size() >= _AMAX_WEAK_BYTES
+    # two quotas: entries that HOLD their tensor (small ones) stay few — they pin memory; weak entries pin nothing and may be many: the
+    # label map that a SPADEResnetBlock's three SPADEs read is found by the third one although a dozen producer entries (K21's weights,
+    # K9's outputs) came in between (with one quota of 8 it had been evicted: 24 max|.| passes per module step)
+    n_strong = sum(1 for e in table.values() if not isinstance(e[0], weakref.ref))
+    if big:
+        for k in [k for k, e in table.items() if isinstance(e[0], weakref.ref) and e[0]() is None]:
+            del table[k]                                     # (dead tensors first)
+        while len(table) - n_strong >= _KNOWN_AMAX_WEAK_MAX:
+            table.pop(next(k for k, e in table.items() if isinstance(e[0], weakref.ref)), None)
+    else:
+        while n_strong >= _KNOWN_AMAX_MAX:
+            table.pop(next(k for k, e in table.items() if not isinstance(e[0], weakref.ref)), None)
+            n_strong -= 1
     table[(t.device, t.untyped_storage().data_ptr())] = (weakref.ref(t) if big else t, t._version, cell)
 
 

@@ -54,6 +54,25 @@ def test_amax_table_is_keyed_by_storage_version_and_consumed_once(monkeypatch):
         ops._remember_amax(x, cell)
     assert ops._recall_amax(xs[0]) is None and all(ops._recall_amax(x) is cell for x in xs[1:])
     assert len(ops._tls.known_amax) == 0
+    # entries that only WATCH their tensor have their own, larger quota: a dozen holding entries in between do not evict them, a dead
+    # tensor's entry is void, and the quota itself is bounded
+    keep = torch.randn(4)
+    ops._remember_amax(keep, cell, weak=True)
+    for x in xs:
+        ops._remember_amax(x, cell)
+    assert ops._recall_amax(keep, consume=False) is cell
+    gone = torch.randn(4)
+    ops._remember_amax(gone, cell, weak=True)
+    key_gone = (gone.device, gone.untyped_storage().data_ptr())
+    del gone
+    many = [torch.randn(4) for _ in range(ops._KNOWN_AMAX_WEAK_MAX + 5)]
+    for x in many:
+        ops._remember_amax(x, cell, weak=True)
+    table = ops._tls.known_amax
+    weak_entries = [e for e in table.values() if not torch.is_tensor(e[0])]
+    assert len(weak_entries) <= ops._KNOWN_AMAX_WEAK_MAX and all(e[0]() is not None for e in weak_entries)
+    assert ops._recall_amax(many[-1]) is cell and ops._recall_amax(many[0]) is None      # the oldest watchers went first
+    assert sum(1 for e in table.values() if torch.is_tensor(e[0])) <= ops._KNOWN_AMAX_MAX
 
 
 def test_host_scratch_is_per_thread():
