@@ -351,47 +351,44 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
         }
 
         // epilogue: accumulator (i, j, r) is row m0 + wm*BM/2 + 32 i + (r&3) + 8 (r>>2) + 4 (lane>>5), position n0 + wn*BN/2 + 32 j + (lane&31)
-        if (SK && s0 > 0) {
-            // the tail of a cut tile (always this workgroup's first segment): park it, raise the flag
-            float* slot = ws + (size_t)blockIdx.x * (BM * BN) + tid;
+        if (SK) {
+            // the accumulators' home is the accumulator file, across the three-way epilogue too (hipcc otherwise spills all 256 of them
+            // to scratch after the k-loop and reloads them in every branch: 0.5 MB per workgroup and segment)
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    float* p = slot + (i * NJ + j) * (16 * NT);
-                    asm volatile("" : "+v"(p));          // addresses made here, not 256 loop-invariant pointers spilled to scratch
+                for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
+        }
+        if (SK && s0 > 0) {
+            // the tail of a cut tile (always this workgroup's first segment): park it, raise the flag
+            // (buffer stores: ONE per-lane offset and a scalar offset per register — with flat stores the compiler made 256 addresses and
+            //  spilled the accumulators around them: 1312 bytes of scratch per lane, ~0.4 GB of scratch traffic per launch by PMC)
+            const __amdgpu_buffer_rsrc_t rs_slot = make_rsrc(ws + (size_t)blockIdx.x * (BM * BN), (size_t)BM * BN * 4);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) p[r * NT] = acc[i][j][r];
-                }
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        buf_store1s(rs_slot, acc[i][j][r], (unsigned)tid * 4u, (unsigned)(((i * NJ + j) * 16 + r) * NT) * 4u);
             __threadfence();
             __syncthreads();
             if (tid == 0) __hip_atomic_store(flags + blockIdx.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            if (SK && s1 < nsteps) {
-                // the head of a cut tile (always the last segment): the next workgroup parked the tail long ago
-                const int partner = (int)blockIdx.x + 1;
+            // the head of a cut tile (always the last segment): the next workgroup parked the tail long ago.  Its partial is ADDED IN THE STORE
+            // LOOP below (a buffer load per register through a descriptor that is empty for an uncut tile: zeros, no memory access) — as a
+            // separate `acc += partial` pass in front of the stores it made hipcc move all 256 accumulators through scratch in every
+            // segment (1312 bytes per lane; PMC: 438 MB read per launch for 56 MB of operands)
+            const bool cut_head = SK && s1 < nsteps;
+            const int partner = (int)blockIdx.x + 1;
+            if (cut_head) {
                 if (tid == 0) {
                     while (__hip_atomic_load(flags + partner, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
                 }
                 __syncthreads();
                 (void)__hip_atomic_load(flags + partner, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);    // every wave acquires
-                const float* slot = ws + (size_t)partner * (BM * BN) + tid;
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        float pv[16];               // 16 loads in flight, then their adds: not 256 (the register file is full of accumulators)
-                        const float* p = slot + (i * NJ + j) * (16 * NT);
-                        asm volatile("" : "+v"(p));
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) pv[r] = __builtin_nontemporal_load(p + r * NT);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] += pv[r];
-                        asm volatile("" ::: "memory");
-                    }
-                __syncthreads();
-                if (tid == 0) __hip_atomic_store(flags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
             }
+            const __amdgpu_buffer_rsrc_t rs_part = make_rsrc(ws + (cut_head ? (size_t)partner * (BM * BN) : (size_t)0), cut_head ? (size_t)BM * BN * 4 : (size_t)0);
             const int corow = m0 + wm * (BM / 2) + 4 * (lane >> 5);
             const float oscale = TERMS == 3 ? 1.0f / (nb_scale_from_amax(sp.x_amax) * (sp.w_scale ? *sp.w_scale : 1.0f)) : 1.0f;
 #pragma unroll
@@ -419,12 +416,22 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_nhwc_bf16_kernel(const void* 
                             yp = sp.ring + (size_t)b * g.Cout * cs + ri;
                         }
                     }
+                    float pv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        pv[r] = SK ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_part, (int)((unsigned)tid * 4u),
+                                                                                                    (int)((unsigned)(((i * NJ + j) * 16 + r) * NT) * 4u), 2))
+                                   : 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int co = corow + i * 32 + (r & 3) + 8 * (r >> 2);
-                        if (co < g.Cout) yp[(size_t)co * cs] = acc[i][j][r] * oscale + bv[r];
+                        if (co < g.Cout) yp[(size_t)co * cs] = (SK ? acc[i][j][r] + pv[r] : acc[i][j][r]) * oscale + bv[r];
                     }
                 }
+            }
+            if (cut_head) {
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(flags + partner, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
             }
         }
         u0 += nseg;
