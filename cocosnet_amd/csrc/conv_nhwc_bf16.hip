@@ -173,6 +173,11 @@ __global__ __launch_bounds__(256) void conv_nhwc_prep_kernel(const float* __rest
 // (k-steps 0..) is the LAST thing workgroup w does, its tail the FIRST thing workgroup w+1 does.  The early finisher
 // parks its partial tile in a workspace slot and raises a flag; the late one adds the parked tile to its own and stores.
 // No atomics on the output (same-address-class fp32 atomics ran at ~140 G/s in the K2 experiments: 0.1 ms for this tensor).
+// Round 6 measured the alternative schedule — whole tiles in k lock-step first (stream-K proper has every workgroup at another k offset:
+// the 6 MB of weight planes are never hot in a 4 MB L2 at the slice a workgroup needs, PMC 1.36 GB read per launch against 97 MB for the
+// plain launch), then the remaining tiles cut into W / rem k-chunks whose LAST arriver adds the other partials: correct (same tests), and
+// SLOWER — 407 -> 407 forward + backward 1.133 -> 1.232 ms, 512 -> 512 1.39 -> 1.465: the last arriver streams 13 parked tiles (3.3 MB)
+// through one CU.  Stream-K proper stays.
 // TERMS = 3 (K16c): every operand is TWO f16 planes (hi, lo), every product three MFMAs (hi hi + hi lo + lo hi) — the arithmetic of
 // conv_f16x3.hip on this kernel's data path; a stage holds four tiles (two stages of 64 KB at 256 x 256), the result is scaled
 // back by 1 / (s_x s_w) in the epilogue.  The stage count follows: TERMS = 1 four stages, TERMS = 3 two.
