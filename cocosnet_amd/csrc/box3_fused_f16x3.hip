@@ -728,6 +728,8 @@ __global__ __launch_bounds__(256, 1) void box3_adjoint_planes_kernel(const float
 
     // (the diagonal-major order of the 128-wide kernel below was measured here too: 0.21 -> 0.25 ms at cfg2' — a 64 x 64
     //  grid's G (67 MB per sample) is served by the memory-side cache either way, and row-major keeps the STORES sequential)
+    // (round 6: consecutive workgroups on one XCD — a sample per XCD at B = 8, so that the three readers of a G block share an L2: PMC says
+    //  784 MB are read for a 537 MB G — was neutral as well: 1.750-1.754 vs 1.752-1.754 ms for the step; the kernel is at the memory side's rate)
     const int grp = blockIdx.x * 4 + wave;                     // (b, ky, py)
     const int per = himg * himg;
     const int b = grp / per, ky = (grp % per) / himg, py = grp % himg;
